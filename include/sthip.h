@@ -1,0 +1,162 @@
+/* sthip.h — C ABI of libstratum_hip.so: the MI355X path-tracing inner loop of Stratum.
+ *
+ * This library replaces exactly two things in the reference:
+ *   - the Slang/HLSL ray-trace pipeline in src/Shaders (entry points
+ *     sample_visibility, bdpt.hlsl:149-300, and trace_shadows, bdpt.hlsl:302-326,
+ *     and everything they call), and
+ *   - the Vulkan dispatch sequence that BDPT::render records for them
+ *     (src/Node/BDPT.cpp:423-838; dispatch_over, src/Core/CommandBuffer.hpp:183-197),
+ *     together with the driver-side acceleration structure it relies on
+ *     (src/Core/AccelerationStructure.cpp:5-27, src/Node/Scene.cpp:435-459,614-629).
+ * Everything above it (Node graph, Scene::update, loaders, GUI) stays as it is and
+ * hands over the same arrays it binds to the shaders today; field names below are the
+ * reflected binding names the reference uses ("gSceneParams.gVertices", ...,
+ * BDPT.cpp:401-417,611-629; parameter blocks bdpt.hlsl:19-62).
+ *
+ * Conventions: plain pointers and sizes, no exceptions across the ABI; every call
+ * returns 0 on success or a negative sthip_status, and sthip_last_error() returns a
+ * description. A context is single-threaded; one context per GPU. There is no CPU
+ * backend: without a HIP device sthip_create fails.
+ */
+#ifndef STHIP_H
+#define STHIP_H
+
+#include <stdint.h>
+#include "sthip_wire.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STHIP_ABI_VERSION 1
+
+typedef struct sthip_ctx sthip_ctx;
+
+enum sthip_status {
+  STHIP_OK = 0,
+  STHIP_ERR_INVALID_ARGUMENT = -1,
+  STHIP_ERR_NO_DEVICE = -2,
+  STHIP_ERR_HIP = -3,
+  STHIP_ERR_UNSUPPORTED = -4, /* a flag / scene feature outside the built hot path */
+  STHIP_ERR_NO_SCENE = -5
+};
+
+/* gSceneParams (bdpt.hlsl:19-35) as produced by Scene::update (Scene.cpp:299-684,
+ * Scene.hpp:46-69). All pointers are host pointers, borrowed for the call and copied to HBM. */
+typedef struct sthip_scene_desc {
+  const sthip_PackedVertexData* gVertices; /* Scene.cpp:643-658 */
+  uint32_t vertex_count;
+  const void* gIndices; /* byte buffer, per-instance stride 2 or 4 (scene.h:139-161) */
+  uint32_t indices_bytes;
+  const sthip_InstanceData* gInstances; /* Scene.cpp:398-427 */
+  uint32_t instance_count;
+  const sthip_TransformData* gInstanceTransforms;
+  const sthip_TransformData* gInstanceInverseTransforms;
+  const sthip_TransformData* gInstanceMotionTransforms; /* may be NULL: identity */
+  const void* gMaterialData; /* Material::store records, Material.hpp:32-38 */
+  uint32_t material_bytes;
+  const uint32_t* gLightInstances; /* Scene.cpp:406-409 */
+  uint32_t light_count;
+} sthip_scene_desc;
+
+/* gFrameParams view arrays (bdpt.hlsl:37-43), filled by BDPT::render (BDPT.cpp:444-467).
+ * gPrevViews / gPrevInverseViewTransforms may be NULL: static camera (previous = current). */
+typedef struct sthip_frame_desc {
+  const sthip_ViewData* gViews;
+  const sthip_TransformData* gViewTransforms;
+  const sthip_TransformData* gInverseViewTransforms;
+  const sthip_ViewData* gPrevViews;
+  const sthip_TransformData* gPrevInverseViewTransforms;
+  uint32_t view_count;
+} sthip_frame_desc;
+
+/* Output images/buffers of the two passes (bdpt.hlsl:44-49, BDPT.cpp:553-558).
+ * gRadiance is required, the others may be NULL. With device_ptrs = 1 every non-NULL
+ * pointer is a device pointer on the context's GPU (no copy; results are complete when
+ * the call's stream work is complete, see sthip_set_stream). */
+typedef struct sthip_outputs {
+  uint32_t device_ptrs;
+  float* gRadiance;                  /* RGBA32F, W*H*4: rgb = mean over the seeds of this call, a = sample count */
+  float* gAlbedo;                    /* RGBA32F */
+  sthip_VisibilityInfo* gVisibility; /* W*H */
+  sthip_DepthInfo* gDepth;           /* W*H */
+  float* gPrevUVs;                   /* RG32F, W*H*2 */
+  uint64_t* gRayCount;               /* [2]: all trace_ray calls / path (non-shadow) rays; intersection.hlsli:66, path.hlsli:1006 */
+} sthip_outputs;
+
+/* ---- lifetime ---- */
+int sthip_abi_version(void);
+int sthip_create(int device, sthip_ctx** out_ctx); /* replaces Device/pipeline creation, BDPT.cpp:35-41,151-187 */
+void sthip_destroy(sthip_ctx* ctx);
+const char* sthip_last_error(const sthip_ctx* ctx); /* ctx may be NULL: error of a failed sthip_create */
+
+/* Stream the kernels are enqueued on (a hipStream_t; NULL = default stream). With host
+ * output pointers sthip_render synchronises before returning; with device pointers it only
+ * enqueues. */
+int sthip_set_stream(sthip_ctx* ctx, void* hip_stream);
+
+/* ---- scene: replaces BLAS/TLAS build + descriptor writes (Scene.cpp:429-509,614-629; BDPT.cpp:341-421) ---- */
+int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* scene);
+
+/* ---- frame: replaces the dispatch sequence of BDPT::render (BDPT.cpp:607-720) ----
+ * Renders seeds seed_begin .. seed_begin+seed_count-1 (gRandomSeed = seed, BDPT.cpp:480), one
+ * sample per pixel centre per seed (bdpt.hlsl:167), and averages them with the running mean of
+ * temporal_accumulation.hlsl:118-131. push_constants->gRandomSeed is ignored. */
+int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* push_constants, uint32_t sampling_flags,
+                 uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin, uint32_t seed_count,
+                 const sthip_outputs* outputs);
+
+/* Pixel-tile sharding for multi-GPU (one context per GPU): the frame is cut into
+ * tile_w x tile_h tiles (multiples of the reference's 8x4 workgroup, bdpt.hlsl:11-12),
+ * tile t is rendered iff t % shard_count == shard_rank; other pixels are written as zero
+ * (including alpha) so that a sum-reduce over ranks assembles the frame.
+ * shard_count = 1 (default) renders everything. */
+int sthip_set_shard(sthip_ctx* ctx, uint32_t shard_rank, uint32_t shard_count, uint32_t tile_w, uint32_t tile_h);
+
+/* ---- the traversal contract on its own (T1/T2 of SURVEY.md §8a; intersection.hlsli:65-239) ---- */
+typedef struct sthip_ray {
+  float origin[3];
+  float tmin;
+  float direction[3];
+  float tmax;
+} sthip_ray;
+
+typedef struct sthip_hit {
+  float t; /* tmax of the ray on a miss */
+  float b1, b2; /* barycentrics: P = v0 + b1 (v1-v0) + b2 (v2-v0), shading_data.hlsli:69-72 */
+  uint32_t instance_primitive_index; /* 0xFFFFFFFF on a miss */
+} sthip_hit;
+
+/* any_hit = 0: closest hit (trace_ray); 1: occlusion (RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH):
+ * hits[i].instance_primitive_index is 0 when occluded, 0xFFFFFFFF when not; t,b1,b2 unspecified.
+ * rays/hits are host pointers unless device_ptrs != 0. */
+int sthip_trace_rays(sthip_ctx* ctx, const sthip_ray* rays, uint32_t ray_count, sthip_hit* hits, uint32_t any_hit,
+                     uint32_t device_ptrs);
+
+/* ---- measurement ---- */
+typedef struct sthip_stats {
+  uint64_t rays_total;     /* gRayCount[0] semantics, last render */
+  uint64_t rays_path;      /* gRayCount[1] semantics */
+  uint64_t rays_shadow;
+  uint64_t nodes_visited;  /* only when collected (sthip_set_option "count_traversal") */
+  uint64_t tris_tested;
+  float ms_trace_closest;  /* hipEvent time spent in the closest-hit traversal kernels of the last render */
+  float ms_trace_shadow;
+  float ms_shade;
+  float ms_total;          /* all kernels of the last render */
+  uint32_t launches_trace_closest;
+  uint32_t launches_trace_shadow;
+  uint32_t bvh_node_bytes; /* bytes of one BVH node as laid out in HBM */
+  uint32_t bvh_tri_bytes;  /* bytes of one leaf triangle */
+  uint64_t bvh_nodes;
+  uint64_t bvh_tris;
+} sthip_stats;
+int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out);
+
+/* named integer options: "count_traversal" (0/1), "time_kernels" (0/1) */
+int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STHIP_H */

@@ -1,0 +1,188 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg. The product package (stratum_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from stratum_amd import wire
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "stratum_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_create.argtypes = [C.POINTER(wire.SceneDesc)]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_render.restype = C.c_int
+        L.orc_render.argtypes = [
+            C.c_void_p,
+            C.POINTER(wire.BDPTPushConstants),
+            C.c_uint32,
+            C.c_uint32,
+            C.POINTER(wire.FrameDesc),
+            C.c_uint32,
+            C.c_uint32,
+            C.POINTER(wire.Outputs),
+            C.c_int,
+            C.c_void_p,
+        ]
+        L.orc_trace_rays.restype = C.c_int
+        L.orc_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_pcg.restype = C.c_uint32
+        L.orc_pcg.argtypes = [C.c_uint32]
+        L.orc_xxhash32.restype = C.c_uint32
+        L.orc_xxhash32.argtypes = [C.c_uint32]
+        _lib = L
+    return _lib
+
+
+class OracleScene:
+    def __init__(self, scene):
+        self.scene = scene  # keep the arrays alive
+        d = scene.desc()
+        self.h = lib().orc_scene_create(C.byref(d))
+        if not self.h:
+            raise RuntimeError("orc_scene_create failed")
+
+    def close(self):
+        if self.h:
+            lib().orc_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def render(self, frame, push_constants, sampling_flags=wire.DEFAULT_SAMPLING_FLAGS, seed_begin=0, seed_count=1, threads=0, aovs=True):
+        W, H = frame.width, frame.height
+        out = {
+            "radiance": np.zeros((H, W, 4), np.float32),
+            "ray_count": np.zeros(2, np.uint64),
+            "stats": np.zeros(4, np.uint64),
+        }
+        o = wire.Outputs()
+        o.device_ptrs = 0
+        o.gRadiance = wire.ptr(out["radiance"])
+        o.gRayCount = wire.ptr(out["ray_count"])
+        if aovs:
+            out["albedo"] = np.zeros((H, W, 4), np.float32)
+            out["visibility"] = np.zeros((H, W), wire.VisibilityInfo)
+            out["depth"] = np.zeros((H, W), wire.DepthInfo)
+            out["prev_uv"] = np.zeros((H, W, 2), np.float32)
+            o.gAlbedo = wire.ptr(out["albedo"])
+            o.gVisibility = wire.ptr(out["visibility"])
+            o.gDepth = wire.ptr(out["depth"])
+            o.gPrevUVs = wire.ptr(out["prev_uv"])
+        fd = frame.desc()
+        rc = lib().orc_render(
+            self.h, C.byref(push_constants), sampling_flags, self.scene.scene_flags, C.byref(fd), seed_begin, seed_count, C.byref(o), threads, wire.ptr(out["stats"])
+        )
+        if rc != 0:
+            raise RuntimeError("orc_render failed: %d" % rc)
+        return out
+
+    def trace(self, rays, any_hit=False, brute=False, threads=0):
+        rays = np.ascontiguousarray(rays, dtype=wire.Ray)
+        hits = np.zeros(rays.shape[0], wire.Hit)
+        counters = np.zeros(2, np.uint64)
+        rc = lib().orc_trace_rays(self.h, wire.ptr(rays), rays.shape[0], wire.ptr(hits), (1 if any_hit else 0) | (2 if brute else 0), threads, wire.ptr(counters))
+        if rc != 0:
+            raise RuntimeError("orc_trace_rays failed: %d" % rc)
+        return hits, counters
+
+    def shading_data(self, inst_prim, bary):
+        inst_prim = np.ascontiguousarray(inst_prim, np.uint32)
+        bary = np.ascontiguousarray(bary, np.float32)
+        out = np.zeros(inst_prim.shape[0], wire.ShadingData)
+        lib().orc_shading_data(C.c_void_p(self.h), wire.ptr(inst_prim), wire.ptr(bary), wire.ptr(out), C.c_uint32(inst_prim.shape[0]))
+        return out
+
+
+# ---- unit functions ----
+def pcg4d(v):
+    v = np.ascontiguousarray(v, np.uint32).reshape(-1, 4).copy()
+    lib().orc_pcg4d(wire.ptr(v), C.c_uint32(v.shape[0]))
+    return v
+
+
+def rng_floats(x, y, seed, counter0, n):
+    out = np.zeros(n, np.float32)
+    lib().orc_rng_floats(C.c_uint32(x), C.c_uint32(y), C.c_uint32(seed), C.c_uint32(counter0), wire.ptr(out), C.c_uint32(n))
+    return out
+
+
+def _map(fn, inputs, out_shape, out_dtype):
+    n = inputs[0].shape[0]
+    out = np.zeros((n,) + out_shape, out_dtype)
+    getattr(lib(), fn)(*[wire.ptr(a) for a in inputs], wire.ptr(out), C.c_uint32(n))
+    return out
+
+
+def pack_normal(v):
+    return _map("orc_pack_normal", [np.ascontiguousarray(v, np.float32)], (), np.uint32)
+
+
+def unpack_normal(p):
+    return _map("orc_unpack_normal", [np.ascontiguousarray(p, np.uint32)], (3,), np.float32)
+
+
+def ray_offset(pos, nrm):
+    return _map("orc_ray_offset", [np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(nrm, np.float32)], (3,), np.float32)
+
+
+def f32tof16(v):
+    return _map("orc_f32tof16", [np.ascontiguousarray(v, np.float32)], (), np.uint32)
+
+
+def f16tof32(v):
+    return _map("orc_f16tof32", [np.ascontiguousarray(v, np.uint32)], (), np.float32)
+
+
+def sincos(x):
+    x = np.ascontiguousarray(x, np.float32)
+    s = np.zeros_like(x)
+    c = np.zeros_like(x)
+    lib().orc_sincos(wire.ptr(x), wire.ptr(s), wire.ptr(c), C.c_uint32(x.shape[0]))
+    return s, c
+
+
+def log(x):
+    return _map("orc_log", [np.ascontiguousarray(x, np.float32)], (), np.float32)
+
+
+def pow(a, b):
+    return _map("orc_pow", [np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)], (), np.float32)
+
+
+def disney_eval(material_record, dir_in, dir_out):
+    rec = np.ascontiguousarray(material_record, wire.MaterialRecord).reshape(1)
+    di, do = np.ascontiguousarray(dir_in, np.float32), np.ascontiguousarray(dir_out, np.float32)
+    out = np.zeros((di.shape[0], 5), np.float32)
+    lib().orc_disney_eval(wire.ptr(rec), wire.ptr(di), wire.ptr(do), wire.ptr(out), C.c_uint32(di.shape[0]))
+    return out
+
+
+def disney_sample(material_record, dir_in, rnd):
+    rec = np.ascontiguousarray(material_record, wire.MaterialRecord).reshape(1)
+    di, r = np.ascontiguousarray(dir_in, np.float32), np.ascontiguousarray(rnd, np.float32)
+    out = np.zeros((di.shape[0], 13), np.float32)
+    lib().orc_disney_sample(wire.ptr(rec), wire.ptr(di), wire.ptr(r), wire.ptr(out), C.c_uint32(di.shape[0]))
+    return out

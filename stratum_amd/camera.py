@@ -1,0 +1,87 @@
+"""Camera / view construction as the reference host does it.
+
+make_perspective: src/Shaders/transform.h:159-168; Camera::view: src/Node/Scene.hpp:19-28;
+the aspect passed by FlyCamera is height/width (src/Node/FlyCamera.cpp:29-32);
+the default camera looks down -Z with near_plane = -1/1024 (src/main.cpp:86).
+"""
+import numpy as np
+
+from . import wire
+
+
+def make_perspective(fovy, aspect, offset=(0.0, 0.0), znear=-1.0 / 1024.0):
+    p = np.zeros((), dtype=wire.ProjectionData)
+    sy = np.float32(1.0) / np.float32(np.tan(np.float32(fovy) / np.float32(2)))
+    p["scale"] = [np.float32(aspect) * sy, sy]
+    p["offset"] = offset
+    p["near_plane"] = znear
+    p["far_plane"] = 0
+    p["vertical_fov"] = fovy
+    return p
+
+
+def _back_project(p, v):
+    near = np.float32(p["near_plane"])
+    if p["vertical_fov"] < 0:
+        return np.array([(v[0] - p["offset"][0]) / p["scale"][0], (v[1] - p["offset"][1]) / p["scale"][1], near], np.float32)
+    s = np.sign(near)
+    return np.array(
+        [near * (v[0] * s - p["offset"][0]) / p["scale"][0], near * (v[1] * s - p["offset"][1]) / p["scale"][1], near], np.float32
+    )
+
+
+def make_view(width, height, fovy):
+    """ViewData for a full-frame camera (Camera::view with mImageRect = the whole image)."""
+    v = np.zeros(1, dtype=wire.ViewData)
+    proj = make_perspective(fovy, height / float(width))
+    ext = _back_project(proj, (1.0, 1.0))[:2] - _back_project(proj, (-1.0, -1.0))[:2]
+    if proj["vertical_fov"] >= 0:
+        ext = ext / np.float32(proj["near_plane"])
+    proj["sensor_area"] = abs(ext[0] * ext[1])
+    v["projection"][0] = proj
+    v["image_min"][0] = [0, 0]
+    v["image_max"][0] = [width, height]
+    return v
+
+
+def look_at(eye, target, up=(0.0, 1.0, 0.0)):
+    """Camera-to-world TransformData (node_to_world of the camera node); camera looks down its -Z."""
+    eye = np.asarray(eye, dtype=np.float64)
+    f = np.asarray(target, dtype=np.float64) - eye
+    f /= np.linalg.norm(f)
+    r = np.cross(f, np.asarray(up, dtype=np.float64))
+    r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    m = np.zeros((3, 4))
+    m[:, 0], m[:, 1], m[:, 2], m[:, 3] = r, u, -f, eye
+    t = np.zeros(1, dtype=wire.TransformData)
+    t["m"][0] = m.astype(np.float32)
+    return t
+
+
+def inverse_transform(t):
+    out = np.zeros_like(t)
+    for i in range(t.shape[0]):
+        m = np.vstack([t["m"][i].astype(np.float64), [0, 0, 0, 1]])
+        out["m"][i] = np.linalg.inv(m)[:3, :].astype(np.float32)
+    return out
+
+
+class Frame:
+    """gFrameParams view arrays for one static camera."""
+
+    def __init__(self, width, height, fovy, eye, target, up=(0.0, 1.0, 0.0)):
+        self.width, self.height = width, height
+        self.views = make_view(width, height, fovy)
+        self.view_transforms = look_at(eye, target, up)
+        self.inverse_view_transforms = inverse_transform(self.view_transforms)
+
+    def desc(self):
+        d = wire.FrameDesc()
+        d.gViews = wire.ptr(self.views)
+        d.gViewTransforms = wire.ptr(self.view_transforms)
+        d.gInverseViewTransforms = wire.ptr(self.inverse_view_transforms)
+        d.gPrevViews = None
+        d.gPrevInverseViewTransforms = None
+        d.view_count = 1
+        return d

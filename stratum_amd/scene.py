@@ -1,0 +1,203 @@
+"""Host-side scene packing: what Scene::update (src/Node/Scene.cpp:299-684) produces.
+
+SceneBuilder collects meshes, materials and mesh instances and emits the arrays the
+shaders bind as gSceneParams.* — PackedVertexData vertices, the byte index buffer,
+InstanceData records, instance / inverse / motion transforms, the material byte buffer
+and the light-instance list — in exactly the reference's layouts (include/sthip_wire.h).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import wire
+
+_IDENTITY = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], dtype=np.float32)
+
+
+def translate(t):
+    m = np.eye(4)
+    m[:3, 3] = t
+    return m
+
+
+def scale(s):
+    s = np.broadcast_to(np.asarray(s, dtype=np.float64), (3,))
+    return np.diag([s[0], s[1], s[2], 1.0])
+
+
+def rotate_y(a):
+    c, s = np.cos(a), np.sin(a)
+    m = np.eye(4)
+    m[0, 0], m[0, 2], m[2, 0], m[2, 2] = c, s, -s, c
+    return m
+
+
+def rotate_x(a):
+    c, s = np.cos(a), np.sin(a)
+    m = np.eye(4)
+    m[1, 1], m[1, 2], m[2, 1], m[2, 2] = c, -s, s, c
+    return m
+
+
+class SceneData:
+    """Packed arrays + the descriptor handed to sthip_scene_upload / the oracle."""
+
+    def __init__(self, vertices, indices, instances, xf, inv_xf, motion_xf, materials, lights, name=""):
+        self.name = name
+        self.vertices = vertices
+        self.indices = indices
+        self.instances = instances
+        self.transforms = xf
+        self.inverse_transforms = inv_xf
+        self.motion_transforms = motion_xf
+        self.materials = materials
+        self.lights = lights
+
+    @property
+    def light_count(self):
+        return int(self.lights.shape[0])
+
+    @property
+    def triangle_count(self):
+        return int(((self.instances["packed"][:, 1] >> 12) & 0xFFFF).sum())
+
+    @property
+    def scene_flags(self):
+        return wire.BDPT_FLAG_HAS_EMISSIVES if self.light_count else 0
+
+    def desc(self):
+        d = wire.SceneDesc()
+        d.gVertices = wire.ptr(self.vertices)
+        d.vertex_count = self.vertices.shape[0]
+        d.gIndices = wire.ptr(self.indices)
+        d.indices_bytes = self.indices.nbytes
+        d.gInstances = wire.ptr(self.instances)
+        d.instance_count = self.instances.shape[0]
+        d.gInstanceTransforms = wire.ptr(self.transforms)
+        d.gInstanceInverseTransforms = wire.ptr(self.inverse_transforms)
+        d.gInstanceMotionTransforms = wire.ptr(self.motion_transforms)
+        d.gMaterialData = wire.ptr(self.materials)
+        d.material_bytes = self.materials.nbytes
+        d.gLightInstances = wire.ptr(self.lights) if self.light_count else None
+        d.light_count = self.light_count
+        return d
+
+
+class SceneBuilder:
+    def __init__(self, name=""):
+        self.name = name
+        self._verts = []  # list of PackedVertexData arrays
+        self._index_chunks = []  # list of bytes
+        self._index_bytes = 0
+        self._vertex_count = 0
+        self._meshes = []  # (first_vertex, indices_byte_offset, prim_count, stride)
+        self._materials = []  # MaterialRecord entries
+        self._instances = []  # (mesh, material_address, 3x4 transform, emission)
+
+    # -- Material::store, Material.hpp:32-38; conventions of load_mitsuba.cpp:330-343,454-489 --
+    def add_material(
+        self,
+        base_color,
+        emission=0.0,
+        metallic=0.0,
+        roughness=0.0,
+        anisotropic=0.0,
+        subsurface=0.0,
+        clearcoat=0.0,
+        clearcoat_gloss=0.0,
+        transmission=0.0,
+        eta=1.5,
+    ):
+        rec = np.zeros((), dtype=wire.MaterialRecord)
+        rec["values"]["value"][0] = [base_color[0], base_color[1], base_color[2], emission]
+        rec["values"]["value"][1] = [metallic, roughness, anisotropic, subsurface]
+        rec["values"]["value"][2] = [clearcoat, clearcoat_gloss, transmission, eta]
+        rec["values"]["image_index"][:] = 0xFFFFFFFF  # MaterialResources::get_index of a null view (image_value.h:40-41)
+        rec["alpha_mask_index"] = 0xFFFFFFFF
+        rec["bump_index"] = 0xFFFFFFFF
+        rec["bump_strength"] = 1.0
+        address = len(self._materials) * wire.MaterialRecord.itemsize
+        self._materials.append(rec)
+        return address
+
+    def add_emitter(self, radiance):
+        """Mitsuba area emitter: base_color = L / lum(L), emission = lum(L), eta = 0 (load_mitsuba.cpp:480-489)."""
+        L = np.asarray(radiance, dtype=np.float32)
+        lum = np.float32(np.dot(L, np.array([0.2126, 0.7152, 0.0722], dtype=np.float32)))
+        return self.add_material(L / lum, emission=float(lum), eta=0.0)
+
+    # -- copy_vertices + concatenation, copy_vertices.hlsl:29-37, Scene.cpp:643-658 --
+    def add_mesh(self, positions, normals, uvs, triangles, index_stride=4):
+        positions = np.asarray(positions, dtype=np.float32).reshape(-1, 3)
+        n = positions.shape[0]
+        normals = np.asarray(normals, dtype=np.float32).reshape(-1, 3) if normals is not None else np.zeros((n, 3), np.float32)
+        uvs = np.asarray(uvs, dtype=np.float32).reshape(-1, 2) if uvs is not None else np.zeros((n, 2), np.float32)
+        triangles = np.asarray(triangles).reshape(-1, 3)
+        assert triangles.shape[0] <= 0xFFFF, "16-bit primitive index (scene.h:23-24,37): chunk the mesh"
+        assert triangles.max() < n
+        v = np.zeros(n, dtype=wire.PackedVertexData)
+        v["position"], v["normal"], v["u"], v["v"] = positions, normals, uvs[:, 0], uvs[:, 1]
+        if index_stride == 2:
+            assert n <= 0x10000
+            ib = triangles.astype("<u2").tobytes()
+        else:
+            ib = triangles.astype("<u4").tobytes()
+        mesh = (self._vertex_count, self._index_bytes, triangles.shape[0], index_stride)
+        self._verts.append(v)
+        self._vertex_count += n
+        pad = (-len(ib)) % 4  # Scene.cpp:507 align_up(size, 4)
+        self._index_chunks.append(ib + b"\0" * pad)
+        self._index_bytes += len(ib) + pad
+        self._meshes.append(mesh)
+        return len(self._meshes) - 1
+
+    def add_instance(self, mesh, material_address, transform=None):
+        m = np.eye(4) if transform is None else np.asarray(transform, dtype=np.float64)
+        if m.shape == (3, 4):
+            m = np.vstack([m, [0, 0, 0, 1]])
+        self._instances.append((mesh, material_address, m))
+        return len(self._instances) - 1
+
+    def build(self):
+        n = len(self._instances)
+        inst = np.zeros(n, dtype=wire.InstanceData)
+        xf = np.zeros(n, dtype=wire.TransformData)
+        inv = np.zeros(n, dtype=wire.TransformData)
+        mot = np.zeros(n, dtype=wire.TransformData)
+        mats = np.array(self._materials, dtype=wire.MaterialRecord) if self._materials else np.zeros(0, wire.MaterialRecord)
+        lights = []
+        for i, (mesh, mat, m) in enumerate(self._instances):
+            fv, ibo, pc, stride = self._meshes[mesh]
+            # make_instance_triangles, scene.h:51-61
+            p0 = 0 | (mat << 4)  # INSTANCE_TYPE_TRIANGLES
+            p1 = 0xFFF | (pc << 12) | (stride << 28)
+            emission = float(mats[mat // wire.MaterialRecord.itemsize]["values"]["value"][0][3])
+            if emission > 0:  # process_instance, Scene.cpp:403-409
+                p1 = (p1 & ~0xFFF) | (len(lights) & 0xFFF)
+                lights.append(i)
+            inst["packed"][i] = [p0 & 0xFFFFFFFF, p1 & 0xFFFFFFFF, fv, ibo]
+            m32 = m[:3, :].astype(np.float32)
+            xf["m"][i] = m32
+            if np.array_equal(m32, _IDENTITY):
+                inv["m"][i] = _IDENTITY
+                mot["m"][i] = _IDENTITY
+            else:
+                # TransformData::inverse, transform.h:26-31 (general 4x4 inverse on the host)
+                mi = np.linalg.inv(np.vstack([m32.astype(np.float64), [0, 0, 0, 1]]))
+                inv["m"][i] = mi[:3, :].astype(np.float32)
+                # make_instance_motion_transform(inv, prevObjectToWorld), scene.h:49; static scene: prev = current
+                mm = np.vstack([m32.astype(np.float64), [0, 0, 0, 1]]) @ np.vstack([inv["m"][i].astype(np.float64), [0, 0, 0, 1]])
+                mot["m"][i] = mm[:3, :].astype(np.float32)
+        vertices = np.concatenate(self._verts) if self._verts else np.zeros(0, wire.PackedVertexData)
+        indices = np.frombuffer(b"".join(self._index_chunks), dtype=np.uint8).copy()
+        return SceneData(
+            np.ascontiguousarray(vertices),
+            indices,
+            inst,
+            xf,
+            inv,
+            mot,
+            np.ascontiguousarray(mats),
+            np.array(lights, dtype=np.uint32),
+            name=self.name,
+        )

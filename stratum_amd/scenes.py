@@ -1,0 +1,385 @@
+"""Deterministic procedural scenes of BASELINE.json's configs (no assets, no textures).
+
+cornell_box  — 32 triangles, diffuse walls + one emissive quad (configs[0], configs[1])
+atrium       — ~1M-triangle "Sponza-class" hall of displaced grids, chunked into meshes of
+               <= 65535 triangles because instance/primitive ids are 16-bit (scene.h:23-24,37)
+forest       — ~10M triangles as ~1000 instances of a few ~10K-triangle tree meshes (configs[4])
+
+Every generator returns (SceneData, camera dict) where camera = {eye, target, fovy}.
+"""
+import numpy as np
+
+from .scene import SceneBuilder, rotate_y, scale, translate
+
+MAX_TRIS = 0xFFFF
+
+
+# ---------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------
+def _quad(p0, p1, p2, p3, n):
+    pos = np.array([p0, p1, p2, p3], dtype=np.float32)
+    nrm = np.tile(np.asarray(n, dtype=np.float32), (4, 1))
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32)
+    tri = np.array([[0, 1, 2], [0, 2, 3]])
+    return pos, nrm, uv, tri
+
+
+def _merge(parts):
+    pos, nrm, uv, tri, base = [], [], [], [], 0
+    for p, n, u, t in parts:
+        pos.append(p)
+        nrm.append(n)
+        uv.append(u)
+        tri.append(np.asarray(t) + base)
+        base += p.shape[0]
+    return np.concatenate(pos), np.concatenate(nrm), np.concatenate(uv), np.concatenate(tri)
+
+
+def grid_surface(fn, nu, nv, flip=False):
+    """Tessellate P(u,v), u,v in [0,1], into nu x nv quads. Normals from central differences."""
+    u = np.linspace(0.0, 1.0, nu + 1)
+    v = np.linspace(0.0, 1.0, nv + 1)
+    U, V = np.meshgrid(u, v, indexing="ij")
+    P = fn(U, V)
+    e = 1e-4
+    dU = fn(U + e, V) - fn(U - e, V)
+    dV = fn(U, V + e) - fn(U, V - e)
+    N = np.cross(dU, dV)
+    N /= np.maximum(np.linalg.norm(N, axis=-1, keepdims=True), 1e-20)
+    if flip:
+        N = -N
+    idx = np.arange((nu + 1) * (nv + 1)).reshape(nu + 1, nv + 1)
+    a, b, c, d = idx[:-1, :-1], idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]
+    tri = np.stack([np.stack([a, b, c], -1), np.stack([a, c, d], -1)], axis=2).reshape(-1, 3)
+    if flip:
+        tri = tri[:, ::-1]
+    uv = np.stack([U, V], -1)
+    return (P.reshape(-1, 3).astype(np.float32), N.reshape(-1, 3).astype(np.float32), uv.reshape(-1, 2).astype(np.float32), tri)
+
+
+def add_chunked(b, part, material, transform=None, index_stride=4, max_tris=MAX_TRIS):
+    """Split a mesh into chunks of <= max_tris triangles, each its own mesh + instance."""
+    pos, nrm, uv, tri = part
+    ids = []
+    for s in range(0, tri.shape[0], max_tris):
+        t = tri[s : s + max_tris]
+        used, inv = np.unique(t, return_inverse=True)
+        m = b.add_mesh(pos[used], nrm[used], uv[used], inv.reshape(-1, 3), index_stride=index_stride)
+        ids.append(b.add_instance(m, material, transform))
+    return ids
+
+
+# ---------------------------------------------------------------------------------------------
+# config 1/2 — Cornell box (SURVEY.md §8d "Config 1")
+# ---------------------------------------------------------------------------------------------
+def cornell_box():
+    b = SceneBuilder("cornell_box")
+    white = b.add_material((0.73, 0.73, 0.73))
+    red = b.add_material((0.65, 0.05, 0.05))
+    green = b.add_material((0.12, 0.45, 0.15))
+    light = b.add_emitter((17.0, 12.0, 4.0))
+
+    def wall(p0, p1, p2, p3, n, mat, stride=4):
+        pos, nrm, uv, tri = _quad(p0, p1, p2, p3, n)
+        b.add_instance(b.add_mesh(pos, nrm, uv, tri, index_stride=stride), mat)
+
+    # box spans [-1,1]^3, open towards +Z (the camera side)
+    wall((-1, -1, 1), (1, -1, 1), (1, -1, -1), (-1, -1, -1), (0, 1, 0), white)  # floor
+    wall((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1), (0, -1, 0), white, stride=2)  # ceiling (16-bit indices)
+    wall((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (0, 0, 1), white)  # back
+    wall((-1, -1, 1), (-1, -1, -1), (-1, 1, -1), (-1, 1, 1), (1, 0, 0), red)  # left
+    wall((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1), (-1, 0, 0), green, stride=2)  # right
+
+    # unit block (5 faces, no bottom): [-0.5,0.5]^2 x [0,1] in y; placed by instance transforms
+    faces = [
+        _quad((-0.5, 1, 0.5), (0.5, 1, 0.5), (0.5, 1, -0.5), (-0.5, 1, -0.5), (0, 1, 0)),
+        _quad((-0.5, 0, 0.5), (0.5, 0, 0.5), (0.5, 1, 0.5), (-0.5, 1, 0.5), (0, 0, 1)),
+        _quad((0.5, 0, -0.5), (-0.5, 0, -0.5), (-0.5, 1, -0.5), (0.5, 1, -0.5), (0, 0, -1)),
+        _quad((0.5, 0, 0.5), (0.5, 0, -0.5), (0.5, 1, -0.5), (0.5, 1, 0.5), (1, 0, 0)),
+        _quad((-0.5, 0, -0.5), (-0.5, 0, 0.5), (-0.5, 1, 0.5), (-0.5, 1, -0.5), (-1, 0, 0)),
+    ]
+    block = b.add_mesh(*_merge(faces))
+    b.add_instance(block, white, translate((0.33, -1.0, 0.3)) @ rotate_y(-0.29) @ scale((0.6, 0.6, 0.6)))  # short block
+    b.add_instance(block, white, translate((-0.35, -1.0, -0.35)) @ rotate_y(0.31) @ scale((0.6, 1.2, 0.6)))  # tall block
+
+    # ceiling light, slightly below the ceiling, facing down
+    wall((-0.24, 0.995, -0.2), (0.24, 0.995, -0.2), (0.24, 0.995, 0.18), (-0.24, 0.995, 0.18), (0, -1, 0), light)
+    sc = b.build()
+    assert sc.triangle_count == 32
+    return sc, {"eye": (0.0, 0.0, 3.9), "target": (0.0, 0.0, 0.0), "fovy": np.radians(39.3)}
+
+
+def furnace_box(albedo=0.5, emission=1.0):
+    """Closed cube whose six walls all emit `emission` and have diffuse albedo 0 (emitters do not
+    scatter, disney_material.hlsli:83) — used for the furnace-style analytic check."""
+    b = SceneBuilder("furnace")
+    m = b.add_material((1.0, 1.0, 1.0), emission=emission, eta=0.0)
+    parts = [
+        _quad((-1, -1, 1), (1, -1, 1), (1, -1, -1), (-1, -1, -1), (0, 1, 0)),
+        _quad((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1), (0, -1, 0)),
+        _quad((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (0, 0, 1)),
+        _quad((1, -1, 1), (-1, -1, 1), (-1, 1, 1), (1, 1, 1), (0, 0, -1)),
+        _quad((-1, -1, 1), (-1, -1, -1), (-1, 1, -1), (-1, 1, 1), (1, 0, 0)),
+        _quad((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1), (-1, 0, 0)),
+    ]
+    b.add_instance(b.add_mesh(*_merge(parts)), m)
+    return b.build(), {"eye": (0.0, 0.0, 0.0), "target": (0.0, 0.0, -1.0), "fovy": np.radians(60.0)}
+
+
+# ---------------------------------------------------------------------------------------------
+# config 3/4 — procedural ~1M-triangle atrium (SURVEY.md §8d "Config 3")
+# ---------------------------------------------------------------------------------------------
+def _hash01(ix, iy, seed):
+    """pcg-style integer hash -> [0,1); deterministic across platforms."""
+    h = (ix.astype(np.uint64) * np.uint64(73856093)) ^ (iy.astype(np.uint64) * np.uint64(19349663)) ^ np.uint64(seed * 83492791 + 12345)
+    h = (h * np.uint64(747796405) + np.uint64(2891336453)) & np.uint64(0xFFFFFFFF)
+    h = (((h >> ((h >> np.uint64(28)) + np.uint64(4))) ^ h) * np.uint64(277803737)) & np.uint64(0xFFFFFFFF)
+    h = ((h >> np.uint64(22)) ^ h) & np.uint64(0xFFFFFFFF)
+    return h.astype(np.float64) / 4294967296.0
+
+
+def _value_noise(x, y, seed):
+    x0, y0 = np.floor(x), np.floor(y)
+    fx, fy = x - x0, y - y0
+    sx, sy = fx * fx * (3 - 2 * fx), fy * fy * (3 - 2 * fy)
+    ix, iy = x0.astype(np.int64) + 10000, y0.astype(np.int64) + 10000
+    a = _hash01(ix, iy, seed)
+    b = _hash01(ix + 1, iy, seed)
+    c = _hash01(ix, iy + 1, seed)
+    d = _hash01(ix + 1, iy + 1, seed)
+    return (a * (1 - sx) + b * sx) * (1 - sy) + (c * (1 - sx) + d * sx) * sy
+
+
+def atrium(target_tris=1_000_000):
+    """Hall 30 x 12 x 10 (x,z,y): bumpy flagstone floor, brick walls, two rows of fluted columns
+    carrying arches and an upper gallery, hanging drapes, a coffered ceiling with emissive
+    skylight panels. `target_tris` scales the tessellation (1.0 -> ~1.0M triangles)."""
+    k = np.sqrt(target_tris / 1_000_000.0)
+
+    def n(x):
+        return max(2, int(round(x * k)))
+
+    b = SceneBuilder("atrium")
+    stone = b.add_material((0.62, 0.58, 0.52))
+    brick = b.add_material((0.55, 0.33, 0.25))
+    marble = b.add_material((0.78, 0.76, 0.72))
+    plaster = b.add_material((0.70, 0.68, 0.62))
+    cloth = [b.add_material(c) for c in ((0.65, 0.08, 0.08), (0.10, 0.20, 0.55), (0.12, 0.45, 0.15), (0.70, 0.55, 0.10))]
+    wood = b.add_material((0.35, 0.22, 0.12))
+    sky = b.add_emitter((22.0, 20.0, 17.0))
+    lamp = b.add_emitter((30.0, 20.0, 9.0))
+
+    LX, LZ, H = 15.0, 6.0, 10.0
+
+    # floor: flagstones with mortar grooves + low-frequency undulation
+    def floor(U, V):
+        x, z = (U * 2 - 1) * LX, (V * 2 - 1) * LZ
+        gx, gz = np.abs(((x * 1.0) % 1.0) - 0.5), np.abs(((z * 1.0) % 1.0) - 0.5)
+        groove = np.clip((np.maximum(gx, gz) - 0.44) / 0.06, 0, 1)
+        y = 0.02 * _value_noise(x * 0.7, z * 0.7, 1) - 0.025 * groove
+        return np.stack([x, y, z], -1)
+
+    add_chunked(b, grid_surface(floor, n(420), n(170)), stone)
+
+    # long walls (z = +-LZ) and end walls (x = +-LX): brick relief
+    def brick_relief(a, h, seed):
+        row = np.floor(h * 4.0)
+        col = a * 2.0 + 0.5 * (row % 2)
+        ga, gh = np.abs((col % 1.0) - 0.5), np.abs(((h * 4.0) % 1.0) - 0.5)
+        groove = np.clip((np.maximum(ga * 0.5 + 0.25, gh) - 0.43) / 0.07, 0, 1)
+        return 0.03 * _value_noise(a * 3.0, h * 3.0, seed) - 0.03 * groove
+
+    def wall_z(sign, seed):
+        def f(U, V):
+            x, y = (U * 2 - 1) * LX, V * H
+            return np.stack([x, y, sign * (LZ + brick_relief(x, y, seed))], -1)
+
+        return f
+
+    def wall_x(sign, seed):
+        def f(U, V):
+            z, y = (U * 2 - 1) * LZ, V * H
+            return np.stack([sign * (LX + brick_relief(z, y, seed)), y, z], -1)
+
+        return f
+
+    add_chunked(b, grid_surface(wall_z(-1, 2), n(300), n(100)), brick)
+    add_chunked(b, grid_surface(wall_z(+1, 3), n(300), n(100), flip=True), brick)
+    add_chunked(b, grid_surface(wall_x(-1, 4), n(120), n(100), flip=True), brick)
+    add_chunked(b, grid_surface(wall_x(+1, 5), n(120), n(100)), brick)
+
+    # ceiling with coffers
+    def ceiling(U, V):
+        x, z = (U * 2 - 1) * LX, (V * 2 - 1) * LZ
+        cx, cz = np.abs(((x / 3.0) % 1.0) - 0.5), np.abs(((z / 3.0) % 1.0) - 0.5)
+        coffer = np.clip((0.38 - np.maximum(cx, cz)) / 0.08, 0, 1)
+        return np.stack([x, H + 0.25 * coffer, z], -1)
+
+    add_chunked(b, grid_surface(ceiling, n(300), n(120), flip=True), plaster)
+
+    # columns: two rows of fluted, slightly tapered shafts with a torus base and capital
+    col_x = np.linspace(-LX + 2.5, LX - 2.5, 10)
+    col_h = 6.0
+
+    def shaft(U, V):
+        a = U * 2 * np.pi
+        y = V * col_h
+        r = (0.42 - 0.06 * V) * (1.0 - 0.05 * np.abs(np.sin(a * 10))) + 0.10 * np.exp(-((V - 0.02) / 0.03) ** 2) + 0.14 * np.exp(-((V - 0.98) / 0.035) ** 2)
+        return np.stack([r * np.cos(a), y, r * np.sin(a)], -1)
+
+    shaft_mesh = grid_surface(shaft, n(96), n(72), flip=True)
+    pos, nrm, uv, tri = shaft_mesh
+    shaft_id = b.add_mesh(pos, nrm, uv, tri)  # one mesh, 20 transformed instances
+    for z in (-3.2, 3.2):
+        for i, x in enumerate(col_x):
+            b.add_instance(shaft_id, marble, translate((x, 0.0, z)) @ rotate_y(0.37 * i))
+
+    # arches between neighbouring columns (half tori), per row
+    def arch(x0, x1, z):
+        cx, R = 0.5 * (x0 + x1), 0.5 * (x1 - x0)
+
+        def f(U, V):
+            a = U * np.pi
+            t = V * 2 * np.pi
+            r = 0.22 * (1 + 0.08 * np.cos(t * 6))
+            rr = R + r * np.cos(t)
+            return np.stack([cx - rr * np.cos(a), col_h + rr * np.sin(a) * 0.75, z + r * np.sin(t)], -1)
+
+        return f
+
+    arch_parts = []
+    for z in (-3.2, 3.2):
+        for i in range(len(col_x) - 1):
+            arch_parts.append(grid_surface(arch(col_x[i], col_x[i + 1], z), n(56), n(20), flip=True))
+    add_chunked(b, _merge(arch_parts), marble)
+
+    # upper gallery slabs along both long walls + balustrade rails
+    def slab(z0, z1, y):
+        def f(U, V):
+            x, z = (U * 2 - 1) * (LX - 0.5), z0 + (z1 - z0) * V
+            return np.stack([x, y + 0.01 * _value_noise(x * 2, z * 2, 7), z], -1)
+
+        return f
+
+    gallery = [grid_surface(slab(-LZ, -3.0, 7.6), n(200), n(24), flip=False), grid_surface(slab(3.0, LZ, 7.6), n(200), n(24), flip=False)]
+    gallery += [grid_surface(slab(-LZ, -3.0, 7.3), n(100), n(12), flip=True), grid_surface(slab(3.0, LZ, 7.3), n(100), n(12), flip=True)]
+    add_chunked(b, _merge(gallery), wood)
+
+    def rail(z, y):
+        def f(U, V):
+            x = (U * 2 - 1) * (LX - 0.5)
+            t = V * 2 * np.pi
+            return np.stack([x, y + 0.06 * np.sin(t), z + 0.06 * np.cos(t)], -1)
+
+        return f
+
+    rails = [grid_surface(rail(z, y), n(240), n(10)) for z in (-3.0, 3.0) for y in (8.0, 8.5)]
+    add_chunked(b, _merge(rails), wood)
+
+    # drapes: hanging cloth with folds, between columns on the gallery level and across the nave
+    def drape(x0, z0, width, height, axis, seed):
+        def f(U, V):
+            s = (U - 0.5) * width
+            y = 7.2 - V * height
+            fold = 0.18 * np.sin(U * 2 * np.pi * 5 + seed) * (0.3 + 0.7 * V) + 0.05 * _value_noise(U * 8, V * 8, seed)
+            sag = 0.25 * np.sin(np.pi * U) * V
+            if axis == 0:
+                return np.stack([x0 + s, y - sag, z0 + fold], -1)
+            return np.stack([x0 + fold, y - sag, z0 + s], -1)
+
+        return f
+
+    d = 0
+    for i in range(0, len(col_x) - 1, 2):
+        for z in (-4.6, 4.6):
+            add_chunked(b, grid_surface(drape(0.5 * (col_x[i] + col_x[i + 1]), z, 2.6, 3.5, 0, 10 + d), n(150), n(150)), cloth[d % 4])
+            d += 1
+    for x in (-9.0, 0.0, 9.0):
+        add_chunked(b, grid_surface(drape(x, 0.0, 5.0, 2.5, 2, 10 + d), n(170), n(120)), cloth[d % 4])
+        d += 1
+
+    # lights: two skylight panels in the ceiling and two warm lamps on the end walls
+    def panel(cx, cz, sx, sz, y):
+        return _quad((cx - sx, y, cz - sz), (cx + sx, y, cz - sz), (cx + sx, y, cz + sz), (cx - sx, y, cz + sz), (0, -1, 0))
+
+    for cx in (-7.5, 7.5):
+        pos, nrm, uv, tri = panel(cx, 0.0, 2.5, 1.2, H - 0.02)
+        b.add_instance(b.add_mesh(pos, nrm, uv, tri), sky)
+    for sx in (-1, 1):
+        pos, nrm, uv, tri = _quad((sx * (LX - 0.15), 3.0, -0.8), (sx * (LX - 0.15), 3.0, 0.8), (sx * (LX - 0.15), 4.2, 0.8), (sx * (LX - 0.15), 4.2, -0.8), (-sx, 0, 0))
+        b.add_instance(b.add_mesh(pos, nrm, uv, tri), lamp)
+
+    sc = b.build()
+    return sc, {"eye": (-12.5, 2.2, 1.4), "target": (6.0, 4.0, -0.6), "fovy": np.radians(60.0)}
+
+
+# ---------------------------------------------------------------------------------------------
+# config 5 — instanced forest (SURVEY.md §8d "Config 5")
+# ---------------------------------------------------------------------------------------------
+def _tree(seed, tris_target=10_000):
+    rng = np.random.RandomState(seed)
+    parts = []
+    k = np.sqrt(tris_target / 10_000.0)
+
+    def n(x):
+        return max(3, int(round(x * k)))
+
+    h = 3.0 + rng.rand() * 1.5
+
+    def trunk(U, V):
+        a = U * 2 * np.pi
+        r = (0.22 - 0.12 * V) * (1 + 0.08 * np.sin(a * 7 + V * 9))
+        return np.stack([r * np.cos(a) + 0.1 * np.sin(V * 3 + seed), V * h, r * np.sin(a)], -1)
+
+    parts.append(grid_surface(trunk, n(20), n(24), flip=True))
+    nb = 9
+    for i in range(nb):
+        cy = h * (0.55 + 0.12 * i / 2.0)
+        ang = i * 2.399963 + seed
+        off = 0.9 * (1 - i / (nb * 1.3))
+        c = np.array([off * np.cos(ang), cy, off * np.sin(ang)])
+        R = 0.9 - 0.05 * i + 0.2 * rng.rand()
+        s = int(rng.randint(1, 1000))
+
+        def blob(U, V, c=c, R=R, s=s):
+            th, ph = V * np.pi, U * 2 * np.pi
+            r = R * (1 + 0.25 * (_value_noise(U * 6, V * 6, s) - 0.5) + 0.1 * np.sin(ph * 5) * np.sin(th * 4))
+            return np.stack([c[0] + r * np.sin(th) * np.cos(ph), c[1] + 0.8 * r * np.cos(th), c[2] + r * np.sin(th) * np.sin(ph)], -1)
+
+        parts.append(grid_surface(blob, n(24), n(20), flip=True))
+    return _merge(parts)
+
+
+def forest(n_instances=1000, tree_tris=10_000, tree_kinds=4):
+    b = SceneBuilder("forest")
+    soil = b.add_material((0.30, 0.24, 0.16))
+    leaf = [b.add_material(c) for c in ((0.12, 0.35, 0.08), (0.20, 0.42, 0.10), (0.30, 0.38, 0.08), (0.10, 0.28, 0.12))]
+    sun = b.add_emitter((60.0, 55.0, 45.0))
+    ext = 2.2 * np.sqrt(n_instances)
+
+    def ground(U, V):
+        x, z = (U * 2 - 1) * ext, (V * 2 - 1) * ext
+        return np.stack([x, 0.6 * _value_noise(x * 0.15, z * 0.15, 3) + 0.05 * _value_noise(x, z, 4), z], -1)
+
+    add_chunked(b, grid_surface(ground, 180, 180), soil)
+    kinds = []
+    for s in range(tree_kinds):
+        pos, nrm, uv, tri = _tree(s + 1, tree_tris)
+        kinds.append(b.add_mesh(pos, nrm, uv, tri[:MAX_TRIS]))
+    rng = np.random.RandomState(7)
+    side = int(np.ceil(np.sqrt(n_instances)))
+    for i in range(n_instances):
+        gx, gz = i % side, i // side
+        x = (gx + 0.5 + 0.7 * (rng.rand() - 0.5)) / side * 2 * ext - ext
+        z = (gz + 0.5 + 0.7 * (rng.rand() - 0.5)) / side * 2 * ext - ext
+        y = 0.6 * float(_value_noise(np.array(x * 0.15), np.array(z * 0.15), 3))
+        s = 0.8 + 0.7 * rng.rand()
+        b.add_instance(kinds[i % tree_kinds], leaf[int(rng.randint(0, 4))], translate((x, y - 0.05, z)) @ rotate_y(rng.rand() * 6.283) @ scale((s, s * (0.9 + 0.3 * rng.rand()), s)))
+    # one large emissive panel high above (an overcast "sky" light)
+    pos, nrm, uv, tri = _quad((-ext, 40.0, -ext), (ext, 40.0, -ext), (ext, 40.0, ext), (-ext, 40.0, ext), (0, -1, 0))
+    b.add_instance(b.add_mesh(pos, nrm, uv, tri), sun)
+    return b.build(), {"eye": (-0.55 * ext, 9.0, -0.55 * ext), "target": (0.0, 1.5, 0.0), "fovy": np.radians(55.0)}
+
+
+SCENES = {"cornell_box": cornell_box, "atrium": atrium, "forest": forest, "furnace": furnace_box}
