@@ -1,0 +1,78 @@
+"""Loader of libstratum_hip.so (the C ABI declared in include/sthip.h).
+
+The library is built in-tree by __graft_entry__.build() / `make -C stratum_amd/csrc`. There is no
+fallback of any kind: if the shared object is missing or a HIP device is absent, every entry point
+of this package raises.
+"""
+import ctypes as C
+import os
+
+from . import wire
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstratum_hip.so")
+
+# every symbol include/sthip.h declares
+EXPORTS = [
+    "sthip_abi_version",
+    "sthip_create",
+    "sthip_destroy",
+    "sthip_last_error",
+    "sthip_set_stream",
+    "sthip_scene_upload",
+    "sthip_render",
+    "sthip_set_shard",
+    "sthip_trace_rays",
+    "sthip_get_stats",
+    "sthip_set_option",
+]
+
+_lib = None
+
+
+class StratumHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StratumHipError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH
+        )
+    L = C.CDLL(LIB_PATH)
+    L.sthip_abi_version.restype = C.c_int
+    L.sthip_create.restype = C.c_int
+    L.sthip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.sthip_destroy.restype = None
+    L.sthip_destroy.argtypes = [C.c_void_p]
+    L.sthip_last_error.restype = C.c_char_p
+    L.sthip_last_error.argtypes = [C.c_void_p]
+    L.sthip_set_stream.restype = C.c_int
+    L.sthip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.sthip_scene_upload.restype = C.c_int
+    L.sthip_scene_upload.argtypes = [C.c_void_p, C.POINTER(wire.SceneDesc)]
+    L.sthip_render.restype = C.c_int
+    L.sthip_render.argtypes = [
+        C.c_void_p,
+        C.POINTER(wire.BDPTPushConstants),
+        C.c_uint32,
+        C.c_uint32,
+        C.POINTER(wire.FrameDesc),
+        C.c_uint32,
+        C.c_uint32,
+        C.POINTER(wire.Outputs),
+    ]
+    L.sthip_set_shard.restype = C.c_int
+    L.sthip_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.sthip_trace_rays.restype = C.c_int
+    L.sthip_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.sthip_get_stats.restype = C.c_int
+    L.sthip_get_stats.argtypes = [C.c_void_p, C.POINTER(wire.Stats)]
+    L.sthip_set_option.restype = C.c_int
+    L.sthip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    _lib = L
+    return L

@@ -1,0 +1,190 @@
+"""Host-side mirror of the reference renderer component `stm::BDPT` (src/Node/BDPT.{hpp,cpp})
+above the C ABI of libstratum_hip.so.
+
+Same knobs, same defaults, same flag resolution: the constructor sets the default sampling
+flags and push constants of BDPT.cpp:55-76 and parses the reference's `--key=value` arguments
+(`minPathVertices`, `maxPathVertices`, `maxDiffuseVertices`, repeated `bdptFlag=[~]name`,
+BDPT.cpp:78-127); `update()` is where the reference binds the scene descriptors
+(BDPT.cpp:341-421) and here uploads the scene arrays; `render()` replaces the recorded
+dispatch sequence (BDPT.cpp:423-838) by one sthip_render call.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import wire
+from ._lib import StratumHipError, lib
+
+
+def _flag_key(name):
+    # to_string(BDPTFlagBits) lower-cased with spaces removed (BDPT.cpp:107-116)
+    table = {
+        "ePerformanceCounters": "performancecounters",
+        "eRemapThreads": "remapthreads",
+        "eCoherentRR": "coherentrr",
+        "eCoherentSampling": "coherentsampling",
+        "eFlipTriangleUVs": "fliptriangleuvs",
+        "eFlipNormalMaps": "flipnormalmaps",
+        "eAlphaTest": "alphatest",
+        "eNormalMaps": "normalmaps",
+        "eShadingNormalShadowFix": "shadingnormalshadowfix",
+        "eRayCones": "raycones",
+        "eSampleBSDFs": "samplebsdfs",
+        "eNEE": "nee",
+        "eNEEReservoirs": "neereservoirs",
+        "eNEEReservoirReuse": "neereservoirreuse",
+        "eMIS": "mis",
+        "eSampleLightPower": "samplelightpower",
+        "eUniformSphereSampling": "uniformspheresampling",
+        "ePresampleLights": "presamplelights",
+        "eDeferShadowRays": "defershadowrays",
+        "eConnectToViews": "connecttoviews",
+        "eConnectToLightPaths": "connecttolightpaths",
+        "eLVC": "lightvertexcache",
+        "eLVCReservoirs": "lvcreservoirs",
+        "eLVCReservoirReuse": "lvcreservoirreuse",
+        "eHashGridJitter": "jitterhashgridlookups",
+        "eSampleEnvironmentMapDirectly": "sampleenvironmentmapdirectly",
+    }
+    return table[name]
+
+
+_FLAG_BY_KEY = {_flag_key(n): i for i, n in enumerate(wire.FLAG_NAMES)}
+
+
+class BDPT:
+    def __init__(self, device=0, args=None):
+        self._lib = lib()
+        h = C.c_void_p()
+        rc = self._lib.sthip_create(device, C.byref(h))
+        if rc != 0:
+            raise StratumHipError("sthip_create(%d) failed (%d): %s" % (device, rc, self._lib.sthip_last_error(None).decode()))
+        self._h = h
+        self.device = device
+        self.mSamplingFlags = wire.DEFAULT_SAMPLING_FLAGS
+        self.mPushConstants = wire.default_push_constants(0, 0, 0)
+        self._scene = None
+        self._prev_result = None
+        args = args or {}
+        for key, field in (
+            ("minPathVertices", "gMinPathVertices"),
+            ("maxPathVertices", "gMaxPathVertices"),
+            ("maxDiffuseVertices", "gMaxDiffuseVertices"),
+            ("maxNullCollisions", "gMaxNullCollisions"),
+        ):
+            if key in args:
+                setattr(self.mPushConstants, field, int(args[key]))
+        for a in args.get("bdptFlag", []):
+            self.set_flag(a)
+
+    # BDPT.cpp:94-127
+    def set_flag(self, arg):
+        if not arg:
+            return
+        on = True
+        if arg[0] in "~!":
+            on, arg = False, arg[1:]
+        bit = _FLAG_BY_KEY.get(arg.lower())
+        if bit is None:
+            return  # the reference silently ignores unknown names
+        if on:
+            self.mSamplingFlags |= 1 << bit
+        else:
+            self.mSamplingFlags &= ~(1 << bit)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise StratumHipError("%s failed (%d): %s" % (what, rc, self._lib.sthip_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sthip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- BDPT::update: (re)bind the scene ----
+    def update(self, scene):
+        d = scene.desc()
+        self._check(self._lib.sthip_scene_upload(self._h, C.byref(d)), "sthip_scene_upload")
+        self._scene = scene
+
+    def set_shard(self, rank, count, tile_w=64, tile_h=32):
+        self._check(self._lib.sthip_set_shard(self._h, rank, count, tile_w, tile_h), "sthip_set_shard")
+
+    def set_stream(self, stream_handle):
+        self._check(self._lib.sthip_set_stream(self._h, C.c_void_p(stream_handle)), "sthip_set_stream")
+
+    def set_option(self, name, value):
+        self._check(self._lib.sthip_set_option(self._h, name.encode(), int(value)), "sthip_set_option")
+
+    def stats(self):
+        s = wire.Stats()
+        self._check(self._lib.sthip_get_stats(self._h, C.byref(s)), "sthip_get_stats")
+        return {f: getattr(s, f) for f, _ in wire.Stats._fields_}
+
+    def push_constants(self, frame):
+        pc = wire.BDPTPushConstants.from_buffer_copy(self.mPushConstants)
+        pc.gOutputExtent[0], pc.gOutputExtent[1] = frame.width, frame.height
+        pc.gViewCount = 1
+        pc.gLightCount = self._scene.light_count
+        pc.gLightPathCount = frame.width * frame.height  # BDPT.cpp:469-470
+        pc.gEnvironmentMaterialAddress = 0xFFFFFFFF
+        pc.gEnvironmentSampleProbability = 0.0
+        pc.gMaxNullCollisions = 0
+        return pc
+
+    # ---- BDPT::render ----
+    def render(self, frame, seed_begin=0, seed_count=1, aovs=True, device_outputs=None):
+        """Host outputs by default (dict of numpy arrays). `device_outputs` = dict of raw device pointers
+        {"radiance": ptr, ["albedo", "visibility", "depth", "prev_uv", "ray_count"]} renders in place on the
+        GPU without synchronising."""
+        if self._scene is None:
+            raise StratumHipError("BDPT.render before BDPT.update(scene)")
+        pc = self.push_constants(frame)
+        fd = frame.desc()
+        o = wire.Outputs()
+        out = None
+        if device_outputs is not None:
+            o.device_ptrs = 1
+            o.gRadiance = device_outputs["radiance"]
+            o.gAlbedo = device_outputs.get("albedo")
+            o.gVisibility = device_outputs.get("visibility")
+            o.gDepth = device_outputs.get("depth")
+            o.gPrevUVs = device_outputs.get("prev_uv")
+            o.gRayCount = device_outputs.get("ray_count")
+        else:
+            W, H = frame.width, frame.height
+            out = {"radiance": np.zeros((H, W, 4), np.float32), "ray_count": np.zeros(2, np.uint64)}
+            o.device_ptrs = 0
+            o.gRadiance = wire.ptr(out["radiance"])
+            o.gRayCount = wire.ptr(out["ray_count"])
+            if aovs:
+                out["albedo"] = np.zeros((H, W, 4), np.float32)
+                out["visibility"] = np.zeros((H, W), wire.VisibilityInfo)
+                out["depth"] = np.zeros((H, W), wire.DepthInfo)
+                out["prev_uv"] = np.zeros((H, W, 2), np.float32)
+                o.gAlbedo = wire.ptr(out["albedo"])
+                o.gVisibility = wire.ptr(out["visibility"])
+                o.gDepth = wire.ptr(out["depth"])
+                o.gPrevUVs = wire.ptr(out["prev_uv"])
+        rc = self._lib.sthip_render(self._h, C.byref(pc), self.mSamplingFlags, self._scene.scene_flags, C.byref(fd), seed_begin, seed_count, C.byref(o))
+        self._check(rc, "sthip_render")
+        if out is not None:
+            self._prev_result = out["radiance"]
+        return out
+
+    def prev_result(self):  # BDPT.hpp:18
+        return self._prev_result
+
+    # ---- the traversal contract on its own ----
+    def trace(self, rays, any_hit=False):
+        rays = np.ascontiguousarray(rays, dtype=wire.Ray)
+        hits = np.zeros(rays.shape[0], wire.Hit)
+        rc = self._lib.sthip_trace_rays(self._h, wire.ptr(rays), rays.shape[0], wire.ptr(hits), 1 if any_hit else 0, 0)
+        self._check(rc, "sthip_trace_rays")
+        return hits

@@ -1,0 +1,574 @@
+// api.hip — the C ABI of include/sthip.h: context, scene upload, the per-frame launch sequence.
+//
+// sthip_render is the replacement of the dispatch sequence BDPT::render records
+// (src/Node/BDPT.cpp:607-720: fill gShadowRays, dispatch sample_visibility, barrier, dispatch
+// trace_shadows) and of the running-mean accumulation the denoiser applies with default settings
+// (src/Node/Denoiser.cpp:73,186-213). There is no CPU fallback: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/sthip.h"
+#include "bvh_build.h"
+#include "kernels.h"
+
+namespace {
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t ensure(size_t count) {
+    if (count <= n && p) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    if (count == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+}  // namespace
+
+struct sthip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+  int cu_count = 256;
+  // scene
+  bool has_scene = false;
+  DevBuf<sthip_PackedVertexData> vertices;
+  DevBuf<uint8_t> indices;
+  DevBuf<sthip_InstanceData> instances;
+  DevBuf<sthip_TransformData> xf, inv_xf, motion_xf;
+  DevBuf<uint8_t> materials;
+  DevBuf<uint32_t> lights;
+  uint32_t instance_count = 0, light_count = 0;
+  DevBuf<BvhNode> nodes;
+  DevBuf<BvhTri> tris;
+  DevBuf<TlasEntry> entries;
+  DeviceBvh bvh{};
+  uint64_t bvh_nodes = 0, bvh_tris = 0;
+  // frame
+  DevBuf<uint8_t> views;  // gViews | gViewTransforms | gPrevViews | gPrevInverseViewTransforms
+  DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays;
+  DevBuf<uint32_t> meta, queue0, queue1;
+  DevBuf<unsigned long long> counters;
+  DevBuf<float4> out_radiance, out_albedo;
+  DevBuf<sthip_VisibilityInfo> out_visibility;
+  DevBuf<sthip_DepthInfo> out_depth;
+  DevBuf<float2> out_prev_uv;
+  uint32_t shard_rank = 0, shard_count = 1, tile_w = 64, tile_h = 32;
+  // options / stats
+  bool count_traversal = false, time_kernels = false;
+  sthip_stats stats{};
+  bool stats_pending = false;  // ray / traversal counters of the last render still live on the device
+  hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+#define HIP_TRY(ctx, expr)                                                                            \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess) {                                                                           \
+      (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(_e);                               \
+      return STHIP_ERR_HIP;                                                                           \
+    }                                                                                                 \
+  } while (0)
+
+static int fail(sthip_ctx* ctx, int code, const std::string& msg) {
+  ctx->error = msg;
+  return code;
+}
+
+extern "C" {
+
+int sthip_abi_version(void) { return STHIP_ABI_VERSION; }
+
+int sthip_create(int device, sthip_ctx** out_ctx) {
+  if (!out_ctx) {
+    g_create_error = "out_ctx is NULL";
+    return STHIP_ERR_INVALID_ARGUMENT;
+  }
+  *out_ctx = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    g_create_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                     " (libstratum_hip has no CPU backend)";
+    return STHIP_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= count) {
+    g_create_error = "device index out of range";
+    return STHIP_ERR_INVALID_ARGUMENT;
+  }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    return STHIP_ERR_HIP;
+  }
+  sthip_ctx* ctx = new sthip_ctx();
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+  (void)hipEventCreate(&ctx->ev[0]);
+  (void)hipEventCreate(&ctx->ev[1]);
+  ctx->stats.bvh_node_bytes = sizeof(BvhNode);
+  ctx->stats.bvh_tri_bytes = sizeof(BvhTri);
+  *out_ctx = ctx;
+  return STHIP_OK;
+}
+
+void sthip_destroy(sthip_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  ctx->vertices.release();
+  ctx->indices.release();
+  ctx->instances.release();
+  ctx->xf.release();
+  ctx->inv_xf.release();
+  ctx->motion_xf.release();
+  ctx->materials.release();
+  ctx->lights.release();
+  ctx->nodes.release();
+  ctx->tris.release();
+  ctx->entries.release();
+  ctx->views.release();
+  ctx->ray_o.release();
+  ctx->ray_d.release();
+  ctx->hit.release();
+  ctx->beta.release();
+  ctx->radiance.release();
+  ctx->shadow_sum.release();
+  ctx->accum.release();
+  ctx->shadow_rays.release();
+  ctx->meta.release();
+  ctx->queue0.release();
+  ctx->queue1.release();
+  ctx->counters.release();
+  ctx->out_radiance.release();
+  ctx->out_albedo.release();
+  ctx->out_visibility.release();
+  ctx->out_depth.release();
+  ctx->out_prev_uv.release();
+  if (ctx->ev[0]) (void)hipEventDestroy(ctx->ev[0]);
+  if (ctx->ev[1]) (void)hipEventDestroy(ctx->ev[1]);
+  delete ctx;
+}
+
+const char* sthip_last_error(const sthip_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int sthip_set_stream(sthip_ctx* ctx, void* hip_stream) {
+  if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
+  ctx->stream = (hipStream_t)hip_stream;
+  return STHIP_OK;
+}
+
+int sthip_set_shard(sthip_ctx* ctx, uint32_t shard_rank, uint32_t shard_count, uint32_t tile_w, uint32_t tile_h) {
+  if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
+  if (shard_count == 0 || shard_rank >= shard_count || tile_w == 0 || tile_h == 0 || (tile_w & 7u) || (tile_h & 7u))
+    return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "shard: need rank < count and tile sizes that are multiples of 8");
+  ctx->shard_rank = shard_rank;
+  ctx->shard_count = shard_count;
+  ctx->tile_w = tile_w;
+  ctx->tile_h = tile_h;
+  return STHIP_OK;
+}
+
+int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
+  if (!ctx || !name) return STHIP_ERR_INVALID_ARGUMENT;
+  if (!strcmp(name, "count_traversal"))
+    ctx->count_traversal = value != 0;
+  else if (!strcmp(name, "time_kernels"))
+    ctx->time_kernels = value != 0;
+  else
+    return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, std::string("unknown option ") + name);
+  return STHIP_OK;
+}
+
+int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out) {
+  if (!ctx || !out) return STHIP_ERR_INVALID_ARGUMENT;
+  if (ctx->stats_pending) {
+    unsigned long long c[CNT_TOTAL];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+    ctx->stats.rays_total = c[CNT_RAYS_CLOSEST] + c[CNT_RAYS_SHADOW];
+    ctx->stats.rays_path = c[CNT_RAYS_CLOSEST];
+    ctx->stats.rays_shadow = c[CNT_RAYS_SHADOW];
+    ctx->stats.nodes_visited = c[CNT_NODES];
+    ctx->stats.tris_tested = c[CNT_TRIS];
+    ctx->stats_pending = false;
+  }
+  *out = ctx->stats;
+  out->bvh_node_bytes = sizeof(BvhNode);
+  out->bvh_tri_bytes = sizeof(BvhTri);
+  out->bvh_nodes = ctx->bvh_nodes;
+  out->bvh_tris = ctx->bvh_tris;
+  return STHIP_OK;
+}
+
+int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
+  if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
+  if (!s || !s->gVertices || !s->gIndices || !s->gInstances || !s->gInstanceTransforms || !s->gInstanceInverseTransforms || !s->gMaterialData || s->instance_count == 0)
+    return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: a required array is NULL or there are no instances");
+  if (s->instance_count > 0xFFFF) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: more than 65535 instances (16-bit instance index, scene.h:23)");
+  if (s->light_count && !s->gLightInstances) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: light_count > 0 but gLightInstances is NULL");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->has_scene = false;
+  for (uint32_t i = 0; i < s->light_count; i++)
+    if (s->gLightInstances[i] >= s->instance_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: gLightInstances entry out of range");
+  // textures are outside the built path: every material must be constant-valued
+  for (uint32_t i = 0; i < s->instance_count; i++) {
+    const uint32_t addr = s->gInstances[i].packed[0] >> 4;
+    if ((size_t)addr + sizeof(sthip_MaterialRecord) > s->material_bytes) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: material_address out of range");
+    sthip_MaterialRecord rec;
+    memcpy(&rec, (const uint8_t*)s->gMaterialData + addr, sizeof(rec));
+    for (int k = 0; k < 3; k++)
+      if (rec.values[k].image_index < STHIP_IMAGE_COUNT) return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: textured materials are not part of the built hot path");
+    if (rec.bump_index < STHIP_IMAGE_COUNT || rec.alpha_mask_index < STHIP_IMAGE_COUNT)
+      return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: bump / alpha-mask images are not part of the built hot path");
+  }
+  sthip::BuiltBvh built;
+  std::string err;
+  if (!sthip::build_scene_bvh(*s, built, err)) return fail(ctx, err.find("only triangle") != std::string::npos ? STHIP_ERR_UNSUPPORTED : STHIP_ERR_INVALID_ARGUMENT, "scene: " + err);
+
+  const uint32_t n = s->instance_count;
+  HIP_TRY(ctx, ctx->vertices.ensure(s->vertex_count));
+  HIP_TRY(ctx, ctx->indices.ensure((size_t)s->indices_bytes + 8));
+  HIP_TRY(ctx, ctx->instances.ensure(n));
+  HIP_TRY(ctx, ctx->xf.ensure(n));
+  HIP_TRY(ctx, ctx->inv_xf.ensure(n));
+  HIP_TRY(ctx, ctx->motion_xf.ensure(n));
+  HIP_TRY(ctx, ctx->materials.ensure(s->material_bytes));
+  HIP_TRY(ctx, ctx->lights.ensure(std::max(1u, s->light_count)));
+  HIP_TRY(ctx, hipMemcpy(ctx->vertices.p, s->gVertices, (size_t)s->vertex_count * sizeof(sthip_PackedVertexData), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemset(ctx->indices.p, 0, (size_t)s->indices_bytes + 8));
+  HIP_TRY(ctx, hipMemcpy(ctx->indices.p, s->gIndices, s->indices_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->instances.p, s->gInstances, (size_t)n * 16, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->xf.p, s->gInstanceTransforms, (size_t)n * 48, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->inv_xf.p, s->gInstanceInverseTransforms, (size_t)n * 48, hipMemcpyHostToDevice));
+  if (s->gInstanceMotionTransforms) {
+    HIP_TRY(ctx, hipMemcpy(ctx->motion_xf.p, s->gInstanceMotionTransforms, (size_t)n * 48, hipMemcpyHostToDevice));
+  } else {
+    std::vector<sthip_TransformData> I(n);
+    memset(I.data(), 0, (size_t)n * 48);
+    for (auto& t : I) t.m[0][0] = t.m[1][1] = t.m[2][2] = 1;
+    HIP_TRY(ctx, hipMemcpy(ctx->motion_xf.p, I.data(), (size_t)n * 48, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(ctx, hipMemcpy(ctx->materials.p, s->gMaterialData, s->material_bytes, hipMemcpyHostToDevice));
+  if (s->light_count) HIP_TRY(ctx, hipMemcpy(ctx->lights.p, s->gLightInstances, (size_t)s->light_count * 4, hipMemcpyHostToDevice));
+  ctx->instance_count = n;
+  ctx->light_count = s->light_count;
+
+  HIP_TRY(ctx, ctx->nodes.ensure(std::max<size_t>(1, built.nodes.size())));
+  HIP_TRY(ctx, ctx->tris.ensure(std::max<size_t>(1, built.tris.size())));
+  HIP_TRY(ctx, ctx->entries.ensure(std::max<size_t>(1, built.entries.size())));
+  if (!built.nodes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->nodes.p, built.nodes.data(), built.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+  if (!built.tris.empty()) HIP_TRY(ctx, hipMemcpy(ctx->tris.p, built.tris.data(), built.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
+  if (!built.entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->entries.p, built.entries.data(), built.entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
+  ctx->bvh.nodes = reinterpret_cast<const float4*>(ctx->nodes.p);
+  ctx->bvh.tris = reinterpret_cast<const float4*>(ctx->tris.p);
+  ctx->bvh.entries = ctx->entries.p;
+  ctx->bvh.root_ref = built.root_ref;
+  ctx->bvh.top_is_world_blas = built.top_is_world_blas;
+  ctx->bvh.stack_depth = built.stack_depth;
+  ctx->bvh.scene_cx = built.scene_center[0];
+  ctx->bvh.scene_cy = built.scene_center[1];
+  ctx->bvh.scene_cz = built.scene_center[2];
+  ctx->bvh.scene_radius = built.scene_radius;
+  ctx->bvh_nodes = built.nodes.size();
+  ctx->bvh_tris = built.tris.size();
+  ctx->has_scene = true;
+  return STHIP_OK;
+}
+
+static uint32_t grid_for(const sthip_ctx* ctx, size_t n) {
+  const size_t blocks = (n + STHIP_BLOCK - 1) / STHIP_BLOCK;
+  const size_t cap = (size_t)ctx->cu_count * 32;  // grid-stride beyond this
+  return (uint32_t)std::max<size_t>(1, std::min(blocks, cap));
+}
+static size_t stack_bytes(const sthip_ctx* ctx) { return (size_t)ctx->bvh.stack_depth * STHIP_BLOCK * sizeof(uint32_t); }
+
+int sthip_trace_rays(sthip_ctx* ctx, const sthip_ray* rays, uint32_t ray_count, sthip_hit* hits, uint32_t any_hit, uint32_t device_ptrs) {
+  if (!ctx || !rays || !hits) return STHIP_ERR_INVALID_ARGUMENT;
+  if (!ctx->has_scene) return fail(ctx, STHIP_ERR_NO_SCENE, "no scene uploaded");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ray_count == 0) return STHIP_OK;
+  const sthip_ray* d_rays = rays;
+  sthip_hit* d_hits = hits;
+  DevBuf<sthip_ray> rb;
+  DevBuf<sthip_hit> hb;
+  if (!device_ptrs) {
+    HIP_TRY(ctx, rb.ensure(ray_count));
+    HIP_TRY(ctx, hb.ensure(ray_count));
+    HIP_TRY(ctx, hipMemcpyAsync(rb.p, rays, (size_t)ray_count * sizeof(sthip_ray), hipMemcpyHostToDevice, ctx->stream));
+    d_rays = rb.p;
+    d_hits = hb.p;
+  }
+  HIP_TRY(ctx, ctx->counters.ensure(CNT_TOTAL));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_TOTAL * sizeof(unsigned long long), ctx->stream));
+  const uint32_t grid = grid_for(ctx, ray_count);
+  const size_t lds = stack_bytes(ctx);
+  if (any_hit) {
+    if (ctx->count_traversal)
+      hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(grid), dim3(STHIP_BLOCK), lds, ctx->stream, ctx->bvh, d_rays, ray_count, d_hits, ctx->counters.p);
+    else
+      hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(STHIP_BLOCK), lds, ctx->stream, ctx->bvh, d_rays, ray_count, d_hits, ctx->counters.p);
+  } else {
+    if (ctx->count_traversal)
+      hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(STHIP_BLOCK), lds, ctx->stream, ctx->bvh, d_rays, ray_count, d_hits, ctx->counters.p);
+    else
+      hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(STHIP_BLOCK), lds, ctx->stream, ctx->bvh, d_rays, ray_count, d_hits, ctx->counters.p);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  if (!device_ptrs) {
+    HIP_TRY(ctx, hipMemcpyAsync(hits, hb.p, (size_t)ray_count * sizeof(sthip_hit), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> c(CNT_TOTAL);
+    HIP_TRY(ctx, hipMemcpyAsync(c.data(), ctx->counters.p, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.nodes_visited = c[CNT_NODES];
+    ctx->stats.tris_tested = c[CNT_TRIS];
+    rb.release();
+    hb.release();
+  }
+  return STHIP_OK;
+}
+
+int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin,
+                 uint32_t seed_count, const sthip_outputs* out) {
+  if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
+  if (!pc || !frame || !out || !out->gRadiance || !frame->gViews || !frame->gViewTransforms || frame->view_count == 0 || seed_count == 0)
+    return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: a required argument is NULL/zero");
+  if (!ctx->has_scene) return fail(ctx, STHIP_ERR_NO_SCENE, "no scene uploaded");
+  if (pc->gViewCount != frame->view_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: gViewCount != frame.view_count");
+  if ((out->gDepth || out->gPrevUVs) && !frame->gInverseViewTransforms && !frame->gPrevInverseViewTransforms)
+    return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: depth / prev-uv outputs need gInverseViewTransforms");
+  // Outside the built hot path: environment maps, media, light tracing, reservoirs, ...
+  if (scene_flags & (STHIP_BDPT_FLAG_HAS_ENVIRONMENT | STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT))
+    return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: environment / media / light-tracing scene flags are not part of the built hot path");
+  const uint32_t unsupported = (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_ePresampleLights) | (1u << STHIP_eConnectToViews) |
+                               (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
+                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eAlphaTest) | (1u << STHIP_eCoherentSampling);
+  if (sampling_flags & unsupported) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: a sampling flag outside the built hot path is set");
+  if (pc->gMaxPathVertices > 60 || pc->gMaxDiffuseVertices > 60) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: path length limits above 60");
+  if (pc->gLightCount > ctx->light_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: gLightCount exceeds the uploaded light list");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+
+  // flag resolution of BDPT::render (BDPT.cpp:504-523)
+  if (!(scene_flags & STHIP_BDPT_FLAG_HAS_EMISSIVES) || pc->gLightCount == 0) sampling_flags &= ~(1u << STHIP_eNEE);
+  if (!(sampling_flags & (1u << STHIP_eNEE))) sampling_flags &= ~(1u << STHIP_eDeferShadowRays);
+
+  const uint32_t W = pc->gOutputExtent[0], H = pc->gOutputExtent[1];
+  if (W == 0 || H == 0) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: empty output extent");
+  const size_t pixels = (size_t)W * H;
+  FrameParams p;
+  memset(&p, 0, sizeof(p));
+  p.pc = *pc;
+  p.sampling_flags = sampling_flags;
+  p.shard_rank = ctx->shard_rank;
+  p.shard_count = ctx->shard_count;
+  p.tile_w = ctx->tile_w;
+  p.tile_h = ctx->tile_h;
+  p.tiles_x = (W + p.tile_w - 1) / p.tile_w;
+  p.tiles_y = (H + p.tile_h - 1) / p.tile_h;
+  const uint32_t tiles = p.tiles_x * p.tiles_y;
+  const uint32_t owned = tiles > p.shard_rank ? (tiles - p.shard_rank + p.shard_count - 1) / p.shard_count : 0;
+  p.path_count = owned * p.tile_w * p.tile_h;
+  const size_t P = std::max<size_t>(1, p.path_count);
+
+  HIP_TRY(ctx, ctx->ray_o.ensure(P));
+  HIP_TRY(ctx, ctx->ray_d.ensure(P));
+  HIP_TRY(ctx, ctx->hit.ensure(P));
+  HIP_TRY(ctx, ctx->beta.ensure(P));
+  HIP_TRY(ctx, ctx->radiance.ensure(P));
+  HIP_TRY(ctx, ctx->shadow_sum.ensure(P));
+  HIP_TRY(ctx, ctx->accum.ensure(P));
+  HIP_TRY(ctx, ctx->shadow_rays.ensure(3 * P));
+  HIP_TRY(ctx, ctx->meta.ensure(P));
+  HIP_TRY(ctx, ctx->queue0.ensure(P));
+  HIP_TRY(ctx, ctx->queue1.ensure(P));
+  HIP_TRY(ctx, ctx->counters.ensure(CNT_TOTAL));
+
+  // views
+  const uint32_t nv = frame->view_count;
+  const size_t vbytes = (size_t)nv * 48;
+  HIP_TRY(ctx, ctx->views.ensure(4 * vbytes));
+  {
+    std::vector<uint8_t> host(4 * vbytes);
+    memcpy(host.data(), frame->gViews, vbytes);
+    memcpy(host.data() + vbytes, frame->gViewTransforms, vbytes);
+    memcpy(host.data() + 2 * vbytes, frame->gPrevViews ? frame->gPrevViews : frame->gViews, vbytes);
+    const sthip_TransformData* piv = frame->gPrevInverseViewTransforms ? frame->gPrevInverseViewTransforms : frame->gInverseViewTransforms;
+    if (piv)
+      memcpy(host.data() + 3 * vbytes, piv, vbytes);
+    else
+      memset(host.data() + 3 * vbytes, 0, vbytes);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->views.p, host.data(), 4 * vbytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));  // `host` goes out of scope
+  }
+  p.views = reinterpret_cast<const sthip_ViewData*>(ctx->views.p);
+  p.view_xf = reinterpret_cast<const sthip_TransformData*>(ctx->views.p + vbytes);
+  p.prev_views = reinterpret_cast<const sthip_ViewData*>(ctx->views.p + 2 * vbytes);
+  p.prev_inv_view_xf = reinterpret_cast<const sthip_TransformData*>(ctx->views.p + 3 * vbytes);
+
+  p.scene.vertices = ctx->vertices.p;
+  p.scene.indices = ctx->indices.p;
+  p.scene.instances = ctx->instances.p;
+  p.scene.xf = ctx->xf.p;
+  p.scene.inv_xf = ctx->inv_xf.p;
+  p.scene.motion_xf = ctx->motion_xf.p;
+  p.scene.materials = ctx->materials.p;
+  p.scene.lights = ctx->lights.p;
+  p.scene.instance_count = ctx->instance_count;
+  p.scene.light_count = ctx->light_count;
+  p.bvh = ctx->bvh;
+  p.ray_o = ctx->ray_o.p;
+  p.ray_d = ctx->ray_d.p;
+  p.hit = ctx->hit.p;
+  p.beta = ctx->beta.p;
+  p.meta = ctx->meta.p;
+  p.radiance = ctx->radiance.p;
+  p.shadow_sum = ctx->shadow_sum.p;
+  p.accum = ctx->accum.p;
+  p.queue[0] = ctx->queue0.p;
+  p.queue[1] = ctx->queue1.p;
+  p.shadow_rays = ctx->shadow_rays.p;
+  p.counters = ctx->counters.p;
+  p.count_traversal = ctx->count_traversal ? 1u : 0u;
+
+  // outputs: device pointers are written in place, host pointers go through staging buffers
+  const bool dev = out->device_ptrs != 0;
+  if (dev) {
+    p.out_radiance = reinterpret_cast<float4*>(out->gRadiance);
+    p.out_albedo = reinterpret_cast<float4*>(out->gAlbedo);
+    p.out_visibility = out->gVisibility;
+    p.out_depth = out->gDepth;
+    p.out_prev_uv = reinterpret_cast<float2*>(out->gPrevUVs);
+  } else {
+    HIP_TRY(ctx, ctx->out_radiance.ensure(pixels));
+    p.out_radiance = ctx->out_radiance.p;
+    if (out->gAlbedo) {
+      HIP_TRY(ctx, ctx->out_albedo.ensure(pixels));
+      p.out_albedo = ctx->out_albedo.p;
+    }
+    if (out->gVisibility) {
+      HIP_TRY(ctx, ctx->out_visibility.ensure(pixels));
+      p.out_visibility = ctx->out_visibility.p;
+    }
+    if (out->gDepth) {
+      HIP_TRY(ctx, ctx->out_depth.ensure(pixels));
+      p.out_depth = ctx->out_depth.p;
+    }
+    if (out->gPrevUVs) {
+      HIP_TRY(ctx, ctx->out_prev_uv.ensure(pixels));
+      p.out_prev_uv = ctx->out_prev_uv.p;
+    }
+  }
+  // pixels this shard does not own are zero (sum-reduce over shards assembles the frame)
+  HIP_TRY(ctx, hipMemsetAsync(p.out_radiance, 0, pixels * 16, st));
+  if (p.out_albedo) HIP_TRY(ctx, hipMemsetAsync(p.out_albedo, 0, pixels * 16, st));
+  if (p.out_visibility) HIP_TRY(ctx, hipMemsetAsync(p.out_visibility, 0, pixels * 8, st));
+  if (p.out_depth) HIP_TRY(ctx, hipMemsetAsync(p.out_depth, 0, pixels * 16, st));
+  if (p.out_prev_uv) HIP_TRY(ctx, hipMemsetAsync(p.out_prev_uv, 0, pixels * 8, st));
+
+  const uint32_t grid = grid_for(ctx, p.path_count);
+  const size_t lds = stack_bytes(ctx);
+  const uint32_t max_bounce_rounds = pc->gMaxPathVertices >= 2 ? pc->gMaxPathVertices - 1 : 0;  // rays per path <= gMaxPathVertices - 1
+  const bool timing = ctx->time_kernels;
+  float ms_closest = 0, ms_shadow = 0, ms_shade = 0, ms_other = 0;
+  uint32_t launches_closest = 0, launches_shadow = 0;
+  auto timed = [&](float& acc, auto&& launch) -> int {
+    if (timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+    launch();
+    HIP_TRY(ctx, hipGetLastError());
+    if (timing) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+      HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
+      float ms = 0;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+      acc += ms;
+    }
+    return STHIP_OK;
+  };
+
+  HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_TOTAL * sizeof(unsigned long long), st));
+  for (uint32_t s = 0; s < seed_count; s++) {
+    p.seed = seed_begin + s;
+    p.write_aov = s == 0 ? 1u : 0u;
+    // queue sizes are per seed; the ray / traversal counters behind them run over the whole call
+    if (s) HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_RAYS_CLOSEST * sizeof(unsigned long long), st));
+    int rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(STHIP_BLOCK), 0, st, p); });
+    if (rc) return rc;
+    for (uint32_t depth = 0; depth < max_bounce_rounds; depth++) {
+      rc = timed(ms_closest, [&]() {
+        if (ctx->count_traversal)
+          hipLaunchKernelGGL((k_trace_closest<true>), dim3(grid), dim3(STHIP_BLOCK), lds, st, p, depth);
+        else
+          hipLaunchKernelGGL((k_trace_closest<false>), dim3(grid), dim3(STHIP_BLOCK), lds, st, p, depth);
+      });
+      if (rc) return rc;
+      launches_closest++;
+      rc = timed(ms_shade, [&]() { hipLaunchKernelGGL(k_shade, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth); });
+      if (rc) return rc;
+      if (sampling_flags & (1u << STHIP_eNEE)) {
+        rc = timed(ms_shadow, [&]() {
+          if (ctx->count_traversal)
+            hipLaunchKernelGGL((k_trace_shadow<true>), dim3(grid), dim3(STHIP_BLOCK), lds, st, p, depth);
+          else
+            hipLaunchKernelGGL((k_trace_shadow<false>), dim3(grid), dim3(STHIP_BLOCK), lds, st, p, depth);
+        });
+        if (rc) return rc;
+        launches_shadow++;
+      }
+    }
+    rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + 1 == seed_count ? 1u : 0u); });
+    if (rc) return rc;
+  }
+
+  if (!dev) {
+    HIP_TRY(ctx, hipMemcpyAsync(out->gRadiance, p.out_radiance, pixels * 16, hipMemcpyDeviceToHost, st));
+    if (out->gAlbedo) HIP_TRY(ctx, hipMemcpyAsync(out->gAlbedo, p.out_albedo, pixels * 16, hipMemcpyDeviceToHost, st));
+    if (out->gVisibility) HIP_TRY(ctx, hipMemcpyAsync(out->gVisibility, p.out_visibility, pixels * 8, hipMemcpyDeviceToHost, st));
+    if (out->gDepth) HIP_TRY(ctx, hipMemcpyAsync(out->gDepth, p.out_depth, pixels * 16, hipMemcpyDeviceToHost, st));
+    if (out->gPrevUVs) HIP_TRY(ctx, hipMemcpyAsync(out->gPrevUVs, p.out_prev_uv, pixels * 8, hipMemcpyDeviceToHost, st));
+    unsigned long long c[CNT_TOTAL];
+    HIP_TRY(ctx, hipMemcpyAsync(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (out->gRayCount) {
+      out->gRayCount[0] = c[CNT_RAYS_CLOSEST] + c[CNT_RAYS_SHADOW];
+      out->gRayCount[1] = c[CNT_RAYS_CLOSEST];
+    }
+    ctx->stats.rays_total = c[CNT_RAYS_CLOSEST] + c[CNT_RAYS_SHADOW];
+    ctx->stats.rays_path = c[CNT_RAYS_CLOSEST];
+    ctx->stats.rays_shadow = c[CNT_RAYS_SHADOW];
+    ctx->stats.nodes_visited = c[CNT_NODES];
+    ctx->stats.tris_tested = c[CNT_TRIS];
+    ctx->stats_pending = false;
+  } else {
+    if (out->gRayCount) hipLaunchKernelGGL(k_write_ray_count, dim3(1), dim3(1), 0, st, ctx->counters.p, reinterpret_cast<unsigned long long*>(out->gRayCount));
+    ctx->stats_pending = true;
+  }
+  if (timing) {
+    ctx->stats.ms_trace_closest = ms_closest;
+    ctx->stats.ms_trace_shadow = ms_shadow;
+    ctx->stats.ms_shade = ms_shade;
+    ctx->stats.ms_total = ms_closest + ms_shadow + ms_shade + ms_other;
+    ctx->stats.launches_trace_closest = launches_closest;
+    ctx->stats.launches_trace_shadow = launches_shadow;
+  }
+  return STHIP_OK;
+}
+
+}  // extern "C"

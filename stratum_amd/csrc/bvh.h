@@ -1,0 +1,57 @@
+// bvh.h — acceleration-structure layout in HBM (product-internal; replaces the driver-built
+// BLAS/TLAS of src/Core/AccelerationStructure.cpp:5-27 and src/Node/Scene.cpp:435-459,614-629).
+//
+// One flat array of 64-byte BVH2 nodes holds the top level and every bottom level. A node stores
+// the boxes of its two children in the Aila-Laine arrangement so that one lane fetches a node with
+// four 16-byte loads from one 64-byte segment:
+//     n0xy = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y)
+//     n1xy = (c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y)
+//     nz   = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)
+//     ref  = (child0, child1, 0, 0)
+// Child references: bit31 = 0 -> index of an inner node; bit31 = 1 -> leaf:
+//     bit30 = 0: triangle leaf, bits[29:2] = first triangle, bits[1:0] = count-1
+//     bit30 = 1: instance leaf, bits[15:0] = index into the TLAS entry table
+// Leaf triangles are stored in leaf order, 48 bytes each: three float4 (v0, v1, v2 in the object
+// space of their mesh); v0.w carries the hit id bits: instance | primitive << 16 for the merged
+// world-space mesh, primitive << 16 for a shared mesh (the instance comes from the TLAS entry).
+#pragma once
+#include <stdint.h>
+
+#define BVH_LEAF_BIT 0x80000000u
+#define BVH_INST_BIT 0x40000000u
+#define BVH_MAX_LEAF_TRIS 4
+#define BVH_INVALID_REF 0xFFFFFFFFu  // empty child (never intersected: box is inverted)
+
+struct BvhNode {
+  float n0xy[4];
+  float n1xy[4];
+  float nz[4];
+  uint32_t ref[4];
+};
+
+struct BvhTri {
+  float v0[3];
+  uint32_t id;
+  float v1[3];
+  uint32_t pad1;
+  float v2[3];
+  uint32_t pad2;
+};
+
+// One entry of the top level: either the merged world-space mesh (identity = 1: all instances whose
+// transform is the identity, flattened into one BLAS) or one transformed instance.
+struct TlasEntry {
+  float inv[12];      // gInstanceInverseTransforms[instance], row-major 3x4
+  uint32_t root;      // index of the BLAS root (always an inner node)
+  uint32_t id_bits;   // OR-ed into BvhTri::id: 0 for the merged mesh, the instance index otherwise
+  uint32_t identity;  // 1: object space == world space
+  uint32_t pad;
+  float center[3];    // object-space bounding sphere of the mesh: sizes the per-ray box padding
+  float radius;
+};
+
+#ifdef __cplusplus
+static_assert(sizeof(BvhNode) == 64, "BvhNode");
+static_assert(sizeof(BvhTri) == 48, "BvhTri");
+static_assert(sizeof(TlasEntry) == 80, "TlasEntry");
+#endif

@@ -1,0 +1,446 @@
+// bvh_build.cpp — host-side construction of the acceleration structure described in bvh.h.
+//
+// The reference hands BLAS/TLAS construction to the Vulkan driver with ePreferFastTrace
+// (src/Core/AccelerationStructure.cpp:6,25); scenes are static, so the build is a load-time step
+// (src/Node/Scene.cpp:345 rebuilds only when dirty). Here: a binned-SAH BVH2 per unique mesh with a
+// hard depth cap (the traversal stack lives in LDS and is sized from it), every identity-transform
+// instance flattened into one world-space mesh, and a small top level over what remains.
+#include "bvh_build.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <tuple>
+
+namespace sthip {
+namespace {
+
+struct Box {
+  float lo[3], hi[3];
+  void reset() {
+    for (int a = 0; a < 3; a++) {
+      lo[a] = INFINITY;
+      hi[a] = -INFINITY;
+    }
+  }
+  void grow(const float* p) {
+    for (int a = 0; a < 3; a++) {
+      lo[a] = std::min(lo[a], p[a]);
+      hi[a] = std::max(hi[a], p[a]);
+    }
+  }
+  void grow(const Box& b) {
+    for (int a = 0; a < 3; a++) {
+      lo[a] = std::min(lo[a], b.lo[a]);
+      hi[a] = std::max(hi[a], b.hi[a]);
+    }
+  }
+  float half_area() const {
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct TmpNode {
+  Box box;
+  int32_t left, right;  // -1: leaf
+  uint32_t first, count;
+};
+
+// Binary binned-SAH build over `boxes`; leaves hold at most `leaf_max` primitives; depth <= depth_cap.
+struct Builder {
+  const std::vector<Box>& boxes;
+  std::vector<float> cen;
+  std::vector<uint32_t> order;
+  std::vector<TmpNode> nodes;
+  uint32_t leaf_max;
+  uint32_t depth_cap;
+  uint32_t max_depth = 0;
+
+  Builder(const std::vector<Box>& b, uint32_t leaf, uint32_t cap) : boxes(b), leaf_max(leaf), depth_cap(cap) {
+    const size_t n = boxes.size();
+    cen.resize(3 * n);
+    order.resize(n);
+    for (size_t i = 0; i < n; i++) {
+      order[i] = (uint32_t)i;
+      for (int a = 0; a < 3; a++) cen[3 * i + a] = 0.5f * (boxes[i].lo[a] + boxes[i].hi[a]);
+    }
+    nodes.reserve(2 * n / std::max(1u, leaf) + 16);
+    if (n) build(0, (uint32_t)n, 0);
+  }
+
+  // largest primitive count a subtree rooted at `depth` may hold
+  uint64_t capacity(uint32_t depth) const {
+    const uint32_t rem = depth_cap > depth ? depth_cap - depth : 0;
+    return (uint64_t)leaf_max << std::min(rem, 40u);
+  }
+
+  int32_t build(uint32_t lo, uint32_t hi, uint32_t depth) {
+    const int32_t idx = (int32_t)nodes.size();
+    nodes.push_back(TmpNode());
+    max_depth = std::max(max_depth, depth);
+    Box box, cbox;
+    box.reset();
+    cbox.reset();
+    for (uint32_t i = lo; i < hi; i++) {
+      box.grow(boxes[order[i]]);
+      cbox.grow(&cen[3 * (size_t)order[i]]);
+    }
+    nodes[idx].box = box;
+    nodes[idx].left = nodes[idx].right = -1;
+    nodes[idx].first = lo;
+    nodes[idx].count = hi - lo;
+    const uint32_t n = hi - lo;
+    if (n <= leaf_max) return idx;
+
+    const int NB = 32;
+    float best_cost = INFINITY;
+    int best_axis = -1, best_bin = -1;
+    for (int axis = 0; axis < 3; axis++) {
+      const float ext = cbox.hi[axis] - cbox.lo[axis];
+      if (!(ext > 0)) continue;
+      Box bb[NB];
+      uint32_t bc[NB];
+      for (int b = 0; b < NB; b++) {
+        bb[b].reset();
+        bc[b] = 0;
+      }
+      const float k = NB / ext;
+      for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t p = order[i];
+        int b = (int)((cen[3 * (size_t)p + axis] - cbox.lo[axis]) * k);
+        b = std::min(std::max(b, 0), NB - 1);
+        bb[b].grow(boxes[p]);
+        bc[b]++;
+      }
+      float ra[NB];
+      uint32_t rc[NB];
+      Box r;
+      r.reset();
+      uint32_t c = 0;
+      for (int b = NB - 1; b > 0; b--) {
+        r.grow(bb[b]);
+        c += bc[b];
+        ra[b] = r.half_area();
+        rc[b] = c;
+      }
+      Box l;
+      l.reset();
+      c = 0;
+      for (int b = 0; b < NB - 1; b++) {
+        l.grow(bb[b]);
+        c += bc[b];
+        if (c == 0 || rc[b + 1] == 0) continue;
+        const float cost = l.half_area() * (float)c + ra[b + 1] * (float)rc[b + 1];
+        if (cost < best_cost) {
+          best_cost = cost;
+          best_axis = axis;
+          best_bin = b;
+        }
+      }
+    }
+    uint32_t mid = lo;
+    if (best_axis >= 0) {
+      const float ext = cbox.hi[best_axis] - cbox.lo[best_axis];
+      const float k = NB / ext;
+      const float clo = cbox.lo[best_axis];
+      uint32_t* m = std::partition(order.data() + lo, order.data() + hi, [&](uint32_t p) {
+        int b = (int)((cen[3 * (size_t)p + best_axis] - clo) * k);
+        b = std::min(std::max(b, 0), NB - 1);
+        return b <= best_bin;
+      });
+      mid = (uint32_t)(m - order.data());
+    }
+    const uint64_t cap = capacity(depth + 1);
+    const bool sah_ok = mid > lo && mid < hi && (uint64_t)(mid - lo) <= cap && (uint64_t)(hi - mid) <= cap;
+    if (!sah_ok) {
+      // balanced split along the widest centroid axis (also the degenerate all-same-centroid case)
+      int axis = 0;
+      for (int a = 1; a < 3; a++)
+        if (cbox.hi[a] - cbox.lo[a] > cbox.hi[axis] - cbox.lo[axis]) axis = a;
+      mid = lo + n / 2;
+      std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi,
+                       [&](uint32_t a, uint32_t b) { return cen[3 * (size_t)a + axis] < cen[3 * (size_t)b + axis]; });
+    }
+    const int32_t l = build(lo, mid, depth + 1);
+    const int32_t r = build(mid, hi, depth + 1);
+    nodes[idx].left = l;
+    nodes[idx].right = r;
+    nodes[idx].count = 0;
+    return idx;
+  }
+};
+
+inline void set_child(BvhNode& n, int c, const Box* b, uint32_t ref) {
+  float* xy = c == 0 ? n.n0xy : n.n1xy;
+  if (b) {
+    xy[0] = b->lo[0];
+    xy[1] = b->hi[0];
+    xy[2] = b->lo[1];
+    xy[3] = b->hi[1];
+    n.nz[2 * c] = b->lo[2];
+    n.nz[2 * c + 1] = b->hi[2];
+  } else {  // empty: inverted box, never hit
+    xy[0] = xy[2] = INFINITY;
+    xy[1] = xy[3] = -INFINITY;
+    n.nz[2 * c] = INFINITY;
+    n.nz[2 * c + 1] = -INFINITY;
+  }
+  n.ref[c] = ref;
+}
+
+// Flattens a Builder tree into out.nodes (depth-first). `leaf_ref(first,count)` makes the leaf reference.
+// Returns the reference of the root (an inner-node index, or a leaf reference for a single-leaf tree).
+template <typename LeafRef>
+uint32_t flatten(const Builder& b, int32_t t, std::vector<BvhNode>& out, LeafRef leaf_ref) {
+  const TmpNode& tn = b.nodes[t];
+  if (tn.left < 0) return leaf_ref(tn.first, tn.count);
+  const uint32_t my = (uint32_t)out.size();
+  out.push_back(BvhNode());
+  memset(&out[my], 0, sizeof(BvhNode));
+  const uint32_t l = flatten(b, tn.left, out, leaf_ref);
+  const uint32_t r = flatten(b, tn.right, out, leaf_ref);
+  set_child(out[my], 0, &b.nodes[tn.left].box, l);
+  set_child(out[my], 1, &b.nodes[tn.right].box, r);
+  return my;
+}
+
+inline uint32_t wrap_leaf(std::vector<BvhNode>& nodes, const Box& box, uint32_t leaf) {
+  BvhNode n;
+  memset(&n, 0, sizeof(n));
+  set_child(n, 0, &box, leaf);
+  set_child(n, 1, nullptr, BVH_INVALID_REF);
+  nodes.push_back(n);
+  return (uint32_t)nodes.size() - 1;
+}
+
+inline bool is_identity(const sthip_TransformData& t) {
+  static const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  return memcmp(&t, I, sizeof(I)) == 0;
+}
+
+struct InstView {
+  uint32_t type, material_address, prim_count, stride, first_vertex, indices_byte_offset;
+};
+inline InstView view(const sthip_InstanceData& d) {
+  InstView v;
+  v.type = d.packed[0] & 0xF;
+  v.material_address = d.packed[0] >> 4;
+  v.prim_count = (d.packed[1] >> 12) & 0xFFFF;
+  v.stride = d.packed[1] >> 28;
+  v.first_vertex = d.packed[2];
+  v.indices_byte_offset = d.packed[3];
+  return v;
+}
+// scene.h:139-161
+inline void load_tri(const sthip_scene_desc& s, const InstView& in, uint32_t prim, uint32_t tri[3]) {
+  const uint8_t* ib = (const uint8_t*)s.gIndices;
+  const size_t off = (size_t)in.indices_byte_offset + (size_t)prim * 3 * in.stride;
+  if (in.stride == 2) {
+    uint16_t w[3];
+    memcpy(w, ib + off, 6);
+    tri[0] = w[0];
+    tri[1] = w[1];
+    tri[2] = w[2];
+  } else {
+    memcpy(tri, ib + off, 12);
+  }
+  for (int k = 0; k < 3; k++) tri[k] += in.first_vertex;
+}
+
+}  // namespace
+
+bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err) {
+  out = BuiltBvh();
+  const uint32_t BLAS_DEPTH_CAP = 24, TLAS_DEPTH_CAP = 18;
+  // ---- validate + classify ----
+  std::vector<uint32_t> merged, separate;
+  for (uint32_t i = 0; i < s.instance_count; i++) {
+    const InstView in = view(s.gInstances[i]);
+    if (in.type != STHIP_INSTANCE_TYPE_TRIANGLES) {
+      err = "only triangle instances are built (sphere/volume instances are SURVEY.md §8f N2/N4)";
+      return false;
+    }
+    if (in.stride != 2 && in.stride != 4) {
+      err = "index stride must be 2 or 4";
+      return false;
+    }
+    const size_t end = (size_t)in.indices_byte_offset + (size_t)in.prim_count * 3 * in.stride;
+    if (end > s.indices_bytes) {
+      err = "instance index range exceeds gIndices";
+      return false;
+    }
+    if ((size_t)in.material_address + sizeof(sthip_MaterialRecord) > s.material_bytes) {
+      err = "instance material_address exceeds gMaterialData";
+      return false;
+    }
+    for (uint32_t p = 0; p < in.prim_count; p++) {
+      uint32_t tri[3];
+      load_tri(s, in, p, tri);
+      for (int k = 0; k < 3; k++)
+        if (tri[k] >= s.vertex_count) {
+          err = "vertex index exceeds gVertices";
+          return false;
+        }
+    }
+    if (is_identity(s.gInstanceInverseTransforms[i]) && is_identity(s.gInstanceTransforms[i]))
+      merged.push_back(i);
+    else
+      separate.push_back(i);
+  }
+
+  auto add_blas = [&](const std::vector<std::pair<uint32_t, uint32_t>>& prims /* (instance, prim) */, bool with_instance_bits, Box& bounds, uint32_t& depth) -> uint32_t {
+    std::vector<Box> boxes(prims.size());
+    bounds.reset();
+    for (size_t k = 0; k < prims.size(); k++) {
+      const InstView in = view(s.gInstances[prims[k].first]);
+      uint32_t tri[3];
+      load_tri(s, in, prims[k].second, tri);
+      boxes[k].reset();
+      for (int v = 0; v < 3; v++) boxes[k].grow(s.gVertices[tri[v]].position);
+      bounds.grow(boxes[k]);
+    }
+    Builder b(boxes, BVH_MAX_LEAF_TRIS, BLAS_DEPTH_CAP);
+    depth = b.max_depth;
+    const uint32_t tri_base = (uint32_t)out.tris.size();
+    out.tris.resize(tri_base + prims.size());
+    for (size_t k = 0; k < prims.size(); k++) {
+      const auto& pr = prims[b.order[k]];
+      const InstView in = view(s.gInstances[pr.first]);
+      uint32_t tri[3];
+      load_tri(s, in, pr.second, tri);
+      BvhTri& t = out.tris[tri_base + k];
+      memcpy(t.v0, s.gVertices[tri[0]].position, 12);
+      memcpy(t.v1, s.gVertices[tri[1]].position, 12);
+      memcpy(t.v2, s.gVertices[tri[2]].position, 12);
+      t.id = (pr.second << 16) | (with_instance_bits ? pr.first : 0u);
+      t.pad1 = t.pad2 = 0;
+    }
+    const uint32_t root = flatten(b, 0, out.nodes, [&](uint32_t first, uint32_t count) { return BVH_LEAF_BIT | ((tri_base + first) << 2) | (count - 1); });
+    if (root & BVH_LEAF_BIT) {  // a mesh of <= 4 triangles: give it a one-child root so kernels always start at an inner node
+      depth = 1;
+      return wrap_leaf(out.nodes, bounds, root);
+    }
+    return root;
+  };
+
+  Box scene_box;
+  scene_box.reset();
+  uint32_t blas_depth = 0;
+  std::vector<Box> entry_boxes;
+
+  if (!merged.empty()) {
+    std::vector<std::pair<uint32_t, uint32_t>> prims;
+    for (uint32_t i : merged) {
+      const InstView in = view(s.gInstances[i]);
+      for (uint32_t p = 0; p < in.prim_count; p++) prims.emplace_back(i, p);
+    }
+    if (!prims.empty()) {
+      if (prims.size() >= (1u << 28)) {
+        err = "too many triangles";
+        return false;
+      }
+      Box bounds;
+      uint32_t depth = 0;
+      TlasEntry e;
+      memset(&e, 0, sizeof(e));
+      e.inv[0] = e.inv[5] = e.inv[10] = 1.0f;
+      e.root = add_blas(prims, true, bounds, depth);
+      e.id_bits = 0;
+      e.identity = 1;
+      for (int a = 0; a < 3; a++) e.center[a] = 0.5f * (bounds.lo[a] + bounds.hi[a]);
+      e.radius = 0.5f * sqrtf((bounds.hi[0] - bounds.lo[0]) * (bounds.hi[0] - bounds.lo[0]) + (bounds.hi[1] - bounds.lo[1]) * (bounds.hi[1] - bounds.lo[1]) +
+                              (bounds.hi[2] - bounds.lo[2]) * (bounds.hi[2] - bounds.lo[2]));
+      blas_depth = std::max(blas_depth, depth);
+      out.entries.push_back(e);
+      entry_boxes.push_back(bounds);
+      scene_box.grow(bounds);
+    }
+  }
+  struct MeshInfo {
+    uint32_t root;
+    Box bounds;
+  };
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, MeshInfo> meshes;
+  for (uint32_t i : separate) {
+    const InstView in = view(s.gInstances[i]);
+    if (in.prim_count == 0) continue;
+    auto key = std::make_tuple(in.first_vertex, in.indices_byte_offset, in.prim_count, in.stride);
+    auto it = meshes.find(key);
+    if (it == meshes.end()) {
+      std::vector<std::pair<uint32_t, uint32_t>> prims;
+      for (uint32_t p = 0; p < in.prim_count; p++) prims.emplace_back(i, p);
+      MeshInfo mi;
+      uint32_t depth = 0;
+      mi.root = add_blas(prims, false, mi.bounds, depth);
+      blas_depth = std::max(blas_depth, depth);
+      it = meshes.emplace(key, mi).first;
+    }
+    TlasEntry e;
+    memset(&e, 0, sizeof(e));
+    memcpy(e.inv, &s.gInstanceInverseTransforms[i], 48);
+    e.root = it->second.root;
+    e.id_bits = i;
+    e.identity = 0;
+    const Box& ob = it->second.bounds;
+    for (int a = 0; a < 3; a++) e.center[a] = 0.5f * (ob.lo[a] + ob.hi[a]);
+    e.radius = 0.5f * sqrtf((ob.hi[0] - ob.lo[0]) * (ob.hi[0] - ob.lo[0]) + (ob.hi[1] - ob.lo[1]) * (ob.hi[1] - ob.lo[1]) + (ob.hi[2] - ob.lo[2]) * (ob.hi[2] - ob.lo[2]));
+    // world box: the transformed vertices of the mesh, padded because the traversal ray reaches
+    // object space through Minv while this box is placed through M (M*Minv is only ~identity)
+    Box wb;
+    wb.reset();
+    const sthip_TransformData& M = s.gInstanceTransforms[i];
+    for (uint32_t p = 0; p < in.prim_count; p++) {
+      uint32_t tri[3];
+      load_tri(s, in, p, tri);
+      for (int v = 0; v < 3; v++) {
+        const float* q = s.gVertices[tri[v]].position;
+        float w[3];
+        for (int r = 0; r < 3; r++) w[r] = M.m[r][0] * q[0] + M.m[r][1] * q[1] + M.m[r][2] * q[2] + M.m[r][3];
+        wb.grow(w);
+      }
+    }
+    for (int a = 0; a < 3; a++) {
+      const float m = std::max(std::max(fabsf(wb.lo[a]), fabsf(wb.hi[a])), wb.hi[a] - wb.lo[a]);
+      wb.lo[a] -= 2e-5f * m;
+      wb.hi[a] += 2e-5f * m;
+    }
+    out.entries.push_back(e);
+    entry_boxes.push_back(wb);
+    scene_box.grow(wb);
+  }
+
+  // ---- top level ----
+  uint32_t tlas_depth = 0;
+  if (out.entries.empty()) {
+    out.root_ref = BVH_INVALID_REF;
+    out.top_is_world_blas = 1;
+  } else if (out.entries.size() == 1 && out.entries[0].identity) {
+    out.root_ref = out.entries[0].root;
+    out.top_is_world_blas = 1;
+  } else {
+    if (out.entries.size() > 0xFFFF) {
+      err = "too many top-level entries";
+      return false;
+    }
+    Builder b(entry_boxes, 1, TLAS_DEPTH_CAP);
+    tlas_depth = b.max_depth + 1;
+    out.root_ref = flatten(b, 0, out.nodes, [&](uint32_t first, uint32_t) { return BVH_LEAF_BIT | BVH_INST_BIT | b.order[first]; });
+    if (out.root_ref & BVH_LEAF_BIT) {
+      out.root_ref = wrap_leaf(out.nodes, entry_boxes[0], out.root_ref);
+      tlas_depth += 1;
+    }
+    out.top_is_world_blas = 0;
+  }
+  out.stack_depth = tlas_depth + blas_depth + 2;
+  if (scene_box.lo[0] <= scene_box.hi[0]) {
+    for (int a = 0; a < 3; a++) out.scene_center[a] = 0.5f * (scene_box.lo[a] + scene_box.hi[a]);
+    out.scene_radius = 0.5f * sqrtf((scene_box.hi[0] - scene_box.lo[0]) * (scene_box.hi[0] - scene_box.lo[0]) + (scene_box.hi[1] - scene_box.lo[1]) * (scene_box.hi[1] - scene_box.lo[1]) +
+                                    (scene_box.hi[2] - scene_box.lo[2]) * (scene_box.hi[2] - scene_box.lo[2]));
+  }
+  return true;
+}
+
+}  // namespace sthip

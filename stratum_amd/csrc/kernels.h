@@ -1,0 +1,517 @@
+// kernels.h — the wavefront path-tracing kernels that replace the reference's two compute passes
+// sample_visibility (bdpt.hlsl:149-300) and trace_shadows (bdpt.hlsl:302-326).
+//
+// The reference runs one megakernel thread per pixel whose loop alternates next_vertex() and trace()
+// (bdpt.hlsl:298-299). Here the same per-path state machine is cut at every trace() into stages that
+// run as separate launches over compacted queues, so that the divergent BVH traversal runs with full
+// waves and the shading stage with coherent memory access:
+//     generate -> [ trace_closest -> shade -> trace_shadow ] x bounces -> resolve
+// Results do not depend on scheduling: the RNG is counter based per (pixel, seed) (rng.hlsli:35-47),
+// every pixel owns its outputs, and per-pixel sums keep the reference's order (emission in path
+// order, then the deferred shadow-ray sum i = 1..gMaxDiffuseVertices, bdpt.hlsl:311-325).
+#pragma once
+
+#include "shading.h"
+#include "traverse.h"
+
+#define STHIP_BLOCK 256
+
+// queue / counter slots in FrameParams::counters
+enum { CNT_QUEUE0 = 0, CNT_SHADOW0 = 64, CNT_RAYS_CLOSEST = 128, CNT_RAYS_SHADOW = 129, CNT_NODES = 130, CNT_TRIS = 132, CNT_TOTAL = 136 };
+
+struct FrameParams {
+  DeviceScene scene;
+  DeviceBvh bvh;
+  sthip_BDPTPushConstants pc;
+  uint32_t sampling_flags;
+  uint32_t seed;
+  // views (device copies)
+  const sthip_ViewData* views;
+  const sthip_TransformData* view_xf;
+  const sthip_ViewData* prev_views;
+  const sthip_TransformData* prev_inv_view_xf;
+  // sharding: tile t is owned iff t % shard_count == shard_rank
+  uint32_t shard_rank, shard_count, tile_w, tile_h, tiles_x, tiles_y;
+  uint32_t path_count;  // owned tiles * tile_w * tile_h
+  // path state, indexed by path slot
+  float4* ray_o;       // xyz origin, w = bsdf_pdf
+  float4* ray_d;       // xyz direction, w = eta_scale
+  float4* hit;         // t, b1, b2, bits(instance_primitive_index)
+  float4* beta;        // xyz beta, w = bits(rng counter)
+  uint32_t* meta;      // path_length | diffuse_vertices << 8
+  float4* radiance;    // gRadiance[px].rgb of the seed in flight
+  float4* shadow_sum;  // the sum `c` of trace_shadows
+  float4* accum;       // running mean over seeds (temporal_accumulation.hlsl:118-131): rgb, n
+  // queues
+  uint32_t* queue[2];
+  float4* shadow_rays;  // 3 x float4 per entry: (origin, distance) (direction, bits(slot)) (contribution, 0)
+  unsigned long long* counters;  // CNT_* (64-bit each)
+  // outputs (device pointers; may be null)
+  float4* out_radiance;
+  float4* out_albedo;
+  sthip_VisibilityInfo* out_visibility;
+  sthip_DepthInfo* out_depth;
+  float2* out_prev_uv;
+  uint32_t write_aov;
+  uint32_t count_traversal;
+};
+
+DEV bool flag(const FrameParams& p, int bit) { return (p.sampling_flags >> bit) & 1u; }
+
+// path slot -> pixel. Slots enumerate the owned tiles, and inside a tile 8x8 pixel blocks, so that a
+// wave64 covers an 8x8 block of the image (the reference's eRemapThreads does the same with 8x4 groups
+// of 32 threads, bdpt_util.hlsli:76-83). Returns false for slots that fall outside the image.
+DEV bool slot_to_pixel(const FrameParams& p, uint32_t slot, uint32_t& px, uint32_t& py) {
+  const uint32_t per_tile = p.tile_w * p.tile_h;
+  const uint32_t local_tile = slot / per_tile;
+  const uint32_t r = slot - local_tile * per_tile;
+  const uint32_t tile = local_tile * p.shard_count + p.shard_rank;
+  const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+  const uint32_t blocks_x = p.tile_w >> 3;
+  const uint32_t b = r >> 6, lane = r & 63u;
+  const uint32_t by = b / blocks_x, bx = b - by * blocks_x;
+  px = tx * p.tile_w + (bx << 3) + (lane & 7u);
+  py = ty * p.tile_h + (by << 3) + (lane >> 3);
+  return px < p.pc.gOutputExtent[0] && py < p.pc.gOutputExtent[1] && tile < p.tiles_x * p.tiles_y;
+}
+
+// scene.h:132-137
+DEV int get_view_index(const FrameParams& p, uint32_t x, uint32_t y) {
+  for (uint32_t i = 0; i < p.pc.gViewCount; i++) {
+    const sthip_ViewData& v = p.views[i];
+    if ((int)x >= v.image_min[0] && (int)y >= v.image_min[1] && (int)x < v.image_max[0] && (int)y < v.image_max[1]) return (int)i;
+  }
+  return -1;
+}
+// transform.h:136-147
+DEV f3 back_project(const sthip_ProjectionData& pr, float cx, float cy) {
+  f3 r;
+  if (pr.vertical_fov < 0) {
+    r.x = (cx - pr.offset[0]) / pr.scale[0];
+    r.y = (cy - pr.offset[1]) / pr.scale[1];
+  } else {
+    r.x = pr.near_plane * (cx * sgnf(pr.near_plane) - pr.offset[0]) / pr.scale[0];
+    r.y = pr.near_plane * (cy * sgnf(pr.near_plane) - pr.offset[1]) / pr.scale[1];
+  }
+  r.z = pr.near_plane;
+  return r;
+}
+// transform.h:118-135
+DEV float4 project_point(const sthip_ProjectionData& pr, f3 v) {
+  float4 r;
+  if (pr.vertical_fov < 0) {
+    r.x = v.x * pr.scale[0] + pr.offset[0];
+    r.y = v.y * pr.scale[1] + pr.offset[1];
+    r.z = (v.z - pr.far_plane) / (pr.near_plane - pr.far_plane);
+    r.w = 1;
+  } else {
+    r.x = v.x * pr.scale[0] + v.z * pr.offset[0];
+    r.y = v.y * pr.scale[1] + v.z * pr.offset[1];
+    r.z = fabsf(pr.near_plane);
+    r.w = v.z * sgnf(pr.near_plane);
+  }
+  return r;
+}
+// bdpt.hlsl:164-171: pixel centre -> world direction
+DEV f3 primary_dir(const sthip_ViewData& view, const Xf& t, float fx, float fy, f3* local_out) {
+  const float ex = (float)(view.image_max[0] - view.image_min[0]), ey = (float)(view.image_max[1] - view.image_min[1]);
+  const float u = (fx + 0.5f - (float)view.image_min[0]) / ex;
+  const float v = (fy + 0.5f - (float)view.image_min[1]) / ey;
+  const float cx = 2 * u - 1;
+  const float cy = -(2 * v - 1);
+  const f3 local_dir = normalize3(back_project(view.projection, cx, cy));
+  if (local_out) *local_out = local_dir;
+  return normalize3(xf_vector(t, local_dir));
+}
+
+// ---------------------------------------------------------------------------------------------
+// generate: PathIntegrator ctor (path.hlsli:285-298) + the prologue of sample_visibility
+// (bdpt.hlsl:151-220): one primary ray per owned pixel
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
+  for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.path_count; slot += gridDim.x * blockDim.x) {
+    uint32_t px, py;
+    const bool inside = slot_to_pixel(p, slot, px, py);
+    const int view_index = inside ? get_view_index(p, px, py) : -1;
+    p.radiance[slot] = make_float4(0, 0, 0, 0);
+    p.shadow_sum[slot] = make_float4(0, 0, 0, 0);
+    if (view_index < 0 || p.pc.gMaxPathVertices < 2) {
+      // not traced: a ray that cannot hit anything and a dead path
+      p.ray_o[slot] = make_float4(0, 0, 0, 1);
+      p.ray_d[slot] = make_float4(0, 0, 1, 1);
+      p.beta[slot] = make_float4(0, 0, 0, __uint_as_float(0u));
+      p.meta[slot] = 0xFFFFFFFFu;  // marks "outside every view": resolve leaves the pixel untouched
+      if (view_index >= 0) p.meta[slot] = 0xFFFFFFFEu;  // inside a view but gMaxPathVertices < 2: radiance stays 0
+      continue;
+    }
+    const sthip_ViewData& view = p.views[view_index];
+    const Xf t = load_xf(p.view_xf, (uint32_t)view_index);
+    const f3 dir = primary_dir(view, t, (float)px, (float)py, nullptr);
+    p.ray_o[slot] = make_float4(t.r0.w, t.r1.w, t.r2.w, 1.0f);
+    p.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
+    p.beta[slot] = make_float4(1, 1, 1, __uint_as_float(0u));
+    p.meta[slot] = 1u;  // path_length = 1, diffuse_vertices = 0
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// trace_closest: trace_ray (intersection.hlsli:65-191) for every queued path
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, uint32_t depth) {
+  extern __shared__ uint32_t lds_stack[];
+  const uint32_t n = depth == 0 ? p.path_count : (uint32_t)p.counters[CNT_QUEUE0 + depth];
+  const uint32_t* queue = p.queue[depth & 1u];
+  TraverseCounters cnt;
+  cnt.nodes = cnt.tris = 0;
+  uint32_t traced = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t slot = depth == 0 ? i : queue[i];
+    if (depth == 0 && p.meta[slot] >= 0xFFFFFFFEu) {
+      p.hit[slot] = make_float4(__builtin_inff(), 0, 0, __uint_as_float(0xFFFFFFFFu));
+      continue;
+    }
+    const float4 ro = p.ray_o[slot], rd = p.ray_d[slot];
+    RayHit h;
+    traverse<false, COUNT>(p.bvh, xyz(ro), xyz(rd), 0.0f, __builtin_inff(), lds_stack + threadIdx.x, blockDim.x, h, cnt);
+    p.hit[slot] = make_float4(h.t, h.b1, h.b2, __uint_as_float(h.ip));
+    traced++;
+  }
+  atomicAdd(&p.counters[CNT_RAYS_CLOSEST], (unsigned long long)traced);
+  if (COUNT) {
+    atomicAdd(&p.counters[CNT_NODES], (unsigned long long)cnt.nodes);
+    atomicAdd(&p.counters[CNT_TRIS], (unsigned long long)cnt.tris);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// trace_shadow: trace_visibility_ray without media (intersection.hlsli:192-239) + the per-pixel sum
+// of trace_shadows (bdpt.hlsl:311-325)
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uint32_t depth) {
+  extern __shared__ uint32_t lds_stack[];
+  const uint32_t n = (uint32_t)p.counters[CNT_SHADOW0 + depth];
+  TraverseCounters cnt;
+  cnt.nodes = cnt.tris = 0;
+  uint32_t traced = 0;
+  float4* target = flag(p, STHIP_eDeferShadowRays) ? p.shadow_sum : p.radiance;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 s0 = p.shadow_rays[3 * (size_t)i], s1 = p.shadow_rays[3 * (size_t)i + 1], s2 = p.shadow_rays[3 * (size_t)i + 2];
+    const uint32_t slot = __float_as_uint(s1.w);
+    bool occluded = false;
+    if (s0.w > 1e-6f) {  // while (t_max > 1e-6f), intersection.hlsli:195
+      RayHit h;
+      occluded = traverse<true, COUNT>(p.bvh, xyz(s0), xyz(s1), 0.0f, s0.w, lds_stack + threadIdx.x, blockDim.x, h, cnt);
+      traced++;
+    }
+    if (!occluded) {
+      float4 c = target[slot];
+      c.x = c.x + s2.x;
+      c.y = c.y + s2.y;
+      c.z = c.z + s2.z;
+      target[slot] = c;
+    }
+  }
+  atomicAdd(&p.counters[CNT_RAYS_SHADOW], (unsigned long long)traced);
+  if (COUNT) {
+    atomicAdd(&p.counters[CNT_NODES], (unsigned long long)cnt.nodes);
+    atomicAdd(&p.counters[CNT_TRIS], (unsigned long long)cnt.tris);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shade: the tail of trace() (path.hlsli:1012-1043), the first-hit block of sample_visibility
+// (bdpt.hlsl:222-296) at depth 0, then next_vertex() (path.hlsli:955-998,1048-1075) up to the point
+// where the next ray is known
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(STHIP_BLOCK) k_shade(FrameParams p, uint32_t depth) {
+  const uint32_t n = depth == 0 ? p.path_count : (uint32_t)p.counters[CNT_QUEUE0 + depth];
+  const uint32_t* queue_in = p.queue[depth & 1u];
+  uint32_t* queue_out = p.queue[(depth + 1) & 1u];
+  const bool use_nee = flag(p, STHIP_eNEE);
+  const bool use_mis = flag(p, STHIP_eMIS);
+  const bool sample_bsdfs = flag(p, STHIP_eSampleBSDFs);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t slot = depth == 0 ? i : queue_in[i];
+    uint32_t meta = p.meta[slot];
+    if (meta >= 0xFFFFFFFEu) continue;
+    uint32_t px, py;
+    slot_to_pixel(p, slot, px, py);
+    const float4 ro = p.ray_o[slot], rd = p.ray_d[slot], hh = p.hit[slot], bb = p.beta[slot];
+    const f3 origin = xyz(ro), direction = xyz(rd);
+    float bsdf_pdf = ro.w;
+    float eta_scale = rd.w;
+    f3 beta = xyz(bb);
+    Rng rng;
+    rng.x = px;
+    rng.y = py;
+    rng.seed = p.seed;
+    rng.counter = __float_as_uint(bb.w);
+    uint32_t path_length = meta & 0xFFu, diffuse_vertices = (meta >> 8) & 0xFFu;
+    const uint32_t ip = __float_as_uint(hh.w);
+    f3 radiance = depth == 0 ? F3s(0.0f) : xyz(p.radiance[slot]);
+    const size_t pixel = (size_t)py * p.pc.gOutputExtent[0] + px;
+    bool alive = false;
+    f3 new_origin = origin, new_direction = direction;
+
+    do {
+      // trace(), path.hlsli:1009-1010: the ray was traced (and counted) even if beta died meanwhile
+      if (all_le0(beta)) break;
+      path_length++;
+      if (ip == 0xFFFFFFFFu) {
+        // miss: bdpt.hlsl:231-242 at depth 0, path.hlsli:1049-1058 later (no environment)
+        if (depth == 0 && p.write_aov) {
+          const int view_index = get_view_index(p, px, py);
+          const sthip_ViewData& view = p.views[view_index];
+          const float ex = (float)(view.image_max[0] - view.image_min[0]), ey = (float)(view.image_max[1] - view.image_min[1]);
+          if (p.out_albedo) p.out_albedo[pixel] = make_float4(1, 1, 1, 1);
+          if (p.out_visibility) {
+            sthip_VisibilityInfo vis;
+            vis.instance_primitive_index = 0xFFFFFFFFu;
+            vis.packed_normal = 0;
+            p.out_visibility[pixel] = vis;
+          }
+          if (p.out_depth) {
+            sthip_DepthInfo dpt;
+            dpt.z = __builtin_inff();
+            dpt.prev_z = __builtin_inff();
+            dpt.dz_dxy[0] = dpt.dz_dxy[1] = 0;
+            p.out_depth[pixel] = dpt;
+          }
+          if (p.out_prev_uv) p.out_prev_uv[pixel] = make_float2(((float)px + 0.5f - (float)view.image_min[0]) / ex, ((float)py + 0.5f - (float)view.image_min[1]) / ey);
+        }
+        break;
+      }
+      const uint32_t inst_index = ip & 0xFFFFu, prim = ip >> 16;
+      const Inst in = load_inst(p.scene, inst_index);
+      ShadingData sd;
+      make_triangle_shading_data(p.scene, sd, inst_index, in, prim, hh.y, hh.z);
+      const float shape_pdf = 1 / (sd.shape_area * (float)in.prim_count());  // intersection.hlsli:172
+      const f3 gn = sd.geometry_normal();
+      // path.hlsli:1023-1040
+      const float dist2 = len_sqr(sd.position - origin);
+      float G = 1 / dist2;
+      const float ngdotin = -dot3(direction, gn);
+      G *= fabsf(ngdotin);
+      if (depth == 0) {  // bdpt.hlsl:213-217
+        bsdf_pdf = 1;
+        G = 1;
+      }
+      DisneyMaterial m;
+      m.load(p.scene, in.material_address());
+      const f3 Le = m.Le();
+
+      // eval_emission, path.hlsli:847-894 (emissive surface, uniform light choice, no BDPT)
+      auto eval_emission = [&]() {
+        if (all_le0(Le)) return;
+        const f3 contrib = beta * Le;
+        const float cos_theta_light = -dot3(gn, direction);
+        if (cos_theta_light < 0) return;
+        float light_pdfA = shape_pdf;  // point_on_light_pdf, light.hlsli:163-171
+        light_pdfA /= (float)p.pc.gLightCount;
+        float weight = 1;
+        if (path_length > 2) {
+          if (use_nee) weight = mis2(use_mis, bsdf_pdf * G, light_pdfA);
+        }
+        radiance = radiance + contrib * weight;
+      };
+
+      if (depth == 0) {
+        eval_emission();  // bdpt.hlsl:253
+        if (p.write_aov) {
+          const int view_index = get_view_index(p, px, py);
+          const sthip_ViewData& view = p.views[view_index];
+          const Xf t = load_xf(p.view_xf, (uint32_t)view_index);
+          if (p.out_albedo) {
+            const f3 a = m.albedo();
+            p.out_albedo[pixel] = make_float4(a.x, a.y, a.z, 1);
+          }
+          if (p.out_visibility) {
+            sthip_VisibilityInfo vis;
+            vis.instance_primitive_index = ip;
+            vis.packed_normal = sd.packed_shading_normal;
+            p.out_visibility[pixel] = vis;
+          }
+          if (p.out_depth || p.out_prev_uv) {
+            const Xf prev_inv_view = load_xf(p.prev_inv_view_xf, (uint32_t)view_index);
+            const Xf motion = load_xf(p.scene.motion_xf, inst_index);
+            const f3 prev_cam_pos = xf_point(xf_mul(prev_inv_view, motion), sd.position);  // bdpt.hlsl:265
+            if (p.out_depth) {
+              sthip_DepthInfo dpt;
+              dpt.z = length3(sd.position - origin);
+              dpt.prev_z = length3(prev_cam_pos);
+              const f3 dir_x = primary_dir(view, t, (float)(px + 1), (float)py, nullptr);
+              dpt.dz_dxy[0] = ray_plane(origin - sd.position, dir_x, gn) - dpt.z;
+              const f3 dir_y = primary_dir(view, t, (float)px, (float)(py + 1), nullptr);
+              dpt.dz_dxy[1] = ray_plane(origin - sd.position, dir_y, gn) - dpt.z;
+              p.out_depth[pixel] = dpt;
+            }
+            if (p.out_prev_uv) {
+              float4 pc4 = project_point(p.prev_views[view_index].projection, prev_cam_pos);
+              pc4.y = -pc4.y;
+              pc4.x = pc4.x / pc4.w;
+              pc4.y = pc4.y / pc4.w;
+              p.out_prev_uv[pixel] = make_float2(pc4.x * .5f + .5f, pc4.y * .5f + .5f);
+            }
+          }
+        }
+      }
+      // loop condition of bdpt.hlsl:298
+      if (!(any_gt0(beta) && !any_nan(beta))) break;
+
+      // ---- next_vertex(), path.hlsli:1048-1075 + :955-998 ----
+      const Frame3 frame = make_frame(sd);
+      const f3 local_dir_in = normalize3(frame.to_local(-direction));
+      if (path_length > 2) eval_emission();
+      if (!m.can_eval() || path_length >= p.pc.gMaxPathVertices) break;
+      if (!m.is_specular()) {
+        diffuse_vertices++;
+        if (diffuse_vertices > p.pc.gMaxDiffuseVertices) break;
+        if (path_length >= p.pc.gMinPathVertices) {
+          // russian_roulette, path.hlsli:829-845, non-coherent form
+          const float rr = luminance3(beta) / eta_scale * 0.95f;
+          if (!(rr >= 1)) {
+            if (rng.next_float() > rr) break;
+            beta = beta / rr;
+          }
+        }
+        if (use_nee) {
+          // connect_light, path.hlsli:311-366; sample_Le :141-164; sample_point_on_light, light.hlsli:37-152
+          const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float(), r3 = rng.next_float();
+          const int li = (int)(r3 * ((float)p.pc.gLightCount * .9999f));
+          float ls_pdf = 1 / (float)p.pc.gLightCount;
+          const uint32_t light_instance_index = p.scene.lights[li];
+          const Inst lin = load_inst(p.scene, light_instance_index);
+          const uint32_t lpc = lin.prim_count();
+          const uint32_t lprim = (uint32_t)fminf(r2 * (float)lpc, (float)(lpc - 1));
+          const float a = sqrtf(r0);
+          ShadingData lsd;
+          make_triangle_shading_data(p.scene, lsd, light_instance_index, lin, lprim, 1 - a, a * r1);
+          const f3 ls_normal = lsd.geometry_normal();
+          f3 to_light = lsd.position - sd.position;
+          const float ls_dist = length3(to_light);
+          to_light = to_light / ls_dist;
+          ls_pdf /= lsd.shape_area * (float)lpc;
+          f3 lLe = F3s(0.0f);
+          if (ls_pdf > 0) {
+            DisneyMaterial lm;
+            lm.load(p.scene, lin.material_address());
+            lLe = lm.Le();
+          }
+          const float pdfA = ls_pdf;
+          float cG = fabsf(dot3(to_light, ls_normal)) / pow2f(ls_dist);
+          // DirectLightSample::setup, path.hlsli:204-221
+          const f3 local_to_light = normalize3(frame.to_local(to_light));
+          const float ngdotout = dot3(gn, to_light);
+          const f3 ray_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
+          const float ray_distance = ls_dist * 0.999f;
+          do {
+            if (all_le0(lLe) && pdfA < 1e-6f) break;
+            MaterialEvalRecord ev;
+            m.eval(ev, local_dir_in, local_to_light, false);
+            const float pdfA_fwd = ev.pdf_fwd * cG;
+            if (pdfA_fwd < 1e-6f) break;
+            cG *= shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout);
+            const f3 contrib = lLe * ev.f * cG / pdfA;
+            if (all_le0(contrib)) break;
+            float weight = 1;
+            if (sample_bsdfs) weight = mis2(use_mis, pdfA, pdfA_fwd);
+            const f3 c = beta * contrib * weight;
+            // a zero/negative contribution never adds light (bdpt.hlsl:313) and needs no ray
+            if (all_le0(c)) break;
+            const uint32_t k = (uint32_t)atomicAdd(&p.counters[CNT_SHADOW0 + depth], 1ull);
+            p.shadow_rays[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
+            p.shadow_rays[3 * (size_t)k + 1] = make_float4(to_light.x, to_light.y, to_light.z, __uint_as_float(slot));
+            p.shadow_rays[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+          } while (0);
+        }
+      }
+      if (!sample_bsdfs) break;
+      // sample_direction, path.hlsli:898-952
+      const float s0 = rng.next_float(), s1 = rng.next_float(), s2 = rng.next_float();
+      MaterialSampleRecord ms;
+      m.sample(ms, F3(s0, s1, s2), local_dir_in, beta, false);
+      if (ms.pdf_fwd < 1e-6f) break;
+      if (ms.eta != 0) eta_scale /= pow2f(ms.eta);
+      bsdf_pdf = ms.pdf_fwd;
+      const float ndotout = ms.dir_out.z;
+      const f3 dir_out = normalize3(frame.to_world(ms.dir_out));
+      const float ngdotout = dot3(gn, dir_out);
+      new_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
+      beta = beta * shading_normal_correction(local_dir_in.z, ndotout, ngdotin, ngdotout);
+      if (all_le0(beta)) break;
+      new_direction = dir_out;
+      alive = true;
+    } while (0);
+
+    p.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    if (alive) {
+      p.ray_o[slot] = make_float4(new_origin.x, new_origin.y, new_origin.z, bsdf_pdf);
+      p.ray_d[slot] = make_float4(new_direction.x, new_direction.y, new_direction.z, eta_scale);
+      p.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(rng.counter));
+      p.meta[slot] = path_length | (diffuse_vertices << 8);
+      const uint32_t k = (uint32_t)atomicAdd(&p.counters[CNT_QUEUE0 + depth + 1], 1ull);
+      queue_out[k] = slot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// resolve: gRadiance += c (bdpt.hlsl:325), then the running mean that defines N samples per pixel
+// (temporal_accumulation.hlsl:102-131), and on the last seed the scatter to the output image
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t first_seed, uint32_t last_seed) {
+  for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.path_count; slot += gridDim.x * blockDim.x) {
+    const uint32_t meta = p.meta[slot];
+    uint32_t px, py;
+    const bool inside = slot_to_pixel(p, slot, px, py);
+    if (!inside || meta == 0xFFFFFFFFu) continue;
+    const float4 r = p.radiance[slot], c = p.shadow_sum[slot];
+    float4 cur = make_float4(r.x + c.x, r.y + c.y, r.z + c.z, 1.0f);
+    if (isinf(cur.x) || isinf(cur.y) || isinf(cur.z) || cur.x != cur.x || cur.y != cur.y || cur.z != cur.z) cur = make_float4(0, 0, 0, 0);
+    float4 acc = first_seed ? make_float4(0, 0, 0, 0) : p.accum[slot];
+    if (acc.w > 0) {
+      const float nn = acc.w + cur.w;
+      const float alpha = fminf(fmaxf(cur.w / nn, 0.0f), 1.0f);
+      acc.x = lerp1(acc.x, cur.x, alpha);
+      acc.y = lerp1(acc.y, cur.y, alpha);
+      acc.z = lerp1(acc.z, cur.z, alpha);
+      acc.w = nn;
+    } else {
+      acc = cur;
+    }
+    p.accum[slot] = acc;
+    if (last_seed && p.out_radiance) p.out_radiance[(size_t)py * p.pc.gOutputExtent[0] + px] = acc;
+  }
+}
+
+// gRayCount[0] = every trace_ray call, [1] = path (closest-hit) rays; intersection.hlsli:66, path.hlsli:1006
+__global__ void k_write_ray_count(const unsigned long long* counters, unsigned long long* out) {
+  out[0] = counters[CNT_RAYS_CLOSEST] + counters[CNT_RAYS_SHADOW];
+  out[1] = counters[CNT_RAYS_CLOSEST];
+}
+
+// plain ray batches: the traversal contract on its own (sthip_trace_rays)
+template <bool ANY_HIT, bool COUNT>
+__global__ void __launch_bounds__(STHIP_BLOCK) k_trace_batch(DeviceBvh bvh, const sthip_ray* rays, uint32_t n, sthip_hit* hits, unsigned long long* counters) {
+  extern __shared__ uint32_t lds_stack[];
+  TraverseCounters cnt;
+  cnt.nodes = cnt.tris = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4* r = reinterpret_cast<const float4*>(rays + i);
+    const float4 a = r[0], b = r[1];
+    RayHit h;
+    traverse<ANY_HIT, COUNT>(bvh, xyz(a), xyz(b), a.w, b.w, lds_stack + threadIdx.x, blockDim.x, h, cnt);
+    sthip_hit out;
+    out.t = h.t;
+    out.b1 = h.b1;
+    out.b2 = h.b2;
+    out.instance_primitive_index = h.ip;
+    hits[i] = out;
+  }
+  if (COUNT && counters) {
+    atomicAdd(&counters[CNT_NODES], (unsigned long long)cnt.nodes);
+    atomicAdd(&counters[CNT_TRIS], (unsigned long long)cnt.tris);
+  }
+}
