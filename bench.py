@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — Mray/s of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]): the procedural ~1M-triangle atrium, 1920x1080, one sample per
+pixel per GPU per step, default reference flags (NEE + MIS + BSDF sampling + deferred shadow rays,
+4/8 path vertices, 2 diffuse vertices). A step = one pass of the hot path (generate, trace, shade,
+shadow, resolve) over that batch; scene, BVH and all buffers are resident in HBM before the timed
+region. With N > 1 GPUs the frame is cut into 64x32 pixel tiles dealt round-robin to the ranks; a step
+renders N seeds of the frame (each rank: its tiles x N seeds = one frame's worth of paths, so per-GPU
+work is fixed: weak scaling) and ends with the RCCL sum-reduce of the RGBA32F framebuffer to rank 0.
+
+value = rays of all ranks / max-over-ranks wall time; a ray is one trace_ray invocation, shadow rays
+included (gRayCount[0], src/Shaders/common/intersection.hlsli:66).
+
+The JSON line also carries
+  roofline      for the dominant kernel (k_trace_closest): algorithmic bytes per launch
+                (48 B ray+hit, + node bytes x nodes visited, + 48 B x triangles tested) over the
+                kernel's mean launch duration, measured here with HIP events on the launch stream;
+  cpu_baseline  the CPU oracle (a port of the reference shaders; the reference has no CPU path) timed on
+                the host cores on a bounded sample of the same workload, plus the rel-L2 between the GPU
+                and the oracle on that sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="atrium")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from stratum_amd import camera, scenes
+    from stratum_amd.bdpt import BDPT
+
+    W, H = args.width, args.height
+    sc, cam = scenes.SCENES[args.scene]()
+    frame = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+    r = BDPT(device=local_rank)
+    r.update(sc)
+    r.set_shard(rank, world, 64, 32)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    radiance = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    dev_out = {"radiance": radiance.data_ptr()}
+    seeds_per_step = world  # weak scaling: every rank renders one frame's worth of paths per step
+
+    def step(i):
+        r.render(frame, seed_begin=i * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
+        if dist is not None:
+            dist.reduce(radiance, dst=0, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    rays_local = 0
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    # rays of the timed region: re-run the same steps with the counters read back (untimed)
+    for i in range(args.steps):
+        r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
+        rays_local += r.stats()["rays_total"]
+    t = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt_all, rays_all = float(tmax[0]), float(t[1])
+    else:
+        dt_all, rays_all = float(t[0]), float(t[1])
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (closest-hit traversal), this rank ----
+        r.set_option("time_kernels", 1)
+        ms_closest, ms_total, launches = 0.0, 0.0, 0
+        ms_shadow, ms_shade = 0.0, 0.0
+        for i in range(args.steps):
+            r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
+            s = r.stats()
+            ms_closest += s["ms_trace_closest"]
+            ms_shadow += s["ms_trace_shadow"]
+            ms_shade += s["ms_shade"]
+            ms_total += s["ms_total"]
+            launches += s["launches_trace_closest"]
+        r.set_option("time_kernels", 0)
+        r.set_option("count_traversal", 1)
+        nodes = tris = rays_closest = rays_shadow = nodes_sh = tris_sh = 0
+        for i in range(args.steps):
+            r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
+            s = r.stats()
+            nodes += s["nodes_visited"]
+            tris += s["tris_tested"]
+            nodes_sh += s["nodes_visited_shadow"]
+            tris_sh += s["tris_tested_shadow"]
+            rays_closest += s["rays_path"]
+            rays_shadow += s["rays_shadow"]
+        r.set_option("count_traversal", 0)
+        node_bytes, tri_bytes = s["bvh_node_bytes"], s["bvh_tri_bytes"]
+        alg_bytes = 48.0 * rays_closest + float(node_bytes) * nodes + float(tri_bytes) * tris
+        achieved = alg_bytes / (ms_closest * 1e-3) / 1e9 if ms_closest > 0 else 0.0
+        roofline = {
+            "bound": "hbm",
+            "kernel": "k_trace_closest",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "bytes_per_launch": round(alg_bytes / max(launches, 1), 1),
+            "launch_ms": round(ms_closest / max(launches, 1), 4),
+            "nodes_per_ray": round(nodes / max(rays_closest, 1), 2),
+            "tris_per_ray": round(tris / max(rays_closest, 1), 2),
+            "bytes_per_ray": round(alg_bytes / max(rays_closest, 1), 1),
+            "kernel_ms_per_step": {
+                "trace_closest": round(ms_closest / args.steps, 3),
+                "trace_shadow": round(ms_shadow / args.steps, 3),
+                "shade": round(ms_shade / args.steps, 3),
+                "all": round(ms_total / args.steps, 3),
+            },
+            "shadow_nodes_per_ray": round(nodes_sh / max(rays_shadow, 1), 2),
+            "shadow_tris_per_ray": round(tris_sh / max(rays_shadow, 1), 2),
+        }
+
+        # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle_py
+
+            sw, sh = W // 4, H // 4  # same scene, camera and flags; 1/16 of the pixels, 1 sample
+            sframe = camera.Frame(sw, sh, cam["fovy"], cam["eye"], cam["target"])
+            r.set_shard(0, 1, 64, 32)
+            got = r.render(sframe, 0, 1, aovs=False)
+            o = oracle_py.OracleScene(sc)
+            threads = os.cpu_count() or 1
+            pc = r.push_constants(sframe)
+            o.render(sframe, pc, r.mSamplingFlags, 0, 1, threads=threads, aovs=False)  # warm-up
+            t1 = time.perf_counter()
+            ref = o.render(sframe, pc, r.mSamplingFlags, 0, 1, threads=threads, aovs=False)
+            cdt = time.perf_counter() - t1
+            a = got["radiance"][..., :3].astype(np.float64)
+            b = ref["radiance"][..., :3].astype(np.float64)
+            rel = float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b**2).sum()), 1e-300))
+            cpu = {
+                "value": round(float(ref["ray_count"][0]) / cdt / 1e6, 3),
+                "unit": "Mray/s",
+                "cores": threads,
+                "kind": "port",
+                "sample": "%s %dx%d x 1 sample, default flags (%d rays, %.2f s)" % (args.scene, sw, sh, int(ref["ray_count"][0]), cdt),
+                "rel_l2_gpu_vs_oracle": rel,
+            }
+        result = {
+            "metric": "Mray/s at 1920x1080x1spp (1M-tri scene)",
+            "value": round(rays_all / dt_all / 1e6, 2),
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt_all / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "procedural %s, %d triangles, %dx%d, %d sample(s)/pixel/step, default BDPT flags, pixel-tile shard 64x32 over %d GPU(s)"
+                % (args.scene, sc.triangle_count, W, H, seeds_per_step, world),
+                "rays_per_step": int(rays_all / args.steps),
+                "parallelism": "tile-shard x%d + RCCL reduce" % world if world > 1 else "single GPU",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if result is not None:
+        print(json.dumps(result))
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

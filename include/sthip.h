@@ -138,8 +138,10 @@ typedef struct sthip_stats {
   uint64_t rays_total;     /* gRayCount[0] semantics, last render */
   uint64_t rays_path;      /* gRayCount[1] semantics */
   uint64_t rays_shadow;
-  uint64_t nodes_visited;  /* only when collected (sthip_set_option "count_traversal") */
+  uint64_t nodes_visited;  /* closest-hit rays; only when collected (sthip_set_option "count_traversal") */
   uint64_t tris_tested;
+  uint64_t nodes_visited_shadow; /* any-hit (shadow) rays */
+  uint64_t tris_tested_shadow;
   float ms_trace_closest;  /* hipEvent time spent in the closest-hit traversal kernels of the last render */
   float ms_trace_shadow;
   float ms_shade;

@@ -85,6 +85,16 @@ struct sthip_ctx {
     }                                                                                                 \
   } while (0)
 
+static void fill_counter_stats(sthip_ctx* ctx, const unsigned long long* c) {
+  ctx->stats.rays_total = c[CNT_RAYS_CLOSEST] + c[CNT_RAYS_SHADOW];
+  ctx->stats.rays_path = c[CNT_RAYS_CLOSEST];
+  ctx->stats.rays_shadow = c[CNT_RAYS_SHADOW];
+  ctx->stats.nodes_visited = c[CNT_NODES];
+  ctx->stats.tris_tested = c[CNT_TRIS];
+  ctx->stats.nodes_visited_shadow = c[CNT_NODES + 1];
+  ctx->stats.tris_tested_shadow = c[CNT_TRIS + 1];
+}
+
 static int fail(sthip_ctx* ctx, int code, const std::string& msg) {
   ctx->error = msg;
   return code;
@@ -203,11 +213,7 @@ int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
-    ctx->stats.rays_total = c[CNT_RAYS_CLOSEST] + c[CNT_RAYS_SHADOW];
-    ctx->stats.rays_path = c[CNT_RAYS_CLOSEST];
-    ctx->stats.rays_shadow = c[CNT_RAYS_SHADOW];
-    ctx->stats.nodes_visited = c[CNT_NODES];
-    ctx->stats.tris_tested = c[CNT_TRIS];
+    fill_counter_stats(ctx, c);
     ctx->stats_pending = false;
   }
   *out = ctx->stats;
@@ -339,6 +345,8 @@ int sthip_trace_rays(sthip_ctx* ctx, const sthip_ray* rays, uint32_t ray_count, 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stats.nodes_visited = c[CNT_NODES];
     ctx->stats.tris_tested = c[CNT_TRIS];
+    ctx->stats.nodes_visited_shadow = c[CNT_NODES + 1];
+    ctx->stats.tris_tested_shadow = c[CNT_TRIS + 1];
     rb.release();
     hb.release();
   }
@@ -550,11 +558,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       out->gRayCount[0] = c[CNT_RAYS_CLOSEST] + c[CNT_RAYS_SHADOW];
       out->gRayCount[1] = c[CNT_RAYS_CLOSEST];
     }
-    ctx->stats.rays_total = c[CNT_RAYS_CLOSEST] + c[CNT_RAYS_SHADOW];
-    ctx->stats.rays_path = c[CNT_RAYS_CLOSEST];
-    ctx->stats.rays_shadow = c[CNT_RAYS_SHADOW];
-    ctx->stats.nodes_visited = c[CNT_NODES];
-    ctx->stats.tris_tested = c[CNT_TRIS];
+    fill_counter_stats(ctx, c);
     ctx->stats_pending = false;
   } else {
     if (out->gRayCount) hipLaunchKernelGGL(k_write_ray_count, dim3(1), dim3(1), 0, st, ctx->counters.p, reinterpret_cast<unsigned long long*>(out->gRayCount));

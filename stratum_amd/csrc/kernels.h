@@ -215,8 +215,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
   }
   atomicAdd(&p.counters[CNT_RAYS_SHADOW], (unsigned long long)traced);
   if (COUNT) {
-    atomicAdd(&p.counters[CNT_NODES], (unsigned long long)cnt.nodes);
-    atomicAdd(&p.counters[CNT_TRIS], (unsigned long long)cnt.tris);
+    atomicAdd(&p.counters[CNT_NODES + 1], (unsigned long long)cnt.nodes);
+    atomicAdd(&p.counters[CNT_TRIS + 1], (unsigned long long)cnt.tris);
   }
 }
 
@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_batch(DeviceBvh bvh, cons
     hits[i] = out;
   }
   if (COUNT && counters) {
-    atomicAdd(&counters[CNT_NODES], (unsigned long long)cnt.nodes);
-    atomicAdd(&counters[CNT_TRIS], (unsigned long long)cnt.tris);
+    atomicAdd(&counters[CNT_NODES + (ANY_HIT ? 1 : 0)], (unsigned long long)cnt.nodes);
+    atomicAdd(&counters[CNT_TRIS + (ANY_HIT ? 1 : 0)], (unsigned long long)cnt.tris);
   }
 }

@@ -155,7 +155,7 @@ def atrium(target_tris=1_000_000):
     """Hall 30 x 12 x 10 (x,z,y): bumpy flagstone floor, brick walls, two rows of fluted columns
     carrying arches and an upper gallery, hanging drapes, a coffered ceiling with emissive
     skylight panels. `target_tris` scales the tessellation (1.0 -> ~1.0M triangles)."""
-    k = np.sqrt(target_tris / 1_000_000.0)
+    k = np.sqrt(target_tris / 1_315_000.0)  # the unscaled tessellation below yields ~1.315M triangles
 
     def n(x):
         return max(2, int(round(x * k)))

@@ -182,6 +182,8 @@ class Stats(C.Structure):
         ("rays_shadow", C.c_uint64),
         ("nodes_visited", C.c_uint64),
         ("tris_tested", C.c_uint64),
+        ("nodes_visited_shadow", C.c_uint64),
+        ("tris_tested_shadow", C.c_uint64),
         ("ms_trace_closest", C.c_float),
         ("ms_trace_shadow", C.c_float),
         ("ms_shade", C.c_float),

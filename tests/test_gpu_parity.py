@@ -73,3 +73,85 @@ def test_cornell_256_one_sample(renderer, cornell):
     assert d <= 1e-4  # north_star tolerance on the HDR framebuffer
     assert np.array_equal(got["depth"]["z"].view(np.uint32), ref["depth"]["z"].view(np.uint32))
     assert np.allclose(got["prev_uv"], ref["prev_uv"], rtol=0, atol=0)
+
+
+@pytest.fixture(scope="module")
+def atrium_scene():
+    return scenes.atrium()
+
+
+def edge_rays(sc, n, seed):
+    """Rays aimed exactly at vertices and edge points of random triangles (ties and watertightness)."""
+    rng = np.random.RandomState(seed)
+    inst = sc.instances["packed"]
+    rays = np.zeros(n, wire.Ray)
+    verts = sc.vertices["position"]
+    k = 0
+    while k < n:
+        i = rng.randint(0, inst.shape[0])
+        pc = (inst[i, 1] >> 12) & 0xFFFF
+        stride = inst[i, 1] >> 28
+        prim = rng.randint(0, pc)
+        off = int(inst[i, 3]) + prim * 3 * int(stride)
+        idx = np.frombuffer(sc.indices[off : off + 3 * int(stride)].tobytes(), dtype="<u2" if stride == 2 else "<u4").astype(np.int64) + int(inst[i, 2])
+        m = np.vstack([sc.transforms["m"][i].astype(np.float64), [0, 0, 0, 1]])
+        p = (m @ np.concatenate([verts[idx].astype(np.float64), np.ones((3, 1))], axis=1).T).T[:, :3]
+        w = rng.dirichlet([1, 1, 1])
+        mode = rng.randint(0, 3)
+        if mode == 0:
+            w = np.eye(3)[rng.randint(0, 3)]  # a vertex
+        elif mode == 1:
+            w[rng.randint(0, 3)] = 0  # an edge
+            w /= w.sum()
+        target = (w[:, None] * p).sum(0)
+        o = target + rng.normal(size=3) * rng.uniform(0.5, 5.0)
+        d = target - o
+        d /= np.linalg.norm(d)
+        rays["origin"][k] = o
+        rays["direction"][k] = d
+        rays["tmin"][k] = 0
+        rays["tmax"][k] = np.inf
+        k += 1
+    return rays
+
+
+def test_trace_contract_atrium(renderer, atrium_scene):
+    """BVH traversal == the oracle's own BVH on 1M triangles (merged world mesh + 20 transformed instances),
+    and == brute force on a subset, including rays through vertices and edges."""
+    from oracle import oracle_py
+
+    sc, _ = atrium_scene
+    renderer.update(sc)
+    o = oracle_py.OracleScene(sc)
+    rays = np.concatenate([random_rays(200000, 2, [-14, 0.2, -5.5], [14, 9.5, 5.5]), edge_rays(sc, 20000, 3)])
+    got = renderer.trace(rays)
+    ref, _ = o.trace(rays)
+    for f in ("instance_primitive_index", "t", "b1", "b2"):
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+    sub = np.concatenate([rays[:300], rays[-300:]])
+    ref_b, _ = o.trace(sub, brute=True)
+    got_b = renderer.trace(sub)
+    for f in ("instance_primitive_index", "t", "b1", "b2"):
+        assert np.array_equal(got_b[f].view(np.uint32), ref_b[f].view(np.uint32)), f
+    rays["tmax"] = 3.0
+    got = renderer.trace(rays, any_hit=True)
+    ref, _ = o.trace(rays, any_hit=True)
+    assert np.array_equal(got["instance_primitive_index"], ref["instance_primitive_index"])
+
+
+def test_atrium_quarter_res(renderer, atrium_scene):
+    """configs[2] scene at 480x270 (the oracle finishes in seconds): bit-exact ids, rel-L2 <= 1e-4."""
+    from oracle import oracle_py
+
+    sc, cam = atrium_scene
+    renderer.update(sc)
+    frame = camera.Frame(480, 270, cam["fovy"], cam["eye"], cam["target"])
+    got = renderer.render(frame, 0, 2)
+    ref = oracle_py.OracleScene(sc).render(frame, renderer.push_constants(frame), renderer.mSamplingFlags, 0, 2)
+    assert np.array_equal(got["visibility"]["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
+    assert np.array_equal(got["ray_count"], ref["ray_count"])
+    d = rel_l2(got["radiance"], ref["radiance"])
+    nd = int((got["radiance"].view(np.uint32) != ref["radiance"].view(np.uint32)).any(axis=-1).sum())
+    print("atrium rel-L2 %.3e, differing pixels %d" % (d, nd))
+    assert d <= 1e-4
+    assert np.array_equal(got["radiance"][..., 3], ref["radiance"][..., 3])
