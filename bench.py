@@ -37,6 +37,18 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
+def host_threads():
+    """CPU threads this process may actually use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,16 +181,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle_py
 
-            sw, sh = W // 4, H // 4  # same scene, camera and flags; 1/16 of the pixels, 1 sample
+            sw, sh, nseed = W, H, 8  # the same workload: full frame, eight samples per pixel (about 10 s of CPU work on 16 cores)
             sframe = camera.Frame(sw, sh, cam["fovy"], cam["eye"], cam["target"])
             r.set_shard(0, 1, 64, 32)
-            got = r.render(sframe, 0, 1, aovs=False)
+            got = r.render(sframe, 0, nseed, aovs=False)
             o = oracle_py.OracleScene(sc)
-            threads = os.cpu_count() or 1
+            threads = host_threads()
             pc = r.push_constants(sframe)
-            o.render(sframe, pc, r.mSamplingFlags, 0, 1, threads=threads, aovs=False)  # warm-up
+            wframe = camera.Frame(sw // 8, sh // 8, cam["fovy"], cam["eye"], cam["target"])
+            o.render(wframe, r.push_constants(wframe), r.mSamplingFlags, 0, 1, threads=threads, aovs=False)  # warm-up
             t1 = time.perf_counter()
-            ref = o.render(sframe, pc, r.mSamplingFlags, 0, 1, threads=threads, aovs=False)
+            ref = o.render(sframe, pc, r.mSamplingFlags, 0, nseed, threads=threads, aovs=False)
             cdt = time.perf_counter() - t1
             a = got["radiance"][..., :3].astype(np.float64)
             b = ref["radiance"][..., :3].astype(np.float64)
@@ -188,7 +201,7 @@ def main():
                 "unit": "Mray/s",
                 "cores": threads,
                 "kind": "port",
-                "sample": "%s %dx%d x 1 sample, default flags (%d rays, %.2f s)" % (args.scene, sw, sh, int(ref["ray_count"][0]), cdt),
+                "sample": "%s %dx%d x %d samples, default flags (%d rays, %.2f s)" % (args.scene, sw, sh, nseed, int(ref["ray_count"][0]), cdt),
                 "rel_l2_gpu_vs_oracle": rel,
             }
         result = {

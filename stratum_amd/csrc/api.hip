@@ -491,6 +491,30 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (p.out_depth) HIP_TRY(ctx, hipMemsetAsync(p.out_depth, 0, pixels * 16, st));
   if (p.out_prev_uv) HIP_TRY(ctx, hipMemsetAsync(p.out_prev_uv, 0, pixels * 8, st));
 
+  // primary rays = owned pixels that lie inside the image and inside a view (known without asking the GPU)
+  uint32_t primary_rays = 0;
+  if (pc->gMaxPathVertices >= 2) {
+    for (uint32_t t = p.shard_rank; t < tiles; t += p.shard_count) {
+      const uint32_t ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+      const int x0 = (int)(tx * p.tile_w), y0 = (int)(ty * p.tile_h);
+      const int x1 = (int)std::min(W, (tx + 1) * p.tile_w), y1 = (int)std::min(H, (ty + 1) * p.tile_h);
+      if (nv == 1) {
+        const int ax0 = std::max(x0, frame->gViews[0].image_min[0]), ay0 = std::max(y0, frame->gViews[0].image_min[1]);
+        const int ax1 = std::min(x1, frame->gViews[0].image_max[0]), ay1 = std::min(y1, frame->gViews[0].image_max[1]);
+        if (ax1 > ax0 && ay1 > ay0) primary_rays += (uint32_t)(ax1 - ax0) * (uint32_t)(ay1 - ay0);
+      } else {
+        for (int y = y0; y < y1; y++)
+          for (int x = x0; x < x1; x++)
+            for (uint32_t v = 0; v < nv; v++) {
+              const sthip_ViewData& vw = frame->gViews[v];
+              if (x >= vw.image_min[0] && y >= vw.image_min[1] && x < vw.image_max[0] && y < vw.image_max[1]) {
+                primary_rays++;
+                break;
+              }
+            }
+      }
+    }
+  }
   const uint32_t grid = grid_for(ctx, p.path_count);
   const size_t lds = stack_bytes(ctx);
   const uint32_t max_bounce_rounds = pc->gMaxPathVertices >= 2 ? pc->gMaxPathVertices - 1 : 0;  // rays per path <= gMaxPathVertices - 1
@@ -530,6 +554,16 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       launches_closest++;
       rc = timed(ms_shade, [&]() { hipLaunchKernelGGL(k_shade, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth); });
       if (rc) return rc;
+      bool last_round = false;
+      if (timing) {
+        // per-kernel timing synchronises anyway: stop at the first empty round so that launch
+        // statistics only cover launches that had rays (untimed runs enqueue every round blindly)
+        unsigned long long nq[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpy(&nq[0], ctx->counters.p + CNT_QUEUE0 + depth + 1, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(&nq[1], ctx->counters.p + CNT_SHADOW0 + depth, 8, hipMemcpyDeviceToHost));
+        last_round = nq[0] == 0;
+        if (nq[1] == 0 && last_round) break;
+      }
       if (sampling_flags & (1u << STHIP_eNEE)) {
         rc = timed(ms_shadow, [&]() {
           if (ctx->count_traversal)
@@ -540,8 +574,9 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
         if (rc) return rc;
         launches_shadow++;
       }
+      if (last_round) break;
     }
-    rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + 1 == seed_count ? 1u : 0u); });
+    rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + 1 == seed_count ? 1u : 0u, primary_rays); });
     if (rc) return rc;
   }
 

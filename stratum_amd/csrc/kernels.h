@@ -58,6 +58,13 @@ struct FrameParams {
 
 DEV bool flag(const FrameParams& p, int bit) { return (p.sampling_flags >> bit) & 1u; }
 
+// one global atomic per wave (and none when the wave's sum is zero): per-thread atomics on one
+// address serialise at the memory side at ~12 ns each
+DEV void wave_add(unsigned long long* counter, uint32_t v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63u) == 0 && v) atomicAdd(counter, (unsigned long long)v);
+}
+
 // path slot -> pixel. Slots enumerate the owned tiles, and inside a tile 8x8 pixel blocks, so that a
 // wave64 covers an 8x8 block of the image (the reference's eRemapThreads does the same with 8x4 groups
 // of 32 threads, bdpt_util.hlsli:76-83). Returns false for slots that fall outside the image.
@@ -164,7 +171,6 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, ui
   const uint32_t* queue = p.queue[depth & 1u];
   TraverseCounters cnt;
   cnt.nodes = cnt.tris = 0;
-  uint32_t traced = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint32_t slot = depth == 0 ? i : queue[i];
     if (depth == 0 && p.meta[slot] >= 0xFFFFFFFEu) {
@@ -175,12 +181,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, ui
     RayHit h;
     traverse<false, COUNT>(p.bvh, xyz(ro), xyz(rd), 0.0f, __builtin_inff(), lds_stack + threadIdx.x, blockDim.x, h, cnt);
     p.hit[slot] = make_float4(h.t, h.b1, h.b2, __uint_as_float(h.ip));
-    traced++;
   }
-  atomicAdd(&p.counters[CNT_RAYS_CLOSEST], (unsigned long long)traced);
   if (COUNT) {
-    atomicAdd(&p.counters[CNT_NODES], (unsigned long long)cnt.nodes);
-    atomicAdd(&p.counters[CNT_TRIS], (unsigned long long)cnt.tris);
+    wave_add(&p.counters[CNT_NODES], cnt.nodes);
+    wave_add(&p.counters[CNT_TRIS], cnt.tris);
   }
 }
 
@@ -194,17 +198,12 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
   const uint32_t n = (uint32_t)p.counters[CNT_SHADOW0 + depth];
   TraverseCounters cnt;
   cnt.nodes = cnt.tris = 0;
-  uint32_t traced = 0;
   float4* target = flag(p, STHIP_eDeferShadowRays) ? p.shadow_sum : p.radiance;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float4 s0 = p.shadow_rays[3 * (size_t)i], s1 = p.shadow_rays[3 * (size_t)i + 1], s2 = p.shadow_rays[3 * (size_t)i + 2];
     const uint32_t slot = __float_as_uint(s1.w);
-    bool occluded = false;
-    if (s0.w > 1e-6f) {  // while (t_max > 1e-6f), intersection.hlsli:195
-      RayHit h;
-      occluded = traverse<true, COUNT>(p.bvh, xyz(s0), xyz(s1), 0.0f, s0.w, lds_stack + threadIdx.x, blockDim.x, h, cnt);
-      traced++;
-    }
+    RayHit h;
+    const bool occluded = traverse<true, COUNT>(p.bvh, xyz(s0), xyz(s1), 0.0f, s0.w, lds_stack + threadIdx.x, blockDim.x, h, cnt);
     if (!occluded) {
       float4 c = target[slot];
       c.x = c.x + s2.x;
@@ -213,10 +212,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
       target[slot] = c;
     }
   }
-  atomicAdd(&p.counters[CNT_RAYS_SHADOW], (unsigned long long)traced);
   if (COUNT) {
-    atomicAdd(&p.counters[CNT_NODES + 1], (unsigned long long)cnt.nodes);
-    atomicAdd(&p.counters[CNT_TRIS + 1], (unsigned long long)cnt.tris);
+    wave_add(&p.counters[CNT_NODES + 1], cnt.nodes);
+    wave_add(&p.counters[CNT_TRIS + 1], cnt.tris);
   }
 }
 
@@ -420,6 +418,18 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_shade(FrameParams p, uint32_t d
             const f3 c = beta * contrib * weight;
             // a zero/negative contribution never adds light (bdpt.hlsl:313) and needs no ray
             if (all_le0(c)) break;
+            if (!(ray_distance > 1e-6f)) {
+              // trace_visibility_ray's `while (t_max > 1e-6f)` (intersection.hlsli:195) never runs: unoccluded,
+              // no ray. This stage sits between shadow stage depth-1 and depth, so adding here keeps the order.
+              float4* target = flag(p, STHIP_eDeferShadowRays) ? p.shadow_sum : nullptr;
+              if (target) {
+                float4 acc = target[slot];
+                target[slot] = make_float4(acc.x + c.x, acc.y + c.y, acc.z + c.z, 0.0f);
+              } else {
+                radiance = radiance + c;
+              }
+              break;
+            }
             const uint32_t k = (uint32_t)atomicAdd(&p.counters[CNT_SHADOW0 + depth], 1ull);
             p.shadow_rays[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
             p.shadow_rays[3 * (size_t)k + 1] = make_float4(to_light.x, to_light.y, to_light.z, __uint_as_float(slot));
@@ -461,7 +471,15 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_shade(FrameParams p, uint32_t d
 // resolve: gRadiance += c (bdpt.hlsl:325), then the running mean that defines N samples per pixel
 // (temporal_accumulation.hlsl:102-131), and on the last seed the scatter to the output image
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t first_seed, uint32_t last_seed) {
+__global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t first_seed, uint32_t last_seed, uint32_t primary_rays) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // every queued path / shadow record was traced exactly once: ray counts are the queue sizes
+    unsigned long long closest = primary_rays, shadow = 0;
+    for (int d = 1; d < 64; d++) closest += p.counters[CNT_QUEUE0 + d];
+    for (int d = 0; d < 64; d++) shadow += p.counters[CNT_SHADOW0 + d];
+    p.counters[CNT_RAYS_CLOSEST] += closest;
+    p.counters[CNT_RAYS_SHADOW] += shadow;
+  }
   for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.path_count; slot += gridDim.x * blockDim.x) {
     const uint32_t meta = p.meta[slot];
     uint32_t px, py;
