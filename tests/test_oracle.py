@@ -1,0 +1,391 @@
+"""Pins of the CPU oracle (no GPU). The reference ships no tests or golden vectors (SURVEY.md §4), so
+the oracle is pinned by independent restatements of the integer code, by IEEE conversions that numpy
+implements on its own, and by analytic properties the estimator must have."""
+import numpy as np
+import pytest
+
+from oracle import oracle_py as orc
+from stratum_amd import camera, scenes, wire
+from stratum_amd.scene import SceneBuilder, rotate_y, scale, translate
+
+U32 = np.uint32
+
+
+# ---------------------------------------------------------------------------------------------
+# R1/R2 integer hashes: independent numpy restatement of rng.hlsli:6-47
+# ---------------------------------------------------------------------------------------------
+def np_pcg4d(v):
+    v = v.astype(np.uint64)
+    M = np.uint64(0xFFFFFFFF)
+    v = (v * np.uint64(1664525) + np.uint64(1013904223)) & M
+    x, y, z, w = v[:, 0], v[:, 1], v[:, 2], v[:, 3]
+    x = (x + y * w) & M
+    y = (y + z * x) & M
+    z = (z + x * y) & M
+    w = (w + y * z) & M
+    x, y, z, w = [a ^ (a >> np.uint64(16)) for a in (x, y, z, w)]
+    x = (x + y * w) & M
+    y = (y + z * x) & M
+    z = (z + x * y) & M
+    w = (w + y * z) & M
+    return np.stack([x, y, z, w], 1).astype(np.uint32)
+
+
+def test_pcg4d_matches_independent_restatement():
+    rng = np.random.RandomState(0)
+    v = rng.randint(0, 2**32, (4096, 4), dtype=np.uint64).astype(np.uint32)
+    v[0] = 0
+    v[1] = 0xFFFFFFFF
+    assert np.array_equal(orc.pcg4d(v), np_pcg4d(v))
+
+
+def test_pcg_and_xxhash_scalar():
+    def pcg(v):
+        state = (v * 747796405 + 2891336453) & 0xFFFFFFFF
+        word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & 0xFFFFFFFF
+        return ((word >> 22) ^ word) & 0xFFFFFFFF
+
+    def xx(p):
+        P2, P3, P4, P5 = 2246822519, 3266489917, 668265263, 374761393
+        h = (p + P5) & 0xFFFFFFFF
+        h = (P4 * (((h << 17) | (h >> 15)) & 0xFFFFFFFF)) & 0xFFFFFFFF
+        h = (P2 * (h ^ (h >> 15))) & 0xFFFFFFFF
+        h = (P3 * (h ^ (h >> 13))) & 0xFFFFFFFF
+        return h ^ (h >> 16)
+
+    for v in [0, 1, 2, 12345, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, 3141592653]:
+        assert orc.lib().orc_pcg(v) == pcg(v)
+        assert orc.lib().orc_xxhash32(v) == xx(v)
+
+
+def test_rng_stream_is_counter_based():
+    """rng.hlsli:35-47: counter++ THEN hash; float = asfloat(0x3f800000 | u >> 9) - 1 in [0, 1)."""
+    f = orc.rng_floats(17, 4, 9, 0, 64)
+    assert (f >= 0).all() and (f < 1).all()
+    state = np.array([[17, 4, 9, c] for c in range(1, 65)], np.uint32)
+    u = np_pcg4d(state)[:, 0]
+    expect = ((u >> 9) | np.uint32(0x3F800000)).view(np.float32) - np.float32(1)
+    assert np.array_equal(f, expect)
+    # restartable from any counter (what ShadowRayData.rng_offset relies on, path.hlsli:358)
+    assert np.array_equal(orc.rng_floats(17, 4, 9, 10, 8), f[10:18])
+
+
+# ---------------------------------------------------------------------------------------------
+# R3 f16 conversions and octahedral normals: numpy's own IEEE conversion is the independent check
+# ---------------------------------------------------------------------------------------------
+def test_f32tof16_is_round_to_nearest_even():
+    rng = np.random.RandomState(1)
+    x = np.concatenate(
+        [
+            rng.uniform(-2, 2, 200000).astype(np.float32),
+            (rng.uniform(-1, 1, 50000) * 10.0 ** rng.uniform(-9, 5, 50000)).astype(np.float32),
+            np.array([0, -0.0, 65504, 65519.99, 65520, 1e9, -1e9, 5.96e-8, 2.98e-8, 2.9802322e-8, 6.1e-5, np.inf, -np.inf], np.float32),
+        ]
+    )
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16).view(np.uint16).astype(np.uint32)
+    assert np.array_equal(orc.f32tof16(x), want)
+
+
+def test_f16tof32_exact_for_all_halves():
+    h = np.arange(65536, dtype=np.uint32)
+    want = h.astype(np.uint16).view(np.float16).astype(np.float32)
+    got = orc.f16tof32(h)
+    nan = np.isnan(want)
+    assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32))
+    assert np.isnan(got[nan]).all()
+
+
+def test_octahedral_normals_roundtrip():
+    rng = np.random.RandomState(2)
+    v = rng.normal(size=(100000, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[:6] = [[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]]
+    u = orc.unpack_normal(orc.pack_normal(v))
+    assert np.abs(np.linalg.norm(u, axis=1) - 1).max() < 1e-6
+    assert np.abs((u * v).sum(1) - 1).max() < 2e-6  # fp16 octahedral: < 0.12 degrees
+    # packing the unpacked vector is a fixed point (the quantised normal is what every cosine sees, B1)
+    assert np.array_equal(orc.pack_normal(u[:6]), orc.pack_normal(v[:6]))
+
+
+def test_detmath_against_libm():
+    rng = np.random.RandomState(3)
+    x = rng.uniform(0, 2 * np.pi, 200000).astype(np.float32)
+    s, c = orc.sincos(x)
+    assert np.abs(s - np.sin(x.astype(np.float64))).max() < 2.5e-7
+    assert np.abs(c - np.cos(x.astype(np.float64))).max() < 2.5e-7
+    a = (10.0 ** rng.uniform(-7, 2, 100000)).astype(np.float32)
+    assert np.abs(orc.log(a) / np.log(a.astype(np.float64)) - 1)[np.abs(np.log(a)) > 1e-2].max() < 1e-6
+    b = rng.uniform(0, 1, 100000).astype(np.float32)
+    a = rng.uniform(1e-6, 1e-2, 100000).astype(np.float32)
+    assert np.abs(orc.pow(a, b) / np.power(a.astype(np.float64), b) - 1).max() < 5e-6
+
+
+def test_ray_offset_properties():
+    """intersection.hlsli:44-62: the offset point lies on the normal's side, |delta| tiny, exact branch at 1/32."""
+    rng = np.random.RandomState(4)
+    p = (rng.uniform(-1, 1, (50000, 3)) * 10.0 ** rng.uniform(-3, 3, (50000, 1))).astype(np.float32)
+    n = rng.normal(size=(50000, 3)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    q = orc.ray_offset(p, n)
+    d = (q.astype(np.float64) - p) * n
+    assert (d >= 0).all()  # every component moves along the normal's sign (or not at all)
+    assert np.abs(q - p).max(axis=1).max() <= 1e-4 * np.abs(p).max(axis=1).max() + 2e-5
+    small = np.abs(p) < 1 / 32.0
+    want = (p + n * np.float32(1 / 65536.0)).astype(np.float32)
+    assert np.array_equal(q[small], want[small])
+
+
+# ---------------------------------------------------------------------------------------------
+# M2/M3 Disney BSDF: sample/eval consistency, pdf normalisation, energy
+# ---------------------------------------------------------------------------------------------
+def material(**kw):
+    b = SceneBuilder()
+    b.add_material(kw.pop("base_color", (0.8, 0.6, 0.4)), **kw)
+    return b._materials[0]
+
+
+MATERIALS = {
+    "diffuse": dict(),
+    "rough_diffuse_subsurface": dict(roughness=0.7, subsurface=0.4),
+    "metal": dict(metallic=1.0, roughness=0.4),
+    "aniso_metal": dict(metallic=0.9, roughness=0.5, anisotropic=0.6),
+    "glass": dict(transmission=1.0, roughness=0.3, eta=1.5),
+    "clearcoat": dict(clearcoat=1.0, clearcoat_gloss=0.6, roughness=0.5),
+    "mixed": dict(metallic=0.3, roughness=0.4, transmission=0.4, clearcoat=0.5, clearcoat_gloss=0.3, subsurface=0.2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MATERIALS))
+def test_disney_sample_agrees_with_eval(name):
+    rec = material(**MATERIALS[name])
+    rng = np.random.RandomState(5)
+    n = 20000
+    di = rng.normal(size=(n, 3)).astype(np.float32)
+    di /= np.linalg.norm(di, axis=1, keepdims=True)
+    if "glass" not in name and name != "mixed":
+        di[:, 2] = np.abs(di[:, 2])
+    rnd = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    smp = orc.disney_sample(rec, di, rnd)
+    do = smp[:, 0:3].copy()
+    ok = smp[:, 3] > 1e-4
+    ev = orc.disney_eval(rec, di, do)
+    f_s, pdf_s, beta = smp[:, 7:10], smp[:, 3], smp[:, 10:13]
+    # eval() of the sampled direction returns the same f and pdf that sample() reported
+    good = ok & (np.abs(do[:, 2]) > 1e-3) & (np.abs(di[:, 2]) > 1e-3)
+    # sample() prices a reflection that ends below the horizon (VNDF on a rough lobe) as a reflection, while
+    # eval() classifies by hemisphere (disney_material.hlsli:155,237-250): compare only where the two agree
+    refracted = smp[:, 5] != 0
+    same_side = di[:, 2] * do[:, 2] > 0
+    good &= np.where(refracted, ~same_side, same_side)
+    assert good.sum() > n // 2
+    rel = np.abs(ev[good, 3] - pdf_s[good]) / np.maximum(pdf_s[good], 1e-3)
+    assert np.percentile(rel, 99) < 2e-2
+    relf = np.abs(ev[good, 0:3] - f_s[good]) / np.maximum(np.abs(f_s[good]), 1e-2)
+    assert np.percentile(relf, 99) < 2e-2
+    # beta *= f / pdf (disney_material.hlsli:313)
+    w = f_s[good] / pdf_s[good, None]
+    assert np.allclose(beta[good], w, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["diffuse", "rough_diffuse_subsurface", "metal", "clearcoat"])
+def test_disney_pdf_integrates_to_one_and_conserves_energy(name):
+    rec = material(base_color=(1.0, 1.0, 1.0), **MATERIALS[name])
+    rng = np.random.RandomState(6)
+    n = 400000
+    z = rng.uniform(-1, 1, n)
+    phi = rng.uniform(0, 2 * np.pi, n)
+    r = np.sqrt(1 - z * z)
+    do = np.stack([r * np.cos(phi), r * np.sin(phi), z], 1).astype(np.float32)
+    th = 0.6
+    di = np.tile(np.array([np.sin(th), 0, np.cos(th)], np.float32), (n, 1))
+    ev = orc.disney_eval(rec, di, do).astype(np.float64)
+    ipdf = ev[:, 3].mean() * 4 * np.pi
+    alb = ev[:, 0].mean() * 4 * np.pi  # f already contains |cos|
+    w_total = {"diffuse": 1.0, "rough_diffuse_subsurface": 1.0, "metal": 1.0, "clearcoat": 1.25}[name]
+    # lobe weights are not normalised (disney_material.hlsli:230-268); clearcoat adds 0.25 on top of diffuse
+    assert abs(ipdf - w_total) < 0.03 * w_total, ipdf
+    assert alb < 1.02 * w_total, alb
+
+
+# ---------------------------------------------------------------------------------------------
+# T1/T2 traversal contract: the oracle's BVH never changes the brute-force answer
+# ---------------------------------------------------------------------------------------------
+def soup_scene(seed, n_meshes=5, tris=300):
+    rng = np.random.RandomState(seed)
+    b = SceneBuilder("soup")
+    m = b.add_material((0.5, 0.5, 0.5))
+    for k in range(n_meshes):
+        c = rng.uniform(-1, 1, (tris, 1, 3))
+        p = (c + rng.normal(scale=0.15, size=(tris, 3, 3))).reshape(-1, 3)
+        tri = np.arange(tris * 3).reshape(-1, 3)
+        mesh = b.add_mesh(p, None, None, tri, index_stride=2 if k % 2 else 4)
+        b.add_instance(mesh, m, None if k == 0 else translate(rng.uniform(-1, 1, 3)) @ rotate_y(rng.uniform(0, 6)) @ scale(rng.uniform(0.5, 1.5, 3)))
+        if k == 1:  # a second instance of the same mesh
+            b.add_instance(mesh, m, translate((2.0, 0.3, -1.0)) @ rotate_y(1.0))
+    return b.build()
+
+
+def random_rays(n, seed, lo=-3.0, hi=3.0):
+    rng = np.random.RandomState(seed)
+    rays = np.zeros(n, wire.Ray)
+    rays["origin"] = rng.uniform(lo, hi, (n, 3))
+    d = rng.normal(size=(n, 3))
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["tmax"] = np.inf
+    return rays
+
+
+def test_bvh_equals_brute_force():
+    sc = soup_scene(7)
+    o = orc.OracleScene(sc)
+    rays = random_rays(20000, 8)
+    a, _ = o.trace(rays)
+    b, _ = o.trace(rays, brute=True)
+    for f in ("instance_primitive_index", "t", "b1", "b2"):
+        assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f
+    assert (a["instance_primitive_index"] != wire.MISS).mean() > 0.15
+    rays["tmax"] = 1.5
+    a, _ = o.trace(rays, any_hit=True)
+    b, _ = o.trace(rays, any_hit=True, brute=True)
+    assert np.array_equal(a["instance_primitive_index"], b["instance_primitive_index"])
+
+
+def test_hits_reconstruct_the_surface_point():
+    """P = v0 + b1 (v1-v0) + b2 (v2-v0) (shading_data.hlsli:69-72) lies on the ray at t."""
+    sc, _ = scenes.cornell_box()
+    o = orc.OracleScene(sc)
+    rays = random_rays(5000, 9, -0.9, 0.9)
+    h, _ = o.trace(rays)
+    hit = h["instance_primitive_index"] != wire.MISS
+    assert hit.mean() > 0.7  # the box is open towards +z
+    sd = o.shading_data(h["instance_primitive_index"][hit], np.stack([h["b1"], h["b2"]], 1)[hit])
+    p = rays["origin"][hit] + rays["direction"][hit] * h["t"][hit, None]
+    assert np.abs(sd["position"] - p).max() < 2e-5
+
+
+def test_watertight_shared_edges():
+    """Rays aimed exactly at the shared diagonal and at shared vertices of a tessellated wall never leak."""
+    b = SceneBuilder()
+    m = b.add_material((0.5, 0.5, 0.5))
+    part = scenes.grid_surface(lambda U, V: np.stack([U * 2 - 1, V * 2 - 1, 0 * U], -1), 16, 16)
+    b.add_instance(b.add_mesh(*part), m)
+    sc = b.build()
+    o = orc.OracleScene(sc)
+    rng = np.random.RandomState(10)
+    n = 20000
+    # targets on grid vertices, on horizontal/vertical/diagonal edges
+    gx = rng.randint(0, 17, n) / 8.0 - 1
+    gy = rng.randint(0, 17, n) / 8.0 - 1
+    t = rng.uniform(0, 1, n)
+    kind = rng.randint(0, 3, n)
+    tx = np.where(kind == 0, gx, np.clip(gx + t / 8.0, -1, 1))
+    ty = np.where(kind == 1, gy, np.where(kind == 2, np.clip(gy + t / 8.0, -1, 1), gy))
+    target = np.stack([tx, ty, np.zeros(n)], 1)
+    origin = target + np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), rng.uniform(0.5, 3, n)], 1)
+    rays = np.zeros(n, wire.Ray)
+    rays["origin"] = origin
+    d = target - origin
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["tmax"] = np.inf
+    inside = (np.abs(tx) < 0.999) & (np.abs(ty) < 0.999)
+    h, _ = o.trace(rays)
+    assert (h["instance_primitive_index"][inside] != wire.MISS).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# estimator: direct illumination against the closed-form form factor; N-sample semantics
+# ---------------------------------------------------------------------------------------------
+def plane_and_light(rho=0.6, Le=5.0, a=0.8, h=1.0):
+    b = SceneBuilder("plane_light")
+    white = b.add_material((rho, rho, rho))
+    light = b.add_emitter((Le, Le, Le))
+    S = 50.0
+    floor = scenes._quad((-S, 0, S), (S, 0, S), (S, 0, -S), (-S, 0, -S), (0, 1, 0))
+    b.add_instance(b.add_mesh(*floor), white)
+    lq = scenes._quad((-a, h, -a), (a, h, -a), (a, h, a), (-a, h, a), (0, -1, 0))
+    b.add_instance(b.add_mesh(*lq), light)
+    return b.build()
+
+
+def form_factor_point_to_coaxial_square(a, h):
+    A = a / h
+
+    def corner(A, B):
+        return (A / np.sqrt(1 + A * A) * np.arctan(B / np.sqrt(1 + A * A)) + B / np.sqrt(1 + B * B) * np.arctan(A / np.sqrt(1 + B * B))) / (2 * np.pi)
+
+    return 4 * corner(A, A)
+
+
+@pytest.mark.parametrize("flags", ["default", "~nee", "~samplebsdfs", "~mis", "~defershadowrays"])
+def test_direct_light_matches_form_factor(flags):
+    """L = rho * Le * F at the floor point under the light, for every estimator combination
+    (NEE + BSDF sampling with MIS, either alone, MIS off = 0.5/0.5, shadow rays not deferred)."""
+    rho, Le, a, h = 0.6, 5.0, 0.8, 1.0
+    sc = plane_and_light(rho, Le, a, h)
+    o = orc.OracleScene(sc)
+    fr = camera.Frame(8, 8, np.radians(0.05), (0.3, 0.5, 0.0), (0.0, 0.0, 0.0), up=(0, 0, 1))  # looks at the origin, below the light
+    pc = wire.default_push_constants(8, 8, sc.light_count)
+    pc.gMaxDiffuseVertices = 1  # direct light only
+    f = wire.DEFAULT_SAMPLING_FLAGS
+    if flags != "default":
+        f &= ~wire.flag_mask({"~nee": "eNEE", "~samplebsdfs": "eSampleBSDFs", "~mis": "eMIS", "~defershadowrays": "eDeferShadowRays"}[flags])
+    out = o.render(fr, pc, f, 0, 2048, aovs=False)
+    got = out["radiance"][..., 0].astype(np.float64).mean()
+    want = rho * Le * form_factor_point_to_coaxial_square(a, h)
+    assert out["radiance"][..., 3].min() == 2048
+    assert abs(got / want - 1) < 0.02, (got, want)
+
+
+def test_directly_visible_emitter_has_weight_one():
+    """path.hlsli:869-870: emission at the first hit is added unweighted; emitters do not scatter."""
+    sc, cam = scenes.furnace_box(emission=3.5)
+    o = orc.OracleScene(sc)
+    fr = camera.Frame(16, 16, cam["fovy"], cam["eye"], cam["target"])
+    out = o.render(fr, wire.default_push_constants(16, 16, sc.light_count), wire.DEFAULT_SAMPLING_FLAGS, 0, 3)
+    assert np.array_equal(out["radiance"][..., :3], np.full((16, 16, 3), 3.5, np.float32))
+    assert out["ray_count"][0] == 16 * 16 * 3  # one ray per pixel-sample, no NEE from an emitter
+
+
+def test_n_samples_is_the_running_mean_of_seeds():
+    """A1: sample i <=> seed i; result = temporal_accumulation's running mean over per-seed frames."""
+    sc, cam = scenes.cornell_box()
+    o = orc.OracleScene(sc)
+    fr = camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"])
+    pc = wire.default_push_constants(32, 32, sc.light_count)
+    per_seed = [o.render(fr, pc, seed_begin=s, seed_count=1, aovs=False)["radiance"] for s in range(3, 8)]
+    acc = per_seed[0][..., :3].copy()
+    for n, cur in enumerate(per_seed[1:], start=2):
+        alpha = np.float32(1.0) / np.float32(n)
+        acc = acc + alpha * (cur[..., :3] - acc)
+    got = o.render(fr, pc, seed_begin=3, seed_count=5, aovs=False)["radiance"]
+    assert np.array_equal(got[..., :3], acc)
+    assert (got[..., 3] == 5).all()
+    # different seeds give different noise, the same seed the same frame
+    assert not np.array_equal(per_seed[0], per_seed[1])
+    assert np.array_equal(per_seed[0], o.render(fr, pc, seed_begin=3, seed_count=1, aovs=False)["radiance"])
+
+
+def test_ray_budget_at_default_flags():
+    """SURVEY.md A.2: <= 3 closest-hit and <= 2 shadow rays per pixel-sample with the default limits."""
+    sc, cam = scenes.cornell_box()
+    o = orc.OracleScene(sc)
+    fr = camera.Frame(64, 64, cam["fovy"], cam["eye"], cam["target"])
+    out = o.render(fr, wire.default_push_constants(64, 64, sc.light_count), aovs=False)
+    total, path = int(out["ray_count"][0]), int(out["ray_count"][1])
+    assert 64 * 64 <= path <= 3 * 64 * 64
+    assert total - path <= 2 * 64 * 64
+
+
+def test_cornell_golden_fixture():
+    """configs[0]: Cornell box 256x256, seed 0 — the committed fixture (tests/golden/make_golden.py)."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cornell_256_seed0.npz"))
+    sc, cam = scenes.cornell_box()
+    o = orc.OracleScene(sc)
+    fr = camera.Frame(256, 256, cam["fovy"], cam["eye"], cam["target"])
+    out = o.render(fr, wire.default_push_constants(256, 256, sc.light_count))
+    assert np.array_equal(out["radiance"].view(np.uint32), g["radiance"].view(np.uint32))
+    assert np.array_equal(out["visibility"]["instance_primitive_index"], g["instance_primitive_index"])
+    assert np.array_equal(out["ray_count"], g["ray_count"])
