@@ -304,6 +304,12 @@ static uint32_t grid_for(const sthip_ctx* ctx, size_t n) {
   const size_t cap = (size_t)ctx->cu_count * 32;  // grid-stride beyond this
   return (uint32_t)std::max<size_t>(1, std::min(blocks, cap));
 }
+// Persistent trace kernels: as many blocks as are resident at once (LDS stack and VGPRs bound it).
+static uint32_t trace_grid(sthip_ctx* ctx, size_t lds_bytes) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false>, STHIP_BLOCK, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+  return (uint32_t)(ctx->cu_count * per_cu);
+}
 static size_t stack_bytes(const sthip_ctx* ctx) { return (size_t)ctx->bvh.stack_depth * STHIP_BLOCK * sizeof(uint32_t); }
 
 int sthip_trace_rays(sthip_ctx* ctx, const sthip_ray* rays, uint32_t ray_count, sthip_hit* hits, uint32_t any_hit, uint32_t device_ptrs) {
@@ -517,6 +523,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   }
   const uint32_t grid = grid_for(ctx, p.path_count);
   const size_t lds = stack_bytes(ctx);
+  const uint32_t tgrid = std::min<uint32_t>(trace_grid(ctx, lds), (uint32_t)((P + STHIP_BLOCK - 1) / STHIP_BLOCK));
   const uint32_t max_bounce_rounds = pc->gMaxPathVertices >= 2 ? pc->gMaxPathVertices - 1 : 0;  // rays per path <= gMaxPathVertices - 1
   const bool timing = ctx->time_kernels;
   float ms_closest = 0, ms_shadow = 0, ms_shade = 0, ms_other = 0;
@@ -540,15 +547,15 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     p.seed = seed_begin + s;
     p.write_aov = s == 0 ? 1u : 0u;
     // queue sizes are per seed; the ray / traversal counters behind them run over the whole call
-    if (s) HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_RAYS_CLOSEST * sizeof(unsigned long long), st));
+    if (s) HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_PER_SEED * sizeof(unsigned long long), st));
     int rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(STHIP_BLOCK), 0, st, p); });
     if (rc) return rc;
     for (uint32_t depth = 0; depth < max_bounce_rounds; depth++) {
       rc = timed(ms_closest, [&]() {
         if (ctx->count_traversal)
-          hipLaunchKernelGGL((k_trace_closest<true>), dim3(grid), dim3(STHIP_BLOCK), lds, st, p, depth);
+          hipLaunchKernelGGL((k_trace_closest<true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, depth);
         else
-          hipLaunchKernelGGL((k_trace_closest<false>), dim3(grid), dim3(STHIP_BLOCK), lds, st, p, depth);
+          hipLaunchKernelGGL((k_trace_closest<false>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, depth);
       });
       if (rc) return rc;
       launches_closest++;
@@ -567,9 +574,9 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       if (sampling_flags & (1u << STHIP_eNEE)) {
         rc = timed(ms_shadow, [&]() {
           if (ctx->count_traversal)
-            hipLaunchKernelGGL((k_trace_shadow<true>), dim3(grid), dim3(STHIP_BLOCK), lds, st, p, depth);
+            hipLaunchKernelGGL((k_trace_shadow<true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, depth);
           else
-            hipLaunchKernelGGL((k_trace_shadow<false>), dim3(grid), dim3(STHIP_BLOCK), lds, st, p, depth);
+            hipLaunchKernelGGL((k_trace_shadow<false>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, depth);
         });
         if (rc) return rc;
         launches_shadow++;

@@ -17,7 +17,19 @@
 #define STHIP_BLOCK 256
 
 // queue / counter slots in FrameParams::counters
-enum { CNT_QUEUE0 = 0, CNT_SHADOW0 = 64, CNT_RAYS_CLOSEST = 128, CNT_RAYS_SHADOW = 129, CNT_NODES = 130, CNT_TRIS = 132, CNT_TOTAL = 136 };
+// [0, CNT_PER_SEED) is cleared for every seed; the rest accumulates over a render call
+enum {
+  CNT_QUEUE0 = 0,     // [depth]: size of the path queue entering bounce `depth`
+  CNT_SHADOW0 = 64,   // [depth]: size of the shadow-ray queue of bounce `depth`
+  CNT_HEAD0 = 128,    // [depth]: dequeue head of k_trace_closest
+  CNT_HEADS0 = 192,   // [depth]: dequeue head of k_trace_shadow
+  CNT_PER_SEED = 256,
+  CNT_RAYS_CLOSEST = 256,
+  CNT_RAYS_SHADOW = 257,
+  CNT_NODES = 258,  // +1: shadow rays
+  CNT_TRIS = 260,   // +1: shadow rays
+  CNT_TOTAL = 264
+};
 
 struct FrameParams {
   DeviceScene scene;
@@ -162,25 +174,54 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// trace_closest: trace_ray (intersection.hlsli:65-191) for every queued path
+// trace_closest: trace_ray (intersection.hlsli:65-191) for every queued path.
+// Persistent waves: the grid only fills the machine; each wave keeps pulling rays from the queue and
+// re-packs its lanes — whenever REFILL_IDLE or more lanes have finished their ray, those lanes fetch
+// new rays (ballot + popcount ranking, WaveWork) while the others keep their traversal state.
 // ---------------------------------------------------------------------------------------------
+#define REFILL_IDLE 20
+
 template <bool COUNT>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, uint32_t depth) {
   extern __shared__ uint32_t lds_stack[];
   const uint32_t n = depth == 0 ? p.path_count : (uint32_t)p.counters[CNT_QUEUE0 + depth];
+  if (n == 0) return;
   const uint32_t* queue = p.queue[depth & 1u];
+  unsigned long long* head = &p.counters[CNT_HEAD0 + depth];
+  uint32_t* stack = lds_stack + threadIdx.x;
+  const uint32_t stride = blockDim.x;
   TraverseCounters cnt;
   cnt.nodes = cnt.tris = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t slot = depth == 0 ? i : queue[i];
-    if (depth == 0 && p.meta[slot] >= 0xFFFFFFFEu) {
-      p.hit[slot] = make_float4(__builtin_inff(), 0, 0, __uint_as_float(0xFFFFFFFFu));
-      continue;
+  Traversal<false, COUNT> tr;
+  tr.reset();
+  WaveWork work;
+  work.init();
+  uint32_t slot = 0;
+  bool busy = false;  // this lane holds a ray whose hit is not stored yet
+  for (;;) {
+    const unsigned long long idle = __ballot(!busy);
+    if ((uint32_t)__popcll(idle) >= REFILL_IDLE || idle == ~0ull) {
+      const uint32_t idx = work.take(!busy, head, n);
+      if (idx != 0xFFFFFFFFu) {
+        slot = depth == 0 ? idx : queue[idx];
+        if (depth == 0 && p.meta[slot] >= 0xFFFFFFFEu) {
+          p.hit[slot] = make_float4(__builtin_inff(), 0, 0, __uint_as_float(0xFFFFFFFFu));
+        } else {
+          const float4 ro = p.ray_o[slot], rd = p.ray_d[slot];
+          tr.start(p.bvh, xyz(ro), xyz(rd), 0.0f, __builtin_inff());
+          busy = true;
+        }
+      }
+      if (!__any(busy)) {
+        if (work.exhausted) break;
+        continue;
+      }
     }
-    const float4 ro = p.ray_o[slot], rd = p.ray_d[slot];
-    RayHit h;
-    traverse<false, COUNT>(p.bvh, xyz(ro), xyz(rd), 0.0f, __builtin_inff(), lds_stack + threadIdx.x, blockDim.x, h, cnt);
-    p.hit[slot] = make_float4(h.t, h.b1, h.b2, __uint_as_float(h.ip));
+    tr.round(p.bvh, stack, stride, cnt);
+    if (busy && !tr.active()) {
+      p.hit[slot] = make_float4(tr.hit.t, tr.hit.b1, tr.hit.b2, __uint_as_float(tr.hit.ip));
+      busy = false;
+    }
   }
   if (COUNT) {
     wave_add(&p.counters[CNT_NODES], cnt.nodes);
@@ -190,26 +231,52 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, ui
 
 // ---------------------------------------------------------------------------------------------
 // trace_shadow: trace_visibility_ray without media (intersection.hlsli:192-239) + the per-pixel sum
-// of trace_shadows (bdpt.hlsl:311-325)
+// of trace_shadows (bdpt.hlsl:311-325). Same persistent scheme.
 // ---------------------------------------------------------------------------------------------
 template <bool COUNT>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uint32_t depth) {
   extern __shared__ uint32_t lds_stack[];
   const uint32_t n = (uint32_t)p.counters[CNT_SHADOW0 + depth];
+  if (n == 0) return;
+  unsigned long long* head = &p.counters[CNT_HEADS0 + depth];
+  uint32_t* stack = lds_stack + threadIdx.x;
+  const uint32_t stride = blockDim.x;
   TraverseCounters cnt;
   cnt.nodes = cnt.tris = 0;
   float4* target = flag(p, STHIP_eDeferShadowRays) ? p.shadow_sum : p.radiance;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float4 s0 = p.shadow_rays[3 * (size_t)i], s1 = p.shadow_rays[3 * (size_t)i + 1], s2 = p.shadow_rays[3 * (size_t)i + 2];
-    const uint32_t slot = __float_as_uint(s1.w);
-    RayHit h;
-    const bool occluded = traverse<true, COUNT>(p.bvh, xyz(s0), xyz(s1), 0.0f, s0.w, lds_stack + threadIdx.x, blockDim.x, h, cnt);
-    if (!occluded) {
-      float4 c = target[slot];
-      c.x = c.x + s2.x;
-      c.y = c.y + s2.y;
-      c.z = c.z + s2.z;
-      target[slot] = c;
+  Traversal<true, COUNT> tr;
+  tr.reset();
+  WaveWork work;
+  work.init();
+  uint32_t slot = 0;
+  f3 contribution = F3s(0.0f);
+  bool busy = false;
+  for (;;) {
+    const unsigned long long idle = __ballot(!busy);
+    if ((uint32_t)__popcll(idle) >= REFILL_IDLE || idle == ~0ull) {
+      const uint32_t idx = work.take(!busy, head, n);
+      if (idx != 0xFFFFFFFFu) {
+        const float4 s0 = p.shadow_rays[3 * (size_t)idx], s1 = p.shadow_rays[3 * (size_t)idx + 1], s2 = p.shadow_rays[3 * (size_t)idx + 2];
+        slot = __float_as_uint(s1.w);
+        contribution = xyz(s2);
+        tr.start(p.bvh, xyz(s0), xyz(s1), 0.0f, s0.w);
+        busy = true;
+      }
+      if (!__any(busy)) {
+        if (work.exhausted) break;
+        continue;
+      }
+    }
+    tr.round(p.bvh, stack, stride, cnt);
+    if (busy && !tr.active()) {
+      if (tr.hit.ip == 0xFFFFFFFFu) {  // unoccluded: each pixel has at most one shadow ray per bounce
+        float4 c = target[slot];
+        c.x = c.x + contribution.x;
+        c.y = c.y + contribution.y;
+        c.z = c.z + contribution.z;
+        target[slot] = c;
+      }
+      busy = false;
     }
   }
   if (COUNT) {

@@ -121,63 +121,97 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
   return true;
 }
 
-// Returns true if something was hit. ANY_HIT: stops at the first accepted triangle (hit.ip = 0).
-// `stack` points at this lane's column of the LDS stack, `stride` = lanes per level (block size).
+#define TRAV_DONE 0xFFFFFFFFu
+
+// Per-lane traversal state machine. `ref` is the next thing to process: an inner-node index, a leaf
+// reference, or TRAV_DONE. The drivers below run it "while-while": every lane of the wave walks inner
+// nodes until it holds a leaf (or is done), then the wave processes leaves together, so that the long
+// triangle code is not executed once per inner-node step of some other lane.
 template <bool ANY_HIT, bool COUNT>
-DEV bool traverse(const DeviceBvh& bvh, f3 o, f3 d, float tmin, float tmax, uint32_t* stack, uint32_t stride, RayHit& hit, TraverseCounters& cnt) {
-  hit.t = tmax;
-  hit.b1 = hit.b2 = 0.0f;
-  hit.ip = 0xFFFFFFFFu;
-  if (bvh.root_ref == BVH_INVALID_REF) return false;
+struct Traversal {
+  f3 o, d;  // world-space ray
+  float tmin, tmax;
+  RaySpace sp;  // the space currently being traversed (world, or the object space of an instance)
+  RayHit hit;
+  uint32_t ref;
+  int top;      // stack height
+  int inst_sp;  // stack height at which the current instance was entered, -1 in world space
+  uint32_t id_bits;
 
-  RaySpace sp;
-  setup_space(sp, o, d, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
-  uint32_t id_bits = 0;
-  int inst_sp = -1;  // stack height at which the current instance was entered
-  int top = 0;
-  uint32_t ref = bvh.root_ref;
+  DEV bool active() const { return ref != TRAV_DONE; }
+  DEV void reset() { ref = TRAV_DONE; }
 
-  for (;;) {
-    bool pop = false;
-    if (!(ref & BVH_LEAF_BIT)) {
-      // ---- inner node: test both children ----
-      const float4* n = bvh.nodes + (size_t)ref * 4;
-      const float4 n0 = n[0], n1 = n[1], nz = n[2];
-      const uint4 cr = *reinterpret_cast<const uint4*>(n + 3);
-      if (COUNT) cnt.nodes++;
-      const float tbest = ANY_HIT ? tmax : hit.t;
-      const float a0x = (n0.x - sp.oL.x) * sp.idir.x, b0x = (n0.y - sp.oH.x) * sp.idir.x;
-      const float a0y = (n0.z - sp.oL.y) * sp.idir.y, b0y = (n0.w - sp.oH.y) * sp.idir.y;
-      const float a0z = (nz.x - sp.oL.z) * sp.idir.z, b0z = (nz.y - sp.oH.z) * sp.idir.z;
-      const float a1x = (n1.x - sp.oL.x) * sp.idir.x, b1x = (n1.y - sp.oH.x) * sp.idir.x;
-      const float a1y = (n1.z - sp.oL.y) * sp.idir.y, b1y = (n1.w - sp.oH.y) * sp.idir.y;
-      const float a1z = (nz.z - sp.oL.z) * sp.idir.z, b1z = (nz.w - sp.oH.z) * sp.idir.z;
-      const float tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), tmin));
-      const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), tbest));
-      const float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), tmin));
-      const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), tbest));
-      const bool h0 = (tn0 <= tf0) && (cr.x != BVH_INVALID_REF);
-      const bool h1 = (tn1 <= tf1) && (cr.y != BVH_INVALID_REF);
-      if (h0 && h1) {
-        const bool swap = tn1 < tn0;
-        const uint32_t nearc = swap ? cr.y : cr.x;
-        const uint32_t farc = swap ? cr.x : cr.y;
-        // the builder caps tree depth at stack_depth - 2, so this bound is never reached; it only
-        // keeps a malformed structure from writing outside the LDS allocation
-        if (top < (int)bvh.stack_depth) {
-          stack[(uint32_t)top * stride] = farc;
-          top++;
-        }
-        ref = nearc;
-      } else if (h0) {
-        ref = cr.x;
-      } else if (h1) {
-        ref = cr.y;
-      } else {
-        pop = true;
+  DEV void start(const DeviceBvh& bvh, f3 ro, f3 rd, float t0, float t1) {
+    o = ro;
+    d = rd;
+    tmin = t0;
+    tmax = t1;
+    hit.t = t1;
+    hit.b1 = hit.b2 = 0.0f;
+    hit.ip = 0xFFFFFFFFu;
+    top = 0;
+    inst_sp = -1;
+    id_bits = 0;
+    ref = bvh.root_ref;  // BVH_INVALID_REF == TRAV_DONE for an empty scene
+    setup_space(sp, ro, rd, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
+  }
+
+  DEV void pop(const DeviceBvh& bvh, const uint32_t* stack, uint32_t stride) {
+    if (top == inst_sp) {  // everything pushed inside the instance is consumed: back to world space
+      setup_space(sp, o, d, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
+      id_bits = 0;
+      inst_sp = -1;
+    }
+    if (top == 0) {
+      ref = TRAV_DONE;
+    } else {
+      top--;
+      ref = stack[(uint32_t)top * stride];
+    }
+  }
+
+  // ref is an inner node: test both children, descend into the nearer, push the farther
+  DEV void inner_step(const DeviceBvh& bvh, uint32_t* stack, uint32_t stride, TraverseCounters& cnt) {
+    const float4* n = bvh.nodes + (size_t)ref * 4;
+    const float4 n0 = n[0], n1 = n[1], nz = n[2];
+    const uint4 cr = *reinterpret_cast<const uint4*>(n + 3);
+    if (COUNT) cnt.nodes++;
+    const float tbest = ANY_HIT ? tmax : hit.t;
+    const float a0x = (n0.x - sp.oL.x) * sp.idir.x, b0x = (n0.y - sp.oH.x) * sp.idir.x;
+    const float a0y = (n0.z - sp.oL.y) * sp.idir.y, b0y = (n0.w - sp.oH.y) * sp.idir.y;
+    const float a0z = (nz.x - sp.oL.z) * sp.idir.z, b0z = (nz.y - sp.oH.z) * sp.idir.z;
+    const float a1x = (n1.x - sp.oL.x) * sp.idir.x, b1x = (n1.y - sp.oH.x) * sp.idir.x;
+    const float a1y = (n1.z - sp.oL.y) * sp.idir.y, b1y = (n1.w - sp.oH.y) * sp.idir.y;
+    const float a1z = (nz.z - sp.oL.z) * sp.idir.z, b1z = (nz.w - sp.oH.z) * sp.idir.z;
+    const float tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), tmin));
+    const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), tbest));
+    const float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), tmin));
+    const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), tbest));
+    const bool h0 = (tn0 <= tf0) && (cr.x != BVH_INVALID_REF);
+    const bool h1 = (tn1 <= tf1) && (cr.y != BVH_INVALID_REF);
+    if (h0 && h1) {
+      const bool swap = tn1 < tn0;
+      const uint32_t nearc = swap ? cr.y : cr.x;
+      const uint32_t farc = swap ? cr.x : cr.y;
+      // the builder caps tree depth at stack_depth - 2, so this bound is never reached; it only
+      // keeps a malformed structure from writing outside the LDS allocation
+      if (top < (int)bvh.stack_depth) {
+        stack[(uint32_t)top * stride] = farc;
+        top++;
       }
-    } else if (ref & BVH_INST_BIT) {
-      // ---- instance leaf: move the ray into the object space of the instance ----
+      ref = nearc;
+    } else if (h0) {
+      ref = cr.x;
+    } else if (h1) {
+      ref = cr.y;
+    } else {
+      pop(bvh, stack, stride);
+    }
+  }
+
+  // ref is a leaf: an instance (move the ray into its object space) or up to 4 triangles
+  DEV void leaf_step(const DeviceBvh& bvh, uint32_t* stack, uint32_t stride, TraverseCounters& cnt) {
+    if (ref & BVH_INST_BIT) {
       const TlasEntry* e = bvh.entries + (ref & 0xFFFFu);
       const float4* ev = reinterpret_cast<const float4*>(e);
       const float4 r0 = ev[0], r1 = ev[1], r2 = ev[2];
@@ -193,41 +227,84 @@ DEV bool traverse(const DeviceBvh& bvh, f3 o, f3 d, float tmin, float tmax, uint
       id_bits = info.y;
       inst_sp = top;
       ref = info.x;
-    } else {
-      // ---- triangle leaf ----
-      const uint32_t first = (ref & 0x3FFFFFFFu) >> 2;
-      const uint32_t count = (ref & 3u) + 1u;
-      for (uint32_t i = 0; i < count; i++) {
-        const float4* tv = bvh.tris + (size_t)(first + i) * 3;
-        const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
-        if (COUNT) cnt.tris++;
-        float t, b1, b2;
-        if (tri_test(sp, xyz(v0), xyz(v1), xyz(v2), tmin, tmax, t, b1, b2)) {
-          if (ANY_HIT) {
-            hit.ip = 0;
-            return true;
-          }
-          const uint32_t ip = __float_as_uint(v0.w) | id_bits;
-          if (t < hit.t || (t == hit.t && hit.ip != 0xFFFFFFFFu && hit_key(ip) < hit_key(hit.ip))) {
-            hit.t = t;
-            hit.b1 = b1;
-            hit.b2 = b2;
-            hit.ip = ip;
-          }
+      return;
+    }
+    const uint32_t first = (ref & 0x3FFFFFFFu) >> 2;
+    const uint32_t count = (ref & 3u) + 1u;
+    for (uint32_t i = 0; i < count; i++) {
+      const float4* tv = bvh.tris + (size_t)(first + i) * 3;
+      const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+      if (COUNT) cnt.tris++;
+      float t, b1, b2;
+      if (tri_test(sp, xyz(v0), xyz(v1), xyz(v2), tmin, tmax, t, b1, b2)) {
+        if (ANY_HIT) {
+          hit.ip = 0;
+          ref = TRAV_DONE;
+          return;
+        }
+        const uint32_t ip = __float_as_uint(v0.w) | id_bits;
+        if (t < hit.t || (t == hit.t && hit.ip != 0xFFFFFFFFu && hit_key(ip) < hit_key(hit.ip))) {
+          hit.t = t;
+          hit.b1 = b1;
+          hit.b2 = b2;
+          hit.ip = ip;
         }
       }
-      pop = true;
     }
-    if (pop) {
-      if (top == inst_sp) {  // everything pushed inside the instance is consumed: back to world space
-        setup_space(sp, o, d, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
-        id_bits = 0;
-        inst_sp = -1;
-      }
-      if (top == 0) break;
-      top--;
-      ref = stack[(uint32_t)top * stride];
-    }
+    pop(bvh, stack, stride);
   }
+
+  // one wave-synchronous round: inner nodes until every lane holds a leaf, then the leaves
+  DEV void round(const DeviceBvh& bvh, uint32_t* stack, uint32_t stride, TraverseCounters& cnt) {
+    while (active() && !(ref & BVH_LEAF_BIT)) inner_step(bvh, stack, stride, cnt);
+    if (active()) leaf_step(bvh, stack, stride, cnt);
+  }
+};
+
+// One ray to completion (ray batches, tests). Returns true if something was hit; ANY_HIT stops at the
+// first accepted triangle (hit.ip = 0). `stack` points at this lane's column of the LDS stack.
+template <bool ANY_HIT, bool COUNT>
+DEV bool traverse(const DeviceBvh& bvh, f3 o, f3 d, float tmin, float tmax, uint32_t* stack, uint32_t stride, RayHit& hit, TraverseCounters& cnt) {
+  Traversal<ANY_HIT, COUNT> tr;
+  tr.start(bvh, o, d, tmin, tmax);
+  while (tr.active()) tr.round(bvh, stack, stride, cnt);
+  hit = tr.hit;
   return hit.ip != 0xFFFFFFFFu;
 }
+
+// Wave-level work distribution for the persistent trace kernels. Every wave owns a private chunk
+// [next, end) of the queue, refilled with ONE global atomic per WORK_CHUNK rays (a single head word
+// saturates at ~88 dequeues/us on MI355X); idle lanes take consecutive entries of the chunk, ranked
+// with ballot + popcount.
+#define WORK_CHUNK 256u
+struct WaveWork {
+  uint32_t next, end;
+  bool exhausted;
+  DEV void init() {
+    next = end = 0;
+    exhausted = false;
+  }
+  // For the lanes in `want`: returns the queue index each one takes, or 0xFFFFFFFF.
+  DEV uint32_t take(bool want, unsigned long long* head, uint32_t n) {
+    const unsigned long long mask = __ballot(want);
+    if (!mask) return 0xFFFFFFFFu;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (next >= end && !exhausted) {
+      uint32_t base = 0;
+      if (lane == 0) base = (uint32_t)atomicAdd(head, (unsigned long long)WORK_CHUNK);
+      base = (uint32_t)__shfl((int)base, 0, 64);
+      if (base >= n) {
+        exhausted = true;
+      } else {
+        next = base;
+        end = base + WORK_CHUNK < n ? base + WORK_CHUNK : n;
+      }
+    }
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const uint32_t idx = next + rank;
+    const uint32_t avail = end - next;
+    const uint32_t wanted = (uint32_t)__popcll(mask);
+    next += wanted < avail ? wanted : avail;
+    return (want && rank < avail) ? idx : 0xFFFFFFFFu;
+  }
+};
