@@ -421,7 +421,7 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err)
     out.root_ref = out.entries[0].root;
     out.top_is_world_blas = 1;
   } else {
-    if (out.entries.size() > 0xFFFF) {
+    if (out.entries.size() >= 0xFFFE) {  // 0xFFFE / 0xFFFF are the traversal's stack sentinels
       err = "too many top-level entries";
       return false;
     }

@@ -179,7 +179,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
 // re-packs its lanes — whenever REFILL_IDLE or more lanes have finished their ray, those lanes fetch
 // new rays (ballot + popcount ranking, WaveWork) while the others keep their traversal state.
 // ---------------------------------------------------------------------------------------------
-#define REFILL_IDLE 20
+#define REFILL_IDLE 20   // refill when this many lanes of the wave are idle
+#define INNER_MIN_LANES 12  // leave the inner-node loop when fewer lanes than this are still walking
 
 template <bool COUNT>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, uint32_t depth) {
@@ -189,10 +190,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, ui
   const uint32_t* queue = p.queue[depth & 1u];
   unsigned long long* head = &p.counters[CNT_HEAD0 + depth];
   uint32_t* stack = lds_stack + threadIdx.x;
-  const uint32_t stride = blockDim.x;
   TraverseCounters cnt;
   cnt.nodes = cnt.tris = 0;
-  Traversal<false, COUNT> tr;
+  Traversal<false, COUNT, STHIP_BLOCK> tr;
   tr.reset();
   WaveWork work;
   work.init();
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, ui
           p.hit[slot] = make_float4(__builtin_inff(), 0, 0, __uint_as_float(0xFFFFFFFFu));
         } else {
           const float4 ro = p.ray_o[slot], rd = p.ray_d[slot];
-          tr.start(p.bvh, xyz(ro), xyz(rd), 0.0f, __builtin_inff());
+          tr.start(p.bvh, stack, xyz(ro), xyz(rd), 0.0f, __builtin_inff());
           busy = true;
         }
       }
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, ui
         continue;
       }
     }
-    tr.round(p.bvh, stack, stride, cnt);
+    tr.round(p.bvh, stack, INNER_MIN_LANES, cnt);
     if (busy && !tr.active()) {
       p.hit[slot] = make_float4(tr.hit.t, tr.hit.b1, tr.hit.b2, __uint_as_float(tr.hit.ip));
       busy = false;
@@ -240,11 +240,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
   if (n == 0) return;
   unsigned long long* head = &p.counters[CNT_HEADS0 + depth];
   uint32_t* stack = lds_stack + threadIdx.x;
-  const uint32_t stride = blockDim.x;
   TraverseCounters cnt;
   cnt.nodes = cnt.tris = 0;
   float4* target = flag(p, STHIP_eDeferShadowRays) ? p.shadow_sum : p.radiance;
-  Traversal<true, COUNT> tr;
+  Traversal<true, COUNT, STHIP_BLOCK> tr;
   tr.reset();
   WaveWork work;
   work.init();
@@ -259,7 +258,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
         const float4 s0 = p.shadow_rays[3 * (size_t)idx], s1 = p.shadow_rays[3 * (size_t)idx + 1], s2 = p.shadow_rays[3 * (size_t)idx + 2];
         slot = __float_as_uint(s1.w);
         contribution = xyz(s2);
-        tr.start(p.bvh, xyz(s0), xyz(s1), 0.0f, s0.w);
+        tr.start(p.bvh, stack, xyz(s0), xyz(s1), 0.0f, s0.w);
         busy = true;
       }
       if (!__any(busy)) {
@@ -267,7 +266,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
         continue;
       }
     }
-    tr.round(p.bvh, stack, stride, cnt);
+    tr.round(p.bvh, stack, INNER_MIN_LANES, cnt);
     if (busy && !tr.active()) {
       if (tr.hit.ip == 0xFFFFFFFFu) {  // unoccluded: each pixel has at most one shadow ray per bounce
         float4 c = target[slot];
@@ -587,7 +586,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_batch(DeviceBvh bvh, cons
     const float4* r = reinterpret_cast<const float4*>(rays + i);
     const float4 a = r[0], b = r[1];
     RayHit h;
-    traverse<ANY_HIT, COUNT>(bvh, xyz(a), xyz(b), a.w, b.w, lds_stack + threadIdx.x, blockDim.x, h, cnt);
+    traverse<ANY_HIT, COUNT, STHIP_BLOCK>(bvh, xyz(a), xyz(b), a.w, b.w, lds_stack + threadIdx.x, h, cnt);
     sthip_hit out;
     out.t = h.t;
     out.b1 = h.b1;

@@ -5,11 +5,13 @@
 // closest hit over all triangles with (t, instance, primitive) ordering, any-hit = existence) is the
 // one stated in include/sthip.h and oracle/stratum_oracle.cpp; the acceleration structure must never
 // change the answer, so every box test is conservative:
-//   * the ray's origin is padded per ray by P = 4e-6 * (L1 distance to the bounding sphere centre +
-//     radius) of the space it is traversing, which bounds the rounding of the slab test and of the
-//     triangle test for every box the ray can reach;
-//   * slab distances use (plane - origin) * inv_dir (no fused form: it cancels catastrophically for
-//     near-axis-parallel rays), |dir| is clamped away from 0, comparisons are inclusive.
+//   * per ray and per axis the origin is padded by P_k = 4e-6 * (L1 distance to the bounding-sphere
+//     centre + radius) + 3e-7 * |o_k| of the space being traversed. The first term bounds the triangle
+//     test's own tolerance (~3e-7 * distance) for every box the ray can reach; the second bounds the
+//     rounding of the precomputed o_k / d_k, which lets the slab distance be ONE fma per plane
+//     (plane * inv_d - (o -+ P) * inv_d) without the cancellation that form has for rays whose origin
+//     is large compared with the box;
+//   * |dir| is clamped away from 0 and comparisons are inclusive.
 // One lane = one ray. The traversal stack is in LDS, laid out [level][lane] so that a wave's pushes
 // and pops of one level hit 64 consecutive banks.
 #pragma once
@@ -38,10 +40,10 @@ struct TraverseCounters {
 
 // per-space ray constants
 struct RaySpace {
-  f3 o, d;
-  f3 idir;
-  f3 oL, oH;  // origin +/- padding: (lo - oL) and (hi - oH) are the padded slab numerators
-  float Sx, Sy, Sz;
+  f3 o;               // origin in this space (triangle test)
+  f3 idir;            // 1 / d, |d| clamped away from 0
+  f3 noodL, noodH;    // -(o + P) * idir and -(o - P) * idir: slab distance = fma(plane, idir, nood)
+  float Sx, Sy, Sz;   // watertight shear constants
   int kx, ky, kz;
 };
 
@@ -53,11 +55,11 @@ DEV float safe_rcp_dir(float d) {
 
 DEV void setup_space(RaySpace& s, f3 o, f3 d, float cx, float cy, float cz, float radius) {
   s.o = o;
-  s.d = d;
   s.idir = F3(safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z));
   const float P = 4e-6f * (fabsf(o.x - cx) + fabsf(o.y - cy) + fabsf(o.z - cz) + radius);
-  s.oL = F3(o.x + P, o.y + P, o.z + P);
-  s.oH = F3(o.x - P, o.y - P, o.z - P);
+  const float Px = P + 3e-7f * fabsf(o.x), Py = P + 3e-7f * fabsf(o.y), Pz = P + 3e-7f * fabsf(o.z);
+  s.noodL = F3(-(o.x + Px) * s.idir.x, -(o.y + Py) * s.idir.y, -(o.z + Pz) * s.idir.z);
+  s.noodH = F3(-(o.x - Px) * s.idir.x, -(o.y - Py) * s.idir.y, -(o.z - Pz) * s.idir.z);
   // watertight shear constants (Woop, Benthin, Wald 2013)
   int kz = 0;
   float m = fabsf(d.x);
@@ -121,27 +123,29 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
   return true;
 }
 
-#define TRAV_DONE 0xFFFFFFFFu
+// stack sentinels (both carry the leaf bits, so the inner-node loop hands them to the leaf handler)
+#define TRAV_DONE 0xFFFFFFFFu           // bottom of the stack: the ray is finished
+#define TRAV_EXIT_INSTANCE 0xFFFFFFFEu  // pushed when a transformed instance is entered
 
 // Per-lane traversal state machine. `ref` is the next thing to process: an inner-node index, a leaf
-// reference, or TRAV_DONE. The drivers below run it "while-while": every lane of the wave walks inner
-// nodes until it holds a leaf (or is done), then the wave processes leaves together, so that the long
-// triangle code is not executed once per inner-node step of some other lane.
-template <bool ANY_HIT, bool COUNT>
+// reference or a sentinel. It runs "while-while": every lane of the wave walks inner nodes until it
+// holds a leaf, then the wave processes leaves together, so that the long triangle code is not executed
+// once per inner-node step of some other lane. The inner loop is kept minimal: no emptiness or
+// instance checks on pop (sentinels on the stack do that), one fma per slab plane, 32-bit offsets.
+template <bool ANY_HIT, bool COUNT, uint32_t STRIDE>
 struct Traversal {
   f3 o, d;  // world-space ray
   float tmin, tmax;
   RaySpace sp;  // the space currently being traversed (world, or the object space of an instance)
   RayHit hit;
   uint32_t ref;
-  int top;      // stack height
-  int inst_sp;  // stack height at which the current instance was entered, -1 in world space
+  uint32_t top;  // stack height in entries * STRIDE (an LDS word offset)
   uint32_t id_bits;
 
   DEV bool active() const { return ref != TRAV_DONE; }
   DEV void reset() { ref = TRAV_DONE; }
 
-  DEV void start(const DeviceBvh& bvh, f3 ro, f3 rd, float t0, float t1) {
+  DEV void start(const DeviceBvh& bvh, uint32_t* stack, f3 ro, f3 rd, float t0, float t1) {
     o = ro;
     d = rd;
     tmin = t0;
@@ -149,90 +153,87 @@ struct Traversal {
     hit.t = t1;
     hit.b1 = hit.b2 = 0.0f;
     hit.ip = 0xFFFFFFFFu;
-    top = 0;
-    inst_sp = -1;
+    stack[0] = TRAV_DONE;
+    top = STRIDE;
     id_bits = 0;
     ref = bvh.root_ref;  // BVH_INVALID_REF == TRAV_DONE for an empty scene
     setup_space(sp, ro, rd, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
   }
 
-  DEV void pop(const DeviceBvh& bvh, const uint32_t* stack, uint32_t stride) {
-    if (top == inst_sp) {  // everything pushed inside the instance is consumed: back to world space
-      setup_space(sp, o, d, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
-      id_bits = 0;
-      inst_sp = -1;
-    }
-    if (top == 0) {
-      ref = TRAV_DONE;
-    } else {
-      top--;
-      ref = stack[(uint32_t)top * stride];
-    }
+  DEV void pop(const uint32_t* stack) {
+    top -= STRIDE;
+    ref = stack[top];
   }
 
-  // ref is an inner node: test both children, descend into the nearer, push the farther
-  DEV void inner_step(const DeviceBvh& bvh, uint32_t* stack, uint32_t stride, TraverseCounters& cnt) {
-    const float4* n = bvh.nodes + (size_t)ref * 4;
-    const float4 n0 = n[0], n1 = n[1], nz = n[2];
-    const uint4 cr = *reinterpret_cast<const uint4*>(n + 3);
-    if (COUNT) cnt.nodes++;
-    const float tbest = ANY_HIT ? tmax : hit.t;
-    const float a0x = (n0.x - sp.oL.x) * sp.idir.x, b0x = (n0.y - sp.oH.x) * sp.idir.x;
-    const float a0y = (n0.z - sp.oL.y) * sp.idir.y, b0y = (n0.w - sp.oH.y) * sp.idir.y;
-    const float a0z = (nz.x - sp.oL.z) * sp.idir.z, b0z = (nz.y - sp.oH.z) * sp.idir.z;
-    const float a1x = (n1.x - sp.oL.x) * sp.idir.x, b1x = (n1.y - sp.oH.x) * sp.idir.x;
-    const float a1y = (n1.z - sp.oL.y) * sp.idir.y, b1y = (n1.w - sp.oH.y) * sp.idir.y;
-    const float a1z = (nz.z - sp.oL.z) * sp.idir.z, b1z = (nz.w - sp.oH.z) * sp.idir.z;
-    const float tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), tmin));
-    const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), tbest));
-    const float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), tmin));
-    const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), tbest));
-    const bool h0 = (tn0 <= tf0) && (cr.x != BVH_INVALID_REF);
-    const bool h1 = (tn1 <= tf1) && (cr.y != BVH_INVALID_REF);
-    if (h0 && h1) {
-      const bool swap = tn1 < tn0;
-      const uint32_t nearc = swap ? cr.y : cr.x;
-      const uint32_t farc = swap ? cr.x : cr.y;
-      // the builder caps tree depth at stack_depth - 2, so this bound is never reached; it only
-      // keeps a malformed structure from writing outside the LDS allocation
-      if (top < (int)bvh.stack_depth) {
-        stack[(uint32_t)top * stride] = farc;
-        top++;
+  // Walks inner nodes until `ref` is a leaf or a sentinel, or until fewer than `min_lanes` lanes of the
+  // wave are still walking (the others would only wait for them).
+  DEV void inner_loop(const DeviceBvh& bvh, uint32_t* stack, uint32_t min_lanes, TraverseCounters& cnt) {
+    const char* base = reinterpret_cast<const char*>(bvh.nodes);
+    while (!(ref & BVH_LEAF_BIT)) {
+      const float4* n = reinterpret_cast<const float4*>(base + ((size_t)ref << 6));
+      const float4 n0 = n[0], n1 = n[1], nz = n[2];
+      const uint2 cr = *reinterpret_cast<const uint2*>(n + 3);
+      if (COUNT) cnt.nodes++;
+      const float tbest = ANY_HIT ? tmax : hit.t;
+      const float a0x = fmaf(n0.x, sp.idir.x, sp.noodL.x), b0x = fmaf(n0.y, sp.idir.x, sp.noodH.x);
+      const float a0y = fmaf(n0.z, sp.idir.y, sp.noodL.y), b0y = fmaf(n0.w, sp.idir.y, sp.noodH.y);
+      const float a0z = fmaf(nz.x, sp.idir.z, sp.noodL.z), b0z = fmaf(nz.y, sp.idir.z, sp.noodH.z);
+      const float a1x = fmaf(n1.x, sp.idir.x, sp.noodL.x), b1x = fmaf(n1.y, sp.idir.x, sp.noodH.x);
+      const float a1y = fmaf(n1.z, sp.idir.y, sp.noodL.y), b1y = fmaf(n1.w, sp.idir.y, sp.noodH.y);
+      const float a1z = fmaf(nz.z, sp.idir.z, sp.noodL.z), b1z = fmaf(nz.w, sp.idir.z, sp.noodH.z);
+      const float tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), tmin));
+      const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), tbest));
+      const float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), tmin));
+      const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), tbest));
+      const bool h0 = (tn0 <= tf0) && (cr.x != BVH_INVALID_REF);
+      const bool h1 = (tn1 <= tf1) && (cr.y != BVH_INVALID_REF);
+      if (h0 | h1) {
+        const bool first1 = h1 && (!h0 || tn1 < tn0);  // descend into child 1 first
+        ref = first1 ? cr.y : cr.x;
+        if (h0 & h1) {  // the builder's exact stack bound makes the push safe
+          stack[top] = first1 ? cr.x : cr.y;
+          top += STRIDE;
+        }
+      } else {
+        pop(stack);
       }
-      ref = nearc;
-    } else if (h0) {
-      ref = cr.x;
-    } else if (h1) {
-      ref = cr.y;
-    } else {
-      pop(bvh, stack, stride);
+      if (min_lanes > 1 && (uint32_t)__popcll(__ballot(!(ref & BVH_LEAF_BIT))) < min_lanes) break;
     }
   }
 
-  // ref is a leaf: an instance (move the ray into its object space) or up to 4 triangles
-  DEV void leaf_step(const DeviceBvh& bvh, uint32_t* stack, uint32_t stride, TraverseCounters& cnt) {
+  // ref has the leaf bit: a sentinel, an instance, or up to 4 triangles
+  DEV void leaf_step(const DeviceBvh& bvh, uint32_t* stack, TraverseCounters& cnt) {
+    if (ref >= TRAV_EXIT_INSTANCE) {
+      if (ref == TRAV_EXIT_INSTANCE) {  // everything pushed inside the instance is consumed: back to world space
+        setup_space(sp, o, d, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
+        id_bits = 0;
+        pop(stack);
+      }
+      return;  // TRAV_DONE stays
+    }
     if (ref & BVH_INST_BIT) {
       const TlasEntry* e = bvh.entries + (ref & 0xFFFFu);
       const float4* ev = reinterpret_cast<const float4*>(e);
-      const float4 r0 = ev[0], r1 = ev[1], r2 = ev[2];
       const uint4 info = *reinterpret_cast<const uint4*>(ev + 3);
-      const float4 sph = ev[4];
-      const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-      f3 oo = o, od = d;
       if (!info.z) {
-        oo = obj_point(m, o);
-        od = obj_vector(m, d);
+        const float4 r0 = ev[0], r1 = ev[1], r2 = ev[2];
+        const float4 sph = ev[4];
+        const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+        setup_space(sp, obj_point(m, o), obj_vector(m, d), sph.x, sph.y, sph.z, sph.w);
+        id_bits = info.y;
+        stack[top] = TRAV_EXIT_INSTANCE;
+        top += STRIDE;
       }
-      setup_space(sp, oo, od, sph.x, sph.y, sph.z, sph.w);
-      id_bits = info.y;
-      inst_sp = top;
+      // identity entry (the merged world-space mesh): same ray, same (larger, still conservative) padding,
+      // id_bits stays 0 because its triangles carry their instance index themselves
       ref = info.x;
       return;
     }
     const uint32_t first = (ref & 0x3FFFFFFFu) >> 2;
     const uint32_t count = (ref & 3u) + 1u;
+    const char* tbase = reinterpret_cast<const char*>(bvh.tris);
     for (uint32_t i = 0; i < count; i++) {
-      const float4* tv = bvh.tris + (size_t)(first + i) * 3;
+      const float4* tv = reinterpret_cast<const float4*>(tbase + (size_t)((first + i) * 48u));
       const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
       if (COUNT) cnt.tris++;
       float t, b1, b2;
@@ -251,23 +252,23 @@ struct Traversal {
         }
       }
     }
-    pop(bvh, stack, stride);
+    pop(stack);
   }
 
-  // one wave-synchronous round: inner nodes until every lane holds a leaf, then the leaves
-  DEV void round(const DeviceBvh& bvh, uint32_t* stack, uint32_t stride, TraverseCounters& cnt) {
-    while (active() && !(ref & BVH_LEAF_BIT)) inner_step(bvh, stack, stride, cnt);
-    if (active()) leaf_step(bvh, stack, stride, cnt);
+  // one wave-synchronous round: inner nodes until (almost) every lane holds a leaf, then the leaves
+  DEV void round(const DeviceBvh& bvh, uint32_t* stack, uint32_t min_lanes, TraverseCounters& cnt) {
+    if (active()) inner_loop(bvh, stack, min_lanes, cnt);
+    if (active() && (ref & BVH_LEAF_BIT)) leaf_step(bvh, stack, cnt);
   }
 };
 
 // One ray to completion (ray batches, tests). Returns true if something was hit; ANY_HIT stops at the
 // first accepted triangle (hit.ip = 0). `stack` points at this lane's column of the LDS stack.
-template <bool ANY_HIT, bool COUNT>
-DEV bool traverse(const DeviceBvh& bvh, f3 o, f3 d, float tmin, float tmax, uint32_t* stack, uint32_t stride, RayHit& hit, TraverseCounters& cnt) {
-  Traversal<ANY_HIT, COUNT> tr;
-  tr.start(bvh, o, d, tmin, tmax);
-  while (tr.active()) tr.round(bvh, stack, stride, cnt);
+template <bool ANY_HIT, bool COUNT, uint32_t STRIDE>
+DEV bool traverse(const DeviceBvh& bvh, f3 o, f3 d, float tmin, float tmax, uint32_t* stack, RayHit& hit, TraverseCounters& cnt) {
+  Traversal<ANY_HIT, COUNT, STRIDE> tr;
+  tr.start(bvh, stack, o, d, tmin, tmax);
+  while (tr.active()) tr.round(bvh, stack, 1, cnt);
   hit = tr.hit;
   return hit.ip != 0xFFFFFFFFu;
 }
