@@ -6,6 +6,7 @@
 // (src/Node/Denoiser.cpp:73,186-213). There is no CPU fallback: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -71,6 +72,7 @@ struct sthip_ctx {
   uint32_t shard_rank = 0, shard_count = 1, tile_w = 64, tile_h = 32;
   // options / stats
   bool count_traversal = false, time_kernels = false;
+  uint32_t refill_idle = 16, inner_min_lanes = 24, trace_blocks_per_cu = 0;
   sthip_stats stats{};
   bool stats_pending = false;  // ray / traversal counters of the last render still live on the device
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -201,6 +203,12 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->count_traversal = value != 0;
   else if (!strcmp(name, "time_kernels"))
     ctx->time_kernels = value != 0;
+  else if (!strcmp(name, "refill_idle"))
+    ctx->refill_idle = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
+  else if (!strcmp(name, "trace_blocks_per_cu"))
+    ctx->trace_blocks_per_cu = (uint32_t)std::min<int64_t>(16, std::max<int64_t>(0, value));
+  else if (!strcmp(name, "inner_min_lanes"))
+    ctx->inner_min_lanes = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
   else
     return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, std::string("unknown option ") + name);
   return STHIP_OK;
@@ -223,6 +231,8 @@ int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out) {
   out->bvh_tris = ctx->bvh_tris;
   return STHIP_OK;
 }
+
+static size_t stack_bytes(const sthip_ctx* ctx);
 
 int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
@@ -296,6 +306,12 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->bvh_nodes = built.nodes.size();
   ctx->bvh_tris = built.tris.size();
   ctx->has_scene = true;
+  if (getenv("STHIP_VERBOSE")) {
+    int per_cu = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false>, STHIP_BLOCK, stack_bytes(ctx));
+    fprintf(stderr, "[sthip] bvh: %zu nodes, %zu tris, %zu top-level entries, stack depth %u (%zu B LDS / block), %d trace blocks / CU\n", built.nodes.size(),
+            built.tris.size(), built.entries.size(), built.stack_depth, stack_bytes(ctx), per_cu);
+  }
   return STHIP_OK;
 }
 
@@ -308,6 +324,7 @@ static uint32_t grid_for(const sthip_ctx* ctx, size_t n) {
 static uint32_t trace_grid(sthip_ctx* ctx, size_t lds_bytes) {
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false>, STHIP_BLOCK, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (ctx->trace_blocks_per_cu) per_cu = (int)ctx->trace_blocks_per_cu;
   return (uint32_t)(ctx->cu_count * per_cu);
 }
 static size_t stack_bytes(const sthip_ctx* ctx) { return (size_t)ctx->bvh.stack_depth * STHIP_BLOCK * sizeof(uint32_t); }
@@ -461,6 +478,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.shadow_rays = ctx->shadow_rays.p;
   p.counters = ctx->counters.p;
   p.count_traversal = ctx->count_traversal ? 1u : 0u;
+  p.refill_idle = ctx->refill_idle;
+  p.inner_min_lanes = ctx->inner_min_lanes;
 
   // outputs: device pointers are written in place, host pointers go through staging buffers
   const bool dev = out->device_ptrs != 0;

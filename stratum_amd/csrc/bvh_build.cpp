@@ -8,6 +8,7 @@
 #include "bvh_build.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -254,7 +255,7 @@ inline void load_tri(const sthip_scene_desc& s, const InstView& in, uint32_t pri
 
 bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err) {
   out = BuiltBvh();
-  const uint32_t BLAS_DEPTH_CAP = 24, TLAS_DEPTH_CAP = 18;
+  const uint32_t BLAS_DEPTH_CAP = 22, TLAS_DEPTH_CAP = 18;
   // ---- validate + classify ----
   std::vector<uint32_t> merged, separate;
   for (uint32_t i = 0; i < s.instance_count; i++) {
@@ -302,7 +303,9 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err)
       for (int v = 0; v < 3; v++) boxes[k].grow(s.gVertices[tri[v]].position);
       bounds.grow(boxes[k]);
     }
-    Builder b(boxes, BVH_MAX_LEAF_TRIS, BLAS_DEPTH_CAP);
+    uint32_t leaf_tris = BVH_MAX_LEAF_TRIS;
+    if (const char* e = getenv("STHIP_LEAF_TRIS")) leaf_tris = (uint32_t)std::min(4, std::max(1, atoi(e)));  // tuning experiments
+    Builder b(boxes, leaf_tris, BLAS_DEPTH_CAP);
     depth = b.max_depth;
     const uint32_t tri_base = (uint32_t)out.tris.size();
     out.tris.resize(tri_base + prims.size());

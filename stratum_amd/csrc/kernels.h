@@ -66,6 +66,8 @@ struct FrameParams {
   float2* out_prev_uv;
   uint32_t write_aov;
   uint32_t count_traversal;
+  uint32_t refill_idle;      // persistent trace kernels: refill when this many lanes of a wave are idle
+  uint32_t inner_min_lanes;  // leave the inner-node loop when fewer lanes than this are still walking
 };
 
 DEV bool flag(const FrameParams& p, int bit) { return (p.sampling_flags >> bit) & 1u; }
@@ -179,8 +181,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
 // re-packs its lanes — whenever REFILL_IDLE or more lanes have finished their ray, those lanes fetch
 // new rays (ballot + popcount ranking, WaveWork) while the others keep their traversal state.
 // ---------------------------------------------------------------------------------------------
-#define REFILL_IDLE 20   // refill when this many lanes of the wave are idle
-#define INNER_MIN_LANES 12  // leave the inner-node loop when fewer lanes than this are still walking
+
 
 template <bool COUNT>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, uint32_t depth) {
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, ui
   bool busy = false;  // this lane holds a ray whose hit is not stored yet
   for (;;) {
     const unsigned long long idle = __ballot(!busy);
-    if ((uint32_t)__popcll(idle) >= REFILL_IDLE || idle == ~0ull) {
+    if ((uint32_t)__popcll(idle) >= p.refill_idle || idle == ~0ull) {
       const uint32_t idx = work.take(!busy, head, n);
       if (idx != 0xFFFFFFFFu) {
         slot = depth == 0 ? idx : queue[idx];
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, ui
         continue;
       }
     }
-    tr.round(p.bvh, stack, INNER_MIN_LANES, cnt);
+    tr.round(p.bvh, stack, p.inner_min_lanes, cnt);
     if (busy && !tr.active()) {
       p.hit[slot] = make_float4(tr.hit.t, tr.hit.b1, tr.hit.b2, __uint_as_float(tr.hit.ip));
       busy = false;
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
   bool busy = false;
   for (;;) {
     const unsigned long long idle = __ballot(!busy);
-    if ((uint32_t)__popcll(idle) >= REFILL_IDLE || idle == ~0ull) {
+    if ((uint32_t)__popcll(idle) >= p.refill_idle || idle == ~0ull) {
       const uint32_t idx = work.take(!busy, head, n);
       if (idx != 0xFFFFFFFFu) {
         const float4 s0 = p.shadow_rays[3 * (size_t)idx], s1 = p.shadow_rays[3 * (size_t)idx + 1], s2 = p.shadow_rays[3 * (size_t)idx + 2];
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
         continue;
       }
     }
-    tr.round(p.bvh, stack, INNER_MIN_LANES, cnt);
+    tr.round(p.bvh, stack, p.inner_min_lanes, cnt);
     if (busy && !tr.active()) {
       if (tr.hit.ip == 0xFFFFFFFFu) {  // unoccluded: each pixel has at most one shadow ray per bounce
         float4 c = target[slot];
