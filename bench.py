@@ -49,6 +49,21 @@ def host_threads():
     return n
 
 
+def measured_traffic():
+    """HBM-side bytes per live k_trace_closest launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+    their own rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes; tools/pmc.sh + tools/traffic.py).
+    Counters cannot be read from inside this process, so this is the value of the newest committed profile."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")))
+    if not files:
+        return None
+    try:
+        return round(json.load(open(files[-1]))["bytes_per_launch"], 1)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,7 +175,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": measured_traffic(),
             "bytes_per_launch": round(alg_bytes / max(launches, 1), 1),
             "launch_ms": round(ms_closest / max(launches, 1), 4),
             "nodes_per_ray": round(nodes / max(rays_closest, 1), 2),

@@ -64,9 +64,9 @@ class OracleScene:
             raise RuntimeError("orc_scene_create failed")
 
     def close(self):
-        if self.h:
-            lib().orc_scene_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.orc_scene_destroy(self.h)
+        self.h = None
 
     def __del__(self):
         self.close()
