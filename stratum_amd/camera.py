@@ -60,10 +60,11 @@ def look_at(eye, target, up=(0.0, 1.0, 0.0)):
 
 
 def inverse_transform(t):
+    from .scene import transform_inverse
+
     out = np.zeros_like(t)
     for i in range(t.shape[0]):
-        m = np.vstack([t["m"][i].astype(np.float64), [0, 0, 0, 1]])
-        out["m"][i] = np.linalg.inv(m)[:3, :].astype(np.float32)
+        out["m"][i] = transform_inverse(t["m"][i])  # views[i].second.inverse(), BDPT.cpp:452
     return out
 
 

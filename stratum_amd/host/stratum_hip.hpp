@@ -1,0 +1,690 @@
+// stratum_hip.hpp — C++ host side above the C ABI (include/sthip.h): the slice of Stratum's host
+// interface that feeds and drives the path-tracing hot path, with the reference's own names, argument
+// meaning and error behaviour (exceptions), so that host code written against Stratum keeps compiling:
+//
+//   stm::NodeGraph / Node / component_ptr<T> / Node::Event     src/Node/NodeGraph.hpp:13-360
+//   stm::TransformData helpers, make_perspective, quatf        src/Shaders/transform.h, quatf.h
+//   stm::Material, Mesh, MeshPrimitive, Camera                 src/Node/Material.hpp, Scene.hpp:15-37
+//   stm::node_to_world                                         src/Node/Scene.cpp:108-117
+//   stm::Application (OnUpdate / OnRenderWindow only)          src/Node/Application.hpp:11-29
+//   stm::Scene  (update() packs SceneData, data())             src/Node/Scene.hpp:44-69, Scene.cpp:299-684
+//   stm::BDPT   (update(), render(), prev_result())            src/Node/BDPT.hpp:13-24, BDPT.cpp:35-127,341-838
+//
+// What is NOT here: Vulkan (Device, CommandBuffer, Image, Buffer), loaders, GUI, window. The
+// CommandBuffer& parameters of the reference's signatures become an opaque stm::CommandBuffer that carries
+// the HIP stream. The reference needs Eigen for its vector types; this header uses plain arrays (Eigen is
+// not in the image), so float3 etc. are minimal structs.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <queue>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <typeindex>
+#include <unordered_map>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+#include "../../include/sthip.h"
+
+namespace stm {
+
+// ------------------------------------------------------------------------------------------------
+// NodeGraph.hpp:13-360
+// ------------------------------------------------------------------------------------------------
+class Node;
+class NodeGraph;
+
+template <typename T>
+class component_ptr {
+ public:
+  component_ptr() = default;
+  component_ptr(std::nullptr_t) {}
+  component_ptr(Node* n, T* c) : mNode(n), mComponent(c) {}
+  component_ptr(const Node* n, T* c) : mNode(const_cast<Node*>(n)), mComponent(c) {}
+  Node& node() const { return *mNode; }
+  operator bool() const { return mComponent != nullptr; }
+  T& operator*() const { return *mComponent; }
+  T* operator->() const { return mComponent; }
+  T* get() const { return mComponent; }
+  void reset() {
+    mNode = nullptr;
+    mComponent = nullptr;
+  }
+
+ private:
+  Node* mNode = nullptr;
+  T* mComponent = nullptr;
+};
+
+class NodeGraph {
+ public:
+  bool empty() const { return mNodes.empty(); }
+  bool contains(const Node* ptr) const { return mNodes.count(ptr) != 0; }
+  inline Node& emplace(const std::string& name);
+  inline void erase(Node& node);
+  template <typename T>
+  size_t component_count() const {
+    auto it = mComponentMap.find(typeid(T));
+    return it == mComponentMap.end() ? 0 : it->second.mComponents.size();
+  }
+  inline ~NodeGraph();
+
+ private:
+  friend class Node;
+  struct component_map {
+    void (*mDestructor)(const void*);
+    std::unordered_map<const Node*, void*> mComponents;
+  };
+  std::unordered_map<const Node*, std::unique_ptr<Node>> mNodes;
+  std::unordered_map<std::type_index, component_map> mComponentMap;
+};
+
+class Node {
+ public:
+  enum EventPriority : uint32_t { eFirst = 0, eAlmostFirst = 0x3FFFFFFF, eDefault = 0x7FFFFFFF, eAlmostLast = 0xBFFFFFFD, eLast = 0xFFFFFFFF };
+
+  template <typename... Args>
+  class Event {
+   public:
+    using function_t = std::function<void(Args...)>;
+    void clear() { mListeners.clear(); }
+    bool empty() const { return mListeners.empty(); }
+    void add_listener(const Node& node, function_t&& fn, uint32_t priority = EventPriority::eDefault) {
+      mListeners.emplace_back(&node, std::move(fn), priority);
+      std::stable_sort(mListeners.begin(), mListeners.end(), [](const auto& a, const auto& b) { return std::get<2>(a) < std::get<2>(b); });
+      if (!mNodeGraph) mNodeGraph = &node.node_graph();
+    }
+    void erase(const Node& node) {
+      for (auto it = mListeners.begin(); it != mListeners.end();) it = (std::get<0>(*it) == &node) ? mListeners.erase(it) : it + 1;
+    }
+    void operator()(Args... args) const {
+      auto tmp = mListeners;  // listeners may add/remove listeners
+      for (const auto& l : tmp)
+        if (mNodeGraph->contains(std::get<0>(l))) std::get<1>(l)(args...);
+    }
+
+   private:
+    const NodeGraph* mNodeGraph = nullptr;
+    std::vector<std::tuple<const Node*, function_t, uint32_t>> mListeners;
+  };
+
+  Node(const Node&) = delete;
+  ~Node() {
+    for (const std::type_index& t : mComponents) {
+      auto& cm = mNodeGraph.mComponentMap.at(t);
+      auto it = cm.mComponents.find(this);
+      if (it != cm.mComponents.end()) {
+        cm.mDestructor(it->second);
+        cm.mComponents.erase(it);
+      }
+    }
+  }
+
+  const std::string& name() const { return mName; }
+  NodeGraph& node_graph() const { return mNodeGraph; }
+  Node* parent() const { return mParent; }
+  // children in insertion order (the reference keeps edges in an unordered_multimap, NodeGraph.hpp:152, so its
+  // instance order follows the hash function; a deterministic order is kept here so that packing is reproducible)
+  const std::vector<Node*>& children() const { return mChildren; }
+  void set_parent(Node& parent) {
+    if (mParent == &parent) return;
+    clear_parent();
+    parent.mChildren.push_back(this);
+    mParent = &parent;
+  }
+  void clear_parent() {
+    if (!mParent) return;
+    auto& c = mParent->mChildren;
+    c.erase(std::remove(c.begin(), c.end(), this), c.end());
+    mParent = nullptr;
+  }
+  Node& root() {
+    Node* r = this;
+    while (r->mParent) r = r->mParent;
+    return *r;
+  }
+  Node& make_child(const std::string& name) {
+    Node& n = mNodeGraph.emplace(name);
+    n.set_parent(*this);
+    return n;
+  }
+
+  // make_component<T>(args...): T(args...), T(Node*, args...) or T(Node&, args...), NodeGraph.hpp:247-268
+  template <typename T, typename... Args>
+  component_ptr<T> make_component(Args&&... args) {
+    if (mComponents.count(typeid(T))) throw std::logic_error("Cannot make multiple components of the same type within the same node");
+    auto it = mNodeGraph.mComponentMap.find(typeid(T));
+    if (it == mNodeGraph.mComponentMap.end())
+      it = mNodeGraph.mComponentMap.emplace(typeid(T), NodeGraph::component_map{[](const void* p) { delete reinterpret_cast<const T*>(p); }, {}}).first;
+    T* ptr;
+    if constexpr (std::is_constructible_v<T, Node&, Args...>)
+      ptr = new T(*this, std::forward<Args>(args)...);
+    else if constexpr (std::is_constructible_v<T, Node*, Args...>)
+      ptr = new T(this, std::forward<Args>(args)...);
+    else
+      ptr = new T(std::forward<Args>(args)...);
+    mComponents.emplace(typeid(T));
+    it->second.mComponents[this] = ptr;
+    return component_ptr<T>(this, ptr);
+  }
+  template <typename T>
+  component_ptr<T> find() const {
+    auto it = mNodeGraph.mComponentMap.find(typeid(T));
+    if (it == mNodeGraph.mComponentMap.end()) return {};
+    auto c = it->second.mComponents.find(this);
+    return c == it->second.mComponents.end() ? component_ptr<T>() : component_ptr<T>(this, reinterpret_cast<T*>(c->second));
+  }
+  template <typename T>
+  component_ptr<T> find_in_ancestor() const {
+    for (const Node* n = this; n; n = n->mParent)
+      if (auto c = n->find<T>()) return c;
+    return {};
+  }
+  template <typename T>
+  component_ptr<T> find_in_descendants() const {
+    component_ptr<T> r;
+    for_each_descendant<T>([&](const component_ptr<T>& c) {
+      if (!r) r = c;
+    });
+    return r;
+  }
+  // breadth-first over this node and its descendants, NodeGraph.hpp:329-346
+  template <typename T, typename F>
+  void for_each_descendant(F&& fn) const {
+    std::queue<const Node*> q;
+    q.push(this);
+    while (!q.empty()) {
+      const Node* n = q.front();
+      q.pop();
+      if (auto c = n->find<T>()) fn(c);
+      for (Node* c : n->children()) q.push(c);
+    }
+  }
+
+ private:
+  friend class NodeGraph;
+  Node(NodeGraph& g, const std::string& name) : mNodeGraph(g), mName(name), mParent(nullptr) {}
+  NodeGraph& mNodeGraph;
+  std::string mName;
+  Node* mParent;
+  std::unordered_set<std::type_index> mComponents;
+  std::vector<Node*> mChildren;
+};
+
+inline Node& NodeGraph::emplace(const std::string& name) {
+  Node* ptr = new Node(*this, name);
+  mNodes.emplace(ptr, std::unique_ptr<Node>(ptr));
+  return *ptr;
+}
+inline void NodeGraph::erase(Node& node) {
+  const std::vector<Node*> kids = node.children();
+  for (Node* c : kids) c->clear_parent();
+  node.clear_parent();
+  mNodes.erase(&node);
+}
+inline NodeGraph::~NodeGraph() {
+  for (auto& n : mNodes) {
+    n.second->mParent = nullptr;
+    n.second->mChildren.clear();
+  }
+  mNodes.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// vector / transform helpers (Common/hlsl_compat.hpp aliases Eigen; plain structs here)
+// ------------------------------------------------------------------------------------------------
+struct float2 {
+  float x = 0, y = 0;
+};
+struct float3 {
+  float x = 0, y = 0, z = 0;
+  float& operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }
+  float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+struct quatf {
+  float3 xyz;
+  float w = 1;
+};
+inline quatf quatf_identity() { return quatf{{0, 0, 0}, 1}; }
+inline quatf angle_axis(float angle, float3 axis) {  // quatf.h:27-29
+  const float s = std::sin(angle / 2);
+  return quatf{{axis.x * s, axis.y * s, axis.z * s}, std::cos(angle / 2)};
+}
+
+using TransformData = sthip_TransformData;
+using ProjectionData = sthip_ProjectionData;
+using ViewData = sthip_ViewData;
+using InstanceData = sthip_InstanceData;
+using PackedVertexData = sthip_PackedVertexData;
+using BDPTPushConstants = sthip_BDPTPushConstants;
+using VisibilityInfo = sthip_VisibilityInfo;
+using DepthInfo = sthip_DepthInfo;
+
+// make_transform, transform.h:47-52: translation * rotation(quaternion) * scaling, the standard rotation matrix
+// Eigen produces on the reference's host side
+inline TransformData make_transform(float3 t, quatf r, float3 s) {
+  TransformData o;
+  const float sqw = r.w * r.w, sqx = r.xyz.x * r.xyz.x, sqy = r.xyz.y * r.xyz.y, sqz = r.xyz.z * r.xyz.z;
+  const float invs = 1 / (sqx + sqy + sqz + sqw);
+  float m[3][3];
+  m[0][0] = (sqx - sqy - sqz + sqw) * invs;
+  m[1][1] = (-sqx + sqy - sqz + sqw) * invs;
+  m[2][2] = (-sqx - sqy + sqz + sqw) * invs;
+  float tmp1 = r.xyz.x * r.xyz.y, tmp2 = r.xyz.z * r.w;
+  m[1][0] = 2 * (tmp1 + tmp2) * invs;
+  m[0][1] = 2 * (tmp1 - tmp2) * invs;
+  tmp1 = r.xyz.x * r.xyz.z;
+  tmp2 = r.xyz.y * r.w;
+  m[2][0] = 2 * (tmp1 - tmp2) * invs;
+  m[0][2] = 2 * (tmp1 + tmp2) * invs;
+  tmp1 = r.xyz.y * r.xyz.z;
+  tmp2 = r.xyz.x * r.w;
+  m[2][1] = 2 * (tmp1 + tmp2) * invs;
+  m[1][2] = 2 * (tmp1 - tmp2) * invs;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) o.m[i][j] = m[i][j] * s[j];  // rotation * scaling
+    o.m[i][3] = t[i];
+  }
+  return o;
+}
+inline TransformData transform_identity() { return make_transform({0, 0, 0}, quatf_identity(), {1, 1, 1}); }
+// transform.h:88-104
+inline TransformData tmul(const TransformData& a, const TransformData& b) {
+  TransformData r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) {
+      float s = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+      if (j == 3) s += a.m[i][3];
+      r.m[i][j] = s;
+    }
+  return r;
+}
+// TransformData::inverse(), transform.h:26-31: the reference takes Eigen's 4x4 inverse. Pinned here (and in
+// stratum_amd/scene.py) as the adjugate of the 3x3 block over its determinant, evaluated in double in this
+// exact order, then 0 - (inv * t); identity in, identity out.
+inline TransformData inverse(const TransformData& t) {
+  const double a00 = t.m[0][0], a01 = t.m[0][1], a02 = t.m[0][2];
+  const double a10 = t.m[1][0], a11 = t.m[1][1], a12 = t.m[1][2];
+  const double a20 = t.m[2][0], a21 = t.m[2][1], a22 = t.m[2][2];
+  const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+  const double det = a00 * c00 + a01 * c01 + a02 * c02;
+  const double i00 = c00 / det, i01 = (a02 * a21 - a01 * a22) / det, i02 = (a01 * a12 - a02 * a11) / det;
+  const double i10 = c01 / det, i11 = (a00 * a22 - a02 * a20) / det, i12 = (a02 * a10 - a00 * a12) / det;
+  const double i20 = c02 / det, i21 = (a01 * a20 - a00 * a21) / det, i22 = (a00 * a11 - a01 * a10) / det;
+  const double tx = t.m[0][3], ty = t.m[1][3], tz = t.m[2][3];
+  TransformData r;
+  r.m[0][0] = (float)i00, r.m[0][1] = (float)i01, r.m[0][2] = (float)i02, r.m[0][3] = (float)(0.0 - (i00 * tx + i01 * ty + i02 * tz));
+  r.m[1][0] = (float)i10, r.m[1][1] = (float)i11, r.m[1][2] = (float)i12, r.m[1][3] = (float)(0.0 - (i10 * tx + i11 * ty + i12 * tz));
+  r.m[2][0] = (float)i20, r.m[2][1] = (float)i21, r.m[2][2] = (float)i22, r.m[2][3] = (float)(0.0 - (i20 * tx + i21 * ty + i22 * tz));
+  return r;
+}
+// transform.h:159-168
+inline ProjectionData make_perspective(float fovy, float aspect, float2 offset, float znear) {
+  ProjectionData r{};
+  r.scale[1] = 1 / std::tan(fovy / 2);
+  r.scale[0] = aspect * r.scale[1];
+  r.offset[0] = offset.x;
+  r.offset[1] = offset.y;
+  r.near_plane = znear;
+  r.far_plane = 0;
+  r.vertical_fov = fovy;
+  return r;
+}
+inline float3 back_project(const ProjectionData& p, float2 v) {  // transform.h:136-147
+  float3 r;
+  if (p.vertical_fov < 0) {
+    r.x = (v.x - p.offset[0]) / p.scale[0];
+    r.y = (v.y - p.offset[1]) / p.scale[1];
+  } else {
+    const float s = p.near_plane > 0 ? 1.f : (p.near_plane < 0 ? -1.f : 0.f);
+    r.x = p.near_plane * (v.x * s - p.offset[0]) / p.scale[0];
+    r.y = p.near_plane * (v.y * s - p.offset[1]) / p.scale[1];
+  }
+  r.z = p.near_plane;
+  return r;
+}
+
+// node_to_world, Scene.cpp:108-117
+inline TransformData node_to_world(const Node& node) {
+  TransformData transform = transform_identity();
+  for (const Node* p = &node; p != nullptr; p = p->parent())
+    if (auto c = p->find<TransformData>()) transform = tmul(*c, transform);
+  return transform;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene components: Material.hpp:13-38, Scene.hpp:15-37
+// ------------------------------------------------------------------------------------------------
+struct ImageValue4 {
+  float value[4] = {0, 0, 0, 0};
+  uint32_t image_index = ~0u;  // no image bound (MaterialResources::get_index of a null view, image_value.h:40-41)
+};
+struct Material {
+  ImageValue4 values[3];
+  uint32_t alpha_mask_index = ~0u, bump_index = ~0u;
+  float bump_strength = 1;
+  float* base_color() { return values[0].value; }
+  float& emission() { return values[0].value[3]; }
+  float& metallic() { return values[1].value[0]; }
+  float& roughness() { return values[1].value[1]; }
+  float& anisotropic() { return values[1].value[2]; }
+  float& subsurface() { return values[1].value[3]; }
+  float& clearcoat() { return values[2].value[0]; }
+  float& clearcoat_gloss() { return values[2].value[1]; }
+  float& transmission() { return values[2].value[2]; }
+  float& eta() { return values[2].value[3]; }
+  // Material::store, Material.hpp:32-38
+  void store(std::vector<uint32_t>& bytes) const {
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 4; j++) {
+        uint32_t u;
+        std::memcpy(&u, &values[i].value[j], 4);
+        bytes.push_back(u);
+      }
+      bytes.push_back(values[i].image_index);
+    }
+    bytes.push_back(alpha_mask_index);
+    bytes.push_back(bump_index);
+    uint32_t u;
+    std::memcpy(&u, &bump_strength, 4);
+    bytes.push_back(u);
+  }
+};
+// what the reference's Mesh + copy_vertices produce for the path (positions, normals, uvs, indices)
+struct Mesh {
+  std::vector<float3> positions, normals;
+  std::vector<float2> uvs;
+  std::vector<uint32_t> indices;
+  uint32_t index_stride = 4;  // 2 or 4 bytes
+};
+struct MeshPrimitive {
+  component_ptr<Material> mMaterial;
+  component_ptr<Mesh> mMesh;
+};
+struct Rect2D {
+  int32_t x = 0, y = 0;
+  uint32_t width = 0, height = 0;
+};
+struct Camera {
+  ProjectionData mProjection{};
+  Rect2D mImageRect;
+  ViewData view() const {  // Scene.hpp:19-28
+    ViewData v{};
+    v.projection = mProjection;
+    v.image_min[0] = mImageRect.x;
+    v.image_min[1] = mImageRect.y;
+    v.image_max[0] = mImageRect.x + (int32_t)mImageRect.width;
+    v.image_max[1] = mImageRect.y + (int32_t)mImageRect.height;
+    const float3 a = back_project(mProjection, {1, 1}), b = back_project(mProjection, {-1, -1});
+    float ex = a.x - b.x, ey = a.y - b.y;
+    if (mProjection.vertical_fov >= 0) {
+      ex /= mProjection.near_plane;
+      ey /= mProjection.near_plane;
+    }
+    v.projection.sensor_area = std::fabs(ex * ey);
+    return v;
+  }
+};
+
+// the HIP stream stands in for the Vulkan command buffer the reference threads through update()/render()
+struct CommandBuffer {
+  void* hip_stream = nullptr;
+};
+
+// Application.hpp:11-29: only the two events the renderer hooks
+class Application {
+ public:
+  Node::Event<CommandBuffer&, float> OnUpdate;
+  Node::Event<CommandBuffer&> OnRenderWindow;
+  explicit Application(Node& node) : mNode(node) {}
+  Node& node() const { return mNode; }
+  void run_frame(CommandBuffer& cb, float dt = 0) {  // Application.cpp:64,69
+    OnUpdate(cb, dt);
+    OnRenderWindow(cb);
+  }
+
+ private:
+  Node& mNode;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Scene: Scene.hpp:44-77, Scene::update Scene.cpp:299-684 (mesh instances only)
+// ------------------------------------------------------------------------------------------------
+class Scene {
+ public:
+  struct SceneData {
+    std::vector<PackedVertexData> mVertices;
+    std::vector<uint8_t> mIndices;
+    std::vector<uint32_t> mMaterialData;
+    std::vector<InstanceData> mInstances;
+    std::vector<TransformData> mInstanceTransforms, mInstanceInverseTransforms, mInstanceMotionTransforms;
+    std::vector<uint32_t> mLightInstanceMap;
+    std::vector<Node*> mInstanceNodes;
+    uint32_t mEnvironmentMaterialAddress = ~0u;
+    uint32_t mMaterialCount = 0;
+    uint32_t mEmissivePrimitiveCount = 0;
+    sthip_scene_desc desc() const {
+      sthip_scene_desc d{};
+      d.gVertices = mVertices.data();
+      d.vertex_count = (uint32_t)mVertices.size();
+      d.gIndices = mIndices.data();
+      d.indices_bytes = (uint32_t)mIndices.size();
+      d.gInstances = mInstances.data();
+      d.instance_count = (uint32_t)mInstances.size();
+      d.gInstanceTransforms = mInstanceTransforms.data();
+      d.gInstanceInverseTransforms = mInstanceInverseTransforms.data();
+      d.gInstanceMotionTransforms = mInstanceMotionTransforms.data();
+      d.gMaterialData = mMaterialData.data();
+      d.material_bytes = (uint32_t)(mMaterialData.size() * 4);
+      d.gLightInstances = mLightInstanceMap.data();
+      d.light_count = (uint32_t)mLightInstanceMap.size();
+      return d;
+    }
+  };
+
+  explicit Scene(Node& node) : mNode(node) {
+    if (auto app = node.find_in_ancestor<Application>()) app->OnUpdate.add_listener(node, [this](CommandBuffer& cb, float dt) { update(cb, dt); }, Node::EventPriority::eDefault);
+  }
+  Node& node() const { return mNode; }
+  const std::shared_ptr<SceneData>& data() const { return mSceneData; }
+  void mark_dirty() { mDirty = true; }
+
+  // Scene.cpp:299-684 for MeshPrimitive instances: same traversal order (breadth-first), same packing
+  void update(CommandBuffer&, float) {
+    if (!mDirty && mSceneData) return;
+    auto sd = std::make_shared<SceneData>();
+    std::unordered_map<const Material*, uint32_t> materialMap;
+    std::unordered_map<const Mesh*, std::pair<uint32_t, uint32_t>> meshMap;  // first_vertex, indices_byte_offset (shared by instances of one mesh)
+    mNode.root().for_each_descendant<MeshPrimitive>([&](const component_ptr<MeshPrimitive>& prim) {
+      if (!prim->mMesh || !prim->mMaterial) return;
+      const Mesh& mesh = *prim->mMesh;
+      // process_material, Scene.cpp:387-396
+      auto mit = materialMap.find(prim->mMaterial.get());
+      if (mit == materialMap.end()) {
+        mit = materialMap.emplace(prim->mMaterial.get(), (uint32_t)(sd->mMaterialData.size() * sizeof(uint32_t))).first;
+        prim->mMaterial->store(sd->mMaterialData);
+        sd->mMaterialCount++;
+      }
+      // copy_vertices + concatenation, copy_vertices.hlsl:29-37, Scene.cpp:461-485,643-658
+      auto meshit = meshMap.find(&mesh);
+      if (meshit == meshMap.end()) {
+        meshit = meshMap.emplace(&mesh, std::make_pair((uint32_t)sd->mVertices.size(), (uint32_t)sd->mIndices.size())).first;
+        for (size_t i = 0; i < mesh.positions.size(); i++) {
+          PackedVertexData v{};
+          v.position[0] = mesh.positions[i].x, v.position[1] = mesh.positions[i].y, v.position[2] = mesh.positions[i].z;
+          if (i < mesh.normals.size()) v.normal[0] = mesh.normals[i].x, v.normal[1] = mesh.normals[i].y, v.normal[2] = mesh.normals[i].z;
+          if (i < mesh.uvs.size()) v.u = mesh.uvs[i].x, v.v = mesh.uvs[i].y;
+          sd->mVertices.push_back(v);
+        }
+        for (uint32_t idx : mesh.indices) {
+          if (mesh.index_stride == 2) {
+            const uint16_t s = (uint16_t)idx;
+            sd->mIndices.insert(sd->mIndices.end(), (const uint8_t*)&s, (const uint8_t*)&s + 2);
+          } else {
+            sd->mIndices.insert(sd->mIndices.end(), (const uint8_t*)&idx, (const uint8_t*)&idx + 4);
+          }
+        }
+        while (sd->mIndices.size() & 3) sd->mIndices.push_back(0);  // align_up(size, 4), Scene.cpp:507
+      }
+      const uint32_t triCount = (uint32_t)(mesh.indices.size() / 3);
+      if (triCount > 0xFFFF) throw std::invalid_argument("MeshPrimitive has more than 65535 triangles (16-bit primitive index, scene.h:23-24,37)");
+      const TransformData transform = node_to_world(prim.node());
+      // make_instance_triangles, scene.h:51-61; process_instance, Scene.cpp:398-427
+      InstanceData inst{};
+      inst.packed[0] = STHIP_INSTANCE_TYPE_TRIANGLES | (mit->second << 4);
+      inst.packed[1] = 0xFFFu | (triCount << 12) | (mesh.index_stride << 28);
+      inst.packed[2] = meshit->second.first;
+      inst.packed[3] = meshit->second.second;
+      const uint32_t instance_index = (uint32_t)sd->mInstances.size();
+      if (prim->mMaterial->emission() > 0) {
+        inst.packed[1] = (inst.packed[1] & ~0xFFFu) | ((uint32_t)sd->mLightInstanceMap.size() & 0xFFFu);
+        sd->mLightInstanceMap.push_back(instance_index);
+        sd->mEmissivePrimitiveCount += triCount;
+      }
+      sd->mInstances.push_back(inst);
+      sd->mInstanceNodes.push_back(&prim.node());
+      const TransformData inv = inverse(transform);
+      sd->mInstanceTransforms.push_back(transform);
+      sd->mInstanceInverseTransforms.push_back(inv);
+      sd->mInstanceMotionTransforms.push_back(tmul(transform, inv));  // make_instance_motion_transform(inv, prev = current), scene.h:49
+    });
+    mSceneData = sd;
+    mDirty = false;
+  }
+
+ private:
+  Node& mNode;
+  std::shared_ptr<SceneData> mSceneData;
+  bool mDirty = true;
+};
+
+// ------------------------------------------------------------------------------------------------
+// BDPT: BDPT.hpp:13-24. Errors surface as exceptions like in the reference (Shader.cpp:115, Instance.cpp:25).
+// ------------------------------------------------------------------------------------------------
+class BDPT {
+ public:
+  struct Frame {  // the outputs BDPT::render leaves in its FrameResources (BDPT.cpp:546-605)
+    uint32_t width = 0, height = 0;
+    std::vector<float> mRadiance, mAlbedo, mPrevUVs;
+    std::vector<VisibilityInfo> mVisibility;
+    std::vector<DepthInfo> mDepth;
+    uint64_t mRayCount[2] = {0, 0};
+  };
+
+  explicit BDPT(Node& node, int device = 0) : mNode(node) {
+    if (sthip_create(device, &mCtx) != STHIP_OK) throw std::runtime_error(std::string("sthip_create: ") + sthip_last_error(nullptr));
+    // BDPT.cpp:55-76
+    mSamplingFlags = (1u << STHIP_eRemapThreads) | (1u << STHIP_eRayCones) | (1u << STHIP_eSampleBSDFs) | (1u << STHIP_eCoherentRR) | (1u << STHIP_eNormalMaps) |
+                     (1u << STHIP_eNEE) | (1u << STHIP_eMIS) | (1u << STHIP_eDeferShadowRays);
+    std::memset(&mPushConstants, 0, sizeof(mPushConstants));
+    mPushConstants.gMinPathVertices = 4;
+    mPushConstants.gMaxPathVertices = 8;
+    mPushConstants.gMaxDiffuseVertices = 2;
+    mPushConstants.gMaxNullCollisions = 64;
+    mPushConstants.gEnvironmentSampleProbability = 0.5f;
+    mPushConstants.gLightPresampleTileSize = 1024;
+    mPushConstants.gLightPresampleTileCount = 128;
+    mPushConstants.gLightPathCount = 64;
+    mPushConstants.gReservoirM = 16;
+    mPushConstants.gReservoirMaxM = 64;
+    mPushConstants.gReservoirSpatialM = 4;
+    mPushConstants.gHashGridBucketCount = 200000;
+    mPushConstants.gHashGridMinBucketRadius = 0.1f;
+    mPushConstants.gHashGridBucketPixelRadius = 6;
+    if (auto app = node.find_in_ancestor<Application>())
+      app->OnUpdate.add_listener(node, [this](CommandBuffer& cb, float dt) { update(cb, dt); }, Node::EventPriority::eAlmostLast);  // BDPT.cpp:38
+  }
+  ~BDPT() { sthip_destroy(mCtx); }
+  BDPT(const BDPT&) = delete;
+
+  Node& node() const { return mNode; }
+  uint32_t& sampling_flags() { return mSamplingFlags; }
+  BDPTPushConstants& push_constants() { return mPushConstants; }
+  const Frame& prev_result() const { return mPrevFrame; }  // BDPT.hpp:18
+
+  // BDPT::update (BDPT.cpp:341-421): (re)bind the scene when Scene::update produced new SceneData
+  void update(CommandBuffer& cb, float) {
+    auto scene = mNode.find_in_ancestor<Scene>();
+    if (!scene) scene = mNode.root().find_in_descendants<Scene>();
+    if (!scene || !scene->data() || scene->data().get() == mBound) return;
+    (void)sthip_set_stream(mCtx, cb.hip_stream);
+    const sthip_scene_desc d = scene->data()->desc();
+    if (sthip_scene_upload(mCtx, &d) != STHIP_OK) throw std::runtime_error(std::string("sthip_scene_upload: ") + sthip_last_error(mCtx));
+    mBound = scene->data().get();
+    mPushConstants.gLightCount = d.light_count;                    // BDPT.cpp:396
+    mPushConstants.gEnvironmentMaterialAddress = 0xFFFFFFFFu;      // no environment
+  }
+
+  // BDPT::render (BDPT.cpp:423-838) for the hot path: one sample per pixel per call, seed = frame number (:480)
+  void render(CommandBuffer& cb, uint32_t width, uint32_t height, const std::vector<std::pair<ViewData, TransformData>>& views, uint32_t seed_count = 1) {
+    if (!mBound) throw std::runtime_error("BDPT::render: no scene bound (Scene::update / BDPT::update have not run)");
+    std::vector<ViewData> v;
+    std::vector<TransformData> t, ti;
+    for (const auto& p : views) {
+      v.push_back(p.first);
+      t.push_back(p.second);
+      ti.push_back(inverse(p.second));  // BDPT.cpp:448-452
+    }
+    sthip_frame_desc f{};
+    f.gViews = v.data();
+    f.gViewTransforms = t.data();
+    f.gInverseViewTransforms = ti.data();
+    f.gPrevViews = mPrevViews.size() == v.size() ? mPrevViews.data() : nullptr;
+    f.gPrevInverseViewTransforms = mPrevInverseViewTransforms.size() == ti.size() ? mPrevInverseViewTransforms.data() : nullptr;
+    f.view_count = (uint32_t)views.size();
+    BDPTPushConstants pc = mPushConstants;
+    pc.gOutputExtent[0] = width;
+    pc.gOutputExtent[1] = height;
+    pc.gViewCount = f.view_count;
+    pc.gLightPathCount = width * height;  // BDPT.cpp:469-470
+    uint32_t scene_flags = 0;             // BDPT.cpp:486-503
+    if (pc.gLightCount) scene_flags |= STHIP_BDPT_FLAG_HAS_EMISSIVES;
+    pc.gEnvironmentSampleProbability = 0;
+    pc.gMaxNullCollisions = 0;
+    Frame fr;
+    fr.width = width;
+    fr.height = height;
+    const size_t n = (size_t)width * height;
+    fr.mRadiance.assign(4 * n, 0.f);
+    fr.mAlbedo.assign(4 * n, 0.f);
+    fr.mPrevUVs.assign(2 * n, 0.f);
+    fr.mVisibility.assign(n, VisibilityInfo{});
+    fr.mDepth.assign(n, DepthInfo{});
+    sthip_outputs o{};
+    o.gRadiance = fr.mRadiance.data();
+    o.gAlbedo = fr.mAlbedo.data();
+    o.gVisibility = fr.mVisibility.data();
+    o.gDepth = fr.mDepth.data();
+    o.gPrevUVs = fr.mPrevUVs.data();
+    o.gRayCount = fr.mRayCount;
+    (void)sthip_set_stream(mCtx, cb.hip_stream);
+    if (sthip_render(mCtx, &pc, mSamplingFlags, scene_flags, &f, mFrameNumber, seed_count, &o) != STHIP_OK)
+      throw std::runtime_error(std::string("sthip_render: ") + sthip_last_error(mCtx));
+    mFrameNumber += seed_count;
+    mPrevViews = v;
+    mPrevInverseViewTransforms = ti;
+    mPrevFrame = std::move(fr);
+  }
+  void reset_frame_number(uint32_t n = 0) { mFrameNumber = n; }
+
+ private:
+  Node& mNode;
+  sthip_ctx* mCtx = nullptr;
+  const void* mBound = nullptr;
+  uint32_t mSamplingFlags = 0;
+  BDPTPushConstants mPushConstants;
+  uint32_t mFrameNumber = 0;
+  std::vector<ViewData> mPrevViews;
+  std::vector<TransformData> mPrevInverseViewTransforms;
+  Frame mPrevFrame;
+};
+
+}  // namespace stm

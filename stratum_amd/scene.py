@@ -39,6 +39,46 @@ def rotate_x(a):
     return m
 
 
+def transform_inverse(m32):
+    """TransformData::inverse (transform.h:26-31). The reference takes Eigen's 4x4 inverse; pinned here — and
+    identically in stratum_amd/host/stratum_hip.hpp — as the adjugate of the 3x3 block over its determinant,
+    evaluated in double in this exact order, then 0 - (inv * t). An identity goes in, an identity comes out."""
+    a = [[float(m32[i][j]) for j in range(4)] for i in range(3)]
+    a00, a01, a02 = a[0][0], a[0][1], a[0][2]
+    a10, a11, a12 = a[1][0], a[1][1], a[1][2]
+    a20, a21, a22 = a[2][0], a[2][1], a[2][2]
+    c00 = a11 * a22 - a12 * a21
+    c01 = a12 * a20 - a10 * a22
+    c02 = a10 * a21 - a11 * a20
+    det = a00 * c00 + a01 * c01 + a02 * c02
+    i = [
+        [c00 / det, (a02 * a21 - a01 * a22) / det, (a01 * a12 - a02 * a11) / det],
+        [c01 / det, (a00 * a22 - a02 * a20) / det, (a02 * a10 - a00 * a12) / det],
+        [c02 / det, (a01 * a20 - a00 * a21) / det, (a00 * a11 - a01 * a10) / det],
+    ]
+    tx, ty, tz = a[0][3], a[1][3], a[2][3]
+    out = np.zeros((3, 4), np.float32)
+    for r in range(3):
+        out[r, 0], out[r, 1], out[r, 2] = i[r][0], i[r][1], i[r][2]
+        out[r, 3] = 0.0 - (i[r][0] * tx + i[r][1] * ty + i[r][2] * tz)
+    return out
+
+
+def tmul(a, b):
+    """tmul (transform.h:88-104) in binary32, rows dotted left to right: a * [b; 0 0 0 1]."""
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    r = np.zeros((3, 4), np.float32)
+    for i in range(3):
+        for j in range(4):
+            s = np.float32(a[i, 0] * b[0, j]) + np.float32(a[i, 1] * b[1, j])
+            s = np.float32(s + np.float32(a[i, 2] * b[2, j]))
+            if j == 3:
+                s = np.float32(s + a[i, 3])
+            r[i, j] = s
+    return r
+
+
 class SceneData:
     """Packed arrays + the descriptor handed to sthip_scene_upload / the oracle."""
 
@@ -92,7 +132,7 @@ class SceneBuilder:
         self._vertex_count = 0
         self._meshes = []  # (first_vertex, indices_byte_offset, prim_count, stride)
         self._materials = []  # MaterialRecord entries
-        self._instances = []  # (mesh, material_address, 3x4 transform, emission)
+        self._instances = []  # (mesh, material index, 4x4 transform)
 
     # -- Material::store, Material.hpp:32-38; conventions of load_mitsuba.cpp:330-343,454-489 --
     def add_material(
@@ -116,9 +156,8 @@ class SceneBuilder:
         rec["alpha_mask_index"] = 0xFFFFFFFF
         rec["bump_index"] = 0xFFFFFFFF
         rec["bump_strength"] = 1.0
-        address = len(self._materials) * wire.MaterialRecord.itemsize
         self._materials.append(rec)
-        return address
+        return len(self._materials) - 1  # a handle; byte addresses are assigned in build() in order of first use
 
     def add_emitter(self, radiance):
         """Mitsuba area emitter: base_color = L / lum(L), emission = lum(L), eta = 0 (load_mitsuba.cpp:480-489)."""
@@ -151,11 +190,11 @@ class SceneBuilder:
         self._meshes.append(mesh)
         return len(self._meshes) - 1
 
-    def add_instance(self, mesh, material_address, transform=None):
+    def add_instance(self, mesh, material, transform=None):
         m = np.eye(4) if transform is None else np.asarray(transform, dtype=np.float64)
         if m.shape == (3, 4):
             m = np.vstack([m, [0, 0, 0, 1]])
-        self._instances.append((mesh, material_address, m))
+        self._instances.append((mesh, material, m))
         return len(self._instances) - 1
 
     def build(self):
@@ -164,33 +203,33 @@ class SceneBuilder:
         xf = np.zeros(n, dtype=wire.TransformData)
         inv = np.zeros(n, dtype=wire.TransformData)
         mot = np.zeros(n, dtype=wire.TransformData)
-        mats = np.array(self._materials, dtype=wire.MaterialRecord) if self._materials else np.zeros(0, wire.MaterialRecord)
+        # process_material, Scene.cpp:387-396: a material is appended to the byte buffer the first time an
+        # instance uses it; its address is the byte offset at that moment
+        address_of, used = {}, []
+        for _, mat, _ in self._instances:
+            if mat not in address_of:
+                address_of[mat] = len(used) * wire.MaterialRecord.itemsize
+                used.append(self._materials[mat])
+        mats = np.array(used, dtype=wire.MaterialRecord) if used else np.zeros(0, wire.MaterialRecord)
         lights = []
         for i, (mesh, mat, m) in enumerate(self._instances):
             fv, ibo, pc, stride = self._meshes[mesh]
             # make_instance_triangles, scene.h:51-61
-            p0 = 0 | (mat << 4)  # INSTANCE_TYPE_TRIANGLES
+            p0 = 0 | (address_of[mat] << 4)  # INSTANCE_TYPE_TRIANGLES
             p1 = 0xFFF | (pc << 12) | (stride << 28)
-            emission = float(mats[mat // wire.MaterialRecord.itemsize]["values"]["value"][0][3])
+            emission = float(self._materials[mat]["values"]["value"][0][3])
             if emission > 0:  # process_instance, Scene.cpp:403-409
                 p1 = (p1 & ~0xFFF) | (len(lights) & 0xFFF)
                 lights.append(i)
             inst["packed"][i] = [p0 & 0xFFFFFFFF, p1 & 0xFFFFFFFF, fv, ibo]
             m32 = m[:3, :].astype(np.float32)
             xf["m"][i] = m32
-            if np.array_equal(m32, _IDENTITY):
-                inv["m"][i] = _IDENTITY
-                mot["m"][i] = _IDENTITY
-            else:
-                # TransformData::inverse, transform.h:26-31 (general 4x4 inverse on the host)
-                mi = np.linalg.inv(np.vstack([m32.astype(np.float64), [0, 0, 0, 1]]))
-                inv["m"][i] = mi[:3, :].astype(np.float32)
-                # make_instance_motion_transform(inv, prevObjectToWorld), scene.h:49; static scene: prev = current
-                mm = np.vstack([m32.astype(np.float64), [0, 0, 0, 1]]) @ np.vstack([inv["m"][i].astype(np.float64), [0, 0, 0, 1]])
-                mot["m"][i] = mm[:3, :].astype(np.float32)
+            inv["m"][i] = transform_inverse(m32)
+            # make_instance_motion_transform(inv, prevObjectToWorld), scene.h:49; static scene: prev = current
+            mot["m"][i] = tmul(m32, inv["m"][i])
         vertices = np.concatenate(self._verts) if self._verts else np.zeros(0, wire.PackedVertexData)
         indices = np.frombuffer(b"".join(self._index_chunks), dtype=np.uint8).copy()
-        return SceneData(
+        sd = SceneData(
             np.ascontiguousarray(vertices),
             indices,
             inst,
@@ -201,3 +240,40 @@ class SceneBuilder:
             np.array(lights, dtype=np.uint32),
             name=self.name,
         )
+        sd.builder = self  # the inputs the arrays were packed from (dump_description)
+        return sd
+
+
+def dump_description(path, scene, frame):
+    """Writes the INPUT of a SceneBuilder (materials, meshes, instances with their node transforms), the view,
+    and the packed OUTPUT arrays to one little-endian binary file. tests/cpp/host_test.cpp rebuilds the scene
+    through the C++ Node-graph API of stratum_amd/host/stratum_hip.hpp from the input part and must reproduce the
+    output part byte for byte."""
+    import struct
+
+    builder = scene.builder
+    with open(path, "wb") as f:
+        mats = np.array(builder._materials, dtype=wire.MaterialRecord)
+        f.write(struct.pack("<I", mats.shape[0]))
+        f.write(mats.tobytes())
+        f.write(struct.pack("<I", len(builder._meshes)))
+        for k, (fv, ibo, pc, stride) in enumerate(builder._meshes):
+            v = builder._verts[k]
+            f.write(struct.pack("<III", v.shape[0], pc, stride))
+            f.write(np.ascontiguousarray(v["position"]).tobytes())
+            f.write(np.ascontiguousarray(v["normal"]).tobytes())
+            f.write(np.ascontiguousarray(np.stack([v["u"], v["v"]], 1)).tobytes())
+            raw = builder._index_chunks[k][: pc * 3 * stride]
+            idx = np.frombuffer(raw, dtype="<u2" if stride == 2 else "<u4").astype("<u4")
+            f.write(idx.tobytes())
+        f.write(struct.pack("<I", len(builder._instances)))
+        for mesh, mat, m in builder._instances:
+            f.write(struct.pack("<II", mesh, mat))
+            f.write(m[:3, :].astype("<f4").tobytes())
+        f.write(frame.views.tobytes())
+        f.write(frame.view_transforms.tobytes())
+        f.write(struct.pack("<II", frame.width, frame.height))
+        for a in (scene.vertices, scene.indices, scene.instances, scene.transforms, scene.inverse_transforms, scene.motion_transforms, scene.materials, scene.lights):
+            b = np.ascontiguousarray(a).tobytes()
+            f.write(struct.pack("<Q", len(b)))
+            f.write(b)

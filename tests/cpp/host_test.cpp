@@ -1,0 +1,141 @@
+// host_test.cpp — drives the C++ host side (stratum_amd/host/stratum_hip.hpp) the way Stratum's main.cpp
+// drives its components (main.cpp:59-66,97-149): build a node graph, let Application fire OnUpdate /
+// OnRenderWindow, read the renderer's result.
+//   host_test pack   <scene.bin>                       (no GPU) Scene::update must reproduce the packed arrays
+//   host_test render <scene.bin> <out.bin> <seeds>     (GPU)    BDPT::update + render, writes RGBA32F radiance
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+#include "../../stratum_amd/host/stratum_hip.hpp"
+
+using namespace stm;
+
+struct Reader {
+  std::ifstream f;
+  explicit Reader(const char* p) : f(p, std::ios::binary) {
+    if (!f) throw std::runtime_error(std::string("cannot open ") + p);
+  }
+  template <typename T>
+  T get() {
+    T v;
+    f.read((char*)&v, sizeof(T));
+    return v;
+  }
+  template <typename T>
+  std::vector<T> vec(size_t n) {
+    std::vector<T> v(n);
+    f.read((char*)v.data(), n * sizeof(T));
+    return v;
+  }
+};
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    std::fprintf(stderr, "usage: host_test pack|render scene.bin [out.bin seeds]\n");
+    return 2;
+  }
+  try {
+    const std::string mode = argv[1];
+    Reader r(argv[2]);
+    NodeGraph graph;
+    Node& root = graph.emplace("Instance");
+    auto app = root.make_child("Application").make_component<Application>();
+    Node& scene_node = app.node().make_child("Scene");
+    auto scene = scene_node.make_component<Scene>();
+
+    // materials
+    const uint32_t n_mat = r.get<uint32_t>();
+    std::vector<component_ptr<Material>> materials;
+    for (uint32_t i = 0; i < n_mat; i++) {
+      const sthip_MaterialRecord rec = r.get<sthip_MaterialRecord>();
+      auto m = scene_node.make_child("material").make_component<Material>();
+      for (int k = 0; k < 3; k++) {
+        std::memcpy(m->values[k].value, rec.values[k].value, 16);
+        m->values[k].image_index = rec.values[k].image_index;
+      }
+      m->alpha_mask_index = rec.alpha_mask_index;
+      m->bump_index = rec.bump_index;
+      m->bump_strength = rec.bump_strength;
+      materials.push_back(m);
+    }
+    // meshes
+    const uint32_t n_mesh = r.get<uint32_t>();
+    std::vector<component_ptr<Mesh>> meshes;
+    for (uint32_t i = 0; i < n_mesh; i++) {
+      const uint32_t nv = r.get<uint32_t>(), nt = r.get<uint32_t>(), stride = r.get<uint32_t>();
+      auto mesh = scene_node.make_child("mesh").make_component<Mesh>();
+      mesh->positions = r.vec<float3>(nv);
+      mesh->normals = r.vec<float3>(nv);
+      mesh->uvs = r.vec<float2>(nv);
+      mesh->indices = r.vec<uint32_t>((size_t)nt * 3);
+      mesh->index_stride = stride;
+      meshes.push_back(mesh);
+    }
+    // instances: one node each, carrying a TransformData and a MeshPrimitive (Scene.hpp:30-33)
+    const uint32_t n_inst = r.get<uint32_t>();
+    for (uint32_t i = 0; i < n_inst; i++) {
+      const uint32_t mesh = r.get<uint32_t>(), mat = r.get<uint32_t>();
+      const TransformData t = r.get<TransformData>();
+      Node& n = scene_node.make_child("prim" + std::to_string(i));
+      n.make_component<TransformData>(t);
+      n.make_component<MeshPrimitive>(MeshPrimitive{materials.at(mat), meshes.at(mesh)});
+    }
+    const ViewData view = r.get<ViewData>();
+    const TransformData view_xf = r.get<TransformData>();
+    const uint32_t W = r.get<uint32_t>(), H = r.get<uint32_t>();
+
+    CommandBuffer cb;
+    if (mode == "pack") {
+      scene->update(cb, 0);
+      const auto& sd = *scene->data();
+      auto check = [&](const char* name, const void* got, size_t got_bytes) {
+        const uint64_t n = r.get<uint64_t>();
+        const std::vector<uint8_t> want = r.vec<uint8_t>(n);
+        if (n != got_bytes || std::memcmp(want.data(), got, n) != 0) {
+          std::printf("MISMATCH %s: %zu bytes packed, %llu expected\n", name, got_bytes, (unsigned long long)n);
+          std::exit(1);
+        }
+      };
+      check("gVertices", sd.mVertices.data(), sd.mVertices.size() * sizeof(PackedVertexData));
+      check("gIndices", sd.mIndices.data(), sd.mIndices.size());
+      check("gInstances", sd.mInstances.data(), sd.mInstances.size() * sizeof(InstanceData));
+      check("gInstanceTransforms", sd.mInstanceTransforms.data(), sd.mInstanceTransforms.size() * sizeof(TransformData));
+      check("gInstanceInverseTransforms", sd.mInstanceInverseTransforms.data(), sd.mInstanceInverseTransforms.size() * sizeof(TransformData));
+      check("gInstanceMotionTransforms", sd.mInstanceMotionTransforms.data(), sd.mInstanceMotionTransforms.size() * sizeof(TransformData));
+      check("gMaterialData", sd.mMaterialData.data(), sd.mMaterialData.size() * 4);
+      check("gLightInstances", sd.mLightInstanceMap.data(), sd.mLightInstanceMap.size() * 4);
+      // event order: Scene (eDefault) before BDPT (eAlmostLast) — checked without a device through a probe
+      std::vector<int> order;
+      Node& probe = app.node().make_child("probe");
+      app->OnUpdate.add_listener(probe, [&](CommandBuffer&, float) { order.push_back(2); }, Node::EventPriority::eAlmostLast);
+      app->OnUpdate.add_listener(probe, [&](CommandBuffer&, float) { order.push_back(1); }, Node::EventPriority::eFirst);
+      app->run_frame(cb);
+      if (order != std::vector<int>{1, 2}) {
+        std::printf("MISMATCH event priority order\n");
+        return 1;
+      }
+      std::printf("PACK OK %zu instances %zu lights\n", sd.mInstances.size(), sd.mLightInstanceMap.size());
+      return 0;
+    }
+    if (mode == "render" && argc >= 5) {
+      const uint32_t seeds = (uint32_t)std::atoi(argv[4]);
+      // init_renderer<BDPT>, main.cpp:59-66
+      auto renderer = app.node().make_child("BDPT").make_component<BDPT>();
+      app->OnRenderWindow.add_listener(renderer.node(), [&](CommandBuffer& c) { renderer->render(c, W, H, {{view, view_xf}}, seeds); });
+      app->run_frame(cb);  // OnUpdate: Scene::update, then BDPT::update (eAlmostLast); OnRenderWindow: BDPT::render
+      const auto& fr = renderer->prev_result();
+      std::ofstream out(argv[3], std::ios::binary);
+      out.write((const char*)fr.mRadiance.data(), fr.mRadiance.size() * 4);
+      out.write((const char*)fr.mVisibility.data(), fr.mVisibility.size() * sizeof(VisibilityInfo));
+      out.write((const char*)fr.mRayCount, 16);
+      std::printf("RENDER OK %ux%u rays %llu\n", W, H, (unsigned long long)fr.mRayCount[0]);
+      return 0;
+    }
+    std::fprintf(stderr, "bad arguments\n");
+    return 2;
+  } catch (const std::exception& e) {
+    std::printf("EXCEPTION %s\n", e.what());
+    return 3;
+  }
+}

@@ -1,0 +1,75 @@
+"""The C++ host side (stratum_amd/host/stratum_hip.hpp): Stratum's Node graph / Scene / BDPT surface above the
+C ABI. tests/cpp/host_test.cpp plays main.cpp: it builds the node graph from a scene description, lets
+Application fire OnUpdate / OnRenderWindow, and is checked against the Python packing and renderer."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from stratum_amd import camera, scenes, wire
+from stratum_amd.scene import SceneBuilder, dump_description, rotate_y, scale, translate
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "host_test")
+
+
+@pytest.fixture(scope="module")
+def host_test(built):
+    src = os.path.join(ROOT, "tests", "cpp", "host_test.cpp")
+    hdr = os.path.join(ROOT, "stratum_amd", "host", "stratum_hip.hpp")
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(
+            ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-Wall", "-o", EXE, src, "-L" + os.path.join(ROOT, "stratum_amd"), "-lstratum_hip", "-Wl,-rpath," + os.path.join(ROOT, "stratum_amd")]
+        )
+    return EXE
+
+
+def shared_mesh_scene():
+    b = SceneBuilder("shared")
+    m0 = b.add_material((0.7, 0.7, 0.7), roughness=0.3)
+    m1 = b.add_material((0.2, 0.5, 0.9), metallic=0.8, roughness=0.2)
+    li = b.add_emitter((9.0, 8.0, 7.0))
+    q = scenes._quad((-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1), (0, 1, 0))
+    quad = b.add_mesh(*q, index_stride=2)
+    for k in range(5):
+        b.add_instance(quad, m0 if k % 2 else m1, translate((0.3 * k, 0.1 * k, -0.2 * k)) @ rotate_y(0.4 * k) @ scale((1.0 + 0.1 * k, 1.0, 0.7)))
+    b.add_instance(quad, li, translate((0, 2.5, 0)) @ scale((0.5, 1.0, 0.5)) @ np.diag([1.0, -1.0, 1.0, 1.0]))
+    return b.build(), {"eye": (0.5, 1.5, 4.0), "target": (0.5, 0.3, 0.0), "fovy": np.radians(50.0)}
+
+
+@pytest.mark.parametrize("make", [scenes.cornell_box, shared_mesh_scene])
+def test_scene_update_packs_like_the_reference_layouts(host_test, tmp_path, make):
+    sc, cam = make()
+    fr = camera.Frame(64, 48, cam["fovy"], cam["eye"], cam["target"])
+    desc = str(tmp_path / "scene.bin")
+    dump_description(desc, sc, fr)
+    out = subprocess.run([host_test, "pack", desc], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("PACK OK"), out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("make", [scenes.cornell_box, shared_mesh_scene])
+def test_cpp_host_renders_what_the_python_host_renders(host_test, tmp_path, make):
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = make()
+    W, H, seeds = 96, 64, 3
+    fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+    desc, outp = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    dump_description(desc, sc, fr)
+    out = subprocess.run([host_test, "render", desc, outp, str(seeds)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("RENDER OK"), out.stdout + out.stderr
+    raw = np.fromfile(outp, dtype=np.uint8)
+    rad = raw[: W * H * 16].view(np.float32).reshape(H, W, 4)
+    vis = raw[W * H * 16 : W * H * 24].view(wire.VisibilityInfo).reshape(H, W)
+    rays = raw[W * H * 24 :].view(np.uint64)
+    r = BDPT(device=0)
+    try:
+        r.update(sc)
+        ref = r.render(fr, 0, seeds)
+    finally:
+        r.close()
+    assert np.array_equal(rad.view(np.uint32), ref["radiance"].view(np.uint32))
+    assert np.array_equal(vis["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
+    assert np.array_equal(rays, ref["ray_count"])
