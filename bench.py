@@ -84,15 +84,22 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    # rehearsal on a one-GPU box (several ranks sharing device 0 over gloo): STHIP_BENCH_ONE_DEVICE=1 STHIP_BENCH_BACKEND=gloo
+    if os.environ.get("STHIP_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("STHIP_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from stratum_amd import camera, scenes
+    from stratum_amd import camera, scenes, shard
     from stratum_amd.bdpt import BDPT
 
     W, H = args.width, args.height
@@ -109,7 +116,7 @@ def main():
     def step(i):
         r.render(frame, seed_begin=i * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
         if dist is not None:
-            dist.reduce(radiance, dst=0, op=dist.ReduceOp.SUM)
+            shard.reduce_framebuffer(radiance, dist, dst=0)  # the one exchange of the path: sum of disjoint tiles
 
     def barrier():
         if dist is not None:

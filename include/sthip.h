@@ -156,7 +156,8 @@ typedef struct sthip_stats {
 int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out);
 
 /* named integer options: "count_traversal" (0/1), "time_kernels" (0/1); scheduler tuning of the persistent
- * trace kernels: "refill_idle" (1..64, default 16), "inner_min_lanes" (1..64, default 24) */
+ * trace kernels: "refill_idle" (1..64, default 16), "inner_min_lanes" (1..64, default 24),
+ * "max_paths_in_flight" (default 4194304: how many seeds of the owned pixels are traced together) */
 int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value);
 
 #ifdef __cplusplus

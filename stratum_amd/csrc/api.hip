@@ -73,6 +73,7 @@ struct sthip_ctx {
   // options / stats
   bool count_traversal = false, time_kernels = false;
   uint32_t refill_idle = 16, inner_min_lanes = 24, trace_blocks_per_cu = 0;
+  uint64_t max_paths_in_flight = 1ull << 22;
   sthip_stats stats{};
   bool stats_pending = false;  // ray / traversal counters of the last render still live on the device
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -205,6 +206,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->time_kernels = value != 0;
   else if (!strcmp(name, "refill_idle"))
     ctx->refill_idle = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
+  else if (!strcmp(name, "max_paths_in_flight"))
+    ctx->max_paths_in_flight = (uint64_t)std::max<int64_t>(1, value);
   else if (!strcmp(name, "trace_blocks_per_cu"))
     ctx->trace_blocks_per_cu = (uint32_t)std::min<int64_t>(16, std::max<int64_t>(0, value));
   else if (!strcmp(name, "inner_min_lanes"))
@@ -416,8 +419,14 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.tiles_y = (H + p.tile_h - 1) / p.tile_h;
   const uint32_t tiles = p.tiles_x * p.tiles_y;
   const uint32_t owned = tiles > p.shard_rank ? (tiles - p.shard_rank + p.shard_count - 1) / p.shard_count : 0;
-  p.path_count = owned * p.tile_w * p.tile_h;
+  p.paths_per_seed = owned * p.tile_w * p.tile_h;
+  // Seeds traced together in one pass. A shard of a frame is small (1/8 of 1080p = 259 K paths does not fill
+  // 256 CUs of persistent waves), so several seeds of the owned pixels share the launches, up to ~4 M paths.
+  const uint32_t max_in_flight = (uint32_t)std::max<uint64_t>(1, (ctx->max_paths_in_flight) / std::max(1u, p.paths_per_seed));
+  const uint32_t batch = std::min(seed_count, max_in_flight);
+  p.path_count = batch * p.paths_per_seed;
   const size_t P = std::max<size_t>(1, p.path_count);
+  const size_t P0 = std::max<size_t>(1, p.paths_per_seed);
 
   HIP_TRY(ctx, ctx->ray_o.ensure(P));
   HIP_TRY(ctx, ctx->ray_d.ensure(P));
@@ -425,7 +434,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   HIP_TRY(ctx, ctx->beta.ensure(P));
   HIP_TRY(ctx, ctx->radiance.ensure(P));
   HIP_TRY(ctx, ctx->shadow_sum.ensure(P));
-  HIP_TRY(ctx, ctx->accum.ensure(P));
+  HIP_TRY(ctx, ctx->accum.ensure(P0));
   HIP_TRY(ctx, ctx->shadow_rays.ensure(3 * P));
   HIP_TRY(ctx, ctx->meta.ensure(P));
   HIP_TRY(ctx, ctx->queue0.ensure(P));
@@ -562,8 +571,11 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   };
 
   HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_TOTAL * sizeof(unsigned long long), st));
-  for (uint32_t s = 0; s < seed_count; s++) {
+  for (uint32_t s = 0; s < seed_count; s += batch) {
+    const uint32_t in_flight = std::min(batch, seed_count - s);
     p.seed = seed_begin + s;
+    p.seeds_in_flight = in_flight;
+    p.path_count = in_flight * p.paths_per_seed;
     p.write_aov = s == 0 ? 1u : 0u;
     // queue sizes are per seed; the ray / traversal counters behind them run over the whole call
     if (s) HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_PER_SEED * sizeof(unsigned long long), st));
@@ -602,7 +614,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       }
       if (last_round) break;
     }
-    rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + 1 == seed_count ? 1u : 0u, primary_rays); });
+    rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + in_flight == seed_count ? 1u : 0u, primary_rays * in_flight); });
     if (rc) return rc;
   }
 

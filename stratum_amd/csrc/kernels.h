@@ -36,7 +36,9 @@ struct FrameParams {
   DeviceBvh bvh;
   sthip_BDPTPushConstants pc;
   uint32_t sampling_flags;
-  uint32_t seed;
+  uint32_t seed;             // gRandomSeed of the first seed in flight
+  uint32_t seeds_in_flight;  // seeds traced together in one pass: slot = seed_index * paths_per_seed + pixel slot
+  uint32_t paths_per_seed;   // owned tiles * tile_w * tile_h
   // views (device copies)
   const sthip_ViewData* views;
   const sthip_TransformData* view_xf;
@@ -44,7 +46,7 @@ struct FrameParams {
   const sthip_TransformData* prev_inv_view_xf;
   // sharding: tile t is owned iff t % shard_count == shard_rank
   uint32_t shard_rank, shard_count, tile_w, tile_h, tiles_x, tiles_y;
-  uint32_t path_count;  // owned tiles * tile_w * tile_h
+  uint32_t path_count;  // seeds_in_flight * paths_per_seed
   // path state, indexed by path slot
   float4* ray_o;       // xyz origin, w = bsdf_pdf
   float4* ray_d;       // xyz direction, w = eta_scale
@@ -83,6 +85,7 @@ DEV void wave_add(unsigned long long* counter, uint32_t v) {
 // wave64 covers an 8x8 block of the image (the reference's eRemapThreads does the same with 8x4 groups
 // of 32 threads, bdpt_util.hlsli:76-83). Returns false for slots that fall outside the image.
 DEV bool slot_to_pixel(const FrameParams& p, uint32_t slot, uint32_t& px, uint32_t& py) {
+  slot %= p.paths_per_seed;  // several seeds of the same pixel set may be in flight
   const uint32_t per_tile = p.tile_w * p.tile_h;
   const uint32_t local_tile = slot / per_tile;
   const uint32_t r = slot - local_tile * per_tile;
@@ -311,7 +314,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_shade(FrameParams p, uint32_t d
     Rng rng;
     rng.x = px;
     rng.y = py;
-    rng.seed = p.seed;
+    const uint32_t seed_index = slot / p.paths_per_seed;
+    rng.seed = p.seed + seed_index;
     rng.counter = __float_as_uint(bb.w);
     uint32_t path_length = meta & 0xFFu, diffuse_vertices = (meta >> 8) & 0xFFu;
     const uint32_t ip = __float_as_uint(hh.w);
@@ -326,7 +330,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_shade(FrameParams p, uint32_t d
       path_length++;
       if (ip == 0xFFFFFFFFu) {
         // miss: bdpt.hlsl:231-242 at depth 0, path.hlsli:1049-1058 later (no environment)
-        if (depth == 0 && p.write_aov) {
+        if (depth == 0 && p.write_aov && seed_index == 0) {
           const int view_index = get_view_index(p, px, py);
           const sthip_ViewData& view = p.views[view_index];
           const float ex = (float)(view.image_max[0] - view.image_min[0]), ey = (float)(view.image_max[1] - view.image_min[1]);
@@ -384,7 +388,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_shade(FrameParams p, uint32_t d
 
       if (depth == 0) {
         eval_emission();  // bdpt.hlsl:253
-        if (p.write_aov) {
+        if (p.write_aov && seed_index == 0) {
           const int view_index = get_view_index(p, px, py);
           const sthip_ViewData& view = p.views[view_index];
           const Xf t = load_xf(p.view_xf, (uint32_t)view_index);
@@ -547,26 +551,29 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
     p.counters[CNT_RAYS_CLOSEST] += closest;
     p.counters[CNT_RAYS_SHADOW] += shadow;
   }
-  for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.path_count; slot += gridDim.x * blockDim.x) {
-    const uint32_t meta = p.meta[slot];
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < p.paths_per_seed; q += gridDim.x * blockDim.x) {
     uint32_t px, py;
-    const bool inside = slot_to_pixel(p, slot, px, py);
-    if (!inside || meta == 0xFFFFFFFFu) continue;
-    const float4 r = p.radiance[slot], c = p.shadow_sum[slot];
-    float4 cur = make_float4(r.x + c.x, r.y + c.y, r.z + c.z, 1.0f);
-    if (isinf(cur.x) || isinf(cur.y) || isinf(cur.z) || cur.x != cur.x || cur.y != cur.y || cur.z != cur.z) cur = make_float4(0, 0, 0, 0);
-    float4 acc = first_seed ? make_float4(0, 0, 0, 0) : p.accum[slot];
-    if (acc.w > 0) {
-      const float nn = acc.w + cur.w;
-      const float alpha = fminf(fmaxf(cur.w / nn, 0.0f), 1.0f);
-      acc.x = lerp1(acc.x, cur.x, alpha);
-      acc.y = lerp1(acc.y, cur.y, alpha);
-      acc.z = lerp1(acc.z, cur.z, alpha);
-      acc.w = nn;
-    } else {
-      acc = cur;
+    const bool inside = slot_to_pixel(p, q, px, py);
+    if (!inside || p.meta[q] == 0xFFFFFFFFu) continue;
+    float4 acc = first_seed ? make_float4(0, 0, 0, 0) : p.accum[q];
+    // the seeds in flight are folded in seed order, so the result does not depend on how many were in flight
+    for (uint32_t s = 0; s < p.seeds_in_flight; s++) {
+      const uint32_t slot = s * p.paths_per_seed + q;
+      const float4 r = p.radiance[slot], c = p.shadow_sum[slot];
+      float4 cur = make_float4(r.x + c.x, r.y + c.y, r.z + c.z, 1.0f);
+      if (isinf(cur.x) || isinf(cur.y) || isinf(cur.z) || cur.x != cur.x || cur.y != cur.y || cur.z != cur.z) cur = make_float4(0, 0, 0, 0);
+      if (acc.w > 0) {
+        const float nn = acc.w + cur.w;
+        const float alpha = fminf(fmaxf(cur.w / nn, 0.0f), 1.0f);
+        acc.x = lerp1(acc.x, cur.x, alpha);
+        acc.y = lerp1(acc.y, cur.y, alpha);
+        acc.z = lerp1(acc.z, cur.z, alpha);
+        acc.w = nn;
+      } else {
+        acc = cur;
+      }
     }
-    p.accum[slot] = acc;
+    p.accum[q] = acc;
     if (last_seed && p.out_radiance) p.out_radiance[(size_t)py * p.pc.gOutputExtent[0] + px] = acc;
   }
 }
