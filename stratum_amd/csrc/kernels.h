@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
 // (bdpt.hlsl:222-296) at depth 0, then next_vertex() (path.hlsli:955-998,1048-1075) up to the point
 // where the next ray is known
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(STHIP_BLOCK) k_shade(FrameParams p, uint32_t depth) {
+__global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_t depth) {
   const uint32_t n = depth == 0 ? p.path_count : (uint32_t)p.counters[CNT_QUEUE0 + depth];
   const uint32_t* queue_in = p.queue[depth & 1u];
   uint32_t* queue_out = p.queue[(depth + 1) & 1u];
