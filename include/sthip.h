@@ -152,12 +152,15 @@ typedef struct sthip_stats {
   uint32_t bvh_tri_bytes;  /* bytes of one leaf triangle */
   uint64_t bvh_nodes;
   uint64_t bvh_tris;
+  float bvh_build_ms;      /* wall time of the acceleration-structure build inside the last sthip_scene_upload */
+  float bvh_build_gpu_ms;  /* of which device time of the LBVH kernels ("bvh_builder" = 1) */
 } sthip_stats;
 int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out);
 
 /* named integer options: "count_traversal" (0/1), "time_kernels" (0/1); scheduler tuning of the persistent
  * trace kernels: "refill_idle" (1..64, default 16), "inner_min_lanes" (1..64, default 24),
- * "max_paths_in_flight" (default 4194304: how many seeds of the owned pixels are traced together) */
+ * "max_paths_in_flight" (default 4194304: how many seeds of the owned pixels are traced together);
+ * "bvh_builder": 0 = binned SAH on the host (default), 1 = LBVH on the GPU (set before sthip_scene_upload) */
 int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value);
 
 #ifdef __cplusplus

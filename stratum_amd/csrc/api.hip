@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -74,6 +75,7 @@ struct sthip_ctx {
   bool count_traversal = false, time_kernels = false;
   uint32_t refill_idle = 16, inner_min_lanes = 24, trace_blocks_per_cu = 0;
   uint64_t max_paths_in_flight = 1ull << 22;
+  int bvh_builder = 0;  // sthip::BvhBuilderKind
   sthip_stats stats{};
   bool stats_pending = false;  // ray / traversal counters of the last render still live on the device
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -206,6 +208,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->time_kernels = value != 0;
   else if (!strcmp(name, "refill_idle"))
     ctx->refill_idle = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
+  else if (!strcmp(name, "bvh_builder"))
+    ctx->bvh_builder = value == 1 ? 1 : 0;
   else if (!strcmp(name, "max_paths_in_flight"))
     ctx->max_paths_in_flight = (uint64_t)std::max<int64_t>(1, value);
   else if (!strcmp(name, "trace_blocks_per_cu"))
@@ -260,8 +264,13 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   }
   sthip::BuiltBvh built;
   std::string err;
-  if (!sthip::build_scene_bvh(*s, built, err)) return fail(ctx, err.find("only triangle") != std::string::npos ? STHIP_ERR_UNSUPPORTED : STHIP_ERR_INVALID_ARGUMENT, "scene: " + err);
+  const auto t_build0 = std::chrono::steady_clock::now();
+  if (!sthip::build_scene_bvh(*s, built, err, ctx->bvh_builder)) return fail(ctx, err.find("only triangle") != std::string::npos ? STHIP_ERR_UNSUPPORTED : STHIP_ERR_INVALID_ARGUMENT, "scene: " + err);
 
+  if ((size_t)built.stack_depth * STHIP_BLOCK * sizeof(uint32_t) > 64 * 1024)
+    return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: the acceleration structure is too deep for the LDS traversal stack (use the SAH builder)");
+  ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
+  ctx->stats.bvh_build_gpu_ms = built.gpu_build_ms;
   const uint32_t n = s->instance_count;
   HIP_TRY(ctx, ctx->vertices.ensure(s->vertex_count));
   HIP_TRY(ctx, ctx->indices.ensure((size_t)s->indices_bytes + 8));
@@ -312,8 +321,9 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (getenv("STHIP_VERBOSE")) {
     int per_cu = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false>, STHIP_BLOCK, stack_bytes(ctx));
-    fprintf(stderr, "[sthip] bvh: %zu nodes, %zu tris, %zu top-level entries, stack depth %u (%zu B LDS / block), %d trace blocks / CU\n", built.nodes.size(),
-            built.tris.size(), built.entries.size(), built.stack_depth, stack_bytes(ctx), per_cu);
+    fprintf(stderr, "[sthip] bvh (%s): %zu nodes, %zu tris, %zu top-level entries, stack depth %u (%zu B LDS / block), %d trace blocks / CU, build %.1f ms (GPU kernels %.2f ms)\n",
+            ctx->bvh_builder ? "lbvh/gpu" : "sah/host", built.nodes.size(), built.tris.size(), built.entries.size(), built.stack_depth, stack_bytes(ctx), per_cu, ctx->stats.bvh_build_ms,
+            ctx->stats.bvh_build_gpu_ms);
   }
   return STHIP_OK;
 }

@@ -253,7 +253,7 @@ inline void load_tri(const sthip_scene_desc& s, const InstView& in, uint32_t pri
 
 }  // namespace
 
-bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err) {
+bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err, int builder) {
   out = BuiltBvh();
   const uint32_t BLAS_DEPTH_CAP = 22, TLAS_DEPTH_CAP = 18;
   // ---- validate + classify ----
@@ -292,7 +292,32 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err)
       separate.push_back(i);
   }
 
+  std::string gpu_err;
   auto add_blas = [&](const std::vector<std::pair<uint32_t, uint32_t>>& prims /* (instance, prim) */, bool with_instance_bits, Box& bounds, uint32_t& depth) -> uint32_t {
+    if (builder == BVH_BUILDER_LBVH_GPU && prims.size() >= 64) {
+      // GPU path: hand the triangles over unsorted; the device sorts them along the Morton curve
+      std::vector<BvhTri> tin(prims.size());
+      bounds.reset();
+      for (size_t k = 0; k < prims.size(); k++) {
+        const InstView in = view(s.gInstances[prims[k].first]);
+        uint32_t tri[3];
+        load_tri(s, in, prims[k].second, tri);
+        BvhTri& t = tin[k];
+        memcpy(t.v0, s.gVertices[tri[0]].position, 12);
+        memcpy(t.v1, s.gVertices[tri[1]].position, 12);
+        memcpy(t.v2, s.gVertices[tri[2]].position, 12);
+        t.id = (prims[k].second << 16) | (with_instance_bits ? prims[k].first : 0u);
+        t.pad1 = t.pad2 = 0;
+        bounds.grow(t.v0);
+        bounds.grow(t.v1);
+        bounds.grow(t.v2);
+      }
+      uint32_t root = 0;
+      float ms = 0;
+      if (!lbvh_build_gpu(tin, out.nodes, out.tris, root, depth, ms, gpu_err)) return BVH_INVALID_REF;
+      out.gpu_build_ms += ms;
+      return root;
+    }
     std::vector<Box> boxes(prims.size());
     bounds.reset();
     for (size_t k = 0; k < prims.size(); k++) {
@@ -351,6 +376,10 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err)
       memset(&e, 0, sizeof(e));
       e.inv[0] = e.inv[5] = e.inv[10] = 1.0f;
       e.root = add_blas(prims, true, bounds, depth);
+      if (e.root == BVH_INVALID_REF) {
+        err = gpu_err;
+        return false;
+      }
       e.id_bits = 0;
       e.identity = 1;
       for (int a = 0; a < 3; a++) e.center[a] = 0.5f * (bounds.lo[a] + bounds.hi[a]);
@@ -378,6 +407,10 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err)
       MeshInfo mi;
       uint32_t depth = 0;
       mi.root = add_blas(prims, false, mi.bounds, depth);
+      if (mi.root == BVH_INVALID_REF) {
+        err = gpu_err;
+        return false;
+      }
       blas_depth = std::max(blas_depth, depth);
       it = meshes.emplace(key, mi).first;
     }

@@ -19,9 +19,17 @@ struct BuiltBvh {
   uint32_t stack_depth = 4;             // upper bound of the traversal stack height
   float scene_center[3] = {0, 0, 0};
   float scene_radius = 0;
+  float gpu_build_ms = 0;  // device time of the LBVH kernels (0 for the host builder)
 };
 
+enum BvhBuilderKind { BVH_BUILDER_SAH_HOST = 0, BVH_BUILDER_LBVH_GPU = 1 };
+
 // Validates the scene arrays and builds. Returns false and sets `err` on malformed input.
-bool build_scene_bvh(const sthip_scene_desc& scene, BuiltBvh& out, std::string& err);
+// `builder`: binned SAH on the host (default; best traversal) or LBVH on the GPU (fastest build; lbvh.hip).
+bool build_scene_bvh(const sthip_scene_desc& scene, BuiltBvh& out, std::string& err, int builder = BVH_BUILDER_SAH_HOST);
+
+// GPU LBVH of one mesh (lbvh.hip): appends nodes and leaf-ordered triangles to the outputs.
+bool lbvh_build_gpu(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhTri>& tris_out, uint32_t& root_ref, uint32_t& stack_need, float& gpu_ms,
+                    std::string& err);
 
 }  // namespace sthip

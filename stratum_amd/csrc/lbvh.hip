@@ -1,0 +1,284 @@
+// lbvh.hip — GPU construction of a bottom-level BVH (LBVH): Morton codes of the triangle centroids,
+// a device radix sort, the Karras (2012) binary radix tree built fully in parallel, a bottom-up refit, and the
+// emission of the 64-byte nodes of bvh.h. This is the "rebuild on dirty" path: the reference rebuilds its
+// acceleration structures on the GPU whenever the scene changes (src/Node/Scene.cpp:345,435-459,614-629);
+// the binned-SAH host builder of bvh_build.cpp stays the default for static scenes because its trees trace
+// faster. The hit contract does not depend on the tree, so both builders give bit-identical images.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <math.h>
+#include <string.h>
+
+#include "bvh_build.h"
+
+namespace sthip {
+namespace {
+
+#define LB_BLOCK 256
+
+struct LBox {
+  float lo[3], hi[3];
+};
+
+// order-preserving float <-> uint mapping for atomicMin/atomicMax
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(uint32_t u) {
+  const uint32_t v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  float f;
+  memcpy(&f, &v, 4);
+  return f;
+}
+
+__global__ void k_lbvh_bounds(const BvhTri* tris, uint32_t n, LBox* boxes, uint32_t* cbounds /* 6 ordered uints */) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const BvhTri t = tris[i];
+  LBox b;
+  for (int a = 0; a < 3; a++) {
+    b.lo[a] = fminf(fminf(t.v0[a], t.v1[a]), t.v2[a]);
+    b.hi[a] = fmaxf(fmaxf(t.v0[a], t.v1[a]), t.v2[a]);
+  }
+  boxes[i] = b;
+  for (int a = 0; a < 3; a++) {
+    const float c = 0.5f * (b.lo[a] + b.hi[a]);
+    atomicMin(&cbounds[a], f2ord(c));
+    atomicMax(&cbounds[3 + a], f2ord(c));
+  }
+}
+
+__device__ __forceinline__ unsigned long long expand21(unsigned long long v) {  // 21 bits -> every third bit
+  v &= 0x1FFFFFull;
+  v = (v | v << 32) & 0x1F00000000FFFFull;
+  v = (v | v << 16) & 0x1F0000FF0000FFull;
+  v = (v | v << 8) & 0x100F00F00F00F00Full;
+  v = (v | v << 4) & 0x10C30C30C30C30C3ull;
+  v = (v | v << 2) & 0x1249249249249249ull;
+  return v;
+}
+
+__global__ void k_lbvh_morton(const LBox* boxes, uint32_t n, const uint32_t* cbounds, unsigned long long* keys, uint32_t* vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long code = 0;
+  for (int a = 0; a < 3; a++) {
+    const float lo = ord2f(cbounds[a]), hi = ord2f(cbounds[3 + a]);
+    const float c = 0.5f * (boxes[i].lo[a] + boxes[i].hi[a]);
+    const float ext = hi - lo;
+    float x = ext > 0 ? (c - lo) / ext : 0.0f;
+    x = fminf(fmaxf(x * 2097152.0f, 0.0f), 2097151.0f);
+    code |= expand21((unsigned long long)x) << (2 - a);
+  }
+  keys[i] = code;
+  vals[i] = i;
+}
+
+// common-prefix length of the keys at sorted positions i and j; equal keys are told apart by position
+__device__ __forceinline__ int delta(const unsigned long long* keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const unsigned long long a = keys[i], b = keys[j];
+  if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+  return __clzll(a ^ b);
+}
+
+// Karras 2012, Algorithm: one thread per internal node; children >= n - 1 + ... are encoded as leaf | 0x80000000
+__global__ void k_lbvh_hierarchy(const unsigned long long* keys, int n, uint32_t* left, uint32_t* right, uint32_t* parent_of_internal, uint32_t* parent_of_leaf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2)
+    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = delta(keys, n, i, j);
+  int s = 0;
+  int t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + min(d, 0);
+  const int lo = min(i, j), hi = max(i, j);
+  const uint32_t L = (lo == gamma) ? (0x80000000u | (uint32_t)gamma) : (uint32_t)gamma;
+  const uint32_t R = (hi == gamma + 1) ? (0x80000000u | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+  left[i] = L;
+  right[i] = R;
+  if (L & 0x80000000u)
+    parent_of_leaf[gamma] = (uint32_t)i;
+  else
+    parent_of_internal[gamma] = (uint32_t)i;
+  if (R & 0x80000000u)
+    parent_of_leaf[gamma + 1] = (uint32_t)i;
+  else
+    parent_of_internal[gamma + 1] = (uint32_t)i;
+}
+
+// One bottom-up pass: an internal node whose children were finished in an EARLIER launch (done < pass) takes
+// the union of their boxes. Kernel boundaries order the writes, so no in-kernel fences are needed.
+__global__ void k_lbvh_refit_pass(int n, uint32_t pass, const uint32_t* left, const uint32_t* right, const uint32_t* sorted, const LBox* leaf_boxes, LBox* node_boxes,
+                                  uint32_t* done, uint32_t* remaining) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1 || done[i]) return;
+  const uint32_t L = left[i], R = right[i];
+  const bool lready = (L & 0x80000000u) || (done[L] && done[L] < pass);
+  const bool rready = (R & 0x80000000u) || (done[R] && done[R] < pass);
+  if (!(lready && rready)) {
+    atomicAdd(remaining, 1u);
+    return;
+  }
+  const LBox a = (L & 0x80000000u) ? leaf_boxes[sorted[L & 0x7FFFFFFFu]] : node_boxes[L];
+  const LBox b = (R & 0x80000000u) ? leaf_boxes[sorted[R & 0x7FFFFFFFu]] : node_boxes[R];
+  LBox u;
+  for (int k = 0; k < 3; k++) {
+    u.lo[k] = fminf(a.lo[k], b.lo[k]);
+    u.hi[k] = fmaxf(a.hi[k], b.hi[k]);
+  }
+  node_boxes[i] = u;
+  done[i] = pass;
+}
+
+__global__ void k_lbvh_emit(int n, uint32_t node_base, uint32_t tri_base, const uint32_t* left, const uint32_t* right, const uint32_t* sorted, const LBox* leaf_boxes,
+                            const LBox* node_boxes, BvhNode* nodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const uint32_t c[2] = {left[i], right[i]};
+  BvhNode out;
+  memset(&out, 0, sizeof(out));
+  for (int k = 0; k < 2; k++) {
+    const bool leaf = c[k] & 0x80000000u;
+    const uint32_t idx = c[k] & 0x7FFFFFFFu;
+    const LBox b = leaf ? leaf_boxes[sorted[idx]] : node_boxes[idx];
+    float* xy = k == 0 ? out.n0xy : out.n1xy;
+    xy[0] = b.lo[0];
+    xy[1] = b.hi[0];
+    xy[2] = b.lo[1];
+    xy[3] = b.hi[1];
+    out.nz[2 * k] = b.lo[2];
+    out.nz[2 * k + 1] = b.hi[2];
+    out.ref[k] = leaf ? (BVH_LEAF_BIT | ((tri_base + idx) << 2)) : (node_base + idx);  // one triangle per leaf
+  }
+  nodes[i] = out;
+}
+
+__global__ void k_lbvh_gather(const BvhTri* in, const uint32_t* sorted, uint32_t n, BvhTri* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[sorted[i]];
+}
+
+#define LB_TRY(expr)                                                            \
+  do {                                                                          \
+    hipError_t _e = (expr);                                                     \
+    if (_e != hipSuccess) {                                                     \
+      err = std::string("lbvh: ") + #expr + ": " + hipGetErrorString(_e);       \
+      ok = false;                                                               \
+      goto done;                                                                \
+    }                                                                           \
+  } while (0)
+
+}  // namespace
+
+// tris_in: n >= 2 triangles (object space, ids filled in). Appends n - 1 nodes and n triangles to the outputs;
+// node and triangle references are made relative to the current sizes of nodes_out / tris_out.
+bool lbvh_build_gpu(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhTri>& tris_out, uint32_t& root_ref, uint32_t& stack_need, float& gpu_ms,
+                    std::string& err) {
+  const uint32_t n = (uint32_t)tris_in.size();
+  const uint32_t node_base = (uint32_t)nodes_out.size(), tri_base = (uint32_t)tris_out.size();
+  bool ok = true;
+  BvhTri *d_in = nullptr, *d_out = nullptr;
+  LBox *d_leaf = nullptr, *d_node = nullptr;
+  uint32_t *d_cb = nullptr, *d_vals = nullptr, *d_sorted = nullptr, *d_left = nullptr, *d_right = nullptr, *d_pi = nullptr, *d_pl = nullptr, *d_done = nullptr, *d_rem = nullptr;
+  unsigned long long *d_keys = nullptr, *d_keys_sorted = nullptr;
+  BvhNode* d_nodes = nullptr;
+  void* d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const uint32_t grid = (n + LB_BLOCK - 1) / LB_BLOCK;
+  uint32_t passes = 0;
+  {
+    LB_TRY(hipMalloc((void**)&d_in, (size_t)n * sizeof(BvhTri)));
+    LB_TRY(hipMalloc((void**)&d_out, (size_t)n * sizeof(BvhTri)));
+    LB_TRY(hipMalloc((void**)&d_leaf, (size_t)n * sizeof(LBox)));
+    LB_TRY(hipMalloc((void**)&d_node, (size_t)n * sizeof(LBox)));
+    LB_TRY(hipMalloc((void**)&d_cb, 8 * sizeof(uint32_t)));
+    LB_TRY(hipMalloc((void**)&d_keys, (size_t)n * 8));
+    LB_TRY(hipMalloc((void**)&d_keys_sorted, (size_t)n * 8));
+    LB_TRY(hipMalloc((void**)&d_vals, (size_t)n * 4));
+    LB_TRY(hipMalloc((void**)&d_sorted, (size_t)n * 4));
+    LB_TRY(hipMalloc((void**)&d_left, (size_t)n * 4));
+    LB_TRY(hipMalloc((void**)&d_right, (size_t)n * 4));
+    LB_TRY(hipMalloc((void**)&d_pi, (size_t)n * 4));
+    LB_TRY(hipMalloc((void**)&d_pl, (size_t)n * 4));
+    LB_TRY(hipMalloc((void**)&d_done, (size_t)n * 4));
+    LB_TRY(hipMalloc((void**)&d_rem, 4));
+    LB_TRY(hipMalloc((void**)&d_nodes, (size_t)n * sizeof(BvhNode)));
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_vals, d_sorted, (int)n, 0, 63));
+    LB_TRY(hipMalloc(&d_tmp, tmp_bytes));
+    LB_TRY(hipMemcpy(d_in, tris_in.data(), (size_t)n * sizeof(BvhTri), hipMemcpyHostToDevice));
+    LB_TRY(hipEventCreate(&e0));
+    LB_TRY(hipEventCreate(&e1));
+    LB_TRY(hipEventRecord(e0, nullptr));
+    const uint32_t init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
+    LB_TRY(hipMemcpyAsync(d_cb, init, sizeof(init), hipMemcpyHostToDevice, nullptr));
+    hipLaunchKernelGGL(k_lbvh_bounds, dim3(grid), dim3(LB_BLOCK), 0, nullptr, d_in, n, d_leaf, d_cb);
+    hipLaunchKernelGGL(k_lbvh_morton, dim3(grid), dim3(LB_BLOCK), 0, nullptr, d_leaf, n, d_cb, d_keys, d_vals);
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_vals, d_sorted, (int)n, 0, 63));
+    hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(grid), dim3(LB_BLOCK), 0, nullptr, d_keys_sorted, (int)n, d_left, d_right, d_pi, d_pl);
+    LB_TRY(hipMemsetAsync(d_done, 0, (size_t)n * 4, nullptr));
+    for (;;) {  // bottom-up, one tree level (at least) per launch; the remaining-node count is read every 8 passes
+      for (int k = 0; k < 8; k++) {
+        passes++;
+        if (k == 7) LB_TRY(hipMemsetAsync(d_rem, 0, 4, nullptr));
+        hipLaunchKernelGGL(k_lbvh_refit_pass, dim3(grid), dim3(LB_BLOCK), 0, nullptr, (int)n, passes, d_left, d_right, d_sorted, d_leaf, d_node, d_done, d_rem);
+      }
+      uint32_t rem = 0;
+      LB_TRY(hipMemcpy(&rem, d_rem, 4, hipMemcpyDeviceToHost));
+      if (rem == 0) break;
+      if (passes > 4096) {
+        err = "lbvh: refit did not converge";
+        ok = false;
+        goto done;
+      }
+    }
+    hipLaunchKernelGGL(k_lbvh_emit, dim3(grid), dim3(LB_BLOCK), 0, nullptr, (int)n, node_base, tri_base, d_left, d_right, d_sorted, d_leaf, d_node, d_nodes);
+    hipLaunchKernelGGL(k_lbvh_gather, dim3(grid), dim3(LB_BLOCK), 0, nullptr, d_in, d_sorted, n, d_out);
+    LB_TRY(hipEventRecord(e1, nullptr));
+    LB_TRY(hipEventSynchronize(e1));
+    LB_TRY(hipGetLastError());
+    LB_TRY(hipEventElapsedTime(&gpu_ms, e0, e1));
+    nodes_out.resize((size_t)node_base + n - 1);
+    tris_out.resize((size_t)tri_base + n);
+    LB_TRY(hipMemcpy(nodes_out.data() + node_base, d_nodes, (size_t)(n - 1) * sizeof(BvhNode), hipMemcpyDeviceToHost));
+    LB_TRY(hipMemcpy(tris_out.data() + tri_base, d_out, (size_t)n * sizeof(BvhTri), hipMemcpyDeviceToHost));
+    root_ref = node_base;  // internal node 0 is the root
+    // done[root] is the pass in which the root was finished = the height of the tree = the bound of the stack
+    LB_TRY(hipMemcpy(&stack_need, d_done, 4, hipMemcpyDeviceToHost));
+  }
+done:
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  (void)hipFree(d_leaf);
+  (void)hipFree(d_node);
+  (void)hipFree(d_cb);
+  (void)hipFree(d_keys);
+  (void)hipFree(d_keys_sorted);
+  (void)hipFree(d_vals);
+  (void)hipFree(d_sorted);
+  (void)hipFree(d_left);
+  (void)hipFree(d_right);
+  (void)hipFree(d_pi);
+  (void)hipFree(d_pl);
+  (void)hipFree(d_done);
+  (void)hipFree(d_rem);
+  (void)hipFree(d_nodes);
+  (void)hipFree(d_tmp);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  return ok;
+}
+
+}  // namespace sthip

@@ -194,6 +194,8 @@ class Stats(C.Structure):
         ("bvh_tri_bytes", C.c_uint32),
         ("bvh_nodes", C.c_uint64),
         ("bvh_tris", C.c_uint64),
+        ("bvh_build_ms", C.c_float),
+        ("bvh_build_gpu_ms", C.c_float),
     ]
 
 
