@@ -49,6 +49,7 @@ struct sthip_ctx {
   int cu_count = 256;
   // scene
   bool has_scene = false;
+  bool has_specular = false;  // some material satisfies DisneyMaterial::is_specular (disney_material.hlsli:125)
   DevBuf<sthip_PackedVertexData> vertices;
   DevBuf<uint8_t> indices;
   DevBuf<sthip_InstanceData> instances;
@@ -251,6 +252,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->has_scene = false;
   for (uint32_t i = 0; i < s->light_count; i++)
     if (s->gLightInstances[i] >= s->instance_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: gLightInstances entry out of range");
+  bool any_specular = false;
   // textures are outside the built path: every material must be constant-valued
   for (uint32_t i = 0; i < s->instance_count; i++) {
     const uint32_t addr = s->gInstances[i].packed[0] >> 4;
@@ -261,7 +263,10 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
       if (rec.values[k].image_index < STHIP_IMAGE_COUNT) return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: textured materials are not part of the built hot path");
     if (rec.bump_index < STHIP_IMAGE_COUNT || rec.alpha_mask_index < STHIP_IMAGE_COUNT)
       return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: bump / alpha-mask images are not part of the built hot path");
+    const float metallic = rec.values[1].value[0], roughness = rec.values[1].value[1], transmission = rec.values[2].value[2];
+    if ((metallic > 0.999f || transmission > 0.999f) && roughness <= 1e-2f) any_specular = true;
   }
+  ctx->has_specular = any_specular;
   sthip::BuiltBvh built;
   std::string err;
   const auto t_build0 = std::chrono::steady_clock::now();
@@ -562,7 +567,11 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   const uint32_t grid = grid_for(ctx, p.path_count);
   const size_t lds = stack_bytes(ctx);
   const uint32_t tgrid = std::min<uint32_t>(trace_grid(ctx, lds), (uint32_t)((P + STHIP_BLOCK - 1) / STHIP_BLOCK));
-  const uint32_t max_bounce_rounds = pc->gMaxPathVertices >= 2 ? pc->gMaxPathVertices - 1 : 0;  // rays per path <= gMaxPathVertices - 1
+  // closest-hit rays per path <= gMaxPathVertices - 1 (path.hlsli:960); without specular materials every scattering
+  // vertex counts as a diffuse vertex, so the path also ends after gMaxDiffuseVertices + 1 rays (path.hlsli:964-966):
+  // rounds beyond that would only be empty launches
+  uint32_t max_bounce_rounds = pc->gMaxPathVertices >= 2 ? pc->gMaxPathVertices - 1 : 0;
+  if (!ctx->has_specular) max_bounce_rounds = std::min(max_bounce_rounds, pc->gMaxDiffuseVertices + 1);
   const bool timing = ctx->time_kernels;
   float ms_closest = 0, ms_shadow = 0, ms_shade = 0, ms_other = 0;
   uint32_t launches_closest = 0, launches_shadow = 0;
