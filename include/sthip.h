@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STHIP_ABI_VERSION 1
+#define STHIP_ABI_VERSION 2
 
 typedef struct sthip_ctx sthip_ctx;
 
@@ -40,6 +40,11 @@ enum sthip_status {
   STHIP_ERR_UNSUPPORTED = -4, /* a flag / scene feature outside the built hot path */
   STHIP_ERR_NO_SCENE = -5
 };
+
+typedef struct sthip_image_desc {
+  const float* pixels; /* width * height * 4 floats */
+  uint32_t width, height;
+} sthip_image_desc;
 
 /* gSceneParams (bdpt.hlsl:19-35) as produced by Scene::update (Scene.cpp:299-684,
  * Scene.hpp:46-69). All pointers are host pointers, borrowed for the call and copied to HBM. */
@@ -57,6 +62,12 @@ typedef struct sthip_scene_desc {
   uint32_t material_bytes;
   const uint32_t* gLightInstances; /* Scene.cpp:406-409 */
   uint32_t light_count;
+  /* Texture2D<float4> gImages[gImageCount] (bdpt.hlsl:33): what ImageValue::image_index refers to. RGBA32F,
+   * row-major, row 0 first. The library builds the mip chain (2x2 box filter) and samples with repeat
+   * addressing and trilinear filtering (the reference's gSamplerRepeat, BDPT.cpp:130-133, minus its 8x
+   * anisotropy, which hardware-defined filtering cannot be restated). May be NULL / 0. */
+  const struct sthip_image_desc* gImages;
+  uint32_t image_count;
 } sthip_scene_desc;
 
 /* gFrameParams view arrays (bdpt.hlsl:37-43), filled by BDPT::render (BDPT.cpp:444-467).

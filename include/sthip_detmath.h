@@ -92,6 +92,9 @@ STHIP_HD float det_logf(float x) {
   return r;
 }
 
+/* log2 of a positive normal float (texture LOD, image_value.h:86,94) */
+STHIP_HD float det_log2f(float x) { return det_logf(x) * 1.44269504088896341f; }
+
 /* e^x for |x| < 87 (Cephes expf) */
 STHIP_HD float det_expf(float x) {
   const float n = floorf(1.44269504088896341f * x + 0.5f);

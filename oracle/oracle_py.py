@@ -108,6 +108,12 @@ class OracleScene:
             raise RuntimeError("orc_trace_rays failed: %d" % rc)
         return hits, counters
 
+    def sample_image(self, index, uv_size, ray_cones=True):
+        q = np.ascontiguousarray(uv_size, np.float32).reshape(-1, 3)
+        out = np.zeros((q.shape[0], 4), np.float32)
+        lib().orc_sample_image(C.c_void_p(self.h), C.c_uint32(index), wire.ptr(q), C.c_uint32(1 if ray_cones else 0), wire.ptr(out), C.c_uint32(q.shape[0]))
+        return out
+
     def shading_data(self, inst_prim, bary):
         inst_prim = np.ascontiguousarray(inst_prim, np.uint32)
         bary = np.ascontiguousarray(bary, np.float32)

@@ -398,7 +398,14 @@ struct RayShear {
 
 }  // namespace
 
+// Texture2D<float4> with its mip chain (2x2 box filter, level k+1 = max(1, floor(dim / 2)))
+struct OrcImage {
+  std::vector<uint32_t> w, h;
+  std::vector<std::vector<float>> mip;  // RGBA32F per level
+};
+
 struct orc_scene {
+  std::vector<OrcImage> images;
   std::vector<sthip_PackedVertexData> vertices;
   std::vector<uint8_t> indices;
   std::vector<Inst> instances;
@@ -653,8 +660,7 @@ Hit trace(const orc_scene& sc, const Ray& r, bool any_hit, bool brute, uint64_t*
 
 // ---------------------------------------------------------------------------------------------
 // W7/S1 — ShadingData and make_triangle_shading_data (shading_data.hlsli:2-73).
-// uv_screen_size / mean_curvature feed only the texture LOD through ray cones (path.hlsli:224-244)
-// and are left 0: the built path has no textures.
+// uv_screen_size / mean_curvature feed the texture LOD through ray cones (path.hlsli:224-244).
 // ---------------------------------------------------------------------------------------------
 struct ShadingData {
   v3 position;
@@ -662,6 +668,7 @@ struct ShadingData {
   uint32_t packed_geometry_normal, packed_shading_normal, packed_tangent;
   float shape_area;
   float u, v;
+  float uv_screen_size, mean_curvature;
   v3 geometry_normal() const { return unpack_normal_octahedron(packed_geometry_normal); }
   v3 shading_normal() const { return unpack_normal_octahedron(packed_shading_normal); }
   v3 tangent() const { return unpack_normal_octahedron(packed_tangent); }
@@ -676,7 +683,7 @@ struct ShadingData {
   }
 };
 
-void make_triangle_shading_data(const orc_scene& sc, ShadingData& r, uint32_t inst_index, uint32_t prim, float b1, float b2) {
+void make_triangle_shading_data(const orc_scene& sc, ShadingData& r, uint32_t inst_index, uint32_t prim, float b1, float b2, bool flip_uvs = false) {
   const Inst& in = sc.instances[inst_index];
   const sthip_TransformData& xf = sc.xf[inst_index];
   uint32_t tri[3];
@@ -695,6 +702,7 @@ void make_triangle_shading_data(const orc_scene& sc, ShadingData& r, uint32_t in
   // :2-63
   r.u = q0.u + (q1.u - q0.u) * b1 + (q2.u - q0.u) * b2;
   r.v = q0.v + (q1.v - q0.v) * b1 + (q2.v - q0.v) * b2;
+  if (flip_uvs) r.v = 1 - r.v;  // gFlipTriangleUVs, shading_data.hlsli:5-6
   const v3 dPds = transform_vector(xf, p0 - p2);
   const v3 dPdt = transform_vector(xf, p1 - p2);
   v3 geometry_normal = cross(dPds, dPdt);
@@ -709,23 +717,35 @@ void make_triangle_shading_data(const orc_scene& sc, ShadingData& r, uint32_t in
   const float inv_det = 1 / det;
   const float dsdu = duvdt1 * inv_det;
   const float dtdu = -duvds1 * inv_det;
+  const float dsdv = duvdt0 * inv_det;
+  const float dtdv = -duvds0 * inv_det;
   v3 dPdu, dPdv;
   if (det != 0) {
     dPdu = -(dPds * dsdu + dPdt * dtdu);
+    dPdv = -(dPds * dsdv + dPdt * dtdv);
+    r.uv_screen_size = 1 / fmaxf(length(dPdu), length(dPdv));
   } else {
     make_orthonormal(geometry_normal, dPdu, dPdv);
+    r.uv_screen_size = 1;
   }
 
   v3 shading_normal = n0 + (n1 - n0) * b1 + (n2 - n0) * b2;
   if ((shading_normal.x == 0 && shading_normal.y == 0 && shading_normal.z == 0) || any_nan(shading_normal)) {
     r.packed_shading_normal = r.packed_geometry_normal;
     r.packed_tangent = pack_normal_octahedron(normalize(dPdu));
+    r.mean_curvature = 0;
   } else {
     shading_normal = normalize(transform_vector(xf, shading_normal));
     const v3 tangent = normalize(dPdu - shading_normal * dot(shading_normal, dPdu));
     r.packed_shading_normal = pack_normal_octahedron(shading_normal);
     r.packed_tangent = pack_normal_octahedron(tangent);
     if (dot(shading_normal, geometry_normal) < 0) r.packed_geometry_normal = pack_normal_octahedron(-geometry_normal);
+    // :56-61
+    const v3 dNds = n2 - n0, dNdt = n2 - n1;
+    const v3 dNdu = dNds * dsdu + dNdt * dtdu;
+    const v3 dNdv = dNds * dsdv + dNdt * dtdv;
+    const v3 bitangent = normalize(cross(shading_normal, tangent));
+    r.mean_curvature = (dot(dNdu, tangent) + dot(dNdv, bitangent)) / 2;
   }
   r.flags = 0;
 }
@@ -823,11 +843,83 @@ struct DisneyMaterial {
   float eta() const { return data[2][3]; }
   float alpha() const { return roughness() * roughness(); }
 
-  // disney_material.hlsli:46-79 with no textures bound (image_index >= gImageCount: image_value.h:187,195)
-  void load(const orc_scene& sc, uint32_t address) {
+  // disney_material.hlsli:46-79; image values: image_value.h:183-207; flags: BDPTFlagBits
+  void load(const orc_scene& sc, uint32_t address, float u, float v, float uv_screen_size, uint32_t& packed_shading_normal, uint32_t& packed_tangent, uint32_t sampling_flags) {
     const sthip_MaterialRecord* rec = (const sthip_MaterialRecord*)&sc.materials[address];
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 4; j++) data[i][j] = rec->values[i].value[j];
+    const bool ray_cones = (sampling_flags >> STHIP_eRayCones) & 1u;
+    for (int i = 0; i < 3; i++) {
+      const sthip_ImageValue4& iv = rec->values[i];
+      float out[4] = {iv.value[0], iv.value[1], iv.value[2], iv.value[3]};
+      if (iv.image_index < STHIP_IMAGE_COUNT) {  // ImageValue4::eval, image_value.h:194-198
+        if (!(iv.value[0] > 0 || iv.value[1] > 0 || iv.value[2] > 0 || iv.value[3] > 0)) {
+          out[0] = out[1] = out[2] = out[3] = 0;
+        } else {
+          float t[4];
+          sample_image(sc, iv.image_index, u, v, uv_screen_size, ray_cones, t);
+          for (int j = 0; j < 4; j++) out[j] = iv.value[j] * t[j];
+        }
+      }
+      for (int j = 0; j < 4; j++) data[i][j] = out[j];
+    }
+    // normal map, disney_material.hlsli:55-74 (flip_bitangent is never set on this path)
+    if (((sampling_flags >> STHIP_eNormalMaps) & 1u) && rec->bump_index < STHIP_IMAGE_COUNT && rec->bump_strength > 0) {
+      float t[4];
+      sample_image(sc, rec->bump_index, u, v, uv_screen_size, ray_cones, t);  // ImageValue3 with value = 1
+      v3 bump = V3(1.0f * t[0], 1.0f * t[1], 1.0f * t[2]) * 2 - V3(1.0f);
+      if ((sampling_flags >> STHIP_eFlipNormalMaps) & 1u) bump.y = -bump.y;
+      bump = normalize(V3(bump.x * rec->bump_strength, bump.y * rec->bump_strength, bump.z > 0 ? bump.z : 1.0f));
+      v3 n = unpack_normal_octahedron(packed_shading_normal);
+      v3 t3 = unpack_normal_octahedron(packed_tangent);
+      n = normalize(t3 * bump.x + cross(n, t3) * bump.y + n * bump.z);
+      t3 = normalize(t3 - n * dot(n, t3));
+      packed_shading_normal = pack_normal_octahedron(n);
+      packed_tangent = pack_normal_octahedron(t3);
+    }
+  }
+  void load(const orc_scene& sc, uint32_t address, ShadingData& sd, uint32_t sampling_flags) {
+    load(sc, address, sd.u, sd.v, sd.uv_screen_size, sd.packed_shading_normal, sd.packed_tangent, sampling_flags);
+  }
+
+  // sample_image, image_value.h:81-97: SampleLevel(gStaticSampler, uv, lod) restated as repeat addressing +
+  // trilinear filtering over the box-filtered mip chain (the reference's 8x anisotropy is hardware-defined)
+  static void texel(const OrcImage& im, uint32_t level, int x, int y, float out[4]) {
+    const int w = (int)im.w[level], h = (int)im.h[level];
+    x = ((x % w) + w) % w;
+    y = ((y % h) + h) % h;
+    const float* p = &im.mip[level][4 * ((size_t)y * w + x)];
+    out[0] = p[0];
+    out[1] = p[1];
+    out[2] = p[2];
+    out[3] = p[3];
+  }
+  static void bilinear(const OrcImage& im, uint32_t level, float u, float v, float out[4]) {
+    const float x = u * (float)im.w[level] - 0.5f, y = v * (float)im.h[level] - 0.5f;
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float fx = x - x0, fy = y - y0;
+    const int ix = (int)x0, iy = (int)y0;
+    float c00[4], c10[4], c01[4], c11[4];
+    texel(im, level, ix, iy, c00);
+    texel(im, level, ix + 1, iy, c10);
+    texel(im, level, ix, iy + 1, c01);
+    texel(im, level, ix + 1, iy + 1, c11);
+    for (int k = 0; k < 4; k++) {
+      const float a = lerpf(c00[k], c10[k], fx), b = lerpf(c01[k], c11[k], fx);
+      out[k] = lerpf(a, b, fy);
+    }
+  }
+  static void sample_image(const orc_scene& sc, uint32_t index, float u, float v, float uv_screen_size, bool ray_cones, float out[4]) {
+    const OrcImage& im = sc.images[index];
+    float lod = 0;
+    if (ray_cones && uv_screen_size > 0) lod = det_log2f(fmaxf(uv_screen_size * fmaxf((float)im.w[0], (float)im.h[0]), 1e-6f));
+    const float top = (float)(im.w.size() - 1);
+    lod = fminf(fmaxf(lod, 0.0f), top);
+    const float l0 = floorf(lod);
+    const uint32_t i0 = (uint32_t)l0, i1 = std::min<uint32_t>(i0 + 1, (uint32_t)im.w.size() - 1);
+    const float f = lod - l0;
+    float a[4], b[4];
+    bilinear(im, i0, u, v, a);
+    bilinear(im, i1, u, v, b);
+    for (int k = 0; k < 4; k++) out[k] = lerpf(a[k], b[k], f);
   }
   v3 Le() const { return base_color() * emission(); }  // :81
   v3 albedo() const { return base_color(); }
@@ -1065,7 +1157,7 @@ float trace_ray(const Frame& fr, v3 origin, v3 direction, float t_max, Intersect
     isect.instance_primitive_index = h.ip;
     if (accept_first) return h.t;  // occlusion query: nothing else is consumed (intersection.hlsli:198-233)
     const Inst& in = fr.sc->instances[isect.instance_index()];
-    make_triangle_shading_data(*fr.sc, isect.sd, isect.instance_index(), isect.primitive_index(), h.b1, h.b2);
+    make_triangle_shading_data(*fr.sc, isect.sd, isect.instance_index(), isect.primitive_index(), h.b1, h.b2, fr.flag(STHIP_eFlipTriangleUVs));
     isect.shape_pdf = 1 / (isect.sd.shape_area * (float)in.prim_count());
     isect.shape_pdf_area_measure = true;
     isect.sd.flags = 0;
@@ -1102,7 +1194,7 @@ void sample_point_on_light(const Frame& fr, LightSampleRecord& ls, const float r
   const float a = sqrtf(rnd[0]);
   const float b1 = 1 - a, b2 = a * rnd[1];
   ShadingData sd;
-  make_triangle_shading_data(sc, sd, light_instance_index, prim_index, b1, b2);
+  make_triangle_shading_data(sc, sd, light_instance_index, prim_index, b1, b2, fr.flag(STHIP_eFlipTriangleUVs));
   ls.position = sd.position;
   ls.normal = sd.geometry_normal();
   ls.to_light = sd.position - ref_pos;
@@ -1113,7 +1205,9 @@ void sample_point_on_light(const Frame& fr, LightSampleRecord& ls, const float r
   ls.radiance = V3(0.0f);
   if (ls.pdf > 0) {
     DisneyMaterial m;
-    m.load(sc, in.material_address());
+    // light.hlsli:143-150: only uv and uv_screen_size = 0 of the ShadingData are set for this lookup
+    uint32_t dummy_n = sd.packed_shading_normal, dummy_t = sd.packed_tangent;
+    m.load(sc, in.material_address(), sd.u, sd.v, 0.0f, dummy_n, dummy_t, fr.sampling_flags & ~(1u << STHIP_eNormalMaps));
     ls.radiance = m.Le();
   }
 }
@@ -1146,6 +1240,7 @@ struct PathIntegrator {
   IntersectionVertex isect;
   v3 local_dir_in;
   float ngdotin, G;
+  float rd_radius, rd_spread;               // RayDifferential (path.hlsli:224-244), only with eRayCones
   v3 radiance;                              // accumulate_contribution target (path.hlsli:300-304)
   sthip_ShadowRayData shadow_rays[32];      // this pixel's gShadowRays slots (path.hlsli:65,355-364)
   uint32_t max_shadow;
@@ -1170,6 +1265,7 @@ struct PathIntegrator {
     G = 1;
     ngdotin = 1;
     prev_cos_out = 1;
+    rd_radius = rd_spread = 0;
   }
 
   // path.hlsli:1003-1044
@@ -1188,6 +1284,10 @@ struct PathIntegrator {
       return;
     }
     const float dist2 = len_sqr(isect.sd.position - origin);
+    if (fr.flag(STHIP_eRayCones)) {  // path.hlsli:1026-1029
+      rd_radius += rd_spread * sqrtf(dist2);
+      isect.sd.uv_screen_size *= rd_radius;
+    }
     G = 1 / dist2;
     ngdotin = -dot(direction, isect.sd.geometry_normal());
     G *= fabsf(ngdotin);
@@ -1297,6 +1397,11 @@ struct PathIntegrator {
       return false;
     }
     if (ms.eta != 0) eta_scale /= pow2(ms.eta);
+    if (fr.flag(STHIP_eRayCones)) {  // path.hlsli:911-916, RayDifferential::reflect / refract :232-243
+      float spec_spread = rd_spread + 2 * isect.sd.mean_curvature * rd_radius;
+      if (ms.eta != 0) spec_spread = spec_spread / ms.eta;
+      rd_spread = fmaxf(0.0f, lerpf(spec_spread, 0.2f, ms.roughness));
+    }
     bsdf_pdf = ms.pdf_fwd;
     const float ndotout = ms.dir_out.z;
     ms.dir_out = normalize(isect.sd.to_world(ms.dir_out));
@@ -1332,7 +1437,7 @@ struct PathIntegrator {
     }
     const uint32_t material_address = fr.sc->instances[isect.instance_index()].material_address();
     DisneyMaterial m;
-    m.load(*fr.sc, material_address);
+    m.load(*fr.sc, material_address, isect.sd, fr.sampling_flags);
     local_dir_in = normalize(isect.sd.to_local(-direction));
     if (!next_vertex_m(m)) {
       beta = V3(0.0f);
@@ -1411,6 +1516,15 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
   path.direction = primary_dir(view, t, (float)x, (float)y, &local_dir_out);
   path.prev_cos_out = fabsf(local_dir_out.z);
   path.origin = V3(t.m[0][3], t.m[1][3], t.m[2][3]);
+  if (fr.flag(STHIP_eRayCones)) {  // bdpt.hlsl:176-189
+    const float cxx = 2 * (((float)x + 1.0f + 0.5f - (float)view.image_min[0]) / ex) - 1, cxy = -(2 * uvy - 1);
+    const float cyx = 2 * uvx - 1, cyy = -(2 * (((float)y + 1.0f + 0.5f - (float)view.image_min[1]) / ey) - 1);
+    const v3 dir_dx = back_project(view.projection, cxx, cxy);
+    const v3 dir_dy = back_project(view.projection, cyx, cyy);
+    const v3 l = local_dir_out / local_dir_out.z;
+    path.rd_radius = 0;
+    path.rd_spread = fminf(length(dir_dx / dir_dx.z - l), length(dir_dy / dir_dy.z - l));
+  }
   path.beta = V3(1.0f);
   path.trace();
   path.bsdf_pdf = 1;
@@ -1433,7 +1547,9 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
   } else {
     {
       DisneyMaterial m;
-      m.load(*fr.sc, fr.sc->instances[path.isect.instance_index()].material_address());
+      ShadingData tmp_sd = path.isect.sd;  // bdpt.hlsl:246-251: the first-hit lookup works on a copy
+      m.load(*fr.sc, fr.sc->instances[path.isect.instance_index()].material_address(), tmp_sd, fr.sampling_flags);
+      vis.packed_normal = tmp_sd.packed_shading_normal;
       path.eval_emission(m.Le());
       if (aov) {
         const v3 a = m.albedo();
@@ -1533,6 +1649,33 @@ orc_scene* orc_scene_create(const sthip_scene_desc* d) {
   }
   sc->materials.assign((const uint8_t*)d->gMaterialData, (const uint8_t*)d->gMaterialData + d->material_bytes);
   if (d->gLightInstances) sc->lights.assign(d->gLightInstances, d->gLightInstances + d->light_count);
+  for (uint32_t i = 0; i < d->image_count && d->gImages; i++) {
+    OrcImage im;
+    uint32_t w = d->gImages[i].width, h = d->gImages[i].height;
+    im.w.push_back(w);
+    im.h.push_back(h);
+    im.mip.emplace_back(d->gImages[i].pixels, d->gImages[i].pixels + (size_t)w * h * 4);
+    while (w > 1 || h > 1) {
+      const uint32_t nw = std::max(1u, w / 2), nh = std::max(1u, h / 2);
+      std::vector<float> next((size_t)nw * nh * 4);
+      const std::vector<float>& prev = im.mip.back();
+      for (uint32_t y = 0; y < nh; y++)
+        for (uint32_t x = 0; x < nw; x++) {
+          const uint32_t x0 = std::min(2 * x, w - 1), x1 = std::min(2 * x + 1, w - 1), y0 = std::min(2 * y, h - 1), y1 = std::min(2 * y + 1, h - 1);
+          for (int k = 0; k < 4; k++) {
+            const float a = prev[4 * ((size_t)y0 * w + x0) + k], b = prev[4 * ((size_t)y0 * w + x1) + k];
+            const float c = prev[4 * ((size_t)y1 * w + x0) + k], e = prev[4 * ((size_t)y1 * w + x1) + k];
+            next[4 * ((size_t)y * nw + x) + k] = ((a + b) + (c + e)) * 0.25f;
+          }
+        }
+      im.mip.push_back(std::move(next));
+      w = nw;
+      h = nh;
+      im.w.push_back(w);
+      im.h.push_back(h);
+    }
+    sc->images.push_back(std::move(im));
+  }
 
   // one BLAS per unique mesh range
   std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t> mesh_of;
@@ -1775,7 +1918,11 @@ void orc_disney_sample(const sthip_MaterialRecord* rec, const float* dir_in, con
     o[12] = beta.z;
   }
 }
-// shading data of (instance, primitive, barycentrics) -> sthip_ShadingData (uv_screen_size, mean_curvature = 0)
+// sample_image (image_value.h:81-97) of gImages[index] at n (u, v, uv_screen_size) triples -> RGBA
+void orc_sample_image(orc_scene* sc, uint32_t index, const float* uvs, uint32_t ray_cones, float* out, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) DisneyMaterial::sample_image(*sc, index, uvs[3 * i], uvs[3 * i + 1], uvs[3 * i + 2], ray_cones != 0, out + 4 * (size_t)i);
+}
+// shading data of (instance, primitive, barycentrics) -> sthip_ShadingData
 void orc_shading_data(orc_scene* sc, const uint32_t* inst_prim, const float* bary, sthip_ShadingData* out, uint32_t n) {
   for (uint32_t i = 0; i < n; i++) {
     ShadingData sd;
@@ -1790,8 +1937,8 @@ void orc_shading_data(orc_scene* sc, const uint32_t* inst_prim, const float* bar
     out[i].shape_area = sd.shape_area;
     out[i].uv[0] = sd.u;
     out[i].uv[1] = sd.v;
-    out[i].uv_screen_size = 0;
-    out[i].mean_curvature = 0;
+    out[i].uv_screen_size = sd.uv_screen_size;
+    out[i].mean_curvature = sd.mean_curvature;
   }
 }
 

@@ -49,6 +49,7 @@ struct sthip_ctx {
   int cu_count = 256;
   // scene
   bool has_scene = false;
+  bool textured = false;      // some material binds an image: k_shade<true> (ray cones, image values, normal maps)
   bool has_specular = false;  // some material satisfies DisneyMaterial::is_specular (disney_material.hlsli:125)
   DevBuf<sthip_PackedVertexData> vertices;
   DevBuf<uint8_t> indices;
@@ -56,6 +57,10 @@ struct sthip_ctx {
   DevBuf<sthip_TransformData> xf, inv_xf, motion_xf;
   DevBuf<uint8_t> materials;
   DevBuf<uint32_t> lights;
+  DevBuf<DeviceImage> images;
+  DevBuf<float4> image_texels;
+  uint32_t image_count = 0;
+  DevBuf<float2> cone;
   uint32_t instance_count = 0, light_count = 0;
   DevBuf<BvhNode> nodes;
   DevBuf<BvhTri> tris;
@@ -156,6 +161,9 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->motion_xf.release();
   ctx->materials.release();
   ctx->lights.release();
+  ctx->images.release();
+  ctx->image_texels.release();
+  ctx->cone.release();
   ctx->nodes.release();
   ctx->tris.release();
   ctx->entries.release();
@@ -252,21 +260,29 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->has_scene = false;
   for (uint32_t i = 0; i < s->light_count; i++)
     if (s->gLightInstances[i] >= s->instance_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: gLightInstances entry out of range");
-  bool any_specular = false;
-  // textures are outside the built path: every material must be constant-valued
+  bool any_specular = false, any_image = false;
+  // materials: constant values or image values over gImages (image_value.h:183-207)
   for (uint32_t i = 0; i < s->instance_count; i++) {
     const uint32_t addr = s->gInstances[i].packed[0] >> 4;
     if ((size_t)addr + sizeof(sthip_MaterialRecord) > s->material_bytes) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: material_address out of range");
     sthip_MaterialRecord rec;
     memcpy(&rec, (const uint8_t*)s->gMaterialData + addr, sizeof(rec));
     for (int k = 0; k < 3; k++)
-      if (rec.values[k].image_index < STHIP_IMAGE_COUNT) return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: textured materials are not part of the built hot path");
-    if (rec.bump_index < STHIP_IMAGE_COUNT || rec.alpha_mask_index < STHIP_IMAGE_COUNT)
-      return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: bump / alpha-mask images are not part of the built hot path");
+      if (rec.values[k].image_index < STHIP_IMAGE_COUNT) {
+        if (rec.values[k].image_index >= s->image_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: a material refers to an image that is not in gImages");
+        any_image = true;
+      }
+    if (rec.bump_index < STHIP_IMAGE_COUNT) {
+      if (rec.bump_index >= s->image_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: a bump map refers to an image that is not in gImages");
+      any_image = true;
+    }
+    if (rec.alpha_mask_index < STHIP_IMAGE_COUNT) return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: alpha-mask images (eAlphaTest) are not part of the built hot path");
     const float metallic = rec.values[1].value[0], roughness = rec.values[1].value[1], transmission = rec.values[2].value[2];
     if ((metallic > 0.999f || transmission > 0.999f) && roughness <= 1e-2f) any_specular = true;
   }
   ctx->has_specular = any_specular;
+  ctx->textured = any_image;
+  if (s->image_count && !s->gImages) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: image_count > 0 but gImages is NULL");
   sthip::BuiltBvh built;
   std::string err;
   const auto t_build0 = std::chrono::steady_clock::now();
@@ -303,6 +319,48 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (s->light_count) HIP_TRY(ctx, hipMemcpy(ctx->lights.p, s->gLightInstances, (size_t)s->light_count * 4, hipMemcpyHostToDevice));
   ctx->instance_count = n;
   ctx->light_count = s->light_count;
+  // images: mip chain by 2x2 box filter, level k+1 = max(1, floor(dim / 2)), ((a + b) + (c + d)) * 0.25
+  {
+    std::vector<DeviceImage> table(s->image_count);
+    std::vector<float> texels;
+    for (uint32_t i = 0; i < s->image_count; i++) {
+      uint32_t w = s->gImages[i].width, h = s->gImages[i].height;
+      if (!s->gImages[i].pixels || w == 0 || h == 0 || w > 0xFFFF || h > 0xFFFF) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: bad image");
+      DeviceImage& im = table[i];
+      memset(&im, 0, sizeof(im));
+      size_t level_start = texels.size();
+      texels.insert(texels.end(), s->gImages[i].pixels, s->gImages[i].pixels + (size_t)w * h * 4);
+      for (uint32_t level = 0;; level++) {
+        im.offset[level] = (uint32_t)(level_start / 4);
+        im.w[level] = (uint16_t)w;
+        im.h[level] = (uint16_t)h;
+        im.levels = level + 1;
+        if ((w == 1 && h == 1) || level + 1 == STHIP_MAX_MIPS) break;
+        const uint32_t nw = std::max(1u, w / 2), nh = std::max(1u, h / 2);
+        const size_t next_start = texels.size();
+        texels.resize(next_start + (size_t)nw * nh * 4);
+        const float* prev = texels.data() + level_start;
+        float* next = texels.data() + next_start;
+        for (uint32_t y = 0; y < nh; y++)
+          for (uint32_t x = 0; x < nw; x++) {
+            const uint32_t x0 = std::min(2 * x, w - 1), x1 = std::min(2 * x + 1, w - 1), y0 = std::min(2 * y, h - 1), y1 = std::min(2 * y + 1, h - 1);
+            for (int k = 0; k < 4; k++) {
+              const float a = prev[4 * ((size_t)y0 * w + x0) + k], b = prev[4 * ((size_t)y0 * w + x1) + k];
+              const float c = prev[4 * ((size_t)y1 * w + x0) + k], e = prev[4 * ((size_t)y1 * w + x1) + k];
+              next[4 * ((size_t)y * nw + x) + k] = ((a + b) + (c + e)) * 0.25f;
+            }
+          }
+        level_start = next_start;
+        w = nw;
+        h = nh;
+      }
+    }
+    HIP_TRY(ctx, ctx->images.ensure(std::max<size_t>(1, table.size())));
+    HIP_TRY(ctx, ctx->image_texels.ensure(std::max<size_t>(1, texels.size() / 4)));
+    if (!table.empty()) HIP_TRY(ctx, hipMemcpy(ctx->images.p, table.data(), table.size() * sizeof(DeviceImage), hipMemcpyHostToDevice));
+    if (!texels.empty()) HIP_TRY(ctx, hipMemcpy(ctx->image_texels.p, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->image_count = s->image_count;
+  }
 
   HIP_TRY(ctx, ctx->nodes.ensure(std::max<size_t>(1, built.nodes.size())));
   HIP_TRY(ctx, ctx->tris.ensure(std::max<size_t>(1, built.tris.size())));
@@ -450,6 +508,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   HIP_TRY(ctx, ctx->radiance.ensure(P));
   HIP_TRY(ctx, ctx->shadow_sum.ensure(P));
   HIP_TRY(ctx, ctx->accum.ensure(P0));
+  if (ctx->textured) HIP_TRY(ctx, ctx->cone.ensure(P));
   HIP_TRY(ctx, ctx->shadow_rays.ensure(3 * P));
   HIP_TRY(ctx, ctx->meta.ensure(P));
   HIP_TRY(ctx, ctx->queue0.ensure(P));
@@ -488,6 +547,9 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.scene.lights = ctx->lights.p;
   p.scene.instance_count = ctx->instance_count;
   p.scene.light_count = ctx->light_count;
+  p.scene.images = ctx->images.p;
+  p.scene.image_texels = ctx->image_texels.p;
+  p.scene.image_count = ctx->image_count;
   p.bvh = ctx->bvh;
   p.ray_o = ctx->ray_o.p;
   p.ray_d = ctx->ray_d.p;
@@ -497,6 +559,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.radiance = ctx->radiance.p;
   p.shadow_sum = ctx->shadow_sum.p;
   p.accum = ctx->accum.p;
+  p.cone = ctx->textured ? ctx->cone.p : nullptr;
   p.queue[0] = ctx->queue0.p;
   p.queue[1] = ctx->queue1.p;
   p.shadow_rays = ctx->shadow_rays.p;
@@ -609,7 +672,12 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       });
       if (rc) return rc;
       launches_closest++;
-      rc = timed(ms_shade, [&]() { hipLaunchKernelGGL(k_shade, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth); });
+      rc = timed(ms_shade, [&]() {
+        if (ctx->textured)
+          hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else
+          hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+      });
       if (rc) return rc;
       bool last_round = false;
       if (timing) {

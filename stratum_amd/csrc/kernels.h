@@ -55,6 +55,7 @@ struct FrameParams {
   uint32_t* meta;      // path_length | diffuse_vertices << 8
   float4* radiance;    // gRadiance[px].rgb of the seed in flight
   float4* shadow_sum;  // the sum `c` of trace_shadows
+  float2* cone;        // RayDifferential (radius, spread), path.hlsli:224-244; only allocated for textured scenes
   float4* accum;       // running mean over seeds (temporal_accumulation.hlsl:118-131): rgb, n
   // queues
   uint32_t* queue[2];
@@ -170,7 +171,19 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
     }
     const sthip_ViewData& view = p.views[view_index];
     const Xf t = load_xf(p.view_xf, (uint32_t)view_index);
-    const f3 dir = primary_dir(view, t, (float)px, (float)py, nullptr);
+    f3 local_dir;
+    const f3 dir = primary_dir(view, t, (float)px, (float)py, &local_dir);
+    if (p.cone) {  // bdpt.hlsl:176-189
+      const float ex = (float)(view.image_max[0] - view.image_min[0]), ey = (float)(view.image_max[1] - view.image_min[1]);
+      const float uvx = ((float)px + 0.5f - (float)view.image_min[0]) / ex, uvy = ((float)py + 0.5f - (float)view.image_min[1]) / ey;
+      const float cxx = 2 * (((float)px + 1.0f + 0.5f - (float)view.image_min[0]) / ex) - 1, cxy = -(2 * uvy - 1);
+      const float cyx = 2 * uvx - 1, cyy = -(2 * (((float)py + 1.0f + 0.5f - (float)view.image_min[1]) / ey) - 1);
+      const f3 dir_dx = back_project(view.projection, cxx, cxy), dir_dy = back_project(view.projection, cyx, cyy);
+      const f3 l = local_dir / local_dir.z;
+      float spread = 0.0f;
+      if (flag(p, STHIP_eRayCones)) spread = fminf(length3(dir_dx / dir_dx.z - l), length3(dir_dy / dir_dy.z - l));
+      p.cone[slot] = make_float2(0.0f, spread);
+    }
     p.ray_o[slot] = make_float4(t.r0.w, t.r1.w, t.r2.w, 1.0f);
     p.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
     p.beta[slot] = make_float4(1, 1, 1, __uint_as_float(0u));
@@ -293,6 +306,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
 // (bdpt.hlsl:222-296) at depth 0, then next_vertex() (path.hlsli:955-998,1048-1075) up to the point
 // where the next ray is known
 // ---------------------------------------------------------------------------------------------
+// TEXTURED: the scene binds images; ray cones, image values and normal maps are evaluated
+template <bool TEXTURED>
 __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_t depth) {
   const uint32_t n = depth == 0 ? p.path_count : (uint32_t)p.counters[CNT_QUEUE0 + depth];
   const uint32_t* queue_in = p.queue[depth & 1u];
@@ -322,6 +337,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
     f3 radiance = depth == 0 ? F3s(0.0f) : xyz(p.radiance[slot]);
     const size_t pixel = (size_t)py * p.pc.gOutputExtent[0] + px;
     bool alive = false;
+    float rd_radius = 0, rd_spread = 0;  // RayDifferential of this path (TEXTURED only)
     f3 new_origin = origin, new_direction = direction;
 
     do {
@@ -355,7 +371,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
       const uint32_t inst_index = ip & 0xFFFFu, prim = ip >> 16;
       const Inst in = load_inst(p.scene, inst_index);
       ShadingData sd;
-      make_triangle_shading_data(p.scene, sd, inst_index, in, prim, hh.y, hh.z);
+      make_triangle_shading_data(p.scene, sd, inst_index, in, prim, hh.y, hh.z, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
       const float shape_pdf = 1 / (sd.shape_area * (float)in.prim_count());  // intersection.hlsli:172
       const f3 gn = sd.geometry_normal();
       // path.hlsli:1023-1040
@@ -368,7 +384,26 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
         G = 1;
       }
       DisneyMaterial m;
-      m.load(p.scene, in.material_address());
+      uint32_t first_hit_normal = sd.packed_shading_normal;
+      if (TEXTURED) {
+        const float2 cone = p.cone[slot];
+        rd_radius = cone.x;
+        rd_spread = cone.y;
+        if (flag(p, STHIP_eRayCones)) {  // path.hlsli:1026-1029
+          rd_radius += rd_spread * sqrtf(dist2);
+          sd.uv_screen_size *= rd_radius;
+        }
+        if (depth == 0) {
+          // bdpt.hlsl:246-253: the first-hit lookup (emission, albedo, visibility normal) works on a copy of sd,
+          // next_vertex() then loads the material again into the real one (path.hlsli:1068): same values
+          uint32_t n_copy = sd.packed_shading_normal, t_copy = sd.packed_tangent;
+          m.load_textured(p.scene, in.material_address(), sd.u, sd.v, sd.uv_screen_size, n_copy, t_copy, p.sampling_flags);
+          first_hit_normal = n_copy;
+        }
+        m.load_textured(p.scene, in.material_address(), sd.u, sd.v, sd.uv_screen_size, sd.packed_shading_normal, sd.packed_tangent, p.sampling_flags);
+      } else {
+        m.load(p.scene, in.material_address());
+      }
       const f3 Le = m.Le();
 
       // eval_emission, path.hlsli:847-894 (emissive surface, uniform light choice, no BDPT)
@@ -399,7 +434,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
           if (p.out_visibility) {
             sthip_VisibilityInfo vis;
             vis.instance_primitive_index = ip;
-            vis.packed_normal = sd.packed_shading_normal;
+            vis.packed_normal = first_hit_normal;
             p.out_visibility[pixel] = vis;
           }
           if (p.out_depth || p.out_prev_uv) {
@@ -456,7 +491,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
           const uint32_t lprim = (uint32_t)fminf(r2 * (float)lpc, (float)(lpc - 1));
           const float a = sqrtf(r0);
           ShadingData lsd;
-          make_triangle_shading_data(p.scene, lsd, light_instance_index, lin, lprim, 1 - a, a * r1);
+          make_triangle_shading_data(p.scene, lsd, light_instance_index, lin, lprim, 1 - a, a * r1, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
           const f3 ls_normal = lsd.geometry_normal();
           f3 to_light = lsd.position - sd.position;
           const float ls_dist = length3(to_light);
@@ -465,7 +500,12 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
           f3 lLe = F3s(0.0f);
           if (ls_pdf > 0) {
             DisneyMaterial lm;
-            lm.load(p.scene, lin.material_address());
+            if (TEXTURED) {  // light.hlsli:143-150: uv of the light sample, uv_screen_size = 0, no normal map
+              uint32_t dn = lsd.packed_shading_normal, dt = lsd.packed_tangent;
+              lm.load_textured(p.scene, lin.material_address(), lsd.u, lsd.v, 0.0f, dn, dt, p.sampling_flags & ~(1u << STHIP_eNormalMaps));
+            } else {
+              lm.load(p.scene, lin.material_address());
+            }
             lLe = lm.Le();
           }
           const float pdfA = ls_pdf;
@@ -515,6 +555,11 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
       m.sample(ms, F3(s0, s1, s2), local_dir_in, beta, false);
       if (ms.pdf_fwd < 1e-6f) break;
       if (ms.eta != 0) eta_scale /= pow2f(ms.eta);
+      if (TEXTURED && flag(p, STHIP_eRayCones)) {  // path.hlsli:911-916, RayDifferential::reflect / refract :232-243
+        float spec_spread = rd_spread + 2 * sd.mean_curvature * rd_radius;
+        if (ms.eta != 0) spec_spread = spec_spread / ms.eta;
+        rd_spread = fmaxf(0.0f, lerp1(spec_spread, 0.2f, ms.roughness));
+      }
       bsdf_pdf = ms.pdf_fwd;
       const float ndotout = ms.dir_out.z;
       const f3 dir_out = normalize3(frame.to_world(ms.dir_out));
@@ -532,6 +577,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
       p.ray_d[slot] = make_float4(new_direction.x, new_direction.y, new_direction.z, eta_scale);
       p.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(rng.counter));
       p.meta[slot] = path_length | (diffuse_vertices << 8);
+      if (TEXTURED) p.cone[slot] = make_float2(rd_radius, rd_spread);
       const uint32_t k = (uint32_t)atomicAdd(&p.counters[CNT_QUEUE0 + depth + 1], 1ull);
       queue_out[k] = slot;
     }

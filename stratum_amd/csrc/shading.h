@@ -18,6 +18,18 @@ struct DeviceScene {
   const uint32_t* lights;
   uint32_t instance_count;
   uint32_t light_count;
+  // Texture2D<float4> gImages[] (bdpt.hlsl:33): mip chains packed into one float4 buffer
+  const struct DeviceImage* images;
+  const float4* image_texels;
+  uint32_t image_count;
+};
+
+#define STHIP_MAX_MIPS 16
+struct DeviceImage {
+  uint32_t offset[STHIP_MAX_MIPS];  // first texel of each level in image_texels
+  uint16_t w[STHIP_MAX_MIPS], h[STHIP_MAX_MIPS];
+  uint32_t levels;
+  uint32_t pad[3];
 };
 
 // scene.h:29-47
@@ -140,7 +152,8 @@ DEV f3 ray_offset(f3 pos, f3 n) {
 
 // ---------------------------------------------------------------------------------------------
 // W7/S1 — ShadingData, shading_data.h:10-37 and shading_data.hlsli:2-73.
-// uv_screen_size / mean_curvature only feed texture LOD via ray cones; untextured path -> not kept.
+// uv_screen_size / mean_curvature feed the texture LOD through ray cones (path.hlsli:224-244); in the untextured
+// kernel instantiation nothing reads them and the compiler drops their computation.
 // ---------------------------------------------------------------------------------------------
 struct ShadingData {
   f3 position;
@@ -148,6 +161,7 @@ struct ShadingData {
   uint32_t packed_geometry_normal, packed_shading_normal, packed_tangent;
   float shape_area;
   float u, v;
+  float uv_screen_size, mean_curvature;
   DEV f3 geometry_normal() const { return unpack_normal_octahedron(packed_geometry_normal); }
   DEV f3 shading_normal() const { return unpack_normal_octahedron(packed_shading_normal); }
   DEV f3 tangent() const { return unpack_normal_octahedron(packed_tangent); }
@@ -167,7 +181,7 @@ DEV Frame3 make_frame(const ShadingData& sd) {
   return f;
 }
 
-DEV void make_triangle_shading_data(const DeviceScene& sc, ShadingData& r, uint32_t inst_index, const Inst& in, uint32_t prim, float b1, float b2) {
+DEV void make_triangle_shading_data(const DeviceScene& sc, ShadingData& r, uint32_t inst_index, const Inst& in, uint32_t prim, float b1, float b2, bool flip_uvs = false) {
   const Xf xf = load_xf(sc.xf, inst_index);
   uint32_t i0, i1, i2;
   load_tri(sc, in, prim, i0, i1, i2);
@@ -185,6 +199,7 @@ DEV void make_triangle_shading_data(const DeviceScene& sc, ShadingData& r, uint3
   // :2-63
   r.u = u0 + (u1 - u0) * b1 + (u2 - u0) * b2;
   r.v = v0 + (v1 - v0) * b1 + (v2 - v0) * b2;
+  if (flip_uvs) r.v = 1 - r.v;  // gFlipTriangleUVs, shading_data.hlsli:5-6
   const f3 dPds = xf_vector(xf, p0 - p2);
   const f3 dPdt = xf_vector(xf, p1 - p2);
   f3 geometry_normal = cross3(dPds, dPdt);
@@ -199,22 +214,34 @@ DEV void make_triangle_shading_data(const DeviceScene& sc, ShadingData& r, uint3
   const float inv_det = 1 / det;
   const float dsdu = duvdt1 * inv_det;
   const float dtdu = -duvds1 * inv_det;
+  const float dsdv = duvdt0 * inv_det;
+  const float dtdv = -duvds0 * inv_det;
   f3 dPdu, dPdv;
   if (det != 0) {
     dPdu = -(dPds * dsdu + dPdt * dtdu);
+    dPdv = -(dPds * dsdv + dPdt * dtdv);
+    r.uv_screen_size = 1 / fmaxf(length3(dPdu), length3(dPdv));
   } else {
     make_orthonormal(geometry_normal, dPdu, dPdv);
+    r.uv_screen_size = 1;
   }
   f3 shading_normal = n0 + (n1 - n0) * b1 + (n2 - n0) * b2;
   if ((shading_normal.x == 0 && shading_normal.y == 0 && shading_normal.z == 0) || any_nan(shading_normal)) {
     r.packed_shading_normal = r.packed_geometry_normal;
     r.packed_tangent = pack_normal_octahedron(normalize3(dPdu));
+    r.mean_curvature = 0;
   } else {
     shading_normal = normalize3(xf_vector(xf, shading_normal));
     const f3 tangent = normalize3(dPdu - shading_normal * dot3(shading_normal, dPdu));
     r.packed_shading_normal = pack_normal_octahedron(shading_normal);
     r.packed_tangent = pack_normal_octahedron(tangent);
     if (dot3(shading_normal, geometry_normal) < 0) r.packed_geometry_normal = pack_normal_octahedron(-geometry_normal);
+    // :56-61
+    const f3 dNds = n2 - n0, dNdt = n2 - n1;
+    const f3 dNdu = dNds * dsdu + dNdt * dtdu;
+    const f3 dNdv = dNds * dsdv + dNdt * dtdv;
+    const f3 bitangent = normalize3(cross3(shading_normal, tangent));
+    r.mean_curvature = (dot3(dNdu, tangent) + dot3(dNdv, bitangent)) / 2;
   }
   r.flags = 0;
 }
@@ -312,12 +339,77 @@ struct DisneyMaterial {
   DEV float eta() const { return d2.w; }
   DEV float alpha() const { return roughness() * roughness(); }
 
-  // disney_material.hlsli:46-79 with no textures bound (checked at upload); records are 72 B at 4-byte alignment
+  // disney_material.hlsli:46-79 with no textures bound; records are 72 B at 4-byte alignment
   DEV void load(const DeviceScene& sc, uint32_t address) {
     const float* p = reinterpret_cast<const float*>(sc.materials + address);
     d0 = make_float4(p[0], p[1], p[2], p[3]);
     d1 = make_float4(p[5], p[6], p[7], p[8]);
     d2 = make_float4(p[10], p[11], p[12], p[13]);
+  }
+
+  // sample_image, image_value.h:81-97: SampleLevel(gStaticSampler, uv, lod) as repeat addressing + trilinear
+  // filtering over the box-filtered mip chain
+  static DEV float4 texel(const DeviceScene& sc, const DeviceImage& im, uint32_t level, int x, int y) {
+    const int w = (int)im.w[level], h = (int)im.h[level];
+    x = ((x % w) + w) % w;
+    y = ((y % h) + h) % h;
+    return sc.image_texels[im.offset[level] + (uint32_t)y * (uint32_t)w + (uint32_t)x];
+  }
+  static DEV float4 bilinear(const DeviceScene& sc, const DeviceImage& im, uint32_t level, float u, float v) {
+    const float x = u * (float)im.w[level] - 0.5f, y = v * (float)im.h[level] - 0.5f;
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float fx = x - x0, fy = y - y0;
+    const int ix = (int)x0, iy = (int)y0;
+    const float4 c00 = texel(sc, im, level, ix, iy), c10 = texel(sc, im, level, ix + 1, iy);
+    const float4 c01 = texel(sc, im, level, ix, iy + 1), c11 = texel(sc, im, level, ix + 1, iy + 1);
+    float4 r;
+    r.x = lerp1(lerp1(c00.x, c10.x, fx), lerp1(c01.x, c11.x, fx), fy);
+    r.y = lerp1(lerp1(c00.y, c10.y, fx), lerp1(c01.y, c11.y, fx), fy);
+    r.z = lerp1(lerp1(c00.z, c10.z, fx), lerp1(c01.z, c11.z, fx), fy);
+    r.w = lerp1(lerp1(c00.w, c10.w, fx), lerp1(c01.w, c11.w, fx), fy);
+    return r;
+  }
+  static DEV float4 sample_image(const DeviceScene& sc, uint32_t index, float u, float v, float uv_screen_size, bool ray_cones) {
+    const DeviceImage& im = sc.images[index];
+    float lod = 0;
+    if (ray_cones && uv_screen_size > 0) lod = det_log2f(fmaxf(uv_screen_size * fmaxf((float)im.w[0], (float)im.h[0]), 1e-6f));
+    const float top = (float)(im.levels - 1);
+    lod = fminf(fmaxf(lod, 0.0f), top);
+    const float l0 = floorf(lod);
+    const uint32_t i0 = (uint32_t)l0, i1 = min(i0 + 1, im.levels - 1);
+    const float f = lod - l0;
+    const float4 a = bilinear(sc, im, i0, u, v), b = bilinear(sc, im, i1, u, v);
+    return make_float4(lerp1(a.x, b.x, f), lerp1(a.y, b.y, f), lerp1(a.z, b.z, f), lerp1(a.w, b.w, f));
+  }
+  static DEV float4 eval_image_value4(const DeviceScene& sc, const float* p, float u, float v, float uvs, bool ray_cones) {  // image_value.h:194-198
+    const float4 value = make_float4(p[0], p[1], p[2], p[3]);
+    const uint32_t image_index = reinterpret_cast<const uint32_t*>(p)[4];
+    if (image_index >= STHIP_IMAGE_COUNT) return value;
+    if (!(value.x > 0 || value.y > 0 || value.z > 0 || value.w > 0)) return make_float4(0, 0, 0, 0);
+    const float4 t = sample_image(sc, image_index, u, v, uvs, ray_cones);
+    return make_float4(value.x * t.x, value.y * t.y, value.z * t.z, value.w * t.w);
+  }
+  // disney_material.hlsli:46-79 with image values and the normal map (flip_bitangent is never set on this path)
+  DEV void load_textured(const DeviceScene& sc, uint32_t address, float u, float v, float uvs, uint32_t& packed_shading_normal, uint32_t& packed_tangent, uint32_t sampling_flags) {
+    const float* p = reinterpret_cast<const float*>(sc.materials + address);
+    const bool ray_cones = (sampling_flags >> STHIP_eRayCones) & 1u;
+    d0 = eval_image_value4(sc, p, u, v, uvs, ray_cones);
+    d1 = eval_image_value4(sc, p + 5, u, v, uvs, ray_cones);
+    d2 = eval_image_value4(sc, p + 10, u, v, uvs, ray_cones);
+    const uint32_t bump_index = reinterpret_cast<const uint32_t*>(p)[16];
+    const float bump_strength = p[17];
+    if (((sampling_flags >> STHIP_eNormalMaps) & 1u) && bump_index < STHIP_IMAGE_COUNT && bump_strength > 0) {
+      const float4 t = sample_image(sc, bump_index, u, v, uvs, ray_cones);
+      f3 bump = F3(1.0f * t.x, 1.0f * t.y, 1.0f * t.z) * 2 - F3s(1.0f);
+      if ((sampling_flags >> STHIP_eFlipNormalMaps) & 1u) bump.y = -bump.y;
+      bump = normalize3(F3(bump.x * bump_strength, bump.y * bump_strength, bump.z > 0 ? bump.z : 1.0f));
+      f3 n = unpack_normal_octahedron(packed_shading_normal);
+      f3 t3 = unpack_normal_octahedron(packed_tangent);
+      n = normalize3(t3 * bump.x + cross3(n, t3) * bump.y + n * bump.z);
+      t3 = normalize3(t3 - n * dot3(n, t3));
+      packed_shading_normal = pack_normal_octahedron(n);
+      packed_tangent = pack_normal_octahedron(t3);
+    }
   }
   DEV f3 Le() const { return base_color() * emission(); }
   DEV f3 albedo() const { return base_color(); }

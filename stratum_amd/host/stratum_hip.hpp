@@ -363,13 +363,29 @@ inline TransformData node_to_world(const Node& node) {
 // ------------------------------------------------------------------------------------------------
 // scene components: Material.hpp:13-38, Scene.hpp:15-37
 // ------------------------------------------------------------------------------------------------
+// an RGBA32F texture (what the reference holds as an Image::View of a Texture2D<float4>)
+struct Image {
+  uint32_t width = 0, height = 0;
+  std::vector<float> pixels;  // width * height * 4, row 0 first
+};
+// MaterialResources, image_value.h:34-66: images get their gImages index the first time a material stores them
+struct MaterialResources {
+  std::vector<const Image*> image4s;
+  uint32_t get_index(const component_ptr<Image>& image) {
+    if (!image) return ~0u;
+    for (size_t i = 0; i < image4s.size(); i++)
+      if (image4s[i] == image.get()) return (uint32_t)i;
+    image4s.push_back(image.get());
+    return (uint32_t)image4s.size() - 1;
+  }
+};
 struct ImageValue4 {
   float value[4] = {0, 0, 0, 0};
-  uint32_t image_index = ~0u;  // no image bound (MaterialResources::get_index of a null view, image_value.h:40-41)
+  component_ptr<Image> image;  // null: constant value
 };
 struct Material {
   ImageValue4 values[3];
-  uint32_t alpha_mask_index = ~0u, bump_index = ~0u;
+  component_ptr<Image> bump_image;
   float bump_strength = 1;
   float* base_color() { return values[0].value; }
   float& emission() { return values[0].value[3]; }
@@ -381,18 +397,18 @@ struct Material {
   float& clearcoat_gloss() { return values[2].value[1]; }
   float& transmission() { return values[2].value[2]; }
   float& eta() { return values[2].value[3]; }
-  // Material::store, Material.hpp:32-38
-  void store(std::vector<uint32_t>& bytes) const {
+  // Material::store, Material.hpp:32-38 (alpha masks are outside the built path: always "no image")
+  void store(std::vector<uint32_t>& bytes, MaterialResources& resources) const {
     for (int i = 0; i < 3; i++) {
       for (int j = 0; j < 4; j++) {
         uint32_t u;
         std::memcpy(&u, &values[i].value[j], 4);
         bytes.push_back(u);
       }
-      bytes.push_back(values[i].image_index);
+      bytes.push_back(resources.get_index(values[i].image));
     }
-    bytes.push_back(alpha_mask_index);
-    bytes.push_back(bump_index);
+    bytes.push_back(~0u);
+    bytes.push_back(resources.get_index(bump_image));
     uint32_t u;
     std::memcpy(&u, &bump_strength, 4);
     bytes.push_back(u);
@@ -468,6 +484,8 @@ class Scene {
     std::vector<TransformData> mInstanceTransforms, mInstanceInverseTransforms, mInstanceMotionTransforms;
     std::vector<uint32_t> mLightInstanceMap;
     std::vector<Node*> mInstanceNodes;
+    MaterialResources mResources;
+    std::vector<sthip_image_desc> mImageDescs;
     uint32_t mEnvironmentMaterialAddress = ~0u;
     uint32_t mMaterialCount = 0;
     uint32_t mEmissivePrimitiveCount = 0;
@@ -486,6 +504,8 @@ class Scene {
       d.material_bytes = (uint32_t)(mMaterialData.size() * 4);
       d.gLightInstances = mLightInstanceMap.data();
       d.light_count = (uint32_t)mLightInstanceMap.size();
+      d.gImages = mImageDescs.data();
+      d.image_count = (uint32_t)mImageDescs.size();
       return d;
     }
   };
@@ -510,7 +530,7 @@ class Scene {
       auto mit = materialMap.find(prim->mMaterial.get());
       if (mit == materialMap.end()) {
         mit = materialMap.emplace(prim->mMaterial.get(), (uint32_t)(sd->mMaterialData.size() * sizeof(uint32_t))).first;
-        prim->mMaterial->store(sd->mMaterialData);
+        prim->mMaterial->store(sd->mMaterialData, sd->mResources);
         sd->mMaterialCount++;
       }
       // copy_vertices + concatenation, copy_vertices.hlsl:29-37, Scene.cpp:461-485,643-658
@@ -556,6 +576,7 @@ class Scene {
       sd->mInstanceInverseTransforms.push_back(inv);
       sd->mInstanceMotionTransforms.push_back(tmul(transform, inv));  // make_instance_motion_transform(inv, prev = current), scene.h:49
     });
+    for (const Image* im : sd->mResources.image4s) sd->mImageDescs.push_back(sthip_image_desc{im->pixels.data(), im->width, im->height});
     mSceneData = sd;
     mDirty = false;
   }

@@ -92,6 +92,7 @@ class SceneData:
         self.motion_transforms = motion_xf
         self.materials = materials
         self.lights = lights
+        self.images = []  # RGBA32F arrays (H, W, 4): Texture2D<float4> gImages[]
 
     @property
     def light_count(self):
@@ -120,6 +121,14 @@ class SceneData:
         d.material_bytes = self.materials.nbytes
         d.gLightInstances = wire.ptr(self.lights) if self.light_count else None
         d.light_count = self.light_count
+        if self.images:
+            self._image_descs = (wire.ImageDesc * len(self.images))()
+            for i, im in enumerate(self.images):
+                self._image_descs[i].pixels = wire.ptr(im)
+                self._image_descs[i].width = im.shape[1]
+                self._image_descs[i].height = im.shape[0]
+            d.gImages = C.cast(self._image_descs, C.c_void_p)
+            d.image_count = len(self.images)
         return d
 
 
@@ -133,6 +142,7 @@ class SceneBuilder:
         self._meshes = []  # (first_vertex, indices_byte_offset, prim_count, stride)
         self._materials = []  # MaterialRecord entries
         self._instances = []  # (mesh, material index, 4x4 transform)
+        self._images = []  # RGBA32F (H, W, 4)
 
     # -- Material::store, Material.hpp:32-38; conventions of load_mitsuba.cpp:330-343,454-489 --
     def add_material(
@@ -158,6 +168,23 @@ class SceneBuilder:
         rec["bump_strength"] = 1.0
         self._materials.append(rec)
         return len(self._materials) - 1  # a handle; byte addresses are assigned in build() in order of first use
+
+    def add_image(self, rgba):
+        """Registers a Texture2D<float4> (float32 array H x W x 4, row 0 first); returns its index in gImages."""
+        im = np.ascontiguousarray(rgba, dtype=np.float32)
+        assert im.ndim == 3 and im.shape[2] == 4
+        self._images.append(im)
+        return len(self._images) - 1
+
+    def set_material_images(self, material, base_color_image=None, params_image=None, lobes_image=None, bump_image=None, bump_strength=1.0):
+        """Binds images to the three ImageValue4 of a material (disney_data.h:1-20) and/or a normal map."""
+        rec = self._materials[material]
+        for k, img in enumerate((base_color_image, params_image, lobes_image)):
+            if img is not None:
+                rec["values"]["image_index"][k] = img
+        if bump_image is not None:
+            rec["bump_index"] = bump_image
+            rec["bump_strength"] = bump_strength
 
     def add_emitter(self, radiance):
         """Mitsuba area emitter: base_color = L / lum(L), emission = lum(L), eta = 0 (load_mitsuba.cpp:480-489)."""
@@ -205,11 +232,27 @@ class SceneBuilder:
         mot = np.zeros(n, dtype=wire.TransformData)
         # process_material, Scene.cpp:387-396: a material is appended to the byte buffer the first time an
         # instance uses it; its address is the byte offset at that moment
-        address_of, used = {}, []
+        # ... and an image gets its gImages index the first time a stored material refers to it
+        # (MaterialResources::get_index, image_value.h:34-48)
+        address_of, used, image_index_of, image_order = {}, [], {}, []
+
+        def image_index(handle):
+            handle = int(handle)
+            if handle == 0xFFFFFFFF:
+                return 0xFFFFFFFF
+            if handle not in image_index_of:
+                image_index_of[handle] = len(image_order)
+                image_order.append(handle)
+            return image_index_of[handle]
+
         for _, mat, _ in self._instances:
             if mat not in address_of:
                 address_of[mat] = len(used) * wire.MaterialRecord.itemsize
-                used.append(self._materials[mat])
+                rec = self._materials[mat].copy()
+                for k in range(3):
+                    rec["values"]["image_index"][k] = image_index(rec["values"]["image_index"][k])
+                rec["bump_index"] = image_index(rec["bump_index"])
+                used.append(rec)
         mats = np.array(used, dtype=wire.MaterialRecord) if used else np.zeros(0, wire.MaterialRecord)
         lights = []
         for i, (mesh, mat, m) in enumerate(self._instances):
@@ -241,6 +284,7 @@ class SceneBuilder:
             name=self.name,
         )
         sd.builder = self  # the inputs the arrays were packed from (dump_description)
+        sd.images = [self._images[h] for h in image_order]
         return sd
 
 
@@ -253,6 +297,10 @@ def dump_description(path, scene, frame):
 
     builder = scene.builder
     with open(path, "wb") as f:
+        f.write(struct.pack("<I", len(builder._images)))
+        for im in builder._images:
+            f.write(struct.pack("<II", im.shape[1], im.shape[0]))
+            f.write(im.tobytes())
         mats = np.array(builder._materials, dtype=wire.MaterialRecord)
         f.write(struct.pack("<I", mats.shape[0]))
         f.write(mats.tobytes())

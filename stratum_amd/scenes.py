@@ -383,3 +383,73 @@ def forest(n_instances=1000, tree_tris=10_000, tree_kinds=4):
 
 
 SCENES = {"cornell_box": cornell_box, "atrium": atrium, "forest": forest, "furnace": furnace_box}
+
+
+# ---------------------------------------------------------------------------------------------
+# textured variant of the Cornell box (image values, normal maps, ray cones)
+# ---------------------------------------------------------------------------------------------
+def _checker(n, cells, a, b):
+    y, x = np.mgrid[0:n, 0:n]
+    m = ((x * cells // n) + (y * cells // n)) % 2
+    img = np.where(m[..., None] == 0, np.asarray(a, np.float32), np.asarray(b, np.float32)).astype(np.float32)
+    return np.concatenate([img, np.ones((n, n, 1), np.float32)], -1)
+
+
+def _noise_image(n, seed, lo, hi, freq=8.0):
+    y, x = np.mgrid[0:n, 0:n].astype(np.float64)
+    v = _value_noise(x * freq / n, y * freq / n, seed) * 0.6 + _value_noise(x * freq * 4 / n, y * freq * 4 / n, seed + 1) * 0.4
+    img = np.asarray(lo, np.float64) + (np.asarray(hi, np.float64) - np.asarray(lo, np.float64)) * v[..., None]
+    return np.concatenate([img, np.ones((n, n, 1))], -1).astype(np.float32)
+
+
+def _bump_image(n, cells):
+    """Tangent-space normal map of a grid of rounded studs."""
+    y, x = np.mgrid[0:n, 0:n].astype(np.float64)
+    u, v = (x * cells / n) % 1.0 - 0.5, (y * cells / n) % 1.0 - 0.5
+    r2 = u * u + v * v
+    hgt = np.exp(-r2 * 18.0)
+    dx = np.gradient(hgt, axis=1) * n / cells * 0.25
+    dy = np.gradient(hgt, axis=0) * n / cells * 0.25
+    nrm = np.stack([-dx, -dy, np.ones_like(dx)], -1)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    return np.concatenate([nrm * 0.5 + 0.5, np.ones((n, n, 1))], -1).astype(np.float32)
+
+
+def textured_box():
+    """Cornell-like box: checker floor with a normal map, noise-textured walls, a textured emitter, metal block
+    with a roughness map. Exercises image values, mip selection through ray cones, normal maps."""
+    b = SceneBuilder("textured_box")
+    img_checker = b.add_image(_checker(256, 8, (0.9, 0.9, 0.9), (0.15, 0.2, 0.6)))
+    img_noise = b.add_image(_noise_image(128, 5, (0.3, 0.3, 0.3), (1.0, 1.0, 1.0)))
+    img_bump = b.add_image(_bump_image(128, 8))
+    img_rough = b.add_image(_noise_image(64, 9, (1.0, 0.05, 0.0, ), (1.0, 1.0, 0.0), freq=4.0))
+    img_light = b.add_image(_checker(16, 4, (1.0, 1.0, 1.0), (0.3, 0.3, 0.3)))
+
+    floor = b.add_material((1.0, 1.0, 1.0), roughness=0.4)
+    b.set_material_images(floor, base_color_image=img_checker, bump_image=img_bump, bump_strength=1.5)
+    wall = b.add_material((0.8, 0.75, 0.7))
+    b.set_material_images(wall, base_color_image=img_noise)
+    red = b.add_material((0.65, 0.05, 0.05))
+    metal = b.add_material((0.9, 0.7, 0.4), metallic=1.0, roughness=0.6)
+    b.set_material_images(metal, params_image=img_rough)
+    light = b.add_emitter((17.0, 12.0, 4.0))
+    b.set_material_images(light, base_color_image=img_light)
+
+    def wall_q(p0, p1, p2, p3, n, mat, uvscale=1.0):
+        pos, nrm, uv, tri = _quad(p0, p1, p2, p3, n)
+        b.add_instance(b.add_mesh(pos, nrm, uv * uvscale, tri), mat)
+
+    wall_q((-1, -1, 1), (1, -1, 1), (1, -1, -1), (-1, -1, -1), (0, 1, 0), floor, 2.0)
+    wall_q((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1), (0, -1, 0), wall)
+    wall_q((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (0, 0, 1), wall, 3.0)
+    wall_q((-1, -1, 1), (-1, -1, -1), (-1, 1, -1), (-1, 1, 1), (1, 0, 0), red)
+    wall_q((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1), (-1, 0, 0), wall)
+    sphere = grid_surface(lambda U, V: np.stack([np.sin(V * np.pi) * np.cos(U * 2 * np.pi), np.cos(V * np.pi), np.sin(V * np.pi) * np.sin(U * 2 * np.pi)], -1), 32, 20, flip=True)
+    ball = b.add_mesh(*sphere)
+    b.add_instance(ball, metal, translate((0.35, -0.55, 0.2)) @ scale(0.45))
+    b.add_instance(ball, floor, translate((-0.45, -0.65, -0.3)) @ rotate_y(0.5) @ scale((0.35, 0.35, 0.35)))
+    wall_q((-0.24, 0.995, -0.2), (0.24, 0.995, -0.2), (0.24, 0.995, 0.18), (-0.24, 0.995, 0.18), (0, -1, 0), light)
+    return b.build(), {"eye": (0.0, 0.0, 3.9), "target": (0.0, 0.0, 0.0), "fovy": np.radians(39.3)}
+
+
+SCENES["textured_box"] = textured_box

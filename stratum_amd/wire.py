@@ -149,7 +149,13 @@ class SceneDesc(C.Structure):
         ("material_bytes", C.c_uint32),
         ("gLightInstances", C.c_void_p),
         ("light_count", C.c_uint32),
+        ("gImages", C.c_void_p),
+        ("image_count", C.c_uint32),
     ]
+
+
+class ImageDesc(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
 class FrameDesc(C.Structure):

@@ -44,6 +44,18 @@ int main(int argc, char** argv) {
     Node& scene_node = app.node().make_child("Scene");
     auto scene = scene_node.make_component<Scene>();
 
+    // images
+    const uint32_t n_img = r.get<uint32_t>();
+    std::vector<component_ptr<Image>> images;
+    for (uint32_t i = 0; i < n_img; i++) {
+      const uint32_t w = r.get<uint32_t>(), h = r.get<uint32_t>();
+      auto im = scene_node.make_child("image").make_component<Image>();
+      im->width = w;
+      im->height = h;
+      im->pixels = r.vec<float>((size_t)w * h * 4);
+      images.push_back(im);
+    }
+    auto image_of = [&](uint32_t index) { return index < images.size() ? images[index] : component_ptr<Image>(); };
     // materials
     const uint32_t n_mat = r.get<uint32_t>();
     std::vector<component_ptr<Material>> materials;
@@ -52,10 +64,9 @@ int main(int argc, char** argv) {
       auto m = scene_node.make_child("material").make_component<Material>();
       for (int k = 0; k < 3; k++) {
         std::memcpy(m->values[k].value, rec.values[k].value, 16);
-        m->values[k].image_index = rec.values[k].image_index;
+        m->values[k].image = image_of(rec.values[k].image_index);
       }
-      m->alpha_mask_index = rec.alpha_mask_index;
-      m->bump_index = rec.bump_index;
+      m->bump_image = image_of(rec.bump_index);
       m->bump_strength = rec.bump_strength;
       materials.push_back(m);
     }

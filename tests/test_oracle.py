@@ -389,3 +389,52 @@ def test_cornell_golden_fixture():
     assert np.array_equal(out["radiance"].view(np.uint32), g["radiance"].view(np.uint32))
     assert np.array_equal(out["visibility"]["instance_primitive_index"], g["instance_primitive_index"])
     assert np.array_equal(out["ray_count"], g["ray_count"])
+
+
+# ---------------------------------------------------------------------------------------------
+# N2: software texture sampler (repeat + trilinear over a box-filtered mip chain), ray cones, normal maps
+# ---------------------------------------------------------------------------------------------
+def test_texture_sampler_properties():
+    b = SceneBuilder()
+    rng = np.random.RandomState(11)
+    img = rng.uniform(0, 1, (8, 16, 4)).astype(np.float32)  # H = 8, W = 16
+    i0 = b.add_image(img)
+    flat = b.add_image(np.full((32, 32, 4), 0.37, np.float32))
+    m = b.add_material((1, 1, 1))
+    b.set_material_images(m, base_color_image=i0, params_image=flat)  # indices follow first use: i0 -> 0, flat -> 1
+    b.add_instance(b.add_mesh(*scenes._quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1))), m)
+    sc = b.build()
+    assert len(sc.images) == 2
+    i0, flat = 0, 1
+    o = orc.OracleScene(sc)
+    # texel centres return the texel (level 0: uv_screen_size = 0 means "no footprint", image_value.h:85)
+    ys, xs = np.mgrid[0:8, 0:16]
+    q = np.stack([(xs + 0.5) / 16, (ys + 0.5) / 8, np.zeros_like(xs, float)], -1).reshape(-1, 3)
+    assert np.array_equal(o.sample_image(i0, q), img.reshape(-1, 4))
+    # repeat addressing
+    assert np.array_equal(o.sample_image(i0, q + [1.0, -2.0, 0.0]), o.sample_image(i0, q))
+    # halfway between two texels = their mean
+    mid = o.sample_image(i0, [[1.0 / 16, 0.5 / 8, 0.0]])[0]
+    assert np.allclose(mid, 0.5 * (img[0, 0] + img[0, 1]), atol=1e-7)
+    # lod = log2(uv_screen_size * max(w, h)): size 2/16 -> level 1 = 2x2 box filter of level 0
+    lvl1 = img.reshape(4, 2, 8, 2, 4).mean(axis=(1, 3))
+    q1 = np.stack([(np.arange(8) + 0.5) / 8, np.full(8, 0.5 / 4), np.full(8, 2.0 / 16)], -1)
+    assert np.allclose(o.sample_image(i0, q1), lvl1[0], atol=1e-6)
+    # without ray cones the footprint is ignored
+    assert np.array_equal(o.sample_image(i0, q1, ray_cones=False), o.sample_image(i0, q1 * [1, 1, 0]))
+    # a constant image is constant at every level and position
+    qq = np.concatenate([rng.uniform(-3, 3, (200, 2)), rng.uniform(0, 2, (200, 1))], 1)
+    assert np.allclose(o.sample_image(flat, qq), 0.37, atol=1e-6)
+
+
+def test_ray_cones_and_normal_maps_change_the_image():
+    sc, cam = scenes.textured_box()
+    o = orc.OracleScene(sc)
+    fr = camera.Frame(64, 48, cam["fovy"], cam["eye"], cam["target"])
+    pc = wire.default_push_constants(64, 48, sc.light_count)
+    base = o.render(fr, pc, wire.DEFAULT_SAMPLING_FLAGS, 0, 1)
+    no_cones = o.render(fr, pc, wire.DEFAULT_SAMPLING_FLAGS & ~wire.flag_mask("eRayCones"), 0, 1)
+    no_bump = o.render(fr, pc, wire.DEFAULT_SAMPLING_FLAGS & ~wire.flag_mask("eNormalMaps"), 0, 1)
+    assert not np.array_equal(base["albedo"], no_cones["albedo"])  # mip level 0 instead of the footprint's level
+    assert not np.array_equal(base["visibility"]["packed_normal"], no_bump["visibility"]["packed_normal"])
+    assert np.array_equal(base["visibility"]["instance_primitive_index"], no_cones["visibility"]["instance_primitive_index"])
