@@ -174,6 +174,62 @@ int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out);
  * "bvh_builder": 0 = binned SAH on the host (default), 1 = LBVH on the GPU (set before sthip_scene_upload) */
 int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value);
 
+/* ---- after the path: display transform, image metric, HDR export ---- */
+
+/* TonemapMode, src/Shaders/tonemap.h:8-21 */
+enum {
+  STHIP_TONEMAP_RAW = 0,
+  STHIP_TONEMAP_REINHARD,
+  STHIP_TONEMAP_REINHARD_EXTENDED,
+  STHIP_TONEMAP_REINHARD_LUMINANCE,
+  STHIP_TONEMAP_REINHARD_LUMINANCE_EXTENDED,
+  STHIP_TONEMAP_UNCHARTED2,
+  STHIP_TONEMAP_FILMIC,
+  STHIP_TONEMAP_ACES,
+  STHIP_TONEMAP_ACES_APPROX,
+  STHIP_TONEMAP_VIRIDIS_R,
+  STHIP_TONEMAP_VIRIDIS_LENGTH_RGB,
+  STHIP_TONEMAP_MODE_COUNT
+};
+
+/* What BDPT::render binds and pushes for its "tone map" block (src/Node/BDPT.cpp:783-815, kernels/tonemap.hlsl:7-19):
+ * specialisation constants gMode / gModulateAlbedo / gGammaCorrection, push constant gExposure, images gInput,
+ * gAlbedo, gOutput (RGBA32F, width*height). The two dispatches of the reference (clear gMax + reduce_max, then main)
+ * happen inside one call. gExposureAlpha (smoothing of the maxima over frames, default 0 = off) is not taken: every
+ * call uses the maxima of its own input. out_max (optional, host memory, 4 floats) receives the rgb and luminance
+ * maxima main() sees. */
+typedef struct sthip_tonemap_desc {
+  uint32_t width, height;
+  uint32_t mode;
+  uint32_t modulate_albedo;
+  uint32_t gamma_correction;
+  float exposure;
+  uint32_t device_ptrs; /* gInput/gAlbedo/gOutput are device pointers */
+  uint32_t _pad;
+  const float* gInput;
+  const float* gAlbedo; /* may be NULL when modulate_albedo == 0 */
+  float* gOutput;
+  float* out_max;
+} sthip_tonemap_desc;
+int sthip_tonemap(sthip_ctx* ctx, const sthip_tonemap_desc* desc);
+
+/* ImageCompareMode, kernels/image_compare.hlsl:5-9 */
+enum { STHIP_COMPARE_SMAPE = 0, STHIP_COMPARE_MSE = 1, STHIP_COMPARE_AVERAGE = 2 };
+
+/* The metric ImageComparer shows (src/Node/ImageComparer.cpp:61-90 dispatching kernels/image_compare.hlsl:13-46):
+ * per-pixel error over rgb, divided by 3*width*height, summed per group of 64 consecutive pixels, scaled by
+ * `quantization` (gQuantization; the node's default is 1024, ImageComparer.hpp:18), truncated to uint and added atomically.
+ * sum_out = the raw uint accumulator, overflow_out = the overflow flag; the displayed number is sum/quantization
+ * (its square root for MSE, ImageComparer.cpp:88). image1/image2: RGBA32F, host unless device_ptrs. */
+int sthip_image_compare(sthip_ctx* ctx, const float* image1, const float* image2, uint32_t width, uint32_t height, uint32_t metric, uint32_t quantization,
+                        uint32_t device_ptrs, uint32_t* sum_out, uint32_t* overflow_out);
+
+/* Radiance .hdr export of an RGBA32F host image, what BDPT's "Export HDR" does through stbi_write_hdr(path, w, h, 4,
+ * pixels) (src/Node/BDPT.cpp:313-337): header "#?RADIANCE", FORMAT=32-bit_rle_rgbe, rows top to bottom, RGBE with
+ * the shared exponent of the largest channel; rows of 8..32767 pixels are run-length coded per channel, others flat.
+ * Host-only, needs no context. Returns STHIP_OK or STHIP_ERR_INVALID_ARGUMENT (bad arguments / cannot write). */
+int sthip_write_hdr(const char* path, uint32_t width, uint32_t height, const float* rgba);
+
 #ifdef __cplusplus
 }
 #endif

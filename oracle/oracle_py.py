@@ -17,8 +17,8 @@ _lib = None
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "stratum_oracle.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("stratum_oracle.cpp", "post_oracle.cpp")]
+    if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(_LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
@@ -192,3 +192,32 @@ def disney_sample(material_record, dir_in, rnd):
     out = np.zeros((di.shape[0], 13), np.float32)
     lib().orc_disney_sample(wire.ptr(rec), wire.ptr(di), wire.ptr(r), wire.ptr(out), C.c_uint32(di.shape[0]))
     return out
+
+
+# ---- steps after the path (post_oracle.cpp) ----
+def tonemap(radiance, albedo=None, mode=0, modulate_albedo=False, gamma_correction=True, exposure=0.0):
+    img = np.ascontiguousarray(radiance, np.float32)
+    alb = np.ascontiguousarray(albedo, np.float32) if albedo is not None else None
+    out = np.empty_like(img)
+    mx = np.zeros(4, np.float32)
+    lib().orc_tonemap(
+        wire.ptr(img),
+        wire.ptr(alb) if alb is not None else None,
+        wire.ptr(out),
+        C.c_uint32(img.shape[1]),
+        C.c_uint32(img.shape[0]),
+        C.c_uint32(mode),
+        C.c_uint32(1 if modulate_albedo else 0),
+        C.c_uint32(1 if gamma_correction else 0),
+        C.c_float(exposure),
+        wire.ptr(mx),
+    )
+    return out, mx
+
+
+def image_compare(image1, image2, metric=0, quantization=1024):
+    a = np.ascontiguousarray(image1, np.float32)
+    b = np.ascontiguousarray(image2, np.float32)
+    s, o = C.c_uint32(0), C.c_uint32(0)
+    lib().orc_image_compare(wire.ptr(a), wire.ptr(b), C.c_uint32(a.shape[1]), C.c_uint32(a.shape[0]), C.c_uint32(metric), C.c_uint32(quantization), C.byref(s), C.byref(o))
+    return s.value, bool(o.value)

@@ -5,7 +5,9 @@ fallback of any kind: if the shared object is missing or a HIP device is absent,
 of this package raises.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 from . import wire
 
@@ -25,6 +27,9 @@ EXPORTS = [
     "sthip_trace_rays",
     "sthip_get_stats",
     "sthip_set_option",
+    "sthip_tonemap",
+    "sthip_image_compare",
+    "sthip_write_hdr",
 ]
 
 _lib = None
@@ -32,6 +37,26 @@ _lib = None
 
 class StratumHipError(RuntimeError):
     pass
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels carry their own libamdhip64.so / libhsa-runtime64.so under torch/lib (sonames
+    libamdhip64.so.7, libhsa-runtime64.so.1, the ones this library links). If torch is imported first the loader
+    gives this library torch's runtime and the two share one; if this library came first the system runtime is
+    loaded, torch then loads its own copy by file name, and the second HSA runtime in the process finds no GPU.
+    Loading torch's copy first (without importing torch) makes the order irrelevant: one HIP runtime either way.
+    Without torch installed nothing happens and the system ROCm runtime is used."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        C.CDLL(hip, mode=C.RTLD_GLOBAL)
 
 
 def lib():
@@ -43,6 +68,7 @@ def lib():
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH
         )
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     L.sthip_abi_version.restype = C.c_int
     L.sthip_create.restype = C.c_int
@@ -74,5 +100,11 @@ def lib():
     L.sthip_get_stats.argtypes = [C.c_void_p, C.POINTER(wire.Stats)]
     L.sthip_set_option.restype = C.c_int
     L.sthip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.sthip_tonemap.restype = C.c_int
+    L.sthip_tonemap.argtypes = [C.c_void_p, C.POINTER(wire.TonemapDesc)]
+    L.sthip_image_compare.restype = C.c_int
+    L.sthip_image_compare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.sthip_write_hdr.restype = C.c_int
+    L.sthip_write_hdr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
     _lib = L
     return L

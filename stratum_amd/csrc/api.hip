@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -16,6 +17,7 @@
 #include "../../include/sthip.h"
 #include "bvh_build.h"
 #include "kernels.h"
+#include "post.h"
 
 namespace {
 thread_local std::string g_create_error;
@@ -72,6 +74,7 @@ struct sthip_ctx {
   DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays;
   DevBuf<uint32_t> meta, queue0, queue1;
   DevBuf<unsigned long long> counters;
+  DevBuf<uint32_t> post_scratch;  // maxima / metric accumulator of post.h
   DevBuf<float4> out_radiance, out_albedo;
   DevBuf<sthip_VisibilityInfo> out_visibility;
   DevBuf<sthip_DepthInfo> out_depth;
@@ -180,6 +183,7 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->queue0.release();
   ctx->queue1.release();
   ctx->counters.release();
+  ctx->post_scratch.release();
   ctx->out_radiance.release();
   ctx->out_albedo.release();
   ctx->out_visibility.release();
@@ -732,6 +736,81 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     ctx->stats.launches_trace_closest = launches_closest;
     ctx->stats.launches_trace_shadow = launches_shadow;
   }
+  return STHIP_OK;
+}
+
+// ---- after the path: tonemap and image metric (post.h) ----
+
+int sthip_tonemap(sthip_ctx* ctx, const sthip_tonemap_desc* d) {
+  if (!ctx || !d) return STHIP_ERR_INVALID_ARGUMENT;
+  if (!d->gInput || !d->gOutput || d->width == 0 || d->height == 0) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_tonemap: gInput, gOutput and a non-empty extent are required");
+  if (d->mode >= eTonemapModeCount) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_tonemap: unknown mode " + std::to_string(d->mode));
+  if (d->modulate_albedo && !d->gAlbedo) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_tonemap: gModulateAlbedo needs gAlbedo");
+  if ((uint64_t)d->width * d->height > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_tonemap: extent too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const uint32_t n = d->width * d->height;
+  const float4 *in = reinterpret_cast<const float4*>(d->gInput), *alb = reinterpret_cast<const float4*>(d->gAlbedo);
+  float4* out = reinterpret_cast<float4*>(d->gOutput);
+  DevBuf<float4> bin, balb, bout;
+  if (!d->device_ptrs) {
+    HIP_TRY(ctx, bin.ensure(n));
+    HIP_TRY(ctx, bout.ensure(n));
+    HIP_TRY(ctx, hipMemcpyAsync(bin.p, d->gInput, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    in = bin.p;
+    out = bout.p;
+    if (d->modulate_albedo) {
+      HIP_TRY(ctx, balb.ensure(n));
+      HIP_TRY(ctx, hipMemcpyAsync(balb.p, d->gAlbedo, (size_t)n * 16, hipMemcpyHostToDevice, st));
+      alb = balb.p;
+    }
+  }
+  HIP_TRY(ctx, ctx->post_scratch.ensure(4));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->post_scratch.p, 0, 16, st));
+  const uint32_t grid = (uint32_t)std::min<size_t>(((size_t)n + 255) / 256, (size_t)ctx->cu_count * 16);
+  hipLaunchKernelGGL(k_tonemap_reduce_max, dim3(grid), dim3(256), 0, st, in, alb, n, d->modulate_albedo, ctx->post_scratch.p);
+  hipLaunchKernelGGL(k_tonemap, dim3(grid), dim3(256), 0, st, in, alb, out, n, d->mode, d->modulate_albedo, d->gamma_correction, d->exposure, ctx->post_scratch.p);
+  HIP_TRY(ctx, hipGetLastError());
+  if (!d->device_ptrs) HIP_TRY(ctx, hipMemcpyAsync(d->gOutput, bout.p, (size_t)n * 16, hipMemcpyDeviceToHost, st));
+  if (d->out_max) {
+    uint32_t m[4];
+    HIP_TRY(ctx, hipMemcpyAsync(m, ctx->post_scratch.p, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int k = 0; k < 4; k++) d->out_max[k] = (float)m[k] / TONEMAP_MAX_QUANTIZATION;
+  } else if (!d->device_ptrs) {
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+  }
+  return STHIP_OK;
+}
+
+int sthip_image_compare(sthip_ctx* ctx, const float* image1, const float* image2, uint32_t width, uint32_t height, uint32_t metric, uint32_t quantization, uint32_t device_ptrs,
+                        uint32_t* sum_out, uint32_t* overflow_out) {
+  if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
+  if (!image1 || !image2 || !sum_out || width == 0 || height == 0) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_image_compare: two images, sum_out and a non-empty extent are required");
+  if (metric > 2) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_image_compare: unknown metric " + std::to_string(metric));
+  if ((uint64_t)width * height * 3 > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_image_compare: extent too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const uint32_t n = width * height;
+  const float4 *a = reinterpret_cast<const float4*>(image1), *b = reinterpret_cast<const float4*>(image2);
+  DevBuf<float4> ba, bb;
+  if (!device_ptrs) {
+    HIP_TRY(ctx, ba.ensure(n));
+    HIP_TRY(ctx, bb.ensure(n));
+    HIP_TRY(ctx, hipMemcpyAsync(ba.p, image1, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(bb.p, image2, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    a = ba.p;
+    b = bb.p;
+  }
+  HIP_TRY(ctx, ctx->post_scratch.ensure(4));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->post_scratch.p, 0, 16, st));
+  hipLaunchKernelGGL(k_image_compare, dim3((n + 63) / 64), dim3(64), 0, st, a, b, n, metric, quantization, ctx->post_scratch.p);
+  HIP_TRY(ctx, hipGetLastError());
+  uint32_t r[2];
+  HIP_TRY(ctx, hipMemcpyAsync(r, ctx->post_scratch.p, 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  *sum_out = r[0];
+  if (overflow_out) *overflow_out = r[1];
   return STHIP_OK;
 }
 

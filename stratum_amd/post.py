@@ -1,0 +1,100 @@
+"""What the reference does with the renderer's output, on the GPU: the tone-map block of BDPT::render
+(src/Node/BDPT.cpp:783-815 -> kernels/tonemap.hlsl), the ImageComparer node (src/Node/ImageComparer.cpp:61-90 ->
+kernels/image_compare.hlsl) and the "Export HDR" button (BDPT.cpp:313-337). Thin host code over the C ABI
+(sthip_tonemap / sthip_image_compare / sthip_write_hdr); there is no CPU implementation behind it."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, wire
+
+
+def _mode(table, m):
+    if isinstance(m, str):
+        if m not in table:
+            raise ValueError("unknown mode %r (one of %s)" % (m, ", ".join(table)))
+        return table[m]
+    return int(m)
+
+
+def _rgba(a, name):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("%s must be an (H, W, 4) float32 image" % name)
+    return a
+
+
+class Tonemapper:
+    """The tone-map state BDPT keeps (BDPT.cpp:44-54,190-196,304-309): mode, exposure, gamma correction."""
+
+    def __init__(self, bdpt, mode="Raw", exposure=0.0, gamma_correction=True):
+        self._bdpt = bdpt
+        self.mode = mode
+        self.exposure = float(exposure)
+        self.gamma_correction = bool(gamma_correction)
+
+    def __call__(self, radiance, albedo=None, modulate_albedo=False, return_max=False):
+        img = _rgba(radiance, "radiance")
+        alb = _rgba(albedo, "albedo") if albedo is not None else None
+        if alb is not None and alb.shape != img.shape:
+            raise ValueError("albedo and radiance extents differ")
+        out = np.empty_like(img)
+        mx = np.zeros(4, np.float32)
+        d = wire.TonemapDesc(
+            img.shape[1],
+            img.shape[0],
+            _mode(wire.TONEMAP, self.mode),
+            int(bool(modulate_albedo)),
+            int(self.gamma_correction),
+            self.exposure,
+            0,
+            0,
+            img.ctypes.data,
+            alb.ctypes.data if alb is not None else None,
+            out.ctypes.data,
+            mx.ctypes.data,
+        )
+        self._bdpt._check(_lib.lib().sthip_tonemap(self._bdpt._h, C.byref(d)), "sthip_tonemap")
+        return (out, mx) if return_max else out
+
+    def device(self, width, height, input_ptr, albedo_ptr, output_ptr, modulate_albedo=False):
+        """Device-pointer form (RGBA32F buffers in HBM); enqueues on the context's stream and returns."""
+        d = wire.TonemapDesc(
+            width, height, _mode(wire.TONEMAP, self.mode), int(bool(modulate_albedo)), int(self.gamma_correction), self.exposure, 1, 0, input_ptr, albedo_ptr, output_ptr, None
+        )
+        self._bdpt._check(_lib.lib().sthip_tonemap(self._bdpt._h, C.byref(d)), "sthip_tonemap")
+
+
+class ImageComparer:
+    """ImageComparer node: error of image1 against image2. `value` is what the GUI prints (ImageComparer.cpp:86-89)."""
+
+    def __init__(self, bdpt, mode="SMAPE", quantization=1024):
+        self._bdpt = bdpt
+        self.mode = mode
+        self.quantization = int(quantization)
+
+    def raw(self, image1, image2):
+        a, b = _rgba(image1, "image1"), _rgba(image2, "image2")
+        if a.shape != b.shape:
+            raise ValueError("image extents differ")
+        s, o = C.c_uint32(0), C.c_uint32(0)
+        rc = _lib.lib().sthip_image_compare(
+            self._bdpt._h, a.ctypes.data, b.ctypes.data, a.shape[1], a.shape[0], _mode(wire.COMPARE, self.mode), self.quantization, 0, C.byref(s), C.byref(o)
+        )
+        self._bdpt._check(rc, "sthip_image_compare")
+        return s.value, bool(o.value)
+
+    def value(self, image1, image2):
+        s, overflow = self.raw(image1, image2)
+        if overflow:
+            return float("inf")
+        v = s / float(self.quantization)
+        return float(np.sqrt(v)) if _mode(wire.COMPARE, self.mode) == wire.COMPARE["MSE"] else v
+
+
+def write_hdr(path, image):
+    """Radiance .hdr of an (H, W, 4) float image, byte-compatible with the reference's stbi_write_hdr export."""
+    img = _rgba(image, "image")
+    rc = _lib.lib().sthip_write_hdr(str(path).encode(), img.shape[1], img.shape[0], img.ctypes.data)
+    if rc != 0:
+        raise _lib.StratumHipError("sthip_write_hdr(%s) failed (%d)" % (path, rc))

@@ -239,3 +239,39 @@ def default_push_constants(width, height, light_count, view_count=1):
     pc.gHashGridMinBucketRadius = 0.1
     pc.gHashGridBucketPixelRadius = 6
     return pc
+
+
+# ---- after the path (include/sthip.h, "display transform, image metric, HDR export") ----
+TONEMAP_MODES = [  # TonemapMode, tonemap.h:8-21
+    "Raw",
+    "Reinhard",
+    "ReinhardExtended",
+    "ReinhardLuminance",
+    "ReinhardLuminanceExtended",
+    "Uncharted2",
+    "Filmic",
+    "ACES",
+    "ACESApprox",
+    "ViridisR",
+    "ViridisLengthRGB",
+]
+TONEMAP = {n: i for i, n in enumerate(TONEMAP_MODES)}
+COMPARE_MODES = ["SMAPE", "MSE", "Average"]  # ImageCompareMode, image_compare.hlsl:5-9
+COMPARE = {n: i for i, n in enumerate(COMPARE_MODES)}
+
+
+class TonemapDesc(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("mode", C.c_uint32),
+        ("modulate_albedo", C.c_uint32),
+        ("gamma_correction", C.c_uint32),
+        ("exposure", C.c_float),
+        ("device_ptrs", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("gInput", C.c_void_p),
+        ("gAlbedo", C.c_void_p),
+        ("gOutput", C.c_void_p),
+        ("out_max", C.c_void_p),
+    ]
