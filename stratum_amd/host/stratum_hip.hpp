@@ -595,6 +595,8 @@ class BDPT {
   struct Frame {  // the outputs BDPT::render leaves in its FrameResources (BDPT.cpp:546-605)
     uint32_t width = 0, height = 0;
     std::vector<float> mRadiance, mAlbedo, mPrevUVs;
+    std::vector<float> mTonemapResult;  // gOutput of the tone-map block, RGBA32F (BDPT.cpp:558)
+    float mTonemapMax[4] = {0, 0, 0, 0};
     std::vector<VisibilityInfo> mVisibility;
     std::vector<DepthInfo> mDepth;
     uint64_t mRayCount[2] = {0, 0};
@@ -630,6 +632,16 @@ class BDPT {
   uint32_t& sampling_flags() { return mSamplingFlags; }
   BDPTPushConstants& push_constants() { return mPushConstants; }
   const Frame& prev_result() const { return mPrevFrame; }  // BDPT.hpp:18
+  // tone-map state the reference keeps on its pipeline objects (BDPT.cpp:44-54,190-193,304-309)
+  uint32_t& tonemap_mode() { return mTonemapMode; }
+  float& exposure() { return mExposure; }
+  bool& gamma_correction() { return mGammaCorrection; }
+  // "Export" -> "Save" (BDPT.cpp:313-337): the last frame's radiance as a Radiance .hdr file
+  void export_hdr(const std::string& path) const {
+    if (mPrevFrame.mRadiance.empty()) throw std::runtime_error("BDPT::export_hdr: no frame rendered yet");
+    if (sthip_write_hdr(path.c_str(), mPrevFrame.width, mPrevFrame.height, mPrevFrame.mRadiance.data()) != STHIP_OK)
+      throw std::runtime_error("BDPT::export_hdr: cannot write " + path);
+  }
 
   // BDPT::update (BDPT.cpp:341-421): (re)bind the scene when Scene::update produced new SceneData
   void update(CommandBuffer& cb, float) {
@@ -689,6 +701,20 @@ class BDPT {
     (void)sthip_set_stream(mCtx, cb.hip_stream);
     if (sthip_render(mCtx, &pc, mSamplingFlags, scene_flags, &f, mFrameNumber, seed_count, &o) != STHIP_OK)
       throw std::runtime_error(std::string("sthip_render: ") + sthip_last_error(mCtx));
+    // tone map (BDPT.cpp:783-815); without a denoiser gModulateAlbedo stays off (:779-780 only run when one exists)
+    fr.mTonemapResult.assign(4 * n, 0.f);
+    sthip_tonemap_desc tm{};
+    tm.width = width;
+    tm.height = height;
+    tm.mode = mTonemapMode;
+    tm.modulate_albedo = 0;
+    tm.gamma_correction = mGammaCorrection ? 1u : 0u;
+    tm.exposure = mExposure;
+    tm.gInput = fr.mRadiance.data();
+    tm.gAlbedo = fr.mAlbedo.data();
+    tm.gOutput = fr.mTonemapResult.data();
+    tm.out_max = fr.mTonemapMax;
+    if (sthip_tonemap(mCtx, &tm) != STHIP_OK) throw std::runtime_error(std::string("sthip_tonemap: ") + sthip_last_error(mCtx));
     mFrameNumber += seed_count;
     mPrevViews = v;
     mPrevInverseViewTransforms = ti;
@@ -703,6 +729,9 @@ class BDPT {
   uint32_t mSamplingFlags = 0;
   BDPTPushConstants mPushConstants;
   uint32_t mFrameNumber = 0;
+  uint32_t mTonemapMode = STHIP_TONEMAP_RAW;  // BDPT.cpp:48
+  float mExposure = 0;
+  bool mGammaCorrection = true;
   std::vector<ViewData> mPrevViews;
   std::vector<TransformData> mPrevInverseViewTransforms;
   Frame mPrevFrame;

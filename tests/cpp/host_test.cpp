@@ -2,7 +2,7 @@
 // drives its components (main.cpp:59-66,97-149): build a node graph, let Application fire OnUpdate /
 // OnRenderWindow, read the renderer's result.
 //   host_test pack   <scene.bin>                       (no GPU) Scene::update must reproduce the packed arrays
-//   host_test render <scene.bin> <out.bin> <seeds>     (GPU)    BDPT::update + render, writes RGBA32F radiance
+//   host_test render <scene.bin> <out.bin> <seeds> [tonemap_mode exposure out.hdr]   (GPU)    BDPT::update + render, writes RGBA32F radiance
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -133,6 +133,10 @@ int main(int argc, char** argv) {
       const uint32_t seeds = (uint32_t)std::atoi(argv[4]);
       // init_renderer<BDPT>, main.cpp:59-66
       auto renderer = app.node().make_child("BDPT").make_component<BDPT>();
+      if (argc >= 8) {  // tone-map settings as the GUI would set them
+        renderer->tonemap_mode() = (uint32_t)std::atoi(argv[5]);
+        renderer->exposure() = (float)std::atof(argv[6]);
+      }
       app->OnRenderWindow.add_listener(renderer.node(), [&](CommandBuffer& c) { renderer->render(c, W, H, {{view, view_xf}}, seeds); });
       app->run_frame(cb);  // OnUpdate: Scene::update, then BDPT::update (eAlmostLast); OnRenderWindow: BDPT::render
       const auto& fr = renderer->prev_result();
@@ -140,6 +144,8 @@ int main(int argc, char** argv) {
       out.write((const char*)fr.mRadiance.data(), fr.mRadiance.size() * 4);
       out.write((const char*)fr.mVisibility.data(), fr.mVisibility.size() * sizeof(VisibilityInfo));
       out.write((const char*)fr.mRayCount, 16);
+      out.write((const char*)fr.mTonemapResult.data(), fr.mTonemapResult.size() * 4);
+      if (argc >= 8) renderer->export_hdr(argv[7]);
       std::printf("RENDER OK %ux%u rays %llu\n", W, H, (unsigned long long)fr.mRayCount[0]);
       return 0;
     }

@@ -52,24 +52,31 @@ def test_scene_update_packs_like_the_reference_layouts(host_test, tmp_path, make
 @pytest.mark.parametrize("make", [scenes.cornell_box, shared_mesh_scene, scenes.textured_box])
 def test_cpp_host_renders_what_the_python_host_renders(host_test, tmp_path, make):
     from stratum_amd.bdpt import BDPT
+    from stratum_amd.post import Tonemapper, write_hdr
 
     sc, cam = make()
     W, H, seeds = 96, 64, 3
     fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
     desc, outp = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
     dump_description(desc, sc, fr)
-    out = subprocess.run([host_test, "render", desc, outp, str(seeds)], capture_output=True, text=True)
+    hdr = str(tmp_path / "image.hdr")
+    out = subprocess.run([host_test, "render", desc, outp, str(seeds), str(wire.TONEMAP["ACES"]), "0.75", hdr], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("RENDER OK"), out.stdout + out.stderr
     raw = np.fromfile(outp, dtype=np.uint8)
     rad = raw[: W * H * 16].view(np.float32).reshape(H, W, 4)
     vis = raw[W * H * 16 : W * H * 24].view(wire.VisibilityInfo).reshape(H, W)
-    rays = raw[W * H * 24 :].view(np.uint64)
+    rays = raw[W * H * 24 : W * H * 24 + 16].view(np.uint64)
+    tm = raw[W * H * 24 + 16 :].view(np.float32).reshape(H, W, 4)
     r = BDPT(device=0)
     try:
         r.update(sc)
         ref = r.render(fr, 0, seeds)
+        ref_tm = Tonemapper(r, "ACES", 0.75, True)(ref["radiance"])
     finally:
         r.close()
+    assert np.array_equal(tm.view(np.uint32), ref_tm.view(np.uint32))
+    write_hdr(tmp_path / "py.hdr", ref["radiance"])
+    assert open(hdr, "rb").read() == (tmp_path / "py.hdr").read_bytes()
     assert np.array_equal(rad.view(np.uint32), ref["radiance"].view(np.uint32))
     assert np.array_equal(vis["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
     assert np.array_equal(rays, ref["ray_count"])
