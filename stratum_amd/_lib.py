@@ -12,7 +12,7 @@ import sys
 from . import wire
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstratum_hip.so")
+LIB_PATH = os.environ.get("STHIP_LIB") or os.path.join(_HERE, "libstratum_hip.so")  # STHIP_LIB: another build of the same library (kernel experiments)
 
 # every symbol include/sthip.h declares
 EXPORTS = [

@@ -74,6 +74,7 @@ struct sthip_ctx {
   DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays;
   DevBuf<uint32_t> meta, queue0, queue1;
   DevBuf<unsigned long long> counters;
+  DevBuf<unsigned long long> heads;  // WaveWork dequeue words
   DevBuf<uint32_t> post_scratch;  // maxima / metric accumulator of post.h
   DevBuf<float4> out_radiance, out_albedo;
   DevBuf<sthip_VisibilityInfo> out_visibility;
@@ -183,6 +184,7 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->queue0.release();
   ctx->queue1.release();
   ctx->counters.release();
+  ctx->heads.release();
   ctx->post_scratch.release();
   ctx->out_radiance.release();
   ctx->out_albedo.release();
@@ -518,6 +520,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   HIP_TRY(ctx, ctx->queue0.ensure(P));
   HIP_TRY(ctx, ctx->queue1.ensure(P));
   HIP_TRY(ctx, ctx->counters.ensure(CNT_TOTAL));
+  HIP_TRY(ctx, ctx->heads.ensure((size_t)128 * WORK_HEADS * WORK_HEAD_STRIDE));
 
   // views
   const uint32_t nv = frame->view_count;
@@ -568,6 +571,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.queue[1] = ctx->queue1.p;
   p.shadow_rays = ctx->shadow_rays.p;
   p.counters = ctx->counters.p;
+  p.heads = ctx->heads.p;
   p.count_traversal = ctx->count_traversal ? 1u : 0u;
   p.refill_idle = ctx->refill_idle;
   p.inner_min_lanes = ctx->inner_min_lanes;
@@ -665,6 +669,11 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     p.write_aov = s == 0 ? 1u : 0u;
     // queue sizes are per seed; the ray / traversal counters behind them run over the whole call
     if (s) HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_PER_SEED * sizeof(unsigned long long), st));
+    {
+      const size_t per_depth = WORK_HEADS * WORK_HEAD_STRIDE;  // words
+      HIP_TRY(ctx, hipMemsetAsync(ctx->heads.p, 0, max_bounce_rounds * per_depth * 8, st));
+      HIP_TRY(ctx, hipMemsetAsync(ctx->heads.p + 64 * per_depth, 0, max_bounce_rounds * per_depth * 8, st));
+    }
     int rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(STHIP_BLOCK), 0, st, p); });
     if (rc) return rc;
     for (uint32_t depth = 0; depth < max_bounce_rounds; depth++) {

@@ -21,8 +21,6 @@
 enum {
   CNT_QUEUE0 = 0,     // [depth]: size of the path queue entering bounce `depth`
   CNT_SHADOW0 = 64,   // [depth]: size of the shadow-ray queue of bounce `depth`
-  CNT_HEAD0 = 128,    // [depth]: dequeue head of k_trace_closest
-  CNT_HEADS0 = 192,   // [depth]: dequeue head of k_trace_shadow
   CNT_PER_SEED = 256,
   CNT_RAYS_CLOSEST = 256,
   CNT_RAYS_SHADOW = 257,
@@ -61,6 +59,7 @@ struct FrameParams {
   uint32_t* queue[2];
   float4* shadow_rays;  // 3 x float4 per entry: (origin, distance) (direction, bits(slot)) (contribution, 0)
   unsigned long long* counters;  // CNT_* (64-bit each)
+  unsigned long long* heads;     // dequeue words of the trace kernels: [closest | shadow][depth < 64][WORK_HEADS] x 128 B (WaveWork)
   // outputs (device pointers; may be null)
   float4* out_radiance;
   float4* out_albedo;
@@ -205,7 +204,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, ui
   const uint32_t n = depth == 0 ? p.path_count : (uint32_t)p.counters[CNT_QUEUE0 + depth];
   if (n == 0) return;
   const uint32_t* queue = p.queue[depth & 1u];
-  unsigned long long* head = &p.counters[CNT_HEAD0 + depth];
+  unsigned long long* head = p.heads + (size_t)depth * (WORK_HEADS * WORK_HEAD_STRIDE);
   uint32_t* stack = lds_stack + threadIdx.x;
   TraverseCounters cnt;
   cnt.nodes = cnt.tris = 0;
@@ -255,7 +254,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
   extern __shared__ uint32_t lds_stack[];
   const uint32_t n = (uint32_t)p.counters[CNT_SHADOW0 + depth];
   if (n == 0) return;
-  unsigned long long* head = &p.counters[CNT_HEADS0 + depth];
+  unsigned long long* head = p.heads + (size_t)(64u + depth) * (WORK_HEADS * WORK_HEAD_STRIDE);
   uint32_t* stack = lds_stack + threadIdx.x;
   TraverseCounters cnt;
   cnt.nodes = cnt.tris = 0;

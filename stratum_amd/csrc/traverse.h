@@ -273,32 +273,57 @@ DEV bool traverse(const DeviceBvh& bvh, f3 o, f3 d, float tmin, float tmax, uint
   return hit.ip != 0xFFFFFFFFu;
 }
 
-// Wave-level work distribution for the persistent trace kernels. Every wave owns a private chunk
-// [next, end) of the queue, refilled with ONE global atomic per WORK_CHUNK rays (a single head word
-// saturates at ~88 dequeues/us on MI355X); idle lanes take consecutive entries of the chunk, ranked
-// with ballot + popcount.
-#define WORK_CHUNK 256u
+// Wave-level work distribution for the persistent trace kernels. The queue [0, n) is cut into WORK_HEADS
+// contiguous slices, each with its own dequeue word on its own 128-byte line: a single word serialises at
+// ~88 dequeues/us on MI355X (device-scope atomics resolve outside the per-XCD L2), which forces big chunks and
+// an uneven tail. A wave starts on slice blockIdx % WORK_HEADS — workgroups go round-robin over the 8 XCDs, so
+// each XCD eats one contiguous part of the queue and its L2 sees one part of the image / the scene — and moves
+// on to the next slice when its own is dry (a dry slice stays dry, so a wave probes each at most once).
+// Within a chunk idle lanes take consecutive entries, ranked with ballot + popcount.
+#ifndef WORK_CHUNK
+#define WORK_CHUNK 64u
+#endif
+#ifndef WORK_HEADS
+#define WORK_HEADS 8u
+#endif
+#define WORK_HEAD_STRIDE 16u  // in 64-bit words: one head per 128-byte line
 struct WaveWork {
   uint32_t next, end;
+  uint32_t cur, dry;  // slice in use, slices found empty
   bool exhausted;
   DEV void init() {
     next = end = 0;
+    cur = blockIdx.x % WORK_HEADS;
+    dry = 0;
     exhausted = false;
   }
   // For the lanes in `want`: returns the queue index each one takes, or 0xFFFFFFFF.
-  DEV uint32_t take(bool want, unsigned long long* head, uint32_t n) {
+  DEV uint32_t take(bool want, unsigned long long* heads, uint32_t n) {
     const unsigned long long mask = __ballot(want);
     if (!mask) return 0xFFFFFFFFu;
     const uint32_t lane = threadIdx.x & 63u;
     if (next >= end && !exhausted) {
-      uint32_t base = 0;
-      if (lane == 0) base = (uint32_t)atomicAdd(head, (unsigned long long)WORK_CHUNK);
-      base = (uint32_t)__shfl((int)base, 0, 64);
-      if (base >= n) {
-        exhausted = true;
-      } else {
-        next = base;
-        end = base + WORK_CHUNK < n ? base + WORK_CHUNK : n;
+      const uint32_t per = (((n + WORK_HEADS - 1u) / WORK_HEADS) + 63u) & ~63u;  // slice length
+      for (;;) {
+        const uint32_t lo = cur * per;
+        const uint32_t hi = lo + per < n ? lo + per : n;
+        uint32_t base = 0xFFFFFFFFu;
+        if (lo < hi) {
+          unsigned long long b = 0;
+          if (lane == 0) b = atomicAdd(&heads[cur * WORK_HEAD_STRIDE], (unsigned long long)WORK_CHUNK);
+          b = (unsigned long long)__shfl((int)(uint32_t)(b > 0xFFFFFFFFull ? 0xFFFFFFFFull : b), 0, 64) & 0xFFFFFFFFull;
+          if (b < (unsigned long long)(hi - lo)) base = lo + (uint32_t)b;
+        }
+        if (base != 0xFFFFFFFFu) {
+          next = base;
+          end = base + WORK_CHUNK < hi ? base + WORK_CHUNK : hi;
+          break;
+        }
+        cur = cur + 1u == WORK_HEADS ? 0u : cur + 1u;
+        if (++dry == WORK_HEADS) {
+          exhausted = true;
+          break;
+        }
       }
     }
     const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
