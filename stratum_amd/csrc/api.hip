@@ -74,7 +74,7 @@ struct sthip_ctx {
   DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays;
   DevBuf<uint32_t> meta, queue0, queue1;
   DevBuf<unsigned long long> counters;
-  DevBuf<unsigned long long> heads;  // WaveWork dequeue words
+  DevBuf<unsigned long long> qctl;  // queue control lines (queue_ctl)
   DevBuf<uint32_t> post_scratch;  // maxima / metric accumulator of post.h
   DevBuf<float4> out_radiance, out_albedo;
   DevBuf<sthip_VisibilityInfo> out_visibility;
@@ -184,7 +184,7 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->queue0.release();
   ctx->queue1.release();
   ctx->counters.release();
-  ctx->heads.release();
+  ctx->qctl.release();
   ctx->post_scratch.release();
   ctx->out_radiance.release();
   ctx->out_albedo.release();
@@ -397,6 +397,9 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   return STHIP_OK;
 }
 
+static unsigned long long* queue_ctl_host(unsigned long long* qctl, uint32_t kind, uint32_t depth) {
+  return qctl + (size_t)((kind * 64u + depth) * QUEUE_SEGMENTS) * QCTL_STRIDE;
+}
 static uint32_t grid_for(const sthip_ctx* ctx, size_t n) {
   const size_t blocks = (n + STHIP_BLOCK - 1) / STHIP_BLOCK;
   const size_t cap = (size_t)ctx->cu_count * 32;  // grid-stride beyond this
@@ -515,12 +518,17 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   HIP_TRY(ctx, ctx->shadow_sum.ensure(P));
   HIP_TRY(ctx, ctx->accum.ensure(P0));
   if (ctx->textured) HIP_TRY(ctx, ctx->cone.ensure(P));
-  HIP_TRY(ctx, ctx->shadow_rays.ensure(3 * P));
+  // The queues are cut into QUEUE_SEGMENTS segments (traverse.h). A segment starts as a contiguous eighth of the
+  // slots and only shrinks from bounce to bounce, which bounds it and the distance between segments.
+  const uint32_t shade_grid = std::max<uint32_t>(grid_for(ctx, P), QUEUE_SEGMENTS);
+  const size_t seg_stride = (((P + QUEUE_SEGMENTS - 1) / QUEUE_SEGMENTS) + 63) & ~(size_t)63;
+  if (seg_stride * QUEUE_SEGMENTS > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many paths in flight");
+  HIP_TRY(ctx, ctx->shadow_rays.ensure(3 * seg_stride * QUEUE_SEGMENTS));
   HIP_TRY(ctx, ctx->meta.ensure(P));
-  HIP_TRY(ctx, ctx->queue0.ensure(P));
-  HIP_TRY(ctx, ctx->queue1.ensure(P));
+  HIP_TRY(ctx, ctx->queue0.ensure(seg_stride * QUEUE_SEGMENTS));
+  HIP_TRY(ctx, ctx->queue1.ensure(seg_stride * QUEUE_SEGMENTS));
   HIP_TRY(ctx, ctx->counters.ensure(CNT_TOTAL));
-  HIP_TRY(ctx, ctx->heads.ensure((size_t)128 * WORK_HEADS * WORK_HEAD_STRIDE));
+  HIP_TRY(ctx, ctx->qctl.ensure((size_t)2 * 64 * QUEUE_SEGMENTS * QCTL_STRIDE));
 
   // views
   const uint32_t nv = frame->view_count;
@@ -571,7 +579,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.queue[1] = ctx->queue1.p;
   p.shadow_rays = ctx->shadow_rays.p;
   p.counters = ctx->counters.p;
-  p.heads = ctx->heads.p;
+  p.qctl = ctx->qctl.p;
+  p.seg_stride = (uint32_t)seg_stride;
   p.count_traversal = ctx->count_traversal ? 1u : 0u;
   p.refill_idle = ctx->refill_idle;
   p.inner_min_lanes = ctx->inner_min_lanes;
@@ -635,7 +644,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       }
     }
   }
-  const uint32_t grid = grid_for(ctx, p.path_count);
+  const uint32_t grid = shade_grid;
   const size_t lds = stack_bytes(ctx);
   const uint32_t tgrid = std::min<uint32_t>(trace_grid(ctx, lds), (uint32_t)((P + STHIP_BLOCK - 1) / STHIP_BLOCK));
   // closest-hit rays per path <= gMaxPathVertices - 1 (path.hlsli:960); without specular materials every scattering
@@ -643,6 +652,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   // rounds beyond that would only be empty launches
   uint32_t max_bounce_rounds = pc->gMaxPathVertices >= 2 ? pc->gMaxPathVertices - 1 : 0;
   if (!ctx->has_specular) max_bounce_rounds = std::min(max_bounce_rounds, pc->gMaxDiffuseVertices + 1);
+  p.rounds = max_bounce_rounds;
   const bool timing = ctx->time_kernels;
   float ms_closest = 0, ms_shadow = 0, ms_shade = 0, ms_other = 0;
   uint32_t launches_closest = 0, launches_shadow = 0;
@@ -667,12 +677,11 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     p.seeds_in_flight = in_flight;
     p.path_count = in_flight * p.paths_per_seed;
     p.write_aov = s == 0 ? 1u : 0u;
-    // queue sizes are per seed; the ray / traversal counters behind them run over the whole call
-    if (s) HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_PER_SEED * sizeof(unsigned long long), st));
+    // queue sizes and heads are per pass; the ray / traversal counters run over the whole call
     {
-      const size_t per_depth = WORK_HEADS * WORK_HEAD_STRIDE;  // words
-      HIP_TRY(ctx, hipMemsetAsync(ctx->heads.p, 0, max_bounce_rounds * per_depth * 8, st));
-      HIP_TRY(ctx, hipMemsetAsync(ctx->heads.p + 64 * per_depth, 0, max_bounce_rounds * per_depth * 8, st));
+      const size_t per_depth = (size_t)QUEUE_SEGMENTS * QCTL_STRIDE * sizeof(unsigned long long);
+      HIP_TRY(ctx, hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 0, 0), 0, (max_bounce_rounds + 1) * per_depth, st));  // k_shade of the last round appends to depth + 1
+      HIP_TRY(ctx, hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 1, 0), 0, max_bounce_rounds * per_depth, st));
     }
     int rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(STHIP_BLOCK), 0, st, p); });
     if (rc) return rc;
@@ -696,9 +705,13 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       if (timing) {
         // per-kernel timing synchronises anyway: stop at the first empty round so that launch
         // statistics only cover launches that had rays (untimed runs enqueue every round blindly)
-        unsigned long long nq[2] = {0, 0};
-        HIP_TRY(ctx, hipMemcpy(&nq[0], ctx->counters.p + CNT_QUEUE0 + depth + 1, 8, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(&nq[1], ctx->counters.p + CNT_SHADOW0 + depth, 8, hipMemcpyDeviceToHost));
+        unsigned long long nq[2] = {0, 0}, lines[2][QUEUE_SEGMENTS * QCTL_STRIDE];
+        HIP_TRY(ctx, hipMemcpy(lines[0], queue_ctl_host(ctx->qctl.p, 0, depth + 1), sizeof(lines[0]), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(lines[1], queue_ctl_host(ctx->qctl.p, 1, depth), sizeof(lines[1]), hipMemcpyDeviceToHost));
+        for (uint32_t g = 0; g < QUEUE_SEGMENTS; g++) {
+          nq[0] += lines[0][g * QCTL_STRIDE + QCTL_SIZE];
+          nq[1] += lines[1][g * QCTL_STRIDE + QCTL_SIZE];
+        }
         last_round = nq[0] == 0;
         if (nq[1] == 0 && last_round) break;
       }

@@ -16,17 +16,13 @@
 
 #define STHIP_BLOCK 256
 
-// queue / counter slots in FrameParams::counters
-// [0, CNT_PER_SEED) is cleared for every seed; the rest accumulates over a render call
+// counter slots in FrameParams::counters: they accumulate over a render call (queue sizes live in FrameParams::qctl)
 enum {
-  CNT_QUEUE0 = 0,     // [depth]: size of the path queue entering bounce `depth`
-  CNT_SHADOW0 = 64,   // [depth]: size of the shadow-ray queue of bounce `depth`
-  CNT_PER_SEED = 256,
-  CNT_RAYS_CLOSEST = 256,
-  CNT_RAYS_SHADOW = 257,
-  CNT_NODES = 258,  // +1: shadow rays
-  CNT_TRIS = 260,   // +1: shadow rays
-  CNT_TOTAL = 264
+  CNT_RAYS_CLOSEST = 0,
+  CNT_RAYS_SHADOW = 1,
+  CNT_NODES = 2,  // +1: shadow rays
+  CNT_TRIS = 4,   // +1: shadow rays
+  CNT_TOTAL = 8
 };
 
 struct FrameParams {
@@ -59,7 +55,9 @@ struct FrameParams {
   uint32_t* queue[2];
   float4* shadow_rays;  // 3 x float4 per entry: (origin, distance) (direction, bits(slot)) (contribution, 0)
   unsigned long long* counters;  // CNT_* (64-bit each)
-  unsigned long long* heads;     // dequeue words of the trace kernels: [closest | shadow][depth < 64][WORK_HEADS] x 128 B (WaveWork)
+  unsigned long long* qctl;      // queue control lines, queue_ctl(): [path | shadow][depth < 64][QUEUE_SEGMENTS] x 128 B
+  uint32_t seg_stride;           // entries between the segments of queue[] / shadow_rays
+  uint32_t rounds;               // bounce rounds of this render (<= 63)
   // outputs (device pointers; may be null)
   float4* out_radiance;
   float4* out_albedo;
@@ -201,10 +199,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
 template <bool COUNT>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, uint32_t depth) {
   extern __shared__ uint32_t lds_stack[];
-  const uint32_t n = depth == 0 ? p.path_count : (uint32_t)p.counters[CNT_QUEUE0 + depth];
-  if (n == 0) return;
+  const uint32_t n = p.path_count;              // first bounce: every slot, no queue
+  const uint32_t stride = depth == 0 ? 0u : p.seg_stride;
   const uint32_t* queue = p.queue[depth & 1u];
-  unsigned long long* head = p.heads + (size_t)depth * (WORK_HEADS * WORK_HEAD_STRIDE);
+  unsigned long long* ctl = queue_ctl(p.qctl, 0, depth, 0);
   uint32_t* stack = lds_stack + threadIdx.x;
   TraverseCounters cnt;
   cnt.nodes = cnt.tris = 0;
@@ -217,7 +215,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, ui
   for (;;) {
     const unsigned long long idle = __ballot(!busy);
     if ((uint32_t)__popcll(idle) >= p.refill_idle || idle == ~0ull) {
-      const uint32_t idx = work.take(!busy, head, n);
+      const uint32_t idx = work.take(!busy, ctl, stride, n);
       if (idx != 0xFFFFFFFFu) {
         slot = depth == 0 ? idx : queue[idx];
         if (depth == 0 && p.meta[slot] >= 0xFFFFFFFEu) {
@@ -252,9 +250,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, ui
 template <bool COUNT>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uint32_t depth) {
   extern __shared__ uint32_t lds_stack[];
-  const uint32_t n = (uint32_t)p.counters[CNT_SHADOW0 + depth];
-  if (n == 0) return;
-  unsigned long long* head = p.heads + (size_t)(64u + depth) * (WORK_HEADS * WORK_HEAD_STRIDE);
+  unsigned long long* ctl = queue_ctl(p.qctl, 1, depth, 0);
   uint32_t* stack = lds_stack + threadIdx.x;
   TraverseCounters cnt;
   cnt.nodes = cnt.tris = 0;
@@ -269,7 +265,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
   for (;;) {
     const unsigned long long idle = __ballot(!busy);
     if ((uint32_t)__popcll(idle) >= p.refill_idle || idle == ~0ull) {
-      const uint32_t idx = work.take(!busy, head, n);
+      const uint32_t idx = work.take(!busy, ctl, p.seg_stride, 0);
       if (idx != 0xFFFFFFFFu) {
         const float4 s0 = p.shadow_rays[3 * (size_t)idx], s1 = p.shadow_rays[3 * (size_t)idx + 1], s2 = p.shadow_rays[3 * (size_t)idx + 2];
         slot = __float_as_uint(s1.w);
@@ -308,14 +304,32 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
 // TEXTURED: the scene binds images; ray cones, image values and normal maps are evaluated
 template <bool TEXTURED>
 __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_t depth) {
-  const uint32_t n = depth == 0 ? p.path_count : (uint32_t)p.counters[CNT_QUEUE0 + depth];
-  const uint32_t* queue_in = p.queue[depth & 1u];
-  uint32_t* queue_out = p.queue[(depth + 1) & 1u];
+  // Workgroup b works on segment b % 8 (its XCD's) of the incoming queue and appends to the same segment of the
+  // outgoing queues, so a segment never grows. In the first bounce a segment is a contiguous eighth of the slots
+  // (the same split WaveWork uses): an XCD keeps one part of the image, and the part of the scene seen from it,
+  // from kernel to kernel.
+  const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
+  const uint32_t seg_base = seg * p.seg_stride;
+  uint32_t n, slot0 = 0;
+  if (depth == 0) {
+    const uint32_t per = (((p.path_count + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) + 63u) & ~63u;
+    slot0 = seg * per;
+    n = slot0 < p.path_count ? (slot0 + per < p.path_count ? per : p.path_count - slot0) : 0u;
+  } else {
+    n = (uint32_t)queue_ctl(p.qctl, 0, depth, seg)[QCTL_SIZE];
+  }
+  const uint32_t first = (blockIdx.x / QUEUE_SEGMENTS) * blockDim.x + threadIdx.x;
+  const uint32_t step = ((gridDim.x - seg + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) * blockDim.x;
+  const uint32_t* queue_in = p.queue[depth & 1u] + seg_base;
+  uint32_t* queue_out = p.queue[(depth + 1) & 1u] + seg_base;
+  float4* shadow_out = p.shadow_rays + 3 * (size_t)seg_base;
+  unsigned long long* queue_size = &queue_ctl(p.qctl, 0, depth + 1, seg)[QCTL_SIZE];
+  unsigned long long* shadow_size = &queue_ctl(p.qctl, 1, depth, seg)[QCTL_SIZE];
   const bool use_nee = flag(p, STHIP_eNEE);
   const bool use_mis = flag(p, STHIP_eMIS);
   const bool sample_bsdfs = flag(p, STHIP_eSampleBSDFs);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t slot = depth == 0 ? i : queue_in[i];
+  for (uint32_t i = first; i < n; i += step) {
+    const uint32_t slot = depth == 0 ? slot0 + i : queue_in[i];
     uint32_t meta = p.meta[slot];
     if (meta >= 0xFFFFFFFEu) continue;
     uint32_t px, py;
@@ -540,10 +554,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
               }
               break;
             }
-            const uint32_t k = (uint32_t)atomicAdd(&p.counters[CNT_SHADOW0 + depth], 1ull);
-            p.shadow_rays[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
-            p.shadow_rays[3 * (size_t)k + 1] = make_float4(to_light.x, to_light.y, to_light.z, __uint_as_float(slot));
-            p.shadow_rays[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+            const uint32_t k = (uint32_t)atomicAdd(shadow_size, 1ull);
+            shadow_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
+            shadow_out[3 * (size_t)k + 1] = make_float4(to_light.x, to_light.y, to_light.z, __uint_as_float(slot));
+            shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
           } while (0);
         }
       }
@@ -577,7 +591,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
       p.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(rng.counter));
       p.meta[slot] = path_length | (diffuse_vertices << 8);
       if (TEXTURED) p.cone[slot] = make_float2(rd_radius, rd_spread);
-      const uint32_t k = (uint32_t)atomicAdd(&p.counters[CNT_QUEUE0 + depth + 1], 1ull);
+      const uint32_t k = (uint32_t)atomicAdd(queue_size, 1ull);
       queue_out[k] = slot;
     }
   }
@@ -591,8 +605,11 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // every queued path / shadow record was traced exactly once: ray counts are the queue sizes
     unsigned long long closest = primary_rays, shadow = 0;
-    for (int d = 1; d < 64; d++) closest += p.counters[CNT_QUEUE0 + d];
-    for (int d = 0; d < 64; d++) shadow += p.counters[CNT_SHADOW0 + d];
+    for (uint32_t d = 0; d < p.rounds; d++)
+      for (uint32_t s = 0; s < QUEUE_SEGMENTS; s++) {
+        if (d) closest += queue_ctl(p.qctl, 0, d, s)[QCTL_SIZE];
+        shadow += queue_ctl(p.qctl, 1, d, s)[QCTL_SIZE];
+      }
     p.counters[CNT_RAYS_CLOSEST] += closest;
     p.counters[CNT_RAYS_SHADOW] += shadow;
   }

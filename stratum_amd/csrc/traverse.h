@@ -273,54 +273,70 @@ DEV bool traverse(const DeviceBvh& bvh, f3 o, f3 d, float tmin, float tmax, uint
   return hit.ip != 0xFFFFFFFFu;
 }
 
-// Wave-level work distribution for the persistent trace kernels. The queue [0, n) is cut into WORK_HEADS
-// contiguous slices, each with its own dequeue word on its own 128-byte line: a single word serialises at
-// ~88 dequeues/us on MI355X (device-scope atomics resolve outside the per-XCD L2), which forces big chunks and
-// an uneven tail. A wave starts on slice blockIdx % WORK_HEADS — workgroups go round-robin over the 8 XCDs, so
-// each XCD eats one contiguous part of the queue and its L2 sees one part of the image / the scene — and moves
-// on to the next slice when its own is dry (a dry slice stays dry, so a wave probes each at most once).
-// Within a chunk idle lanes take consecutive entries, ranked with ballot + popcount.
+// Work queues of the wavefront pipeline are cut into QUEUE_SEGMENTS segments, each with its own control words
+// (entries produced; dequeue head — on separate 128-byte lines). One word serialises at ~88 atomics/us on MI355X
+// (device-scope atomics resolve outside the per-XCD L2), which bounds a producer kernel that appends once per wave
+// and forces a consumer into big chunks with an uneven tail; eight lines give eight times that. Workgroups go
+// round-robin over the 8 XCDs, so segment = blockIdx % 8 keeps a path on "its" XCD from kernel to kernel.
+#define QUEUE_SEGMENTS 8u
+#define QCTL_STRIDE 32u  // 64-bit words per segment: two 128-byte lines, so that reading the size (constant while a
+                         // consumer runs) never touches the line its dequeue atomics keep busy
+#define QCTL_SIZE 0u     // word: entries produced
+#define QCTL_HEAD 16u    // word: dequeue head of the consuming trace kernel
+// control line of (kind: 0 = path queue entering bounce `depth`, 1 = shadow rays of bounce `depth`; depth < 64; segment)
+DEV unsigned long long* queue_ctl(unsigned long long* qctl, uint32_t kind, uint32_t depth, uint32_t seg) {
+  return qctl + (size_t)((kind * 64u + depth) * QUEUE_SEGMENTS + seg) * QCTL_STRIDE;
+}
+
+// Wave-level work distribution for the persistent trace kernels. A wave starts on segment blockIdx % 8 and moves
+// on to the next when its own is dry (a dry segment stays dry, so each is probed at most once); it takes WORK_CHUNK
+// entries per atomic and hands them to idle lanes ranked with ballot + popcount.
 #ifndef WORK_CHUNK
 #define WORK_CHUNK 64u
 #endif
-#ifndef WORK_HEADS
-#define WORK_HEADS 8u
-#endif
-#define WORK_HEAD_STRIDE 16u  // in 64-bit words: one head per 128-byte line
 struct WaveWork {
   uint32_t next, end;
-  uint32_t cur, dry;  // slice in use, slices found empty
+  uint32_t cur, dry;  // segment in use, segments found empty
   bool exhausted;
   DEV void init() {
     next = end = 0;
-    cur = blockIdx.x % WORK_HEADS;
+    cur = blockIdx.x % QUEUE_SEGMENTS;
     dry = 0;
     exhausted = false;
   }
-  // For the lanes in `want`: returns the queue index each one takes, or 0xFFFFFFFF.
-  DEV uint32_t take(bool want, unsigned long long* heads, uint32_t n) {
+  // ctl: control line of segment 0. Segment s holds entries [s * stride, s * stride + len_s) where len_s is the
+  // produced count (stride != 0) or, for the un-queued first bounce (stride == 0), an equal share of n.
+  // For the lanes in `want`: returns the entry index each one takes, or 0xFFFFFFFF.
+  DEV uint32_t take(bool want, unsigned long long* ctl, uint32_t stride, uint32_t n) {
     const unsigned long long mask = __ballot(want);
     if (!mask) return 0xFFFFFFFFu;
     const uint32_t lane = threadIdx.x & 63u;
     if (next >= end && !exhausted) {
-      const uint32_t per = (((n + WORK_HEADS - 1u) / WORK_HEADS) + 63u) & ~63u;  // slice length
+      const uint32_t per = (((n + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) + 63u) & ~63u;
       for (;;) {
-        const uint32_t lo = cur * per;
-        const uint32_t hi = lo + per < n ? lo + per : n;
-        uint32_t base = 0xFFFFFFFFu;
-        if (lo < hi) {
-          unsigned long long b = 0;
-          if (lane == 0) b = atomicAdd(&heads[cur * WORK_HEAD_STRIDE], (unsigned long long)WORK_CHUNK);
-          b = (unsigned long long)__shfl((int)(uint32_t)(b > 0xFFFFFFFFull ? 0xFFFFFFFFull : b), 0, 64) & 0xFFFFFFFFull;
-          if (b < (unsigned long long)(hi - lo)) base = lo + (uint32_t)b;
+        unsigned long long* line = ctl + (size_t)cur * QCTL_STRIDE;
+        uint32_t lo, len;
+        if (stride) {
+          lo = cur * stride;
+          len = (uint32_t)line[QCTL_SIZE];
+        } else {
+          lo = cur * per;
+          len = lo < n ? (lo + per < n ? per : n - lo) : 0u;
         }
-        if (base != 0xFFFFFFFFu) {
-          next = base;
-          end = base + WORK_CHUNK < hi ? base + WORK_CHUNK : hi;
+        uint32_t got = 0xFFFFFFFFu;
+        if (len) {
+          unsigned long long b = 0;
+          if (lane == 0) b = atomicAdd(&line[QCTL_HEAD], (unsigned long long)WORK_CHUNK);
+          const uint32_t b32 = (uint32_t)__shfl((int)(uint32_t)(b > 0xFFFFFFFFull ? 0xFFFFFFFFull : b), 0, 64);
+          if (b32 < len) got = b32;
+        }
+        if (got != 0xFFFFFFFFu) {
+          next = lo + got;
+          end = lo + (got + WORK_CHUNK < len ? got + WORK_CHUNK : len);
           break;
         }
-        cur = cur + 1u == WORK_HEADS ? 0u : cur + 1u;
-        if (++dry == WORK_HEADS) {
+        cur = cur + 1u == QUEUE_SEGMENTS ? 0u : cur + 1u;
+        if (++dry == QUEUE_SEGMENTS) {
           exhausted = true;
           break;
         }
