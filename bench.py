@@ -196,6 +196,9 @@ def main():
             },
             "shadow_nodes_per_ray": round(nodes_sh / max(rays_shadow, 1), 2),
             "shadow_tris_per_ray": round(tris_sh / max(rays_shadow, 1), 2),
+            "note": "achieved counts ALGORITHMIC bytes (48 B/ray + node and triangle bytes per visit, SURVEY 8d); most node "
+            "fetches hit L2 / Infinity Cache (compare traffic), so frac > 1 means the kernel runs above what HBM alone could "
+            "feed: it is bound by dependent-load latency and lane divergence, see profiles/README.md",
         }
 
         # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----

@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/profile_round.sh <tag>
+# Everything profiles/<round>/ holds, from one build: kernel-trace stats of the bench command, the PMC passes, traffic.json.
+set -e
+tag=$1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python3 bench.py --steps 10 --warmup 2 > gpurun_out/prof_${tag}.log 2>&1
+grep '"metric"' gpurun_out/prof_${tag}.log > gpurun_out/prof_${tag}_bench_line.json
+cp gpurun_out/prof_${tag}/*/*_kernel_stats.csv gpurun_out/prof_${tag}_kernel_stats.csv
+tools/pmc.sh ${tag}
+python3 tools/traffic.py gpurun_out/pmc_${tag}_fetch/*/*_counter_collection.csv gpurun_out/pmc_${tag}_write/*/*_counter_collection.csv k_trace_closest gpurun_out/pmc_${tag}_traffic.json
+echo done
