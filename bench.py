@@ -15,7 +15,7 @@ value = rays of all ranks / max-over-ranks wall time; a ray is one trace_ray inv
 included (gRayCount[0], src/Shaders/common/intersection.hlsli:66).
 
 The JSON line also carries
-  roofline      for the dominant kernel (k_trace_closest): algorithmic bytes per launch
+  roofline      for the dominant kernel (k_trace): algorithmic bytes per launch
                 (48 B ray+hit, + node bytes x nodes visited, + 48 B x triangles tested) over the
                 kernel's mean launch duration, measured here with HIP events on the launch stream;
   cpu_baseline  the CPU oracle (a port of the reference shaders; the reference has no CPU path) timed on
@@ -50,7 +50,7 @@ def host_threads():
 
 
 def measured_traffic():
-    """HBM-side bytes per live k_trace_closest launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+    """HBM-side bytes per live k_trace launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in
     their own rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes; tools/pmc.sh + tools/traffic.py).
     Counters cannot be read from inside this process, so this is the value of the newest committed profile."""
     import glob
@@ -147,18 +147,16 @@ def main():
 
     result = None
     if rank == 0:
-        # ---- roofline of the dominant kernel (closest-hit traversal), this rank ----
+        # ---- roofline of the dominant kernel (k_trace: BVH traversal of closest-hit and shadow rays), this rank ----
         r.set_option("time_kernels", 1)
-        ms_closest, ms_total, launches = 0.0, 0.0, 0
-        ms_shadow, ms_shade = 0.0, 0.0
+        ms_trace, ms_shade, ms_total, launches = 0.0, 0.0, 0.0, 0
         for i in range(args.steps):
             r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
             s = r.stats()
-            ms_closest += s["ms_trace_closest"]
-            ms_shadow += s["ms_trace_shadow"]
+            ms_trace += s["ms_trace"]
             ms_shade += s["ms_shade"]
             ms_total += s["ms_total"]
-            launches += s["launches_trace_closest"]
+            launches += s["launches_trace"]
         r.set_option("time_kernels", 0)
         r.set_option("count_traversal", 1)
         nodes = tris = rays_closest = rays_shadow = nodes_sh = tris_sh = 0
@@ -173,29 +171,31 @@ def main():
             rays_shadow += s["rays_shadow"]
         r.set_option("count_traversal", 0)
         node_bytes, tri_bytes = s["bvh_node_bytes"], s["bvh_tri_bytes"]
-        alg_bytes = 48.0 * rays_closest + float(node_bytes) * nodes + float(tri_bytes) * tris
-        achieved = alg_bytes / (ms_closest * 1e-3) / 1e9 if ms_closest > 0 else 0.0
+        rays = rays_closest + rays_shadow
+        # B_ray = 48 (ray in + hit out; a shadow record is 48 B too) + node bytes * nodes + triangle bytes * tris
+        alg_bytes = 48.0 * rays + float(node_bytes) * (nodes + nodes_sh) + float(tri_bytes) * (tris + tris_sh)
+        achieved = alg_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else 0.0
         roofline = {
             "bound": "hbm",
-            "kernel": "k_trace_closest",
+            "kernel": "k_trace",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": measured_traffic(),
             "bytes_per_launch": round(alg_bytes / max(launches, 1), 1),
-            "launch_ms": round(ms_closest / max(launches, 1), 4),
-            "nodes_per_ray": round(nodes / max(rays_closest, 1), 2),
-            "tris_per_ray": round(tris / max(rays_closest, 1), 2),
-            "bytes_per_ray": round(alg_bytes / max(rays_closest, 1), 1),
+            "launch_ms": round(ms_trace / max(launches, 1), 4),
+            "launches_per_step": round(launches / args.steps, 2),
+            "nodes_per_ray": round((nodes + nodes_sh) / max(rays, 1), 2),
+            "tris_per_ray": round((tris + tris_sh) / max(rays, 1), 2),
+            "bytes_per_ray": round(alg_bytes / max(rays, 1), 1),
             "kernel_ms_per_step": {
-                "trace_closest": round(ms_closest / args.steps, 3),
-                "trace_shadow": round(ms_shadow / args.steps, 3),
+                "trace": round(ms_trace / args.steps, 3),
                 "shade": round(ms_shade / args.steps, 3),
                 "all": round(ms_total / args.steps, 3),
             },
+            "closest_nodes_per_ray": round(nodes / max(rays_closest, 1), 2),
             "shadow_nodes_per_ray": round(nodes_sh / max(rays_shadow, 1), 2),
-            "shadow_tris_per_ray": round(tris_sh / max(rays_shadow, 1), 2),
             "note": "achieved counts ALGORITHMIC bytes (48 B/ray + node and triangle bytes per visit, SURVEY 8d); most node "
             "fetches hit L2 / Infinity Cache (compare traffic), so frac > 1 means the kernel runs above what HBM alone could "
             "feed: it is bound by dependent-load latency and lane divergence, see profiles/README.md",

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STHIP_ABI_VERSION 2
+#define STHIP_ABI_VERSION 3
 
 typedef struct sthip_ctx sthip_ctx;
 
@@ -153,18 +153,23 @@ typedef struct sthip_stats {
   uint64_t tris_tested;
   uint64_t nodes_visited_shadow; /* any-hit (shadow) rays */
   uint64_t tris_tested_shadow;
-  float ms_trace_closest;  /* hipEvent time spent in the closest-hit traversal kernels of the last render */
-  float ms_trace_shadow;
+  float ms_trace;          /* hipEvent time spent in the traversal kernel (k_trace) during the last render ("time_kernels") */
   float ms_shade;
   float ms_total;          /* all kernels of the last render */
-  uint32_t launches_trace_closest;
-  uint32_t launches_trace_shadow;
+  uint32_t launches_trace; /* k_trace launches of the last render */
   uint32_t bvh_node_bytes; /* bytes of one BVH node as laid out in HBM */
   uint32_t bvh_tri_bytes;  /* bytes of one leaf triangle */
   uint64_t bvh_nodes;
   uint64_t bvh_tris;
   float bvh_build_ms;      /* wall time of the acceleration-structure build inside the last sthip_scene_upload */
   float bvh_build_gpu_ms;  /* of which device time of the LBVH kernels ("bvh_builder" = 1) */
+  /* lane-occupancy diagnostics of the trace kernels, [0] closest-hit, [1] shadow rays (with "count_traversal"):
+   * 64 per wave-level iteration of the node loop / the triangle loop / per scheduling round of a persistent wave, and
+   * the number of lanes that held a ray summed over rounds: nodes_visited / inner_slots etc. are lane utilisations */
+  uint64_t inner_slots[2];
+  uint64_t tri_slots[2];
+  uint64_t round_slots[2];
+  uint64_t busy_rounds[2];
 } sthip_stats;
 int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out);
 

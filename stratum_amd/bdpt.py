@@ -125,7 +125,7 @@ class BDPT:
     def stats(self):
         s = wire.Stats()
         self._check(self._lib.sthip_get_stats(self._h, C.byref(s)), "sthip_get_stats")
-        return {f: getattr(s, f) for f, _ in wire.Stats._fields_}
+        return {f: (list(getattr(s, f)) if hasattr(getattr(s, f), "__len__") else getattr(s, f)) for f, _ in wire.Stats._fields_}
 
     def push_constants(self, frame):
         pc = wire.BDPTPushConstants.from_buffer_copy(self.mPushConstants)

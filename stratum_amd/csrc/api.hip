@@ -85,6 +85,7 @@ struct sthip_ctx {
   bool count_traversal = false, time_kernels = false;
   uint32_t refill_idle = 16, inner_min_lanes = 24, trace_blocks_per_cu = 0;
   uint64_t max_paths_in_flight = 1ull << 22;
+  bool fuse_trace = true;  // closest-hit rays of a bounce and the shadow rays of the previous one in one launch
   int bvh_builder = 0;  // sthip::BvhBuilderKind
   sthip_stats stats{};
   bool stats_pending = false;  // ray / traversal counters of the last render still live on the device
@@ -108,6 +109,12 @@ static void fill_counter_stats(sthip_ctx* ctx, const unsigned long long* c) {
   ctx->stats.tris_tested = c[CNT_TRIS];
   ctx->stats.nodes_visited_shadow = c[CNT_NODES + 1];
   ctx->stats.tris_tested_shadow = c[CNT_TRIS + 1];
+  for (int k = 0; k < 2; k++) {
+    ctx->stats.inner_slots[k] = c[CNT_INNER_SLOTS + k];
+    ctx->stats.tri_slots[k] = c[CNT_TRI_SLOTS + k];
+    ctx->stats.round_slots[k] = c[CNT_ROUND_SLOTS + k];
+    ctx->stats.busy_rounds[k] = c[CNT_BUSY_ROUNDS + k];
+  }
 }
 
 static int fail(sthip_ctx* ctx, int code, const std::string& msg) {
@@ -221,6 +228,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->count_traversal = value != 0;
   else if (!strcmp(name, "time_kernels"))
     ctx->time_kernels = value != 0;
+  else if (!strcmp(name, "fuse_trace"))
+    ctx->fuse_trace = value != 0;
   else if (!strcmp(name, "refill_idle"))
     ctx->refill_idle = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
   else if (!strcmp(name, "bvh_builder"))
@@ -389,7 +398,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->has_scene = true;
   if (getenv("STHIP_VERBOSE")) {
     int per_cu = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false>, STHIP_BLOCK, stack_bytes(ctx));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, STHIP_BLOCK, stack_bytes(ctx));
     fprintf(stderr, "[sthip] bvh (%s): %zu nodes, %zu tris, %zu top-level entries, stack depth %u (%zu B LDS / block), %d trace blocks / CU, build %.1f ms (GPU kernels %.2f ms)\n",
             ctx->bvh_builder ? "lbvh/gpu" : "sah/host", built.nodes.size(), built.tris.size(), built.entries.size(), built.stack_depth, stack_bytes(ctx), per_cu, ctx->stats.bvh_build_ms,
             ctx->stats.bvh_build_gpu_ms);
@@ -408,7 +417,7 @@ static uint32_t grid_for(const sthip_ctx* ctx, size_t n) {
 // Persistent trace kernels: as many blocks as are resident at once (LDS stack and VGPRs bound it).
 static uint32_t trace_grid(sthip_ctx* ctx, size_t lds_bytes) {
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false>, STHIP_BLOCK, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, STHIP_BLOCK, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
   if (ctx->trace_blocks_per_cu) per_cu = (int)ctx->trace_blocks_per_cu;
   return (uint32_t)(ctx->cu_count * per_cu);
 }
@@ -654,8 +663,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (!ctx->has_specular) max_bounce_rounds = std::min(max_bounce_rounds, pc->gMaxDiffuseVertices + 1);
   p.rounds = max_bounce_rounds;
   const bool timing = ctx->time_kernels;
-  float ms_closest = 0, ms_shadow = 0, ms_shade = 0, ms_other = 0;
-  uint32_t launches_closest = 0, launches_shadow = 0;
+  float ms_trace = 0, ms_shade = 0, ms_other = 0;
+  uint32_t launches_trace = 0;
   auto timed = [&](float& acc, auto&& launch) -> int {
     if (timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     launch();
@@ -685,15 +694,32 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     }
     int rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(STHIP_BLOCK), 0, st, p); });
     if (rc) return rc;
-    for (uint32_t depth = 0; depth < max_bounce_rounds; depth++) {
-      rc = timed(ms_closest, [&]() {
+    // Round r traces the paths entering bounce r together with the shadow rays bounce r - 1 produced (one launch,
+    // k_trace), then shades bounce r; a last launch traces the shadow rays of the last bounce.
+    const bool nee = (sampling_flags & (1u << STHIP_eNEE)) != 0;
+    auto trace = [&](uint32_t dc, uint32_t ds) -> int {
+      if (dc == TRACE_NONE && ds == TRACE_NONE) return STHIP_OK;
+      launches_trace++;
+      return timed(ms_trace, [&]() {
         if (ctx->count_traversal)
-          hipLaunchKernelGGL((k_trace_closest<true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, depth);
+          hipLaunchKernelGGL((k_trace<true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
         else
-          hipLaunchKernelGGL((k_trace_closest<false>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, depth);
+          hipLaunchKernelGGL((k_trace<false>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
       });
-      if (rc) return rc;
-      launches_closest++;
+    };
+    for (uint32_t depth = 0; depth <= max_bounce_rounds; depth++) {
+      const uint32_t dc = depth < max_bounce_rounds ? depth : TRACE_NONE;
+      const uint32_t ds = depth >= 1 && nee ? depth - 1 : TRACE_NONE;
+      if (ctx->fuse_trace) {
+        rc = trace(dc, ds);
+        if (rc) return rc;
+      } else {  // analysis: the two ray kinds in launches of their own
+        rc = trace(TRACE_NONE, ds);
+        if (rc) return rc;
+        rc = trace(dc, TRACE_NONE);
+        if (rc) return rc;
+      }
+      if (dc == TRACE_NONE) break;
       rc = timed(ms_shade, [&]() {
         if (ctx->textured)
           hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
@@ -701,31 +727,6 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
           hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
       });
       if (rc) return rc;
-      bool last_round = false;
-      if (timing) {
-        // per-kernel timing synchronises anyway: stop at the first empty round so that launch
-        // statistics only cover launches that had rays (untimed runs enqueue every round blindly)
-        unsigned long long nq[2] = {0, 0}, lines[2][QUEUE_SEGMENTS * QCTL_STRIDE];
-        HIP_TRY(ctx, hipMemcpy(lines[0], queue_ctl_host(ctx->qctl.p, 0, depth + 1), sizeof(lines[0]), hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(lines[1], queue_ctl_host(ctx->qctl.p, 1, depth), sizeof(lines[1]), hipMemcpyDeviceToHost));
-        for (uint32_t g = 0; g < QUEUE_SEGMENTS; g++) {
-          nq[0] += lines[0][g * QCTL_STRIDE + QCTL_SIZE];
-          nq[1] += lines[1][g * QCTL_STRIDE + QCTL_SIZE];
-        }
-        last_round = nq[0] == 0;
-        if (nq[1] == 0 && last_round) break;
-      }
-      if (sampling_flags & (1u << STHIP_eNEE)) {
-        rc = timed(ms_shadow, [&]() {
-          if (ctx->count_traversal)
-            hipLaunchKernelGGL((k_trace_shadow<true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, depth);
-          else
-            hipLaunchKernelGGL((k_trace_shadow<false>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, depth);
-        });
-        if (rc) return rc;
-        launches_shadow++;
-      }
-      if (last_round) break;
     }
     rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + in_flight == seed_count ? 1u : 0u, primary_rays * in_flight); });
     if (rc) return rc;
@@ -751,12 +752,10 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     ctx->stats_pending = true;
   }
   if (timing) {
-    ctx->stats.ms_trace_closest = ms_closest;
-    ctx->stats.ms_trace_shadow = ms_shadow;
+    ctx->stats.ms_trace = ms_trace;
     ctx->stats.ms_shade = ms_shade;
-    ctx->stats.ms_total = ms_closest + ms_shadow + ms_shade + ms_other;
-    ctx->stats.launches_trace_closest = launches_closest;
-    ctx->stats.launches_trace_shadow = launches_shadow;
+    ctx->stats.ms_total = ms_trace + ms_shade + ms_other;
+    ctx->stats.launches_trace = launches_trace;
   }
   return STHIP_OK;
 }

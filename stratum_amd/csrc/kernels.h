@@ -22,7 +22,11 @@ enum {
   CNT_RAYS_SHADOW = 1,
   CNT_NODES = 2,  // +1: shadow rays
   CNT_TRIS = 4,   // +1: shadow rays
-  CNT_TOTAL = 8
+  CNT_INNER_SLOTS = 6,  // +1: shadow rays
+  CNT_TRI_SLOTS = 8,    // +1: shadow rays
+  CNT_ROUND_SLOTS = 10, // +1: shadow rays: 64 per round of a persistent wave
+  CNT_BUSY_ROUNDS = 12, // +1: shadow rays: lanes holding a ray, summed over rounds
+  CNT_TOTAL = 16
 };
 
 struct FrameParams {
@@ -196,91 +200,90 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
 // ---------------------------------------------------------------------------------------------
 
 
+#define TRACE_NONE 0xFFFFFFFFu
+// One persistent kernel serves both ray kinds. A wave first feeds its idle lanes from the path queue of bounce
+// `depth_closest` (trace_ray, intersection.hlsli:65-191) and, once that queue is dry, from the shadow-ray queue of
+// bounce `depth_shadow` (trace_visibility_ray without media, intersection.hlsli:192-239, and the per-pixel sum of
+// trace_shadows, bdpt.hlsl:311-325) — the two are independent, and the shadow rays of the previous bounce fill the
+// lanes that would otherwise idle while the last, longest closest-hit rays of a launch finish. Either depth may be
+// TRACE_NONE.
 template <bool COUNT>
-__global__ void __launch_bounds__(STHIP_BLOCK) k_trace_closest(FrameParams p, uint32_t depth) {
+__global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t depth_closest, uint32_t depth_shadow) {
   extern __shared__ uint32_t lds_stack[];
-  const uint32_t n = p.path_count;              // first bounce: every slot, no queue
-  const uint32_t stride = depth == 0 ? 0u : p.seg_stride;
-  const uint32_t* queue = p.queue[depth & 1u];
-  unsigned long long* ctl = queue_ctl(p.qctl, 0, depth, 0);
+  const bool first = depth_closest == 0;        // first bounce: every slot, no queue
+  const uint32_t* queue = p.queue[depth_closest & 1u];
+  unsigned long long* ctl_c = queue_ctl(p.qctl, 0, depth_closest == TRACE_NONE ? 0u : depth_closest, 0);
+  unsigned long long* ctl_s = queue_ctl(p.qctl, 1, depth_shadow == TRACE_NONE ? 0u : depth_shadow, 0);
   uint32_t* stack = lds_stack + threadIdx.x;
-  TraverseCounters cnt;
-  cnt.nodes = cnt.tris = 0;
-  Traversal<false, COUNT, STHIP_BLOCK> tr;
+  float4* target = flag(p, STHIP_eDeferShadowRays) ? p.shadow_sum : p.radiance;
+  TraverseCounters cnt[2];
+  cnt[0].clear();
+  cnt[1].clear();
+  uint32_t round_slots[2] = {0, 0}, busy_rounds[2] = {0, 0};
+  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK> tr;
   tr.reset();
-  WaveWork work;
-  work.init();
+  tr.any = false;
+  WaveWork work_c, work_s;
+  work_c.init();
+  work_s.init();
+  work_c.exhausted = depth_closest == TRACE_NONE;
+  work_s.exhausted = depth_shadow == TRACE_NONE;
   uint32_t slot = 0;
-  bool busy = false;  // this lane holds a ray whose hit is not stored yet
+  f3 contribution = F3s(0.0f);
+  bool busy = false;  // this lane holds a ray whose result is not stored yet
   for (;;) {
     const unsigned long long idle = __ballot(!busy);
     if ((uint32_t)__popcll(idle) >= p.refill_idle || idle == ~0ull) {
-      const uint32_t idx = work.take(!busy, ctl, stride, n);
-      if (idx != 0xFFFFFFFFu) {
-        slot = depth == 0 ? idx : queue[idx];
-        if (depth == 0 && p.meta[slot] >= 0xFFFFFFFEu) {
-          p.hit[slot] = make_float4(__builtin_inff(), 0, 0, __uint_as_float(0xFFFFFFFFu));
-        } else {
-          const float4 ro = p.ray_o[slot], rd = p.ray_d[slot];
-          tr.start(p.bvh, stack, xyz(ro), xyz(rd), 0.0f, __builtin_inff());
+      if (!work_c.exhausted) {
+        const uint32_t idx = work_c.take(!busy, ctl_c, first ? 0u : p.seg_stride, p.path_count);
+        if (idx != 0xFFFFFFFFu) {
+          slot = first ? idx : queue[idx];
+          if (first && p.meta[slot] >= 0xFFFFFFFEu) {
+            p.hit[slot] = make_float4(__builtin_inff(), 0, 0, __uint_as_float(0xFFFFFFFFu));
+          } else {
+            const float4 ro = p.ray_o[slot], rd = p.ray_d[slot];
+            tr.any = false;
+            tr.start(p.bvh, stack, xyz(ro), xyz(rd), 0.0f, __builtin_inff());
+            busy = true;
+          }
+        }
+      }
+      if (work_c.exhausted && !work_s.exhausted) {
+        const uint32_t idx = work_s.take(!busy, ctl_s, p.seg_stride, 0);
+        if (idx != 0xFFFFFFFFu) {
+          const float4 s0 = p.shadow_rays[3 * (size_t)idx], s1 = p.shadow_rays[3 * (size_t)idx + 1], s2 = p.shadow_rays[3 * (size_t)idx + 2];
+          slot = __float_as_uint(s1.w);
+          contribution = xyz(s2);
+          tr.any = true;
+          tr.start(p.bvh, stack, xyz(s0), xyz(s1), 0.0f, s0.w);
           busy = true;
         }
       }
       if (!__any(busy)) {
-        if (work.exhausted) break;
+        if (work_c.exhausted && work_s.exhausted) break;
         continue;
       }
     }
-    tr.round(p.bvh, stack, p.inner_min_lanes, cnt);
-    if (busy && !tr.active()) {
-      p.hit[slot] = make_float4(tr.hit.t, tr.hit.b1, tr.hit.b2, __uint_as_float(tr.hit.ip));
-      busy = false;
+    if (COUNT) {
+      // a round belongs to the kind most of the wave is working on (the kinds only mix while the path queue drains)
+      const uint32_t k = work_c.exhausted && (uint32_t)__popcll(__ballot(busy && tr.any)) * 2u >= (uint32_t)__popcll(__ballot(busy)) ? 1u : 0u;
+      if ((threadIdx.x & 63u) == 0) round_slots[k] += 64;
+      if (busy) busy_rounds[k]++;
+      const uint32_t n0 = cnt[k].inner_slots, t0 = cnt[k].tri_slots;
+      TraverseCounters c;
+      c.clear();
+      tr.round(p.bvh, stack, p.inner_min_lanes, c);
+      cnt[tr.any ? 1 : 0].nodes += c.nodes;
+      cnt[tr.any ? 1 : 0].tris += c.tris;
+      cnt[k].inner_slots = n0 + c.inner_slots;
+      cnt[k].tri_slots = t0 + c.tri_slots;
+    } else {
+      tr.round(p.bvh, stack, p.inner_min_lanes, cnt[0]);
     }
-  }
-  if (COUNT) {
-    wave_add(&p.counters[CNT_NODES], cnt.nodes);
-    wave_add(&p.counters[CNT_TRIS], cnt.tris);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// trace_shadow: trace_visibility_ray without media (intersection.hlsli:192-239) + the per-pixel sum
-// of trace_shadows (bdpt.hlsl:311-325). Same persistent scheme.
-// ---------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uint32_t depth) {
-  extern __shared__ uint32_t lds_stack[];
-  unsigned long long* ctl = queue_ctl(p.qctl, 1, depth, 0);
-  uint32_t* stack = lds_stack + threadIdx.x;
-  TraverseCounters cnt;
-  cnt.nodes = cnt.tris = 0;
-  float4* target = flag(p, STHIP_eDeferShadowRays) ? p.shadow_sum : p.radiance;
-  Traversal<true, COUNT, STHIP_BLOCK> tr;
-  tr.reset();
-  WaveWork work;
-  work.init();
-  uint32_t slot = 0;
-  f3 contribution = F3s(0.0f);
-  bool busy = false;
-  for (;;) {
-    const unsigned long long idle = __ballot(!busy);
-    if ((uint32_t)__popcll(idle) >= p.refill_idle || idle == ~0ull) {
-      const uint32_t idx = work.take(!busy, ctl, p.seg_stride, 0);
-      if (idx != 0xFFFFFFFFu) {
-        const float4 s0 = p.shadow_rays[3 * (size_t)idx], s1 = p.shadow_rays[3 * (size_t)idx + 1], s2 = p.shadow_rays[3 * (size_t)idx + 2];
-        slot = __float_as_uint(s1.w);
-        contribution = xyz(s2);
-        tr.start(p.bvh, stack, xyz(s0), xyz(s1), 0.0f, s0.w);
-        busy = true;
-      }
-      if (!__any(busy)) {
-        if (work.exhausted) break;
-        continue;
-      }
-    }
-    tr.round(p.bvh, stack, p.inner_min_lanes, cnt);
     if (busy && !tr.active()) {
-      if (tr.hit.ip == 0xFFFFFFFFu) {  // unoccluded: each pixel has at most one shadow ray per bounce
+      if (!tr.any) {
+        p.hit[slot] = make_float4(tr.hit.t, tr.hit.b1, tr.hit.b2, __uint_as_float(tr.hit.ip));
+      } else if (tr.hit.ip == 0xFFFFFFFFu) {  // unoccluded: each pixel has at most one shadow ray per bounce
         float4 c = target[slot];
         c.x = c.x + contribution.x;
         c.y = c.y + contribution.y;
@@ -291,8 +294,14 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_shadow(FrameParams p, uin
     }
   }
   if (COUNT) {
-    wave_add(&p.counters[CNT_NODES + 1], cnt.nodes);
-    wave_add(&p.counters[CNT_TRIS + 1], cnt.tris);
+    for (uint32_t k = 0; k < 2; k++) {
+      wave_add(&p.counters[CNT_NODES + k], cnt[k].nodes);
+      wave_add(&p.counters[CNT_TRIS + k], cnt[k].tris);
+      wave_add(&p.counters[CNT_INNER_SLOTS + k], cnt[k].inner_slots);
+      wave_add(&p.counters[CNT_TRI_SLOTS + k], cnt[k].tri_slots);
+      wave_add(&p.counters[CNT_ROUND_SLOTS + k], round_slots[k]);
+      wave_add(&p.counters[CNT_BUSY_ROUNDS + k], busy_rounds[k]);
+    }
   }
 }
 
@@ -651,12 +660,12 @@ template <bool ANY_HIT, bool COUNT>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_batch(DeviceBvh bvh, const sthip_ray* rays, uint32_t n, sthip_hit* hits, unsigned long long* counters) {
   extern __shared__ uint32_t lds_stack[];
   TraverseCounters cnt;
-  cnt.nodes = cnt.tris = 0;
+  cnt.clear();
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float4* r = reinterpret_cast<const float4*>(rays + i);
     const float4 a = r[0], b = r[1];
     RayHit h;
-    traverse<ANY_HIT, COUNT, STHIP_BLOCK>(bvh, xyz(a), xyz(b), a.w, b.w, lds_stack + threadIdx.x, h, cnt);
+    traverse<ANY_HIT ? TRAV_ANY : TRAV_CLOSEST, COUNT, STHIP_BLOCK>(bvh, xyz(a), xyz(b), a.w, b.w, lds_stack + threadIdx.x, h, cnt);
     sthip_hit out;
     out.t = h.t;
     out.b1 = h.b1;

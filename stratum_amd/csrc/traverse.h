@@ -34,9 +34,14 @@ struct RayHit {
   uint32_t ip;  // instance | primitive << 16; 0xFFFFFFFF = miss
 };
 
+// Diagnostics of the COUNT instantiations. *_slots count 64 per wave-level iteration (added by the first active
+// lane), so nodes / inner_slots and tris / tri_slots are the lane utilisations of the two loops.
 struct TraverseCounters {
   uint32_t nodes, tris;
+  uint32_t inner_slots, tri_slots;
+  DEV void clear() { nodes = tris = inner_slots = tri_slots = 0; }
 };
+DEV bool first_active_lane() { return (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1); }
 
 // per-space ray constants
 struct RaySpace {
@@ -132,8 +137,14 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
 // holds a leaf, then the wave processes leaves together, so that the long triangle code is not executed
 // once per inner-node step of some other lane. The inner loop is kept minimal: no emptiness or
 // instance checks on pop (sentinels on the stack do that), one fma per slab plane, 32-bit offsets.
-template <bool ANY_HIT, bool COUNT, uint32_t STRIDE>
+// MODE: which kind of query the lanes run
+#define TRAV_CLOSEST 0  // closest hit
+#define TRAV_ANY 1      // occlusion: stop at the first accepted triangle (hit.ip = 0)
+#define TRAV_MIXED 2    // per lane, member `any` (the persistent kernel feeds closest-hit and shadow rays to one wave)
+template <int MODE, bool COUNT, uint32_t STRIDE>
 struct Traversal {
+  bool any;  // TRAV_MIXED only
+  DEV bool is_any() const { return MODE == TRAV_ANY || (MODE == TRAV_MIXED && any); }
   f3 o, d;  // world-space ray
   float tmin, tmax;
   RaySpace sp;  // the space currently being traversed (world, or the object space of an instance)
@@ -173,8 +184,11 @@ struct Traversal {
       const float4* n = reinterpret_cast<const float4*>(base + ((size_t)ref << 6));
       const float4 n0 = n[0], n1 = n[1], nz = n[2];
       const uint2 cr = *reinterpret_cast<const uint2*>(n + 3);
-      if (COUNT) cnt.nodes++;
-      const float tbest = ANY_HIT ? tmax : hit.t;
+      if (COUNT) {
+        cnt.nodes++;
+        if (first_active_lane()) cnt.inner_slots += 64;
+      }
+      const float tbest = hit.t;  // an occlusion lane stops at its first hit, so for it hit.t stays tmax
       const float a0x = fmaf(n0.x, sp.idir.x, sp.noodL.x), b0x = fmaf(n0.y, sp.idir.x, sp.noodH.x);
       const float a0y = fmaf(n0.z, sp.idir.y, sp.noodL.y), b0y = fmaf(n0.w, sp.idir.y, sp.noodH.y);
       const float a0z = fmaf(nz.x, sp.idir.z, sp.noodL.z), b0z = fmaf(nz.y, sp.idir.z, sp.noodH.z);
@@ -235,10 +249,13 @@ struct Traversal {
     for (uint32_t i = 0; i < count; i++) {
       const float4* tv = reinterpret_cast<const float4*>(tbase + (size_t)((first + i) * 48u));
       const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
-      if (COUNT) cnt.tris++;
+      if (COUNT) {
+        cnt.tris++;
+        if (first_active_lane()) cnt.tri_slots += 64;
+      }
       float t, b1, b2;
       if (tri_test(sp, xyz(v0), xyz(v1), xyz(v2), tmin, tmax, t, b1, b2)) {
-        if (ANY_HIT) {
+        if (is_any()) {
           hit.ip = 0;
           ref = TRAV_DONE;
           return;
@@ -264,9 +281,10 @@ struct Traversal {
 
 // One ray to completion (ray batches, tests). Returns true if something was hit; ANY_HIT stops at the
 // first accepted triangle (hit.ip = 0). `stack` points at this lane's column of the LDS stack.
-template <bool ANY_HIT, bool COUNT, uint32_t STRIDE>
+template <int MODE, bool COUNT, uint32_t STRIDE>
 DEV bool traverse(const DeviceBvh& bvh, f3 o, f3 d, float tmin, float tmax, uint32_t* stack, RayHit& hit, TraverseCounters& cnt) {
-  Traversal<ANY_HIT, COUNT, STRIDE> tr;
+  Traversal<MODE, COUNT, STRIDE> tr;
+  tr.any = MODE == TRAV_ANY;
   tr.start(bvh, stack, o, d, tmin, tmax);
   while (tr.active()) tr.round(bvh, stack, 1, cnt);
   hit = tr.hit;

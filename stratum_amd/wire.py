@@ -190,18 +190,20 @@ class Stats(C.Structure):
         ("tris_tested", C.c_uint64),
         ("nodes_visited_shadow", C.c_uint64),
         ("tris_tested_shadow", C.c_uint64),
-        ("ms_trace_closest", C.c_float),
-        ("ms_trace_shadow", C.c_float),
+        ("ms_trace", C.c_float),
         ("ms_shade", C.c_float),
         ("ms_total", C.c_float),
-        ("launches_trace_closest", C.c_uint32),
-        ("launches_trace_shadow", C.c_uint32),
+        ("launches_trace", C.c_uint32),
         ("bvh_node_bytes", C.c_uint32),
         ("bvh_tri_bytes", C.c_uint32),
         ("bvh_nodes", C.c_uint64),
         ("bvh_tris", C.c_uint64),
         ("bvh_build_ms", C.c_float),
         ("bvh_build_gpu_ms", C.c_float),
+        ("inner_slots", C.c_uint64 * 2),
+        ("tri_slots", C.c_uint64 * 2),
+        ("round_slots", C.c_uint64 * 2),
+        ("busy_rounds", C.c_uint64 * 2),
     ]
 
 

@@ -20,6 +20,8 @@ print("rel-L2 %.3e" % (np.sqrt(((a-b)**2).sum())/np.sqrt((b**2).sum())), "bit-di
 
 fr4 = camera.Frame(3840, 2160, cam["fovy"], cam["eye"], cam["target"])
 rad = torch.zeros((2160,3840,4), device="cuda"); out={"radiance": rad.data_ptr()}
+import os
+if os.environ.get("STHIP_FUSE_TRACE"): r.set_option("fuse_trace", int(os.environ["STHIP_FUSE_TRACE"]))
 for i in range(2): r.render(fr4, i, 1, device_outputs=out)
 torch.cuda.synchronize(); t=time.time()
 for i in range(4): r.render(fr4, 2+i, 1, device_outputs=out)
