@@ -68,6 +68,12 @@ typedef struct sthip_scene_desc {
    * anisotropy, which hardware-defined filtering cannot be restated). May be NULL / 0. */
   const struct sthip_image_desc* gImages;
   uint32_t image_count;
+  /* StructuredBuffer<float> gDistributions (bdpt.hlsl:27): the concatenated distribution tables
+   * MaterialResources::get_index(Buffer::View<float>) hands out offsets into (image_value.h:56-66, Scene.cpp:670-683);
+   * here the four tables of the environment map (environment.h:17-22, built by dist2.h build_distributions).
+   * May be NULL / 0. */
+  const float* gDistributions;
+  uint32_t distribution_count;
 } sthip_scene_desc;
 
 /* gFrameParams view arrays (bdpt.hlsl:37-43), filled by BDPT::render (BDPT.cpp:444-467).

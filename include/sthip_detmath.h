@@ -36,6 +36,8 @@ STHIP_HD float det_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); retur
 #define DET_PI 3.14159274101257324f       /* (float)M_PI */
 #define DET_2PI 6.28318548202514648f      /* (float)(2*M_PI) */
 #define DET_INV_PI 0.318309873342514038f  /* (float)(1/M_PI) */
+#define DET_2PI2 19.7392082214355469f     /* (float)(2*M_PI*M_PI), environment.h:73,92 */
+#define DET_INV_4PI 0.0795774683356285095f /* (float)(1/(4*M_PI)), common.h:153 */
 
 /* sin and cos of x (|x| up to a few thousand), ~1-2 ulp.
  * Cody-Waite reduction by pi/2 in three fmaf steps, Cephes sinf/cosf kernels. */
@@ -114,6 +116,65 @@ STHIP_HD float det_expf(float x) {
 
 /* pow(a, b) for a > 0 */
 STHIP_HD float det_powf(float a, float b) { return det_expf(b * det_logf(a)); }
+
+/* atan(x), Cephes atanf: range reduction at tan(pi/8), tan(3pi/8) */
+STHIP_HD float det_atanf(float xx) {
+  float x = fabsf(xx), y;
+  if (x > 2.414213562373095f) {
+    y = 1.5707963267948966192f;
+    x = -(1.0f / x);
+  } else if (x > 0.4142135623730950f) {
+    y = 0.7853981633974483096f;
+    x = (x - 1.0f) / (x + 1.0f);
+  } else {
+    y = 0.0f;
+  }
+  const float z = x * x;
+  float p = 8.05374449538e-2f;
+  p = p * z - 1.38776856032e-1f;
+  p = p * z + 1.99777106478e-1f;
+  p = p * z - 3.33329491539e-1f;
+  y = y + (p * z * x + x);
+  return xx < 0.0f ? -y : y;
+}
+
+/* atan2(y, x) as the reference's stable_atan2 uses it (common.h:134-136): x == 0 is decided by the caller's
+ * rule (y == 0 -> 0, else +-pi/2), everything else goes through atan(y / x) and the quadrant */
+STHIP_HD float det_atan2f(float y, float x) {
+  if (x == 0.0f) return y == 0.0f ? 0.0f : (y < 0.0f ? -1.5707963267948966192f : 1.5707963267948966192f);
+  if (y == 0.0f) return x < 0.0f ? DET_PI : 0.0f;
+  const float z = det_atanf(y / x);
+  if (x > 0.0f) return z;
+  return y < 0.0f ? z - DET_PI : z + DET_PI;
+}
+
+/* asin / acos on [-1, 1], Cephes asinf / acosf */
+STHIP_HD float det_asinf(float xx) {
+  const float a = fabsf(xx);
+  if (a < 1.0e-4f) return xx;
+  float x, z;
+  const int big = a > 0.5f;
+  if (big) {
+    z = 0.5f * (1.0f - a);
+    x = sqrtf(z);
+  } else {
+    x = a;
+    z = x * x;
+  }
+  float p = 4.2163199048e-2f;
+  p = p * z + 2.4181311049e-2f;
+  p = p * z + 4.5470025998e-2f;
+  p = p * z + 7.4953002686e-2f;
+  p = p * z + 1.6666752422e-1f;
+  float r = p * z * x + x;
+  if (big) r = 1.5707963267948966192f - (r + r);
+  return xx < 0.0f ? -r : r;
+}
+STHIP_HD float det_acosf(float x) {
+  if (x > 0.5f) return 2.0f * det_asinf(sqrtf(0.5f * (1.0f - x)));
+  if (x < -0.5f) return DET_PI - 2.0f * det_asinf(sqrtf(0.5f * (1.0f + x)));
+  return 1.5707963267948966192f - det_asinf(x);
+}
 
 /* pow(x, 5) as written by the reference's own pow5 (common.h:45-49): pow4(x)*x */
 STHIP_HD float det_pow5f(float x) {

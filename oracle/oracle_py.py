@@ -108,6 +108,23 @@ class OracleScene:
             raise RuntimeError("orc_trace_rays failed: %d" % rc)
         return hits, counters
 
+    def sample_light(self, push_constants, rnd4, ref_pos, sampling_flags=wire.DEFAULT_SAMPLING_FLAGS):
+        """sample_point_on_light (light.hlsli:37-152) -> dict of arrays"""
+        rnd4 = np.ascontiguousarray(rnd4, np.float32).reshape(-1, 4)
+        ref_pos = np.ascontiguousarray(np.broadcast_to(np.asarray(ref_pos, np.float32), (rnd4.shape[0], 3)))
+        out = np.zeros((rnd4.shape[0], 16), np.float32)
+        lib().orc_sample_light(C.c_void_p(self.h), C.byref(push_constants), C.c_uint32(sampling_flags), C.c_uint32(self.scene.scene_flags), wire.ptr(rnd4), wire.ptr(ref_pos), wire.ptr(out), C.c_uint32(rnd4.shape[0]))
+        return {
+            "radiance": out[:, 0:3],
+            "pdf": out[:, 3],
+            "to_light": out[:, 4:7],
+            "dist": out[:, 7],
+            "position": out[:, 8:11],
+            "normal": out[:, 11:14],
+            "pdf_area_measure": out[:, 14] != 0,
+            "is_environment": out[:, 15] != 0,
+        }
+
     def sample_image(self, index, uv_size, ray_cones=True):
         q = np.ascontiguousarray(uv_size, np.float32).reshape(-1, 3)
         out = np.zeros((q.shape[0], 4), np.float32)
@@ -172,6 +189,18 @@ def sincos(x):
 
 def log(x):
     return _map("orc_log", [np.ascontiguousarray(x, np.float32)], (), np.float32)
+
+
+def atan2(y, x):
+    return _map("orc_atan2", [np.ascontiguousarray(y, np.float32), np.ascontiguousarray(x, np.float32)], (), np.float32)
+
+
+def acos(x):
+    return _map("orc_acos", [np.ascontiguousarray(x, np.float32)], (), np.float32)
+
+
+def asin(x):
+    return _map("orc_asin", [np.ascontiguousarray(x, np.float32)], (), np.float32)
 
 
 def pow(a, b):

@@ -227,6 +227,7 @@ struct Inst {
   uint32_t index_stride() const { return bf_get(d.packed[1], 28, 4); }
   uint32_t first_vertex() const { return d.packed[2]; }
   uint32_t indices_byte_offset() const { return d.packed[3]; }
+  float radius() const { return det_u2f(d.packed[2]); }  // sphere instances, scene.h:43
 };
 
 struct Aabb {
@@ -412,6 +413,7 @@ struct orc_scene {
   std::vector<sthip_TransformData> xf, inv_xf, motion_xf;
   std::vector<uint8_t> materials;
   std::vector<uint32_t> lights;
+  std::vector<float> distributions;  // gDistributions (dist2.h tables of the environment map)
   std::vector<Mesh> meshes;
   std::vector<uint32_t> inst_mesh;
   std::vector<uint8_t> inst_identity;
@@ -561,9 +563,41 @@ inline void accept(Hit& h, float t, float b1, float b2, uint32_t ip) {
   }
 }
 
+// Sphere instances (intersection.hlsli:79-89 with ray_sphere, common.h:163-173), part of the traversal contract:
+// the ray goes to object space through Minv like a triangle ray, ray_sphere's arithmetic is taken as written
+// (products rounded separately), t is the near root if it lies beyond tmin, else the far root, and a hit needs
+// tmin < t < tmax. Its id is instance | INVALID_PRIMITIVE << 16; b1, b2 are 0.
+inline bool sphere_test(v3 o, v3 d, float r, float tmin, float tmax, float& t) {
+  const float a = dot(d, d);
+  const float b = dot(o, d);
+  const v3 l = V3(a * o.x - d.x * b, a * o.y - d.y * b, a * o.z - d.z * b);
+  float det = (a * r) * (a * r) - dot(l, l);
+  if (det < 0) return false;
+  const float inv_a = 1 / a;
+  det = sqrtf(det * inv_a) * inv_a;
+  const float e = (-b) * inv_a;
+  const float t0 = e - det, t1 = e + det;
+  if (!(t0 < t1)) return false;
+  const float tt = t0 > tmin ? t0 : t1;
+  if (!(tt > tmin && tt < tmax)) return false;
+  t = tt;
+  return true;
+}
+
 // one instance, object-space ray; returns true as soon as something is hit when any_hit
 bool trace_instance(const orc_scene& sc, uint32_t inst_index, const Ray& wr, Hit& h, bool any_hit, bool brute, uint64_t& n_nodes, uint64_t& n_tris) {
   const Inst& in = sc.instances[inst_index];
+  if (in.type() == STHIP_INSTANCE_TYPE_SPHERE) {
+    float t;
+    n_tris++;
+    if (!sphere_test(obj_point(sc.inv_xf[inst_index], wr.o), obj_vector(sc.inv_xf[inst_index], wr.d), in.radius(), wr.tmin, wr.tmax, t)) return false;
+    if (any_hit) {
+      h.ip = 0;
+      return true;
+    }
+    accept(h, t, 0.0f, 0.0f, inst_index | (STHIP_INVALID_PRIMITIVE << 16));
+    return false;
+  }
   if (in.type() != STHIP_INSTANCE_TYPE_TRIANGLES) return false;
   v3 o = wr.o, d = wr.d;
   if (!sc.inst_identity[inst_index]) {
@@ -753,6 +787,41 @@ void make_triangle_shading_data(const orc_scene& sc, ShadingData& r, uint32_t in
 // ---------------------------------------------------------------------------------------------
 // S3/M1-M4 — DisneyMaterial (materials/disney_material.hlsli, disney_*.hlsli, microfacet.h)
 // ---------------------------------------------------------------------------------------------
+// common.h:134-147
+inline void cartesian_to_spherical_uv(v3 v, float& u, float& vv) {
+  const float theta = det_atan2f(v.z, v.x);
+  u = theta * DET_INV_PI * .5f + .5f;
+  vv = det_acosf(fminf(fmaxf(v.y, -1.f), 1.f)) * DET_INV_PI;
+}
+inline v3 spherical_uv_to_cartesian(float u, float v) {
+  u = u * 2 - 1;
+  u *= DET_PI;
+  v *= DET_PI;
+  float su, cu, sv, cv;
+  det_sincosf(u, &su, &cu);
+  det_sincosf(v, &sv, &cv);
+  return V3(sv * cu, cv, sv * su);
+}
+
+// shading_data.hlsli:93-105 (the angles of dpdu / dpdv are the uv themselves, as the reference writes them)
+void make_sphere_shading_data(const orc_scene& sc, ShadingData& r, uint32_t inst_index, v3 local_position) {
+  const sthip_TransformData& t = sc.xf[inst_index];
+  const v3 normal = normalize(transform_vector(t, local_position));
+  r.position = transform_point(t, local_position);
+  r.packed_geometry_normal = r.packed_shading_normal = pack_normal_octahedron(normal);
+  const float radius = sc.instances[inst_index].radius();
+  r.shape_area = 4 * DET_PI * radius * radius;
+  r.mean_curvature = 1 / radius;
+  cartesian_to_spherical_uv(normalize(local_position), r.u, r.v);
+  float su, cu, sv, cv;
+  det_sincosf(r.u, &su, &cu);
+  det_sincosf(r.v, &sv, &cv);
+  const v3 dpdu = transform_vector(t, V3(-su * sv, 0, cu * sv));
+  const v3 dpdv = transform_vector(t, V3(cu * cv, -sv, su * cv));
+  r.packed_tangent = pack_normal_octahedron(normalize(dpdu - normal * dot(normal, dpdu)));
+  r.uv_screen_size = 1 / fmaxf(length(dpdu), length(dpdv));
+}
+
 struct MaterialEvalRecord {
   v3 f;
   float pdf_fwd, pdf_rev;
@@ -1136,6 +1205,104 @@ struct Frame {
   bool flag(int b) const { return (sampling_flags >> b) & 1u; }
 };
 
+// dist2.h:6-20 (upper_bound), :29-57 (dist2d_pdf / dist2d_sample) over gDistributions
+inline uint32_t dist_upper_bound(const std::vector<float>& data, uint32_t first, uint32_t last, float value) {
+  int count = (int)(last - first);
+  while (count > 0) {
+    uint32_t it = first;
+    const int step = count / 2;
+    it += (uint32_t)step;
+    if (value >= data[it]) {
+      first = ++it;
+      count -= step + 1;
+    } else
+      count = step;
+  }
+  return first;
+}
+inline int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+inline float dist2d_pdf(const std::vector<float>& data, uint32_t pdf_marginals, uint32_t pdf_rows, uint32_t w, uint32_t h, float u, float v) {
+  const int x = (int)fminf(fmaxf(u * (float)w, 0.0f), (float)(w - 1));
+  const int y = (int)fminf(fmaxf(v * (float)h, 0.0f), (float)(h - 1));
+  const float pdf_y = data[pdf_marginals + y];
+  const float pdf_x = data[pdf_rows + y * w + x];
+  return pdf_y * pdf_x * (float)w * (float)h;
+}
+inline void dist2d_sample(const std::vector<float>& data, uint32_t cdf_marginals, uint32_t cdf_rows, uint32_t w, uint32_t h, float rx, float ry, float& u, float& v) {
+  const uint32_t y_ptr = dist_upper_bound(data, cdf_marginals, cdf_marginals + h + 1, ry) - cdf_marginals;
+  const int y_offset = clampi((int)y_ptr - 1, 0, (int)h - 1);
+  float dy = ry - data[cdf_marginals + y_offset];
+  if ((data[cdf_marginals + y_offset + 1] - data[cdf_marginals + y_offset]) > 0) dy /= (data[cdf_marginals + y_offset + 1] - data[cdf_marginals + y_offset]);
+  const int row_offset = y_offset * ((int)w + 1);
+  const uint32_t x_ptr = dist_upper_bound(data, cdf_rows + row_offset, cdf_rows + row_offset + w + 1, rx) - cdf_rows;
+  const int x_offset = clampi((int)x_ptr - row_offset - 1, 0, (int)w - 1);
+  float dx = rx - data[cdf_rows + row_offset + x_offset];
+  if (data[cdf_rows + row_offset + x_offset + 1] - data[cdf_rows + row_offset + x_offset] > 0) dx /= (data[cdf_rows + row_offset + x_offset + 1] - data[cdf_rows + row_offset + x_offset]);
+  u = ((float)x_offset + dx) / (float)w;
+  v = ((float)y_offset + dy) / (float)h;
+}
+
+// environment.h:8-95. Record in gMaterialData: ImageValue3 (float3 value, uint image_index) and, when an image is
+// bound, the offsets of marginal_pdf, row_pdf, marginal_cdf, row_cdf in gDistributions (:17-22,37-45).
+// eSampleEnvironmentMapDirectly (sample_texel) is not restated.
+struct Environment {
+  v3 value;
+  uint32_t image_index;
+  uint32_t marginal_pdf, row_pdf, marginal_cdf, row_cdf;
+  const orc_scene* sc;
+  bool has_image() const { return image_index < sc->images.size(); }
+  void load(const orc_scene& scene, uint32_t address) {
+    sc = &scene;
+    float f[3];
+    memcpy(f, &scene.materials[address], 12);
+    value = V3(f[0], f[1], f[2]);
+    memcpy(&image_index, &scene.materials[address + 12], 4);
+    marginal_pdf = row_pdf = marginal_cdf = row_cdf = 0;
+    if (has_image()) {
+      uint32_t d[4];
+      memcpy(d, &scene.materials[address + 16], 16);
+      marginal_pdf = d[0];
+      row_pdf = d[1];
+      marginal_cdf = d[2];
+      row_cdf = d[3];
+    }
+  }
+  v3 lookup(float u, float v) const {
+    float c[4];
+    DisneyMaterial::sample_image(*sc, image_index, u, v, 0.0f, false, c);
+    return V3(c[0], c[1], c[2]);
+  }
+  v3 eval(v3 dir_out) const {
+    if (!has_image()) return value;
+    float u, v;
+    cartesian_to_spherical_uv(dir_out, u, v);
+    return lookup(u, v) * value;
+  }
+  v3 sample(float rx, float ry, v3& dir_out, float& pdf) const {
+    if (!has_image()) {
+      // sample_uniform_sphere's (phi, theta) go through spherical_uv_to_cartesian as if they were uv (as upstream)
+      dir_out = spherical_uv_to_cartesian(2 * DET_PI * ry, det_acosf(2 * rx - 1));
+      pdf = DET_INV_4PI;
+      return value;
+    }
+    const uint32_t w = sc->images[image_index].w[0], h = sc->images[image_index].h[0];
+    float u, v;
+    dist2d_sample(sc->distributions, marginal_cdf, row_cdf, w, h, rx, ry, u, v);
+    pdf = dist2d_pdf(sc->distributions, marginal_pdf, row_pdf, w, h, u, v);
+    dir_out = spherical_uv_to_cartesian(u, v);
+    pdf /= (DET_2PI2 * sqrtf(1 - dir_out.y * dir_out.y));
+    return value * lookup(u, v);
+  }
+  float eval_pdf(v3 dir_out) const {
+    if (!has_image()) return DET_INV_4PI;
+    float u, v;
+    cartesian_to_spherical_uv(dir_out, u, v);
+    const uint32_t w = sc->images[image_index].w[0], h = sc->images[image_index].h[0];
+    const float pdf = dist2d_pdf(sc->distributions, marginal_pdf, row_pdf, w, h, u, v);
+    return pdf / (DET_2PI2 * sqrtf(1 - dir_out.y * dir_out.y));
+  }
+};
+
 struct IntersectionVertex {
   ShadingData sd;
   uint32_t instance_primitive_index;
@@ -1157,9 +1324,26 @@ float trace_ray(const Frame& fr, v3 origin, v3 direction, float t_max, Intersect
     isect.instance_primitive_index = h.ip;
     if (accept_first) return h.t;  // occlusion query: nothing else is consumed (intersection.hlsli:198-233)
     const Inst& in = fr.sc->instances[isect.instance_index()];
-    make_triangle_shading_data(*fr.sc, isect.sd, isect.instance_index(), isect.primitive_index(), h.b1, h.b2, fr.flag(STHIP_eFlipTriangleUVs));
-    isect.shape_pdf = 1 / (isect.sd.shape_area * (float)in.prim_count());
-    isect.shape_pdf_area_measure = true;
+    if (in.type() == STHIP_INSTANCE_TYPE_SPHERE) {  // intersection.hlsli:140-159
+      const sthip_TransformData& inv = fr.sc->inv_xf[isect.instance_index()];
+      const v3 local_hit_pos = obj_point(inv, origin) + obj_vector(inv, direction) * h.t;
+      make_sphere_shading_data(*fr.sc, isect.sd, isect.instance_index(), local_hit_pos);
+      if (fr.flag(STHIP_eUniformSphereSampling)) {
+        isect.shape_pdf = 1 / isect.sd.shape_area;
+        isect.shape_pdf_area_measure = true;
+      } else {
+        const sthip_TransformData& t = fr.sc->xf[isect.instance_index()];
+        const v3 to_center = V3(t.m[0][3], t.m[1][3], t.m[2][3]) - origin;
+        const float sin_elevation_max_sq = pow2(in.radius()) / dot(to_center, to_center);
+        const float cos_elevation_max = sqrtf(fmaxf(0.0f, 1 - sin_elevation_max_sq));
+        isect.shape_pdf = 1 / (DET_2PI * (1 - cos_elevation_max));
+        isect.shape_pdf_area_measure = false;
+      }
+    } else {
+      make_triangle_shading_data(*fr.sc, isect.sd, isect.instance_index(), isect.primitive_index(), h.b1, h.b2, fr.flag(STHIP_eFlipTriangleUVs));
+      isect.shape_pdf = 1 / (isect.sd.shape_area * (float)in.prim_count());
+      isect.shape_pdf_area_measure = true;
+    }
     isect.sd.flags = 0;
     if (dot(direction, isect.sd.geometry_normal()) < 0) isect.sd.flags |= STHIP_SHADING_FLAG_FRONT_FACE;
     return h.t;
@@ -1173,43 +1357,141 @@ float trace_ray(const Frame& fr, v3 origin, v3 direction, float t_max, Intersect
   }
 }
 
-// light.hlsli:14-35,122-152 — emissive-triangle branch (uniform light choice; B4: power sampling is broken upstream)
+// light.hlsli:6-152 (uniform light choice; B4: power sampling is broken upstream)
 struct LightSampleRecord {
   v3 radiance;
   float pdf;
   bool pdf_area_measure;
+  bool is_environment;
   v3 to_light;
   float dist;
   v3 position;
   v3 normal;
 };
+inline bool has_environment(const Frame& fr) { return (fr.scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) != 0; }
+inline bool has_emissives(const Frame& fr) { return (fr.scene_flags & STHIP_BDPT_FLAG_HAS_EMISSIVES) != 0; }
 void sample_point_on_light(const Frame& fr, LightSampleRecord& ls, const float rnd[4], v3 ref_pos) {
   const orc_scene& sc = *fr.sc;
-  const int li = (int)(rnd[3] * ((float)fr.pc.gLightCount * .9999f));
+  ls.is_environment = false;
+  ls.radiance = V3(0.0f);
+  ls.position = ls.normal = V3(0.0f);
+  if (has_environment(fr) && (!has_emissives(fr) || rnd[3] <= fr.pc.gEnvironmentSampleProbability)) {
+    Environment env;
+    env.load(sc, fr.pc.gEnvironmentMaterialAddress);
+    ls.radiance = env.sample(rnd[0], rnd[1], ls.to_light, ls.pdf);
+    if (has_emissives(fr)) ls.pdf *= fr.pc.gEnvironmentSampleProbability;
+    ls.is_environment = true;
+    ls.dist = POS_INF;
+    ls.pdf_area_measure = false;
+    return;
+  }
+  if (!has_emissives(fr)) {
+    ls.pdf = 0;
+    ls.pdf_area_measure = true;
+    ls.to_light = V3(0.0f);
+    ls.dist = 0;
+    return;
+  }
+  const float rw = has_environment(fr) ? (rnd[3] - fr.pc.gEnvironmentSampleProbability) / (1 - fr.pc.gEnvironmentSampleProbability) : rnd[3];
+  const int li = (int)(rw * ((float)fr.pc.gLightCount * .9999f));
   ls.pdf = 1 / (float)fr.pc.gLightCount;
   const uint32_t light_instance_index = sc.lights[li];
+  if (has_environment(fr)) ls.pdf *= 1 - fr.pc.gEnvironmentSampleProbability;
   const Inst& in = sc.instances[light_instance_index];
-  const uint32_t pc = in.prim_count();
-  const uint32_t prim_index = (uint32_t)fminf(rnd[2] * (float)pc, (float)(pc - 1));
-  const float a = sqrtf(rnd[0]);
-  const float b1 = 1 - a, b2 = a * rnd[1];
-  ShadingData sd;
-  make_triangle_shading_data(sc, sd, light_instance_index, prim_index, b1, b2, fr.flag(STHIP_eFlipTriangleUVs));
-  ls.position = sd.position;
-  ls.normal = sd.geometry_normal();
-  ls.to_light = sd.position - ref_pos;
-  ls.dist = length(ls.to_light);
-  ls.to_light = ls.to_light / ls.dist;
-  ls.pdf /= sd.shape_area * (float)pc;
-  ls.pdf_area_measure = true;
-  ls.radiance = V3(0.0f);
+  float u, v;
+  if (in.type() == STHIP_INSTANCE_TYPE_SPHERE) {  // light.hlsli:58-121
+    const float r = in.radius();
+    const sthip_TransformData& t = sc.xf[light_instance_index];
+    if (fr.flag(STHIP_eUniformSphereSampling)) {
+      ls.pdf /= 4 * DET_PI * r * r;
+      ls.pdf_area_measure = true;
+      const float z = 1 - 2 * rnd[0];
+      const float r_ = sqrtf(fmaxf(0.0f, 1 - z * z));
+      const float phi = DET_2PI * rnd[1];
+      float sp, cp;
+      det_sincosf(phi, &sp, &cp);
+      const v3 local_normal = V3(r_ * cp, z, r_ * sp);
+      cartesian_to_spherical_uv(local_normal, u, v);
+      ls.position = transform_point(t, r * local_normal);
+      ls.normal = normalize(transform_vector(t, local_normal));
+      ls.to_light = ls.position - ref_pos;
+      ls.dist = length(ls.to_light);
+      ls.to_light = ls.to_light / ls.dist;
+    } else {
+      const v3 center = V3(t.m[0][3], t.m[1][3], t.m[2][3]);
+      v3 to_center = center - ref_pos;
+      const float dist = length(to_center);
+      to_center = to_center / dist;
+      const float sinThetaMax = r / dist;
+      const float sinThetaMax2 = sinThetaMax * sinThetaMax;
+      const float invSinThetaMax = 1 / sinThetaMax;
+      const float cosThetaMax = sqrtf(fmaxf(0.0f, 1 - sinThetaMax2));
+      ls.pdf /= DET_2PI * (1 - cosThetaMax);
+      ls.pdf_area_measure = false;
+      float cosTheta = (cosThetaMax - 1) * rnd[0] + 1;
+      float sinTheta2 = 1 - cosTheta * cosTheta;
+      if (sinThetaMax2 < 0.00068523f) {
+        sinTheta2 = sinThetaMax2 * rnd[0];
+        cosTheta = sqrtf(1 - sinTheta2);
+      }
+      const float cosAlpha = sinTheta2 * invSinThetaMax + cosTheta * sqrtf(fmaxf(0.0f, 1 - sinTheta2 * invSinThetaMax * invSinThetaMax));
+      const float sinAlpha = sqrtf(fmaxf(0.0f, 1 - cosAlpha * cosAlpha));
+      const float phi = rnd[1] * 2 * DET_PI;
+      float sp, cp;
+      det_sincosf(phi, &sp, &cp);
+      v3 T, B;
+      make_orthonormal(to_center, T, B);
+      ls.normal = -(T * sinAlpha * cp + B * sinAlpha * sp + to_center * cosAlpha);
+      ls.position = center + r * ls.normal;
+      ls.to_light = ls.position - ref_pos;
+      ls.dist = length(ls.to_light);
+      ls.to_light = ls.to_light / ls.dist;
+      const v3 local_normal = transform_vector(sc.inv_xf[light_instance_index], ls.normal);
+      cartesian_to_spherical_uv(local_normal, u, v);
+    }
+  } else {
+    const uint32_t pc = in.prim_count();
+    const uint32_t prim_index = (uint32_t)fminf(rnd[2] * (float)pc, (float)(pc - 1));
+    const float a = sqrtf(rnd[0]);
+    const float b1 = 1 - a, b2 = a * rnd[1];
+    ShadingData sd;
+    make_triangle_shading_data(sc, sd, light_instance_index, prim_index, b1, b2, fr.flag(STHIP_eFlipTriangleUVs));
+    u = sd.u;
+    v = sd.v;
+    ls.position = sd.position;
+    ls.normal = sd.geometry_normal();
+    ls.to_light = sd.position - ref_pos;
+    ls.dist = length(ls.to_light);
+    ls.to_light = ls.to_light / ls.dist;
+    ls.pdf /= sd.shape_area * (float)pc;
+    ls.pdf_area_measure = true;
+  }
   if (ls.pdf > 0) {
     DisneyMaterial m;
     // light.hlsli:143-150: only uv and uv_screen_size = 0 of the ShadingData are set for this lookup
-    uint32_t dummy_n = sd.packed_shading_normal, dummy_t = sd.packed_tangent;
-    m.load(sc, in.material_address(), sd.u, sd.v, 0.0f, dummy_n, dummy_t, fr.sampling_flags & ~(1u << STHIP_eNormalMaps));
+    uint32_t dummy_n = 0, dummy_t = 0;
+    m.load(sc, in.material_address(), u, v, 0.0f, dummy_n, dummy_t, fr.sampling_flags & ~(1u << STHIP_eNormalMaps));
     ls.radiance = m.Le();
   }
+}
+
+// light.hlsli:154-174
+inline float point_on_light_pdf(const Frame& fr, const IntersectionVertex& isect, v3 direction, bool& area_measure) {
+  if (isect.instance_index() == STHIP_INVALID_INSTANCE) {
+    area_measure = false;
+    if (!has_environment(fr)) return 0;
+    Environment env;
+    env.load(*fr.sc, fr.pc.gEnvironmentMaterialAddress);
+    float pdf = env.eval_pdf(direction);  // _isect.sd.position holds the ray direction on a miss (intersection.hlsli:183)
+    if (has_emissives(fr)) pdf *= fr.pc.gEnvironmentSampleProbability;
+    return pdf;
+  }
+  area_measure = isect.shape_pdf_area_measure;
+  if (!has_emissives(fr)) return 0;
+  float pdf = isect.shape_pdf;
+  pdf /= (float)fr.pc.gLightCount;
+  if (has_environment(fr)) pdf *= 1 - fr.pc.gEnvironmentSampleProbability;
+  return pdf;
 }
 
 // path.hlsli:8-15
@@ -1297,11 +1579,16 @@ struct PathIntegrator {
   void eval_emission(v3 Le) {
     if (all_le0(Le)) return;
     const v3 contrib = beta * Le;
-    const float cos_theta_light = -dot(isect.sd.geometry_normal(), direction);
-    if (cos_theta_light < 0) return;
-    // point_on_light_pdf, light.hlsli:154-174 (emissive branch, uniform light choice)
-    float light_pdfA = isect.shape_pdf;
-    light_pdfA /= (float)fr.pc.gLightCount;
+    float cos_theta_light;
+    if (isect.instance_index() == STHIP_INVALID_INSTANCE || isect.sd.shape_area == 0) {
+      cos_theta_light = 1;  // background
+    } else {
+      cos_theta_light = -dot(isect.sd.geometry_normal(), direction);
+      if (cos_theta_light < 0) return;
+    }
+    bool area_measure;
+    float light_pdfA = point_on_light_pdf(fr, isect, direction, area_measure);
+    if (!area_measure) light_pdfA = light_pdfA * G;  // pdfWtoA
     float weight = 1;
     if (path_length > 2) {
       if (fr.flag(STHIP_eNEE)) weight = mis2(fr, bsdf_pdf * G, light_pdfA);
@@ -1329,10 +1616,16 @@ struct PathIntegrator {
     LightSampleRecord ls;
     sample_point_on_light(fr, ls, rnd, isect.sd.position);
     v3 Le = ls.radiance;
-    const float pdfA = ls.pdf;
+    float pdfA = ls.pdf;
     v3 ray_direction = ls.to_light;
     float ray_distance = ls.dist;
-    float cG = fabsf(dot(ls.to_light, ls.normal)) / pow2(ls.dist);
+    float cG;
+    if (ls.is_environment) {  // sample_Le, path.hlsli:156-162
+      cG = 1;
+    } else {
+      cG = fabsf(dot(ls.to_light, ls.normal)) / pow2(ls.dist);
+      if (!ls.pdf_area_measure) pdfA = pdfA * cG;
+    }
     // setup()
     v3 ray_origin = isect.sd.position;
     const v3 local_to_light = normalize(isect.sd.to_local(ray_direction));
@@ -1432,6 +1725,11 @@ struct PathIntegrator {
   // path.hlsli:1048-1075
   void next_vertex() {
     if (isect.instance_index() == STHIP_INVALID_INSTANCE) {
+      if (has_environment(fr)) {
+        Environment env;
+        env.load(*fr.sc, fr.pc.gEnvironmentMaterialAddress);
+        eval_emission(env.eval(direction));
+      }
       beta = V3(0.0f);
       return;
     }
@@ -1544,6 +1842,11 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
       aov->prev_uv[0] = uvx;
       aov->prev_uv[1] = uvy;
     }
+    if (has_environment(fr)) {  // bdpt.hlsl:236-240
+      Environment env;
+      env.load(*fr.sc, fr.pc.gEnvironmentMaterialAddress);
+      path.eval_emission(env.eval(path.direction));
+    }
   } else {
     {
       DisneyMaterial m;
@@ -1649,6 +1952,7 @@ orc_scene* orc_scene_create(const sthip_scene_desc* d) {
   }
   sc->materials.assign((const uint8_t*)d->gMaterialData, (const uint8_t*)d->gMaterialData + d->material_bytes);
   if (d->gLightInstances) sc->lights.assign(d->gLightInstances, d->gLightInstances + d->light_count);
+  if (d->gDistributions) sc->distributions.assign(d->gDistributions, d->gDistributions + d->distribution_count);
   for (uint32_t i = 0; i < d->image_count && d->gImages; i++) {
     OrcImage im;
     uint32_t w = d->gImages[i].width, h = d->gImages[i].height;
@@ -1686,6 +1990,16 @@ orc_scene* orc_scene_create(const sthip_scene_desc* d) {
     const Inst& in = sc->instances[i];
     sc->inst_identity[i] = is_identity(sc->inv_xf[i]) ? 1 : 0;
     inst_boxes[i].reset();
+    if (in.type() == STHIP_INSTANCE_TYPE_SPHERE) {  // the sphere's world box, generously padded (sphere_test decides)
+      const float r = fabsf(in.radius());
+      for (int a = 0; a < 3; a++) {
+        const float c = sc->xf[i].m[a][3];
+        const float pad = 1e-3f * r + 1e-5f * fabsf(c);
+        inst_boxes[i].lo[a] = c - r - pad;
+        inst_boxes[i].hi[a] = c + r + pad;
+      }
+      continue;
+    }
     if (in.type() != STHIP_INSTANCE_TYPE_TRIANGLES) continue;
     auto key = std::make_tuple(in.first_vertex(), in.indices_byte_offset(), in.prim_count(), in.index_stride());
     auto it = mesh_of.find(key);
@@ -1736,10 +2050,12 @@ void orc_scene_destroy(orc_scene* sc) { delete sc; }
 int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin,
                uint32_t seed_count, const sthip_outputs* out, int threads, uint64_t* stats_out) {
   if (!sc || !pc || !frame || !out || !out->gRadiance || !frame->gViews || !frame->gViewTransforms) return STHIP_ERR_INVALID_ARGUMENT;
-  if (scene_flags & (STHIP_BDPT_FLAG_HAS_ENVIRONMENT | STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT)) return STHIP_ERR_UNSUPPORTED;
+  if (scene_flags & (STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT)) return STHIP_ERR_UNSUPPORTED;
+  if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
   const uint32_t unsupported = (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_ePresampleLights) | (1u << STHIP_eConnectToViews) |
                                (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
-                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eAlphaTest) | (1u << STHIP_eCoherentSampling);
+                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eAlphaTest) | (1u << STHIP_eCoherentSampling) |
+                               (1u << STHIP_eSampleEnvironmentMapDirectly);
   if (sampling_flags & unsupported) return STHIP_ERR_UNSUPPORTED;
   Frame fr;
   fr.sc = sc;
@@ -1747,7 +2063,11 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
   fr.sampling_flags = sampling_flags;
   fr.scene_flags = scene_flags;
   fr.fd = *frame;
-  if (!(scene_flags & STHIP_BDPT_FLAG_HAS_EMISSIVES) || pc->gLightCount == 0) fr.sampling_flags &= ~(1u << STHIP_eNEE);  // BDPT.cpp:504-509
+  // BDPT.cpp:488-509
+  if (pc->gLightCount == 0) fr.scene_flags &= ~STHIP_BDPT_FLAG_HAS_EMISSIVES;
+  if (!has_environment(fr)) fr.pc.gEnvironmentSampleProbability = 0;
+  if (!has_emissives(fr)) fr.pc.gEnvironmentSampleProbability = 1;
+  if (!has_emissives(fr) && !has_environment(fr)) fr.sampling_flags &= ~(1u << STHIP_eNEE);
   if (!(fr.sampling_flags & (1u << STHIP_eNEE))) fr.sampling_flags &= ~(1u << STHIP_eDeferShadowRays);                // BDPT.cpp:522-523
   if (fr.pc.gLightCount > sc->lights.size()) return STHIP_ERR_INVALID_ARGUMENT;
   const uint32_t W = pc->gOutputExtent[0], H = pc->gOutputExtent[1];
@@ -1874,6 +2194,34 @@ void orc_sincos(const float* x, float* s, float* c, uint32_t n) {
 }
 void orc_log(const float* x, float* out, uint32_t n) {
   for (uint32_t i = 0; i < n; i++) out[i] = det_logf(x[i]);
+}
+// sample_point_on_light for n (rnd4, ref_pos): out = radiance(3) pdf to_light(3) dist position(3) normal(3) area_measure is_environment
+void orc_sample_light(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const float* rnd4, const float* ref_pos, float* out16, uint32_t n) {
+  Frame fr;
+  fr.sc = sc;
+  fr.pc = *pc;
+  fr.sampling_flags = sampling_flags;
+  fr.scene_flags = scene_flags;
+  for (uint32_t i = 0; i < n; i++) {
+    LightSampleRecord ls;
+    sample_point_on_light(fr, ls, rnd4 + 4 * i, V3(ref_pos[3 * i], ref_pos[3 * i + 1], ref_pos[3 * i + 2]));
+    float* o = out16 + 16 * (size_t)i;
+    o[0] = ls.radiance.x, o[1] = ls.radiance.y, o[2] = ls.radiance.z, o[3] = ls.pdf;
+    o[4] = ls.to_light.x, o[5] = ls.to_light.y, o[6] = ls.to_light.z, o[7] = ls.dist;
+    o[8] = ls.position.x, o[9] = ls.position.y, o[10] = ls.position.z;
+    o[11] = ls.normal.x, o[12] = ls.normal.y, o[13] = ls.normal.z;
+    o[14] = ls.pdf_area_measure ? 1.0f : 0.0f;
+    o[15] = ls.is_environment ? 1.0f : 0.0f;
+  }
+}
+void orc_atan2(const float* y, const float* x, float* out, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) out[i] = det_atan2f(y[i], x[i]);
+}
+void orc_acos(const float* x, float* out, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) out[i] = det_acosf(x[i]);
+}
+void orc_asin(const float* x, float* out, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) out[i] = det_asinf(x[i]);
 }
 void orc_pow(const float* a, const float* b, float* out, uint32_t n) {
   for (uint32_t i = 0; i < n; i++) out[i] = det_powf(a[i], b[i]);

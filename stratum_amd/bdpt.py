@@ -133,8 +133,12 @@ class BDPT:
         pc.gViewCount = 1
         pc.gLightCount = self._scene.light_count
         pc.gLightPathCount = frame.width * frame.height  # BDPT.cpp:469-470
-        pc.gEnvironmentMaterialAddress = 0xFFFFFFFF
-        pc.gEnvironmentSampleProbability = 0.0
+        # BDPT.cpp:393,486-496
+        pc.gEnvironmentMaterialAddress = self._scene.environment_address
+        if self._scene.environment_address == 0xFFFFFFFF:
+            pc.gEnvironmentSampleProbability = 0.0
+        if pc.gLightCount == 0:
+            pc.gEnvironmentSampleProbability = 1.0
         pc.gMaxNullCollisions = 0
         return pc
 

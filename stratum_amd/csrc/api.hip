@@ -52,6 +52,10 @@ struct sthip_ctx {
   // scene
   bool has_scene = false;
   bool textured = false;      // some material binds an image: k_shade<true> (ray cones, image values, normal maps)
+  bool has_spheres = false;   // some instance is a sphere: k_shade<., true>
+  std::vector<uint8_t> materials_host;                    // gMaterialData as uploaded (validation of the environment record)
+  std::vector<std::pair<uint32_t, uint32_t>> image_dims;  // (width, height) of gImages
+  uint32_t distribution_count = 0;
   bool has_specular = false;  // some material satisfies DisneyMaterial::is_specular (disney_material.hlsli:125)
   DevBuf<sthip_PackedVertexData> vertices;
   DevBuf<uint8_t> indices;
@@ -74,6 +78,7 @@ struct sthip_ctx {
   DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays;
   DevBuf<uint32_t> meta, queue0, queue1;
   DevBuf<unsigned long long> counters;
+  DevBuf<float> distributions;  // gDistributions
   DevBuf<unsigned long long> qctl;  // queue control lines (queue_ctl)
   DevBuf<uint32_t> post_scratch;  // maxima / metric accumulator of post.h
   DevBuf<float4> out_radiance, out_albedo;
@@ -191,6 +196,7 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->queue0.release();
   ctx->queue1.release();
   ctx->counters.release();
+  ctx->distributions.release();
   ctx->qctl.release();
   ctx->post_scratch.release();
   ctx->out_radiance.release();
@@ -334,6 +340,16 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (s->light_count) HIP_TRY(ctx, hipMemcpy(ctx->lights.p, s->gLightInstances, (size_t)s->light_count * 4, hipMemcpyHostToDevice));
   ctx->instance_count = n;
   ctx->light_count = s->light_count;
+  ctx->materials_host.assign((const uint8_t*)s->gMaterialData, (const uint8_t*)s->gMaterialData + s->material_bytes);
+  ctx->has_spheres = false;
+  for (uint32_t i = 0; i < n; i++)
+    if ((s->gInstances[i].packed[0] & 0xF) == STHIP_INSTANCE_TYPE_SPHERE) ctx->has_spheres = true;
+  if (s->distribution_count && !s->gDistributions) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: distribution_count > 0 but gDistributions is NULL");
+  HIP_TRY(ctx, ctx->distributions.ensure(std::max<size_t>(1, s->distribution_count)));
+  if (s->distribution_count) HIP_TRY(ctx, hipMemcpy(ctx->distributions.p, s->gDistributions, (size_t)s->distribution_count * 4, hipMemcpyHostToDevice));
+  ctx->distribution_count = s->distribution_count;
+  ctx->image_dims.clear();
+  for (uint32_t i = 0; i < s->image_count; i++) ctx->image_dims.emplace_back(s->gImages[i].width, s->gImages[i].height);
   // images: mip chain by 2x2 box filter, level k+1 = max(1, floor(dim / 2)), ((a + b) + (c + d)) * 0.25
   {
     std::vector<DeviceImage> table(s->image_count);
@@ -479,21 +495,42 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (pc->gViewCount != frame->view_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: gViewCount != frame.view_count");
   if ((out->gDepth || out->gPrevUVs) && !frame->gInverseViewTransforms && !frame->gPrevInverseViewTransforms)
     return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: depth / prev-uv outputs need gInverseViewTransforms");
-  // Outside the built hot path: environment maps, media, light tracing, reservoirs, ...
-  if (scene_flags & (STHIP_BDPT_FLAG_HAS_ENVIRONMENT | STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT))
-    return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: environment / media / light-tracing scene flags are not part of the built hot path");
+  // Outside the built hot path: media, light tracing, reservoirs, ...
+  if (scene_flags & (STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT))
+    return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media / light-tracing scene flags are not part of the built hot path");
   const uint32_t unsupported = (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_ePresampleLights) | (1u << STHIP_eConnectToViews) |
                                (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
-                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eAlphaTest) | (1u << STHIP_eCoherentSampling);
+                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eAlphaTest) | (1u << STHIP_eCoherentSampling) |
+                               (1u << STHIP_eSampleEnvironmentMapDirectly);
   if (sampling_flags & unsupported) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: a sampling flag outside the built hot path is set");
   if (pc->gMaxPathVertices > 60 || pc->gMaxDiffuseVertices > 60) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: path length limits above 60");
   if (pc->gLightCount > ctx->light_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: gLightCount exceeds the uploaded light list");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
 
-  // flag resolution of BDPT::render (BDPT.cpp:504-523)
-  if (!(scene_flags & STHIP_BDPT_FLAG_HAS_EMISSIVES) || pc->gLightCount == 0) sampling_flags &= ~(1u << STHIP_eNEE);
+  // flag resolution of BDPT::render (BDPT.cpp:486-523), idempotent if the host has done it already
+  sthip_BDPTPushConstants pcn = *pc;
+  if (pcn.gLightCount == 0) scene_flags &= ~STHIP_BDPT_FLAG_HAS_EMISSIVES;
+  const bool has_env = (scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) != 0, has_emissives = (scene_flags & STHIP_BDPT_FLAG_HAS_EMISSIVES) != 0;
+  if (!has_env) pcn.gEnvironmentSampleProbability = 0;
+  if (!has_emissives) pcn.gEnvironmentSampleProbability = 1;
+  if (!has_emissives && !has_env) sampling_flags &= ~(1u << STHIP_eNEE);
   if (!(sampling_flags & (1u << STHIP_eNEE))) sampling_flags &= ~(1u << STHIP_eDeferShadowRays);
+  pc = &pcn;
+  if (has_env) {  // the Environment record (environment.h:17-22): ImageValue3, then 4 offsets into gDistributions when an image is bound
+    const size_t addr = pcn.gEnvironmentMaterialAddress;
+    if (addr + 16 > ctx->materials_host.size() || (addr & 3)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: gEnvironmentMaterialAddress is outside gMaterialData");
+    uint32_t rec[8] = {0};
+    memcpy(rec, ctx->materials_host.data() + addr, 16);
+    if (rec[3] < STHIP_IMAGE_COUNT) {
+      if (rec[3] >= ctx->image_count || addr + 32 > ctx->materials_host.size()) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: the environment refers to an image that is not in gImages");
+      memcpy(rec, ctx->materials_host.data() + addr, 32);
+      const size_t w = ctx->image_dims[rec[3]].first, h = ctx->image_dims[rec[3]].second;
+      const size_t need[4] = {h, w * h, h + 1, (w + 1) * h};  // marginal_pdf, row_pdf, marginal_cdf, row_cdf (dist2.h)
+      for (int k = 0; k < 4; k++)
+        if ((size_t)rec[4 + k] + need[k] > ctx->distribution_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: an environment distribution table lies outside gDistributions");
+    }
+  }
 
   const uint32_t W = pc->gOutputExtent[0], H = pc->gOutputExtent[1];
   if (W == 0 || H == 0) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: empty output extent");
@@ -502,6 +539,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   memset(&p, 0, sizeof(p));
   p.pc = *pc;
   p.sampling_flags = sampling_flags;
+  p.scene_flags = scene_flags;
   p.shard_rank = ctx->shard_rank;
   p.shard_count = ctx->shard_count;
   p.tile_w = ctx->tile_w;
@@ -574,6 +612,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.scene.images = ctx->images.p;
   p.scene.image_texels = ctx->image_texels.p;
   p.scene.image_count = ctx->image_count;
+  p.scene.distributions = ctx->distributions.p;
+  p.scene.distribution_count = ctx->distribution_count;
   p.bvh = ctx->bvh;
   p.ray_o = ctx->ray_o.p;
   p.ray_d = ctx->ray_d.p;
@@ -721,10 +761,15 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       }
       if (dc == TRACE_NONE) break;
       rc = timed(ms_shade, [&]() {
-        if (ctx->textured)
-          hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        const bool ext = ctx->has_spheres || has_env;
+        if (ctx->textured && ext)
+          hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else if (ctx->textured)
+          hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else if (ext)
+          hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
         else
-          hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+          hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
       });
       if (rc) return rc;
     }

@@ -38,16 +38,19 @@ struct BvhTri {
   uint32_t pad2;
 };
 
-// One entry of the top level: either the merged world-space mesh (identity = 1: all instances whose
-// transform is the identity, flattened into one BLAS) or one transformed instance.
+// One entry of the top level: the merged world-space mesh (all instances whose transform is the identity,
+// flattened into one BLAS), one transformed triangle instance, or one sphere instance (tested in place, no BLAS).
+#define TLAS_ENTRY_TRANSFORMED 0u
+#define TLAS_ENTRY_IDENTITY 1u
+#define TLAS_ENTRY_SPHERE 2u
 struct TlasEntry {
   float inv[12];      // gInstanceInverseTransforms[instance], row-major 3x4
-  uint32_t root;      // index of the BLAS root (always an inner node)
+  uint32_t root;      // index of the BLAS root (always an inner node); unused for a sphere
   uint32_t id_bits;   // OR-ed into BvhTri::id: 0 for the merged mesh, the instance index otherwise
-  uint32_t identity;  // 1: object space == world space
+  uint32_t identity;  // TLAS_ENTRY_*
   uint32_t pad;
   float center[3];    // object-space bounding sphere of the mesh: sizes the per-ray box padding
-  float radius;
+  float radius;       // ... or the radius of the sphere instance (InstanceData::radius, scene.h:43)
 };
 
 #ifdef __cplusplus

@@ -8,6 +8,7 @@
 #include "bvh_build.h"
 
 #include <math.h>
+#include <cmath>
 #include <stdlib.h>
 #include <string.h>
 
@@ -257,11 +258,25 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
   out = BuiltBvh();
   const uint32_t BLAS_DEPTH_CAP = 22, TLAS_DEPTH_CAP = 18;
   // ---- validate + classify ----
-  std::vector<uint32_t> merged, separate;
+  std::vector<uint32_t> merged, separate, spheres;
   for (uint32_t i = 0; i < s.instance_count; i++) {
     const InstView in = view(s.gInstances[i]);
+    if (in.type == STHIP_INSTANCE_TYPE_SPHERE) {
+      float r;
+      memcpy(&r, &s.gInstances[i].packed[2], 4);
+      if (!(fabsf(r) > 0.0f) || !std::isfinite(r)) {
+        err = "sphere instance with a zero or non-finite radius";
+        return false;
+      }
+      if ((size_t)in.material_address + sizeof(sthip_MaterialRecord) > s.material_bytes) {
+        err = "instance material_address exceeds gMaterialData";
+        return false;
+      }
+      spheres.push_back(i);
+      continue;
+    }
     if (in.type != STHIP_INSTANCE_TYPE_TRIANGLES) {
-      err = "only triangle instances are built (sphere/volume instances are SURVEY.md §8f N2/N4)";
+      err = "only triangle and sphere instances are built (volume instances are SURVEY.md §8f N4)";
       return false;
     }
     if (in.stride != 2 && in.stride != 4) {
@@ -381,7 +396,7 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
         return false;
       }
       e.id_bits = 0;
-      e.identity = 1;
+      e.identity = TLAS_ENTRY_IDENTITY;
       for (int a = 0; a < 3; a++) e.center[a] = 0.5f * (bounds.lo[a] + bounds.hi[a]);
       e.radius = 0.5f * sqrtf((bounds.hi[0] - bounds.lo[0]) * (bounds.hi[0] - bounds.lo[0]) + (bounds.hi[1] - bounds.lo[1]) * (bounds.hi[1] - bounds.lo[1]) +
                               (bounds.hi[2] - bounds.lo[2]) * (bounds.hi[2] - bounds.lo[2]));
@@ -419,7 +434,7 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
     memcpy(e.inv, &s.gInstanceInverseTransforms[i], 48);
     e.root = it->second.root;
     e.id_bits = i;
-    e.identity = 0;
+    e.identity = TLAS_ENTRY_TRANSFORMED;
     const Box& ob = it->second.bounds;
     for (int a = 0; a < 3; a++) e.center[a] = 0.5f * (ob.lo[a] + ob.hi[a]);
     e.radius = 0.5f * sqrtf((ob.hi[0] - ob.lo[0]) * (ob.hi[0] - ob.lo[0]) + (ob.hi[1] - ob.lo[1]) * (ob.hi[1] - ob.lo[1]) + (ob.hi[2] - ob.lo[2]) * (ob.hi[2] - ob.lo[2]));
@@ -448,12 +463,35 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
     scene_box.grow(wb);
   }
 
+  // sphere instances (Scene.cpp:511-553): one top-level entry each, tested in place by the traversal. The box is the
+  // sphere's world box, generously padded: sphere_test alone decides what is hit.
+  for (uint32_t i : spheres) {
+    TlasEntry e;
+    memset(&e, 0, sizeof(e));
+    memcpy(e.inv, &s.gInstanceInverseTransforms[i], 48);
+    e.root = BVH_INVALID_REF;
+    e.id_bits = i;
+    e.identity = TLAS_ENTRY_SPHERE;
+    memcpy(&e.radius, &s.gInstances[i].packed[2], 4);
+    Box wb;
+    const float r = fabsf(e.radius);
+    for (int a = 0; a < 3; a++) {
+      const float c = s.gInstanceTransforms[i].m[a][3];
+      const float pad = 1e-3f * r + 1e-5f * fabsf(c);
+      wb.lo[a] = c - r - pad;
+      wb.hi[a] = c + r + pad;
+    }
+    out.entries.push_back(e);
+    entry_boxes.push_back(wb);
+    scene_box.grow(wb);
+  }
+
   // ---- top level ----
   uint32_t tlas_depth = 0;
   if (out.entries.empty()) {
     out.root_ref = BVH_INVALID_REF;
     out.top_is_world_blas = 1;
-  } else if (out.entries.size() == 1 && out.entries[0].identity) {
+  } else if (out.entries.size() == 1 && out.entries[0].identity == TLAS_ENTRY_IDENTITY) {
     out.root_ref = out.entries[0].root;
     out.top_is_world_blas = 1;
   } else {

@@ -34,6 +34,7 @@ struct FrameParams {
   DeviceBvh bvh;
   sthip_BDPTPushConstants pc;
   uint32_t sampling_flags;
+  uint32_t scene_flags;      // BDPT_FLAG_HAS_* after the host-side resolution (BDPT.cpp:486-496)
   uint32_t seed;             // gRandomSeed of the first seed in flight
   uint32_t seeds_in_flight;  // seeds traced together in one pass: slot = seed_index * paths_per_seed + pixel slot
   uint32_t paths_per_seed;   // owned tiles * tile_w * tile_h
@@ -311,7 +312,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
 // where the next ray is known
 // ---------------------------------------------------------------------------------------------
 // TEXTURED: the scene binds images; ray cones, image values and normal maps are evaluated
-template <bool TEXTURED>
+// EXT: the scene has sphere instances or an environment: sphere hits, sphere lights, environment
+// emission and environment light sampling. Scenes without them run the instantiation that carries none of it.
+template <bool TEXTURED, bool EXT>
 __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_t depth) {
   // Workgroup b works on segment b % 8 (its XCD's) of the incoming queue and appends to the same segment of the
   // outgoing queues, so a segment never grows. In the first bounce a segment is a contiguous eighth of the slots
@@ -337,6 +340,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
   const bool use_nee = flag(p, STHIP_eNEE);
   const bool use_mis = flag(p, STHIP_eMIS);
   const bool sample_bsdfs = flag(p, STHIP_eSampleBSDFs);
+  const bool has_env = EXT && (p.scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) != 0;
+  const bool has_emissives = !EXT || (p.scene_flags & STHIP_BDPT_FLAG_HAS_EMISSIVES) != 0;
   for (uint32_t i = first; i < n; i += step) {
     const uint32_t slot = depth == 0 ? slot0 + i : queue_in[i];
     uint32_t meta = p.meta[slot];
@@ -388,13 +393,46 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
           }
           if (p.out_prev_uv) p.out_prev_uv[pixel] = make_float2(((float)px + 0.5f - (float)view.image_min[0]) / ex, ((float)py + 0.5f - (float)view.image_min[1]) / ey);
         }
+        if (has_env) {
+          // bdpt.hlsl:236-240 / path.hlsli:1051-1055 -> eval_emission (path.hlsli:847-894) for the background: cos = 1,
+          // G = 1 (trace(), path.hlsli:1015-1019), pdf of the direction from Environment::eval_pdf (light.hlsli:155-162)
+          Environment env;
+          env.load(p.scene, p.pc.gEnvironmentMaterialAddress);
+          const f3 eLe = env.eval(p.scene, direction);
+          if (!all_le0(eLe)) {
+            float light_pdf = env.eval_pdf(p.scene, direction);
+            if (has_emissives) light_pdf *= p.pc.gEnvironmentSampleProbability;
+            float weight = 1;
+            if (path_length > 2 && use_nee) weight = mis2(use_mis, bsdf_pdf, light_pdf);
+            radiance = radiance + (beta * eLe) * weight;
+          }
+        }
         break;
       }
       const uint32_t inst_index = ip & 0xFFFFu, prim = ip >> 16;
       const Inst in = load_inst(p.scene, inst_index);
       ShadingData sd;
-      make_triangle_shading_data(p.scene, sd, inst_index, in, prim, hh.y, hh.z, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
-      const float shape_pdf = 1 / (sd.shape_area * (float)in.prim_count());  // intersection.hlsli:172
+      float shape_pdf;
+      bool shape_pdf_area_measure = true;
+      if (EXT && in.type() == STHIP_INSTANCE_TYPE_SPHERE) {  // intersection.hlsli:140-159
+        const Xf inv = load_xf(p.scene.inv_xf, inst_index);
+        const float im[12] = {inv.r0.x, inv.r0.y, inv.r0.z, inv.r0.w, inv.r1.x, inv.r1.y, inv.r1.z, inv.r1.w, inv.r2.x, inv.r2.y, inv.r2.z, inv.r2.w};
+        const f3 local_hit_pos = obj_point(im, origin) + obj_vector(im, direction) * hh.x;
+        make_sphere_shading_data(p.scene, sd, inst_index, in, local_hit_pos);
+        if (flag(p, STHIP_eUniformSphereSampling)) {
+          shape_pdf = 1 / sd.shape_area;
+        } else {
+          const Xf t = load_xf(p.scene.xf, inst_index);
+          const f3 to_center = F3(t.r0.w, t.r1.w, t.r2.w) - origin;
+          const float sin_elevation_max_sq = pow2f(in.radius()) / dot3(to_center, to_center);
+          const float cos_elevation_max = sqrtf(fmaxf(0.0f, 1 - sin_elevation_max_sq));
+          shape_pdf = 1 / (DET_2PI * (1 - cos_elevation_max));
+          shape_pdf_area_measure = false;
+        }
+      } else {
+        make_triangle_shading_data(p.scene, sd, inst_index, in, prim, hh.y, hh.z, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
+        shape_pdf = 1 / (sd.shape_area * (float)in.prim_count());  // intersection.hlsli:172
+      }
       const f3 gn = sd.geometry_normal();
       // path.hlsli:1023-1040
       const float dist2 = len_sqr(sd.position - origin);
@@ -436,6 +474,11 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
         if (cos_theta_light < 0) return;
         float light_pdfA = shape_pdf;  // point_on_light_pdf, light.hlsli:163-171
         light_pdfA /= (float)p.pc.gLightCount;
+        if (EXT) {
+          if (!has_emissives) light_pdfA = 0;
+          if (has_env) light_pdfA *= 1 - p.pc.gEnvironmentSampleProbability;
+          if (!shape_pdf_area_measure) light_pdfA = light_pdfA * G;  // pdfWtoA, path.hlsli:864
+        }
         float weight = 1;
         if (path_length > 2) {
           if (use_nee) weight = mis2(use_mis, bsdf_pdf * G, light_pdfA);
@@ -505,33 +548,105 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
         if (use_nee) {
           // connect_light, path.hlsli:311-366; sample_Le :141-164; sample_point_on_light, light.hlsli:37-152
           const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float(), r3 = rng.next_float();
-          const int li = (int)(r3 * ((float)p.pc.gLightCount * .9999f));
-          float ls_pdf = 1 / (float)p.pc.gLightCount;
-          const uint32_t light_instance_index = p.scene.lights[li];
-          const Inst lin = load_inst(p.scene, light_instance_index);
-          const uint32_t lpc = lin.prim_count();
-          const uint32_t lprim = (uint32_t)fminf(r2 * (float)lpc, (float)(lpc - 1));
-          const float a = sqrtf(r0);
-          ShadingData lsd;
-          make_triangle_shading_data(p.scene, lsd, light_instance_index, lin, lprim, 1 - a, a * r1, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
-          const f3 ls_normal = lsd.geometry_normal();
-          f3 to_light = lsd.position - sd.position;
-          const float ls_dist = length3(to_light);
-          to_light = to_light / ls_dist;
-          ls_pdf /= lsd.shape_area * (float)lpc;
-          f3 lLe = F3s(0.0f);
-          if (ls_pdf > 0) {
-            DisneyMaterial lm;
-            if (TEXTURED) {  // light.hlsli:143-150: uv of the light sample, uv_screen_size = 0, no normal map
-              uint32_t dn = lsd.packed_shading_normal, dt = lsd.packed_tangent;
-              lm.load_textured(p.scene, lin.material_address(), lsd.u, lsd.v, 0.0f, dn, dt, p.sampling_flags & ~(1u << STHIP_eNormalMaps));
+          f3 lLe = F3s(0.0f), to_light = F3s(0.0f), ls_normal = F3s(0.0f);
+          float ls_pdf = 0, ls_dist = 0;
+          bool ls_is_env = false, ls_area_measure = true;
+          if (has_env && (!has_emissives || r3 <= p.pc.gEnvironmentSampleProbability)) {  // light.hlsli:38-48
+            Environment env;
+            env.load(p.scene, p.pc.gEnvironmentMaterialAddress);
+            lLe = env.sample(p.scene, r0, r1, to_light, ls_pdf);
+            if (has_emissives) ls_pdf *= p.pc.gEnvironmentSampleProbability;
+            ls_is_env = true;
+            ls_dist = __builtin_inff();
+            ls_area_measure = false;
+          } else if (has_emissives) {
+            const float rw = has_env ? (r3 - p.pc.gEnvironmentSampleProbability) / (1 - p.pc.gEnvironmentSampleProbability) : r3;
+            const int li = (int)(rw * ((float)p.pc.gLightCount * .9999f));
+            ls_pdf = 1 / (float)p.pc.gLightCount;
+            const uint32_t light_instance_index = p.scene.lights[li];
+            if (has_env) ls_pdf *= 1 - p.pc.gEnvironmentSampleProbability;
+            const Inst lin = load_inst(p.scene, light_instance_index);
+            float lu, lv;
+            if (EXT && lin.type() == STHIP_INSTANCE_TYPE_SPHERE) {  // light.hlsli:58-121
+              const float r = lin.radius();
+              const Xf t = load_xf(p.scene.xf, light_instance_index);
+              f3 ls_position;
+              if (flag(p, STHIP_eUniformSphereSampling)) {
+                ls_pdf /= 4 * DET_PI * r * r;
+                const float z = 1 - 2 * r0;
+                const float r_ = sqrtf(fmaxf(0.0f, 1 - z * z));
+                const float phi = DET_2PI * r1;
+                float sp, cp;
+                det_sincosf(phi, &sp, &cp);
+                const f3 local_normal = F3(r_ * cp, z, r_ * sp);
+                cartesian_to_spherical_uv(local_normal, lu, lv);
+                ls_position = xf_point(t, r * local_normal);
+                ls_normal = normalize3(xf_vector(t, local_normal));
+              } else {
+                const f3 center = F3(t.r0.w, t.r1.w, t.r2.w);
+                f3 to_center = center - sd.position;
+                const float dist = length3(to_center);
+                to_center = to_center / dist;
+                const float sinThetaMax = r / dist;
+                const float sinThetaMax2 = sinThetaMax * sinThetaMax;
+                const float invSinThetaMax = 1 / sinThetaMax;
+                const float cosThetaMax = sqrtf(fmaxf(0.0f, 1 - sinThetaMax2));
+                ls_pdf /= DET_2PI * (1 - cosThetaMax);
+                ls_area_measure = false;
+                float cosTheta = (cosThetaMax - 1) * r0 + 1;
+                float sinTheta2 = 1 - cosTheta * cosTheta;
+                if (sinThetaMax2 < 0.00068523f) {
+                  sinTheta2 = sinThetaMax2 * r0;
+                  cosTheta = sqrtf(1 - sinTheta2);
+                }
+                const float cosAlpha = sinTheta2 * invSinThetaMax + cosTheta * sqrtf(fmaxf(0.0f, 1 - sinTheta2 * invSinThetaMax * invSinThetaMax));
+                const float sinAlpha = sqrtf(fmaxf(0.0f, 1 - cosAlpha * cosAlpha));
+                const float phi = r1 * 2 * DET_PI;
+                float sp, cp;
+                det_sincosf(phi, &sp, &cp);
+                f3 T, B;
+                make_orthonormal(to_center, T, B);
+                ls_normal = -(T * sinAlpha * cp + B * sinAlpha * sp + to_center * cosAlpha);
+                ls_position = center + r * ls_normal;
+                const f3 local_normal = xf_vector(load_xf(p.scene.inv_xf, light_instance_index), ls_normal);
+                cartesian_to_spherical_uv(local_normal, lu, lv);
+              }
+              to_light = ls_position - sd.position;
+              ls_dist = length3(to_light);
+              to_light = to_light / ls_dist;
             } else {
-              lm.load(p.scene, lin.material_address());
+              const uint32_t lpc = lin.prim_count();
+              const uint32_t lprim = (uint32_t)fminf(r2 * (float)lpc, (float)(lpc - 1));
+              const float a = sqrtf(r0);
+              ShadingData lsd;
+              make_triangle_shading_data(p.scene, lsd, light_instance_index, lin, lprim, 1 - a, a * r1, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
+              lu = lsd.u;
+              lv = lsd.v;
+              ls_normal = lsd.geometry_normal();
+              to_light = lsd.position - sd.position;
+              ls_dist = length3(to_light);
+              to_light = to_light / ls_dist;
+              ls_pdf /= lsd.shape_area * (float)lpc;
             }
-            lLe = lm.Le();
+            if (ls_pdf > 0) {
+              DisneyMaterial lm;
+              if (TEXTURED) {  // light.hlsli:143-150: uv of the light sample, uv_screen_size = 0, no normal map
+                uint32_t dn = 0, dt = 0;
+                lm.load_textured(p.scene, lin.material_address(), lu, lv, 0.0f, dn, dt, p.sampling_flags & ~(1u << STHIP_eNormalMaps));
+              } else {
+                lm.load(p.scene, lin.material_address());
+              }
+              lLe = lm.Le();
+            }
           }
-          const float pdfA = ls_pdf;
-          float cG = fabsf(dot3(to_light, ls_normal)) / pow2f(ls_dist);
+          float pdfA = ls_pdf;
+          float cG;
+          if (ls_is_env) {  // sample_Le, path.hlsli:156-162
+            cG = 1;
+          } else {
+            cG = fabsf(dot3(to_light, ls_normal)) / pow2f(ls_dist);
+            if (!ls_area_measure) pdfA = pdfA * cG;
+          }
           // DirectLightSample::setup, path.hlsli:204-221
           const f3 local_to_light = normalize3(frame.to_local(to_light));
           const float ngdotout = dot3(gn, to_light);

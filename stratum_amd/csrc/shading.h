@@ -22,6 +22,8 @@ struct DeviceScene {
   const struct DeviceImage* images;
   const float4* image_texels;
   uint32_t image_count;
+  const float* distributions;  // StructuredBuffer<float> gDistributions (environment map tables, dist2.h)
+  uint32_t distribution_count;
 };
 
 #define STHIP_MAX_MIPS 16
@@ -42,6 +44,7 @@ struct Inst {
   DEV uint32_t index_stride() const { return p.y >> 28; }
   DEV uint32_t first_vertex() const { return p.z; }
   DEV uint32_t indices_byte_offset() const { return p.w; }
+  DEV float radius() const { return __uint_as_float(p.z); }  // sphere instances, scene.h:43
 };
 DEV Inst load_inst(const DeviceScene& sc, uint32_t i) {
   Inst r;
@@ -243,6 +246,42 @@ DEV void make_triangle_shading_data(const DeviceScene& sc, ShadingData& r, uint3
     const f3 bitangent = normalize3(cross3(shading_normal, tangent));
     r.mean_curvature = (dot3(dNdu, tangent) + dot3(dNdv, bitangent)) / 2;
   }
+  r.flags = 0;
+}
+
+// common.h:134-147
+DEV void cartesian_to_spherical_uv(f3 v, float& u, float& vv) {
+  const float theta = det_atan2f(v.z, v.x);
+  u = theta * DET_INV_PI * .5f + .5f;
+  vv = det_acosf(fminf(fmaxf(v.y, -1.f), 1.f)) * DET_INV_PI;
+}
+DEV f3 spherical_uv_to_cartesian(float u, float v) {
+  u = u * 2 - 1;
+  u *= DET_PI;
+  v *= DET_PI;
+  float su, cu, sv, cv;
+  det_sincosf(u, &su, &cu);
+  det_sincosf(v, &sv, &cv);
+  return F3(sv * cu, cv, sv * su);
+}
+
+// shading_data.hlsli:93-105 (the angles of dpdu / dpdv are the uv themselves, as the reference writes them)
+DEV void make_sphere_shading_data(const DeviceScene& sc, ShadingData& r, uint32_t inst_index, const Inst& in, f3 local_position) {
+  const Xf t = load_xf(sc.xf, inst_index);
+  const f3 normal = normalize3(xf_vector(t, local_position));
+  r.position = xf_point(t, local_position);
+  r.packed_geometry_normal = r.packed_shading_normal = pack_normal_octahedron(normal);
+  const float radius = in.radius();
+  r.shape_area = 4 * DET_PI * radius * radius;
+  r.mean_curvature = 1 / radius;
+  cartesian_to_spherical_uv(normalize3(local_position), r.u, r.v);
+  float su, cu, sv, cv;
+  det_sincosf(r.u, &su, &cu);
+  det_sincosf(r.v, &sv, &cv);
+  const f3 dpdu = xf_vector(t, F3(-su * sv, 0, cu * sv));
+  const f3 dpdv = xf_vector(t, F3(cu * cv, -sv, su * cv));
+  r.packed_tangent = pack_normal_octahedron(normalize3(dpdu - normal * dot3(normal, dpdu)));
+  r.uv_screen_size = 1 / fmaxf(length3(dpdu), length3(dpdv));
   r.flags = 0;
 }
 
@@ -615,6 +654,95 @@ struct DisneyMaterial {
     }
     beta = beta * F3(f.x / r.pdf_fwd, f.y / r.pdf_fwd, f.z / r.pdf_fwd);
     return f;
+  }
+};
+
+// dist2.h:6-20 (upper_bound), :29-57 (dist2d_pdf / dist2d_sample) over gDistributions
+DEV uint32_t dist_upper_bound(const float* data, uint32_t first, uint32_t last, float value) {
+  int count = (int)(last - first);
+  while (count > 0) {
+    uint32_t it = first;
+    const int step = count / 2;
+    it += (uint32_t)step;
+    if (value >= data[it]) {
+      first = ++it;
+      count -= step + 1;
+    } else
+      count = step;
+  }
+  return first;
+}
+DEV int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+DEV float dist2d_pdf(const float* data, uint32_t pdf_marginals, uint32_t pdf_rows, uint32_t w, uint32_t h, float u, float v) {
+  const int x = (int)fminf(fmaxf(u * (float)w, 0.0f), (float)(w - 1));
+  const int y = (int)fminf(fmaxf(v * (float)h, 0.0f), (float)(h - 1));
+  const float pdf_y = data[pdf_marginals + y];
+  const float pdf_x = data[pdf_rows + y * w + x];
+  return pdf_y * pdf_x * (float)w * (float)h;
+}
+DEV void dist2d_sample(const float* data, uint32_t cdf_marginals, uint32_t cdf_rows, uint32_t w, uint32_t h, float rx, float ry, float& u, float& v) {
+  const uint32_t y_ptr = dist_upper_bound(data, cdf_marginals, cdf_marginals + h + 1, ry) - cdf_marginals;
+  const int y_offset = clampi((int)y_ptr - 1, 0, (int)h - 1);
+  float dy = ry - data[cdf_marginals + y_offset];
+  if ((data[cdf_marginals + y_offset + 1] - data[cdf_marginals + y_offset]) > 0) dy /= (data[cdf_marginals + y_offset + 1] - data[cdf_marginals + y_offset]);
+  const int row_offset = y_offset * ((int)w + 1);
+  const uint32_t x_ptr = dist_upper_bound(data, cdf_rows + row_offset, cdf_rows + row_offset + w + 1, rx) - cdf_rows;
+  const int x_offset = clampi((int)x_ptr - row_offset - 1, 0, (int)w - 1);
+  float dx = rx - data[cdf_rows + row_offset + x_offset];
+  if (data[cdf_rows + row_offset + x_offset + 1] - data[cdf_rows + row_offset + x_offset] > 0) dx /= (data[cdf_rows + row_offset + x_offset + 1] - data[cdf_rows + row_offset + x_offset]);
+  u = ((float)x_offset + dx) / (float)w;
+  v = ((float)y_offset + dy) / (float)h;
+}
+
+// environment.h:8-95. Record in gMaterialData: ImageValue3 (float3 value, uint image_index) and, when an image is
+// bound, the offsets of marginal_pdf, row_pdf, marginal_cdf, row_cdf in gDistributions (:17-22,37-45).
+// eSampleEnvironmentMapDirectly (sample_texel) is not built (the ABI rejects the flag).
+struct Environment {
+  f3 value;
+  uint32_t image_index;
+  uint32_t marginal_pdf, row_pdf, marginal_cdf, row_cdf;
+  DEV bool has_image(const DeviceScene& sc) const { return image_index < sc.image_count; }
+  DEV void load(const DeviceScene& sc, uint32_t address) {
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(sc.materials + address);  // 4-byte aligned (72-byte records before it)
+    value = F3(__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]));
+    image_index = a[3];
+    marginal_pdf = row_pdf = marginal_cdf = row_cdf = 0;
+    if (has_image(sc)) {
+      marginal_pdf = a[4];
+      row_pdf = a[5];
+      marginal_cdf = a[6];
+      row_cdf = a[7];
+    }
+  }
+  DEV f3 lookup(const DeviceScene& sc, float u, float v) const { return xyz(DisneyMaterial::sample_image(sc, image_index, u, v, 0.0f, false)); }
+  DEV f3 eval(const DeviceScene& sc, f3 dir_out) const {
+    if (!has_image(sc)) return value;
+    float u, v;
+    cartesian_to_spherical_uv(dir_out, u, v);
+    return lookup(sc, u, v) * value;
+  }
+  DEV f3 sample(const DeviceScene& sc, float rx, float ry, f3& dir_out, float& pdf) const {
+    if (!has_image(sc)) {
+      // sample_uniform_sphere's (phi, theta) go through spherical_uv_to_cartesian as if they were uv (as upstream)
+      dir_out = spherical_uv_to_cartesian(2 * DET_PI * ry, det_acosf(2 * rx - 1));
+      pdf = DET_INV_4PI;
+      return value;
+    }
+    const uint32_t w = sc.images[image_index].w[0], h = sc.images[image_index].h[0];
+    float u, v;
+    dist2d_sample(sc.distributions, marginal_cdf, row_cdf, w, h, rx, ry, u, v);
+    pdf = dist2d_pdf(sc.distributions, marginal_pdf, row_pdf, w, h, u, v);
+    dir_out = spherical_uv_to_cartesian(u, v);
+    pdf /= (DET_2PI2 * sqrtf(1 - dir_out.y * dir_out.y));
+    return value * lookup(sc, u, v);
+  }
+  DEV float eval_pdf(const DeviceScene& sc, f3 dir_out) const {
+    if (!has_image(sc)) return DET_INV_4PI;
+    float u, v;
+    cartesian_to_spherical_uv(dir_out, u, v);
+    const uint32_t w = sc.images[image_index].w[0], h = sc.images[image_index].h[0];
+    const float pdf = dist2d_pdf(sc.distributions, marginal_pdf, row_pdf, w, h, u, v);
+    return pdf / (DET_2PI2 * sqrtf(1 - dir_out.y * dir_out.y));
   }
 };
 

@@ -100,6 +100,25 @@ DEV f3 obj_vector(const float* m, f3 p) {
   return F3(fmaf(m[2], p.z, fmaf(m[1], p.y, m[0] * p.x)), fmaf(m[6], p.z, fmaf(m[5], p.y, m[4] * p.x)), fmaf(m[10], p.z, fmaf(m[9], p.y, m[8] * p.x)));
 }
 
+// Sphere instances (ray_sphere, common.h:163-173, as used by intersection.hlsli:79-89), arithmetic exactly as the
+// contract states: products rounded separately, near root if it lies beyond tmin, else the far root
+DEV bool sphere_test(f3 o, f3 d, float r, float tmin, float tmax, float& t) {
+  const float a = dot3(d, d);
+  const float b = dot3(o, d);
+  const f3 l = F3(a * o.x - d.x * b, a * o.y - d.y * b, a * o.z - d.z * b);
+  float det = (a * r) * (a * r) - dot3(l, l);
+  if (det < 0) return false;
+  const float inv_a = 1 / a;
+  det = sqrtf(det * inv_a) * inv_a;
+  const float e = (-b) * inv_a;
+  const float t0 = e - det, t1 = e + det;
+  if (!(t0 < t1)) return false;
+  const float tt = t0 > tmin ? t0 : t1;
+  if (!(tt > tmin && tt < tmax)) return false;
+  t = tt;
+  return true;
+}
+
 // closest-hit ordering key: instance first, then primitive
 DEV uint32_t hit_key(uint32_t ip) { return (ip << 16) | (ip >> 16); }
 
@@ -229,10 +248,32 @@ struct Traversal {
       const TlasEntry* e = bvh.entries + (ref & 0xFFFFu);
       const float4* ev = reinterpret_cast<const float4*>(e);
       const uint4 info = *reinterpret_cast<const uint4*>(ev + 3);
-      if (!info.z) {
+      if (info.z != TLAS_ENTRY_IDENTITY) {
         const float4 r0 = ev[0], r1 = ev[1], r2 = ev[2];
         const float4 sph = ev[4];
         const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+        if (info.z == TLAS_ENTRY_SPHERE) {  // a sphere instance is tested right here (intersection.hlsli:79-89)
+          if (COUNT) {
+            cnt.tris++;
+            if (first_active_lane()) cnt.tri_slots += 64;
+          }
+          float t;
+          if (sphere_test(obj_point(m, o), obj_vector(m, d), sph.w, tmin, tmax, t)) {
+            if (is_any()) {
+              hit.ip = 0;
+              ref = TRAV_DONE;
+              return;
+            }
+            const uint32_t ip = info.y | 0xFFFF0000u;  // instance | INVALID_PRIMITIVE << 16
+            if (t < hit.t || (t == hit.t && hit.ip != 0xFFFFFFFFu && hit_key(ip) < hit_key(hit.ip))) {
+              hit.t = t;
+              hit.b1 = hit.b2 = 0.0f;
+              hit.ip = ip;
+            }
+          }
+          pop(stack);
+          return;
+        }
         setup_space(sp, obj_point(m, o), obj_vector(m, d), sph.x, sph.y, sph.z, sph.w);
         id_bits = info.y;
         stack[top] = TRAV_EXIT_INSTANCE;

@@ -93,6 +93,8 @@ class SceneData:
         self.materials = materials
         self.lights = lights
         self.images = []  # RGBA32F arrays (H, W, 4): Texture2D<float4> gImages[]
+        self.distributions = np.zeros(0, np.float32)  # StructuredBuffer<float> gDistributions
+        self.environment_address = 0xFFFFFFFF  # SceneData::mEnvironmentMaterialAddress, Scene.cpp:631-640
 
     @property
     def light_count(self):
@@ -103,8 +105,11 @@ class SceneData:
         return int(((self.instances["packed"][:, 1] >> 12) & 0xFFFF).sum())
 
     @property
-    def scene_flags(self):
-        return wire.BDPT_FLAG_HAS_EMISSIVES if self.light_count else 0
+    def scene_flags(self):  # BDPT.cpp:486-496
+        f = wire.BDPT_FLAG_HAS_EMISSIVES if self.light_count else 0
+        if self.environment_address != 0xFFFFFFFF:
+            f |= wire.BDPT_FLAG_HAS_ENVIRONMENT
+        return f
 
     def desc(self):
         d = wire.SceneDesc()
@@ -129,6 +134,9 @@ class SceneData:
                 self._image_descs[i].height = im.shape[0]
             d.gImages = C.cast(self._image_descs, C.c_void_p)
             d.image_count = len(self.images)
+        if self.distributions.size:
+            d.gDistributions = wire.ptr(self.distributions)
+            d.distribution_count = self.distributions.size
         return d
 
 
@@ -143,6 +151,8 @@ class SceneBuilder:
         self._materials = []  # MaterialRecord entries
         self._instances = []  # (mesh, material index, 4x4 transform)
         self._images = []  # RGBA32F (H, W, 4)
+        self._spheres = []  # (material index, 4x4 node transform, radius): SpherePrimitive, Scene.hpp:34-37
+        self._environment = None  # (value rgb, image handle or None): Environment, environment.h
 
     # -- Material::store, Material.hpp:32-38; conventions of load_mitsuba.cpp:330-343,454-489 --
     def add_material(
@@ -224,8 +234,20 @@ class SceneBuilder:
         self._instances.append((mesh, material, m))
         return len(self._instances) - 1
 
+    def add_sphere(self, material, radius, transform=None):
+        """SpherePrimitive: a sphere of `radius` at the node's origin (Scene.cpp:511-553)."""
+        m = np.eye(4) if transform is None else np.asarray(transform, dtype=np.float64)
+        if m.shape == (3, 4):
+            m = np.vstack([m, [0, 0, 0, 1]])
+        self._spheres.append((material, m, float(radius)))
+        return len(self._instances) + len(self._spheres) - 1
+
+    def set_environment(self, value, image=None):
+        """Environment component: constant radiance `value`, or `value` times a lat-long image (environment.h)."""
+        self._environment = (np.asarray(value, dtype=np.float32).reshape(3), image)
+
     def build(self):
-        n = len(self._instances)
+        n = len(self._instances) + len(self._spheres)
         inst = np.zeros(n, dtype=wire.InstanceData)
         xf = np.zeros(n, dtype=wire.TransformData)
         inv = np.zeros(n, dtype=wire.TransformData)
@@ -245,7 +267,7 @@ class SceneBuilder:
                 image_order.append(handle)
             return image_index_of[handle]
 
-        for _, mat, _ in self._instances:
+        for mat in [m for _, m, _ in self._instances] + [m for m, _, _ in self._spheres]:
             if mat not in address_of:
                 address_of[mat] = len(used) * wire.MaterialRecord.itemsize
                 rec = self._materials[mat].copy()
@@ -270,22 +292,107 @@ class SceneBuilder:
             inv["m"][i] = transform_inverse(m32)
             # make_instance_motion_transform(inv, prevObjectToWorld), scene.h:49; static scene: prev = current
             mot["m"][i] = tmul(m32, inv["m"][i])
+        for k, (mat, m, radius) in enumerate(self._spheres):  # Scene.cpp:511-553, after every mesh instance
+            i = len(self._instances) + k
+            m32 = m[:3, :].astype(np.float32)
+            # the reference scales the radius by the DETERMINANT of the node's 3x3 block (:520) and keeps only the
+            # translation of the node transform (:521)
+            b = m32[:, :3]
+            det = np.float32(
+                b[0, 0] * (b[1, 1] * b[2, 2] - b[1, 2] * b[2, 1]) - b[0, 1] * (b[1, 0] * b[2, 2] - b[1, 2] * b[2, 0]) + b[0, 2] * (b[1, 0] * b[2, 1] - b[1, 1] * b[2, 0])
+            )
+            r = np.float32(np.float32(radius) * det)
+            t32 = np.zeros((3, 4), np.float32)
+            t32[0, 0] = t32[1, 1] = t32[2, 2] = 1
+            t32[:, 3] = m32[:, 3]
+            p0 = wire.INSTANCE_TYPE_SPHERE | (address_of[mat] << 4)  # make_instance_sphere, scene.h:62-70
+            p1 = 0xFFF
+            emission = float(self._materials[mat]["values"]["value"][0][3])
+            if emission * (4 * np.pi * float(r) * float(r)) > 0:
+                p1 = (p1 & ~0xFFF) | (len(lights) & 0xFFF)
+                lights.append(i)
+            inst["packed"][i] = [p0 & 0xFFFFFFFF, p1 & 0xFFFFFFFF, int(np.array([r], np.float32).view(np.uint32)[0]), 0]
+            xf["m"][i] = t32
+            inv["m"][i] = transform_inverse(t32)
+            mot["m"][i] = tmul(t32, inv["m"][i])
         vertices = np.concatenate(self._verts) if self._verts else np.zeros(0, wire.PackedVertexData)
         indices = np.frombuffer(b"".join(self._index_chunks), dtype=np.uint8).copy()
+        # environment material, Scene.cpp:631-640: appended after every instance material, only if its value is not zero
+        mat_bytes = np.ascontiguousarray(mats).view(np.uint8).reshape(-1)
+        env_address, dist = 0xFFFFFFFF, np.zeros(0, np.float32)
+        if self._environment is not None and np.any(self._environment[0] != 0):
+            value, image = self._environment
+            env_address = mat_bytes.size
+            rec = np.zeros(4, np.uint32)
+            rec[:3] = value.view(np.uint32)
+            rec[3] = image_index(0xFFFFFFFF if image is None else image)
+            parts = [rec]
+            if image is not None:  # Environment::store, environment.h:17-22: offsets into gDistributions in get_index order
+                tables = build_distributions(self._images[int(image)])  # marginal_pdf, row_pdf, marginal_cdf, row_cdf
+                offs, off = [], 0
+                for t in tables:
+                    offs.append(off)
+                    off += t.size
+                parts.append(np.array(offs, np.uint32))
+                dist = np.concatenate(tables).astype(np.float32)
+            mat_bytes = np.concatenate([mat_bytes, np.concatenate(parts).view(np.uint8)])
         sd = SceneData(
-            np.ascontiguousarray(vertices),
-            indices,
+            np.ascontiguousarray(vertices) if len(vertices) else np.zeros(1, wire.PackedVertexData),
+            indices if indices.size else np.zeros(4, np.uint8),
             inst,
             xf,
             inv,
             mot,
-            np.ascontiguousarray(mats),
+            np.ascontiguousarray(mat_bytes),
             np.array(lights, dtype=np.uint32),
             name=self.name,
         )
         sd.builder = self  # the inputs the arrays were packed from (dump_description)
         sd.images = [self._images[h] for h in image_order]
+        sd.distributions = dist
+        sd.environment_address = env_address
         return sd
+
+
+def build_distributions(image):
+    """dist2.h:80-154 build_distributions for a lat-long RGBA32F image (H, W, 4): returns (marginal_pdf[H],
+    row_pdf[H*W], marginal_cdf[H+1], row_cdf[H*(W+1)]). Accumulation order and the float/double mix follow the
+    reference's loops: f(x, y) is a double (float luminance times double sin), every running sum is stored as float."""
+    img = np.asarray(image, dtype=np.float32)
+    H, W = img.shape[0], img.shape[1]
+    lum = (img[..., 0] * np.float32(0.2126) + img[..., 1] * np.float32(0.7152)) + img[..., 2] * np.float32(0.0722)
+    inv_h = np.float64(np.float32(1.0) / np.float32(H))
+    y = np.arange(H, dtype=np.float32) + np.float32(0.5)
+    f = lum.astype(np.float64) * np.sin(np.pi * y.astype(np.float64) * inv_h)[:, None]
+    cdf_rows = np.zeros((H, W + 1), np.float32)
+    for x in range(W):
+        cdf_rows[:, x + 1] = (cdf_rows[:, x].astype(np.float64) + f[:, x]).astype(np.float32)
+    integral = cdf_rows[:, W].copy()
+    pdf_rows = np.zeros((H, W), np.float32)
+    pos = integral > 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cdf_rows[pos, :W] = cdf_rows[pos, :W] / integral[pos, None]
+        pdf_rows[pos] = (f[pos] / integral[pos, None].astype(np.float64)).astype(np.float32)
+    if np.any(~pos):
+        pdf_rows[~pos] = np.float32(1) / np.float32(W)
+        cdf_rows[~pos, :W] = np.arange(W, dtype=np.float32) / np.float32(W)
+        cdf_rows[~pos, W] = 1
+    cdf_marg = np.zeros(H + 1, np.float32)
+    for yy in range(H):
+        cdf_marg[yy + 1] = cdf_marg[yy] + cdf_rows[yy, W]
+    total = cdf_marg[H]
+    pdf_marg = np.zeros(H, np.float32)
+    if total > 0:
+        weights = cdf_rows[:, W].copy()
+        cdf_marg[:H] = cdf_marg[:H] / total
+        cdf_marg[H] = 1
+        pdf_marg[:] = weights / total
+    else:
+        pdf_marg[:] = np.float32(1) / np.float32(H)
+        cdf_marg[:H] = np.arange(H, dtype=np.float32) / np.float32(H)
+        cdf_marg[H] = 1
+    cdf_rows[:, W] = 1
+    return pdf_marg, pdf_rows.reshape(-1), cdf_marg, cdf_rows.reshape(-1)
 
 
 def dump_description(path, scene, frame):

@@ -453,3 +453,78 @@ def textured_box():
 
 
 SCENES["textured_box"] = textured_box
+
+
+# ---------------------------------------------------------------------------------------------
+# sphere instances / sphere lights and environment maps
+# ---------------------------------------------------------------------------------------------
+def sky_image(w=64, h=32, sun=(0.3, 0.25), sun_radiance=60.0):
+    """Procedural lat-long environment (RGBA32F, row 0 = +Y pole): blue gradient, a ground tone and a soft sun."""
+    v, u = np.meshgrid((np.arange(h) + 0.5) / h, (np.arange(w) + 0.5) / w, indexing="ij")
+    up = np.cos(np.pi * v)
+    sky = np.stack([0.35 + 0.3 * (1 - up), 0.5 + 0.3 * (1 - up), 0.9 + 0.0 * up], -1) * np.clip(up + 0.15, 0.05, 1)[..., None] * 1.5
+    ground = np.stack([0.25 + 0 * up, 0.22 + 0 * up, 0.2 + 0 * up], -1)
+    img = np.where((up > 0)[..., None], sky, ground)
+    d2 = ((u - sun[0] + 0.5) % 1.0 - 0.5) ** 2 + (v - sun[1]) ** 2
+    img = img + sun_radiance * np.exp(-d2 / (2 * 0.02**2))[..., None] * np.array([1.0, 0.9, 0.7])
+    out = np.ones((h, w, 4), np.float32)
+    out[..., :3] = img
+    return out
+
+
+def spheres_room():
+    """Closed room lit by one sphere light and one quad light, with diffuse / metal / glass sphere instances
+    (SpherePrimitive) next to a triangle box: spheres in the traversal contract, sphere-light sampling."""
+    b = SceneBuilder("spheres_room")
+    white = b.add_material((0.73, 0.73, 0.73))
+    red = b.add_material((0.65, 0.05, 0.05))
+    green = b.add_material((0.12, 0.45, 0.15))
+    metal = b.add_material((0.9, 0.8, 0.5), metallic=1.0, roughness=0.15)
+    glass = b.add_material((1.0, 1.0, 1.0), transmission=1.0, roughness=0.05, eta=1.5)
+    blue = b.add_material((0.2, 0.3, 0.8), roughness=0.6)
+    lamp = b.add_emitter((18.0, 15.0, 10.0))
+    panel = b.add_emitter((6.0, 7.0, 9.0))
+    S = 2.0
+    b.add_instance(b.add_mesh(*_quad((-S, 0, S), (S, 0, S), (S, 0, -S), (-S, 0, -S), (0, 1, 0))), white)
+    b.add_instance(b.add_mesh(*_quad((-S, 3, -S), (S, 3, -S), (S, 3, S), (-S, 3, S), (0, -1, 0))), white)
+    b.add_instance(b.add_mesh(*_quad((-S, 0, -S), (S, 0, -S), (S, 3, -S), (-S, 3, -S), (0, 0, 1))), white)
+    b.add_instance(b.add_mesh(*_quad((-S, 0, S), (-S, 0, -S), (-S, 3, -S), (-S, 3, S), (1, 0, 0))), red)
+    b.add_instance(b.add_mesh(*_quad((S, 0, -S), (S, 0, S), (S, 3, S), (S, 3, -S), (-1, 0, 0))), green)
+    b.add_instance(b.add_mesh(*_quad((-0.5, 2.99, -0.3), (0.5, 2.99, -0.3), (0.5, 2.99, 0.3), (-0.5, 2.99, 0.3), (0, -1, 0))), panel, translate((1.0, 0.0, -0.8)))
+    b.add_sphere(lamp, 0.25, translate((-0.9, 2.2, -0.6)))
+    b.add_sphere(blue, 0.5, translate((-1.0, 0.5, -0.8)))
+    b.add_sphere(metal, 0.45, translate((0.2, 0.45, -1.1)))
+    b.add_sphere(glass, 0.35, translate((0.9, 0.35, 0.2)))
+    b.add_sphere(white, 0.2, translate((-0.2, 0.4, 0.6)) @ scale((1.0, 2.0, 1.0)))  # radius scaled by det = 2
+    return b.build(), {"eye": (0.0, 1.5, 4.6), "target": (0.0, 1.2, 0.0), "fovy": np.radians(45.0)}
+
+
+def environment_scene(image=True, emitter=True):
+    """Objects on a ground plane under an environment map (lat-long image with a sun, or a constant colour), with an
+    optional triangle emitter so that the environment / emitter choice of light sampling is exercised."""
+    b = SceneBuilder("environment")
+    ground = b.add_material((0.5, 0.5, 0.5), roughness=0.8)
+    metal = b.add_material((0.95, 0.95, 0.95), metallic=1.0, roughness=0.05)
+    clay = b.add_material((0.7, 0.35, 0.25))
+    S = 6.0
+    b.add_instance(b.add_mesh(*_quad((-S, 0, S), (S, 0, S), (S, 0, -S), (-S, 0, -S), (0, 1, 0))), ground)
+    parts = [
+        _quad((-0.5, 0, 0.5), (0.5, 0, 0.5), (0.5, 1, 0.5), (-0.5, 1, 0.5), (0, 0, 1)),
+        _quad((0.5, 0, -0.5), (-0.5, 0, -0.5), (-0.5, 1, -0.5), (0.5, 1, -0.5), (0, 0, -1)),
+        _quad((-0.5, 0, -0.5), (-0.5, 0, 0.5), (-0.5, 1, 0.5), (-0.5, 1, -0.5), (-1, 0, 0)),
+        _quad((0.5, 0, 0.5), (0.5, 0, -0.5), (0.5, 1, -0.5), (0.5, 1, 0.5), (1, 0, 0)),
+        _quad((-0.5, 1, 0.5), (0.5, 1, 0.5), (0.5, 1, -0.5), (-0.5, 1, -0.5), (0, 1, 0)),
+    ]
+    b.add_instance(b.add_mesh(*_merge(parts)), clay, translate((-1.0, 0.0, 0.0)) @ rotate_y(0.5))
+    b.add_sphere(metal, 0.6, translate((0.8, 0.6, 0.2)))
+    if emitter:
+        lamp = b.add_emitter((8.0, 4.0, 2.0))
+        b.add_instance(b.add_mesh(*_quad((-0.3, 0, -0.3), (0.3, 0, -0.3), (0.3, 0, 0.3), (-0.3, 0, 0.3), (0, -1, 0))), lamp, translate((0.0, 2.0, 0.5)))
+    if image:
+        b.set_environment((1.0, 1.0, 1.0), b.add_image(sky_image()))
+    else:
+        b.set_environment((0.6, 0.8, 1.2))
+    return b.build(), {"eye": (0.0, 1.3, 4.5), "target": (0.0, 0.6, 0.0), "fovy": np.radians(40.0)}
+
+SCENES["spheres_room"] = spheres_room
+SCENES["environment"] = environment_scene

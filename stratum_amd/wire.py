@@ -84,6 +84,7 @@ BDPT_FLAG_HAS_EMISSIVES = 2
 BDPT_FLAG_HAS_MEDIA = 4
 BDPT_FLAG_TRACE_LIGHT = 8
 
+INSTANCE_TYPE_TRIANGLES, INSTANCE_TYPE_SPHERE, INSTANCE_TYPE_VOLUME = 0, 1, 2
 INVALID_INSTANCE = 0xFFFF
 MISS = 0xFFFFFFFF
 
@@ -151,6 +152,8 @@ class SceneDesc(C.Structure):
         ("light_count", C.c_uint32),
         ("gImages", C.c_void_p),
         ("image_count", C.c_uint32),
+        ("gDistributions", C.c_void_p),
+        ("distribution_count", C.c_uint32),
     ]
 
 
@@ -225,7 +228,7 @@ def default_push_constants(width, height, light_count, view_count=1):
     pc.gLightDistributionPDF = 0
     pc.gLightDistributionCDF = 0
     pc.gEnvironmentMaterialAddress = 0xFFFFFFFF
-    pc.gEnvironmentSampleProbability = 0.0
+    pc.gEnvironmentSampleProbability = 0.5  # BDPT.cpp:67; BDPT::render forces 0 / 1 without an environment / without emitters (:488-496)
     pc.gRandomSeed = 0
     pc.gMinPathVertices = 4
     pc.gMaxPathVertices = 8

@@ -355,3 +355,84 @@ def test_textured_scene(flags):
         assert d <= 1e-4
     finally:
         r.close()
+
+
+# ---- sphere instances / sphere lights / environment maps ----
+def _compare_frame(sc, cam, flags, w=176, h=128, seeds=2, args=None):
+    from oracle import oracle_py
+    from stratum_amd.bdpt import BDPT
+
+    a = {"bdptFlag": flags}
+    a.update(args or {})
+    r = BDPT(device=0, args=a)
+    try:
+        r.update(sc)
+        frame = camera.Frame(w, h, cam["fovy"], cam["eye"], cam["target"])
+        got = r.render(frame, 0, seeds)
+        ref = oracle_py.OracleScene(sc).render(frame, r.push_constants(frame), r.mSamplingFlags, 0, seeds)
+        assert np.array_equal(got["visibility"]["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
+        assert np.array_equal(got["visibility"]["packed_normal"], ref["visibility"]["packed_normal"])
+        assert np.array_equal(got["albedo"].view(np.uint32), ref["albedo"].view(np.uint32))
+        assert np.array_equal(got["depth"]["z"].view(np.uint32), ref["depth"]["z"].view(np.uint32))
+        assert np.array_equal(got["ray_count"], ref["ray_count"])
+        d = rel_l2(got["radiance"], ref["radiance"])
+        nd = int((got["radiance"].view(np.uint32) != ref["radiance"].view(np.uint32)).any(axis=-1).sum())
+        print("%s %s rel-L2 %.3e, differing pixels %d, rays %s" % (sc.name, flags, d, nd, got["ray_count"]))
+        assert np.isfinite(got["radiance"]).all() and got["radiance"][..., :3].mean() > 0.01
+        assert d <= 1e-4
+        return got
+    finally:
+        r.close()
+
+
+def test_trace_contract_with_spheres(renderer):
+    """Sphere instances next to triangle meshes: closest hit and occlusion equal the oracle's brute force."""
+    from oracle import oracle_py
+
+    sc, _ = scenes.spheres_room()
+    renderer.update(sc)
+    o = oracle_py.OracleScene(sc)
+    rays = random_rays(60000, 4, -1.9, 2.9)
+    got = renderer.trace(rays)
+    ref, _ = o.trace(rays, brute=True)
+    for f in ("instance_primitive_index", "t", "b1", "b2"):
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+    on_sphere = (ref["instance_primitive_index"] >> 16 == 0xFFFF) & (ref["instance_primitive_index"] != wire.MISS)
+    assert on_sphere.mean() > 0.03
+    rays["tmax"] = 1.2
+    got = renderer.trace(rays, any_hit=True)
+    ref, _ = o.trace(rays, any_hit=True, brute=True)
+    assert np.array_equal(got["instance_primitive_index"], ref["instance_primitive_index"])
+
+
+@pytest.mark.parametrize("flags", [[], ["uniformspheresampling"], ["~defershadowrays"], ["~nee"], ["~samplebsdfs"]])
+def test_sphere_instances_and_sphere_lights(flags):
+    sc, cam = scenes.spheres_room()
+    _compare_frame(sc, cam, flags, args={"maxDiffuseVertices": 3})
+
+
+@pytest.mark.parametrize("image,emitter", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("flags", [[], ["~mis"]])
+def test_environment(image, emitter, flags):
+    """Environment emission on misses, environment light sampling (dist2d tables of the lat-long image, or the
+    image-less constant environment), and the environment / emitter choice (gEnvironmentSampleProbability)."""
+    sc, cam = scenes.environment_scene(image=image, emitter=emitter)
+    got = _compare_frame(sc, cam, flags)
+    sky = got["visibility"]["instance_primitive_index"] == wire.MISS
+    assert sky.mean() > 0.2 and got["radiance"][sky][:, :3].min() > 0.05
+
+
+def test_environment_errors(renderer):
+    from stratum_amd import _lib
+
+    sc, cam = scenes.environment_scene(image=True, emitter=False)
+    renderer.update(sc)
+    frame = camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"])
+    renderer.set_flag("sampleenvironmentmapdirectly")
+    with pytest.raises(_lib.StratumHipError, match="sampling flag"):
+        renderer.render(frame)
+    renderer.set_flag("~sampleenvironmentmapdirectly")
+    sc.distributions = sc.distributions[:-5]  # a table that runs past gDistributions
+    renderer.update(sc)
+    with pytest.raises(_lib.StratumHipError, match="gDistributions"):
+        renderer.render(frame)

@@ -6,7 +6,7 @@ import pytest
 
 from oracle import oracle_py as orc
 from stratum_amd import camera, scenes, wire
-from stratum_amd.scene import SceneBuilder, rotate_y, scale, translate
+from stratum_amd.scene import SceneBuilder, build_distributions, rotate_y, scale, translate
 
 U32 = np.uint32
 
@@ -438,3 +438,145 @@ def test_ray_cones_and_normal_maps_change_the_image():
     assert not np.array_equal(base["albedo"], no_cones["albedo"])  # mip level 0 instead of the footprint's level
     assert not np.array_equal(base["visibility"]["packed_normal"], no_bump["visibility"]["packed_normal"])
     assert np.array_equal(base["visibility"]["instance_primitive_index"], no_cones["visibility"]["instance_primitive_index"])
+
+
+# ---------------------------------------------------------------------------------------------
+# sphere instances, sphere lights, environment maps
+# ---------------------------------------------------------------------------------------------
+def test_detmath_inverse_trig_against_libm():
+    rng = np.random.RandomState(11)
+    y = rng.uniform(-3, 3, 200000).astype(np.float32)
+    x = rng.uniform(-3, 3, 200000).astype(np.float32)
+    assert np.abs(orc.atan2(y, x) - np.arctan2(y.astype(np.float64), x.astype(np.float64))).max() < 6e-7
+    # stable_atan2's x == 0 rule (common.h:134-136) and the axes
+    assert orc.atan2(np.float32([0, 1, -1, 0, 0]), np.float32([0, 0, 0, 1, -1])).tolist() == [0.0, np.float32(np.pi / 2), -np.float32(np.pi / 2), 0.0, np.float32(np.pi)]
+    c = np.concatenate([rng.uniform(-1, 1, 200000), [-1, 1, 0, 0.5, -0.5]]).astype(np.float32)
+    assert np.abs(orc.acos(c) - np.arccos(c.astype(np.float64))).max() < 5e-7
+    assert np.abs(orc.asin(c) - np.arcsin(c.astype(np.float64))).max() < 5e-7
+
+
+def sphere_soup(seed, n_spheres=12):
+    sc0 = soup_scene(seed, n_meshes=3, tris=150)
+    b = sc0.builder
+    rng = np.random.RandomState(seed + 100)
+    m = b.add_material((0.5, 0.5, 0.5))
+    for _ in range(n_spheres):
+        b.add_sphere(m, rng.uniform(0.1, 0.8), translate(rng.uniform(-2, 2, 3)))
+    return b.build()
+
+
+def test_spheres_in_the_trace_contract():
+    sc = sphere_soup(3)
+    o = orc.OracleScene(sc)
+    rays = random_rays(6000, 5)
+    h_bvh, _ = o.trace(rays, any_hit=False, brute=False)
+    h_brute, _ = o.trace(rays, any_hit=False, brute=True)
+    for f in ("instance_primitive_index", "t", "b1", "b2"):
+        assert np.array_equal(h_bvh[f].view(np.uint32), h_brute[f].view(np.uint32)), f
+    a_bvh, _ = o.trace(rays, any_hit=True, brute=False)
+    a_brute, _ = o.trace(rays, any_hit=True, brute=True)
+    assert np.array_equal(a_bvh["instance_primitive_index"], a_brute["instance_primitive_index"])
+    ip = h_bvh["instance_primitive_index"]
+    on_sphere = (ip != wire.MISS) & ((ip >> 16) == 0xFFFF)
+    assert on_sphere.sum() > 300
+    # a sphere hit lies on its sphere: |o + t d - c| = r
+    inst = ip[on_sphere] & 0xFFFF
+    centre = sc.transforms["m"][inst][:, :, 3]
+    radius = sc.instances["packed"][inst, 2].astype(np.uint32).view(np.float32)
+    p = rays["origin"][on_sphere] + rays["direction"][on_sphere] * h_bvh["t"][on_sphere, None]
+    assert np.abs(np.linalg.norm(p - centre, axis=1) - radius).max() < 2e-5
+    # rays that start inside a sphere leave through the far root
+    inside = np.zeros(1, wire.Ray)
+    inside["origin"], inside["direction"], inside["tmax"] = centre[0], (0, 0, 1), np.inf
+    only = SceneBuilder("one")
+    only.add_sphere(only.add_material((1, 1, 1)), float(radius[0]), translate(centre[0]))
+    h, _ = orc.OracleScene(only.build()).trace(inside)
+    assert abs(h["t"][0] - radius[0]) < 1e-6
+
+
+def plane_and_sphere_light(rho, Le, r, d):
+    b = SceneBuilder("plane_sphere_light")
+    white = b.add_material((rho, rho, rho))
+    light = b.add_emitter((Le, Le, Le))
+    S = 50.0
+    b.add_instance(b.add_mesh(*scenes._quad((-S, 0, S), (S, 0, S), (S, 0, -S), (-S, 0, -S), (0, 1, 0))), white)
+    b.add_sphere(light, r, translate((0.0, d, 0.0)))
+    return b.build()
+
+
+@pytest.mark.parametrize("flags", ["default", "~nee", "~samplebsdfs", "uniformspheresampling", "~defershadowrays"])
+def test_sphere_light_matches_the_closed_form(flags):
+    """A sphere light of radius r whose centre is d above a diffuse floor point: E = pi Le (r/d)^2, L = rho Le (r/d)^2,
+    with cone sampling (default), uniform area sampling, and either estimator alone."""
+    rho, Le, r, d = 0.7, 9.0, 0.4, 1.5
+    sc = plane_and_sphere_light(rho, Le, r, d)
+    o = orc.OracleScene(sc)
+    # seen from the same steep direction as the form-factor test: the Disney diffuse lobe is Lambertian only to ~1 % there
+    fr = camera.Frame(8, 8, np.radians(0.05), (0.3, 0.5, 0.0), (0.0, 0.0, 0.0), up=(0, 0, 1))
+    pc = wire.default_push_constants(8, 8, sc.light_count)
+    pc.gMaxDiffuseVertices = 1
+    f = wire.DEFAULT_SAMPLING_FLAGS
+    if flags == "uniformspheresampling":
+        f |= wire.flag_mask("eUniformSphereSampling")
+    elif flags != "default":
+        f &= ~wire.flag_mask({"~nee": "eNEE", "~samplebsdfs": "eSampleBSDFs", "~defershadowrays": "eDeferShadowRays"}[flags])
+    out = o.render(fr, pc, f, 0, 2048, aovs=False)
+    got = out["radiance"][..., 0].astype(np.float64).mean()
+    want = rho * Le * (r / d) ** 2
+    assert abs(got / want - 1) < 0.02, (got, want)
+
+
+def sphere_under_sky(rho, value, image):
+    b = SceneBuilder("furnace_env")
+    b.add_sphere(b.add_material((rho, rho, rho)), 1.0, translate((0, 0, 0)))
+    b.set_environment(value, None if image is None else b.add_image(image))
+    return b.build()
+
+
+def test_environment_estimators_agree():
+    """A diffuse sphere under a uniform environment L: the background shows L exactly, and the three estimators of the
+    lat-long image path (dist2d light sampling + MIS, light sampling alone, BSDF sampling alone) agree on the sphere,
+    as does BSDF sampling under the image-less environment of the same radiance. (The Disney diffuse lobe is not
+    Lambertian, so the value itself is not rho L.) The image-less environment is not checked with light sampling: its
+    direction mapping is biased upstream (sample_uniform_sphere's angles are fed to spherical_uv_to_cartesian as if
+    they were uv, environment.h:58-62), and that bias is restated, not fixed."""
+    rho, L = 0.6, 2.5
+    fr = camera.Frame(24, 24, np.radians(35.0), (0.0, 0.0, 5.0), (0.0, 0.0, 0.0))
+    D = wire.DEFAULT_SAMPLING_FLAGS
+    means = {}
+    for kind, image, f in (
+        ("image mis", True, D),
+        ("image light sampling", True, D & ~wire.flag_mask("eSampleBSDFs")),
+        ("image bsdf sampling", True, D & ~wire.flag_mask("eNEE")),
+        ("constant bsdf sampling", False, D & ~wire.flag_mask("eNEE")),
+    ):
+        sc = sphere_under_sky(rho, (L, L, L), np.ones((8, 16, 4), np.float32) if image else None)
+        pc = wire.default_push_constants(24, 24, sc.light_count)
+        pc.gEnvironmentMaterialAddress = sc.environment_address
+        pc.gMaxDiffuseVertices = 1
+        out = orc.OracleScene(sc).render(fr, pc, f, 0, 512)
+        on = out["visibility"]["instance_primitive_index"] != wire.MISS
+        assert 100 < on.sum() < 400
+        rad = out["radiance"][..., 0].astype(np.float64)
+        assert np.allclose(rad[~on], L, rtol=1e-6)
+        means[kind] = rad[on].mean()
+    ref = means["image bsdf sampling"]
+    assert 0.85 * rho * L < ref < 1.05 * rho * L
+    for kind, m in means.items():
+        assert abs(m / ref - 1) < 0.01, means
+
+
+def test_build_distributions_follows_dist2():
+    img = scenes.sky_image(32, 16)
+    pdf_m, pdf_r, cdf_m, cdf_r = build_distributions(img)
+    H, W = 16, 32
+    assert pdf_m.shape == (H,) and pdf_r.shape == (H * W,) and cdf_m.shape == (H + 1,) and cdf_r.shape == (H * (W + 1),)
+    cr = cdf_r.reshape(H, W + 1)
+    assert cdf_m[0] == 0 and cdf_m[-1] == 1 and np.all(np.diff(cdf_m) >= 0)
+    assert np.all(cr[:, 0] == 0) and np.all(cr[:, -1] == 1) and np.all(np.diff(cr, axis=1) >= -1e-7)
+    assert abs(pdf_m.sum() - 1) < 1e-5 and np.abs(pdf_r.reshape(H, W).sum(1) - 1).max() < 1e-5
+    # the sun's row carries most of the probability
+    assert pdf_m.argmax() == int(0.25 * H)
+    # an all-black image falls back to the uniform tables (dist2.h:112-119,142-149)
+    z = build_distributions(np.zeros((4, 8, 4), np.float32))
+    assert np.allclose(z[0], 0.25) and np.allclose(z[1], 0.125) and np.allclose(z[2], [0, 0.25, 0.5, 0.75, 1])
