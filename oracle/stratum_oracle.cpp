@@ -1933,10 +1933,11 @@ void parallel_rows(uint32_t rows, int threads, F fn) {
 extern "C" {
 
 orc_scene* orc_scene_create(const sthip_scene_desc* d) {
-  if (!d || !d->gVertices || !d->gIndices || !d->gInstances || !d->gInstanceTransforms || !d->gInstanceInverseTransforms || !d->gMaterialData) return nullptr;
+  if (!d || !d->gInstances || !d->gInstanceTransforms || !d->gInstanceInverseTransforms || !d->gMaterialData) return nullptr;
+  if ((d->vertex_count && !d->gVertices) || (d->indices_bytes && !d->gIndices)) return nullptr;
   orc_scene* sc = new orc_scene();
-  sc->vertices.assign(d->gVertices, d->gVertices + d->vertex_count);
-  sc->indices.assign((const uint8_t*)d->gIndices, (const uint8_t*)d->gIndices + d->indices_bytes);
+  if (d->vertex_count) sc->vertices.assign(d->gVertices, d->gVertices + d->vertex_count);
+  if (d->indices_bytes) sc->indices.assign((const uint8_t*)d->gIndices, (const uint8_t*)d->gIndices + d->indices_bytes);
   sc->indices.resize(sc->indices.size() + 8, 0);  // Load2 at the tail of a 16-bit index buffer
   sc->instances.resize(d->instance_count);
   for (uint32_t i = 0; i < d->instance_count; i++) sc->instances[i].d = d->gInstances[i];

@@ -273,8 +273,10 @@ static size_t stack_bytes(const sthip_ctx* ctx);
 
 int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
-  if (!s || !s->gVertices || !s->gIndices || !s->gInstances || !s->gInstanceTransforms || !s->gInstanceInverseTransforms || !s->gMaterialData || s->instance_count == 0)
+  if (!s || !s->gInstances || !s->gInstanceTransforms || !s->gInstanceInverseTransforms || !s->gMaterialData || s->instance_count == 0)
     return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: a required array is NULL or there are no instances");
+  if ((s->vertex_count && !s->gVertices) || (s->indices_bytes && !s->gIndices))  // a scene of sphere instances alone has neither
+    return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: vertex_count / indices_bytes > 0 but the array is NULL");
   if (s->instance_count > 0xFFFF) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: more than 65535 instances (16-bit instance index, scene.h:23)");
   if (s->light_count && !s->gLightInstances) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: light_count > 0 but gLightInstances is NULL");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -314,7 +316,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
   ctx->stats.bvh_build_gpu_ms = built.gpu_build_ms;
   const uint32_t n = s->instance_count;
-  HIP_TRY(ctx, ctx->vertices.ensure(s->vertex_count));
+  HIP_TRY(ctx, ctx->vertices.ensure(std::max(1u, s->vertex_count)));
   HIP_TRY(ctx, ctx->indices.ensure((size_t)s->indices_bytes + 8));
   HIP_TRY(ctx, ctx->instances.ensure(n));
   HIP_TRY(ctx, ctx->xf.ensure(n));
@@ -322,9 +324,9 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   HIP_TRY(ctx, ctx->motion_xf.ensure(n));
   HIP_TRY(ctx, ctx->materials.ensure(s->material_bytes));
   HIP_TRY(ctx, ctx->lights.ensure(std::max(1u, s->light_count)));
-  HIP_TRY(ctx, hipMemcpy(ctx->vertices.p, s->gVertices, (size_t)s->vertex_count * sizeof(sthip_PackedVertexData), hipMemcpyHostToDevice));
+  if (s->vertex_count) HIP_TRY(ctx, hipMemcpy(ctx->vertices.p, s->gVertices, (size_t)s->vertex_count * sizeof(sthip_PackedVertexData), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemset(ctx->indices.p, 0, (size_t)s->indices_bytes + 8));
-  HIP_TRY(ctx, hipMemcpy(ctx->indices.p, s->gIndices, s->indices_bytes, hipMemcpyHostToDevice));
+  if (s->indices_bytes) HIP_TRY(ctx, hipMemcpy(ctx->indices.p, s->gIndices, s->indices_bytes, hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(ctx->instances.p, s->gInstances, (size_t)n * 16, hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(ctx->xf.p, s->gInstanceTransforms, (size_t)n * 48, hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(ctx->inv_xf.p, s->gInstanceInverseTransforms, (size_t)n * 48, hipMemcpyHostToDevice));

@@ -371,12 +371,22 @@ struct Image {
 // MaterialResources, image_value.h:34-66: images get their gImages index the first time a material stores them
 struct MaterialResources {
   std::vector<const Image*> image4s;
+  std::vector<std::pair<const std::vector<float>*, uint32_t>> distribution_data_map;  // table -> offset in gDistributions
+  uint32_t distribution_data_size = 0;
   uint32_t get_index(const component_ptr<Image>& image) {
     if (!image) return ~0u;
     for (size_t i = 0; i < image4s.size(); i++)
       if (image4s[i] == image.get()) return (uint32_t)i;
     image4s.push_back(image.get());
     return (uint32_t)image4s.size() - 1;
+  }
+  uint32_t get_index(const std::vector<float>& data) {  // image_value.h:56-66
+    for (const auto& e : distribution_data_map)
+      if (e.first == &data) return e.second;
+    const uint32_t r = distribution_data_size;
+    distribution_data_map.emplace_back(&data, r);
+    distribution_data_size += (uint32_t)data.size();
+    return r;
   }
 };
 struct ImageValue4 {
@@ -425,6 +435,87 @@ struct MeshPrimitive {
   component_ptr<Material> mMaterial;
   component_ptr<Mesh> mMesh;
 };
+struct SpherePrimitive {  // Scene.hpp:34-37
+  component_ptr<Material> mMaterial;
+  float mRadius = 1;
+};
+
+// dist2.h:80-154 build_distributions for a lat-long RGBA32F image: f(x, y) = luminance * sin(pi (y + 0.5) / H) is a
+// double (float luminance times double sin), every running sum is stored as float, exactly as the reference's loops
+inline void build_distributions(const Image& img, std::vector<float>& pdf_marginals, std::vector<float>& pdf_rows, std::vector<float>& cdf_marginals, std::vector<float>& cdf_rows) {
+  const uint32_t W = img.width, H = img.height;
+  pdf_marginals.assign(H, 0.f);
+  pdf_rows.assign((size_t)W * H, 0.f);
+  cdf_marginals.assign(H + 1, 0.f);
+  cdf_rows.assign((size_t)(W + 1) * H, 0.f);
+  const float invHeight = 1 / (float)H;
+  auto f = [&](uint32_t x, uint32_t y) -> double {
+    const float* c = &img.pixels[4 * ((size_t)y * W + x)];
+    const float lum = (c[0] * 0.2126f + c[1] * 0.7152f) + c[2] * 0.0722f;
+    return lum * std::sin(M_PI * (y + 0.5f) * invHeight);
+  };
+  for (uint32_t y = 0; y < H; y++) {
+    float* row = &cdf_rows[(size_t)y * (W + 1)];
+    row[0] = 0;
+    for (uint32_t x = 0; x < W; x++) row[x + 1] = (float)(row[x] + f(x, y));
+    const float integral = row[W];
+    if (integral > 0) {
+      for (uint32_t x = 0; x < W; x++) row[x] /= integral;
+      for (uint32_t x = 0; x < W; x++) pdf_rows[(size_t)y * W + x] = (float)(f(x, y) / integral);
+    } else {
+      for (uint32_t x = 0; x < W; x++) {
+        pdf_rows[(size_t)y * W + x] = float(1) / float(W);
+        row[x] = float(x) / float(W);
+      }
+      row[W] = 1;
+    }
+  }
+  cdf_marginals[0] = 0;
+  for (uint32_t y = 0; y < H; y++) cdf_marginals[y + 1] = cdf_marginals[y] + cdf_rows[(size_t)y * (W + 1) + W];
+  const float total_values = cdf_marginals[H];
+  if (total_values > 0) {
+    for (uint32_t y = 0; y < H; y++) cdf_marginals[y] /= total_values;
+    cdf_marginals[H] = 1;
+    for (uint32_t y = 0; y < H; y++) pdf_marginals[y] = cdf_rows[(size_t)y * (W + 1) + W] / total_values;
+  } else {
+    for (uint32_t y = 0; y < H; y++) {
+      pdf_marginals[y] = float(1) / float(H);
+      cdf_marginals[y] = float(y) / float(H);
+    }
+    cdf_marginals[H] = 1;
+  }
+  for (uint32_t y = 0; y < H; y++) cdf_rows[(size_t)y * (W + 1) + W] = 1;
+}
+
+// environment.h:8-25,96-150: constant radiance, or a lat-long image scaled by `value` with its sampling tables
+struct Environment {
+  float value[3] = {0, 0, 0};
+  component_ptr<Image> image;
+  std::vector<float> marginal_pdf, row_pdf, marginal_cdf, row_cdf;
+  bool is_zero() const { return value[0] == 0 && value[1] == 0 && value[2] == 0; }
+  void store(std::vector<uint32_t>& bytes, MaterialResources& resources) const {
+    for (int j = 0; j < 3; j++) {
+      uint32_t u;
+      std::memcpy(&u, &value[j], 4);
+      bytes.push_back(u);
+    }
+    bytes.push_back(resources.get_index(image));
+    if (image) {
+      bytes.push_back(resources.get_index(marginal_pdf));
+      bytes.push_back(resources.get_index(row_pdf));
+      bytes.push_back(resources.get_index(marginal_cdf));
+      bytes.push_back(resources.get_index(row_cdf));
+    }
+  }
+};
+// load_environment, environment.h:99-150, for an image that is already in memory
+inline Environment make_environment(const component_ptr<Image>& image, float r = 1, float g = 1, float b = 1) {
+  Environment e;
+  e.value[0] = r, e.value[1] = g, e.value[2] = b;
+  e.image = image;
+  if (image) build_distributions(*image, e.marginal_pdf, e.row_pdf, e.marginal_cdf, e.row_cdf);
+  return e;
+}
 struct Rect2D {
   int32_t x = 0, y = 0;
   uint32_t width = 0, height = 0;
@@ -486,6 +577,7 @@ class Scene {
     std::vector<Node*> mInstanceNodes;
     MaterialResources mResources;
     std::vector<sthip_image_desc> mImageDescs;
+    std::vector<float> mDistributionData;  // gDistributions, Scene.cpp:670-683
     uint32_t mEnvironmentMaterialAddress = ~0u;
     uint32_t mMaterialCount = 0;
     uint32_t mEmissivePrimitiveCount = 0;
@@ -506,6 +598,8 @@ class Scene {
       d.light_count = (uint32_t)mLightInstanceMap.size();
       d.gImages = mImageDescs.data();
       d.image_count = (uint32_t)mImageDescs.size();
+      d.gDistributions = mDistributionData.empty() ? nullptr : mDistributionData.data();
+      d.distribution_count = (uint32_t)mDistributionData.size();
       return d;
     }
   };
@@ -576,7 +670,51 @@ class Scene {
       sd->mInstanceInverseTransforms.push_back(inv);
       sd->mInstanceMotionTransforms.push_back(tmul(transform, inv));  // make_instance_motion_transform(inv, prev = current), scene.h:49
     });
+    // sphere instances, Scene.cpp:511-553 (after every mesh instance)
+    mNode.root().for_each_descendant<SpherePrimitive>([&](const component_ptr<SpherePrimitive>& prim) {
+      if (!prim->mMaterial) return;
+      auto mit = materialMap.find(prim->mMaterial.get());
+      if (mit == materialMap.end()) {
+        mit = materialMap.emplace(prim->mMaterial.get(), (uint32_t)(sd->mMaterialData.size() * sizeof(uint32_t))).first;
+        prim->mMaterial->store(sd->mMaterialData, sd->mResources);
+        sd->mMaterialCount++;
+      }
+      if (prim->mMaterial->emission() > 0) sd->mEmissivePrimitiveCount++;
+      TransformData transform = node_to_world(prim.node());
+      // :520-521: the radius is scaled by the DETERMINANT of the 3x3 block, the instance keeps only the translation
+      const float(*m)[4] = transform.m;
+      const float det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+      const float r = prim->mRadius * det;
+      TransformData t{};
+      t.m[0][0] = t.m[1][1] = t.m[2][2] = 1;
+      t.m[0][3] = m[0][3], t.m[1][3] = m[1][3], t.m[2][3] = m[2][3];
+      InstanceData inst{};  // make_instance_sphere, scene.h:62-70
+      inst.packed[0] = STHIP_INSTANCE_TYPE_SPHERE | (mit->second << 4);
+      inst.packed[1] = 0xFFFu;
+      std::memcpy(&inst.packed[2], &r, 4);
+      const uint32_t instance_index = (uint32_t)sd->mInstances.size();
+      if (prim->mMaterial->emission() * (4 * M_PI * r * r) > 0) {
+        inst.packed[1] = (inst.packed[1] & ~0xFFFu) | ((uint32_t)sd->mLightInstanceMap.size() & 0xFFFu);
+        sd->mLightInstanceMap.push_back(instance_index);
+      }
+      sd->mInstances.push_back(inst);
+      sd->mInstanceNodes.push_back(&prim.node());
+      const TransformData inv = inverse(t);
+      sd->mInstanceTransforms.push_back(t);
+      sd->mInstanceInverseTransforms.push_back(inv);
+      sd->mInstanceMotionTransforms.push_back(tmul(t, inv));
+    });
+    // environment material, Scene.cpp:631-640: the first Environment whose value is not zero
+    mNode.root().for_each_descendant<Environment>([&](const component_ptr<Environment>& environment) {
+      if (environment && !environment->is_zero() && sd->mEnvironmentMaterialAddress == ~0u) {
+        sd->mEnvironmentMaterialAddress = (uint32_t)(sd->mMaterialData.size() * sizeof(uint32_t));
+        sd->mMaterialCount++;
+        environment->store(sd->mMaterialData, sd->mResources);
+      }
+    });
     for (const Image* im : sd->mResources.image4s) sd->mImageDescs.push_back(sthip_image_desc{im->pixels.data(), im->width, im->height});
+    sd->mDistributionData.resize(sd->mResources.distribution_data_size);
+    for (const auto& e : sd->mResources.distribution_data_map) std::copy(e.first->begin(), e.first->end(), sd->mDistributionData.begin() + e.second);  // Scene.cpp:679-680
     mSceneData = sd;
     mDirty = false;
   }
@@ -653,7 +791,7 @@ class BDPT {
     if (sthip_scene_upload(mCtx, &d) != STHIP_OK) throw std::runtime_error(std::string("sthip_scene_upload: ") + sthip_last_error(mCtx));
     mBound = scene->data().get();
     mPushConstants.gLightCount = d.light_count;                    // BDPT.cpp:396
-    mPushConstants.gEnvironmentMaterialAddress = 0xFFFFFFFFu;      // no environment
+    mPushConstants.gEnvironmentMaterialAddress = scene->data()->mEnvironmentMaterialAddress;  // BDPT.cpp:393
   }
 
   // BDPT::render (BDPT.cpp:423-838) for the hot path: one sample per pixel per call, seed = frame number (:480)
@@ -679,8 +817,14 @@ class BDPT {
     pc.gViewCount = f.view_count;
     pc.gLightPathCount = width * height;  // BDPT.cpp:469-470
     uint32_t scene_flags = 0;             // BDPT.cpp:486-503
-    if (pc.gLightCount) scene_flags |= STHIP_BDPT_FLAG_HAS_EMISSIVES;
-    pc.gEnvironmentSampleProbability = 0;
+    if (pc.gEnvironmentMaterialAddress != ~0u)
+      scene_flags |= STHIP_BDPT_FLAG_HAS_ENVIRONMENT;
+    else
+      pc.gEnvironmentSampleProbability = 0;
+    if (pc.gLightCount)
+      scene_flags |= STHIP_BDPT_FLAG_HAS_EMISSIVES;
+    else
+      pc.gEnvironmentSampleProbability = 1;
     pc.gMaxNullCollisions = 0;
     Frame fr;
     fr.width = width;

@@ -7,6 +7,8 @@ and the light-instance list — in exactly the reference's layouts (include/sthi
 """
 import ctypes as C
 
+import math
+
 import numpy as np
 
 from . import wire
@@ -337,8 +339,8 @@ class SceneBuilder:
                 dist = np.concatenate(tables).astype(np.float32)
             mat_bytes = np.concatenate([mat_bytes, np.concatenate(parts).view(np.uint8)])
         sd = SceneData(
-            np.ascontiguousarray(vertices) if len(vertices) else np.zeros(1, wire.PackedVertexData),
-            indices if indices.size else np.zeros(4, np.uint8),
+            np.ascontiguousarray(vertices),
+            indices,
             inst,
             xf,
             inv,
@@ -363,7 +365,9 @@ def build_distributions(image):
     lum = (img[..., 0] * np.float32(0.2126) + img[..., 1] * np.float32(0.7152)) + img[..., 2] * np.float32(0.0722)
     inv_h = np.float64(np.float32(1.0) / np.float32(H))
     y = np.arange(H, dtype=np.float32) + np.float32(0.5)
-    f = lum.astype(np.float64) * np.sin(np.pi * y.astype(np.float64) * inv_h)[:, None]
+    # libm's sin (math.sin), the function the C++ hosts call: numpy's vectorised sin may differ in the last bit
+    sin_row = np.array([math.sin(float(v)) for v in (np.pi * y.astype(np.float64) * inv_h)], np.float64)
+    f = lum.astype(np.float64) * sin_row[:, None]
     cdf_rows = np.zeros((H, W + 1), np.float32)
     for x in range(W):
         cdf_rows[:, x + 1] = (cdf_rows[:, x].astype(np.float64) + f[:, x]).astype(np.float32)
@@ -425,10 +429,21 @@ def dump_description(path, scene, frame):
         for mesh, mat, m in builder._instances:
             f.write(struct.pack("<II", mesh, mat))
             f.write(m[:3, :].astype("<f4").tobytes())
+        f.write(struct.pack("<I", len(builder._spheres)))
+        for mat, m, radius in builder._spheres:
+            f.write(struct.pack("<If", mat, radius))
+            f.write(m[:3, :].astype("<f4").tobytes())
+        if builder._environment is None:
+            f.write(struct.pack("<I", 0))
+        else:
+            value, image = builder._environment
+            f.write(struct.pack("<I", 1 if image is None else 2))
+            f.write(value.astype("<f4").tobytes())
+            f.write(struct.pack("<I", 0xFFFFFFFF if image is None else int(image)))
         f.write(frame.views.tobytes())
         f.write(frame.view_transforms.tobytes())
         f.write(struct.pack("<II", frame.width, frame.height))
-        for a in (scene.vertices, scene.indices, scene.instances, scene.transforms, scene.inverse_transforms, scene.motion_transforms, scene.materials, scene.lights):
+        for a in (scene.vertices, scene.indices, scene.instances, scene.transforms, scene.inverse_transforms, scene.motion_transforms, scene.materials, scene.lights, scene.distributions):
             b = np.ascontiguousarray(a).tobytes()
             f.write(struct.pack("<Q", len(b)))
             f.write(b)

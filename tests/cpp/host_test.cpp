@@ -92,6 +92,23 @@ int main(int argc, char** argv) {
       n.make_component<TransformData>(t);
       n.make_component<MeshPrimitive>(MeshPrimitive{materials.at(mat), meshes.at(mesh)});
     }
+    // sphere primitives (Scene.hpp:34-37) and the environment component (environment.h)
+    const uint32_t n_sph = r.get<uint32_t>();
+    for (uint32_t i = 0; i < n_sph; i++) {
+      const uint32_t mat = r.get<uint32_t>();
+      const float radius = r.get<float>();
+      const TransformData t = r.get<TransformData>();
+      Node& n = scene_node.make_child("sphere" + std::to_string(i));
+      n.make_component<TransformData>(t);
+      n.make_component<SpherePrimitive>(SpherePrimitive{materials.at(mat), radius});
+    }
+    const uint32_t env_kind = r.get<uint32_t>();
+    if (env_kind) {
+      float value[3];
+      for (float& v : value) v = r.get<float>();
+      const uint32_t image = r.get<uint32_t>();
+      scene_node.make_child("environment").make_component<Environment>(make_environment(env_kind == 2 ? images.at(image) : component_ptr<Image>(), value[0], value[1], value[2]));
+    }
     const ViewData view = r.get<ViewData>();
     const TransformData view_xf = r.get<TransformData>();
     const uint32_t W = r.get<uint32_t>(), H = r.get<uint32_t>();
@@ -116,6 +133,7 @@ int main(int argc, char** argv) {
       check("gInstanceMotionTransforms", sd.mInstanceMotionTransforms.data(), sd.mInstanceMotionTransforms.size() * sizeof(TransformData));
       check("gMaterialData", sd.mMaterialData.data(), sd.mMaterialData.size() * 4);
       check("gLightInstances", sd.mLightInstanceMap.data(), sd.mLightInstanceMap.size() * 4);
+      check("gDistributions", sd.mDistributionData.data(), sd.mDistributionData.size() * 4);
       // event order: Scene (eDefault) before BDPT (eAlmostLast) — checked without a device through a probe
       std::vector<int> order;
       Node& probe = app.node().make_child("probe");
