@@ -113,10 +113,52 @@ def main():
     dev_out = {"radiance": radiance.data_ptr()}
     seeds_per_step = world  # weak scaling: every rank renders one frame's worth of paths per step
 
-    def step(i):
-        r.render(frame, seed_begin=i * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
-        if dist is not None:
-            shard.reduce_framebuffer(radiance, dist, dst=0)  # the one exchange of the path: sum of disjoint tiles
+    if world == 1:
+
+        def step(i):
+            r.render(frame, seed_begin=i * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
+
+        def drain():
+            pass
+
+    else:
+        # Sharded frame: every rank renders only its tiles (packed, 1 / world of the frame) and the one exchange of the
+        # path is a gather of those to rank 0, which scatters them into the image (sthip_assemble_tiles). The gather of
+        # step i runs on RCCL's stream while step i + 1 renders into the other buffer.
+        stride = shard.slot_count(W, H, 0, world)  # rank 0 owns the most tiles: equal-size messages
+        packed = [torch.zeros((stride, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        gathered = [torch.zeros((world, stride, 4), dtype=torch.float32, device="cuda") if rank == 0 else None for _ in range(2)]
+        host_staged = backend != "nccl"  # gloo rehearsal: collectives on CPU tensors
+        pending = [None, None]
+
+        def finish(k):
+            if pending[k] is None:
+                return
+            work, g_cpu = pending[k]
+            if work is not None:
+                work.wait()
+            if rank == 0:
+                if g_cpu is not None:
+                    gathered[k].copy_(g_cpu)
+                r.assemble_tiles(frame, gathered[k].data_ptr(), stride, radiance.data_ptr())
+            pending[k] = None
+
+        def step(i):
+            k = i & 1
+            finish(k)  # buffer k is free again once its gather has been consumed
+            r.render(frame, seed_begin=i * seeds_per_step, seed_count=seeds_per_step, device_outputs={"radiance": packed[k].data_ptr()}, packed_tiles=True)
+            if host_staged:
+                src = packed[k].cpu()
+                g_cpu = torch.zeros((world, stride, 4)) if rank == 0 else None
+                shard.gather_tiles(src, g_cpu, dist, dst=0)
+                pending[k] = (None, g_cpu)
+            else:
+                pending[k] = (shard.gather_tiles(packed[k], gathered[k], dist, dst=0, async_op=True), None)
+            finish(k ^ 1)  # the previous step's tiles have arrived meanwhile: assemble them behind this render
+
+        def drain():
+            finish(0)
+            finish(1)
 
     def barrier():
         if dist is not None:
@@ -125,11 +167,13 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    drain()
     barrier()
     t0 = time.perf_counter()
     rays_local = 0
     for i in range(args.steps):
         step(args.warmup + i)
+    drain()
     barrier()
     dt = time.perf_counter() - t0
     # rays of the timed region: re-run the same steps with the counters read back (untimed)
@@ -246,7 +290,7 @@ def main():
                 "workload": "procedural %s, %d triangles, %dx%d, %d sample(s)/pixel/step, default BDPT flags, pixel-tile shard 64x32 over %d GPU(s)"
                 % (args.scene, sc.triangle_count, W, H, seeds_per_step, world),
                 "rays_per_step": int(rays_all / args.steps),
-                "parallelism": "tile-shard x%d + RCCL reduce" % world if world > 1 else "single GPU",
+                "parallelism": "tile-shard x%d + RCCL gather of the packed tiles" % world if world > 1 else "single GPU",
             },
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -91,8 +91,11 @@ typedef struct sthip_frame_desc {
  * gRadiance is required, the others may be NULL. With device_ptrs = 1 every non-NULL
  * pointer is a device pointer on the context's GPU (no copy; results are complete when
  * the call's stream work is complete, see sthip_set_stream). */
+#define STHIP_LAYOUT_IMAGE 0u       /* gRadiance is the W x H image; pixels the shard does not own are zero */
+#define STHIP_LAYOUT_SHARD_TILES 1u /* gRadiance holds only the shard's tiles, in slot order: sthip_shard_slot_count() float4 */
 typedef struct sthip_outputs {
   uint32_t device_ptrs;
+  uint32_t radiance_layout; /* STHIP_LAYOUT_*: the packed form is what ranks exchange (sthip_assemble_tiles) */
   float* gRadiance;                  /* RGBA32F, W*H*4: rgb = mean over the seeds of this call, a = sample count */
   float* gAlbedo;                    /* RGBA32F */
   sthip_VisibilityInfo* gVisibility; /* W*H */
@@ -129,6 +132,16 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* push_constants, 
  * (including alpha) so that a sum-reduce over ranks assembles the frame.
  * shard_count = 1 (default) renders everything. */
 int sthip_set_shard(sthip_ctx* ctx, uint32_t shard_rank, uint32_t shard_count, uint32_t tile_w, uint32_t tile_h);
+
+/* The exchange step of a sharded frame without the zero padding: each rank renders with
+ * outputs.radiance_layout = STHIP_LAYOUT_SHARD_TILES (sthip_shard_slot_count() float4 entries, 1/shard_count of the
+ * frame), the ranks' buffers are gathered on one GPU (RCCL gather / all_gather, rank r at packed + r * rank_stride
+ * float4 entries; rank_stride >= rank 0's slot count, which is the largest), and sthip_assemble_tiles scatters them into
+ * the W x H image on that GPU's context (device pointers, enqueued on the context's stream). */
+uint32_t sthip_shard_slot_count(uint32_t width, uint32_t height, uint32_t shard_rank, uint32_t shard_count, uint32_t tile_w,
+                                uint32_t tile_h);
+int sthip_assemble_tiles(sthip_ctx* ctx, const float* packed, uint64_t rank_stride, uint32_t shard_count, uint32_t tile_w,
+                         uint32_t tile_h, uint32_t width, uint32_t height, float* frame);
 
 /* ---- the traversal contract on its own (T1/T2 of SURVEY.md §8a; intersection.hlsli:65-239) ---- */
 typedef struct sthip_ray {

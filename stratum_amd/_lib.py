@@ -27,6 +27,8 @@ EXPORTS = [
     "sthip_trace_rays",
     "sthip_get_stats",
     "sthip_set_option",
+    "sthip_shard_slot_count",
+    "sthip_assemble_tiles",
     "sthip_tonemap",
     "sthip_image_compare",
     "sthip_write_hdr",
@@ -100,6 +102,10 @@ def lib():
     L.sthip_get_stats.argtypes = [C.c_void_p, C.POINTER(wire.Stats)]
     L.sthip_set_option.restype = C.c_int
     L.sthip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.sthip_shard_slot_count.restype = C.c_uint32
+    L.sthip_shard_slot_count.argtypes = [C.c_uint32] * 6
+    L.sthip_assemble_tiles.restype = C.c_int
+    L.sthip_assemble_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     L.sthip_tonemap.restype = C.c_int
     L.sthip_tonemap.argtypes = [C.c_void_p, C.POINTER(wire.TonemapDesc)]
     L.sthip_image_compare.restype = C.c_int

@@ -113,9 +113,6 @@ class BDPT:
         self._check(self._lib.sthip_scene_upload(self._h, C.byref(d)), "sthip_scene_upload")
         self._scene = scene
 
-    def set_shard(self, rank, count, tile_w=64, tile_h=32):
-        self._check(self._lib.sthip_set_shard(self._h, rank, count, tile_w, tile_h), "sthip_set_shard")
-
     def set_stream(self, stream_handle):
         self._check(self._lib.sthip_set_stream(self._h, C.c_void_p(stream_handle)), "sthip_set_stream")
 
@@ -143,16 +140,18 @@ class BDPT:
         return pc
 
     # ---- BDPT::render ----
-    def render(self, frame, seed_begin=0, seed_count=1, aovs=True, device_outputs=None):
+    def render(self, frame, seed_begin=0, seed_count=1, aovs=True, device_outputs=None, packed_tiles=False):
         """Host outputs by default (dict of numpy arrays). `device_outputs` = dict of raw device pointers
         {"radiance": ptr, ["albedo", "visibility", "depth", "prev_uv", "ray_count"]} renders in place on the
-        GPU without synchronising."""
+        GPU without synchronising. packed_tiles: "radiance" holds only this shard's tiles in slot order
+        (shard_slot_count() float4 entries) — the form ranks exchange, see assemble_tiles."""
         if self._scene is None:
             raise StratumHipError("BDPT.render before BDPT.update(scene)")
         pc = self.push_constants(frame)
         fd = frame.desc()
         o = wire.Outputs()
         out = None
+        o.radiance_layout = wire.LAYOUT_SHARD_TILES if packed_tiles else wire.LAYOUT_IMAGE
         if device_outputs is not None:
             o.device_ptrs = 1
             o.gRadiance = device_outputs["radiance"]
@@ -163,7 +162,7 @@ class BDPT:
             o.gRayCount = device_outputs.get("ray_count")
         else:
             W, H = frame.width, frame.height
-            out = {"radiance": np.zeros((H, W, 4), np.float32), "ray_count": np.zeros(2, np.uint64)}
+            out = {"radiance": np.zeros((self.shard_slot_count(frame), 4) if packed_tiles else (H, W, 4), np.float32), "ray_count": np.zeros(2, np.uint64)}
             o.device_ptrs = 0
             o.gRadiance = wire.ptr(out["radiance"])
             o.gRayCount = wire.ptr(out["ray_count"])
@@ -181,6 +180,20 @@ class BDPT:
         if out is not None:
             self._prev_result = out["radiance"]
         return out
+
+    # ---- multi-GPU assembly (include/sthip.h: sthip_shard_slot_count / sthip_assemble_tiles) ----
+    def set_shard(self, rank, count, tile_w=64, tile_h=32):
+        self._check(self._lib.sthip_set_shard(self._h, rank, count, tile_w, tile_h), "sthip_set_shard")
+        self._shard = (rank, count, tile_w, tile_h)
+
+    def shard_slot_count(self, frame, rank=None):
+        r, n, tw, th = getattr(self, "_shard", (0, 1, 64, 32))
+        return int(self._lib.sthip_shard_slot_count(frame.width, frame.height, r if rank is None else rank, n, tw, th))
+
+    def assemble_tiles(self, frame, packed_ptr, rank_stride, frame_ptr):
+        """packed_ptr: device buffer with rank r's tiles at r * rank_stride float4 entries; frame_ptr: W x H RGBA32F."""
+        _, n, tw, th = getattr(self, "_shard", (0, 1, 64, 32))
+        self._check(self._lib.sthip_assemble_tiles(self._h, packed_ptr, rank_stride, n, tw, th, frame.width, frame.height, frame_ptr), "sthip_assemble_tiles")
 
     def prev_result(self):  # BDPT.hpp:18
         return self._prev_result

@@ -638,6 +638,9 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
 
   // outputs: device pointers are written in place, host pointers go through staging buffers
   const bool dev = out->device_ptrs != 0;
+  p.out_packed = out->radiance_layout == STHIP_LAYOUT_SHARD_TILES ? 1u : 0u;
+  if (out->radiance_layout > STHIP_LAYOUT_SHARD_TILES) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: unknown radiance_layout");
+  const size_t radiance_entries = p.out_packed ? std::max<size_t>(1, p.paths_per_seed) : pixels;
   if (dev) {
     p.out_radiance = reinterpret_cast<float4*>(out->gRadiance);
     p.out_albedo = reinterpret_cast<float4*>(out->gAlbedo);
@@ -645,7 +648,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     p.out_depth = out->gDepth;
     p.out_prev_uv = reinterpret_cast<float2*>(out->gPrevUVs);
   } else {
-    HIP_TRY(ctx, ctx->out_radiance.ensure(pixels));
+    HIP_TRY(ctx, ctx->out_radiance.ensure(radiance_entries));
     p.out_radiance = ctx->out_radiance.p;
     if (out->gAlbedo) {
       HIP_TRY(ctx, ctx->out_albedo.ensure(pixels));
@@ -665,7 +668,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     }
   }
   // pixels this shard does not own are zero (sum-reduce over shards assembles the frame)
-  HIP_TRY(ctx, hipMemsetAsync(p.out_radiance, 0, pixels * 16, st));
+  HIP_TRY(ctx, hipMemsetAsync(p.out_radiance, 0, radiance_entries * 16, st));
   if (p.out_albedo) HIP_TRY(ctx, hipMemsetAsync(p.out_albedo, 0, pixels * 16, st));
   if (p.out_visibility) HIP_TRY(ctx, hipMemsetAsync(p.out_visibility, 0, pixels * 8, st));
   if (p.out_depth) HIP_TRY(ctx, hipMemsetAsync(p.out_depth, 0, pixels * 16, st));
@@ -780,7 +783,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   }
 
   if (!dev) {
-    HIP_TRY(ctx, hipMemcpyAsync(out->gRadiance, p.out_radiance, pixels * 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(out->gRadiance, p.out_radiance, radiance_entries * 16, hipMemcpyDeviceToHost, st));
     if (out->gAlbedo) HIP_TRY(ctx, hipMemcpyAsync(out->gAlbedo, p.out_albedo, pixels * 16, hipMemcpyDeviceToHost, st));
     if (out->gVisibility) HIP_TRY(ctx, hipMemcpyAsync(out->gVisibility, p.out_visibility, pixels * 8, hipMemcpyDeviceToHost, st));
     if (out->gDepth) HIP_TRY(ctx, hipMemcpyAsync(out->gDepth, p.out_depth, pixels * 16, hipMemcpyDeviceToHost, st));
@@ -804,6 +807,30 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     ctx->stats.ms_total = ms_trace + ms_shade + ms_other;
     ctx->stats.launches_trace = launches_trace;
   }
+  return STHIP_OK;
+}
+
+// ---- multi-GPU assembly: the packed tiles of every shard -> the frame ----
+
+uint32_t sthip_shard_slot_count(uint32_t width, uint32_t height, uint32_t shard_rank, uint32_t shard_count, uint32_t tile_w, uint32_t tile_h) {
+  if (!width || !height || !shard_count || !tile_w || !tile_h || shard_rank >= shard_count) return 0;
+  const uint32_t tiles = ((width + tile_w - 1) / tile_w) * ((height + tile_h - 1) / tile_h);
+  const uint32_t owned = tiles > shard_rank ? (tiles - shard_rank + shard_count - 1) / shard_count : 0;
+  return owned * tile_w * tile_h;
+}
+
+int sthip_assemble_tiles(sthip_ctx* ctx, const float* packed, uint64_t rank_stride, uint32_t shard_count, uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height,
+                         float* frame) {
+  if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
+  if (!packed || !frame || !shard_count || !width || !height) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_assemble_tiles: a required argument is NULL/zero");
+  if (tile_w == 0 || tile_h == 0 || (tile_w & 7) || (tile_h & 7)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_assemble_tiles: tile size must be a multiple of 8");
+  const uint32_t slots = sthip_shard_slot_count(width, height, 0, shard_count, tile_w, tile_h);  // rank 0 owns the most tiles
+  if (rank_stride < slots) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_assemble_tiles: rank_stride is smaller than a shard's slot count");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)shard_count * slots;
+  hipLaunchKernelGGL(k_assemble_tiles, dim3((unsigned)((n + STHIP_BLOCK - 1) / STHIP_BLOCK)), dim3(STHIP_BLOCK), 0, ctx->stream, reinterpret_cast<const float4*>(packed), (size_t)rank_stride, shard_count,
+                     slots, tile_w, tile_h, width, height, reinterpret_cast<float4*>(frame));
+  HIP_TRY(ctx, hipGetLastError());
   return STHIP_OK;
 }
 

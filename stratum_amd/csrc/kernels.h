@@ -70,6 +70,7 @@ struct FrameParams {
   sthip_DepthInfo* out_depth;
   float2* out_prev_uv;
   uint32_t write_aov;
+  uint32_t out_packed;       // out_radiance holds this shard's tiles in slot order instead of the W x H image
   uint32_t count_traversal;
   uint32_t refill_idle;      // persistent trace kernels: refill when this many lanes of a wave are idle
   uint32_t inner_min_lanes;  // leave the inner-node loop when fewer lanes than this are still walking
@@ -760,7 +761,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
       }
     }
     p.accum[q] = acc;
-    if (last_seed && p.out_radiance) p.out_radiance[(size_t)py * p.pc.gOutputExtent[0] + px] = acc;
+    if (last_seed && p.out_radiance) p.out_radiance[p.out_packed ? (size_t)q : (size_t)py * p.pc.gOutputExtent[0] + px] = acc;
   }
 }
 
@@ -792,4 +793,27 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_batch(DeviceBvh bvh, cons
     atomicAdd(&counters[CNT_NODES + (ANY_HIT ? 1 : 0)], (unsigned long long)cnt.nodes);
     atomicAdd(&counters[CNT_TRIS + (ANY_HIT ? 1 : 0)], (unsigned long long)cnt.tris);
   }
+}
+
+
+// Assembles the frame from the packed tiles of every shard (sthip_assemble_tiles): entry (rank, slot) of `packed`
+// is the pixel slot_to_pixel() gives for that shard; one thread per packed entry, disjoint pixels.
+__global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const float4* packed, size_t rank_stride, uint32_t shard_count, uint32_t slots, uint32_t tile_w, uint32_t tile_h, uint32_t width,
+                                                                 uint32_t height, float4* frame) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)shard_count * slots) return;
+  const uint32_t rank = (uint32_t)(i / slots), slot = (uint32_t)(i % slots);
+  FrameParams p;  // only the fields slot_to_pixel reads
+  p.paths_per_seed = slots;
+  p.tile_w = tile_w;
+  p.tile_h = tile_h;
+  p.shard_count = shard_count;
+  p.shard_rank = rank;
+  p.tiles_x = (width + tile_w - 1) / tile_w;
+  p.tiles_y = (height + tile_h - 1) / tile_h;
+  p.pc.gOutputExtent[0] = width;
+  p.pc.gOutputExtent[1] = height;
+  uint32_t px, py;
+  if (!slot_to_pixel(p, slot, px, py)) return;
+  frame[(size_t)py * width + px] = packed[(size_t)rank * rank_stride + slot];
 }

@@ -85,6 +85,7 @@ BDPT_FLAG_HAS_MEDIA = 4
 BDPT_FLAG_TRACE_LIGHT = 8
 
 INSTANCE_TYPE_TRIANGLES, INSTANCE_TYPE_SPHERE, INSTANCE_TYPE_VOLUME = 0, 1, 2
+LAYOUT_IMAGE, LAYOUT_SHARD_TILES = 0, 1
 INVALID_INSTANCE = 0xFFFF
 MISS = 0xFFFFFFFF
 
@@ -175,6 +176,7 @@ class FrameDesc(C.Structure):
 class Outputs(C.Structure):
     _fields_ = [
         ("device_ptrs", C.c_uint32),
+        ("radiance_layout", C.c_uint32),  # LAYOUT_IMAGE / LAYOUT_SHARD_TILES
         ("gRadiance", C.c_void_p),
         ("gAlbedo", C.c_void_p),
         ("gVisibility", C.c_void_p),

@@ -436,3 +436,35 @@ def test_environment_errors(renderer):
     renderer.update(sc)
     with pytest.raises(_lib.StratumHipError, match="gDistributions"):
         renderer.render(frame)
+
+
+def test_packed_tiles_and_assembly(renderer, cornell):
+    """The exchange format of the multi-GPU path: each shard's tiles in slot order (STHIP_LAYOUT_SHARD_TILES),
+    scattered back by sthip_assemble_tiles, reproduce the unsharded frame bit for bit; the host mirror agrees."""
+    import torch
+
+    from stratum_amd import shard
+
+    sc, cam = cornell
+    renderer.update(sc)
+    W, H, world, seeds = 200, 136, 3, 2  # neither extent is a multiple of the tile size
+    frame = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+    renderer.set_shard(0, 1)
+    full = renderer.render(frame, 0, seeds, aovs=False)["radiance"]
+    stride = shard.slot_count(W, H, 0, world, 16, 8)
+    gathered = torch.zeros((world, stride, 4), dtype=torch.float32, device="cuda")
+    host = []
+    try:
+        for rank in range(world):
+            renderer.set_shard(rank, world, 16, 8)
+            assert renderer.shard_slot_count(frame) == shard.slot_count(W, H, rank, world, 16, 8)
+            renderer.render(frame, 0, seeds, device_outputs={"radiance": gathered[rank].data_ptr()}, packed_tiles=True)
+            host.append(renderer.render(frame, 0, seeds, aovs=False, packed_tiles=True)["radiance"])
+        out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        renderer.assemble_tiles(frame, gathered.data_ptr(), stride, out.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        renderer.set_shard(0, 1)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), full.view(np.uint32))
+    assert np.array_equal(shard.assemble_tiles(host, W, H, 16, 8).view(np.uint32), full.view(np.uint32))
+

@@ -26,6 +26,27 @@ def test_owner_map_partitions_the_frame():
     assert counts.max() - counts.min() <= 1
 
 
+def test_packed_tiles_cover_the_frame_once():
+    """slot_pixels (host mirror of slot_to_pixel): the packed buffers of all ranks hold every pixel exactly once, each
+    on the rank owner_map names; assemble_tiles puts them back."""
+    for (w, h, world, tw, th) in [(1920, 1080, 8, 64, 32), (100, 70, 3, 16, 8), (64, 32, 4, 64, 32), (96, 64, 2, 16, 8)]:
+        om = shard.owner_map(w, h, world, tw, th)
+        seen = np.zeros((h, w), np.int32)
+        ref = np.random.RandomState(1).rand(h, w, 4).astype(np.float32)
+        packed = []
+        for r in range(world):
+            xy = shard.slot_pixels(w, h, r, world, tw, th)
+            assert xy.shape[0] == shard.slot_count(w, h, r, world, tw, th) <= shard.slot_count(w, h, 0, world, tw, th)
+            ok = xy[:, 0] >= 0
+            assert np.all(om[xy[ok, 1], xy[ok, 0]] == r)
+            np.add.at(seen, (xy[ok, 1], xy[ok, 0]), 1)
+            buf = np.zeros((shard.slot_count(w, h, 0, world, tw, th), 4), np.float32)  # equal-size messages
+            buf[: xy.shape[0]][ok] = ref[xy[ok, 1], xy[ok, 0]]
+            packed.append(buf)
+        assert np.all(seen == 1)
+        assert np.array_equal(shard.assemble_tiles(packed, w, h, tw, th), ref)
+
+
 def _worker(rank, world, port, tmp):
     import torch
     import torch.distributed as dist
@@ -44,8 +65,17 @@ def _worker(rank, world, port, tmp):
     mine = full * shard.owned_mask(W, H, rank, world, 16, 8)[..., None]
     t = torch.from_numpy(mine.copy())
     shard.reduce_framebuffer(t, dist, dst=0)
+    # the same frame through the packed exchange: every rank sends only its tiles, rank 0 gathers and scatters
+    stride = shard.slot_count(W, H, 0, world, 16, 8)
+    xy = shard.slot_pixels(W, H, rank, world, 16, 8)
+    ok = xy[:, 0] >= 0
+    packed = np.zeros((stride, 4), np.float32)
+    packed[: xy.shape[0]][ok] = full[xy[ok, 1], xy[ok, 0]]
+    gathered = torch.zeros((world, stride, 4)) if rank == 0 else None
+    shard.gather_tiles(torch.from_numpy(packed), gathered, dist, dst=0)
     if rank == 0:
         np.save(os.path.join(tmp, "assembled.npy"), t.numpy())
+        np.save(os.path.join(tmp, "gathered.npy"), shard.assemble_tiles([g.numpy() for g in gathered], W, H, 16, 8))
         np.save(os.path.join(tmp, "full.npy"), full)
     dist.barrier()
     dist.destroy_process_group()
@@ -59,3 +89,5 @@ def test_gloo_world2_assembles_the_frame(tmp_path):
     a = np.load(tmp_path / "assembled.npy")
     b = np.load(tmp_path / "full.npy")
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    g = np.load(tmp_path / "gathered.npy")
+    assert np.array_equal(g.view(np.uint32), b.view(np.uint32))
