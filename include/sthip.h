@@ -200,6 +200,37 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value);
 
 /* ---- after the path: display transform, image metric, HDR export ---- */
 
+/* Temporal accumulation of the renderer's output over frames, what Denoiser::denoise dispatches first
+ * (src/Node/Denoiser.cpp:176-213 -> kernels/temporal_accumulation.hlsl:59-145): with `reprojection` the previous
+ * frame's accumulated colour and luminance moments are fetched at gPrevUVs with a bilinear footprint whose taps must
+ * pass the instance / normal / depth tests (:74-97), without it the same pixel is used (:102-109); then the new sample
+ * is blended in with alpha = n_new / n, n clamped by history_limit (gHistoryLimit, 0 = unlimited). The binding names
+ * are the shader's (denoiser.h). gViews is always a host pointer; the images are host pointers unless device_ptrs.
+ * (sthip_render's own N-seed mean is the same-pixel branch of this kernel applied seed by seed.) */
+typedef struct sthip_accumulate_desc {
+  uint32_t width, height;
+  uint32_t view_count;        /* gViewCount */
+  uint32_t reprojection;      /* specialisation constant gReprojection (Denoiser.cpp:76: on by default) */
+  uint32_t demodulate_albedo; /* gDemodulateAlbedo: gRadiance.rgb /= 1e-2 + gAlbedo.rgb */
+  float history_limit;        /* gHistoryLimit */
+  uint32_t device_ptrs;
+  uint32_t instance_count;    /* entries of gInstanceIndexMap */
+  const sthip_ViewData* gViews;
+  const float* gRadiance;                      /* RGBA32F: rgb = sample, a = its sample count */
+  const float* gAlbedo;                        /* RGBA32F; may be NULL unless demodulate_albedo */
+  const sthip_VisibilityInfo* gVisibility;     /* these five only with reprojection */
+  const sthip_DepthInfo* gDepth;
+  const float* gPrevUVs;                       /* RG32F */
+  const sthip_VisibilityInfo* gPrevVisibility;
+  const sthip_DepthInfo* gPrevDepth;
+  const float* gPrevAccumColor;                /* RGBA32F: rgb = mean so far, a = sample count */
+  const float* gPrevAccumMoments;              /* RG32F: mean luminance, mean squared luminance */
+  const uint32_t* gInstanceIndexMap;           /* SceneData::mInstanceIndexMap (Scene.cpp:383-385,414-418); NULL = identity */
+  float* gAccumColor;                          /* out, RGBA32F */
+  float* gAccumMoments;                        /* out, RG32F */
+} sthip_accumulate_desc;
+int sthip_accumulate(sthip_ctx* ctx, const sthip_accumulate_desc* desc);
+
 /* TonemapMode, src/Shaders/tonemap.h:8-21 */
 enum {
   STHIP_TONEMAP_RAW = 0,

@@ -250,3 +250,14 @@ def image_compare(image1, image2, metric=0, quantization=1024):
     s, o = C.c_uint32(0), C.c_uint32(0)
     lib().orc_image_compare(wire.ptr(a), wire.ptr(b), C.c_uint32(a.shape[1]), C.c_uint32(a.shape[0]), C.c_uint32(metric), C.c_uint32(quantization), C.byref(s), C.byref(o))
     return s.value, bool(o.value)
+
+
+def accumulate(frame_out, history, views, reprojection=True, demodulate_albedo=False, history_limit=0.0, instance_index_map=None):
+    """orc_accumulate over the same descriptor the product takes (stratum_amd.post.accumulate_desc)."""
+    from stratum_amd.post import accumulate_desc
+
+    keep = []
+    d, out_c, out_m = accumulate_desc(frame_out, history, views, reprojection, demodulate_albedo, history_limit, instance_index_map, keep)
+    lib().orc_accumulate(C.byref(d))
+    return out_c, out_m
+

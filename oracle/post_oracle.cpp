@@ -3,6 +3,7 @@
 //   orc_tonemap        kernels/tonemap.hlsl:21-226 (curves :21-102, reduce_max :106-153, main :155-226),
 //                      colour helpers of common.h:66-69 (luminance), :107-113 (rgb_to_srgb), :115-123 (viridis)
 //   orc_image_compare  kernels/image_compare.hlsl:13-46
+//   orc_accumulate     kernels/temporal_accumulation.hlsl:59-145 (both gReprojection specialisations)
 // Parity: pow/exp follow the arithmetic contract (include/sthip_detmath.h); the wave sum of image_compare is pinned
 // to 64 consecutive pixels added in order (see include/sthip.h). The reference's own tests hold no vectors for these
 // kernels, so this part of the oracle is "parity unpinned" against the reference and pinned only by its own
@@ -38,9 +39,116 @@ void viridis(float x, float* out) {  // common.h:115-123
   }
 }
 
+
+// bitfield.h:76-93 unpack_normal_octahedron (as in stratum_oracle.cpp)
+void unpack_oct(uint32_t packed, float out[3]) {
+  const float px = det_f16tof32(packed & 0xFFFFu), py = det_f16tof32(packed >> 16);
+  float v[3] = {px, py, 1.0f - (fabsf(px) + fabsf(py))};
+  if (v[2] < 0) {
+    const float qx = (1.0f - fabsf(v[1])) * (v[0] >= 0 ? 1.0f : -1.0f);
+    const float qy = (1.0f - fabsf(v[0])) * (v[1] >= 0 ? 1.0f : -1.0f);
+    v[0] = qx;
+    v[1] = qy;
+  }
+  const float len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  out[0] = v[0] / len;
+  out[1] = v[1] / len;
+  out[2] = v[2] / len;
+}
+bool notfinite(float x) { return x != x || isinf(x); }
+float mixf(float a, float b, float t) { return a + t * (b - a); }
+
 }  // namespace
 
 extern "C" {
+
+// temporal_accumulation.hlsl:59-145; all pointers of the descriptor are host pointers here
+void orc_accumulate(const sthip_accumulate_desc* d) {
+  const uint32_t W = d->width, H = d->height;
+  float sd, cd;
+  det_sincosf(2.0f * 57.2957795130823f, &sd, &cd);  // cos(degrees(2)), :88
+  for (uint32_t y = 0; y < H; y++)
+    for (uint32_t x = 0; x < W; x++) {
+      const size_t i = (size_t)y * W + x;
+      const sthip_ViewData* view = nullptr;
+      for (uint32_t v = 0; v < d->view_count && !view; v++) {
+        const sthip_ViewData& c = d->gViews[v];
+        if ((int)x >= c.image_min[0] && (int)y >= c.image_min[1] && (int)x < c.image_max[0] && (int)y < c.image_max[1]) view = &c;
+      }
+      if (!view) continue;
+      float cp[4] = {0, 0, 0, 0}, mp[2] = {0, 0}, sum_w = 0;
+      if (d->reprojection) {
+        const sthip_VisibilityInfo vis = d->gVisibility[i];
+        const sthip_DepthInfo depth = d->gDepth[i];
+        const uint32_t inst = vis.instance_primitive_index & 0xFFFFu;
+        if (inst != STHIP_INVALID_INSTANCE) {
+          const float pos_x = (float)view->image_min[0] + d->gPrevUVs[2 * i] * (float)(view->image_max[0] - view->image_min[0]) - 0.5f;
+          const float pos_y = (float)view->image_min[1] + d->gPrevUVs[2 * i + 1] * (float)(view->image_max[1] - view->image_min[1]) - 0.5f;
+          const bool finite_pos = fabsf(pos_x) < 1e9f && fabsf(pos_y) < 1e9f;
+          const int px = finite_pos ? (int)pos_x : -0x40000000, py = finite_pos ? (int)pos_y : -0x40000000;
+          const float wx = pos_x - floorf(pos_x), wy = pos_y - floorf(pos_y);
+          float n[3];
+          unpack_oct(vis.packed_normal, n);
+          const uint32_t mapped = d->gInstanceIndexMap ? (inst < d->instance_count ? d->gInstanceIndexMap[inst] : 0xFFFFFFFFu) : inst;
+          const float dz = sqrtf(depth.dz_dxy[0] * depth.dz_dxy[0] + depth.dz_dxy[1] * depth.dz_dxy[1]);
+          for (int yy = 0; yy <= 1; yy++)
+            for (int xx = 0; xx <= 1; xx++) {
+              const int qx = px + xx, qy = py + yy;
+              if (!(qx >= view->image_min[0] && qy >= view->image_min[1] && qx < view->image_max[0] && qy < view->image_max[1])) continue;
+              const size_t q = (size_t)qy * W + qx;
+              const sthip_VisibilityInfo pv = d->gPrevVisibility[q];
+              if (mapped != (pv.instance_primitive_index & 0xFFFFu)) continue;
+              float pn[3];
+              unpack_oct(pv.packed_normal, pn);
+              if (n[0] * pn[0] + n[1] * pn[1] + n[2] * pn[2] < cd) continue;
+              if (fabsf(depth.prev_z - d->gPrevDepth[q].z) >= 1.5f * dz) continue;
+              const float* c = d->gPrevAccumColor + 4 * q;
+              if (c[3] <= 0 || notfinite(c[0]) || notfinite(c[1]) || notfinite(c[2]) || notfinite(c[3])) continue;
+              const float wc = (xx == 0 ? (1 - wx) : wx) * (yy == 0 ? (1 - wy) : wy);
+              for (int k = 0; k < 4; k++) cp[k] += c[k] * wc;
+              mp[0] += d->gPrevAccumMoments[2 * q] * wc;
+              mp[1] += d->gPrevAccumMoments[2 * q + 1] * wc;
+              sum_w += wc;
+            }
+        }
+      } else {
+        memcpy(cp, d->gPrevAccumColor + 4 * i, 16);
+        if (notfinite(cp[0]) || notfinite(cp[1]) || notfinite(cp[2])) {
+          cp[0] = cp[1] = cp[2] = cp[3] = 0;
+        } else {
+          mp[0] = d->gPrevAccumMoments[2 * i];
+          mp[1] = d->gPrevAccumMoments[2 * i + 1];
+        }
+        sum_w = 1;
+      }
+      float cc[4];
+      memcpy(cc, d->gRadiance + 4 * i, 16);
+      if (d->demodulate_albedo)
+        for (int k = 0; k < 3; k++) cc[k] /= (1e-2f + d->gAlbedo[4 * i + k]);
+      if (notfinite(cc[0]) || notfinite(cc[1]) || notfinite(cc[2])) cc[0] = cc[1] = cc[2] = cc[3] = 0;
+      if (notfinite(mp[0]) || notfinite(mp[1])) mp[0] = mp[1] = 0;
+      const float l = lum(cc);
+      float* oc = d->gAccumColor + 4 * i;
+      float* om = d->gAccumMoments + 2 * i;
+      if (sum_w > 0 && cp[3] > 0) {
+        const float inv_sum = 1 / sum_w;
+        for (int k = 0; k < 4; k++) cp[k] *= inv_sum;
+        mp[0] *= inv_sum;
+        mp[1] *= inv_sum;
+        float n = cp[3] + cc[3];
+        if (d->history_limit > 0 && n > d->history_limit) n = d->history_limit;
+        const float alpha = sat(cc[3] / n);
+        for (int k = 0; k < 3; k++) oc[k] = mixf(cp[k], cc[k], alpha);
+        oc[3] = n;
+        om[0] = mixf(mp[0], l, alpha);
+        om[1] = mixf(mp[1], l * l, alpha);
+      } else {
+        memcpy(oc, cc, 16);
+        om[0] = l;
+        om[1] = l * l;
+      }
+    }
+}
 
 // gInput/gAlbedo/gOutput: RGBA32F of width*height; out_max[4] = the maxima main() sees
 void orc_tonemap(const float* input, const float* albedo, float* output, uint32_t width, uint32_t height, uint32_t mode, uint32_t modulate, uint32_t gamma, float exposure, float* out_max) {

@@ -29,6 +29,7 @@ EXPORTS = [
     "sthip_set_option",
     "sthip_shard_slot_count",
     "sthip_assemble_tiles",
+    "sthip_accumulate",
     "sthip_tonemap",
     "sthip_image_compare",
     "sthip_write_hdr",
@@ -106,6 +107,8 @@ def lib():
     L.sthip_shard_slot_count.argtypes = [C.c_uint32] * 6
     L.sthip_assemble_tiles.restype = C.c_int
     L.sthip_assemble_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.sthip_accumulate.restype = C.c_int
+    L.sthip_accumulate.argtypes = [C.c_void_p, C.POINTER(wire.AccumulateDesc)]
     L.sthip_tonemap.restype = C.c_int
     L.sthip_tonemap.argtypes = [C.c_void_p, C.POINTER(wire.TonemapDesc)]
     L.sthip_image_compare.restype = C.c_int

@@ -69,20 +69,23 @@ def inverse_transform(t):
 
 
 class Frame:
-    """gFrameParams view arrays for one static camera."""
+    """gFrameParams view arrays for one camera. `prev` = the Frame of the previous render call: its views and
+    inverse view transforms become gPrevViews / gPrevInverseViewTransforms (BDPT.cpp:453-467), which is what the
+    prev-uv / prev_z outputs and the temporal reprojection use; without it the camera is static."""
 
-    def __init__(self, width, height, fovy, eye, target, up=(0.0, 1.0, 0.0)):
+    def __init__(self, width, height, fovy, eye, target, up=(0.0, 1.0, 0.0), prev=None):
         self.width, self.height = width, height
         self.views = make_view(width, height, fovy)
         self.view_transforms = look_at(eye, target, up)
         self.inverse_view_transforms = inverse_transform(self.view_transforms)
+        self.prev = prev
 
     def desc(self):
         d = wire.FrameDesc()
         d.gViews = wire.ptr(self.views)
         d.gViewTransforms = wire.ptr(self.view_transforms)
         d.gInverseViewTransforms = wire.ptr(self.inverse_view_transforms)
-        d.gPrevViews = None
-        d.gPrevInverseViewTransforms = None
+        d.gPrevViews = wire.ptr(self.prev.views) if self.prev is not None else None
+        d.gPrevInverseViewTransforms = wire.ptr(self.prev.inverse_view_transforms) if self.prev is not None else None
         d.view_count = 1
         return d

@@ -834,7 +834,92 @@ int sthip_assemble_tiles(sthip_ctx* ctx, const float* packed, uint64_t rank_stri
   return STHIP_OK;
 }
 
-// ---- after the path: tonemap and image metric (post.h) ----
+// ---- after the path: temporal accumulation, tonemap and image metric (post.h) ----
+
+int sthip_accumulate(sthip_ctx* ctx, const sthip_accumulate_desc* d) {
+  if (!ctx || !d) return STHIP_ERR_INVALID_ARGUMENT;
+  if (!d->gViews || !d->view_count || !d->gRadiance || !d->gPrevAccumColor || !d->gPrevAccumMoments || !d->gAccumColor || !d->gAccumMoments || !d->width || !d->height)
+    return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_accumulate: gViews, gRadiance, gPrevAccum*, gAccum* and a non-empty extent are required");
+  if (d->demodulate_albedo && !d->gAlbedo) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_accumulate: gDemodulateAlbedo needs gAlbedo");
+  if (d->reprojection && (!d->gVisibility || !d->gDepth || !d->gPrevUVs || !d->gPrevVisibility || !d->gPrevDepth))
+    return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_accumulate: gReprojection needs gVisibility, gDepth, gPrevUVs, gPrevVisibility, gPrevDepth");
+  if ((uint64_t)d->width * d->height > 0x7FFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_accumulate: extent too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t n = (size_t)d->width * d->height;
+  std::vector<void*> staged;  // device copies of host inputs, freed on return
+  auto release = [&]() {
+    for (void* q : staged) (void)hipFree(q);
+  };
+  bool bad = false;
+  auto in = [&](const void* host, size_t bytes) -> const void* {
+    if (!host || d->device_ptrs) return host;
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess || hipMemcpyAsync(q, host, bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
+      bad = true;
+      return nullptr;
+    }
+    staged.push_back(q);
+    return q;
+  };
+  AccumulateParams p{};
+  p.width = d->width;
+  p.height = d->height;
+  p.view_count = d->view_count;
+  p.reprojection = d->reprojection;
+  p.demodulate_albedo = d->demodulate_albedo;
+  p.history_limit = d->history_limit;
+  p.instance_count = d->instance_count;
+  {  // gViews is a host array in either mode
+    void* q = nullptr;
+    if (hipMalloc(&q, (size_t)d->view_count * sizeof(sthip_ViewData)) != hipSuccess ||
+        hipMemcpyAsync(q, d->gViews, (size_t)d->view_count * sizeof(sthip_ViewData), hipMemcpyHostToDevice, st) != hipSuccess)
+      bad = true;
+    else
+      staged.push_back(q);
+    p.views = (const sthip_ViewData*)q;
+  }
+  p.radiance = (const float4*)in(d->gRadiance, n * 16);
+  p.albedo = (const float4*)in(d->gAlbedo, n * 16);
+  p.visibility = (const sthip_VisibilityInfo*)in(d->gVisibility, n * 8);
+  p.depth = (const sthip_DepthInfo*)in(d->gDepth, n * 16);
+  p.prev_uvs = (const float2*)in(d->gPrevUVs, n * 8);
+  p.prev_visibility = (const sthip_VisibilityInfo*)in(d->gPrevVisibility, n * 8);
+  p.prev_depth = (const sthip_DepthInfo*)in(d->gPrevDepth, n * 16);
+  p.prev_accum_color = (const float4*)in(d->gPrevAccumColor, n * 16);
+  p.prev_accum_moments = (const float2*)in(d->gPrevAccumMoments, n * 8);
+  p.instance_index_map = (const uint32_t*)in(d->gInstanceIndexMap, (size_t)d->instance_count * 4);
+  float4* out_c = reinterpret_cast<float4*>(d->gAccumColor);
+  float2* out_m = reinterpret_cast<float2*>(d->gAccumMoments);
+  if (!d->device_ptrs) {
+    void *qc = nullptr, *qm = nullptr;
+    if (hipMalloc(&qc, n * 16) != hipSuccess || hipMalloc(&qm, n * 8) != hipSuccess) bad = true;
+    if (qc) staged.push_back(qc);
+    if (qm) staged.push_back(qm);
+    out_c = (float4*)qc;
+    out_m = (float2*)qm;
+    // pixels outside every view keep what the caller's buffers hold
+    if (!bad && (hipMemcpyAsync(qc, d->gAccumColor, n * 16, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(qm, d->gAccumMoments, n * 8, hipMemcpyHostToDevice, st) != hipSuccess)) bad = true;
+  }
+  if (bad) {
+    (void)hipStreamSynchronize(st);
+    release();
+    return fail(ctx, STHIP_ERR_HIP, "sthip_accumulate: staging the host images on the device failed");
+  }
+  p.accum_color = out_c;
+  p.accum_moments = out_m;
+  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && !d->device_ptrs) {
+    e = hipMemcpyAsync(d->gAccumColor, out_c, n * 16, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d->gAccumMoments, out_m, n * 8, hipMemcpyDeviceToHost, st);
+  }
+  // the staged copies (gViews at least) must outlive the kernel
+  const hipError_t es = hipStreamSynchronize(st);
+  release();
+  if (e != hipSuccess || es != hipSuccess) return fail(ctx, STHIP_ERR_HIP, std::string("sthip_accumulate: ") + hipGetErrorString(e != hipSuccess ? e : es));
+  return STHIP_OK;
+}
 
 int sthip_tonemap(sthip_ctx* ctx, const sthip_tonemap_desc* d) {
   if (!ctx || !d) return STHIP_ERR_INVALID_ARGUMENT;

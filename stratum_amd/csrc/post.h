@@ -8,6 +8,7 @@
 #pragma once
 
 #include "device_math.h"
+#include "shading.h"
 
 #define TONEMAP_MAX_QUANTIZATION 16384.0f  // gMaxQuantization, tonemap.hlsl:104
 
@@ -164,3 +165,123 @@ __global__ void __launch_bounds__(64) k_image_compare(const float4* image1, cons
     if (valf >= 4294967295.0f || 0xFFFFFFFFu - val < prev) out[1] = 1;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// temporal accumulation, kernels/temporal_accumulation.hlsl:59-145 (host: Denoiser.cpp:73-77,176-213): reprojects
+// the previous frame's accumulated colour / moments through gPrevUVs with per-tap validity tests, then blends the
+// new sample in with alpha = n_new / n. Both specialisations (gReprojection on / off) and gDemodulateAlbedo.
+// As upstream: the normal test compares against cos(degrees(2)) (degrees, not radians: 114.59 rad).
+// ---------------------------------------------------------------------------------------------------------------
+struct AccumulateParams {
+  uint32_t width, height, view_count, reprojection, demodulate_albedo;
+  float history_limit;
+  uint32_t instance_count;
+  const sthip_ViewData* views;
+  const float4* radiance;
+  const float4* albedo;
+  const sthip_VisibilityInfo* visibility;
+  const sthip_DepthInfo* depth;
+  const float2* prev_uvs;
+  const sthip_VisibilityInfo* prev_visibility;
+  const sthip_DepthInfo* prev_depth;
+  const float4* prev_accum_color;
+  const float2* prev_accum_moments;
+  const uint32_t* instance_index_map;  // may be null: identity
+  float4* accum_color;
+  float2* accum_moments;
+};
+DEV bool bad4(float4 c) { return c.x != c.x || c.y != c.y || c.z != c.z || c.w != c.w || isinf(c.x) || isinf(c.y) || isinf(c.z) || isinf(c.w); }
+__global__ void __launch_bounds__(256) k_accumulate(AccumulateParams p) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.width * p.height) return;
+  const uint32_t x = i % p.width, y = i / p.width;
+  int view_index = -1;
+  for (uint32_t v = 0; v < p.view_count; v++) {
+    const sthip_ViewData& vw = p.views[v];
+    if ((int)x >= vw.image_min[0] && (int)y >= vw.image_min[1] && (int)x < vw.image_max[0] && (int)y < vw.image_max[1]) {
+      view_index = (int)v;
+      break;
+    }
+  }
+  if (view_index < 0) return;
+  const sthip_ViewData& view = p.views[view_index];
+  float4 color_prev = make_float4(0, 0, 0, 0);
+  float2 moments_prev = make_float2(0, 0);
+  float sum_w = 0;
+  if (p.reprojection) {
+    const sthip_VisibilityInfo vis = p.visibility[i];
+    const sthip_DepthInfo depth = p.depth[i];
+    if ((vis.instance_primitive_index & 0xFFFFu) != STHIP_INVALID_INSTANCE) {
+      const float2 uv = p.prev_uvs[i];
+      const float pos_x = (float)view.image_min[0] + uv.x * (float)(view.image_max[0] - view.image_min[0]) - 0.5f;
+      const float pos_y = (float)view.image_min[1] + uv.y * (float)(view.image_max[1] - view.image_min[1]) - 0.5f;
+      // (a position that no int can hold selects no tap; the conversion of such a float is implementation-defined)
+      const bool finite_pos = fabsf(pos_x) < 1e9f && fabsf(pos_y) < 1e9f;
+      const int px = finite_pos ? (int)pos_x : -0x40000000, py = finite_pos ? (int)pos_y : -0x40000000;  // int2 p = pos_prev: truncation
+      const float wx = pos_x - floorf(pos_x), wy = pos_y - floorf(pos_y);    // frac()
+      float sd, cd;
+      det_sincosf(2.0f * 57.2957795130823f, &sd, &cd);  // cos(degrees(2))
+      const f3 n = unpack_normal_octahedron(vis.packed_normal);
+      const uint32_t inst = vis.instance_primitive_index & 0xFFFFu;
+      const uint32_t mapped = p.instance_index_map ? (inst < p.instance_count ? p.instance_index_map[inst] : 0xFFFFFFFFu) : inst;
+      const float dz = sqrtf(depth.dz_dxy[0] * depth.dz_dxy[0] + depth.dz_dxy[1] * depth.dz_dxy[1]);
+      for (int yy = 0; yy <= 1; yy++)
+        for (int xx = 0; xx <= 1; xx++) {
+          const int qx = px + xx, qy = py + yy;
+          if (!(qx >= view.image_min[0] && qy >= view.image_min[1] && qx < view.image_max[0] && qy < view.image_max[1])) continue;
+          const size_t q = (size_t)qy * p.width + qx;
+          const sthip_VisibilityInfo pv = p.prev_visibility[q];
+          if (mapped != (pv.instance_primitive_index & 0xFFFFu)) continue;
+          if (dot3(n, unpack_normal_octahedron(pv.packed_normal)) < cd) continue;
+          if (fabsf(depth.prev_z - p.prev_depth[q].z) >= 1.5f * dz) continue;
+          const float4 c = p.prev_accum_color[q];
+          if (c.w <= 0 || bad4(c)) continue;
+          const float wc = (xx == 0 ? (1 - wx) : wx) * (yy == 0 ? (1 - wy) : wy);
+          color_prev.x += c.x * wc;
+          color_prev.y += c.y * wc;
+          color_prev.z += c.z * wc;
+          color_prev.w += c.w * wc;
+          const float2 m = p.prev_accum_moments[q];
+          moments_prev.x += m.x * wc;
+          moments_prev.y += m.y * wc;
+          sum_w += wc;
+        }
+    }
+  } else {
+    color_prev = p.prev_accum_color[i];
+    if (color_prev.x != color_prev.x || color_prev.y != color_prev.y || color_prev.z != color_prev.z || isinf(color_prev.x) || isinf(color_prev.y) || isinf(color_prev.z))
+      color_prev = make_float4(0, 0, 0, 0);
+    else
+      moments_prev = p.prev_accum_moments[i];
+    sum_w = 1;
+  }
+  float4 color_curr = p.radiance[i];
+  if (p.demodulate_albedo) {
+    const float4 a = p.albedo[i];
+    color_curr.x /= (1e-2f + a.x);
+    color_curr.y /= (1e-2f + a.y);
+    color_curr.z /= (1e-2f + a.z);
+  }
+  if (isinf(color_curr.x) || isinf(color_curr.y) || isinf(color_curr.z) || color_curr.x != color_curr.x || color_curr.y != color_curr.y || color_curr.z != color_curr.z)
+    color_curr = make_float4(0, 0, 0, 0);
+  if (isinf(moments_prev.x) || isinf(moments_prev.y) || moments_prev.x != moments_prev.x || moments_prev.y != moments_prev.y) moments_prev = make_float2(0, 0);
+  const float l = luminance3(xyz(color_curr));
+  if (sum_w > 0 && color_prev.w > 0) {
+    const float inv_sum = 1 / sum_w;
+    color_prev.x *= inv_sum;
+    color_prev.y *= inv_sum;
+    color_prev.z *= inv_sum;
+    color_prev.w *= inv_sum;
+    moments_prev.x *= inv_sum;
+    moments_prev.y *= inv_sum;
+    float n = color_prev.w + color_curr.w;
+    if (p.history_limit > 0 && n > p.history_limit) n = p.history_limit;
+    const float alpha = saturate1(color_curr.w / n);
+    p.accum_color[i] = make_float4(lerp1(color_prev.x, color_curr.x, alpha), lerp1(color_prev.y, color_curr.y, alpha), lerp1(color_prev.z, color_curr.z, alpha), n);
+    p.accum_moments[i] = make_float2(lerp1(moments_prev.x, l, alpha), lerp1(moments_prev.y, l * l, alpha));
+  } else {
+    p.accum_color[i] = color_curr;
+    p.accum_moments[i] = make_float2(l, l * l);
+  }
+}
+

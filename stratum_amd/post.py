@@ -24,6 +24,73 @@ def _rgba(a, name):
     return a
 
 
+def accumulate_desc(frame_out, history, views, reprojection, demodulate_albedo, history_limit, instance_index_map, keep):
+    """Fills a wire.AccumulateDesc from a render's output dict (`frame_out`: radiance, albedo, visibility, depth,
+    prev_uv) and the previous state (`history`: accum_color, accum_moments, visibility, depth). `keep` receives the
+    arrays the descriptor points at. Returns (desc, accum_color, accum_moments)."""
+    rad = _rgba(frame_out["radiance"], "radiance")
+    H, W = rad.shape[0], rad.shape[1]
+    d = wire.AccumulateDesc()
+    d.width, d.height = W, H
+    v = np.ascontiguousarray(views, dtype=wire.ViewData)
+    d.view_count = v.shape[0]
+    d.reprojection = int(bool(reprojection))
+    d.demodulate_albedo = int(bool(demodulate_albedo))
+    d.history_limit = float(history_limit)
+    d.device_ptrs = 0
+    out_c = np.zeros((H, W, 4), np.float32)
+    out_m = np.zeros((H, W, 2), np.float32)
+    arrays = {
+        "gViews": v,
+        "gRadiance": rad,
+        "gAlbedo": np.ascontiguousarray(frame_out["albedo"], np.float32) if "albedo" in frame_out else None,
+        "gVisibility": np.ascontiguousarray(frame_out["visibility"], wire.VisibilityInfo) if "visibility" in frame_out else None,
+        "gDepth": np.ascontiguousarray(frame_out["depth"], wire.DepthInfo) if "depth" in frame_out else None,
+        "gPrevUVs": np.ascontiguousarray(frame_out["prev_uv"], np.float32) if "prev_uv" in frame_out else None,
+        "gPrevVisibility": np.ascontiguousarray(history["visibility"], wire.VisibilityInfo) if history.get("visibility") is not None else None,
+        "gPrevDepth": np.ascontiguousarray(history["depth"], wire.DepthInfo) if history.get("depth") is not None else None,
+        "gPrevAccumColor": np.ascontiguousarray(history["accum_color"], np.float32),
+        "gPrevAccumMoments": np.ascontiguousarray(history["accum_moments"], np.float32),
+        "gInstanceIndexMap": np.ascontiguousarray(instance_index_map, np.uint32) if instance_index_map is not None else None,
+        "gAccumColor": out_c,
+        "gAccumMoments": out_m,
+    }
+    for k, a in arrays.items():
+        setattr(d, k, a.ctypes.data if a is not None else None)
+    d.instance_count = arrays["gInstanceIndexMap"].shape[0] if instance_index_map is not None else 0
+    keep.append(arrays)
+    return d, out_c, out_m
+
+
+class TemporalAccumulation:
+    """The accumulation state Denoiser keeps between frames (Denoiser.cpp:66-77,176-213): accumulated colour (rgb =
+    mean, a = sample count) and luminance moments, plus last frame's visibility / depth for the reprojection tests."""
+
+    def __init__(self, bdpt, reprojection=True, demodulate_albedo=False, history_limit=0.0):
+        self._bdpt = bdpt
+        self.reprojection = reprojection
+        self.demodulate_albedo = demodulate_albedo
+        self.history_limit = history_limit
+        self.history = None
+
+    def reset(self):  # Denoiser::reset_accumulation
+        self.history = None
+
+    def __call__(self, frame_out, views, instance_index_map=None):
+        rad = _rgba(frame_out["radiance"], "radiance")
+        H, W = rad.shape[0], rad.shape[1]
+        history = self.history
+        if history is None:  # first frame: nothing accumulated yet (sample count 0 everywhere)
+            vis = np.zeros((H, W), wire.VisibilityInfo)
+            vis["instance_primitive_index"] = wire.MISS
+            history = {"accum_color": np.zeros((H, W, 4), np.float32), "accum_moments": np.zeros((H, W, 2), np.float32), "visibility": vis, "depth": np.zeros((H, W), wire.DepthInfo)}
+        keep = []
+        d, out_c, out_m = accumulate_desc(frame_out, history, views, self.reprojection, self.demodulate_albedo, self.history_limit, instance_index_map, keep)
+        self._bdpt._check(_lib.lib().sthip_accumulate(self._bdpt._h, C.byref(d)), "sthip_accumulate")
+        self.history = {"accum_color": out_c, "accum_moments": out_m, "visibility": frame_out.get("visibility"), "depth": frame_out.get("depth")}
+        return out_c, out_m
+
+
 class Tonemapper:
     """The tone-map state BDPT keeps (BDPT.cpp:44-54,190-196,304-309): mode, exposure, gamma correction."""
 

@@ -282,3 +282,30 @@ class TonemapDesc(C.Structure):
         ("gOutput", C.c_void_p),
         ("out_max", C.c_void_p),
     ]
+
+
+class AccumulateDesc(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("view_count", C.c_uint32),
+        ("reprojection", C.c_uint32),
+        ("demodulate_albedo", C.c_uint32),
+        ("history_limit", C.c_float),
+        ("device_ptrs", C.c_uint32),
+        ("instance_count", C.c_uint32),
+        ("gViews", C.c_void_p),
+        ("gRadiance", C.c_void_p),
+        ("gAlbedo", C.c_void_p),
+        ("gVisibility", C.c_void_p),
+        ("gDepth", C.c_void_p),
+        ("gPrevUVs", C.c_void_p),
+        ("gPrevVisibility", C.c_void_p),
+        ("gPrevDepth", C.c_void_p),
+        ("gPrevAccumColor", C.c_void_p),
+        ("gPrevAccumMoments", C.c_void_p),
+        ("gInstanceIndexMap", C.c_void_p),
+        ("gAccumColor", C.c_void_p),
+        ("gAccumMoments", C.c_void_p),
+    ]
+

@@ -318,3 +318,108 @@ def test_gpu_post_error_reporting(gpu_ctx):
         Tonemapper(gpu_ctx, "Raw")(img, None, modulate_albedo=True)
     with pytest.raises(_lib.StratumHipError, match="unknown metric"):
         ImageComparer(gpu_ctx, 7).raw(img, img)
+
+
+# ---- temporal accumulation (temporal_accumulation.hlsl) ----
+def _oracle_frames(n_frames, moving, w=96, h=64):
+    """Renders n_frames of the Cornell box with the oracle: one seed per frame, optionally a camera that slides."""
+    from stratum_amd import camera, scenes
+
+    sc, cam = scenes.cornell_box()
+    o = oracle_py.OracleScene(sc)
+    frames, outs, prev = [], [], None
+    for k in range(n_frames):
+        eye = np.array(cam["eye"]) + (np.array([0.05, 0.02, 0.0]) * k if moving else 0)
+        fr = camera.Frame(w, h, cam["fovy"], tuple(eye), cam["target"], prev=prev)
+        outs.append(o.render(fr, wire.default_push_constants(w, h, sc.light_count), wire.DEFAULT_SAMPLING_FLAGS, k, 1, threads=4))
+        frames.append(fr)
+        prev = fr
+    return sc, frames, outs
+
+
+def _empty_history(h, w):
+    vis = np.zeros((h, w), wire.VisibilityInfo)
+    vis["instance_primitive_index"] = wire.MISS
+    return {"accum_color": np.zeros((h, w, 4), np.float32), "accum_moments": np.zeros((h, w, 2), np.float32), "visibility": vis, "depth": np.zeros((h, w), wire.DepthInfo)}
+
+
+def test_oracle_accumulation_without_reprojection_is_the_running_mean():
+    _, frames, outs = _oracle_frames(4, moving=False, w=48, h=32)
+    hist = _empty_history(32, 48)
+    for out in outs:
+        c, m = oracle_py.accumulate(out, hist, frames[0].views, reprojection=False)
+        hist = {"accum_color": c, "accum_moments": m, "visibility": out["visibility"], "depth": out["depth"]}
+    mean = np.mean([o["radiance"][..., :3].astype(np.float64) for o in outs], axis=0)
+    assert np.all(c[..., 3] == 4)
+    assert np.allclose(c[..., :3], mean, rtol=2e-6, atol=1e-7)
+    lum = [o["radiance"][..., :3].astype(np.float64) @ np.array([0.2126, 0.7152, 0.0722]) for o in outs]
+    assert np.allclose(m[..., 0], np.mean(lum, axis=0), rtol=1e-5, atol=1e-7)
+    assert np.allclose(m[..., 1], np.mean(np.square(lum), axis=0), rtol=1e-5, atol=1e-7)
+    # gHistoryLimit caps the sample count, i.e. turns the mean into an exponential average with alpha = 1 / limit
+    c2, _ = oracle_py.accumulate(outs[0], hist, frames[0].views, reprojection=False, history_limit=2.0)
+    assert np.all(c2[..., 3] == 2)
+    want = 0.5 * c[..., :3].astype(np.float64) + 0.5 * outs[0]["radiance"][..., :3]
+    assert np.allclose(c2[..., :3], want, rtol=2e-6, atol=1e-7)
+    # a NaN sample is dropped, not accumulated
+    bad = {k: v.copy() for k, v in outs[1].items() if hasattr(v, "copy")}
+    bad["radiance"][3, 5, 0] = np.nan
+    c3, _ = oracle_py.accumulate(bad, hist, frames[0].views, reprojection=False)
+    assert np.isfinite(c3).all() and c3[3, 5, 3] == 4
+
+
+def test_oracle_reprojection_static_and_moving_camera():
+    _, frames, outs = _oracle_frames(3, moving=False, w=48, h=32)
+    hist = _empty_history(32, 48)
+    hist_n = _empty_history(32, 48)
+    for out in outs:
+        c, m = oracle_py.accumulate(out, hist, frames[0].views, reprojection=True)
+        cn, mn = oracle_py.accumulate(out, hist_n, frames[0].views, reprojection=False)
+        hist = {"accum_color": c, "accum_moments": m, "visibility": out["visibility"], "depth": out["depth"]}
+        hist_n = {"accum_color": cn, "accum_moments": mn, "visibility": out["visibility"], "depth": out["depth"]}
+    hit = outs[-1]["visibility"]["instance_primitive_index"] != wire.MISS
+    # a static camera reprojects every surface pixel onto itself (weight 1 on one tap): same result as without
+    assert hit.mean() > 0.5
+    same = np.isclose(c[..., 3], 3) & hit
+    assert same.sum() > 0.97 * hit.sum()
+    assert np.allclose(c[same], cn[same], rtol=1e-5, atol=1e-6)
+    # pixels that see nothing have no history to reproject: they restart
+    assert np.all(c[~hit][:, 3] == 1)
+    # moving camera: most pixels keep a history, disocclusions and frame edges restart at n = 1
+    _, frames, outs = _oracle_frames(3, moving=True, w=48, h=32)
+    hist = _empty_history(32, 48)
+    for fr, out in zip(frames, outs):
+        c, m = oracle_py.accumulate(out, hist, fr.views, reprojection=True)
+        hist = {"accum_color": c, "accum_moments": m, "visibility": out["visibility"], "depth": out["depth"]}
+    n = c[..., 3]
+    assert (n > 2.5).mean() > 0.5 and (n == 1).mean() > 0.02 and n.max() <= 3.0001
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("moving,reprojection,demodulate,limit", [(False, False, False, 0.0), (False, True, False, 0.0), (True, True, False, 0.0), (True, True, True, 2.0)])
+def test_gpu_accumulation_equals_oracle(gpu_ctx, moving, reprojection, demodulate, limit):
+    from stratum_amd.post import TemporalAccumulation
+
+    _, frames, outs = _oracle_frames(3, moving=moving)
+    acc = TemporalAccumulation(gpu_ctx, reprojection, demodulate, limit)
+    hist = _empty_history(64, 96)
+    for fr, out in zip(frames, outs):
+        gc, gm = acc(out, fr.views)
+        oc, om = oracle_py.accumulate(out, hist, fr.views, reprojection, demodulate, limit)
+        hist = {"accum_color": oc, "accum_moments": om, "visibility": out["visibility"], "depth": out["depth"]}
+        assert np.array_equal(gc.view(np.uint32), oc.view(np.uint32))
+        assert np.array_equal(gm.view(np.uint32), om.view(np.uint32))
+    assert gc[..., 3].max() == (limit if limit else 3)
+
+
+@pytest.mark.gpu
+def test_gpu_accumulation_errors(gpu_ctx):
+    from stratum_amd.post import TemporalAccumulation
+
+    _, frames, outs = _oracle_frames(1, moving=False, w=32, h=32)
+    out = {"radiance": outs[0]["radiance"]}  # no AOVs
+    with pytest.raises(_lib.StratumHipError, match="gReprojection needs"):
+        TemporalAccumulation(gpu_ctx, reprojection=True)(out, frames[0].views)
+    with pytest.raises(_lib.StratumHipError, match="gAlbedo"):
+        TemporalAccumulation(gpu_ctx, reprojection=False, demodulate_albedo=True)(out, frames[0].views)
+    c, _ = TemporalAccumulation(gpu_ctx, reprojection=False)(out, frames[0].views)
+    assert np.array_equal(c, outs[0]["radiance"])
