@@ -468,3 +468,26 @@ def test_packed_tiles_and_assembly(renderer, cornell):
     assert np.array_equal(out.cpu().numpy().view(np.uint32), full.view(np.uint32))
     assert np.array_equal(shard.assemble_tiles(host, W, H, 16, 8).view(np.uint32), full.view(np.uint32))
 
+
+
+def test_moving_camera_aovs(renderer, cornell):
+    """gPrevViews / gPrevInverseViewTransforms of a camera that moved since the last frame: prev-uv, prev_z and dz/dxy
+    (the inputs of the temporal reprojection) equal the oracle's."""
+    from oracle import oracle_py
+
+    sc, cam = cornell
+    renderer.update(sc)
+    W, H = 160, 120
+    prev = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+    eye = tuple(np.array(cam["eye"]) + np.array([0.07, -0.03, 0.1]))
+    frame = camera.Frame(W, H, cam["fovy"], eye, cam["target"], prev=prev)
+    got = renderer.render(frame, 5, 1)
+    ref = oracle_py.OracleScene(sc).render(frame, renderer.push_constants(frame), renderer.mSamplingFlags, 5, 1)
+    assert np.array_equal(got["prev_uv"].view(np.uint32), ref["prev_uv"].view(np.uint32))
+    for f in ("z", "prev_z", "dz_dxy"):
+        assert np.array_equal(got["depth"][f].view(np.uint32), ref["depth"][f].view(np.uint32)), f
+    assert np.array_equal(got["radiance"].view(np.uint32), ref["radiance"].view(np.uint32))
+    hit = ref["visibility"]["instance_primitive_index"] != wire.MISS
+    uv = (np.stack(np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5), -1) / [W, H]).astype(np.float32)
+    moved = np.abs(ref["prev_uv"] - uv).max(-1)
+    assert moved[hit].mean() > 2e-3  # the reprojected position really differs from the pixel's own
