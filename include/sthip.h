@@ -74,6 +74,13 @@ typedef struct sthip_scene_desc {
    * May be NULL / 0. */
   const float* gDistributions;
   uint32_t distribution_count;
+  /* Texture2D<float> gImage1s[] (bdpt.hlsl:34): what Material::alpha_mask refers to (MaterialRecord.alpha_mask_index,
+   * Material.hpp:35). One float per texel (the reference stores R8Unorm coverage, Scene.cpp:182), row 0 first. With
+   * eAlphaTest a triangle of a material that has a mask is hit only where the mask, sampled bilinearly with repeat
+   * addressing at the hit's uv, is >= 0.75 (intersection.hlsli:117-131) — for closest-hit and shadow rays alike.
+   * May be NULL / 0. */
+  const struct sthip_image_desc* gImage1s;
+  uint32_t image1_count;
 } sthip_scene_desc;
 
 /* gFrameParams view arrays (bdpt.hlsl:37-43), filled by BDPT::render (BDPT.cpp:444-467).
@@ -157,8 +164,9 @@ typedef struct sthip_hit {
   uint32_t instance_primitive_index; /* 0xFFFFFFFF on a miss */
 } sthip_hit;
 
-/* any_hit = 0: closest hit (trace_ray); 1: occlusion (RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH):
+/* any_hit bit 0 = 0: closest hit (trace_ray); 1: occlusion (RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH):
  * hits[i].instance_primitive_index is 0 when occluded, 0xFFFFFFFF when not; t,b1,b2 unspecified.
+ * bit 1: alpha test on (gAlphaTest), bit 2: gFlipTriangleUVs for the mask lookup.
  * rays/hits are host pointers unless device_ptrs != 0. */
 int sthip_trace_rays(sthip_ctx* ctx, const sthip_ray* rays, uint32_t ray_count, sthip_hit* hits, uint32_t any_hit,
                      uint32_t device_ptrs);

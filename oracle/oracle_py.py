@@ -99,11 +99,11 @@ class OracleScene:
             raise RuntimeError("orc_render failed: %d" % rc)
         return out
 
-    def trace(self, rays, any_hit=False, brute=False, threads=0):
+    def trace(self, rays, any_hit=False, brute=False, threads=0, alpha_test=False, flip_uvs=False):
         rays = np.ascontiguousarray(rays, dtype=wire.Ray)
         hits = np.zeros(rays.shape[0], wire.Hit)
         counters = np.zeros(2, np.uint64)
-        rc = lib().orc_trace_rays(self.h, wire.ptr(rays), rays.shape[0], wire.ptr(hits), (1 if any_hit else 0) | (2 if brute else 0), threads, wire.ptr(counters))
+        rc = lib().orc_trace_rays(self.h, wire.ptr(rays), rays.shape[0], wire.ptr(hits), (1 if any_hit else 0) | (2 if brute else 0) | (4 if alpha_test else 0) | (8 if flip_uvs else 0), threads, wire.ptr(counters))
         if rc != 0:
             raise RuntimeError("orc_trace_rays failed: %d" % rc)
         return hits, counters

@@ -385,6 +385,8 @@ struct Mesh {  // one BLAS: unique (first_vertex, indices_byte_offset, prim_coun
 struct Ray {
   v3 o, d;
   float tmin, tmax;
+  bool alpha_test = false;  // gAlphaTest: triangles of masked materials are hit only where the mask is >= 0.75
+  bool flip_uvs = false;    // gFlipTriangleUVs for the mask lookup
 };
 struct Hit {
   float t, b1, b2;
@@ -405,8 +407,14 @@ struct OrcImage {
   std::vector<std::vector<float>> mip;  // RGBA32F per level
 };
 
+struct OrcImage1 {  // Texture2D<float>: one coverage value per texel (alpha masks)
+  uint32_t w = 0, h = 0;
+  std::vector<float> px;
+};
+
 struct orc_scene {
   std::vector<OrcImage> images;
+  std::vector<OrcImage1> images1;
   std::vector<sthip_PackedVertexData> vertices;
   std::vector<uint8_t> indices;
   std::vector<Inst> instances;
@@ -584,6 +592,35 @@ inline bool sphere_test(v3 o, v3 d, float r, float tmin, float tmax, float& t) {
   return true;
 }
 
+// The alpha test of a candidate triangle hit (intersection.hlsli:117-131): the mask of the instance's material
+// (MaterialRecord.alpha_mask_index, read at material_address + 60) sampled at the hit's uv
+// (make_triangle_shading_data's interpolation, shading_data.hlsli:2-6) at level 0 — bilinear, repeat addressing — must
+// be >= 0.75. Materials without a mask are opaque.
+inline float sample_image1(const OrcImage1& im, float u, float v) {
+  const float x = u * (float)im.w - 0.5f, y = v * (float)im.h - 0.5f;
+  const float x0 = floorf(x), y0 = floorf(y);
+  const float fx = x - x0, fy = y - y0;
+  const int w = (int)im.w, h = (int)im.h;
+  auto at = [&](int xi, int yi) {
+    xi = ((xi % w) + w) % w;
+    yi = ((yi % h) + h) % h;
+    return im.px[(size_t)yi * w + xi];
+  };
+  const int ix = (int)x0, iy = (int)y0;
+  const float a = lerpf(at(ix, iy), at(ix + 1, iy), fx), b = lerpf(at(ix, iy + 1), at(ix + 1, iy + 1), fx);
+  return lerpf(a, b, fy);
+}
+inline bool alpha_passes(const orc_scene& sc, const Inst& in, const uint32_t tri[3], float b1, float b2, bool flip_uvs) {
+  uint32_t mask_index;
+  memcpy(&mask_index, &sc.materials[in.material_address() + 60], 4);
+  if (mask_index >= sc.images1.size()) return true;
+  const sthip_PackedVertexData &q0 = sc.vertices[tri[0]], &q1 = sc.vertices[tri[1]], &q2 = sc.vertices[tri[2]];
+  const float u = q0.u + (q1.u - q0.u) * b1 + (q2.u - q0.u) * b2;
+  float v = q0.v + (q1.v - q0.v) * b1 + (q2.v - q0.v) * b2;
+  if (flip_uvs) v = 1 - v;
+  return sample_image1(sc.images1[mask_index], u, v) >= 0.75f;
+}
+
 // one instance, object-space ray; returns true as soon as something is hit when any_hit
 bool trace_instance(const orc_scene& sc, uint32_t inst_index, const Ray& wr, Hit& h, bool any_hit, bool brute, uint64_t& n_nodes, uint64_t& n_tris) {
   const Inst& in = sc.instances[inst_index];
@@ -612,6 +649,7 @@ bool trace_instance(const orc_scene& sc, uint32_t inst_index, const Ray& wr, Hit
     float t, b1, b2;
     n_tris++;
     if (tri_test(o, sh, vpos(sc, tri[0]), vpos(sc, tri[1]), vpos(sc, tri[2]), wr.tmin, wr.tmax, t, b1, b2)) {
+      if (wr.alpha_test && !alpha_passes(sc, in, tri, b1, b2, wr.flip_uvs)) return false;  // intersection.hlsli:117-131
       if (any_hit) {
         h.ip = 0;
         return true;
@@ -1319,6 +1357,8 @@ float trace_ray(const Frame& fr, v3 origin, v3 direction, float t_max, Intersect
   r.d = direction;
   r.tmin = 0;
   r.tmax = t_max;
+  r.alpha_test = fr.flag(STHIP_eAlphaTest);
+  r.flip_uvs = fr.flag(STHIP_eFlipTriangleUVs);
   const Hit h = trace(*fr.sc, r, accept_first, false, counters);
   if (h.ip != 0xFFFFFFFFu) {
     isect.instance_primitive_index = h.ip;
@@ -1954,6 +1994,13 @@ orc_scene* orc_scene_create(const sthip_scene_desc* d) {
   sc->materials.assign((const uint8_t*)d->gMaterialData, (const uint8_t*)d->gMaterialData + d->material_bytes);
   if (d->gLightInstances) sc->lights.assign(d->gLightInstances, d->gLightInstances + d->light_count);
   if (d->gDistributions) sc->distributions.assign(d->gDistributions, d->gDistributions + d->distribution_count);
+  for (uint32_t i = 0; i < d->image1_count && d->gImage1s; i++) {
+    OrcImage1 im;
+    im.w = d->gImage1s[i].width;
+    im.h = d->gImage1s[i].height;
+    im.px.assign(d->gImage1s[i].pixels, d->gImage1s[i].pixels + (size_t)im.w * im.h);
+    sc->images1.push_back(std::move(im));
+  }
   for (uint32_t i = 0; i < d->image_count && d->gImages; i++) {
     OrcImage im;
     uint32_t w = d->gImages[i].width, h = d->gImages[i].height;
@@ -2055,8 +2102,7 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
   const uint32_t unsupported = (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_ePresampleLights) | (1u << STHIP_eConnectToViews) |
                                (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
-                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eAlphaTest) | (1u << STHIP_eCoherentSampling) |
-                               (1u << STHIP_eSampleEnvironmentMapDirectly);
+                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eCoherentSampling) | (1u << STHIP_eSampleEnvironmentMapDirectly);
   if (sampling_flags & unsupported) return STHIP_ERR_UNSUPPORTED;
   Frame fr;
   fr.sc = sc;
@@ -2133,6 +2179,8 @@ int orc_trace_rays(orc_scene* sc, const sthip_ray* rays, uint32_t n, sthip_hit* 
       r.d = V3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
       r.tmin = rays[i].tmin;
       r.tmax = rays[i].tmax;
+      r.alpha_test = (mode & 4) != 0;  // mode: 1 = any hit, 2 = brute force, 4 = alpha test, 8 = flipped triangle uvs
+      r.flip_uvs = (mode & 8) != 0;
       const Hit h = trace(*sc, r, (mode & 1) != 0, (mode & 2) != 0, &tc[(size_t)tid * 2]);
       hits[i].t = h.t;
       hits[i].b1 = h.b1;

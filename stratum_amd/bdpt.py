@@ -199,9 +199,10 @@ class BDPT:
         return self._prev_result
 
     # ---- the traversal contract on its own ----
-    def trace(self, rays, any_hit=False):
+    def trace(self, rays, any_hit=False, alpha_test=False, flip_uvs=False):
         rays = np.ascontiguousarray(rays, dtype=wire.Ray)
         hits = np.zeros(rays.shape[0], wire.Hit)
-        rc = self._lib.sthip_trace_rays(self._h, wire.ptr(rays), rays.shape[0], wire.ptr(hits), 1 if any_hit else 0, 0)
+        mode = (1 if any_hit else 0) | (2 if alpha_test else 0) | (4 if flip_uvs else 0)
+        rc = self._lib.sthip_trace_rays(self._h, wire.ptr(rays), rays.shape[0], wire.ptr(hits), mode, 0)
         self._check(rc, "sthip_trace_rays")
         return hits

@@ -52,6 +52,7 @@ struct sthip_ctx {
   // scene
   bool has_scene = false;
   bool textured = false;      // some material binds an image: k_shade<true> (ray cones, image values, normal maps)
+  bool has_alpha = false;     // some triangle material has an alpha mask (gImage1s)
   bool has_spheres = false;   // some instance is a sphere: k_shade<., true>
   std::vector<uint8_t> materials_host;                    // gMaterialData as uploaded (validation of the environment record)
   std::vector<std::pair<uint32_t, uint32_t>> image_dims;  // (width, height) of gImages
@@ -79,6 +80,10 @@ struct sthip_ctx {
   DevBuf<uint32_t> meta, queue0, queue1;
   DevBuf<unsigned long long> counters;
   DevBuf<float> distributions;  // gDistributions
+  DevBuf<DeviceImage1> images1;  // gImage1s (alpha masks)
+  DevBuf<float> image1_texels;
+  DevBuf<BvhTriUv> tri_uvs;
+  DevBuf<uint32_t> inst_alpha;
   DevBuf<unsigned long long> qctl;  // queue control lines (queue_ctl)
   DevBuf<uint32_t> post_scratch;  // maxima / metric accumulator of post.h
   DevBuf<float4> out_radiance, out_albedo;
@@ -197,6 +202,10 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->queue1.release();
   ctx->counters.release();
   ctx->distributions.release();
+  ctx->images1.release();
+  ctx->image1_texels.release();
+  ctx->tri_uvs.release();
+  ctx->inst_alpha.release();
   ctx->qctl.release();
   ctx->post_scratch.release();
   ctx->out_radiance.release();
@@ -283,7 +292,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->has_scene = false;
   for (uint32_t i = 0; i < s->light_count; i++)
     if (s->gLightInstances[i] >= s->instance_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: gLightInstances entry out of range");
-  bool any_specular = false, any_image = false;
+  bool any_specular = false, any_image = false, any_alpha = false;
   // materials: constant values or image values over gImages (image_value.h:183-207)
   for (uint32_t i = 0; i < s->instance_count; i++) {
     const uint32_t addr = s->gInstances[i].packed[0] >> 4;
@@ -299,13 +308,17 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
       if (rec.bump_index >= s->image_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: a bump map refers to an image that is not in gImages");
       any_image = true;
     }
-    if (rec.alpha_mask_index < STHIP_IMAGE_COUNT) return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: alpha-mask images (eAlphaTest) are not part of the built hot path");
+    if (rec.alpha_mask_index < STHIP_IMAGE_COUNT && (s->gInstances[i].packed[0] & 0xF) == STHIP_INSTANCE_TYPE_TRIANGLES) {
+      if (rec.alpha_mask_index >= s->image1_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: a material refers to an alpha mask that is not in gImage1s");
+      any_alpha = true;
+    }
     const float metallic = rec.values[1].value[0], roughness = rec.values[1].value[1], transmission = rec.values[2].value[2];
     if ((metallic > 0.999f || transmission > 0.999f) && roughness <= 1e-2f) any_specular = true;
   }
   ctx->has_specular = any_specular;
   ctx->textured = any_image;
   if (s->image_count && !s->gImages) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: image_count > 0 but gImages is NULL");
+  if (s->image1_count && !s->gImage1s) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: image1_count > 0 but gImage1s is NULL");
   sthip::BuiltBvh built;
   std::string err;
   const auto t_build0 = std::chrono::steady_clock::now();
@@ -401,6 +414,34 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (!built.nodes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->nodes.p, built.nodes.data(), built.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
   if (!built.tris.empty()) HIP_TRY(ctx, hipMemcpy(ctx->tris.p, built.tris.data(), built.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
   if (!built.entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->entries.p, built.entries.data(), built.entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
+  {  // alpha masks: one-channel images and the per-triangle uvs the traversal interpolates
+    std::vector<DeviceImage1> table(s->image1_count);
+    std::vector<float> texels;
+    for (uint32_t i = 0; i < s->image1_count; i++) {
+      const sthip_image_desc& im = s->gImage1s[i];
+      if (!im.pixels || im.width == 0 || im.height == 0 || im.width > 0xFFFF || im.height > 0xFFFF) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: bad alpha-mask image");
+      table[i].offset = (uint32_t)texels.size();
+      table[i].w = im.width;
+      table[i].h = im.height;
+      table[i].pad = 0;
+      texels.insert(texels.end(), im.pixels, im.pixels + (size_t)im.width * im.height);
+    }
+    HIP_TRY(ctx, ctx->images1.ensure(std::max<size_t>(1, table.size())));
+    HIP_TRY(ctx, ctx->image1_texels.ensure(std::max<size_t>(1, texels.size())));
+    HIP_TRY(ctx, ctx->tri_uvs.ensure(std::max<size_t>(1, built.tri_uvs.size())));
+    if (!table.empty()) HIP_TRY(ctx, hipMemcpy(ctx->images1.p, table.data(), table.size() * sizeof(DeviceImage1), hipMemcpyHostToDevice));
+    if (!texels.empty()) HIP_TRY(ctx, hipMemcpy(ctx->image1_texels.p, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!built.tri_uvs.empty()) HIP_TRY(ctx, hipMemcpy(ctx->tri_uvs.p, built.tri_uvs.data(), built.tri_uvs.size() * sizeof(BvhTriUv), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, ctx->inst_alpha.ensure(std::max<size_t>(1, built.inst_alpha.size())));
+    if (!built.inst_alpha.empty()) HIP_TRY(ctx, hipMemcpy(ctx->inst_alpha.p, built.inst_alpha.data(), built.inst_alpha.size() * 4, hipMemcpyHostToDevice));
+    ctx->bvh.inst_alpha = ctx->inst_alpha.p;
+    ctx->has_alpha = any_alpha && !built.tri_uvs.empty();
+    ctx->bvh.tri_uv = reinterpret_cast<const float2*>(ctx->tri_uvs.p);
+    ctx->bvh.images1 = ctx->images1.p;
+    ctx->bvh.image1_texels = ctx->image1_texels.p;
+    ctx->bvh.alpha_test = 0;
+    ctx->bvh.flip_uvs = 0;
+  }
   ctx->bvh.nodes = reinterpret_cast<const float4*>(ctx->nodes.p);
   ctx->bvh.tris = reinterpret_cast<const float4*>(ctx->tris.p);
   ctx->bvh.entries = ctx->entries.p;
@@ -416,7 +457,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->has_scene = true;
   if (getenv("STHIP_VERBOSE")) {
     int per_cu = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, STHIP_BLOCK, stack_bytes(ctx));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false>, STHIP_BLOCK, stack_bytes(ctx));
     fprintf(stderr, "[sthip] bvh (%s): %zu nodes, %zu tris, %zu top-level entries, stack depth %u (%zu B LDS / block), %d trace blocks / CU, build %.1f ms (GPU kernels %.2f ms)\n",
             ctx->bvh_builder ? "lbvh/gpu" : "sah/host", built.nodes.size(), built.tris.size(), built.entries.size(), built.stack_depth, stack_bytes(ctx), per_cu, ctx->stats.bvh_build_ms,
             ctx->stats.bvh_build_gpu_ms);
@@ -435,7 +476,7 @@ static uint32_t grid_for(const sthip_ctx* ctx, size_t n) {
 // Persistent trace kernels: as many blocks as are resident at once (LDS stack and VGPRs bound it).
 static uint32_t trace_grid(sthip_ctx* ctx, size_t lds_bytes) {
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, STHIP_BLOCK, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false>, STHIP_BLOCK, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
   if (ctx->trace_blocks_per_cu) per_cu = (int)ctx->trace_blocks_per_cu;
   return (uint32_t)(ctx->cu_count * per_cu);
 }
@@ -461,16 +502,20 @@ int sthip_trace_rays(sthip_ctx* ctx, const sthip_ray* rays, uint32_t ray_count, 
   HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_TOTAL * sizeof(unsigned long long), ctx->stream));
   const uint32_t grid = grid_for(ctx, ray_count);
   const size_t lds = stack_bytes(ctx);
+  DeviceBvh bvh = ctx->bvh;
+  bvh.alpha_test = (ctx->has_alpha && (any_hit & 2u)) ? 1u : 0u;
+  bvh.flip_uvs = (any_hit & 4u) ? 1u : 0u;
+  any_hit &= 1u;
   if (any_hit) {
     if (ctx->count_traversal)
-      hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(grid), dim3(STHIP_BLOCK), lds, ctx->stream, ctx->bvh, d_rays, ray_count, d_hits, ctx->counters.p);
+      hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(grid), dim3(STHIP_BLOCK), lds, ctx->stream, bvh, d_rays, ray_count, d_hits, ctx->counters.p);
     else
-      hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(STHIP_BLOCK), lds, ctx->stream, ctx->bvh, d_rays, ray_count, d_hits, ctx->counters.p);
+      hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(STHIP_BLOCK), lds, ctx->stream, bvh, d_rays, ray_count, d_hits, ctx->counters.p);
   } else {
     if (ctx->count_traversal)
-      hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(STHIP_BLOCK), lds, ctx->stream, ctx->bvh, d_rays, ray_count, d_hits, ctx->counters.p);
+      hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(STHIP_BLOCK), lds, ctx->stream, bvh, d_rays, ray_count, d_hits, ctx->counters.p);
     else
-      hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(STHIP_BLOCK), lds, ctx->stream, ctx->bvh, d_rays, ray_count, d_hits, ctx->counters.p);
+      hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(STHIP_BLOCK), lds, ctx->stream, bvh, d_rays, ray_count, d_hits, ctx->counters.p);
   }
   HIP_TRY(ctx, hipGetLastError());
   if (!device_ptrs) {
@@ -502,8 +547,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media / light-tracing scene flags are not part of the built hot path");
   const uint32_t unsupported = (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_ePresampleLights) | (1u << STHIP_eConnectToViews) |
                                (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
-                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eAlphaTest) | (1u << STHIP_eCoherentSampling) |
-                               (1u << STHIP_eSampleEnvironmentMapDirectly);
+                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eCoherentSampling) | (1u << STHIP_eSampleEnvironmentMapDirectly);
   if (sampling_flags & unsupported) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: a sampling flag outside the built hot path is set");
   if (pc->gMaxPathVertices > 60 || pc->gMaxDiffuseVertices > 60) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: path length limits above 60");
   if (pc->gLightCount > ctx->light_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: gLightCount exceeds the uploaded light list");
@@ -601,6 +645,9 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.prev_views = reinterpret_cast<const sthip_ViewData*>(ctx->views.p + 2 * vbytes);
   p.prev_inv_view_xf = reinterpret_cast<const sthip_TransformData*>(ctx->views.p + 3 * vbytes);
 
+  p.bvh = ctx->bvh;
+  p.bvh.alpha_test = (ctx->has_alpha && (sampling_flags & (1u << STHIP_eAlphaTest))) ? 1u : 0u;  // intersection.hlsli:118
+  p.bvh.flip_uvs = (sampling_flags & (1u << STHIP_eFlipTriangleUVs)) ? 1u : 0u;
   p.scene.vertices = ctx->vertices.p;
   p.scene.indices = ctx->indices.p;
   p.scene.instances = ctx->instances.p;
@@ -616,7 +663,6 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.scene.image_count = ctx->image_count;
   p.scene.distributions = ctx->distributions.p;
   p.scene.distribution_count = ctx->distribution_count;
-  p.bvh = ctx->bvh;
   p.ray_o = ctx->ray_o.p;
   p.ray_d = ctx->ray_d.p;
   p.hit = ctx->hit.p;
@@ -746,10 +792,15 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       if (dc == TRACE_NONE && ds == TRACE_NONE) return STHIP_OK;
       launches_trace++;
       return timed(ms_trace, [&]() {
-        if (ctx->count_traversal)
-          hipLaunchKernelGGL((k_trace<true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
+        if (p.bvh.alpha_test) {  // scenes with alpha masks under eAlphaTest: the instantiation that carries the mask lookup
+          if (ctx->count_traversal)
+            hipLaunchKernelGGL((k_trace<true, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
+          else
+            hipLaunchKernelGGL((k_trace<false, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
+        } else if (ctx->count_traversal)
+          hipLaunchKernelGGL((k_trace<true, false>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
         else
-          hipLaunchKernelGGL((k_trace<false>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
+          hipLaunchKernelGGL((k_trace<false, false>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
       });
     };
     for (uint32_t depth = 0; depth <= max_bounce_rounds; depth++) {

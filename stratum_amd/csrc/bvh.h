@@ -37,6 +37,11 @@ struct BvhTri {
   float v2[3];
   uint32_t pad2;
 };
+#define BVH_NO_ALPHA 0xFFFFFFFFu  // DeviceBvh::inst_alpha entry of an instance whose material has no alpha mask
+// uv of the three vertices of a leaf triangle, in leaf order next to BvhTri; only built for scenes with alpha masks
+struct BvhTriUv {
+  float uv[3][2];
+};
 
 // One entry of the top level: the merged world-space mesh (all instances whose transform is the identity,
 // flattened into one BLAS), one transformed triangle instance, or one sphere instance (tested in place, no BLAS).

@@ -307,6 +307,28 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       separate.push_back(i);
   }
 
+  // alpha masks (Material.hpp:35): MaterialRecord.alpha_mask_index of the instance's material, if it names an image
+  std::vector<uint32_t> inst_alpha(s.instance_count, BVH_NO_ALPHA);
+  bool any_alpha = false;
+  for (uint32_t i = 0; i < s.instance_count; i++) {
+    const InstView in = view(s.gInstances[i]);
+    if (in.type != STHIP_INSTANCE_TYPE_TRIANGLES) continue;
+    sthip_MaterialRecord rec;
+    memcpy(&rec, (const uint8_t*)s.gMaterialData + in.material_address, sizeof(rec));
+    if (rec.alpha_mask_index < STHIP_IMAGE_COUNT) {
+      if (rec.alpha_mask_index >= s.image1_count) {
+        err = "a material refers to an alpha mask that is not in gImage1s";
+        return false;
+      }
+      inst_alpha[i] = rec.alpha_mask_index;
+      any_alpha = true;
+    }
+  }
+  if (any_alpha && builder == BVH_BUILDER_LBVH_GPU) {
+    err = "only triangle soups without alpha masks go through the GPU LBVH builder (use the SAH builder)";
+    return false;
+  }
+
   std::string gpu_err;
   auto add_blas = [&](const std::vector<std::pair<uint32_t, uint32_t>>& prims /* (instance, prim) */, bool with_instance_bits, Box& bounds, uint32_t& depth) -> uint32_t {
     if (builder == BVH_BUILDER_LBVH_GPU && prims.size() >= 64) {
@@ -360,6 +382,15 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       memcpy(t.v2, s.gVertices[tri[2]].position, 12);
       t.id = (pr.second << 16) | (with_instance_bits ? pr.first : 0u);
       t.pad1 = t.pad2 = 0;
+      if (any_alpha) {
+        BvhTriUv uv;
+        for (int v = 0; v < 3; v++) {
+          uv.uv[v][0] = s.gVertices[tri[v]].u;
+          uv.uv[v][1] = s.gVertices[tri[v]].v;
+        }
+        if (out.tri_uvs.size() < tri_base + prims.size()) out.tri_uvs.resize(tri_base + prims.size());
+        out.tri_uvs[tri_base + k] = uv;
+      }
     }
     const uint32_t root = flatten(b, 0, out.nodes, [&](uint32_t first, uint32_t count) { return BVH_LEAF_BIT | ((tri_base + first) << 2) | (count - 1); });
     if (root & BVH_LEAF_BIT) {  // a mesh of <= 4 triangles: give it a one-child root so kernels always start at an inner node
@@ -514,6 +545,8 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
     out.scene_radius = 0.5f * sqrtf((scene_box.hi[0] - scene_box.lo[0]) * (scene_box.hi[0] - scene_box.lo[0]) + (scene_box.hi[1] - scene_box.lo[1]) * (scene_box.hi[1] - scene_box.lo[1]) +
                                     (scene_box.hi[2] - scene_box.lo[2]) * (scene_box.hi[2] - scene_box.lo[2]));
   }
+  if (any_alpha) out.tri_uvs.resize(out.tris.size());
+  out.inst_alpha = inst_alpha;
   return true;
 }
 

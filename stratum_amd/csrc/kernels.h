@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
 // trace_shadows, bdpt.hlsl:311-325) — the two are independent, and the shadow rays of the previous bounce fill the
 // lanes that would otherwise idle while the last, longest closest-hit rays of a launch finish. Either depth may be
 // TRACE_NONE.
-template <bool COUNT>
+template <bool COUNT, bool ALPHA>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t depth_closest, uint32_t depth_shadow) {
   extern __shared__ uint32_t lds_stack[];
   const bool first = depth_closest == 0;        // first bounce: every slot, no queue
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
   cnt[0].clear();
   cnt[1].clear();
   uint32_t round_slots[2] = {0, 0}, busy_rounds[2] = {0, 0};
-  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK> tr;
+  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA> tr;
   tr.reset();
   tr.any = false;
   WaveWork work_c, work_s;
@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_batch(DeviceBvh bvh, cons
     const float4* r = reinterpret_cast<const float4*>(rays + i);
     const float4 a = r[0], b = r[1];
     RayHit h;
-    traverse<ANY_HIT ? TRAV_ANY : TRAV_CLOSEST, COUNT, STHIP_BLOCK>(bvh, xyz(a), xyz(b), a.w, b.w, lds_stack + threadIdx.x, h, cnt);
+    traverse<ANY_HIT ? TRAV_ANY : TRAV_CLOSEST, COUNT, STHIP_BLOCK, true>(bvh, xyz(a), xyz(b), a.w, b.w, lds_stack + threadIdx.x, h, cnt);
     sthip_hit out;
     out.t = h.t;
     out.b1 = h.b1;

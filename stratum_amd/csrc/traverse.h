@@ -27,7 +27,30 @@ struct DeviceBvh {
   uint32_t top_is_world_blas;
   uint32_t stack_depth;
   float scene_cx, scene_cy, scene_cz, scene_radius;
+  // alpha masks (gAlphaTest, intersection.hlsli:117-131); alpha_test = 0 unless the flag is set AND a material has a mask
+  const float2* tri_uv;         // BvhTriUv: 3 x float2 per leaf triangle
+  const uint32_t* inst_alpha;   // per instance: gImage1s index of its material's mask, BVH_NO_ALPHA if none
+  const struct DeviceImage1* images1;
+  const float* image1_texels;
+  uint32_t alpha_test;
+  uint32_t flip_uvs;            // gFlipTriangleUVs for the mask lookup
 };
+struct DeviceImage1 {
+  uint32_t offset, w, h, pad;
+};
+// level-0 lookup of a one-channel image: bilinear, repeat addressing (the same arithmetic as DisneyMaterial::bilinear)
+DEV float sample_image1(const DeviceBvh& bvh, uint32_t index, float u, float v) {
+  const DeviceImage1 im = bvh.images1[index];
+  const float x = u * (float)im.w - 0.5f, y = v * (float)im.h - 0.5f;
+  const float x0 = floorf(x), y0 = floorf(y);
+  const float fx = x - x0, fy = y - y0;
+  const int w = (int)im.w, h = (int)im.h;
+  const int ix = (int)x0, iy = (int)y0;
+  const int xa = ((ix % w) + w) % w, xb = (((ix + 1) % w) + w) % w, ya = ((iy % h) + h) % h, yb = (((iy + 1) % h) + h) % h;
+  const float* t = bvh.image1_texels + im.offset;
+  const float a = lerp1(t[(size_t)ya * w + xa], t[(size_t)ya * w + xb], fx), b = lerp1(t[(size_t)yb * w + xa], t[(size_t)yb * w + xb], fx);
+  return lerp1(a, b, fy);
+}
 
 struct RayHit {
   float t, b1, b2;
@@ -160,7 +183,7 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
 #define TRAV_CLOSEST 0  // closest hit
 #define TRAV_ANY 1      // occlusion: stop at the first accepted triangle (hit.ip = 0)
 #define TRAV_MIXED 2    // per lane, member `any` (the persistent kernel feeds closest-hit and shadow rays to one wave)
-template <int MODE, bool COUNT, uint32_t STRIDE>
+template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
 struct Traversal {
   bool any;  // TRAV_MIXED only
   DEV bool is_any() const { return MODE == TRAV_ANY || (MODE == TRAV_MIXED && any); }
@@ -296,6 +319,17 @@ struct Traversal {
       }
       float t, b1, b2;
       if (tri_test(sp, xyz(v0), xyz(v1), xyz(v2), tmin, tmax, t, b1, b2)) {
+        // gAlphaTest: the candidate must pass the mask of its instance's material (instances that share a mesh may
+        // have different materials, so the mask comes from the instance, the uvs from the leaf triangle)
+        const uint32_t mask = (ALPHA && bvh.alpha_test) ? bvh.inst_alpha[(__float_as_uint(v0.w) | id_bits) & 0xFFFFu] : BVH_NO_ALPHA;
+        if (mask != BVH_NO_ALPHA) {
+          const float2* q = bvh.tri_uv + (size_t)(first + i) * 3u;
+          const float2 u0 = q[0], u1 = q[1], u2 = q[2];
+          const float u = u0.x + (u1.x - u0.x) * b1 + (u2.x - u0.x) * b2;  // shading_data.hlsli:2-6
+          float v = u0.y + (u1.y - u0.y) * b1 + (u2.y - u0.y) * b2;
+          if (bvh.flip_uvs) v = 1 - v;
+          if (!(sample_image1(bvh, mask, u, v) >= 0.75f)) continue;
+        }
         if (is_any()) {
           hit.ip = 0;
           ref = TRAV_DONE;
@@ -322,9 +356,9 @@ struct Traversal {
 
 // One ray to completion (ray batches, tests). Returns true if something was hit; ANY_HIT stops at the
 // first accepted triangle (hit.ip = 0). `stack` points at this lane's column of the LDS stack.
-template <int MODE, bool COUNT, uint32_t STRIDE>
+template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false>
 DEV bool traverse(const DeviceBvh& bvh, f3 o, f3 d, float tmin, float tmax, uint32_t* stack, RayHit& hit, TraverseCounters& cnt) {
-  Traversal<MODE, COUNT, STRIDE> tr;
+  Traversal<MODE, COUNT, STRIDE, ALPHA> tr;
   tr.any = MODE == TRAV_ANY;
   tr.start(bvh, stack, o, d, tmin, tmax);
   while (tr.active()) tr.round(bvh, stack, 1, cnt);

@@ -368,9 +368,22 @@ struct Image {
   uint32_t width = 0, height = 0;
   std::vector<float> pixels;  // width * height * 4, row 0 first
 };
-// MaterialResources, image_value.h:34-66: images get their gImages index the first time a material stores them
+// a one-channel float texture (Texture2D<float>): what Material::alpha_mask holds (R8Unorm coverage upstream, Scene.cpp:182)
+struct Image1 {
+  uint32_t width = 0, height = 0;
+  std::vector<float> pixels;  // width * height, row 0 first
+};
+// MaterialResources, image_value.h:34-66: images get their gImages / gImage1s index the first time a material stores them
 struct MaterialResources {
   std::vector<const Image*> image4s;
+  std::vector<const Image1*> image1s;
+  uint32_t get_index(const component_ptr<Image1>& image) {
+    if (!image) return ~0u;
+    for (size_t i = 0; i < image1s.size(); i++)
+      if (image1s[i] == image.get()) return (uint32_t)i;
+    image1s.push_back(image.get());
+    return (uint32_t)image1s.size() - 1;
+  }
   std::vector<std::pair<const std::vector<float>*, uint32_t>> distribution_data_map;  // table -> offset in gDistributions
   uint32_t distribution_data_size = 0;
   uint32_t get_index(const component_ptr<Image>& image) {
@@ -395,6 +408,7 @@ struct ImageValue4 {
 };
 struct Material {
   ImageValue4 values[3];
+  component_ptr<Image1> alpha_mask;  // Material.hpp:14
   component_ptr<Image> bump_image;
   float bump_strength = 1;
   float* base_color() { return values[0].value; }
@@ -407,7 +421,7 @@ struct Material {
   float& clearcoat_gloss() { return values[2].value[1]; }
   float& transmission() { return values[2].value[2]; }
   float& eta() { return values[2].value[3]; }
-  // Material::store, Material.hpp:32-38 (alpha masks are outside the built path: always "no image")
+  // Material::store, Material.hpp:32-38
   void store(std::vector<uint32_t>& bytes, MaterialResources& resources) const {
     for (int i = 0; i < 3; i++) {
       for (int j = 0; j < 4; j++) {
@@ -417,7 +431,7 @@ struct Material {
       }
       bytes.push_back(resources.get_index(values[i].image));
     }
-    bytes.push_back(~0u);
+    bytes.push_back(resources.get_index(alpha_mask));
     bytes.push_back(resources.get_index(bump_image));
     uint32_t u;
     std::memcpy(&u, &bump_strength, 4);
@@ -576,7 +590,7 @@ class Scene {
     std::vector<uint32_t> mLightInstanceMap;
     std::vector<Node*> mInstanceNodes;
     MaterialResources mResources;
-    std::vector<sthip_image_desc> mImageDescs;
+    std::vector<sthip_image_desc> mImageDescs, mImage1Descs;
     std::vector<float> mDistributionData;  // gDistributions, Scene.cpp:670-683
     uint32_t mEnvironmentMaterialAddress = ~0u;
     uint32_t mMaterialCount = 0;
@@ -598,6 +612,8 @@ class Scene {
       d.light_count = (uint32_t)mLightInstanceMap.size();
       d.gImages = mImageDescs.data();
       d.image_count = (uint32_t)mImageDescs.size();
+      d.gImage1s = mImage1Descs.data();
+      d.image1_count = (uint32_t)mImage1Descs.size();
       d.gDistributions = mDistributionData.empty() ? nullptr : mDistributionData.data();
       d.distribution_count = (uint32_t)mDistributionData.size();
       return d;
@@ -713,6 +729,7 @@ class Scene {
       }
     });
     for (const Image* im : sd->mResources.image4s) sd->mImageDescs.push_back(sthip_image_desc{im->pixels.data(), im->width, im->height});
+    for (const Image1* im : sd->mResources.image1s) sd->mImage1Descs.push_back(sthip_image_desc{im->pixels.data(), im->width, im->height});
     sd->mDistributionData.resize(sd->mResources.distribution_data_size);
     for (const auto& e : sd->mResources.distribution_data_map) std::copy(e.first->begin(), e.first->end(), sd->mDistributionData.begin() + e.second);  // Scene.cpp:679-680
     mSceneData = sd;

@@ -95,6 +95,7 @@ class SceneData:
         self.materials = materials
         self.lights = lights
         self.images = []  # RGBA32F arrays (H, W, 4): Texture2D<float4> gImages[]
+        self.images1 = []  # float32 arrays (H, W): Texture2D<float> gImage1s[] (alpha masks)
         self.distributions = np.zeros(0, np.float32)  # StructuredBuffer<float> gDistributions
         self.environment_address = 0xFFFFFFFF  # SceneData::mEnvironmentMaterialAddress, Scene.cpp:631-640
 
@@ -136,6 +137,14 @@ class SceneData:
                 self._image_descs[i].height = im.shape[0]
             d.gImages = C.cast(self._image_descs, C.c_void_p)
             d.image_count = len(self.images)
+        if self.images1:
+            self._image1_descs = (wire.ImageDesc * len(self.images1))()
+            for i, im in enumerate(self.images1):
+                self._image1_descs[i].pixels = wire.ptr(im)
+                self._image1_descs[i].width = im.shape[1]
+                self._image1_descs[i].height = im.shape[0]
+            d.gImage1s = C.cast(self._image1_descs, C.c_void_p)
+            d.image1_count = len(self.images1)
         if self.distributions.size:
             d.gDistributions = wire.ptr(self.distributions)
             d.distribution_count = self.distributions.size
@@ -153,6 +162,7 @@ class SceneBuilder:
         self._materials = []  # MaterialRecord entries
         self._instances = []  # (mesh, material index, 4x4 transform)
         self._images = []  # RGBA32F (H, W, 4)
+        self._images1 = []  # float32 (H, W): one-channel images (alpha masks)
         self._spheres = []  # (material index, 4x4 node transform, radius): SpherePrimitive, Scene.hpp:34-37
         self._environment = None  # (value rgb, image handle or None): Environment, environment.h
 
@@ -187,6 +197,17 @@ class SceneBuilder:
         assert im.ndim == 3 and im.shape[2] == 4
         self._images.append(im)
         return len(self._images) - 1
+
+    def add_image1(self, gray):
+        """Registers a Texture2D<float> (float32 array H x W, row 0 first); returns its handle (gImage1s index by first use)."""
+        im = np.ascontiguousarray(gray, dtype=np.float32)
+        assert im.ndim == 2
+        self._images1.append(im)
+        return len(self._images1) - 1
+
+    def set_material_alpha_mask(self, material, image1):
+        """Material::alpha_mask (Material.hpp:14,35): coverage image tested by eAlphaTest."""
+        self._materials[material]["alpha_mask_index"] = image1
 
     def set_material_images(self, material, base_color_image=None, params_image=None, lobes_image=None, bump_image=None, bump_strength=1.0):
         """Binds images to the three ImageValue4 of a material (disney_data.h:1-20) and/or a normal map."""
@@ -259,6 +280,16 @@ class SceneBuilder:
         # ... and an image gets its gImages index the first time a stored material refers to it
         # (MaterialResources::get_index, image_value.h:34-48)
         address_of, used, image_index_of, image_order = {}, [], {}, []
+        image1_index_of, image1_order = {}, []
+
+        def image1_index(handle):
+            handle = int(handle)
+            if handle == 0xFFFFFFFF:
+                return 0xFFFFFFFF
+            if handle not in image1_index_of:
+                image1_index_of[handle] = len(image1_order)
+                image1_order.append(handle)
+            return image1_index_of[handle]
 
         def image_index(handle):
             handle = int(handle)
@@ -273,8 +304,9 @@ class SceneBuilder:
             if mat not in address_of:
                 address_of[mat] = len(used) * wire.MaterialRecord.itemsize
                 rec = self._materials[mat].copy()
-                for k in range(3):
+                for k in range(3):  # Material::store's order, Material.hpp:32-37: the three values, the alpha mask, the bump map
                     rec["values"]["image_index"][k] = image_index(rec["values"]["image_index"][k])
+                rec["alpha_mask_index"] = image1_index(rec["alpha_mask_index"])
                 rec["bump_index"] = image_index(rec["bump_index"])
                 used.append(rec)
         mats = np.array(used, dtype=wire.MaterialRecord) if used else np.zeros(0, wire.MaterialRecord)
@@ -351,6 +383,7 @@ class SceneBuilder:
         )
         sd.builder = self  # the inputs the arrays were packed from (dump_description)
         sd.images = [self._images[h] for h in image_order]
+        sd.images1 = [self._images1[h] for h in image1_order]
         sd.distributions = dist
         sd.environment_address = env_address
         return sd
@@ -410,6 +443,10 @@ def dump_description(path, scene, frame):
     with open(path, "wb") as f:
         f.write(struct.pack("<I", len(builder._images)))
         for im in builder._images:
+            f.write(struct.pack("<II", im.shape[1], im.shape[0]))
+            f.write(im.tobytes())
+        f.write(struct.pack("<I", len(builder._images1)))
+        for im in builder._images1:
             f.write(struct.pack("<II", im.shape[1], im.shape[0]))
             f.write(im.tobytes())
         mats = np.array(builder._materials, dtype=wire.MaterialRecord)

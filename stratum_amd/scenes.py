@@ -9,7 +9,7 @@ Every generator returns (SceneData, camera dict) where camera = {eye, target, fo
 """
 import numpy as np
 
-from .scene import SceneBuilder, rotate_y, scale, translate
+from .scene import SceneBuilder, rotate_x, rotate_y, scale, translate
 
 MAX_TRIS = 0xFFFF
 
@@ -526,5 +526,43 @@ def environment_scene(image=True, emitter=True):
         b.set_environment((0.6, 0.8, 1.2))
     return b.build(), {"eye": (0.0, 1.3, 4.5), "target": (0.0, 0.6, 0.0), "fovy": np.radians(40.0)}
 
+def leaf_mask(n=64, seed=3):
+    """Coverage image of a leaf-like shape (1 inside, 0 outside, a soft rim in between) with a few holes."""
+    v, u = np.meshgrid((np.arange(n) + 0.5) / n, (np.arange(n) + 0.5) / n, indexing="ij")
+    x, y = 2 * u - 1, 2 * v - 1
+    r = np.sqrt((x / 0.55) ** 2 + (y / 0.95) ** 2) + 0.15 * np.sin(6 * np.arctan2(y, x))
+    a = np.clip((1.0 - r) * 6.0, 0.0, 1.0)
+    rng = np.random.RandomState(seed)
+    for _ in range(5):
+        cx, cy = rng.uniform(-0.3, 0.3), rng.uniform(-0.6, 0.6)
+        a *= np.clip((np.sqrt((x - cx) ** 2 + (y - cy) ** 2) - 0.08) * 12.0, 0.0, 1.0)
+    return a.astype(np.float32)
+
+
+def foliage():
+    """Alpha-masked cards (leaves) over a floor, lit by a quad light: with eAlphaTest the cut-out shapes and their
+    shadows appear, without it the cards are solid quads (intersection.hlsli:117-131)."""
+    b = SceneBuilder("foliage")
+    floor = b.add_material((0.6, 0.6, 0.6))
+    leaf = b.add_material((0.15, 0.55, 0.1), roughness=0.6)
+    leaf2 = b.add_material((0.6, 0.5, 0.1), roughness=0.6)
+    lamp = b.add_emitter((30.0, 28.0, 25.0))
+    mask = b.add_image1(leaf_mask())
+    b.set_material_alpha_mask(leaf, mask)
+    b.set_material_alpha_mask(leaf2, b.add_image1(leaf_mask(32, 9)))
+    S = 4.0
+    b.add_instance(b.add_mesh(*_quad((-S, 0, S), (S, 0, S), (S, 0, -S), (-S, 0, -S), (0, 1, 0))), floor)
+    b.add_instance(b.add_mesh(*_quad((-0.6, 0, -0.6), (0.6, 0, -0.6), (0.6, 0, 0.6), (-0.6, 0, 0.6), (0, -1, 0))), lamp, translate((0.0, 4.0, 0.0)))
+    p, n, uv, tri = _quad((-0.5, 0, 0.5), (0.5, 0, 0.5), (0.5, 0, -0.5), (-0.5, 0, -0.5), (0, 1, 0))
+    uv = np.array([[0, 1], [1, 1], [1, 0], [0, 0]], np.float32)
+    card = b.add_mesh(p, n, uv, tri)
+    rng = np.random.RandomState(5)
+    for k in range(24):
+        m = translate((rng.uniform(-1.5, 1.5), rng.uniform(0.6, 2.2), rng.uniform(-1.5, 1.0))) @ rotate_y(rng.uniform(0, 6.28)) @ rotate_x(rng.uniform(-0.9, 0.9)) @ scale((rng.uniform(0.5, 1.0),) * 3)
+        b.add_instance(card, leaf if k % 3 else leaf2, m)
+    return b.build(), {"eye": (0.0, 1.6, 5.0), "target": (0.0, 1.0, 0.0), "fovy": np.radians(42.0)}
+
+
+SCENES["foliage"] = foliage
 SCENES["spheres_room"] = spheres_room
 SCENES["environment"] = environment_scene

@@ -155,6 +155,8 @@ class SceneDesc(C.Structure):
         ("image_count", C.c_uint32),
         ("gDistributions", C.c_void_p),
         ("distribution_count", C.c_uint32),
+        ("gImage1s", C.c_void_p),
+        ("image1_count", C.c_uint32),
     ]
 
 

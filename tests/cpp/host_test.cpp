@@ -56,6 +56,16 @@ int main(int argc, char** argv) {
       images.push_back(im);
     }
     auto image_of = [&](uint32_t index) { return index < images.size() ? images[index] : component_ptr<Image>(); };
+    const uint32_t n_img1 = r.get<uint32_t>();
+    std::vector<component_ptr<Image1>> images1;
+    for (uint32_t i = 0; i < n_img1; i++) {
+      const uint32_t w = r.get<uint32_t>(), h = r.get<uint32_t>();
+      auto im = scene_node.make_child("image1").make_component<Image1>();
+      im->width = w;
+      im->height = h;
+      im->pixels = r.vec<float>((size_t)w * h);
+      images1.push_back(im);
+    }
     // materials
     const uint32_t n_mat = r.get<uint32_t>();
     std::vector<component_ptr<Material>> materials;
@@ -66,6 +76,7 @@ int main(int argc, char** argv) {
         std::memcpy(m->values[k].value, rec.values[k].value, 16);
         m->values[k].image = image_of(rec.values[k].image_index);
       }
+      if (rec.alpha_mask_index < images1.size()) m->alpha_mask = images1[rec.alpha_mask_index];
       m->bump_image = image_of(rec.bump_index);
       m->bump_strength = rec.bump_strength;
       materials.push_back(m);

@@ -491,3 +491,45 @@ def test_moving_camera_aovs(renderer, cornell):
     uv = (np.stack(np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5), -1) / [W, H]).astype(np.float32)
     moved = np.abs(ref["prev_uv"] - uv).max(-1)
     assert moved[hit].mean() > 2e-3  # the reprojected position really differs from the pixel's own
+
+
+def test_trace_contract_with_alpha_masks(renderer):
+    from oracle import oracle_py
+
+    sc, _ = scenes.foliage()
+    renderer.update(sc)
+    o = oracle_py.OracleScene(sc)
+    rays = random_rays(60000, 6, -2.0, 2.5)
+    for flip in (False, True):
+        got = renderer.trace(rays, alpha_test=True, flip_uvs=flip)
+        ref, _ = o.trace(rays, brute=True, alpha_test=True, flip_uvs=flip)
+        for f in ("instance_primitive_index", "t", "b1", "b2"):
+            assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), (f, flip)
+    solid = renderer.trace(rays)
+    ref_solid, _ = o.trace(rays, brute=True)
+    assert np.array_equal(solid["instance_primitive_index"], ref_solid["instance_primitive_index"])
+    assert (solid["instance_primitive_index"] != got["instance_primitive_index"]).mean() > 0.005
+    rays["tmax"] = 3.0
+    got = renderer.trace(rays, any_hit=True, alpha_test=True)
+    ref, _ = o.trace(rays, any_hit=True, brute=True, alpha_test=True)
+    assert np.array_equal(got["instance_primitive_index"], ref["instance_primitive_index"])
+
+
+@pytest.mark.parametrize("flags", [["alphatest"], [], ["alphatest", "fliptriangleuvs", "~defershadowrays"]])
+def test_alpha_masked_foliage(flags):
+    sc, cam = scenes.foliage()
+    _compare_frame(sc, cam, flags, args={"maxDiffuseVertices": 3})
+
+
+def test_alpha_masks_need_the_sah_builder():
+    from stratum_amd import _lib
+    from stratum_amd.bdpt import BDPT
+
+    sc, _ = scenes.foliage()
+    r = BDPT(device=0)
+    try:
+        r.set_option("bvh_builder", 1)
+        with pytest.raises(_lib.StratumHipError, match="alpha masks"):
+            r.update(sc)
+    finally:
+        r.close()

@@ -38,7 +38,7 @@ def shared_mesh_scene():
     return b.build(), {"eye": (0.5, 1.5, 4.0), "target": (0.5, 0.3, 0.0), "fovy": np.radians(50.0)}
 
 
-@pytest.mark.parametrize("make", [scenes.cornell_box, shared_mesh_scene, scenes.textured_box, scenes.spheres_room, scenes.environment_scene])
+@pytest.mark.parametrize("make", [scenes.cornell_box, shared_mesh_scene, scenes.textured_box, scenes.spheres_room, scenes.environment_scene, scenes.foliage])
 def test_scene_update_packs_like_the_reference_layouts(host_test, tmp_path, make):
     sc, cam = make()
     fr = camera.Frame(64, 48, cam["fovy"], cam["eye"], cam["target"])
@@ -49,7 +49,7 @@ def test_scene_update_packs_like_the_reference_layouts(host_test, tmp_path, make
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("make", [scenes.cornell_box, shared_mesh_scene, scenes.textured_box, scenes.spheres_room, scenes.environment_scene])
+@pytest.mark.parametrize("make", [scenes.cornell_box, shared_mesh_scene, scenes.textured_box, scenes.spheres_room, scenes.environment_scene, scenes.foliage])
 def test_cpp_host_renders_what_the_python_host_renders(host_test, tmp_path, make):
     from stratum_amd.bdpt import BDPT
     from stratum_amd.post import Tonemapper, write_hdr

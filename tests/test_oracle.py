@@ -580,3 +580,49 @@ def test_build_distributions_follows_dist2():
     # an all-black image falls back to the uniform tables (dist2.h:112-119,142-149)
     z = build_distributions(np.zeros((4, 8, 4), np.float32))
     assert np.allclose(z[0], 0.25) and np.allclose(z[1], 0.125) and np.allclose(z[2], [0, 0.25, 0.5, 0.75, 1])
+
+
+def test_alpha_masks_in_the_trace_contract():
+    """gAlphaTest (intersection.hlsli:117-131): a masked triangle is hit only where its coverage image is >= 0.75 at the
+    hit's uv; the acceleration structure does not change that; without the flag the card is solid."""
+    b = SceneBuilder("card")
+    m = b.add_material((1, 1, 1))
+    mask = np.zeros((8, 8), np.float32)
+    mask[:, :4] = 1.0  # left half of uv space covered
+    b.set_material_alpha_mask(m, b.add_image1(mask))
+    p, n, _, tri = scenes._quad((-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0), (0, 0, 1))
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    b.add_instance(b.add_mesh(p, n, uv, tri), m)
+    o = orc.OracleScene(b.build())
+    rays = np.zeros(2, wire.Ray)
+    rays["origin"] = [(-0.5, 0.1, 1), (0.5, 0.1, 1)]
+    rays["direction"] = (0, 0, -1)
+    rays["tmax"] = np.inf
+    h, _ = o.trace(rays)
+    assert (h["instance_primitive_index"] != wire.MISS).all()  # flag off: solid
+    h, _ = o.trace(rays, alpha_test=True)
+    assert h["instance_primitive_index"][0] != wire.MISS and h["instance_primitive_index"][1] == wire.MISS
+    # bilinear coverage: the edge between covered and empty texels passes 0.75 a quarter texel into the covered side
+    xs = np.linspace(-0.2, 0.2, 81).astype(np.float32)
+    edge = np.zeros(81, wire.Ray)
+    edge["origin"] = np.stack([xs, np.full(81, 0.1, np.float32), np.ones(81, np.float32)], 1)
+    edge["direction"] = (0, 0, -1)
+    edge["tmax"] = np.inf
+    h, _ = o.trace(edge, alpha_test=True)
+    hit = h["instance_primitive_index"] != wire.MISS
+    u_edge = (xs[hit].max() + 1) / 2  # uv.x of the last hit
+    assert abs(u_edge - (0.5 - 0.25 / 8)) < 0.01
+    # foliage: BVH == brute force, closest and any hit, with flipped uvs too
+    sc, _ = scenes.foliage()
+    o = orc.OracleScene(sc)
+    rays = random_rays(20000, 2, -2.0, 2.5)
+    for flip in (False, True):
+        a, _ = o.trace(rays, alpha_test=True, flip_uvs=flip)
+        bb, _ = o.trace(rays, brute=True, alpha_test=True, flip_uvs=flip)
+        for f in ("instance_primitive_index", "t", "b1", "b2"):
+            assert np.array_equal(a[f].view(np.uint32), bb[f].view(np.uint32)), f
+    solid, _ = o.trace(rays)
+    assert (solid["instance_primitive_index"] != a["instance_primitive_index"]).mean() > 0.01
+    a, _ = o.trace(rays, any_hit=True, alpha_test=True)
+    bb, _ = o.trace(rays, any_hit=True, brute=True, alpha_test=True)
+    assert np.array_equal(a["instance_primitive_index"], bb["instance_primitive_index"])
