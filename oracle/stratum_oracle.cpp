@@ -1074,7 +1074,7 @@ struct DisneyMaterial {
   }
   // disney_clearcoat.hlsli:1-9
   static float clearcoat_eval_pdf(float D, v3 h, float hdotwo) { return D * fabsf(h.z) / (4 * fabsf(hdotwo)); }
-  static float clearcoat_eval(float D, v3 dir_in, v3 dir_out, v3 h, float hdotwo) {
+  static float clearcoat_eval(float D, v3 dir_in, v3 dir_out, v3 /*h*/, float hdotwo) {
     const float Fc = schlick_fresnel1(R0(1.5f), hdotwo);
     return Fc * D * Gc(dir_in) * Gc(dir_out) / (4 * fabsf(dir_in.z));
   }
