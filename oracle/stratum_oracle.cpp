@@ -1235,11 +1235,20 @@ struct DisneyMaterial {
 // ---------------------------------------------------------------------------------------------
 // frame state shared by all pixels
 // ---------------------------------------------------------------------------------------------
+struct PresampledLightPoint {  // bdpt.h:92-100
+  v3 position;
+  uint32_t packed_geometry_normal;
+  v3 Le;
+  float pdfA;  // negative for environment map samples
+};
 struct Frame {
   const orc_scene* sc;
   sthip_BDPTPushConstants pc;
   uint32_t sampling_flags, scene_flags;
   sthip_frame_desc fd;
+  // gPresampledLights of every seed of the call (ePresampleLights): [seed - seed_begin][gLightPresampleTileSize * TileCount]
+  const std::vector<PresampledLightPoint>* presampled = nullptr;
+  uint32_t seed_begin = 0;
   bool flag(int b) const { return (sampling_flags >> b) & 1u; }
 };
 
@@ -1569,7 +1578,20 @@ struct PathIntegrator {
   uint64_t counters[2];                      // nodes, tris
   uint64_t rays_total, rays_path;
 
-  PathIntegrator(const Frame& f, uint32_t x, uint32_t y, uint32_t seed) : fr(f), px(x), py(y) {
+  uint32_t seed;
+  // map_pixel_coord, bdpt_util.hlsli:76-83, with the 8x4 groups of bdpt.hlsl:11-12
+  uint32_t path_index() const {
+    const uint32_t W = fr.pc.gOutputExtent[0];
+    if (fr.flag(STHIP_eRemapThreads)) {
+      const uint32_t dispatch_w = (W + 7) / 8;
+      const uint32_t group_index = (py / 4) * dispatch_w + (px / 8);
+      return group_index * 32 + (py % 4) * 8 + (px % 8);
+    }
+    return py * W + px;
+  }
+
+  PathIntegrator(const Frame& f, uint32_t x, uint32_t y, uint32_t seed_) : fr(f), px(x), py(y), seed(seed_) {
+    const uint32_t seed = seed_;
     diffuse_vertices = 0;
     path_length = 1;
     eta_scale = 1;
@@ -1648,23 +1670,39 @@ struct PathIntegrator {
 
   // path.hlsli:311-366 + sample_Le :141-164 + DirectLightSample :166-222
   void connect_light(const DisneyMaterial& m) {
-    float rnd[4];
-    rnd[0] = rng.next_float();
-    rnd[1] = rng.next_float();
-    rnd[2] = rng.next_float();
-    rnd[3] = rng.next_float();
-    LightSampleRecord ls;
-    sample_point_on_light(fr, ls, rnd, isect.sd.position);
-    v3 Le = ls.radiance;
-    float pdfA = ls.pdf;
-    v3 ray_direction = ls.to_light;
-    float ray_distance = ls.dist;
-    float cG;
-    if (ls.is_environment) {  // sample_Le, path.hlsli:156-162
-      cG = 1;
+    v3 Le, ray_direction;
+    float pdfA, ray_distance, cG;
+    if (fr.flag(STHIP_ePresampleLights)) {
+      // path.hlsli:313-320: one of the tile's presampled points; DirectLightSample(_isect, PresampledLightPoint) :184-201
+      const uint32_t tile_size = fr.pc.gLightPresampleTileSize;
+      const uint32_t tile_offset = ((path_index() / tile_size) % fr.pc.gLightPresampleTileCount) * tile_size;
+      const uint32_t ti = rng.next_uint() % tile_size;
+      const PresampledLightPoint& lp = fr.presampled[seed - fr.seed_begin][tile_offset + ti];
+      Le = lp.Le;
+      pdfA = lp.pdfA;
+      ray_direction = lp.position - isect.sd.position;
+      const float dist2 = len_sqr(ray_direction);
+      ray_distance = sqrtf(dist2);
+      ray_direction = ray_direction / ray_distance;
+      cG = fabsf(dot(ray_direction, unpack_normal_octahedron(lp.packed_geometry_normal))) / dist2;
     } else {
-      cG = fabsf(dot(ls.to_light, ls.normal)) / pow2(ls.dist);
-      if (!ls.pdf_area_measure) pdfA = pdfA * cG;
+      float rnd[4];
+      rnd[0] = rng.next_float();
+      rnd[1] = rng.next_float();
+      rnd[2] = rng.next_float();
+      rnd[3] = rng.next_float();
+      LightSampleRecord ls;
+      sample_point_on_light(fr, ls, rnd, isect.sd.position);
+      Le = ls.radiance;
+      pdfA = ls.pdf;
+      ray_direction = ls.to_light;
+      ray_distance = ls.dist;
+      if (ls.is_environment) {  // sample_Le, path.hlsli:156-162
+        cG = 1;
+      } else {
+        cG = fabsf(dot(ls.to_light, ls.normal)) / pow2(ls.dist);
+        if (!ls.pdf_area_measure) pdfA = pdfA * cG;
+      }
     }
     // setup()
     v3 ray_origin = isect.sd.position;
@@ -2100,7 +2138,7 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
   if (!sc || !pc || !frame || !out || !out->gRadiance || !frame->gViews || !frame->gViewTransforms) return STHIP_ERR_INVALID_ARGUMENT;
   if (scene_flags & (STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT)) return STHIP_ERR_UNSUPPORTED;
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
-  const uint32_t unsupported = (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_ePresampleLights) | (1u << STHIP_eConnectToViews) |
+  const uint32_t unsupported = (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_eConnectToViews) |
                                (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
                                (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eCoherentSampling) | (1u << STHIP_eSampleEnvironmentMapDirectly);
   if (sampling_flags & unsupported) return STHIP_ERR_UNSUPPORTED;
@@ -2117,6 +2155,36 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
   if (!has_emissives(fr) && !has_environment(fr)) fr.sampling_flags &= ~(1u << STHIP_eNEE);
   if (!(fr.sampling_flags & (1u << STHIP_eNEE))) fr.sampling_flags &= ~(1u << STHIP_eDeferShadowRays);                // BDPT.cpp:522-523
   if (fr.pc.gLightCount > sc->lights.size()) return STHIP_ERR_INVALID_ARGUMENT;
+  if (!fr.flag(STHIP_eNEE)) fr.sampling_flags &= ~(1u << STHIP_ePresampleLights);  // BDPT.cpp:511-515
+  // presample_lights, bdpt.hlsl:84-99, once per seed (BDPT.cpp:644-651): rng_init(-1, index), reference point 0.
+  // An environment sample leaves `position` unset upstream, so that combination is not restated.
+  std::vector<std::vector<PresampledLightPoint>> presampled;
+  if (fr.flag(STHIP_ePresampleLights) && fr.pc.gMaxPathVertices > 2) {
+    if (has_environment(fr)) return STHIP_ERR_UNSUPPORTED;
+    const size_t n = (size_t)fr.pc.gLightPresampleTileSize * fr.pc.gLightPresampleTileCount;
+    if (n == 0 || n * seed_count > (1u << 26)) return STHIP_ERR_INVALID_ARGUMENT;
+    presampled.resize(seed_count);
+    for (uint32_t s = 0; s < seed_count; s++) {
+      presampled[s].resize(n);
+      for (size_t i = 0; i < n; i++) {
+        Rng rng;
+        rng.v[0] = rng.v[1] = 0xFFFFFFFFu;
+        rng.v[2] = seed_begin + s;
+        rng.v[3] = (uint32_t)i;
+        float rnd[4];
+        for (float& r : rnd) r = rng.next_float();
+        LightSampleRecord ls;
+        sample_point_on_light(fr, ls, rnd, V3(0.0f));
+        PresampledLightPoint& l = presampled[s][i];
+        l.position = ls.position;
+        l.packed_geometry_normal = pack_normal_octahedron(ls.normal);
+        l.Le = ls.radiance;
+        l.pdfA = ls.is_environment ? -ls.pdf : ls.pdf;
+      }
+    }
+    fr.presampled = presampled.data();
+    fr.seed_begin = seed_begin;
+  }
   const uint32_t W = pc->gOutputExtent[0], H = pc->gOutputExtent[1];
   if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
   std::vector<uint64_t> tstats((size_t)threads * 4, 0);

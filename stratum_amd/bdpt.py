@@ -71,9 +71,13 @@ class BDPT:
             ("maxPathVertices", "gMaxPathVertices"),
             ("maxDiffuseVertices", "gMaxDiffuseVertices"),
             ("maxNullCollisions", "gMaxNullCollisions"),
+            ("lightPresampleTileSize", "gLightPresampleTileSize"),
+            ("lightPresampleTileCount", "gLightPresampleTileCount"),
         ):
             if key in args:
                 setattr(self.mPushConstants, field, int(args[key]))
+        if "environmentSampleProbability" in args:  # BDPT.cpp:82
+            self.mPushConstants.gEnvironmentSampleProbability = float(args["environmentSampleProbability"])
         for a in args.get("bdptFlag", []):
             self.set_flag(a)
 

@@ -80,6 +80,7 @@ struct sthip_ctx {
   DevBuf<uint32_t> meta, queue0, queue1;
   DevBuf<unsigned long long> counters;
   DevBuf<float> distributions;  // gDistributions
+  DevBuf<float4> presampled;    // gPresampledLights
   DevBuf<DeviceImage1> images1;  // gImage1s (alpha masks)
   DevBuf<float> image1_texels;
   DevBuf<BvhTriUv> tri_uvs;
@@ -202,6 +203,7 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->queue1.release();
   ctx->counters.release();
   ctx->distributions.release();
+  ctx->presampled.release();
   ctx->images1.release();
   ctx->image1_texels.release();
   ctx->tri_uvs.release();
@@ -545,7 +547,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   // Outside the built hot path: media, light tracing, reservoirs, ...
   if (scene_flags & (STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT))
     return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media / light-tracing scene flags are not part of the built hot path");
-  const uint32_t unsupported = (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_ePresampleLights) | (1u << STHIP_eConnectToViews) |
+  const uint32_t unsupported = (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_eConnectToViews) |
                                (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
                                (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eCoherentSampling) | (1u << STHIP_eSampleEnvironmentMapDirectly);
   if (sampling_flags & unsupported) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: a sampling flag outside the built hot path is set");
@@ -561,7 +563,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (!has_env) pcn.gEnvironmentSampleProbability = 0;
   if (!has_emissives) pcn.gEnvironmentSampleProbability = 1;
   if (!has_emissives && !has_env) sampling_flags &= ~(1u << STHIP_eNEE);
-  if (!(sampling_flags & (1u << STHIP_eNEE))) sampling_flags &= ~(1u << STHIP_eDeferShadowRays);
+  if (!(sampling_flags & (1u << STHIP_eNEE))) sampling_flags &= ~((1u << STHIP_eDeferShadowRays) | (1u << STHIP_ePresampleLights));
   pc = &pcn;
   if (has_env) {  // the Environment record (environment.h:17-22): ImageValue3, then 4 offsets into gDistributions when an image is bound
     const size_t addr = pcn.gEnvironmentMaterialAddress;
@@ -622,6 +624,14 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   HIP_TRY(ctx, ctx->queue1.ensure(seg_stride * QUEUE_SEGMENTS));
   HIP_TRY(ctx, ctx->counters.ensure(CNT_TOTAL));
   HIP_TRY(ctx, ctx->qctl.ensure((size_t)2 * 64 * QUEUE_SEGMENTS * QCTL_STRIDE));
+  // ePresampleLights (BDPT.cpp:644-651): gLightPresampleTileSize x TileCount light points per seed in flight
+  const bool presample = (sampling_flags & (1u << STHIP_ePresampleLights)) && pc->gMaxPathVertices > 2;
+  const size_t presample_n = (size_t)pc->gLightPresampleTileSize * pc->gLightPresampleTileCount;
+  if (sampling_flags & (1u << STHIP_ePresampleLights)) {
+    if (has_env) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: ePresampleLights with an environment (upstream leaves the presampled environment direction unset, bdpt.hlsl:93)");
+    if (presample_n == 0 || presample_n > (1u << 24)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: gLightPresampleTileSize * gLightPresampleTileCount must be in 1 .. 2^24");
+    HIP_TRY(ctx, ctx->presampled.ensure(2 * presample_n * batch));
+  }
 
   // views
   const uint32_t nv = frame->view_count;
@@ -675,6 +685,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.queue[0] = ctx->queue0.p;
   p.queue[1] = ctx->queue1.p;
   p.shadow_rays = ctx->shadow_rays.p;
+  p.presampled = ctx->presampled.p;
   p.counters = ctx->counters.p;
   p.qctl = ctx->qctl.p;
   p.seg_stride = (uint32_t)seg_stride;
@@ -785,6 +796,21 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     }
     int rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(STHIP_BLOCK), 0, st, p); });
     if (rc) return rc;
+    if (presample) {
+      const unsigned pgrid = (unsigned)((presample_n * in_flight + STHIP_BLOCK - 1) / STHIP_BLOCK);
+      const bool ext = ctx->has_spheres || has_env;
+      rc = timed(ms_other, [&]() {
+        if (ctx->textured && ext)
+          hipLaunchKernelGGL((k_presample_lights<true, true>), dim3(pgrid), dim3(STHIP_BLOCK), 0, st, p);
+        else if (ctx->textured)
+          hipLaunchKernelGGL((k_presample_lights<true, false>), dim3(pgrid), dim3(STHIP_BLOCK), 0, st, p);
+        else if (ext)
+          hipLaunchKernelGGL((k_presample_lights<false, true>), dim3(pgrid), dim3(STHIP_BLOCK), 0, st, p);
+        else
+          hipLaunchKernelGGL((k_presample_lights<false, false>), dim3(pgrid), dim3(STHIP_BLOCK), 0, st, p);
+      });
+      if (rc) return rc;
+    }
     // Round r traces the paths entering bounce r together with the shadow rays bounce r - 1 produced (one launch,
     // k_trace), then shades bounce r; a last launch traces the shadow rays of the last bounce.
     const bool nee = (sampling_flags & (1u << STHIP_eNEE)) != 0;

@@ -58,6 +58,7 @@ struct FrameParams {
   float4* accum;       // running mean over seeds (temporal_accumulation.hlsl:118-131): rgb, n
   // queues
   uint32_t* queue[2];
+  float4* presampled;   // gPresampledLights (ePresampleLights): per seed in flight, 2 x float4 per point: (position, bits(packed normal)) (Le, pdfA)
   float4* shadow_rays;  // 3 x float4 per entry: (origin, distance) (direction, bits(slot)) (contribution, 0)
   unsigned long long* counters;  // CNT_* (64-bit each)
   unsigned long long* qctl;      // queue control lines, queue_ctl(): [path | shadow][depth < 64][QUEUE_SEGMENTS] x 128 B
@@ -307,6 +308,134 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
   }
 }
 
+// sample_point_on_light, light.hlsli:37-152 (uniform light choice), as one function for connect_light and presample_lights
+struct LightSample {
+  f3 Le, to_light, normal, position;
+  float pdf, dist;
+  bool is_env, area_measure;
+};
+template <bool TEXTURED, bool EXT>
+DEV void sample_point_on_light(const FrameParams& p, bool has_env, bool has_emissives, float r0, float r1, float r2, float r3, f3 ref_pos, LightSample& ls) {
+  ls.Le = F3s(0.0f);
+  ls.to_light = F3s(0.0f);
+  ls.normal = F3s(0.0f);
+  ls.position = F3s(0.0f);
+  ls.pdf = 0;
+  ls.dist = 0;
+  ls.is_env = false;
+  ls.area_measure = true;
+  if (has_env && (!has_emissives || r3 <= p.pc.gEnvironmentSampleProbability)) {  // light.hlsli:38-48
+    Environment env;
+    env.load(p.scene, p.pc.gEnvironmentMaterialAddress);
+    ls.Le = env.sample(p.scene, r0, r1, ls.to_light, ls.pdf);
+    if (has_emissives) ls.pdf *= p.pc.gEnvironmentSampleProbability;
+    ls.is_env = true;
+    ls.dist = __builtin_inff();
+    ls.area_measure = false;
+  } else if (has_emissives) {
+    const float rw = has_env ? (r3 - p.pc.gEnvironmentSampleProbability) / (1 - p.pc.gEnvironmentSampleProbability) : r3;
+    const int li = (int)(rw * ((float)p.pc.gLightCount * .9999f));
+    ls.pdf = 1 / (float)p.pc.gLightCount;
+    const uint32_t light_instance_index = p.scene.lights[li];
+    if (has_env) ls.pdf *= 1 - p.pc.gEnvironmentSampleProbability;
+    const Inst lin = load_inst(p.scene, light_instance_index);
+    float lu, lv;
+    if (EXT && lin.type() == STHIP_INSTANCE_TYPE_SPHERE) {  // light.hlsli:58-121
+      const float r = lin.radius();
+      const Xf t = load_xf(p.scene.xf, light_instance_index);
+
+      if (flag(p, STHIP_eUniformSphereSampling)) {
+        ls.pdf /= 4 * DET_PI * r * r;
+        const float z = 1 - 2 * r0;
+        const float r_ = sqrtf(fmaxf(0.0f, 1 - z * z));
+        const float phi = DET_2PI * r1;
+        float sp, cp;
+        det_sincosf(phi, &sp, &cp);
+        const f3 local_normal = F3(r_ * cp, z, r_ * sp);
+        cartesian_to_spherical_uv(local_normal, lu, lv);
+        ls.position = xf_point(t, r * local_normal);
+        ls.normal = normalize3(xf_vector(t, local_normal));
+      } else {
+        const f3 center = F3(t.r0.w, t.r1.w, t.r2.w);
+        f3 to_center = center - ref_pos;
+        const float dist = length3(to_center);
+        to_center = to_center / dist;
+        const float sinThetaMax = r / dist;
+        const float sinThetaMax2 = sinThetaMax * sinThetaMax;
+        const float invSinThetaMax = 1 / sinThetaMax;
+        const float cosThetaMax = sqrtf(fmaxf(0.0f, 1 - sinThetaMax2));
+        ls.pdf /= DET_2PI * (1 - cosThetaMax);
+        ls.area_measure = false;
+        float cosTheta = (cosThetaMax - 1) * r0 + 1;
+        float sinTheta2 = 1 - cosTheta * cosTheta;
+        if (sinThetaMax2 < 0.00068523f) {
+          sinTheta2 = sinThetaMax2 * r0;
+          cosTheta = sqrtf(1 - sinTheta2);
+        }
+        const float cosAlpha = sinTheta2 * invSinThetaMax + cosTheta * sqrtf(fmaxf(0.0f, 1 - sinTheta2 * invSinThetaMax * invSinThetaMax));
+        const float sinAlpha = sqrtf(fmaxf(0.0f, 1 - cosAlpha * cosAlpha));
+        const float phi = r1 * 2 * DET_PI;
+        float sp, cp;
+        det_sincosf(phi, &sp, &cp);
+        f3 T, B;
+        make_orthonormal(to_center, T, B);
+        ls.normal = -(T * sinAlpha * cp + B * sinAlpha * sp + to_center * cosAlpha);
+        ls.position = center + r * ls.normal;
+        const f3 local_normal = xf_vector(load_xf(p.scene.inv_xf, light_instance_index), ls.normal);
+        cartesian_to_spherical_uv(local_normal, lu, lv);
+      }
+      ls.to_light = ls.position - ref_pos;
+      ls.dist = length3(ls.to_light);
+      ls.to_light = ls.to_light / ls.dist;
+    } else {
+      const uint32_t lpc = lin.prim_count();
+      const uint32_t lprim = (uint32_t)fminf(r2 * (float)lpc, (float)(lpc - 1));
+      const float a = sqrtf(r0);
+      ShadingData lsd;
+      make_triangle_shading_data(p.scene, lsd, light_instance_index, lin, lprim, 1 - a, a * r1, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
+      lu = lsd.u;
+      lv = lsd.v;
+      ls.normal = lsd.geometry_normal();
+      ls.position = lsd.position;
+      ls.to_light = lsd.position - ref_pos;
+      ls.dist = length3(ls.to_light);
+      ls.to_light = ls.to_light / ls.dist;
+      ls.pdf /= lsd.shape_area * (float)lpc;
+    }
+    if (ls.pdf > 0) {
+      DisneyMaterial lm;
+      if (TEXTURED) {  // light.hlsli:143-150: uv of the light sample, uv_screen_size = 0, no normal map
+        uint32_t dn = 0, dt = 0;
+        lm.load_textured(p.scene, lin.material_address(), lu, lv, 0.0f, dn, dt, p.sampling_flags & ~(1u << STHIP_eNormalMaps));
+      } else {
+        lm.load(p.scene, lin.material_address());
+      }
+      ls.Le = lm.Le();
+    }
+  }
+}
+
+// presample_lights, bdpt.hlsl:84-99 (dispatched once per frame, BDPT.cpp:644-651): gLightPresampleTileSize x TileCount
+// light points per seed, drawn with rng_init(-1, index) and the reference point 0
+template <bool TEXTURED, bool EXT>
+__global__ void __launch_bounds__(STHIP_BLOCK) k_presample_lights(FrameParams p) {
+  const uint32_t n = p.pc.gLightPresampleTileSize * p.pc.gLightPresampleTileCount;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * p.seeds_in_flight) return;
+  const uint32_t seed_index = i / n, index = i - seed_index * n;
+  Rng rng;
+  rng.x = rng.y = 0xFFFFFFFFu;
+  rng.seed = p.seed + seed_index;
+  rng.counter = index;
+  const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float(), r3 = rng.next_float();
+  const bool has_env = EXT && (p.scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) != 0;
+  const bool has_emissives = !EXT || (p.scene_flags & STHIP_BDPT_FLAG_HAS_EMISSIVES) != 0;
+  LightSample ls;
+  sample_point_on_light<TEXTURED, EXT>(p, has_env, has_emissives, r0, r1, r2, r3, F3s(0.0f), ls);
+  p.presampled[2 * (size_t)i] = make_float4(ls.position.x, ls.position.y, ls.position.z, __uint_as_float(pack_normal_octahedron(ls.normal)));
+  p.presampled[2 * (size_t)i + 1] = make_float4(ls.Le.x, ls.Le.y, ls.Le.z, ls.is_env ? -ls.pdf : ls.pdf);
+}
+
 // ---------------------------------------------------------------------------------------------
 // shade: the tail of trace() (path.hlsli:1012-1043), the first-hit block of sample_visibility
 // (bdpt.hlsl:222-296) at depth 0, then next_vertex() (path.hlsli:955-998,1048-1075) up to the point
@@ -548,105 +677,41 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
         }
         if (use_nee) {
           // connect_light, path.hlsli:311-366; sample_Le :141-164; sample_point_on_light, light.hlsli:37-152
-          const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float(), r3 = rng.next_float();
-          f3 lLe = F3s(0.0f), to_light = F3s(0.0f), ls_normal = F3s(0.0f);
-          float ls_pdf = 0, ls_dist = 0;
-          bool ls_is_env = false, ls_area_measure = true;
-          if (has_env && (!has_emissives || r3 <= p.pc.gEnvironmentSampleProbability)) {  // light.hlsli:38-48
-            Environment env;
-            env.load(p.scene, p.pc.gEnvironmentMaterialAddress);
-            lLe = env.sample(p.scene, r0, r1, to_light, ls_pdf);
-            if (has_emissives) ls_pdf *= p.pc.gEnvironmentSampleProbability;
-            ls_is_env = true;
-            ls_dist = __builtin_inff();
-            ls_area_measure = false;
-          } else if (has_emissives) {
-            const float rw = has_env ? (r3 - p.pc.gEnvironmentSampleProbability) / (1 - p.pc.gEnvironmentSampleProbability) : r3;
-            const int li = (int)(rw * ((float)p.pc.gLightCount * .9999f));
-            ls_pdf = 1 / (float)p.pc.gLightCount;
-            const uint32_t light_instance_index = p.scene.lights[li];
-            if (has_env) ls_pdf *= 1 - p.pc.gEnvironmentSampleProbability;
-            const Inst lin = load_inst(p.scene, light_instance_index);
-            float lu, lv;
-            if (EXT && lin.type() == STHIP_INSTANCE_TYPE_SPHERE) {  // light.hlsli:58-121
-              const float r = lin.radius();
-              const Xf t = load_xf(p.scene.xf, light_instance_index);
-              f3 ls_position;
-              if (flag(p, STHIP_eUniformSphereSampling)) {
-                ls_pdf /= 4 * DET_PI * r * r;
-                const float z = 1 - 2 * r0;
-                const float r_ = sqrtf(fmaxf(0.0f, 1 - z * z));
-                const float phi = DET_2PI * r1;
-                float sp, cp;
-                det_sincosf(phi, &sp, &cp);
-                const f3 local_normal = F3(r_ * cp, z, r_ * sp);
-                cartesian_to_spherical_uv(local_normal, lu, lv);
-                ls_position = xf_point(t, r * local_normal);
-                ls_normal = normalize3(xf_vector(t, local_normal));
-              } else {
-                const f3 center = F3(t.r0.w, t.r1.w, t.r2.w);
-                f3 to_center = center - sd.position;
-                const float dist = length3(to_center);
-                to_center = to_center / dist;
-                const float sinThetaMax = r / dist;
-                const float sinThetaMax2 = sinThetaMax * sinThetaMax;
-                const float invSinThetaMax = 1 / sinThetaMax;
-                const float cosThetaMax = sqrtf(fmaxf(0.0f, 1 - sinThetaMax2));
-                ls_pdf /= DET_2PI * (1 - cosThetaMax);
-                ls_area_measure = false;
-                float cosTheta = (cosThetaMax - 1) * r0 + 1;
-                float sinTheta2 = 1 - cosTheta * cosTheta;
-                if (sinThetaMax2 < 0.00068523f) {
-                  sinTheta2 = sinThetaMax2 * r0;
-                  cosTheta = sqrtf(1 - sinTheta2);
-                }
-                const float cosAlpha = sinTheta2 * invSinThetaMax + cosTheta * sqrtf(fmaxf(0.0f, 1 - sinTheta2 * invSinThetaMax * invSinThetaMax));
-                const float sinAlpha = sqrtf(fmaxf(0.0f, 1 - cosAlpha * cosAlpha));
-                const float phi = r1 * 2 * DET_PI;
-                float sp, cp;
-                det_sincosf(phi, &sp, &cp);
-                f3 T, B;
-                make_orthonormal(to_center, T, B);
-                ls_normal = -(T * sinAlpha * cp + B * sinAlpha * sp + to_center * cosAlpha);
-                ls_position = center + r * ls_normal;
-                const f3 local_normal = xf_vector(load_xf(p.scene.inv_xf, light_instance_index), ls_normal);
-                cartesian_to_spherical_uv(local_normal, lu, lv);
-              }
-              to_light = ls_position - sd.position;
-              ls_dist = length3(to_light);
-              to_light = to_light / ls_dist;
-            } else {
-              const uint32_t lpc = lin.prim_count();
-              const uint32_t lprim = (uint32_t)fminf(r2 * (float)lpc, (float)(lpc - 1));
-              const float a = sqrtf(r0);
-              ShadingData lsd;
-              make_triangle_shading_data(p.scene, lsd, light_instance_index, lin, lprim, 1 - a, a * r1, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
-              lu = lsd.u;
-              lv = lsd.v;
-              ls_normal = lsd.geometry_normal();
-              to_light = lsd.position - sd.position;
-              ls_dist = length3(to_light);
-              to_light = to_light / ls_dist;
-              ls_pdf /= lsd.shape_area * (float)lpc;
-            }
-            if (ls_pdf > 0) {
-              DisneyMaterial lm;
-              if (TEXTURED) {  // light.hlsli:143-150: uv of the light sample, uv_screen_size = 0, no normal map
-                uint32_t dn = 0, dt = 0;
-                lm.load_textured(p.scene, lin.material_address(), lu, lv, 0.0f, dn, dt, p.sampling_flags & ~(1u << STHIP_eNormalMaps));
-              } else {
-                lm.load(p.scene, lin.material_address());
-              }
-              lLe = lm.Le();
-            }
-          }
-          float pdfA = ls_pdf;
-          float cG;
-          if (ls_is_env) {  // sample_Le, path.hlsli:156-162
-            cG = 1;
+          f3 lLe, to_light;
+          float pdfA, cG, ls_dist;
+          if (flag(p, STHIP_ePresampleLights)) {
+            // path.hlsli:313-320: one of the tile's presampled points; DirectLightSample(_isect, PresampledLightPoint) :184-201
+            uint32_t path_index;  // map_pixel_coord, bdpt_util.hlsli:76-83, with the 8x4 groups of bdpt.hlsl:11-12
+            if (flag(p, STHIP_eRemapThreads))
+              path_index = ((py >> 2) * ((p.pc.gOutputExtent[0] + 7u) >> 3) + (px >> 3)) * 32u + (py & 3u) * 8u + (px & 7u);
+            else
+              path_index = py * p.pc.gOutputExtent[0] + px;
+            const uint32_t tile_size = p.pc.gLightPresampleTileSize;
+            const uint32_t tile_offset = ((path_index / tile_size) % p.pc.gLightPresampleTileCount) * tile_size;
+            const uint32_t ti = rng.next_uint() % tile_size;
+            const float4* lp = p.presampled + 2 * ((size_t)seed_index * tile_size * p.pc.gLightPresampleTileCount + tile_offset + ti);
+            const float4 l0 = lp[0], l1 = lp[1];
+            lLe = xyz(l1);
+            pdfA = l1.w;
+            to_light = xyz(l0) - sd.position;
+            const float dist2 = len_sqr(to_light);
+            ls_dist = sqrtf(dist2);
+            to_light = to_light / ls_dist;
+            cG = fabsf(dot3(to_light, unpack_normal_octahedron(__float_as_uint(l0.w)))) / dist2;
           } else {
-            cG = fabsf(dot3(to_light, ls_normal)) / pow2f(ls_dist);
-            if (!ls_area_measure) pdfA = pdfA * cG;
+            const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float(), r3 = rng.next_float();
+            LightSample ls;
+            sample_point_on_light<TEXTURED, EXT>(p, has_env, has_emissives, r0, r1, r2, r3, sd.position, ls);
+            lLe = ls.Le;
+            to_light = ls.to_light;
+            ls_dist = ls.dist;
+            pdfA = ls.pdf;
+            if (ls.is_env) {  // sample_Le, path.hlsli:156-162
+              cG = 1;
+            } else {
+              cG = fabsf(dot3(to_light, ls.normal)) / pow2f(ls_dist);
+              if (!ls.area_measure) pdfA = pdfA * cG;
+            }
           }
           // DirectLightSample::setup, path.hlsli:204-221
           const f3 local_to_light = normalize3(frame.to_local(to_light));

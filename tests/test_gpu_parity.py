@@ -533,3 +533,26 @@ def test_alpha_masks_need_the_sah_builder():
             r.update(sc)
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("flags", [["presamplelights"], ["presamplelights", "~remapthreads", "~defershadowrays"], ["presamplelights", "~samplebsdfs"]])
+def test_presampled_lights(flags):
+    """ePresampleLights (bdpt.hlsl:84-99, path.hlsli:313-320): NEE picks one of gLightPresampleTileSize points of the
+    tile the path index selects; the points are drawn once per seed with rng_init(-1, index)."""
+    sc, cam = scenes.cornell_box()
+    _compare_frame(sc, cam, flags, seeds=3, args={"lightPresampleTileSize": 64, "lightPresampleTileCount": 16})
+    sc, cam = scenes.spheres_room()  # sphere lights keep their solid-angle pdf in the presampled point, as upstream
+    _compare_frame(sc, cam, flags, seeds=2)
+
+
+def test_presampled_lights_with_an_environment_are_rejected(renderer):
+    from stratum_amd import _lib
+
+    sc, cam = scenes.environment_scene(image=False, emitter=True)
+    renderer.update(sc)
+    renderer.set_flag("presamplelights")
+    try:
+        with pytest.raises(_lib.StratumHipError, match="ePresampleLights with an environment"):
+            renderer.render(camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"]))
+    finally:
+        renderer.set_flag("~presamplelights")
