@@ -1653,7 +1653,7 @@ struct PathIntegrator {
     if (!area_measure) light_pdfA = light_pdfA * G;  // pdfWtoA
     float weight = 1;
     if (path_length > 2) {
-      if (fr.flag(STHIP_eNEE)) weight = mis2(fr, bsdf_pdf * G, light_pdfA);
+      if (fr.flag(STHIP_eNEE)) weight = fr.flag(STHIP_eNEEReservoirs) ? 0.5f : mis2(fr, bsdf_pdf * G, light_pdfA);  // path.hlsli:881-886
     }
     radiance = radiance + contrib * weight;
   }
@@ -1668,23 +1668,26 @@ struct PathIntegrator {
     return true;
   }
 
-  // path.hlsli:311-366 + sample_Le :141-164 + DirectLightSample :166-222
-  void connect_light(const DisneyMaterial& m) {
+  // one light candidate: DirectLightSample's two constructors (path.hlsli:179-201) in front of setup()
+  struct LightCandidate {
     v3 Le, ray_direction;
-    float pdfA, ray_distance, cG;
-    if (fr.flag(STHIP_ePresampleLights)) {
+    float pdfA, ray_distance, G;
+  };
+  // presampled = true: `ti` picks the tile's point; else four randoms are drawn (sample_Le, path.hlsli:141-164)
+  LightCandidate light_candidate(bool presampled, uint32_t ti) {
+    LightCandidate c;
+    if (presampled) {
       // path.hlsli:313-320: one of the tile's presampled points; DirectLightSample(_isect, PresampledLightPoint) :184-201
       const uint32_t tile_size = fr.pc.gLightPresampleTileSize;
       const uint32_t tile_offset = ((path_index() / tile_size) % fr.pc.gLightPresampleTileCount) * tile_size;
-      const uint32_t ti = rng.next_uint() % tile_size;
-      const PresampledLightPoint& lp = fr.presampled[seed - fr.seed_begin][tile_offset + ti];
-      Le = lp.Le;
-      pdfA = lp.pdfA;
-      ray_direction = lp.position - isect.sd.position;
-      const float dist2 = len_sqr(ray_direction);
-      ray_distance = sqrtf(dist2);
-      ray_direction = ray_direction / ray_distance;
-      cG = fabsf(dot(ray_direction, unpack_normal_octahedron(lp.packed_geometry_normal))) / dist2;
+      const PresampledLightPoint& lp = fr.presampled[seed - fr.seed_begin][tile_offset + ti % tile_size];
+      c.Le = lp.Le;
+      c.pdfA = lp.pdfA;
+      c.ray_direction = lp.position - isect.sd.position;
+      const float dist2 = len_sqr(c.ray_direction);
+      c.ray_distance = sqrtf(dist2);
+      c.ray_direction = c.ray_direction / c.ray_distance;
+      c.G = fabsf(dot(c.ray_direction, unpack_normal_octahedron(lp.packed_geometry_normal))) / dist2;
     } else {
       float rnd[4];
       rnd[0] = rng.next_float();
@@ -1693,17 +1696,30 @@ struct PathIntegrator {
       rnd[3] = rng.next_float();
       LightSampleRecord ls;
       sample_point_on_light(fr, ls, rnd, isect.sd.position);
-      Le = ls.radiance;
-      pdfA = ls.pdf;
-      ray_direction = ls.to_light;
-      ray_distance = ls.dist;
+      c.Le = ls.radiance;
+      c.pdfA = ls.pdf;
+      c.ray_direction = ls.to_light;
+      c.ray_distance = ls.dist;
       if (ls.is_environment) {  // sample_Le, path.hlsli:156-162
-        cG = 1;
+        c.G = 1;
       } else {
-        cG = fabsf(dot(ls.to_light, ls.normal)) / pow2(ls.dist);
-        if (!ls.pdf_area_measure) pdfA = pdfA * cG;
+        c.G = fabsf(dot(ls.to_light, ls.normal)) / pow2(ls.dist);
+        if (!ls.pdf_area_measure) c.pdfA = c.pdfA * c.G;
       }
     }
+    return c;
+  }
+
+  // path.hlsli:311-366 + sample_Le :141-164 + DirectLightSample :166-222
+  void connect_light(const DisneyMaterial& m) {
+    if (fr.flag(STHIP_eNEEReservoirs)) {
+      connect_light_reservoir(m);
+      return;
+    }
+    const bool presampled = fr.flag(STHIP_ePresampleLights);
+    const LightCandidate cand = light_candidate(presampled, presampled ? rng.next_uint() : 0u);
+    v3 Le = cand.Le, ray_direction = cand.ray_direction;
+    float pdfA = cand.pdfA, ray_distance = cand.ray_distance, cG = cand.G;
     // setup()
     v3 ray_origin = isect.sd.position;
     const v3 local_to_light = normalize(isect.sd.to_local(ray_direction));
@@ -1745,6 +1761,68 @@ struct PathIntegrator {
         rd.ray_distance = ray_distance;
       }
     } else {
+      radiance = radiance + beta * contrib * weight;
+    }
+  }
+
+  // connect_light_reservoir, path.hlsli:368-486, without spatial reuse (eNEEReservoirReuse is not restated):
+  // resampled importance sampling over gReservoirM candidates, target = luminance(Le) G |cos|
+  void connect_light_reservoir(const DisneyMaterial& m) {
+    const bool presampled = fr.flag(STHIP_ePresampleLights);
+    const v3 geometry_normal = isect.sd.geometry_normal();
+    LightCandidate c;
+    memset(&c, 0, sizeof(c));
+    v3 c_local_to_light = V3(0.0f);
+    float total_weight = 0, r_target_pdf = 0;
+    uint32_t M = 0;
+    uint32_t ti = rng.next_uint();  // :378 (drawn in either mode)
+    for (uint32_t i = 0; i < fr.pc.gReservoirM; i++) {
+      if (presampled) ti = rng.next_uint();
+      const LightCandidate c_i = light_candidate(presampled, ti);
+      if (c_i.pdfA <= 0 || all_le0(c_i.Le)) continue;
+      const v3 local_to_light = normalize(isect.sd.to_local(c_i.ray_direction));  // setup(), :209
+      const float target_pdf_i = luminance(c_i.Le) * c_i.G * fabsf(local_to_light.z);
+      const float w = target_pdf_i / c_i.pdfA;
+      M++;  // Reservoir::update, reservoir.h:22-26
+      total_weight += w;
+      if (rng.next_float() * total_weight <= w) {
+        r_target_pdf = target_pdf_i;
+        c = c_i;
+        c_local_to_light = local_to_light;
+      }
+    }
+    const float W = (r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0;  // reservoir.h:8-13
+    if (W <= 1e-6f || W != W) return;
+    // setup() of the chosen candidate
+    const float ngdotout = dot(geometry_normal, c.ray_direction);
+    const v3 ray_origin = ray_offset(isect.sd.position, ngdotout > 0 ? geometry_normal : -geometry_normal);
+    const float ray_distance = c.ray_distance * 0.999f;
+    MaterialEvalRecord ev;
+    m.eval(ev, local_dir_in, c_local_to_light, false);
+    float cG = c.G * shading_normal_correction(local_dir_in.z, c_local_to_light.z, ngdotin, ngdotout);
+    v3 contrib = c.Le * ev.f * cG * W;
+    if (all_le0(contrib) || c.pdfA < 1e-6f) return;
+    float weight = 1;
+    if (fr.flag(STHIP_eSampleBSDFs)) weight = 1 - 0.5f;  // DirectLightSample::reservoir_bsdf_mis, path.hlsli:175-177
+    if (fr.flag(STHIP_eDeferShadowRays)) {
+      const v3 cc = beta * contrib * weight;
+      if (diffuse_vertices >= 1 && diffuse_vertices <= max_shadow) {
+        sthip_ShadowRayData& rd = shadow_rays[diffuse_vertices - 1];
+        rd.contribution[0] = cc.x;
+        rd.contribution[1] = cc.y;
+        rd.contribution[2] = cc.z;
+        rd.rng_offset = rng.v[3];
+        rd.ray_origin[0] = ray_origin.x;
+        rd.ray_origin[1] = ray_origin.y;
+        rd.ray_origin[2] = ray_origin.z;
+        rd.medium = STHIP_INVALID_INSTANCE;
+        rd.ray_direction[0] = c.ray_direction.x;
+        rd.ray_direction[1] = c.ray_direction.y;
+        rd.ray_direction[2] = c.ray_direction.z;
+        rd.ray_distance = ray_distance;
+      }
+    } else {
+      if (occluded(ray_origin, c.ray_direction, ray_distance)) return;
       radiance = radiance + beta * contrib * weight;
     }
   }
@@ -2138,7 +2216,7 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
   if (!sc || !pc || !frame || !out || !out->gRadiance || !frame->gViews || !frame->gViewTransforms) return STHIP_ERR_INVALID_ARGUMENT;
   if (scene_flags & (STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT)) return STHIP_ERR_UNSUPPORTED;
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
-  const uint32_t unsupported = (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_eConnectToViews) |
+  const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_eConnectToViews) |
                                (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
                                (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eCoherentSampling) | (1u << STHIP_eSampleEnvironmentMapDirectly);
   if (sampling_flags & unsupported) return STHIP_ERR_UNSUPPORTED;
@@ -2155,7 +2233,7 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
   if (!has_emissives(fr) && !has_environment(fr)) fr.sampling_flags &= ~(1u << STHIP_eNEE);
   if (!(fr.sampling_flags & (1u << STHIP_eNEE))) fr.sampling_flags &= ~(1u << STHIP_eDeferShadowRays);                // BDPT.cpp:522-523
   if (fr.pc.gLightCount > sc->lights.size()) return STHIP_ERR_INVALID_ARGUMENT;
-  if (!fr.flag(STHIP_eNEE)) fr.sampling_flags &= ~(1u << STHIP_ePresampleLights);  // BDPT.cpp:511-515
+  if (!fr.flag(STHIP_eNEE)) fr.sampling_flags &= ~((1u << STHIP_ePresampleLights) | (1u << STHIP_eNEEReservoirs));  // BDPT.cpp:511-515
   // presample_lights, bdpt.hlsl:84-99, once per seed (BDPT.cpp:644-651): rng_init(-1, index), reference point 0.
   // An environment sample leaves `position` unset upstream, so that combination is not restated.
   std::vector<std::vector<PresampledLightPoint>> presampled;

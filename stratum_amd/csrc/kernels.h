@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
             float light_pdf = env.eval_pdf(p.scene, direction);
             if (has_emissives) light_pdf *= p.pc.gEnvironmentSampleProbability;
             float weight = 1;
-            if (path_length > 2 && use_nee) weight = mis2(use_mis, bsdf_pdf, light_pdf);
+            if (path_length > 2 && use_nee) weight = flag(p, STHIP_eNEEReservoirs) ? 0.5f : mis2(use_mis, bsdf_pdf, light_pdf);
             radiance = radiance + (beta * eLe) * weight;
           }
         }
@@ -611,7 +611,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
         }
         float weight = 1;
         if (path_length > 2) {
-          if (use_nee) weight = mis2(use_mis, bsdf_pdf * G, light_pdfA);
+          if (use_nee) weight = (EXT && flag(p, STHIP_eNEEReservoirs)) ? 0.5f : mis2(use_mis, bsdf_pdf * G, light_pdfA);  // path.hlsli:881-886
         }
         radiance = radiance + contrib * weight;
       };
@@ -677,41 +677,79 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
         }
         if (use_nee) {
           // connect_light, path.hlsli:311-366; sample_Le :141-164; sample_point_on_light, light.hlsli:37-152
+          // one light candidate: DirectLightSample's two constructors (path.hlsli:179-201) in front of setup()
+          const bool presampled = flag(p, STHIP_ePresampleLights);
+          auto light_candidate = [&](uint32_t ti, f3& cLe, float& c_pdfA, f3& c_dir, float& c_dist, float& c_G) {
+            if (presampled) {
+              // path.hlsli:313-320: one of the tile's presampled points; DirectLightSample(_isect, PresampledLightPoint) :184-201
+              uint32_t path_index;  // map_pixel_coord, bdpt_util.hlsli:76-83, with the 8x4 groups of bdpt.hlsl:11-12
+              if (flag(p, STHIP_eRemapThreads))
+                path_index = ((py >> 2) * ((p.pc.gOutputExtent[0] + 7u) >> 3) + (px >> 3)) * 32u + (py & 3u) * 8u + (px & 7u);
+              else
+                path_index = py * p.pc.gOutputExtent[0] + px;
+              const uint32_t tile_size = p.pc.gLightPresampleTileSize;
+              const uint32_t tile_offset = ((path_index / tile_size) % p.pc.gLightPresampleTileCount) * tile_size;
+              const float4* lp = p.presampled + 2 * ((size_t)seed_index * tile_size * p.pc.gLightPresampleTileCount + tile_offset + ti % tile_size);
+              const float4 l0 = lp[0], l1 = lp[1];
+              cLe = xyz(l1);
+              c_pdfA = l1.w;
+              c_dir = xyz(l0) - sd.position;
+              const float dist2 = len_sqr(c_dir);
+              c_dist = sqrtf(dist2);
+              c_dir = c_dir / c_dist;
+              c_G = fabsf(dot3(c_dir, unpack_normal_octahedron(__float_as_uint(l0.w)))) / dist2;
+            } else {
+              const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float(), r3 = rng.next_float();
+              LightSample ls;
+              sample_point_on_light<TEXTURED, EXT>(p, has_env, has_emissives, r0, r1, r2, r3, sd.position, ls);
+              cLe = ls.Le;
+              c_dir = ls.to_light;
+              c_dist = ls.dist;
+              c_pdfA = ls.pdf;
+              if (ls.is_env) {  // sample_Le, path.hlsli:156-162
+                c_G = 1;
+              } else {
+                c_G = fabsf(dot3(c_dir, ls.normal)) / pow2f(c_dist);
+                if (!ls.area_measure) c_pdfA = c_pdfA * c_G;
+              }
+            }
+          };
           f3 lLe, to_light;
           float pdfA, cG, ls_dist;
-          if (flag(p, STHIP_ePresampleLights)) {
-            // path.hlsli:313-320: one of the tile's presampled points; DirectLightSample(_isect, PresampledLightPoint) :184-201
-            uint32_t path_index;  // map_pixel_coord, bdpt_util.hlsli:76-83, with the 8x4 groups of bdpt.hlsl:11-12
-            if (flag(p, STHIP_eRemapThreads))
-              path_index = ((py >> 2) * ((p.pc.gOutputExtent[0] + 7u) >> 3) + (px >> 3)) * 32u + (py & 3u) * 8u + (px & 7u);
-            else
-              path_index = py * p.pc.gOutputExtent[0] + px;
-            const uint32_t tile_size = p.pc.gLightPresampleTileSize;
-            const uint32_t tile_offset = ((path_index / tile_size) % p.pc.gLightPresampleTileCount) * tile_size;
-            const uint32_t ti = rng.next_uint() % tile_size;
-            const float4* lp = p.presampled + 2 * ((size_t)seed_index * tile_size * p.pc.gLightPresampleTileCount + tile_offset + ti);
-            const float4 l0 = lp[0], l1 = lp[1];
-            lLe = xyz(l1);
-            pdfA = l1.w;
-            to_light = xyz(l0) - sd.position;
-            const float dist2 = len_sqr(to_light);
-            ls_dist = sqrtf(dist2);
-            to_light = to_light / ls_dist;
-            cG = fabsf(dot3(to_light, unpack_normal_octahedron(__float_as_uint(l0.w)))) / dist2;
-          } else {
-            const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float(), r3 = rng.next_float();
-            LightSample ls;
-            sample_point_on_light<TEXTURED, EXT>(p, has_env, has_emissives, r0, r1, r2, r3, sd.position, ls);
-            lLe = ls.Le;
-            to_light = ls.to_light;
-            ls_dist = ls.dist;
-            pdfA = ls.pdf;
-            if (ls.is_env) {  // sample_Le, path.hlsli:156-162
-              cG = 1;
-            } else {
-              cG = fabsf(dot3(to_light, ls.normal)) / pow2f(ls_dist);
-              if (!ls.area_measure) pdfA = pdfA * cG;
+          float ris_W = 0;  // eNEEReservoirs: the reservoir's weight replaces 1 / pdfA
+          const bool reservoirs = EXT && flag(p, STHIP_eNEEReservoirs);
+          if (reservoirs) {
+            // connect_light_reservoir, path.hlsli:368-486, without spatial reuse: resampled importance sampling over
+            // gReservoirM candidates with target = luminance(Le) G |cos| (Reservoir, reservoir.h)
+            float total_weight = 0, r_target_pdf = 0;
+            uint32_t M = 0;
+            lLe = to_light = F3s(0.0f);
+            pdfA = cG = ls_dist = 0;
+            uint32_t ti = rng.next_uint();
+            for (uint32_t k = 0; k < p.pc.gReservoirM; k++) {
+              if (presampled) ti = rng.next_uint();
+              f3 cLe, c_dir;
+              float c_pdfA, c_dist, c_G;
+              light_candidate(ti, cLe, c_pdfA, c_dir, c_dist, c_G);
+              if (c_pdfA <= 0 || all_le0(cLe)) continue;
+              const f3 c_local = normalize3(frame.to_local(c_dir));
+              const float target_pdf = luminance3(cLe) * c_G * fabsf(c_local.z);
+              const float w = target_pdf / c_pdfA;
+              M++;
+              total_weight += w;
+              if (rng.next_float() * total_weight <= w) {
+                r_target_pdf = target_pdf;
+                lLe = cLe;
+                to_light = c_dir;
+                pdfA = c_pdfA;
+                cG = c_G;
+                ls_dist = c_dist;
+              }
             }
+            ris_W = (r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0;
+            if (ris_W <= 1e-6f || ris_W != ris_W) lLe = F3s(0.0f), pdfA = 0;  // :440: nothing to connect
+          } else {
+            light_candidate(presampled ? rng.next_uint() : 0u, lLe, pdfA, to_light, ls_dist, cG);
           }
           // DirectLightSample::setup, path.hlsli:204-221
           const f3 local_to_light = normalize3(frame.to_local(to_light));
@@ -723,12 +761,13 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
             MaterialEvalRecord ev;
             m.eval(ev, local_dir_in, local_to_light, false);
             const float pdfA_fwd = ev.pdf_fwd * cG;
-            if (pdfA_fwd < 1e-6f) break;
+            if (!reservoirs && pdfA_fwd < 1e-6f) break;
             cG *= shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout);
-            const f3 contrib = lLe * ev.f * cG / pdfA;
+            const f3 contrib = reservoirs ? lLe * ev.f * cG * ris_W : lLe * ev.f * cG / pdfA;
             if (all_le0(contrib)) break;
+            if (reservoirs && pdfA < 1e-6f) break;  // path.hlsli:456
             float weight = 1;
-            if (sample_bsdfs) weight = mis2(use_mis, pdfA, pdfA_fwd);
+            if (sample_bsdfs) weight = reservoirs ? 1 - 0.5f : mis2(use_mis, pdfA, pdfA_fwd);  // reservoir_bsdf_mis, :175-177
             const f3 c = beta * contrib * weight;
             // a zero/negative contribution never adds light (bdpt.hlsl:313) and needs no ray
             if (all_le0(c)) break;

@@ -556,3 +556,16 @@ def test_presampled_lights_with_an_environment_are_rejected(renderer):
             renderer.render(camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"]))
     finally:
         renderer.set_flag("~presamplelights")
+
+
+@pytest.mark.parametrize("flags", [["neereservoirs"], ["neereservoirs", "presamplelights"], ["neereservoirs", "~defershadowrays"], ["neereservoirs", "~samplebsdfs"]])
+def test_nee_reservoirs(flags):
+    """eNEEReservoirs without reuse (connect_light_reservoir, path.hlsli:368-486): resampled importance sampling over
+    gReservoirM light candidates, fresh or presampled."""
+    sc, cam = scenes.cornell_box()
+    _compare_frame(sc, cam, flags, seeds=2)
+    sc, cam = scenes.spheres_room()
+    _compare_frame(sc, cam, flags, seeds=1, args={"maxDiffuseVertices": 3})
+    if "presamplelights" not in flags:
+        sc, cam = scenes.environment_scene(image=True, emitter=True)
+        _compare_frame(sc, cam, flags, seeds=1)

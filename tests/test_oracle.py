@@ -317,7 +317,7 @@ def form_factor_point_to_coaxial_square(a, h):
     return 4 * corner(A, A)
 
 
-@pytest.mark.parametrize("flags", ["default", "~nee", "~samplebsdfs", "~mis", "~defershadowrays", "presamplelights"])
+@pytest.mark.parametrize("flags", ["default", "~nee", "~samplebsdfs", "~mis", "~defershadowrays", "presamplelights", "neereservoirs", "neereservoirs ~samplebsdfs"])
 def test_direct_light_matches_form_factor(flags):
     """L = rho * Le * F at the floor point under the light, for every estimator combination
     (NEE + BSDF sampling with MIS, either alone, MIS off = 0.5/0.5, shadow rays not deferred)."""
@@ -331,6 +331,10 @@ def test_direct_light_matches_form_factor(flags):
     if flags == "presamplelights":  # NEE from a small presampled tile per seed (bdpt.hlsl:84-99): unbiased over the seeds
         f |= wire.flag_mask("ePresampleLights")
         pc.gLightPresampleTileSize, pc.gLightPresampleTileCount = 64, 4
+    elif flags.startswith("neereservoirs"):  # RIS over gReservoirM candidates (path.hlsli:368-486); 0.5 / 0.5 with BSDF sampling
+        f |= wire.flag_mask("eNEEReservoirs")
+        if flags.endswith("~samplebsdfs"):
+            f &= ~wire.flag_mask("eSampleBSDFs")
     elif flags != "default":
         f &= ~wire.flag_mask({"~nee": "eNEE", "~samplebsdfs": "eSampleBSDFs", "~mis": "eMIS", "~defershadowrays": "eDeferShadowRays"}[flags])
     out = o.render(fr, pc, f, 0, 2048, aovs=False)
