@@ -96,6 +96,7 @@ struct sthip_ctx {
   bool count_traversal = false, time_kernels = false;
   uint32_t refill_idle = 16, inner_min_lanes = 24, trace_blocks_per_cu = 0;
   uint64_t max_paths_in_flight = 1ull << 22;
+  bool packet_primary = true;  // the first bounce is traced as wave packets (k_trace_primary)
   bool fuse_trace = true;  // closest-hit rays of a bounce and the shadow rays of the previous one in one launch
   int bvh_builder = 0;  // sthip::BvhBuilderKind
   sthip_stats stats{};
@@ -247,6 +248,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->time_kernels = value != 0;
   else if (!strcmp(name, "fuse_trace"))
     ctx->fuse_trace = value != 0;
+  else if (!strcmp(name, "packet_primary"))
+    ctx->packet_primary = value != 0;
   else if (!strcmp(name, "refill_idle"))
     ctx->refill_idle = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
   else if (!strcmp(name, "bvh_builder"))
@@ -829,10 +832,31 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
           hipLaunchKernelGGL((k_trace<false, false>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
       });
     };
+    // the first bounce as wave packets (k_trace_primary): one 8x8 pixel block per wave
+    auto trace_primary = [&]() -> int {
+      launches_trace++;
+      const uint32_t packets = (p.path_count + 63) / 64;
+      const unsigned pgrid = std::max(1u, std::min((packets + 3) / 4, (uint32_t)ctx->cu_count * 64u));
+      const size_t plds = (size_t)ctx->bvh.stack_depth * (STHIP_BLOCK / 64) * sizeof(uint32_t);
+      return timed(ms_trace, [&]() {
+        if (p.bvh.alpha_test) {
+          if (ctx->count_traversal)
+            hipLaunchKernelGGL((k_trace_primary<true, true>), dim3(pgrid), dim3(STHIP_BLOCK), plds, st, p);
+          else
+            hipLaunchKernelGGL((k_trace_primary<false, true>), dim3(pgrid), dim3(STHIP_BLOCK), plds, st, p);
+        } else if (ctx->count_traversal)
+          hipLaunchKernelGGL((k_trace_primary<true, false>), dim3(pgrid), dim3(STHIP_BLOCK), plds, st, p);
+        else
+          hipLaunchKernelGGL((k_trace_primary<false, false>), dim3(pgrid), dim3(STHIP_BLOCK), plds, st, p);
+      });
+    };
     for (uint32_t depth = 0; depth <= max_bounce_rounds; depth++) {
       const uint32_t dc = depth < max_bounce_rounds ? depth : TRACE_NONE;
       const uint32_t ds = depth >= 1 && nee ? depth - 1 : TRACE_NONE;
-      if (ctx->fuse_trace) {
+      if (depth == 0 && dc == 0 && ctx->packet_primary) {
+        rc = trace_primary();
+        if (rc) return rc;
+      } else if (ctx->fuse_trace) {
         rc = trace(dc, ds);
         if (rc) return rc;
       } else {  // analysis: the two ray kinds in launches of their own

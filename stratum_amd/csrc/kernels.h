@@ -308,6 +308,165 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// trace_primary: the first bounce as wave packets. The 64 slots of a wave are one 8x8 pixel block (slot_to_pixel),
+// i.e. 64 rays from one origin through neighbouring pixels, so the wave walks the tree ONCE for all of them: one
+// shared stack, every node and triangle fetched at a wave-uniform address (one cache line for the wave instead of 64),
+// no lane divergence; a subtree is entered when any lane's ray hits its box. Each lane still tests its own ray with
+// the contract's arithmetic against every triangle the packet reaches, and the closest hit is a minimum over all
+// triangles (ties by id), so visiting more leaves than a single ray would cannot change the answer: results are
+// bit-identical to k_trace's.
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT, bool ALPHA>
+__global__ void __launch_bounds__(STHIP_BLOCK) k_trace_primary(FrameParams p) {
+  extern __shared__ uint32_t lds_stack[];
+  const uint32_t wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  uint32_t* stack = lds_stack + wave_in_block * p.bvh.stack_depth;  // one stack per wave
+  const uint32_t packets = (p.path_count + 63u) >> 6;
+  TraverseCounters cnt;
+  cnt.clear();
+  for (uint32_t packet = blockIdx.x * (blockDim.x >> 6) + wave_in_block; packet < packets; packet += gridDim.x * (blockDim.x >> 6)) {
+    const uint32_t slot = packet * 64u + lane;
+    bool live = slot < p.path_count && p.meta[slot] < 0xFFFFFFFEu;
+    f3 o = F3s(0.0f), d = F3(0.0f, 0.0f, 1.0f);
+    if (live) {
+      o = xyz(p.ray_o[slot]);
+      d = xyz(p.ray_d[slot]);
+    }
+    RayHit hit;
+    hit.t = __builtin_inff();
+    hit.b1 = hit.b2 = 0.0f;
+    hit.ip = 0xFFFFFFFFu;
+    if (!__any(live)) {
+      if (slot < p.path_count) p.hit[slot] = make_float4(hit.t, 0, 0, __uint_as_float(hit.ip));
+      continue;
+    }
+    RaySpace sp;
+    setup_space(sp, o, d, p.bvh.scene_cx, p.bvh.scene_cy, p.bvh.scene_cz, p.bvh.scene_radius);
+    uint32_t id_bits = 0;
+    uint32_t top = 0;
+    uint32_t ref = p.bvh.root_ref;  // wave-uniform throughout
+    const char* nbase = reinterpret_cast<const char*>(p.bvh.nodes);
+    const char* tbase = reinterpret_cast<const char*>(p.bvh.tris);
+    while (ref != TRAV_DONE) {
+      ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
+      if (!(ref & BVH_LEAF_BIT)) {
+        const float4* n = reinterpret_cast<const float4*>(nbase + ((size_t)ref << 6));
+        const float4 n0 = n[0], n1 = n[1], nz = n[2];
+        const uint2 cr = *reinterpret_cast<const uint2*>(n + 3);
+        if (COUNT && lane == 0) {
+          cnt.nodes++;
+          cnt.inner_slots += 64;
+        }
+        const float tbest = hit.t;
+        const float a0x = fmaf(n0.x, sp.idir.x, sp.noodL.x), b0x = fmaf(n0.y, sp.idir.x, sp.noodH.x);
+        const float a0y = fmaf(n0.z, sp.idir.y, sp.noodL.y), b0y = fmaf(n0.w, sp.idir.y, sp.noodH.y);
+        const float a0z = fmaf(nz.x, sp.idir.z, sp.noodL.z), b0z = fmaf(nz.y, sp.idir.z, sp.noodH.z);
+        const float a1x = fmaf(n1.x, sp.idir.x, sp.noodL.x), b1x = fmaf(n1.y, sp.idir.x, sp.noodH.x);
+        const float a1y = fmaf(n1.z, sp.idir.y, sp.noodL.y), b1y = fmaf(n1.w, sp.idir.y, sp.noodH.y);
+        const float a1z = fmaf(nz.z, sp.idir.z, sp.noodL.z), b1z = fmaf(nz.w, sp.idir.z, sp.noodH.z);
+        const float tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), 0.0f));
+        const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), tbest));
+        const float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), 0.0f));
+        const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), tbest));
+        const bool h0 = live && (tn0 <= tf0) && (cr.x != BVH_INVALID_REF);
+        const bool h1 = live && (tn1 <= tf1) && (cr.y != BVH_INVALID_REF);
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+        if (m0 | m1) {
+          // nearer child first by vote: lanes that hit child 1 and see it nearer (or do not hit child 0 at all)
+          const unsigned long long prefer1 = __ballot(h1 && (!h0 || tn1 < tn0));
+          const bool first1 = m1 && (!m0 || __popcll(prefer1) * 2 > __popcll(m0 | m1));
+          ref = first1 ? cr.y : cr.x;
+          if (m0 && m1) {
+            stack[top] = first1 ? cr.x : cr.y;
+            top++;
+          }
+        } else {
+          ref = top ? stack[--top] : TRAV_DONE;
+        }
+        continue;
+      }
+      // leaf bit: exit sentinel, instance entry, or triangles
+      if (ref == TRAV_EXIT_INSTANCE) {
+        setup_space(sp, o, d, p.bvh.scene_cx, p.bvh.scene_cy, p.bvh.scene_cz, p.bvh.scene_radius);
+        id_bits = 0;
+        ref = top ? stack[--top] : TRAV_DONE;
+        continue;
+      }
+      if (ref & BVH_INST_BIT) {
+        const TlasEntry* e = p.bvh.entries + (ref & 0xFFFFu);
+        const float4* ev = reinterpret_cast<const float4*>(e);
+        const uint4 info = *reinterpret_cast<const uint4*>(ev + 3);
+        if (info.z != TLAS_ENTRY_IDENTITY) {
+          const float4 r0 = ev[0], r1 = ev[1], r2 = ev[2];
+          const float4 sph = ev[4];
+          const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+          if (info.z == TLAS_ENTRY_SPHERE) {
+            if (COUNT && lane == 0) {
+              cnt.tris++;
+              cnt.tri_slots += 64;
+            }
+            float t;
+            if (live && sphere_test(obj_point(m, o), obj_vector(m, d), sph.w, 0.0f, __builtin_inff(), t)) {
+              const uint32_t ip = info.y | 0xFFFF0000u;
+              if (t < hit.t || (t == hit.t && hit.ip != 0xFFFFFFFFu && hit_key(ip) < hit_key(hit.ip))) {
+                hit.t = t;
+                hit.b1 = hit.b2 = 0.0f;
+                hit.ip = ip;
+              }
+            }
+            ref = top ? stack[--top] : TRAV_DONE;
+            continue;
+          }
+          setup_space(sp, obj_point(m, o), obj_vector(m, d), sph.x, sph.y, sph.z, sph.w);
+          id_bits = info.y;
+          stack[top] = TRAV_EXIT_INSTANCE;
+          top++;
+        }
+        ref = info.x;
+        continue;
+      }
+      const uint32_t first = (ref & 0x3FFFFFFFu) >> 2;
+      const uint32_t count = (ref & 3u) + 1u;
+      for (uint32_t i = 0; i < count; i++) {
+        const float4* tv = reinterpret_cast<const float4*>(tbase + (size_t)((first + i) * 48u));
+        const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+        if (COUNT && lane == 0) {
+          cnt.tris++;
+          cnt.tri_slots += 64;
+        }
+        float t, b1, b2;
+        if (live && tri_test(sp, xyz(v0), xyz(v1), xyz(v2), 0.0f, __builtin_inff(), t, b1, b2)) {
+          const uint32_t mask = (ALPHA && p.bvh.alpha_test) ? p.bvh.inst_alpha[(__float_as_uint(v0.w) | id_bits) & 0xFFFFu] : BVH_NO_ALPHA;
+          if (mask != BVH_NO_ALPHA) {
+            const float2* q = p.bvh.tri_uv + (size_t)(first + i) * 3u;
+            const float2 u0 = q[0], u1 = q[1], u2 = q[2];
+            const float u = u0.x + (u1.x - u0.x) * b1 + (u2.x - u0.x) * b2;
+            float v = u0.y + (u1.y - u0.y) * b1 + (u2.y - u0.y) * b2;
+            if (p.bvh.flip_uvs) v = 1 - v;
+            if (!(sample_image1(p.bvh, mask, u, v) >= 0.75f)) continue;
+          }
+          const uint32_t ip = __float_as_uint(v0.w) | id_bits;
+          if (t < hit.t || (t == hit.t && hit.ip != 0xFFFFFFFFu && hit_key(ip) < hit_key(hit.ip))) {
+            hit.t = t;
+            hit.b1 = b1;
+            hit.b2 = b2;
+            hit.ip = ip;
+          }
+        }
+      }
+      ref = top ? stack[--top] : TRAV_DONE;
+    }
+    if (slot < p.path_count) p.hit[slot] = make_float4(hit.t, hit.b1, hit.b2, __uint_as_float(hit.ip));
+  }
+  if (COUNT) {
+    wave_add(&p.counters[CNT_NODES], cnt.nodes);
+    wave_add(&p.counters[CNT_TRIS], cnt.tris);
+    wave_add(&p.counters[CNT_INNER_SLOTS], cnt.inner_slots);
+    wave_add(&p.counters[CNT_TRI_SLOTS], cnt.tri_slots);
+  }
+}
+
 // sample_point_on_light, light.hlsli:37-152 (uniform light choice), as one function for connect_light and presample_lights
 struct LightSample {
   f3 Le, to_light, normal, position;
