@@ -212,8 +212,10 @@ uint32_t flatten(const Builder& b, int32_t t, std::vector<BvhNode>& out, LeafRef
 inline uint32_t wrap_leaf(std::vector<BvhNode>& nodes, const Box& box, uint32_t leaf) {
   BvhNode n;
   memset(&n, 0, sizeof(n));
+  // both slots hold the leaf: the traversal then needs no "is this child there" test in its inner loop; testing the
+  // leaf's triangles twice changes neither the closest hit nor an occlusion answer
   set_child(n, 0, &box, leaf);
-  set_child(n, 1, nullptr, BVH_INVALID_REF);
+  set_child(n, 1, &box, leaf);
   nodes.push_back(n);
   return (uint32_t)nodes.size() - 1;
 }
@@ -539,7 +541,7 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
     }
     out.top_is_world_blas = 0;
   }
-  out.stack_depth = tlas_depth + blas_depth + 2;
+  out.stack_depth = tlas_depth + blas_depth + 3;  // + the sentinels, + one spare level for the traversal's speculative push
   if (scene_box.lo[0] <= scene_box.hi[0]) {
     for (int a = 0; a < 3; a++) out.scene_center[a] = 0.5f * (scene_box.lo[a] + scene_box.hi[a]);
     out.scene_radius = 0.5f * sqrtf((scene_box.hi[0] - scene_box.lo[0]) * (scene_box.hi[0] - scene_box.lo[0]) + (scene_box.hi[1] - scene_box.lo[1]) * (scene_box.hi[1] - scene_box.lo[1]) +

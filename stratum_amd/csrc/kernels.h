@@ -369,8 +369,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_primary(FrameParams p) {
         const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), tbest));
         const float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), 0.0f));
         const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), tbest));
-        const bool h0 = live && (tn0 <= tf0) && (cr.x != BVH_INVALID_REF);
-        const bool h1 = live && (tn1 <= tf1) && (cr.y != BVH_INVALID_REF);
+        const bool h0 = live && (tn0 <= tf0);
+        const bool h1 = live && (tn1 <= tf1);
         const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
         if (m0 | m1) {
           // nearer child first by vote: lanes that hit child 1 and see it nearer (or do not hit child 0 at all)

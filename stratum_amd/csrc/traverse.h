@@ -226,6 +226,7 @@ struct Traversal {
       const float4* n = reinterpret_cast<const float4*>(base + ((size_t)ref << 6));
       const float4 n0 = n[0], n1 = n[1], nz = n[2];
       const uint2 cr = *reinterpret_cast<const uint2*>(n + 3);
+      const uint32_t popped = stack[top - STRIDE];
       if (COUNT) {
         cnt.nodes++;
         if (first_active_lane()) cnt.inner_slots += 64;
@@ -241,18 +242,16 @@ struct Traversal {
       const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), tbest));
       const float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), tmin));
       const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), tbest));
-      const bool h0 = (tn0 <= tf0) && (cr.x != BVH_INVALID_REF);
-      const bool h1 = (tn1 <= tf1) && (cr.y != BVH_INVALID_REF);
-      if (h0 | h1) {
-        const bool first1 = h1 && (!h0 || tn1 < tn0);  // descend into child 1 first
-        ref = first1 ? cr.y : cr.x;
-        if (h0 & h1) {  // the builder's exact stack bound makes the push safe
-          stack[top] = first1 ? cr.x : cr.y;
-          top += STRIDE;
-        }
-      } else {
-        pop(stack);
-      }
+      // (every node has two valid children: a single-leaf tree is wrapped with the leaf in both slots, bvh_build.cpp)
+      // Branch-free step: the pop is read speculatively (the slot below `top` always exists: the DONE sentinel sits
+      // at the bottom) next to the node loads, the push is written speculatively (the slot at `top` is free; the LDS
+      // stack has one spare level for it), and selects pick what applies — no exec-mask regions in the loop.
+      const bool h0 = tn0 <= tf0;
+      const bool h1 = tn1 <= tf1;
+      const bool first1 = h1 && (!h0 || tn1 < tn0);  // descend into child 1 first
+      stack[top] = first1 ? cr.x : cr.y;
+      ref = (h0 || h1) ? (first1 ? cr.y : cr.x) : popped;
+      top = (h0 && h1) ? top + STRIDE : ((h0 || h1) ? top : top - STRIDE);
       if (min_lanes > 1 && (uint32_t)__popcll(__ballot(!(ref & BVH_LEAF_BIT))) < min_lanes) break;
     }
   }
