@@ -222,7 +222,10 @@ struct Traversal {
   // wave are still walking (the others would only wait for them).
   DEV void inner_loop(const DeviceBvh& bvh, uint32_t* stack, uint32_t min_lanes, TraverseCounters& cnt) {
     const char* base = reinterpret_cast<const char*>(bvh.nodes);
-    while (!(ref & BVH_LEAF_BIT)) {
+    // Every lane that holds an inner node takes at least one step per call (progress), then the wave goes on while
+    // at least `min_lanes` lanes (>= 1) still hold an inner node: one wave-uniform test per step.
+    for (;;) {
+      if (!(ref & BVH_LEAF_BIT)) {
       const float4* n = reinterpret_cast<const float4*>(base + ((size_t)ref << 6));
       const float4 n0 = n[0], n1 = n[1], nz = n[2];
       const uint2 cr = *reinterpret_cast<const uint2*>(n + 3);
@@ -252,7 +255,8 @@ struct Traversal {
       stack[top] = first1 ? cr.x : cr.y;
       ref = (h0 || h1) ? (first1 ? cr.y : cr.x) : popped;
       top = (h0 && h1) ? top + STRIDE : ((h0 || h1) ? top : top - STRIDE);
-      if (min_lanes > 1 && (uint32_t)__popcll(__ballot(!(ref & BVH_LEAF_BIT))) < min_lanes) break;
+      }
+      if ((uint32_t)__popcll(__ballot(!(ref & BVH_LEAF_BIT))) < min_lanes) break;
     }
   }
 
