@@ -1550,9 +1550,16 @@ inline float mis2(const Frame& fr, float a, float b) {
   return a2 / (a2 + b * b);
 }
 // path.hlsli:67-98 (gShadingNormalFix off, adjoint=false on view paths)
-inline float shading_normal_correction(float ndotin, float ndotout, float ngdotin, float ngdotout) {
+// path.hlsli:67-98, view paths (adjoint = false): the light-leak test, and with eShadingNormalShadowFix the shadow
+// terminator term G = min(1, |ngdotout / (ndotout ngdotns)|), G <- -G^3 + G^2 + G
+inline float shading_normal_correction(float ndotin, float ndotout, float ngdotin, float ngdotout, float ngdotns = 1.0f, bool terminator_fix = false) {
   if (sgn(ngdotout * ngdotin) != sgn(ndotin * ndotout)) return 0;
-  return 1;
+  float G = 1;
+  if (terminator_fix) {
+    G = fminf(1.0f, fabsf(ngdotout / (ndotout * ngdotns)));
+    G = -(pow2(G) * G) + pow2(G) + G;
+  }
+  return G;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1738,7 +1745,7 @@ struct PathIntegrator {
       if (occluded(ray_origin, ray_direction, ray_distance)) Le = V3(0.0f);
       if (all_le0(Le)) return;
     }
-    cG *= shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout);
+    cG *= shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, dot(geometry_normal, isect.sd.shading_normal()), fr.flag(STHIP_eShadingNormalShadowFix));
     const v3 contrib = Le * ev.f * cG / pdfA;
     if (all_le0(contrib)) return;
     float weight = 1;
@@ -1799,7 +1806,7 @@ struct PathIntegrator {
     const float ray_distance = c.ray_distance * 0.999f;
     MaterialEvalRecord ev;
     m.eval(ev, local_dir_in, c_local_to_light, false);
-    float cG = c.G * shading_normal_correction(local_dir_in.z, c_local_to_light.z, ngdotin, ngdotout);
+    float cG = c.G * shading_normal_correction(local_dir_in.z, c_local_to_light.z, ngdotin, ngdotout, dot(geometry_normal, isect.sd.shading_normal()), fr.flag(STHIP_eShadingNormalShadowFix));
     v3 contrib = c.Le * ev.f * cG * W;
     if (all_le0(contrib) || c.pdfA < 1e-6f) return;
     float weight = 1;
@@ -1857,7 +1864,7 @@ struct PathIntegrator {
     const v3 geometry_normal = isect.sd.geometry_normal();
     const float ngdotout = dot(geometry_normal, ms.dir_out);
     origin = ray_offset(isect.sd.position, ngdotout > 0 ? geometry_normal : -geometry_normal);
-    beta = beta * shading_normal_correction(local_dir_in.z, ndotout, ngdotin, ngdotout);
+    beta = beta * shading_normal_correction(local_dir_in.z, ndotout, ngdotin, ngdotout, dot(geometry_normal, isect.sd.shading_normal()), fr.flag(STHIP_eShadingNormalShadowFix));
     prev_cos_out = ngdotout;
     if (all_le0(beta)) return false;
     direction = ms.dir_out;
@@ -2218,7 +2225,7 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
   const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_eConnectToViews) |
                                (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
-                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eShadingNormalShadowFix) | (1u << STHIP_eCoherentSampling) | (1u << STHIP_eSampleEnvironmentMapDirectly);
+                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling) | (1u << STHIP_eSampleEnvironmentMapDirectly);
   if (sampling_flags & unsupported) return STHIP_ERR_UNSUPPORTED;
   Frame fr;
   fr.sc = sc;

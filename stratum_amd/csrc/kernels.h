@@ -921,7 +921,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
             m.eval(ev, local_dir_in, local_to_light, false);
             const float pdfA_fwd = ev.pdf_fwd * cG;
             if (!reservoirs && pdfA_fwd < 1e-6f) break;
-            cG *= shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout);
+            cG *= shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, dot3(gn, sd.shading_normal()), EXT && flag(p, STHIP_eShadingNormalShadowFix));
             const f3 contrib = reservoirs ? lLe * ev.f * cG * ris_W : lLe * ev.f * cG / pdfA;
             if (all_le0(contrib)) break;
             if (reservoirs && pdfA < 1e-6f) break;  // path.hlsli:456
@@ -966,7 +966,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
       const f3 dir_out = normalize3(frame.to_world(ms.dir_out));
       const float ngdotout = dot3(gn, dir_out);
       new_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
-      beta = beta * shading_normal_correction(local_dir_in.z, ndotout, ngdotin, ngdotout);
+      beta = beta * shading_normal_correction(local_dir_in.z, ndotout, ngdotin, ngdotout, dot3(gn, sd.shading_normal()), EXT && flag(p, STHIP_eShadingNormalShadowFix));
       if (all_le0(beta)) break;
       new_direction = dir_out;
       alive = true;

@@ -753,7 +753,12 @@ DEV float mis2(bool use_mis, float a, float b) {
   return a2 / (a2 + b * b);
 }
 // path.hlsli:67-98 with gShadingNormalFix off, adjoint = false (view paths)
-DEV float shading_normal_correction(float ndotin, float ndotout, float ngdotin, float ngdotout) {
+DEV float shading_normal_correction(float ndotin, float ndotout, float ngdotin, float ngdotout, float ngdotns = 1.0f, bool terminator_fix = false) {
   if (sgnf(ngdotout * ngdotin) != sgnf(ndotin * ndotout)) return 0;
-  return 1;
+  float G = 1;
+  if (terminator_fix) {  // eShadingNormalShadowFix, path.hlsli:84-86 (view paths: adjoint = false)
+    G = fminf(1.0f, fabsf(ngdotout / (ndotout * ngdotns)));
+    G = -(pow2f(G) * G) + pow2f(G) + G;
+  }
+  return G;
 }

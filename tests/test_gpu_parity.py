@@ -331,7 +331,7 @@ def test_gpu_lbvh_builder_gives_the_same_image(atrium_scene):
     assert b[2]["bvh_build_gpu_ms"] > 0
 
 
-@pytest.mark.parametrize("flags", [[], ["~raycones"], ["flipnormalmaps", "fliptriangleuvs"], ["~normalmaps"]])
+@pytest.mark.parametrize("flags", [[], ["~raycones"], ["flipnormalmaps", "fliptriangleuvs"], ["~normalmaps"], ["shadingnormalshadowfix"]])
 def test_textured_scene(flags):
     """Image values (base colour, roughness/metallic maps, textured emitter), mip selection through ray cones,
     normal maps — software repeat/trilinear sampler on both sides."""
@@ -405,7 +405,7 @@ def test_trace_contract_with_spheres(renderer):
     assert np.array_equal(got["instance_primitive_index"], ref["instance_primitive_index"])
 
 
-@pytest.mark.parametrize("flags", [[], ["uniformspheresampling"], ["~defershadowrays"], ["~nee"], ["~samplebsdfs"]])
+@pytest.mark.parametrize("flags", [[], ["uniformspheresampling"], ["~defershadowrays"], ["~nee"], ["~samplebsdfs"], ["shadingnormalshadowfix", "neereservoirs"]])
 def test_sphere_instances_and_sphere_lights(flags):
     sc, cam = scenes.spheres_room()
     _compare_frame(sc, cam, flags, args={"maxDiffuseVertices": 3})

@@ -633,3 +633,25 @@ def test_alpha_masks_in_the_trace_contract():
     a, _ = o.trace(rays, any_hit=True, alpha_test=True)
     bb, _ = o.trace(rays, any_hit=True, brute=True, alpha_test=True)
     assert np.array_equal(a["instance_primitive_index"], bb["instance_primitive_index"])
+
+
+def test_shading_normal_shadow_fix_only_touches_bumped_shading():
+    """eShadingNormalShadowFix (path.hlsli:84-86): G = min(1, |ngdotout / (ndotout ngdotns)|) -> -G^3 + G^2 + G is 1 where the
+    shading normal equals the geometry normal (flat-shaded Cornell box), and darkens terminators where a normal map
+    bends it (textured box)."""
+    f_on = wire.DEFAULT_SAMPLING_FLAGS | wire.flag_mask("eShadingNormalShadowFix")
+    sc, cam = scenes.cornell_box()
+    fr = camera.Frame(48, 48, cam["fovy"], cam["eye"], cam["target"])
+    pc = wire.default_push_constants(48, 48, sc.light_count)
+    o = orc.OracleScene(sc)
+    a = o.render(fr, pc, wire.DEFAULT_SAMPLING_FLAGS, 0, 2)["radiance"]
+    b = o.render(fr, pc, f_on, 0, 2)["radiance"]
+    assert np.abs(a - b).max() < 2e-3 * a.max()  # fp16-packed normals make ngdotns differ from 1 by ~1e-3
+    sc, cam = scenes.textured_box()
+    fr = camera.Frame(64, 48, cam["fovy"], cam["eye"], cam["target"])
+    pc = wire.default_push_constants(64, 48, sc.light_count)
+    o = orc.OracleScene(sc)
+    a = o.render(fr, pc, wire.DEFAULT_SAMPLING_FLAGS, 0, 4)["radiance"][..., :3]
+    b = o.render(fr, pc, f_on, 0, 4)["radiance"][..., :3]
+    assert np.isfinite(b).all() and np.abs(a - b).mean() > 1e-3 * a.mean()
+
