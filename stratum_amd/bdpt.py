@@ -131,7 +131,7 @@ class BDPT:
     def push_constants(self, frame):
         pc = wire.BDPTPushConstants.from_buffer_copy(self.mPushConstants)
         pc.gOutputExtent[0], pc.gOutputExtent[1] = frame.width, frame.height
-        pc.gViewCount = 1
+        pc.gViewCount = frame.views.shape[0]
         pc.gLightCount = self._scene.light_count
         pc.gLightPathCount = frame.width * frame.height  # BDPT.cpp:469-470
         # BDPT.cpp:393,486-496

@@ -80,6 +80,24 @@ class Frame:
         self.inverse_view_transforms = inverse_transform(self.view_transforms)
         self.prev = prev
 
+    @classmethod
+    def stereo(cls, width, height, fovy, eye, target, eye_separation=0.1, up=(0.0, 1.0, 0.0)):
+        """Two views side by side in one image (what the XR node hands BDPT::render: one ViewData per eye with its own
+        image rectangle, BDPT.cpp:444-467): left half = left eye, right half = right eye."""
+        half = width // 2
+        f = np.asarray(target, np.float64) - np.asarray(eye, np.float64)
+        r = np.cross(f / np.linalg.norm(f), np.asarray(up, np.float64))
+        r /= np.linalg.norm(r)
+        frames = [cls(half, height, fovy, tuple(np.asarray(eye) + s * 0.5 * eye_separation * r), target, up) for s in (-1.0, 1.0)]
+        self = cls.__new__(cls)
+        self.width, self.height, self.prev = width, height, None
+        self.views = np.concatenate([fr.views for fr in frames])
+        self.views["image_min"][1] = [half, 0]
+        self.views["image_max"][1] = [2 * half, height]
+        self.view_transforms = np.concatenate([fr.view_transforms for fr in frames])
+        self.inverse_view_transforms = np.concatenate([fr.inverse_view_transforms for fr in frames])
+        return self
+
     def desc(self):
         d = wire.FrameDesc()
         d.gViews = wire.ptr(self.views)
@@ -87,5 +105,5 @@ class Frame:
         d.gInverseViewTransforms = wire.ptr(self.inverse_view_transforms)
         d.gPrevViews = wire.ptr(self.prev.views) if self.prev is not None else None
         d.gPrevInverseViewTransforms = wire.ptr(self.prev.inverse_view_transforms) if self.prev is not None else None
-        d.view_count = 1
+        d.view_count = self.views.shape[0]
         return d

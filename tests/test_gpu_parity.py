@@ -569,3 +569,23 @@ def test_nee_reservoirs(flags):
     if "presamplelights" not in flags:
         sc, cam = scenes.environment_scene(image=True, emitter=True)
         _compare_frame(sc, cam, flags, seeds=1)
+
+
+def test_two_views_in_one_frame(renderer, cornell):
+    """gViewCount = 2 (one ViewData per eye with its own image rectangle, scene.h:132-137): every output of both halves
+    equals the oracle's; pixels outside every view (odd width: the last column) stay untouched."""
+    from oracle import oracle_py
+
+    sc, cam = cornell
+    renderer.update(sc)
+    frame = camera.Frame.stereo(161, 96, cam["fovy"], cam["eye"], cam["target"], eye_separation=0.3)
+    got = renderer.render(frame, 2, 2)
+    ref = oracle_py.OracleScene(sc).render(frame, renderer.push_constants(frame), renderer.mSamplingFlags, 2, 2)
+    for k in ("radiance", "albedo", "prev_uv"):
+        assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
+    assert np.array_equal(got["visibility"]["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
+    assert np.array_equal(got["depth"]["z"].view(np.uint32), ref["depth"]["z"].view(np.uint32))
+    assert np.array_equal(got["ray_count"], ref["ray_count"])
+    assert np.all(got["radiance"][:, 160] == 0) and got["radiance"][:, :160, 3].min() == 2
+    # the two eyes see the box from different positions
+    assert np.abs(got["radiance"][:, :80, :3] - got["radiance"][:, 80:160, :3]).mean() > 1e-3
