@@ -1249,6 +1249,9 @@ struct Frame {
   // gPresampledLights of every seed of the call (ePresampleLights): [seed - seed_begin][gLightPresampleTileSize * TileCount]
   const std::vector<PresampledLightPoint>* presampled = nullptr;
   uint32_t seed_begin = 0;
+  // gLightTraceSamples of the seed being traced (eConnectToViews): uint4 per pixel = quantised rgb sums + overflow bits
+  std::atomic<uint32_t>* light_trace = nullptr;
+  uint32_t light_trace_quantization = 65536;  // BDPT.hpp:55
   bool flag(int b) const { return (sampling_flags >> b) & 1u; }
 };
 
@@ -1552,15 +1555,23 @@ inline float mis2(const Frame& fr, float a, float b) {
 // path.hlsli:67-98 (gShadingNormalFix off, adjoint=false on view paths)
 // path.hlsli:67-98, view paths (adjoint = false): the light-leak test, and with eShadingNormalShadowFix the shadow
 // terminator term G = min(1, |ngdotout / (ndotout ngdotns)|), G <- -G^3 + G^2 + G
-inline float shading_normal_correction(float ndotin, float ndotout, float ngdotin, float ngdotout, float ngdotns = 1.0f, bool terminator_fix = false) {
+inline float shading_normal_correction(float ndotin, float ndotout, float ngdotin, float ngdotout, float ngdotns = 1.0f, bool terminator_fix = false, bool adjoint = false) {
   if (sgn(ngdotout * ngdotin) != sgn(ndotin * ndotout)) return 0;
   float G = 1;
   if (terminator_fix) {
-    G = fminf(1.0f, fabsf(ngdotout / (ndotout * ngdotns)));
+    G = fminf(1.0f, fabsf(adjoint ? ngdotin / (ndotin * ngdotns) : ngdotout / (ndotout * ngdotns)));
     G = -(pow2(G) * G) + pow2(G) + G;
+  }
+  if (adjoint) {  // light paths: the non-symmetry of shading normals (Veach), path.hlsli:90-95
+    const float num = ngdotout * ndotin;
+    const float denom = ndotout * ngdotin;
+    if (fabsf(denom) > 1e-5f) G *= fabsf(num / denom);
   }
   return G;
 }
+inline void project_point(const sthip_ProjectionData& p, v3 v, float r[4]);
+// path.hlsli:29-36: dE (or dL) of a vertex from the previous vertex's
+inline float connection_dVC(float dVC, float pdfA_rev, float prev_pdfA_fwd, bool specular) { return ((specular ? 0.0f : 1.0f) + dVC * pow2(pdfA_rev)) / pow2(prev_pdfA_fwd); }
 
 // ---------------------------------------------------------------------------------------------
 // P1-P8 — PathIntegrator (path.hlsli:248-1075), view paths, no media, no environment
@@ -1579,6 +1590,10 @@ struct PathIntegrator {
   v3 local_dir_in;
   float ngdotin, G;
   float rd_radius, rd_spread;               // RayDifferential (path.hlsli:224-244), only with eRayCones
+  // BDPT quantities (path.hlsli:262-267), used when eConnectToViews is on
+  float path_pdf, path_pdf_rev, dVC;
+  bool prev_specular;
+  bool trace_light;                         // gTraceLight: this is a light subpath (sample_photons)
   v3 radiance;                              // accumulate_contribution target (path.hlsli:300-304)
   sthip_ShadowRayData shadow_rays[32];      // this pixel's gShadowRays slots (path.hlsli:65,355-364)
   uint32_t max_shadow;
@@ -1597,15 +1612,18 @@ struct PathIntegrator {
     return py * W + px;
   }
 
-  PathIntegrator(const Frame& f, uint32_t x, uint32_t y, uint32_t seed_) : fr(f), px(x), py(y), seed(seed_) {
+  PathIntegrator(const Frame& f, uint32_t x, uint32_t y, uint32_t seed_, bool light = false) : fr(f), px(x), py(y), seed(seed_) {
     const uint32_t seed = seed_;
+    trace_light = light;
+    path_pdf = path_pdf_rev = dVC = 1;
+    prev_specular = false;
     diffuse_vertices = 0;
     path_length = 1;
     eta_scale = 1;
     rng.v[0] = x;
     rng.v[1] = y;
     rng.v[2] = seed;
-    rng.v[3] = 0;  // path.hlsli:295-297 with gTraceLight=0, no media
+    rng.v[3] = light ? 0xFFFFFFu : 0u;  // path.hlsli:295-297, no media
     radiance = V3(0.0f);
     max_shadow = std::min(32u, std::max(fr.pc.gMaxDiffuseVertices, 1u));
     memset(shadow_rays, 0, sizeof(shadow_rays));  // BDPT.cpp:672-676 fill(0)
@@ -1642,6 +1660,7 @@ struct PathIntegrator {
     G = 1 / dist2;
     ngdotin = -dot(direction, isect.sd.geometry_normal());
     G *= fabsf(ngdotin);
+    path_pdf *= bsdf_pdf * G;  // pdfWtoA, path.hlsli:1042
   }
 
   // path.hlsli:847-894
@@ -1660,7 +1679,15 @@ struct PathIntegrator {
     if (!area_measure) light_pdfA = light_pdfA * G;  // pdfWtoA
     float weight = 1;
     if (path_length > 2) {
-      if (fr.flag(STHIP_eNEE)) weight = fr.flag(STHIP_eNEEReservoirs) ? 0.5f : mis2(fr, bsdf_pdf * G, light_pdfA);  // path.hlsli:881-886
+      if (fr.flag(STHIP_eConnectToViews)) {  // path.hlsli:870-880 (no light-subpath connections)
+        if (fr.flag(STHIP_eMIS)) {
+          const float p_rev_k = cosine_hemisphere_pdfW(fabsf(cos_theta_light)) * (fabsf(prev_cos_out) / len_sqr(origin - isect.sd.position));
+          weight = prev_specular ? 0.0f : mis2(fr, path_pdf, path_pdf_rev * p_rev_k * light_pdfA);
+        } else {
+          weight = path_weight(path_length, 0);
+        }
+      } else if (fr.flag(STHIP_eNEE))
+        weight = fr.flag(STHIP_eNEEReservoirs) ? 0.5f : mis2(fr, bsdf_pdf * G, light_pdfA);  // path.hlsli:881-886
     }
     radiance = radiance + contrib * weight;
   }
@@ -1749,7 +1776,18 @@ struct PathIntegrator {
     const v3 contrib = Le * ev.f * cG / pdfA;
     if (all_le0(contrib)) return;
     float weight = 1;
-    if (fr.flag(STHIP_eSampleBSDFs)) weight = mis2(fr, pdfA, pdfA_fwd);
+    if (fr.flag(STHIP_eConnectToViews)) {  // BDPT MIS, path.hlsli:341-351
+      if (fr.flag(STHIP_eMIS)) {
+        const float emission_pdfA = cosine_hemisphere_pdfW(ngdotout) * (ngdotout / pow2(ray_distance));  // setup(), :219 (after the distance epsilon)
+        const float dL = connection_dVC(1 / pdfA, emission_pdfA, pdfA, false);
+        const float G_rev = prev_cos_out / len_sqr(origin - isect.sd.position);
+        const float dE = connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular);
+        weight = 1 / (1 + dE * pow2(emission_pdfA) + dL * pow2(pdfA_fwd));
+      } else {
+        weight = path_weight(path_length, 1);
+      }
+    } else if (fr.flag(STHIP_eSampleBSDFs))
+      weight = mis2(fr, pdfA, pdfA_fwd);
     if (defer) {
       const v3 c = beta * contrib * weight;
       if (diffuse_vertices >= 1 && diffuse_vertices <= max_shadow) {
@@ -1847,7 +1885,7 @@ struct PathIntegrator {
   bool sample_direction(const DisneyMaterial& m) {
     const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float();
     MaterialSampleRecord ms;
-    m.sample(ms, V3(r0, r1, r2), local_dir_in, beta, false);
+    m.sample(ms, V3(r0, r1, r2), local_dir_in, beta, trace_light);
     if (ms.pdf_fwd < 1e-6f) {
       beta = V3(0.0f);
       return false;
@@ -1858,13 +1896,19 @@ struct PathIntegrator {
       if (ms.eta != 0) spec_spread = spec_spread / ms.eta;
       rd_spread = fmaxf(0.0f, lerpf(spec_spread, 0.2f, ms.roughness));
     }
+    {  // MIS quantities, path.hlsli:919-925
+      const float G_rev = prev_cos_out / len_sqr(origin - isect.sd.position);
+      if (trace_light || path_length > 2) path_pdf_rev *= ms.pdf_rev * G_rev;
+      dVC = connection_dVC(dVC, ms.pdf_rev * G_rev, bsdf_pdf * G, m.is_specular());
+      prev_specular = m.is_specular();
+    }
     bsdf_pdf = ms.pdf_fwd;
     const float ndotout = ms.dir_out.z;
     ms.dir_out = normalize(isect.sd.to_world(ms.dir_out));
     const v3 geometry_normal = isect.sd.geometry_normal();
     const float ngdotout = dot(geometry_normal, ms.dir_out);
     origin = ray_offset(isect.sd.position, ngdotout > 0 ? geometry_normal : -geometry_normal);
-    beta = beta * shading_normal_correction(local_dir_in.z, ndotout, ngdotin, ngdotout, dot(geometry_normal, isect.sd.shading_normal()), fr.flag(STHIP_eShadingNormalShadowFix));
+    beta = beta * shading_normal_correction(local_dir_in.z, ndotout, ngdotin, ngdotout, dot(geometry_normal, isect.sd.shading_normal()), fr.flag(STHIP_eShadingNormalShadowFix), trace_light);
     prev_cos_out = ngdotout;
     if (all_le0(beta)) return false;
     direction = ms.dir_out;
@@ -1873,17 +1917,89 @@ struct PathIntegrator {
 
   // path.hlsli:955-998
   bool next_vertex_m(const DisneyMaterial& m) {
-    if (path_length > 2) eval_emission(m.Le());
+    if (!trace_light && path_length > 2) eval_emission(m.Le());
     if (!m.can_eval() || path_length >= fr.pc.gMaxPathVertices) return false;
     if (!m.is_specular()) {
       diffuse_vertices++;
       if (diffuse_vertices > fr.pc.gMaxDiffuseVertices) return false;
-      if (path_length >= fr.pc.gMinPathVertices)
-        if (!russian_roulette()) return false;
-      if (fr.flag(STHIP_eNEE)) connect_light(m);
+      if (trace_light) {
+        if (fr.flag(STHIP_eConnectToViews)) connect_view(m);
+      } else {
+        if (path_length >= fr.pc.gMinPathVertices)
+          if (!russian_roulette()) return false;
+        if (fr.flag(STHIP_eNEE)) connect_light(m);
+      }
     }
-    if (fr.flag(STHIP_eSampleBSDFs)) return sample_direction(m);
+    if (fr.flag(STHIP_eSampleBSDFs) || trace_light) return sample_direction(m);
     return false;
+  }
+
+  // path_weight, path.hlsli:16-28 (no light-subpath connections)
+  float path_weight(uint32_t view_length, uint32_t light_length) const {
+    const uint32_t n_vertices = view_length + light_length;
+    if (n_vertices <= 2) return 1;
+    uint32_t n = 1;
+    if (fr.flag(STHIP_eNEE)) n++;
+    if (fr.flag(STHIP_eConnectToViews) && n_vertices <= fr.pc.gMaxPathVertices + 1) n++;
+    return 1.f / (float)n;
+  }
+
+  // connect_view, path.hlsli:533-613: the light-path vertex seen from the camera, splatted into gLightTraceSamples
+  void connect_view(const DisneyMaterial& m) {
+    uint32_t view_index = 0;
+    if (fr.pc.gViewCount > 1) view_index = (uint32_t)fminf(rng.next_float() * (float)fr.pc.gViewCount, (float)(fr.pc.gViewCount - 1));
+    const sthip_ViewData& view = fr.fd.gViews[view_index];
+    float sp[4];
+    project_point(view.projection, transform_point(fr.fd.gInverseViewTransforms[view_index], isect.sd.position), sp);
+    sp[1] = -sp[1];
+    sp[0] = sp[0] / sp[3];
+    sp[1] = sp[1] / sp[3];
+    sp[2] = sp[2] / sp[3];
+    if (fabsf(sp[0]) >= 1 || fabsf(sp[1]) >= 1 || fabsf(sp[2]) >= 1 || sp[2] <= 0) return;
+    const float u = sp[0] * .5f + .5f, v = sp[1] * .5f + .5f;
+    const int ix = view.image_min[0] + (int)((float)(view.image_max[0] - view.image_min[0]) * u);
+    const int iy = view.image_min[1] + (int)((float)(view.image_max[1] - view.image_min[1]) * v);
+    const uint32_t output_index = (uint32_t)iy * fr.pc.gOutputExtent[0] + (uint32_t)ix;
+    const sthip_TransformData& t = fr.fd.gViewTransforms[view_index];
+    const v3 position = V3(t.m[0][3], t.m[1][3], t.m[2][3]);
+    const v3 view_normal = normalize(transform_vector(t, V3(0, 0, 1)));
+    v3 to_view = position - isect.sd.position;
+    const float dist = length(to_view);
+    to_view = to_view / dist;
+    const float sensor_cos_theta = fabsf(dot(to_view, view_normal));
+    const float sensor_importance = 1 / (view.projection.sensor_area * 1.0f * (pow2(sensor_cos_theta) * pow2(sensor_cos_theta)));
+    // pdfAtoW(1 / lens_area, cos / dist^2) = 1 / (cos / dist^2)
+    v3 contribution = beta * sensor_importance / (1.0f / (sensor_cos_theta / pow2(dist)));
+    const float G_rev = fabsf(prev_cos_out) / len_sqr(origin - isect.sd.position);
+    const v3 geometry_normal = isect.sd.geometry_normal();
+    const float ngdotout = dot(to_view, geometry_normal);
+    const v3 ray_origin = ray_offset(isect.sd.position, ngdotout > 0 ? geometry_normal : -geometry_normal);
+    const v3 local_to_view = normalize(isect.sd.to_local(to_view));
+    contribution = contribution * shading_normal_correction(local_dir_in.z, local_to_view.z, ngdotin, ngdotout, dot(geometry_normal, isect.sd.shading_normal()), fr.flag(STHIP_eShadingNormalShadowFix), true);
+    MaterialEvalRecord ev;
+    m.eval(ev, local_dir_in, local_to_view, true);
+    if (ev.pdf_fwd < 1e-6f) return;
+    contribution = contribution * ev.f;
+    if (all_le0(contribution)) return;
+    if (occluded(ray_origin, to_view, dist)) return;  // trace_visibility_ray over the full distance (:580)
+    float weight;
+    if (fr.flag(STHIP_eMIS))
+      weight = prev_specular ? 1.0f : mis2(fr, path_pdf, 1.0f * path_pdf_rev * (ev.pdf_rev * G_rev));
+    else
+      weight = path_weight(1, path_length);
+    // accumulate_light_contribution, path.hlsli:47-60: quantised integer sums (order-independent) + overflow bits
+    const v3 c = contribution * weight;
+    const float q = (float)fr.light_trace_quantization;
+    const float cf[3] = {fmaxf(0.0f, c.x) * q, fmaxf(0.0f, c.y) * q, fmaxf(0.0f, c.z) * q};
+    uint32_t ci[3];
+    for (int k = 0; k < 3; k++) ci[k] = cf[k] >= 4294967296.0f ? 0xFFFFFFFFu : (cf[k] == cf[k] ? (uint32_t)cf[k] : 0u);
+    if (ci[0] == 0 && ci[1] == 0 && ci[2] == 0) return;
+    uint32_t overflow_mask = 0;
+    for (int k = 0; k < 3; k++) {
+      const uint32_t prev = fr.light_trace[4 * (size_t)output_index + k].fetch_add(ci[k], std::memory_order_relaxed);
+      if (ci[k] > 0xFFFFFFFFu - prev) overflow_mask |= 1u << k;
+    }
+    if (overflow_mask) fr.light_trace[4 * (size_t)output_index + 3].fetch_or(overflow_mask, std::memory_order_relaxed);
   }
   // path.hlsli:1048-1075
   void next_vertex() {
@@ -1988,8 +2104,11 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
   }
   path.beta = V3(1.0f);
   path.trace();
+  path.path_pdf = 1;  // bdpt.hlsl:213-220
+  path.path_pdf_rev = 1;
   path.bsdf_pdf = 1;
   path.G = 1;
+  path.dVC = 1;
 
   sthip_VisibilityInfo vis;
   vis.instance_primitive_index = path.isect.instance_primitive_index;
@@ -2058,7 +2177,17 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
       contribution = V3(0.0f);
     c = c + contribution;
   }
-  const v3 rad = path.radiance + c;
+  v3 rad = path.radiance + c;
+  if (fr.light_trace) {  // add_light_trace, bdpt.hlsl:328-338 with load_light_sample, path.hlsli:38-46
+    const size_t idx = (size_t)y * fr.pc.gOutputExtent[0] + x;
+    uint32_t v[4];
+    for (int k = 0; k < 4; k++) v[k] = fr.light_trace[4 * idx + k].load(std::memory_order_relaxed);
+    for (int k = 0; k < 3; k++)
+      if (v[3] & (1u << k)) v[k] = 0xFFFFFFFFu;
+    v3 lc = V3((float)v[0], (float)v[1], (float)v[2]) / (float)fr.light_trace_quantization;
+    if (lc.x < 0 || lc.y < 0 || lc.z < 0 || any_nan(lc)) lc = V3(0.0f);
+    rad = rad + lc;
+  }
   out_rgb[0] = rad.x;
   out_rgb[1] = rad.y;
   out_rgb[2] = rad.z;
@@ -2217,13 +2346,65 @@ orc_scene* orc_scene_create(const sthip_scene_desc* d) {
 
 void orc_scene_destroy(orc_scene* sc) { delete sc; }
 
+// sample_photons, bdpt.hlsl:101-147: one light subpath per thread of dispatch_over(W, ceil(gLightPathCount / W)) in 8x4
+// groups (threads of the padding columns run too when their path index is below gLightPathCount, as upstream)
+void trace_light_paths(const Frame& fr, uint32_t seed, int threads, uint64_t* tstats) {
+  const uint32_t W = fr.pc.gOutputExtent[0];
+  const uint32_t count = fr.pc.gLightPathCount;
+  const uint32_t rows = (count + W - 1) / W;
+  const uint32_t gw = (W + 7) / 8, gh = (rows + 3) / 4;
+  parallel_rows(gh * 4, threads, [&](uint32_t y, int tid) {
+    for (uint32_t x = 0; x < gw * 8; x++) {
+      uint32_t path_index;
+      if (fr.flag(STHIP_eRemapThreads))
+        path_index = ((y / 4) * gw + (x / 8)) * 32 + (y % 4) * 8 + (x % 8);
+      else
+        path_index = y * W + x;
+      if (path_index >= count) continue;
+      PathIntegrator path(fr, x, y, seed, true);
+      float rnd[4];
+      for (float& r : rnd) r = path.rng.next_float();
+      LightSampleRecord ls;
+      sample_point_on_light(fr, ls, rnd, V3(0.0f));
+      if (ls.pdf <= 0 || all_le0(ls.radiance)) continue;
+      path.isect.instance_primitive_index = 0xFFFFFFFFu;
+      path.isect.sd.position = ls.position;
+      path.isect.sd.packed_geometry_normal = pack_normal_octahedron(ls.normal);
+      path.isect.sd.shape_area = 1;
+      path.beta = ls.radiance / ls.pdf;
+      path.path_pdf = ls.pdf;
+      path.path_pdf_rev = 1;
+      path.dVC = 1 / ls.pdf;
+      path.G = 1;
+      path.prev_cos_out = 1;
+      path.bsdf_pdf = ls.pdf;
+      const float u1 = path.rng.next_float(), u2 = path.rng.next_float();
+      const v3 local_dir_out = sample_cos_hemisphere(u1, u2);
+      path.bsdf_pdf = cosine_hemisphere_pdfW(local_dir_out.z);
+      path.beta = path.beta * (local_dir_out.z / path.bsdf_pdf);
+      path.prev_cos_out = local_dir_out.z;
+      v3 T, B;
+      make_orthonormal(ls.normal, T, B);
+      path.direction = T * local_dir_out.x + B * local_dir_out.y + ls.normal * local_dir_out.z;
+      path.origin = ray_offset(ls.position, ls.normal);
+      path.trace();
+      while (any_gt0(path.beta) && !any_nan(path.beta)) path.next_vertex();
+      uint64_t* st = tstats + (size_t)tid * 4;
+      st[0] += path.rays_total;
+      st[1] += path.rays_path;
+      st[2] += path.counters[0];
+      st[3] += path.counters[1];
+    }
+  });
+}
+
 // stats_out[4]: rays_total (gRayCount[0]), rays_path (gRayCount[1]), nodes visited, triangles tested
 int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin,
                uint32_t seed_count, const sthip_outputs* out, int threads, uint64_t* stats_out) {
   if (!sc || !pc || !frame || !out || !out->gRadiance || !frame->gViews || !frame->gViewTransforms) return STHIP_ERR_INVALID_ARGUMENT;
   if (scene_flags & (STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT)) return STHIP_ERR_UNSUPPORTED;
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
-  const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_eConnectToViews) |
+  const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) |
                                (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
                                (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling) | (1u << STHIP_eSampleEnvironmentMapDirectly);
   if (sampling_flags & unsupported) return STHIP_ERR_UNSUPPORTED;
@@ -2273,6 +2454,26 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
   const uint32_t W = pc->gOutputExtent[0], H = pc->gOutputExtent[1];
   if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
   std::vector<uint64_t> tstats((size_t)threads * 4, 0);
+  // light tracing (eConnectToViews, BDPT.cpp:653-667,740-748): per seed, sample_photons fills gLightTraceSamples before
+  // the view paths run, add_light_trace adds it to gRadiance afterwards
+  if (!has_emissives(fr) && !has_environment(fr)) fr.sampling_flags &= ~(1u << STHIP_eConnectToViews);  // BDPT.cpp:504-509
+  const bool light_tracing = fr.flag(STHIP_eConnectToViews) && fr.pc.gMaxPathVertices > 2;
+  std::vector<std::vector<std::atomic<uint32_t>>> light_images;
+  if (fr.flag(STHIP_eConnectToViews)) {
+    if (has_environment(fr) || fr.flag(STHIP_eNEEReservoirs)) return STHIP_ERR_UNSUPPORTED;  // env light paths start from an unset position upstream
+    if (!frame->gInverseViewTransforms) return STHIP_ERR_INVALID_ARGUMENT;
+    if ((uint64_t)seed_count * W * H > (1ull << 26)) return STHIP_ERR_INVALID_ARGUMENT;
+  }
+  if (light_tracing) {
+    light_images = std::vector<std::vector<std::atomic<uint32_t>>>(seed_count);
+    for (uint32_t s = 0; s < seed_count; s++) {
+      light_images[s] = std::vector<std::atomic<uint32_t>>((size_t)W * H * 4);
+      for (auto& a : light_images[s]) a.store(0, std::memory_order_relaxed);
+      Frame lf = fr;
+      lf.light_trace = light_images[s].data();
+      trace_light_paths(lf, seed_begin + s, threads, tstats.data());
+    }
+  }
   parallel_rows(H, threads, [&](uint32_t y, int tid) {
     for (uint32_t x = 0; x < W; x++) {
       const size_t p = (size_t)y * W + x;
@@ -2283,7 +2484,9 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
         float rgb[3];
         PixelAOV aov;
         const bool want_aov = (s == 0) && (out->gAlbedo || out->gVisibility || out->gDepth || out->gPrevUVs);
-        if (!render_pixel(fr, x, y, seed_begin + s, rgb, want_aov ? &aov : nullptr, &tstats[(size_t)tid * 4])) break;
+        Frame sf = fr;
+        if (light_tracing) sf.light_trace = light_images[s].data();
+        if (!render_pixel(sf, x, y, seed_begin + s, rgb, want_aov ? &aov : nullptr, &tstats[(size_t)tid * 4])) break;
         inside = true;
         float cur[4] = {rgb[0], rgb[1], rgb[2], 1};
         if (std::isinf(cur[0]) || std::isinf(cur[1]) || std::isinf(cur[2]) || cur[0] != cur[0] || cur[1] != cur[1] || cur[2] != cur[2]) cur[0] = cur[1] = cur[2] = cur[3] = 0;

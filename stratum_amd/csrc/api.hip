@@ -81,6 +81,8 @@ struct sthip_ctx {
   DevBuf<unsigned long long> counters;
   DevBuf<float> distributions;  // gDistributions
   DevBuf<float4> presampled;    // gPresampledLights
+  DevBuf<float4> bdpt;          // BDPT quantities per path (eConnectToViews)
+  DevBuf<uint32_t> light_trace; // gLightTraceSamples
   DevBuf<DeviceImage1> images1;  // gImage1s (alpha masks)
   DevBuf<float> image1_texels;
   DevBuf<BvhTriUv> tri_uvs;
@@ -205,6 +207,8 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->counters.release();
   ctx->distributions.release();
   ctx->presampled.release();
+  ctx->bdpt.release();
+  ctx->light_trace.release();
   ctx->images1.release();
   ctx->image1_texels.release();
   ctx->tri_uvs.release();
@@ -550,7 +554,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   // Outside the built hot path: media, light tracing, reservoirs, ...
   if (scene_flags & (STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT))
     return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media / light-tracing scene flags are not part of the built hot path");
-  const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_eConnectToViews) |
+  const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) |
                                (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
                                (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling) | (1u << STHIP_eSampleEnvironmentMapDirectly);
   if (sampling_flags & unsupported) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: a sampling flag outside the built hot path is set");
@@ -565,7 +569,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   const bool has_env = (scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) != 0, has_emissives = (scene_flags & STHIP_BDPT_FLAG_HAS_EMISSIVES) != 0;
   if (!has_env) pcn.gEnvironmentSampleProbability = 0;
   if (!has_emissives) pcn.gEnvironmentSampleProbability = 1;
-  if (!has_emissives && !has_env) sampling_flags &= ~(1u << STHIP_eNEE);
+  if (!has_emissives && !has_env) sampling_flags &= ~((1u << STHIP_eNEE) | (1u << STHIP_eConnectToViews));
   if (!(sampling_flags & (1u << STHIP_eNEE))) sampling_flags &= ~((1u << STHIP_eDeferShadowRays) | (1u << STHIP_ePresampleLights) | (1u << STHIP_eNEEReservoirs));
   pc = &pcn;
   if (has_env) {  // the Environment record (environment.h:17-22): ImageValue3, then 4 offsets into gDistributions when an image is bound
@@ -605,8 +609,23 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   const uint32_t max_in_flight = (uint32_t)std::max<uint64_t>(1, (ctx->max_paths_in_flight) / std::max(1u, p.paths_per_seed));
   const uint32_t batch = std::min(seed_count, max_in_flight);
   p.path_count = batch * p.paths_per_seed;
-  const size_t P = std::max<size_t>(1, p.path_count);
+  // light tracing (eConnectToViews, BDPT.cpp:653-667): sample_photons' padded dispatch, dispatch_over(W, ceil(gLightPathCount / W))
+  const bool connect_views = (sampling_flags & (1u << STHIP_eConnectToViews)) != 0;
+  const bool light_tracing = connect_views && pc->gMaxPathVertices > 2;
+  if (connect_views) {
+    if (has_env) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eConnectToViews with an environment (upstream starts environment light paths from an unset position, bdpt.hlsl:109-113)");
+    if (sampling_flags & (1u << STHIP_eNEEReservoirs)) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eConnectToViews together with eNEEReservoirs is not built");
+    if (!frame->gInverseViewTransforms) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eConnectToViews needs gInverseViewTransforms");
+  }
+  const uint32_t light_rows = (pc->gLightPathCount + W - 1) / W;
+  const uint32_t light_threads = light_tracing ? ((W + 7) / 8) * 8 * ((light_rows + 3) / 4) * 4 : 0;
+  if ((uint64_t)light_threads * batch > 0x7FFFFFFFull || (light_tracing && (uint64_t)batch * W * H > 0x7FFFFFFFull)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many light paths in flight");
+  const size_t P = std::max<size_t>(std::max<size_t>(1, p.path_count), (size_t)light_threads * batch);
   const size_t P0 = std::max<size_t>(1, p.paths_per_seed);
+  if (connect_views) {
+    HIP_TRY(ctx, ctx->bdpt.ensure(P));
+    if (light_tracing) HIP_TRY(ctx, ctx->light_trace.ensure((size_t)batch * W * H * 4));
+  }
 
   HIP_TRY(ctx, ctx->ray_o.ensure(P));
   HIP_TRY(ctx, ctx->ray_d.ensure(P));
@@ -639,9 +658,13 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   // views
   const uint32_t nv = frame->view_count;
   const size_t vbytes = (size_t)nv * 48;
-  HIP_TRY(ctx, ctx->views.ensure(4 * vbytes));
+  HIP_TRY(ctx, ctx->views.ensure(5 * vbytes));
   {
-    std::vector<uint8_t> host(4 * vbytes);
+    std::vector<uint8_t> host(5 * vbytes);
+    if (frame->gInverseViewTransforms)
+      memcpy(host.data() + 4 * vbytes, frame->gInverseViewTransforms, vbytes);
+    else
+      memset(host.data() + 4 * vbytes, 0, vbytes);
     memcpy(host.data(), frame->gViews, vbytes);
     memcpy(host.data() + vbytes, frame->gViewTransforms, vbytes);
     memcpy(host.data() + 2 * vbytes, frame->gPrevViews ? frame->gPrevViews : frame->gViews, vbytes);
@@ -650,13 +673,18 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       memcpy(host.data() + 3 * vbytes, piv, vbytes);
     else
       memset(host.data() + 3 * vbytes, 0, vbytes);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->views.p, host.data(), 4 * vbytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->views.p, host.data(), 5 * vbytes, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));  // `host` goes out of scope
   }
   p.views = reinterpret_cast<const sthip_ViewData*>(ctx->views.p);
   p.view_xf = reinterpret_cast<const sthip_TransformData*>(ctx->views.p + vbytes);
   p.prev_views = reinterpret_cast<const sthip_ViewData*>(ctx->views.p + 2 * vbytes);
   p.prev_inv_view_xf = reinterpret_cast<const sthip_TransformData*>(ctx->views.p + 3 * vbytes);
+  p.inv_view_xf = reinterpret_cast<const sthip_TransformData*>(ctx->views.p + 4 * vbytes);
+  p.bdpt = connect_views ? ctx->bdpt.p : nullptr;
+  p.light_trace = light_tracing ? ctx->light_trace.p : nullptr;
+  p.light_threads = light_threads;
+  p.light_trace_quantization = 65536;  // BDPT.hpp:55 mLightTraceQuantization
 
   p.bvh = ctx->bvh;
   p.bvh.alpha_test = (ctx->has_alpha && (sampling_flags & (1u << STHIP_eAlphaTest))) ? 1u : 0u;  // intersection.hlsli:118
@@ -785,38 +813,21 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   };
 
   HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_TOTAL * sizeof(unsigned long long), st));
+  const bool nee = (sampling_flags & (1u << STHIP_eNEE)) != 0;
+  const bool ext = ctx->has_spheres || has_env || connect_views || (sampling_flags & ((1u << STHIP_eNEEReservoirs) | (1u << STHIP_eShadingNormalShadowFix)));
   for (uint32_t s = 0; s < seed_count; s += batch) {
     const uint32_t in_flight = std::min(batch, seed_count - s);
     p.seed = seed_begin + s;
     p.seeds_in_flight = in_flight;
-    p.path_count = in_flight * p.paths_per_seed;
     p.write_aov = s == 0 ? 1u : 0u;
+    int rc = STHIP_OK;
     // queue sizes and heads are per pass; the ray / traversal counters run over the whole call
-    {
+    auto reset_queues = [&]() -> int {
       const size_t per_depth = (size_t)QUEUE_SEGMENTS * QCTL_STRIDE * sizeof(unsigned long long);
-      HIP_TRY(ctx, hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 0, 0), 0, (max_bounce_rounds + 1) * per_depth, st));  // k_shade of the last round appends to depth + 1
+      HIP_TRY(ctx, hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 0, 0), 0, (max_bounce_rounds + 1) * per_depth, st));  // the last round's shade appends to depth + 1
       HIP_TRY(ctx, hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 1, 0), 0, max_bounce_rounds * per_depth, st));
-    }
-    int rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(STHIP_BLOCK), 0, st, p); });
-    if (rc) return rc;
-    if (presample) {
-      const unsigned pgrid = (unsigned)((presample_n * in_flight + STHIP_BLOCK - 1) / STHIP_BLOCK);
-      const bool ext = ctx->has_spheres || has_env;
-      rc = timed(ms_other, [&]() {
-        if (ctx->textured && ext)
-          hipLaunchKernelGGL((k_presample_lights<true, true>), dim3(pgrid), dim3(STHIP_BLOCK), 0, st, p);
-        else if (ctx->textured)
-          hipLaunchKernelGGL((k_presample_lights<true, false>), dim3(pgrid), dim3(STHIP_BLOCK), 0, st, p);
-        else if (ext)
-          hipLaunchKernelGGL((k_presample_lights<false, true>), dim3(pgrid), dim3(STHIP_BLOCK), 0, st, p);
-        else
-          hipLaunchKernelGGL((k_presample_lights<false, false>), dim3(pgrid), dim3(STHIP_BLOCK), 0, st, p);
-      });
-      if (rc) return rc;
-    }
-    // Round r traces the paths entering bounce r together with the shadow rays bounce r - 1 produced (one launch,
-    // k_trace), then shades bounce r; a last launch traces the shadow rays of the last bounce.
-    const bool nee = (sampling_flags & (1u << STHIP_eNEE)) != 0;
+      return STHIP_OK;
+    };
     auto trace = [&](uint32_t dc, uint32_t ds) -> int {
       if (dc == TRACE_NONE && ds == TRACE_NONE) return STHIP_OK;
       launches_trace++;
@@ -850,35 +861,92 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
           hipLaunchKernelGGL((k_trace_primary<false, false>), dim3(pgrid), dim3(STHIP_BLOCK), plds, st, p);
       });
     };
-    for (uint32_t depth = 0; depth <= max_bounce_rounds; depth++) {
-      const uint32_t dc = depth < max_bounce_rounds ? depth : TRACE_NONE;
-      const uint32_t ds = depth >= 1 && nee ? depth - 1 : TRACE_NONE;
-      if (depth == 0 && dc == 0 && ctx->packet_primary) {
-        rc = trace_primary();
-        if (rc) return rc;
-      } else if (ctx->fuse_trace) {
-        rc = trace(dc, ds);
-        if (rc) return rc;
-      } else {  // analysis: the two ray kinds in launches of their own
-        rc = trace(TRACE_NONE, ds);
-        if (rc) return rc;
-        rc = trace(dc, TRACE_NONE);
-        if (rc) return rc;
+    // Round r traces the paths entering bounce r together with the shadow rays bounce r - 1 produced (one launch,
+    // k_trace), then shades bounce r; a last launch traces the shadow rays of the last bounce. `shade(depth)` is the
+    // pass's shading kernel; the light pass (sample_photons) has visibility rays to the camera in place of NEE rays.
+    auto run_rounds = [&](bool light, bool shadow_rays, auto&& shade) -> int {
+      for (uint32_t depth = 0; depth <= max_bounce_rounds; depth++) {
+        const uint32_t dc = depth < max_bounce_rounds ? depth : TRACE_NONE;
+        const uint32_t ds = depth >= 1 && shadow_rays ? depth - 1 : TRACE_NONE;
+        int r;
+        if (!light && depth == 0 && dc == 0 && ctx->packet_primary) {
+          r = trace_primary();
+        } else if (ctx->fuse_trace) {
+          r = trace(dc, ds);
+        } else {  // analysis: the two ray kinds in launches of their own
+          r = trace(TRACE_NONE, ds);
+          if (!r) r = trace(dc, TRACE_NONE);
+        }
+        if (r) return r;
+        if (dc == TRACE_NONE) break;
+        r = timed(ms_shade, [&]() { shade(depth); });
+        if (r) return r;
       }
-      if (dc == TRACE_NONE) break;
-      rc = timed(ms_shade, [&]() {
-        const bool ext = ctx->has_spheres || has_env || (sampling_flags & ((1u << STHIP_eNEEReservoirs) | (1u << STHIP_eShadingNormalShadowFix)));
-        if (ctx->textured && ext)
-          hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
-        else if (ctx->textured)
-          hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
-        else if (ext)
-          hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+      return STHIP_OK;
+    };
+
+    if (light_tracing) {  // sample_photons before the view paths, BDPT.cpp:653-667
+      HIP_TRY(ctx, hipMemsetAsync(ctx->light_trace.p, 0, (size_t)in_flight * W * H * 16, st));
+      p.light_pass = 1;
+      p.path_count = in_flight * light_threads;
+      rc = reset_queues();
+      if (rc) return rc;
+      const uint32_t lgrid = grid_for(ctx, p.path_count);
+      rc = timed(ms_other, [&]() {
+        if (ctx->textured)
+          hipLaunchKernelGGL((k_generate_light<true, true>), dim3(lgrid), dim3(STHIP_BLOCK), 0, st, p);
         else
-          hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+          hipLaunchKernelGGL((k_generate_light<false, true>), dim3(lgrid), dim3(STHIP_BLOCK), 0, st, p);
+      });
+      if (rc) return rc;
+      rc = run_rounds(true, true, [&](uint32_t depth) {
+        if (ctx->textured)
+          hipLaunchKernelGGL((k_shade_light<true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else
+          hipLaunchKernelGGL((k_shade_light<false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+      });
+      if (rc) return rc;
+      rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_count_rays, dim3(1), dim3(1), 0, st, p); });
+      if (rc) return rc;
+      p.light_pass = 0;
+    }
+
+    p.path_count = in_flight * p.paths_per_seed;
+    rc = reset_queues();
+    if (rc) return rc;
+    rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(STHIP_BLOCK), 0, st, p); });
+    if (rc) return rc;
+    if (presample) {
+      const unsigned pgrid = (unsigned)((presample_n * in_flight + STHIP_BLOCK - 1) / STHIP_BLOCK);
+      const bool pext = ctx->has_spheres || has_env;
+      rc = timed(ms_other, [&]() {
+        if (ctx->textured && pext)
+          hipLaunchKernelGGL((k_presample_lights<true, true>), dim3(pgrid), dim3(STHIP_BLOCK), 0, st, p);
+        else if (ctx->textured)
+          hipLaunchKernelGGL((k_presample_lights<true, false>), dim3(pgrid), dim3(STHIP_BLOCK), 0, st, p);
+        else if (pext)
+          hipLaunchKernelGGL((k_presample_lights<false, true>), dim3(pgrid), dim3(STHIP_BLOCK), 0, st, p);
+        else
+          hipLaunchKernelGGL((k_presample_lights<false, false>), dim3(pgrid), dim3(STHIP_BLOCK), 0, st, p);
       });
       if (rc) return rc;
     }
+    rc = run_rounds(false, nee, [&](uint32_t depth) {
+      if (connect_views) {
+        if (ctx->textured)
+          hipLaunchKernelGGL((k_shade<true, true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else
+          hipLaunchKernelGGL((k_shade<false, true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+      } else if (ctx->textured && ext)
+        hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+      else if (ctx->textured)
+        hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+      else if (ext)
+        hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+      else
+        hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+    });
+    if (rc) return rc;
     rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + in_flight == seed_count ? 1u : 0u, primary_rays * in_flight); });
     if (rc) return rc;
   }

@@ -58,6 +58,13 @@ struct FrameParams {
   float4* accum;       // running mean over seeds (temporal_accumulation.hlsl:118-131): rgb, n
   // queues
   uint32_t* queue[2];
+  // light tracing (eConnectToViews)
+  float4* bdpt;               // per path: path_pdf, path_pdf_rev, dVC, prev_cos_out (path.hlsli:262-267); prev_specular = meta bit 16
+  uint32_t* light_trace;      // gLightTraceSamples: per seed in flight, uint4 per pixel = quantised rgb sums + overflow bits
+  const sthip_TransformData* inv_view_xf;
+  uint32_t light_pass;        // this pass traces light subpaths (sample_photons)
+  uint32_t light_threads;     // threads of sample_photons' padded dispatch per seed
+  uint32_t light_trace_quantization;
   float4* presampled;   // gPresampledLights (ePresampleLights): per seed in flight, 2 x float4 per point: (position, bits(packed normal)) (Le, pdfA)
   float4* shadow_rays;  // 3 x float4 per entry: (origin, distance) (direction, bits(slot)) (contribution, 0)
   unsigned long long* counters;  // CNT_* (64-bit each)
@@ -192,6 +199,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
     p.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
     p.beta[slot] = make_float4(1, 1, 1, __uint_as_float(0u));
     p.meta[slot] = 1u;  // path_length = 1, diffuse_vertices = 0
+    if (p.bdpt) p.bdpt[slot] = make_float4(1, 1, 1, fabsf(local_dir.z));  // bdpt.hlsl:172,213-220: path_pdf, path_pdf_rev, dVC, prev_cos_out
   }
 }
 
@@ -286,12 +294,29 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
     if (busy && !tr.active()) {
       if (!tr.any) {
         p.hit[slot] = make_float4(tr.hit.t, tr.hit.b1, tr.hit.b2, __uint_as_float(tr.hit.ip));
-      } else if (tr.hit.ip == 0xFFFFFFFFu) {  // unoccluded: each pixel has at most one shadow ray per bounce
-        float4 c = target[slot];
-        c.x = c.x + contribution.x;
-        c.y = c.y + contribution.y;
-        c.z = c.z + contribution.z;
-        target[slot] = c;
+      } else if (tr.hit.ip == 0xFFFFFFFFu) {  // unoccluded
+        if (slot & 0x80000000u) {
+          // a light-path vertex seen by the camera: accumulate_light_contribution, path.hlsli:47-60 — quantised
+          // integer sums (order-independent, so the image does not depend on scheduling) + overflow bits
+          uint32_t* lt = p.light_trace + 4 * (size_t)(slot & 0x7FFFFFFFu);
+          const float q = (float)p.light_trace_quantization;
+          const float cf[3] = {fmaxf(0.0f, contribution.x) * q, fmaxf(0.0f, contribution.y) * q, fmaxf(0.0f, contribution.z) * q};
+          uint32_t overflow = 0;
+          for (int k = 0; k < 3; k++) {
+            const uint32_t ci = cf[k] >= 4294967296.0f ? 0xFFFFFFFFu : (cf[k] == cf[k] ? (uint32_t)cf[k] : 0u);
+            if (ci) {
+              const uint32_t prev = atomicAdd(&lt[k], ci);
+              if (ci > 0xFFFFFFFFu - prev) overflow |= 1u << k;
+            }
+          }
+          if (overflow) atomicOr(&lt[3], overflow);
+        } else {  // NEE: each pixel has at most one shadow ray per bounce
+          float4 c = target[slot];
+          c.x = c.x + contribution.x;
+          c.y = c.y + contribution.y;
+          c.z = c.z + contribution.z;
+          target[slot] = c;
+        }
       }
       busy = false;
     }
@@ -596,6 +621,270 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_presample_lights(FrameParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Light tracing (eConnectToViews): sample_photons (bdpt.hlsl:101-147) as a second kind of path through the same
+// wavefront pipeline. k_generate_light starts one light subpath per thread of the reference's padded dispatch,
+// k_trace extends it, k_shade_light runs next_vertex() for light paths: connect_view (a visibility ray to the camera
+// that splats into gLightTraceSamples when it arrives) and the adjoint bounce.
+// ---------------------------------------------------------------------------------------------
+// thread (x, y) of dispatch_over(W, ceil(gLightPathCount / W)) in 8x4 groups for light slot e, and its path index
+DEV void light_thread(const FrameParams& p, uint32_t e, uint32_t& x, uint32_t& y, uint32_t& path_index) {
+  const uint32_t W = p.pc.gOutputExtent[0];
+  const uint32_t gw = (W + 7u) >> 3;
+  const uint32_t group = e >> 5, local = e & 31u;
+  x = (group % gw) * 8u + (local & 7u);
+  y = (group / gw) * 4u + (local >> 3);
+  path_index = flag(p, STHIP_eRemapThreads) ? e : y * W + x;  // map_pixel_coord, bdpt_util.hlsli:76-83
+}
+
+template <bool TEXTURED, bool EXT>
+__global__ void __launch_bounds__(STHIP_BLOCK) k_generate_light(FrameParams p) {
+  const bool has_env = EXT && (p.scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) != 0;
+  const bool has_emissives = !EXT || (p.scene_flags & STHIP_BDPT_FLAG_HAS_EMISSIVES) != 0;
+  uint32_t live = 0;
+  for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.path_count; slot += gridDim.x * blockDim.x) {
+    const uint32_t seed_index = slot / p.light_threads, e = slot - seed_index * p.light_threads;
+    uint32_t x, y, path_index;
+    light_thread(p, e, x, y, path_index);
+    p.meta[slot] = 0xFFFFFFFEu;  // no path unless everything below succeeds
+    p.beta[slot] = make_float4(0, 0, 0, 0);
+    if (path_index >= p.pc.gLightPathCount) continue;
+    Rng rng;
+    rng.x = x;
+    rng.y = y;
+    rng.seed = p.seed + seed_index;
+    rng.counter = 0xFFFFFFu;  // path.hlsli:295-297 with gTraceLight
+    const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float(), r3 = rng.next_float();
+    LightSample ls;
+    sample_point_on_light<TEXTURED, EXT>(p, has_env, has_emissives, r0, r1, r2, r3, F3s(0.0f), ls);
+    if (ls.pdf <= 0 || all_le0(ls.Le)) continue;
+    f3 beta = ls.Le / ls.pdf;
+    const float u1 = rng.next_float(), u2 = rng.next_float();
+    const f3 local_dir_out = sample_cos_hemisphere(u1, u2);
+    const float bsdf_pdf = cosine_hemisphere_pdfW(local_dir_out.z);
+    beta = beta * (local_dir_out.z / bsdf_pdf);
+    f3 T, B;
+    make_orthonormal(ls.normal, T, B);
+    const f3 direction = T * local_dir_out.x + B * local_dir_out.y + ls.normal * local_dir_out.z;
+    const f3 origin = ray_offset(ls.position, ls.normal);
+    p.ray_o[slot] = make_float4(origin.x, origin.y, origin.z, bsdf_pdf);
+    p.ray_d[slot] = make_float4(direction.x, direction.y, direction.z, 1.0f);
+    p.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(rng.counter));
+    p.bdpt[slot] = make_float4(ls.pdf, 1.0f, 1 / ls.pdf, local_dir_out.z);  // path_pdf, path_pdf_rev, dVC, prev_cos_out
+    p.meta[slot] = 1u;
+    if (TEXTURED) p.cone[slot] = make_float2(0.0f, 0.0f);
+    live++;
+  }
+  wave_add(&p.counters[CNT_RAYS_CLOSEST], live);  // every live light path traces its first ray (path.hlsli:1006)
+}
+
+// ray counts of a finished pass: every queued path / shadow record was traced exactly once
+__global__ void k_count_rays(FrameParams p) {
+  unsigned long long closest = 0, shadow = 0;
+  for (uint32_t d = 0; d < p.rounds; d++)
+    for (uint32_t s = 0; s < QUEUE_SEGMENTS; s++) {
+      if (d) closest += queue_ctl(p.qctl, 0, d, s)[QCTL_SIZE];
+      shadow += queue_ctl(p.qctl, 1, d, s)[QCTL_SIZE];
+    }
+  p.counters[CNT_RAYS_CLOSEST] += closest;
+  p.counters[CNT_RAYS_SHADOW] += shadow;
+}
+
+template <bool TEXTURED, bool EXT>
+__global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, uint32_t depth) {
+  const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
+  const uint32_t seg_base = seg * p.seg_stride;
+  uint32_t n, slot0 = 0;
+  if (depth == 0) {
+    const uint32_t per = (((p.path_count + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) + 63u) & ~63u;
+    slot0 = seg * per;
+    n = slot0 < p.path_count ? (slot0 + per < p.path_count ? per : p.path_count - slot0) : 0u;
+  } else {
+    n = (uint32_t)queue_ctl(p.qctl, 0, depth, seg)[QCTL_SIZE];
+  }
+  const uint32_t first = (blockIdx.x / QUEUE_SEGMENTS) * blockDim.x + threadIdx.x;
+  const uint32_t step = ((gridDim.x - seg + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) * blockDim.x;
+  const uint32_t* queue_in = p.queue[depth & 1u] + seg_base;
+  uint32_t* queue_out = p.queue[(depth + 1) & 1u] + seg_base;
+  float4* shadow_out = p.shadow_rays + 3 * (size_t)seg_base;
+  unsigned long long* queue_size = &queue_ctl(p.qctl, 0, depth + 1, seg)[QCTL_SIZE];
+  unsigned long long* shadow_size = &queue_ctl(p.qctl, 1, depth, seg)[QCTL_SIZE];
+  const uint32_t W = p.pc.gOutputExtent[0], H = p.pc.gOutputExtent[1];
+  for (uint32_t i = first; i < n; i += step) {
+    const uint32_t slot = depth == 0 ? slot0 + i : queue_in[i];
+    const uint32_t meta = p.meta[slot];
+    if (meta >= 0xFFFFFFFEu) continue;
+    const uint32_t seed_index = slot / p.light_threads;
+    uint32_t tx, ty, path_index;
+    light_thread(p, slot - seed_index * p.light_threads, tx, ty, path_index);
+    const float4 ro = p.ray_o[slot], rd = p.ray_d[slot], hh = p.hit[slot], bb = p.beta[slot], bd = p.bdpt[slot];
+    const f3 origin = xyz(ro), direction = xyz(rd);
+    float bsdf_pdf = ro.w, eta_scale = rd.w;
+    f3 beta = xyz(bb);
+    float path_pdf = bd.x, path_pdf_rev = bd.y, dVC = bd.z, prev_cos_out = bd.w;
+    bool prev_specular = (meta >> 16) & 1u;
+    Rng rng;
+    rng.x = tx;
+    rng.y = ty;
+    rng.seed = p.seed + seed_index;
+    rng.counter = __float_as_uint(bb.w);
+    uint32_t path_length = meta & 0xFFu, diffuse_vertices = (meta >> 8) & 0xFFu;
+    const uint32_t ip = __float_as_uint(hh.w);
+    bool alive = false;
+    f3 new_origin = origin, new_direction = direction;
+    float2 cone_out = make_float2(0.0f, 0.0f);
+    do {
+      if (all_le0(beta)) break;  // trace(), path.hlsli:1009-1010
+      path_length++;
+      if (ip == 0xFFFFFFFFu) break;  // light paths that leave the scene end (no environment with light tracing)
+      const uint32_t inst_index = ip & 0xFFFFu, prim = ip >> 16;
+      const Inst in = load_inst(p.scene, inst_index);
+      ShadingData sd;
+      if (EXT && in.type() == STHIP_INSTANCE_TYPE_SPHERE) {
+        const Xf inv = load_xf(p.scene.inv_xf, inst_index);
+        const float im[12] = {inv.r0.x, inv.r0.y, inv.r0.z, inv.r0.w, inv.r1.x, inv.r1.y, inv.r1.z, inv.r1.w, inv.r2.x, inv.r2.y, inv.r2.z, inv.r2.w};
+        make_sphere_shading_data(p.scene, sd, inst_index, in, obj_point(im, origin) + obj_vector(im, direction) * hh.x);
+      } else {
+        make_triangle_shading_data(p.scene, sd, inst_index, in, prim, hh.y, hh.z, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
+      }
+      const f3 gn = sd.geometry_normal();
+      const float dist2 = len_sqr(sd.position - origin);
+      float G = 1 / dist2;
+      const float ngdotin = -dot3(direction, gn);
+      G *= fabsf(ngdotin);
+      path_pdf *= bsdf_pdf * G;  // path.hlsli:1042
+      DisneyMaterial m;
+      float rd_radius = 0, rd_spread = 0;  // RayDifferential of the light path: starts at (0, 0), bounces spread it (path.hlsli:911-916)
+      if (TEXTURED) {
+        const float2 cone = p.cone[slot];
+        rd_radius = cone.x;
+        rd_spread = cone.y;
+        if (flag(p, STHIP_eRayCones)) {  // path.hlsli:1026-1029
+          rd_radius += rd_spread * sqrtf(dist2);
+          sd.uv_screen_size *= rd_radius;
+        }
+        m.load_textured(p.scene, in.material_address(), sd.u, sd.v, sd.uv_screen_size, sd.packed_shading_normal, sd.packed_tangent, p.sampling_flags);
+      } else {
+        m.load(p.scene, in.material_address());
+      }
+      const Frame3 frame = make_frame(sd);
+      const f3 local_dir_in = normalize3(frame.to_local(-direction));
+      // next_vertex(BSDF), path.hlsli:955-998, light branch
+      if (!m.can_eval() || path_length >= p.pc.gMaxPathVertices) break;
+      const float ngdotns = dot3(gn, sd.shading_normal());
+      const bool fix = flag(p, STHIP_eShadingNormalShadowFix);
+      if (!m.is_specular()) {
+        diffuse_vertices++;
+        if (diffuse_vertices > p.pc.gMaxDiffuseVertices) break;
+        do {  // connect_view, path.hlsli:533-613
+          uint32_t view_index = 0;
+          if (p.pc.gViewCount > 1) view_index = (uint32_t)fminf(rng.next_float() * (float)p.pc.gViewCount, (float)(p.pc.gViewCount - 1));
+          const sthip_ViewData& view = p.views[view_index];
+          float4 sp = project_point(view.projection, xf_point(load_xf(p.inv_view_xf, view_index), sd.position));
+          sp.y = -sp.y;
+          sp.x = sp.x / sp.w;
+          sp.y = sp.y / sp.w;
+          sp.z = sp.z / sp.w;
+          if (fabsf(sp.x) >= 1 || fabsf(sp.y) >= 1 || fabsf(sp.z) >= 1 || sp.z <= 0) break;
+          const float u = sp.x * .5f + .5f, v = sp.y * .5f + .5f;
+          const int ix = view.image_min[0] + (int)((float)(view.image_max[0] - view.image_min[0]) * u);
+          const int iy = view.image_min[1] + (int)((float)(view.image_max[1] - view.image_min[1]) * v);
+          const Xf t = load_xf(p.view_xf, view_index);
+          const f3 position = F3(t.r0.w, t.r1.w, t.r2.w);
+          const f3 view_normal = normalize3(xf_vector(t, F3(0, 0, 1)));
+          f3 to_view = position - sd.position;
+          const float dist = length3(to_view);
+          to_view = to_view / dist;
+          const float sensor_cos_theta = fabsf(dot3(to_view, view_normal));
+          const float sensor_importance = 1 / (view.projection.sensor_area * 1.0f * (pow2f(sensor_cos_theta) * pow2f(sensor_cos_theta)));
+          f3 contribution = beta * sensor_importance / (1.0f / (sensor_cos_theta / pow2f(dist)));
+          const float G_rev = fabsf(prev_cos_out) / len_sqr(origin - sd.position);
+          const float ngdotout = dot3(to_view, gn);
+          const f3 ray_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
+          const f3 local_to_view = normalize3(frame.to_local(to_view));
+          contribution = contribution * shading_normal_correction(local_dir_in.z, local_to_view.z, ngdotin, ngdotout, ngdotns, fix, true);
+          MaterialEvalRecord ev;
+          m.eval(ev, local_dir_in, local_to_view, true);
+          if (ev.pdf_fwd < 1e-6f) break;
+          contribution = contribution * ev.f;
+          if (all_le0(contribution)) break;
+          float weight;
+          if (flag(p, STHIP_eMIS)) {
+            weight = prev_specular ? 1.0f : mis2(true, path_pdf, 1.0f * path_pdf_rev * (ev.pdf_rev * G_rev));
+          } else {  // path_weight(1, path_length), path.hlsli:16-28
+            const uint32_t nv = 1 + path_length;
+            uint32_t ways = 1;
+            if (flag(p, STHIP_eNEE)) ways++;
+            if (nv <= p.pc.gMaxPathVertices + 1) ways++;
+            weight = nv <= 2 ? 1.0f : 1.f / (float)ways;
+          }
+          const f3 c = contribution * weight;
+          // the splat lands on pixel (ix, iy) of this seed's image; a sharded renderer keeps only its own pixels
+          if (ix < 0 || iy < 0 || (uint32_t)ix >= W || (uint32_t)iy >= H) break;
+          if (p.shard_count > 1 && (((uint32_t)iy / p.tile_h) * p.tiles_x + (uint32_t)ix / p.tile_w) % p.shard_count != p.shard_rank) break;
+          if (!(dist > 1e-6f)) {  // trace_visibility_ray's loop never runs: visible, no ray
+            uint32_t* lt = p.light_trace + 4 * ((size_t)seed_index * W * H + (size_t)iy * W + ix);
+            const float q = (float)p.light_trace_quantization;
+            const float cf[3] = {fmaxf(0.0f, c.x) * q, fmaxf(0.0f, c.y) * q, fmaxf(0.0f, c.z) * q};
+            uint32_t overflow = 0;
+            for (int k = 0; k < 3; k++) {
+              const uint32_t ci = cf[k] >= 4294967296.0f ? 0xFFFFFFFFu : (cf[k] == cf[k] ? (uint32_t)cf[k] : 0u);
+              if (ci) {
+                const uint32_t prev = atomicAdd(&lt[k], ci);
+                if (ci > 0xFFFFFFFFu - prev) overflow |= 1u << k;
+              }
+            }
+            if (overflow) atomicOr(&lt[3], overflow);
+            break;
+          }
+          const uint32_t k = (uint32_t)atomicAdd(shadow_size, 1ull);
+          shadow_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, dist);
+          shadow_out[3 * (size_t)k + 1] = make_float4(to_view.x, to_view.y, to_view.z, __uint_as_float(0x80000000u | (uint32_t)((size_t)seed_index * W * H + (size_t)iy * W + ix)));
+          shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+        } while (0);
+      }
+      // sample_direction with the adjoint BSDF, path.hlsli:898-952
+      const float s0 = rng.next_float(), s1 = rng.next_float(), s2 = rng.next_float();
+      MaterialSampleRecord ms;
+      m.sample(ms, F3(s0, s1, s2), local_dir_in, beta, true);
+      if (ms.pdf_fwd < 1e-6f) break;
+      if (ms.eta != 0) eta_scale /= pow2f(ms.eta);
+      if (TEXTURED && flag(p, STHIP_eRayCones)) {
+        float spec_spread = rd_spread + 2 * sd.mean_curvature * rd_radius;
+        if (ms.eta != 0) spec_spread = spec_spread / ms.eta;
+        rd_spread = fmaxf(0.0f, lerp1(spec_spread, 0.2f, ms.roughness));
+      }
+      cone_out = make_float2(rd_radius, rd_spread);
+      {
+        const float G_rev = prev_cos_out / len_sqr(origin - sd.position);
+        path_pdf_rev *= ms.pdf_rev * G_rev;
+        dVC = connection_dVC(dVC, ms.pdf_rev * G_rev, bsdf_pdf * G, m.is_specular());
+        prev_specular = m.is_specular();
+      }
+      bsdf_pdf = ms.pdf_fwd;
+      const float ndotout = ms.dir_out.z;
+      const f3 dir_out = normalize3(frame.to_world(ms.dir_out));
+      const float ngdotout = dot3(gn, dir_out);
+      new_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
+      beta = beta * shading_normal_correction(local_dir_in.z, ndotout, ngdotin, ngdotout, ngdotns, fix, true);
+      prev_cos_out = ngdotout;
+      if (all_le0(beta)) break;
+      new_direction = dir_out;
+      alive = true;
+    } while (0);
+    if (alive) {
+      p.ray_o[slot] = make_float4(new_origin.x, new_origin.y, new_origin.z, bsdf_pdf);
+      p.ray_d[slot] = make_float4(new_direction.x, new_direction.y, new_direction.z, eta_scale);
+      p.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(rng.counter));
+      p.bdpt[slot] = make_float4(path_pdf, path_pdf_rev, dVC, prev_cos_out);
+      if (TEXTURED) p.cone[slot] = cone_out;
+      p.meta[slot] = path_length | (diffuse_vertices << 8) | (prev_specular ? 1u << 16 : 0u);
+      const uint32_t k = (uint32_t)atomicAdd(queue_size, 1ull);
+      queue_out[k] = slot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // shade: the tail of trace() (path.hlsli:1012-1043), the first-hit block of sample_visibility
 // (bdpt.hlsl:222-296) at depth 0, then next_vertex() (path.hlsli:955-998,1048-1075) up to the point
 // where the next ray is known
@@ -603,7 +892,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_presample_lights(FrameParams p)
 // TEXTURED: the scene binds images; ray cones, image values and normal maps are evaluated
 // EXT: the scene has sphere instances or an environment: sphere hits, sphere lights, environment
 // emission and environment light sampling. Scenes without them run the instantiation that carries none of it.
-template <bool TEXTURED, bool EXT>
+// LT: eConnectToViews is on: the view path carries the BDPT quantities (path_pdf, path_pdf_rev, dVC, prev_specular) and
+// uses the weights of path.hlsli:341-351,870-880 (only instantiated with EXT).
+template <bool TEXTURED, bool EXT, bool LT = false>
 __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_t depth) {
   // Workgroup b works on segment b % 8 (its XCD's) of the incoming queue and appends to the same segment of the
   // outgoing queues, so a segment never grows. In the first bounce a segment is a contiguous eighth of the slots
@@ -649,6 +940,16 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
     rng.seed = p.seed + seed_index;
     rng.counter = __float_as_uint(bb.w);
     uint32_t path_length = meta & 0xFFu, diffuse_vertices = (meta >> 8) & 0xFFu;
+    float path_pdf = 1, path_pdf_rev = 1, dVC = 1, prev_cos_out = 1;
+    bool prev_specular = false;
+    if (LT) {
+      const float4 bd = p.bdpt[slot];
+      path_pdf = bd.x;
+      path_pdf_rev = bd.y;
+      dVC = bd.z;
+      prev_cos_out = bd.w;
+      prev_specular = (meta >> 16) & 1u;
+    }
     const uint32_t ip = __float_as_uint(hh.w);
     f3 radiance = depth == 0 ? F3s(0.0f) : xyz(p.radiance[slot]);
     const size_t pixel = (size_t)py * p.pc.gOutputExtent[0] + px;
@@ -728,9 +1029,11 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
       float G = 1 / dist2;
       const float ngdotin = -dot3(direction, gn);
       G *= fabsf(ngdotin);
-      if (depth == 0) {  // bdpt.hlsl:213-217
+      if (LT) path_pdf *= bsdf_pdf * G;  // path.hlsli:1042
+      if (depth == 0) {  // bdpt.hlsl:213-220
         bsdf_pdf = 1;
         G = 1;
+        if (LT) path_pdf = path_pdf_rev = dVC = 1;
       }
       DisneyMaterial m;
       uint32_t first_hit_normal = sd.packed_shading_normal;
@@ -770,7 +1073,18 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
         }
         float weight = 1;
         if (path_length > 2) {
-          if (use_nee) weight = (EXT && flag(p, STHIP_eNEEReservoirs)) ? 0.5f : mis2(use_mis, bsdf_pdf * G, light_pdfA);  // path.hlsli:881-886
+          if (LT) {  // path.hlsli:870-880 (no light-subpath connections)
+            if (use_mis) {
+              const float p_rev_k = cosine_hemisphere_pdfW(fabsf(cos_theta_light)) * (fabsf(prev_cos_out) / len_sqr(origin - sd.position));
+              weight = prev_specular ? 0.0f : mis2(true, path_pdf, path_pdf_rev * p_rev_k * light_pdfA);
+            } else {  // path_weight(path_length, 0)
+              uint32_t ways = 1;
+              if (use_nee) ways++;
+              if (path_length <= p.pc.gMaxPathVertices + 1) ways++;
+              weight = 1.f / (float)ways;
+            }
+          } else if (use_nee)
+            weight = (EXT && flag(p, STHIP_eNEEReservoirs)) ? 0.5f : mis2(use_mis, bsdf_pdf * G, light_pdfA);  // path.hlsli:881-886
         }
         radiance = radiance + contrib * weight;
       };
@@ -926,7 +1240,21 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
             if (all_le0(contrib)) break;
             if (reservoirs && pdfA < 1e-6f) break;  // path.hlsli:456
             float weight = 1;
-            if (sample_bsdfs) weight = reservoirs ? 1 - 0.5f : mis2(use_mis, pdfA, pdfA_fwd);  // reservoir_bsdf_mis, :175-177
+            if (LT) {  // BDPT MIS, path.hlsli:341-351
+              if (use_mis) {
+                const float emission_pdfA = cosine_hemisphere_pdfW(ngdotout) * (ngdotout / pow2f(ray_distance));  // setup(), :219
+                const float dL = connection_dVC(1 / pdfA, emission_pdfA, pdfA, false);
+                const float G_rev = prev_cos_out / len_sqr(origin - sd.position);
+                const float dE = connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular);
+                weight = 1 / (1 + dE * pow2f(emission_pdfA) + dL * pow2f(pdfA_fwd));
+              } else {  // path_weight(path_length, 1)
+                const uint32_t nv = path_length + 1;
+                uint32_t ways = 2;  // this is a connection to a light: gConnectToLights is on
+                if (nv <= p.pc.gMaxPathVertices + 1) ways++;
+                weight = nv <= 2 ? 1.0f : 1.f / (float)ways;
+              }
+            } else if (sample_bsdfs)
+              weight = reservoirs ? 1 - 0.5f : mis2(use_mis, pdfA, pdfA_fwd);  // reservoir_bsdf_mis, :175-177
             const f3 c = beta * contrib * weight;
             // a zero/negative contribution never adds light (bdpt.hlsl:313) and needs no ray
             if (all_le0(c)) break;
@@ -961,10 +1289,17 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
         if (ms.eta != 0) spec_spread = spec_spread / ms.eta;
         rd_spread = fmaxf(0.0f, lerp1(spec_spread, 0.2f, ms.roughness));
       }
+      if (LT) {  // MIS quantities, path.hlsli:919-925
+        const float G_rev = prev_cos_out / len_sqr(origin - sd.position);
+        if (path_length > 2) path_pdf_rev *= ms.pdf_rev * G_rev;
+        dVC = connection_dVC(dVC, ms.pdf_rev * G_rev, bsdf_pdf * G, m.is_specular());
+        prev_specular = m.is_specular();
+      }
       bsdf_pdf = ms.pdf_fwd;
       const float ndotout = ms.dir_out.z;
       const f3 dir_out = normalize3(frame.to_world(ms.dir_out));
       const float ngdotout = dot3(gn, dir_out);
+      if (LT) prev_cos_out = ngdotout;
       new_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
       beta = beta * shading_normal_correction(local_dir_in.z, ndotout, ngdotin, ngdotout, dot3(gn, sd.shading_normal()), EXT && flag(p, STHIP_eShadingNormalShadowFix));
       if (all_le0(beta)) break;
@@ -977,7 +1312,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
       p.ray_o[slot] = make_float4(new_origin.x, new_origin.y, new_origin.z, bsdf_pdf);
       p.ray_d[slot] = make_float4(new_direction.x, new_direction.y, new_direction.z, eta_scale);
       p.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(rng.counter));
-      p.meta[slot] = path_length | (diffuse_vertices << 8);
+      p.meta[slot] = path_length | (diffuse_vertices << 8) | ((LT && prev_specular) ? 1u << 16 : 0u);
+      if (LT) p.bdpt[slot] = make_float4(path_pdf, path_pdf_rev, dVC, prev_cos_out);
       if (TEXTURED) p.cone[slot] = make_float2(rd_radius, rd_spread);
       const uint32_t k = (uint32_t)atomicAdd(queue_size, 1ull);
       queue_out[k] = slot;
@@ -1011,6 +1347,15 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
       const uint32_t slot = s * p.paths_per_seed + q;
       const float4 r = p.radiance[slot], c = p.shadow_sum[slot];
       float4 cur = make_float4(r.x + c.x, r.y + c.y, r.z + c.z, 1.0f);
+      if (p.light_trace) {  // add_light_trace, bdpt.hlsl:328-338 with load_light_sample, path.hlsli:38-46
+        const uint4 v = *reinterpret_cast<const uint4*>(p.light_trace + 4 * ((size_t)s * p.pc.gOutputExtent[0] * p.pc.gOutputExtent[1] + (size_t)py * p.pc.gOutputExtent[0] + px));
+        const float q = (float)p.light_trace_quantization;
+        f3 lc = F3((float)((v.w & 1u) ? 0xFFFFFFFFu : v.x), (float)((v.w & 2u) ? 0xFFFFFFFFu : v.y), (float)((v.w & 4u) ? 0xFFFFFFFFu : v.z)) / q;
+        if (lc.x < 0 || lc.y < 0 || lc.z < 0 || any_nan(lc)) lc = F3s(0.0f);
+        cur.x = cur.x + lc.x;
+        cur.y = cur.y + lc.y;
+        cur.z = cur.z + lc.z;
+      }
       if (isinf(cur.x) || isinf(cur.y) || isinf(cur.z) || cur.x != cur.x || cur.y != cur.y || cur.z != cur.z) cur = make_float4(0, 0, 0, 0);
       if (acc.w > 0) {
         const float nn = acc.w + cur.w;

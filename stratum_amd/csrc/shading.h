@@ -753,12 +753,19 @@ DEV float mis2(bool use_mis, float a, float b) {
   return a2 / (a2 + b * b);
 }
 // path.hlsli:67-98 with gShadingNormalFix off, adjoint = false (view paths)
-DEV float shading_normal_correction(float ndotin, float ndotout, float ngdotin, float ngdotout, float ngdotns = 1.0f, bool terminator_fix = false) {
+DEV float shading_normal_correction(float ndotin, float ndotout, float ngdotin, float ngdotout, float ngdotns = 1.0f, bool terminator_fix = false, bool adjoint = false) {
   if (sgnf(ngdotout * ngdotin) != sgnf(ndotin * ndotout)) return 0;
   float G = 1;
-  if (terminator_fix) {  // eShadingNormalShadowFix, path.hlsli:84-86 (view paths: adjoint = false)
-    G = fminf(1.0f, fabsf(ngdotout / (ndotout * ngdotns)));
+  if (terminator_fix) {  // eShadingNormalShadowFix, path.hlsli:84-86
+    G = fminf(1.0f, fabsf(adjoint ? ngdotin / (ndotin * ngdotns) : ngdotout / (ndotout * ngdotns)));
     G = -(pow2f(G) * G) + pow2f(G) + G;
+  }
+  if (adjoint) {  // light paths: the non-symmetry of shading normals, path.hlsli:90-95
+    const float num = ngdotout * ndotin;
+    const float denom = ndotout * ngdotin;
+    if (fabsf(denom) > 1e-5f) G *= fabsf(num / denom);
   }
   return G;
 }
+// path.hlsli:29-36: dE (or dL) of a vertex from the previous vertex's
+DEV float connection_dVC(float dVC, float pdfA_rev, float prev_pdfA_fwd, bool specular) { return ((specular ? 0.0f : 1.0f) + dVC * pow2f(pdfA_rev)) / pow2f(prev_pdfA_fwd); }

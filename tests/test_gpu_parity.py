@@ -289,7 +289,7 @@ def test_errors_are_reported_not_ignored(renderer, cornell):
     from stratum_amd.bdpt import BDPT
 
     sc, cam = cornell
-    r = BDPT(device=0, args={"bdptFlag": ["connecttoviews"]})
+    r = BDPT(device=0, args={"bdptFlag": ["connecttolightpaths"]})
     try:
         r.update(sc)
         with pytest.raises(StratumHipError, match="outside the built hot path"):
@@ -589,3 +589,51 @@ def test_two_views_in_one_frame(renderer, cornell):
     assert np.all(got["radiance"][:, 160] == 0) and got["radiance"][:, :160, 3].min() == 2
     # the two eyes see the box from different positions
     assert np.abs(got["radiance"][:, :80, :3] - got["radiance"][:, 80:160, :3]).mean() > 1e-3
+
+
+@pytest.mark.parametrize("flags", [["connecttoviews"], ["connecttoviews", "~nee"], ["connecttoviews", "~mis"], ["connecttoviews", "~samplebsdfs", "~defershadowrays"], ["connecttoviews", "~remapthreads", "presamplelights"]])
+def test_light_tracing(flags):
+    """eConnectToViews: light subpaths (sample_photons, bdpt.hlsl:101-147) connect their vertices to the camera and splat
+    into gLightTraceSamples (quantised integer sums: order-independent), view paths use the BDPT weights
+    (path.hlsli:341-351,870-880), add_light_trace adds the two."""
+    sc, cam = scenes.cornell_box()
+    _compare_frame(sc, cam, flags, w=100, h=76, seeds=2)  # extents that are not multiples of the 8x4 groups
+    sc, cam = scenes.spheres_room()
+    _compare_frame(sc, cam, flags + ["uniformspheresampling"], w=96, h=64, seeds=1, args={"maxDiffuseVertices": 3})
+
+
+def test_light_tracing_textured_and_sharded(renderer):
+    from stratum_amd import shard
+
+    sc, cam = scenes.textured_box()
+    _compare_frame(sc, cam, ["connecttoviews", "~nee"], w=96, h=80, seeds=1)
+    # shards keep the splats that land on their own tiles: the sum over shards is the unsharded frame
+    sc, cam = scenes.cornell_box()
+    renderer.update(sc)
+    renderer.set_flag("connecttoviews")
+    try:
+        frame = camera.Frame(96, 64, cam["fovy"], cam["eye"], cam["target"])
+        full = renderer.render(frame, 0, 2, aovs=False)["radiance"]
+        total = np.zeros_like(full)
+        for rank in range(3):
+            renderer.set_shard(rank, 3, 16, 8)
+            part = renderer.render(frame, 0, 2, aovs=False)["radiance"]
+            assert np.all(part[shard.owner_map(96, 64, 3, 16, 8) != rank] == 0)
+            total += part
+        assert np.array_equal(total.view(np.uint32), full.view(np.uint32))
+    finally:
+        renderer.set_shard(0, 1)
+        renderer.set_flag("~connecttoviews")
+
+
+def test_light_tracing_limits(renderer):
+    from stratum_amd import _lib
+
+    sc, cam = scenes.environment_scene(image=False, emitter=True)
+    renderer.update(sc)
+    renderer.set_flag("connecttoviews")
+    try:
+        with pytest.raises(_lib.StratumHipError, match="eConnectToViews with an environment"):
+            renderer.render(camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"]))
+    finally:
+        renderer.set_flag("~connecttoviews")

@@ -655,3 +655,23 @@ def test_shading_normal_shadow_fix_only_touches_bumped_shading():
     b = o.render(fr, pc, f_on, 0, 4)["radiance"][..., :3]
     assert np.isfinite(b).all() and np.abs(a - b).mean() > 1e-3 * a.mean()
 
+
+
+def test_light_tracing_is_unbiased_against_path_tracing():
+    """eConnectToViews with BSDF sampling (NEE off): light tracing and the view paths share every transport path through
+    the MIS weights of path.hlsli:600-605,870-880, so the image converges to the path tracer's; without MIS the uniform
+    path_weight does the same with NEE on. (With MIS AND NEE on the three strategies' weights do not sum to one upstream —
+    eval_emission and connect_view only weigh against each other — and that is restated, not fixed.)"""
+    sc, cam = scenes.cornell_box()
+    o = orc.OracleScene(sc)
+    W = H = 40
+    fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+    pc = wire.default_push_constants(W, H, sc.light_count)
+    D = wire.DEFAULT_SAMPLING_FLAGS
+    ref = o.render(fr, pc, D, 0, 512, aovs=False)["radiance"][..., :3].astype(np.float64)
+    for f in ((D | wire.flag_mask("eConnectToViews")) & ~wire.flag_mask("eNEE"), (D | wire.flag_mask("eConnectToViews")) & ~wire.flag_mask("eMIS")):
+        out = o.render(fr, pc, f, 0, 512, aovs=False)
+        img = out["radiance"][..., :3].astype(np.float64)
+        assert abs(img.mean() / ref.mean() - 1) < 0.02  # 40 x 40 x 512 samples: ~1 % noise on the mean
+        assert np.sqrt(((img - ref) ** 2).sum() / (ref**2).sum()) < 0.04
+        assert out["ray_count"][0] > 1.5 * W * H * 512  # the light paths' rays are counted too
