@@ -1241,7 +1241,35 @@ struct PresampledLightPoint {  // bdpt.h:92-100
   v3 Le;
   float pdfA;  // negative for environment map samples
 };
+// PathVertex, bdpt.h:102-155: a stored light-subpath vertex (eConnectToLightPaths), 64 bytes
+struct PathVertex {
+  float position[3];
+  uint32_t packed_geometry_normal;
+  uint32_t material_address;
+  uint32_t packed_local_dir_in;
+  uint32_t packed_shading_normal;
+  uint32_t packed_tangent;
+  float uv[2];
+  uint32_t packed_beta[2];  // f16 beta rgb | subpath_length:7 | diffuse_vertices:5 | flags:4
+  float prev_dVC, G_rev, prev_pdfA_fwd, path_pdf;
+  void pack_beta(v3 b, uint32_t subpath_length, uint32_t diffuse_vertices, uint32_t flags) {
+    packed_beta[0] = det_f32tof16(b.x) | (det_f32tof16(b.y) << 16);
+    packed_beta[1] = det_f32tof16(b.z) | ((subpath_length & 0x7Fu) << 16) | ((diffuse_vertices & 0x1Fu) << 23) | ((flags & 0xFu) << 28);
+  }
+  v3 beta() const { return V3(det_f16tof32(packed_beta[0] & 0xFFFFu), det_f16tof32(packed_beta[0] >> 16), det_f16tof32(packed_beta[1] & 0xFFFFu)); }
+  uint32_t subpath_length() const { return (packed_beta[1] >> 16) & 0x7Fu; }
+  uint32_t diffuse_vertices() const { return (packed_beta[1] >> 23) & 0x1Fu; }
+  bool is_prev_delta() const { return (packed_beta[1] >> 28) & 8u; }  // PATH_VERTEX_FLAG_IS_PREV_DELTA
+  bool flip_bitangent() const { return (packed_beta[1] >> 28) & 1u; }
+};
+static_assert(sizeof(PathVertex) == 64, "PathVertex is 64 bytes");
+
 struct Frame {
+  // gLightPathVertices of the seed being traced (eConnectToLightPaths): [diffuse_vertices - 1][W * H], zero-filled
+  // before sample_photons (BDPT.cpp:569-572,655-659)
+  PathVertex* light_vertices = nullptr;
+  size_t light_vertex_count = 0;
+  bool bdpt() const { return flag(STHIP_eConnectToViews) || flag(STHIP_eConnectToLightPaths); }
   const orc_scene* sc;
   sthip_BDPTPushConstants pc;
   uint32_t sampling_flags, scene_flags;
@@ -1679,10 +1707,14 @@ struct PathIntegrator {
     if (!area_measure) light_pdfA = light_pdfA * G;  // pdfWtoA
     float weight = 1;
     if (path_length > 2) {
-      if (fr.flag(STHIP_eConnectToViews)) {  // path.hlsli:870-880 (no light-subpath connections)
+      if (fr.bdpt()) {  // path.hlsli:870-880
         if (fr.flag(STHIP_eMIS)) {
           const float p_rev_k = cosine_hemisphere_pdfW(fabsf(cos_theta_light)) * (fabsf(prev_cos_out) / len_sqr(origin - isect.sd.position));
-          weight = prev_specular ? 0.0f : mis2(fr, path_pdf, path_pdf_rev * p_rev_k * light_pdfA);
+          if (fr.flag(STHIP_eConnectToLightPaths)) {
+            const float dE_k = connection_dVC(dVC, p_rev_k, bsdf_pdf * G, prev_specular);
+            weight = 1 / (1 + dE_k * pow2(light_pdfA));
+          } else
+            weight = prev_specular ? 0.0f : mis2(fr, path_pdf, path_pdf_rev * p_rev_k * light_pdfA);
         } else {
           weight = path_weight(path_length, 0);
         }
@@ -1776,7 +1808,7 @@ struct PathIntegrator {
     const v3 contrib = Le * ev.f * cG / pdfA;
     if (all_le0(contrib)) return;
     float weight = 1;
-    if (fr.flag(STHIP_eConnectToViews)) {  // BDPT MIS, path.hlsli:341-351
+    if (fr.bdpt()) {  // BDPT MIS, path.hlsli:341-351
       if (fr.flag(STHIP_eMIS)) {
         const float emission_pdfA = cosine_hemisphere_pdfW(ngdotout) * (ngdotout / pow2(ray_distance));  // setup(), :219 (after the distance epsilon)
         const float dL = connection_dVC(1 / pdfA, emission_pdfA, pdfA, false);
@@ -1922,26 +1954,138 @@ struct PathIntegrator {
     if (!m.is_specular()) {
       diffuse_vertices++;
       if (diffuse_vertices > fr.pc.gMaxDiffuseVertices) return false;
+      if (trace_light && fr.flag(STHIP_eConnectToLightPaths) && path_length + 2 <= fr.pc.gMaxPathVertices && diffuse_vertices < fr.pc.gMaxDiffuseVertices)
+        store_light_vertex();
       if (trace_light) {
         if (fr.flag(STHIP_eConnectToViews)) connect_view(m);
       } else {
         if (path_length >= fr.pc.gMinPathVertices)
           if (!russian_roulette()) return false;
         if (fr.flag(STHIP_eNEE)) connect_light(m);
+        if (fr.flag(STHIP_eConnectToLightPaths)) connect_light_subpath(m);
       }
     }
     if (fr.flag(STHIP_eSampleBSDFs) || trace_light) return sample_direction(m);
     return false;
   }
 
-  // path_weight, path.hlsli:16-28 (no light-subpath connections)
+  // path_weight, path.hlsli:16-28
   float path_weight(uint32_t view_length, uint32_t light_length) const {
     const uint32_t n_vertices = view_length + light_length;
     if (n_vertices <= 2) return 1;
     uint32_t n = 1;
     if (fr.flag(STHIP_eNEE)) n++;
     if (fr.flag(STHIP_eConnectToViews) && n_vertices <= fr.pc.gMaxPathVertices + 1) n++;
+    if (fr.flag(STHIP_eConnectToLightPaths)) n += std::min(fr.pc.gMaxPathVertices, n_vertices - 2);
     return 1.f / (float)n;
+  }
+
+  // vertex() / store_light_vertex(), path.hlsli:491-531 (no light vertex cache: slot = light_vertex_index, :64)
+  void store_light_vertex() {
+    uint32_t flags = 0;
+    if (isect.instance_index() != STHIP_INVALID_INSTANCE) flags |= 2u;  // IS_BACKGROUND as upstream sets it
+    if (prev_specular) flags |= 8u;
+    PathVertex v;
+    if (path_length > 1) {
+      v.material_address = fr.pc.gEnvironmentMaterialAddress;
+      if (isect.instance_index() != STHIP_INVALID_INSTANCE) v.material_address = fr.sc->instances[isect.instance_index()].material_address();
+    } else
+      v.material_address = 0xFFFFFFFFu;
+    v.position[0] = isect.sd.position.x;
+    v.position[1] = isect.sd.position.y;
+    v.position[2] = isect.sd.position.z;
+    v.packed_geometry_normal = isect.sd.packed_geometry_normal;
+    v.packed_local_dir_in = pack_normal_octahedron(local_dir_in);
+    v.packed_shading_normal = isect.sd.packed_shading_normal;
+    v.packed_tangent = isect.sd.packed_tangent;
+    v.uv[0] = isect.sd.u;
+    v.uv[1] = isect.sd.v;
+    v.pack_beta(beta, path_length, diffuse_vertices, flags);
+    v.prev_dVC = dVC;
+    v.G_rev = prev_cos_out / len_sqr(origin - isect.sd.position);
+    v.prev_pdfA_fwd = bsdf_pdf * G;
+    v.path_pdf = path_pdf;
+    const size_t idx = (size_t)fr.pc.gOutputExtent[0] * fr.pc.gOutputExtent[1] * (diffuse_vertices - 1) + path_index();
+    if (idx < fr.light_vertex_count) fr.light_vertices[idx] = v;
+  }
+
+  // eval_bsdf(PathVertex, ...), path.hlsli:100-123: the BSDF of a stored light vertex towards dir_out. The material is
+  // loaded again at the stored uv with a zero footprint, and a normal map perturbs the stored (already perturbed) frame
+  // a second time, as upstream's inout arguments do.
+  bool eval_bsdf_vertex(PathVertex v, v3 dir_out, MaterialEvalRecord& ev, float& ngdotout) const {
+    DisneyMaterial lm;
+    lm.load(*fr.sc, v.material_address, v.uv[0], v.uv[1], 0.0f, v.packed_shading_normal, v.packed_tangent, fr.sampling_flags);
+    if (lm.is_specular()) return false;
+    const v3 n = unpack_normal_octahedron(v.packed_shading_normal), t = unpack_normal_octahedron(v.packed_tangent);
+    const v3 b = cross(n, t) * (v.flip_bitangent() ? -1.0f : 1.0f);
+    const v3 lv_dir_in = unpack_normal_octahedron(v.packed_local_dir_in);
+    const v3 lv_dir_out = normalize(V3(dot(dir_out, t), dot(dir_out, b), dot(dir_out, n)));
+    lm.eval(ev, lv_dir_in, lv_dir_out, true);
+    if (ev.pdf_fwd < 1e-6f) return false;
+    const v3 ng = unpack_normal_octahedron(v.packed_geometry_normal);
+    ngdotout = dot(ng, dir_out);
+    const v3 world_in = normalize(t * lv_dir_in.x + b * lv_dir_in.y + n * lv_dir_in.z);
+    ev.f = ev.f * shading_normal_correction(lv_dir_in.z, lv_dir_out.z, dot(ng, world_in), ngdotout, dot(ng, n), fr.flag(STHIP_eShadingNormalShadowFix), true);
+    return true;
+  }
+
+  // connect_light_vertex, path.hlsli:618-680 (surfaces only)
+  v3 connect_light_vertex(const DisneyMaterial& m, const PathVertex& lv, float& weight, v3& ray_origin, v3& ray_direction, float& ray_distance) const {
+    v3 contrib = lv.beta();
+    if (all_le0(contrib) || any_nan(contrib)) return V3(0.0f);
+    ray_origin = isect.sd.position;
+    ray_direction = V3(lv.position[0], lv.position[1], lv.position[2]) - isect.sd.position;
+    ray_distance = length(ray_direction);
+    const float rcp_dist = 1 / ray_distance;
+    ray_direction = ray_direction * rcp_dist;
+    const float rcp_dist2 = pow2(rcp_dist);
+    contrib = contrib * rcp_dist2;
+    float connection_G_fwd = rcp_dist2;
+    ray_distance = ray_distance * 0.999f;  // visibility_distance_epsilon
+    float cos_theta_light = 0;
+    MaterialEvalRecord lv_eval;
+    if (!eval_bsdf_vertex(lv, -ray_direction, lv_eval, cos_theta_light)) return V3(0.0f);  // f = 0 upstream
+    contrib = contrib * lv_eval.f;
+    connection_G_fwd *= fabsf(cos_theta_light);
+    const float dL = connection_dVC(lv.prev_dVC, lv_eval.pdf_rev * lv.G_rev, lv.prev_pdfA_fwd, lv.is_prev_delta());
+    float pdfA_rev = lv_eval.pdf_fwd * rcp_dist2;
+    if (all_le0(contrib) || any_nan(contrib)) return V3(0.0f);
+    const v3 local_to_light = normalize(isect.sd.to_local(ray_direction));
+    const v3 geometry_normal = isect.sd.geometry_normal();
+    const float ngdotout = dot(geometry_normal, ray_direction);
+    const float ngdotns = dot(geometry_normal, isect.sd.shading_normal());
+    ray_origin = ray_offset(ray_origin, ngdotout > 0 ? geometry_normal : -geometry_normal);
+    pdfA_rev *= fabsf(ngdotout);
+    contrib = contrib * shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, ngdotns, fr.flag(STHIP_eShadingNormalShadowFix), false);
+    MaterialEvalRecord ev;
+    m.eval(ev, local_dir_in, local_to_light, false);
+    if (ev.pdf_fwd < 1e-6f) return V3(0.0f);
+    contrib = contrib * ev.f;
+    if (all_le0(contrib)) return V3(0.0f);
+    if (fr.flag(STHIP_eMIS)) {
+      const float G_rev = prev_cos_out / len_sqr(origin - isect.sd.position);
+      const float dE = connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular);
+      weight = 1 / (1 + dE * pow2(pdfA_rev) + dL * pow2(ev.pdf_fwd * connection_G_fwd));
+    } else
+      weight = path_weight(path_length, lv.subpath_length());
+    return contrib;
+  }
+
+  // connect_light_subpath, path.hlsli:802-822: this view vertex to every stored vertex of the light subpath that shares
+  // its path index; a slot beyond the buffer reads as a zero vertex (robust buffer access)
+  void connect_light_subpath(const DisneyMaterial& m) {
+    for (uint32_t i = 1; i < fr.pc.gMaxDiffuseVertices; i++) {
+      const size_t idx = (size_t)fr.pc.gOutputExtent[0] * fr.pc.gOutputExtent[1] * (i - 1) + path_index();
+      if (idx >= fr.light_vertex_count) break;
+      const PathVertex lv = fr.light_vertices[idx];
+      if (lv.subpath_length() + path_length > fr.pc.gMaxPathVertices || lv.diffuse_vertices() + diffuse_vertices > fr.pc.gMaxDiffuseVertices || all_le0(lv.beta())) break;
+      v3 ray_origin, ray_direction;
+      float ray_distance, weight = 0;
+      const v3 contrib = beta * connect_light_vertex(m, lv, weight, ray_origin, ray_direction, ray_distance);
+      if (all_le0(contrib) || weight <= 0) continue;
+      if (occluded(ray_origin, ray_direction, ray_distance)) continue;
+      radiance = radiance + contrib * weight;
+    }
   }
 
   // connect_view, path.hlsli:533-613: the light-path vertex seen from the camera, splatted into gLightTraceSamples
@@ -1983,9 +2127,13 @@ struct PathIntegrator {
     if (all_le0(contribution)) return;
     if (occluded(ray_origin, to_view, dist)) return;  // trace_visibility_ray over the full distance (:580)
     float weight;
-    if (fr.flag(STHIP_eMIS))
-      weight = prev_specular ? 1.0f : mis2(fr, path_pdf, 1.0f * path_pdf_rev * (ev.pdf_rev * G_rev));
-    else
+    if (fr.flag(STHIP_eMIS)) {
+      if (fr.flag(STHIP_eConnectToLightPaths)) {  // dL_1, path.hlsli:591-596
+        const float dL_1 = connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular);
+        weight = 1 / (1 + dL_1 * pow2(1.0f));
+      } else
+        weight = prev_specular ? 1.0f : mis2(fr, path_pdf, 1.0f * path_pdf_rev * (ev.pdf_rev * G_rev));
+    } else
       weight = path_weight(1, path_length);
     // accumulate_light_contribution, path.hlsli:47-60: quantised integer sums (order-independent) + overflow bits
     const v3 c = contribution * weight;
@@ -2405,7 +2553,7 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
   if (scene_flags & (STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT)) return STHIP_ERR_UNSUPPORTED;
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
   const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) |
-                               (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
+                               (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
                                (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling) | (1u << STHIP_eSampleEnvironmentMapDirectly);
   if (sampling_flags & unsupported) return STHIP_ERR_UNSUPPORTED;
   Frame fr;
@@ -2456,22 +2604,31 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
   std::vector<uint64_t> tstats((size_t)threads * 4, 0);
   // light tracing (eConnectToViews, BDPT.cpp:653-667,740-748): per seed, sample_photons fills gLightTraceSamples before
   // the view paths run, add_light_trace adds it to gRadiance afterwards
-  if (!has_emissives(fr) && !has_environment(fr)) fr.sampling_flags &= ~(1u << STHIP_eConnectToViews);  // BDPT.cpp:504-509
-  const bool light_tracing = fr.flag(STHIP_eConnectToViews) && fr.pc.gMaxPathVertices > 2;
+  if (!has_emissives(fr) && !has_environment(fr)) fr.sampling_flags &= ~((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths));  // BDPT.cpp:504-509
+  const bool light_tracing = fr.bdpt() && fr.pc.gMaxPathVertices > 2;
   std::vector<std::vector<std::atomic<uint32_t>>> light_images;
-  if (fr.flag(STHIP_eConnectToViews)) {
+  std::vector<std::vector<PathVertex>> light_vertices;
+  if (fr.bdpt()) {
     if (has_environment(fr) || fr.flag(STHIP_eNEEReservoirs)) return STHIP_ERR_UNSUPPORTED;  // env light paths start from an unset position upstream
     if (!frame->gInverseViewTransforms) return STHIP_ERR_INVALID_ARGUMENT;
     if ((uint64_t)seed_count * W * H > (1ull << 26)) return STHIP_ERR_INVALID_ARGUMENT;
+    // without eRemapThreads the padding columns of sample_photons alias the next row's vertex slots (a write race upstream)
+    if (fr.flag(STHIP_eConnectToLightPaths) && !fr.flag(STHIP_eRemapThreads) && W % 8 != 0) return STHIP_ERR_UNSUPPORTED;
   }
-  if (light_tracing) {
+  if (fr.bdpt()) {
     light_images = std::vector<std::vector<std::atomic<uint32_t>>>(seed_count);
+    if (fr.flag(STHIP_eConnectToLightPaths)) light_vertices.resize(seed_count);
     for (uint32_t s = 0; s < seed_count; s++) {
       light_images[s] = std::vector<std::atomic<uint32_t>>((size_t)W * H * 4);
       for (auto& a : light_images[s]) a.store(0, std::memory_order_relaxed);
       Frame lf = fr;
       lf.light_trace = light_images[s].data();
-      trace_light_paths(lf, seed_begin + s, threads, tstats.data());
+      if (fr.flag(STHIP_eConnectToLightPaths)) {  // BDPT.cpp:569-572
+        light_vertices[s].assign((size_t)fr.pc.gLightPathCount * fr.pc.gMaxDiffuseVertices, PathVertex{});
+        lf.light_vertices = light_vertices[s].data();
+        lf.light_vertex_count = light_vertices[s].size();
+      }
+      if (light_tracing) trace_light_paths(lf, seed_begin + s, threads, tstats.data());
     }
   }
   parallel_rows(H, threads, [&](uint32_t y, int tid) {
@@ -2485,7 +2642,11 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
         PixelAOV aov;
         const bool want_aov = (s == 0) && (out->gAlbedo || out->gVisibility || out->gDepth || out->gPrevUVs);
         Frame sf = fr;
-        if (light_tracing) sf.light_trace = light_images[s].data();
+        if (fr.flag(STHIP_eConnectToViews)) sf.light_trace = light_images[s].data();
+        if (fr.flag(STHIP_eConnectToLightPaths)) {
+          sf.light_vertices = light_vertices[s].data();
+          sf.light_vertex_count = light_vertices[s].size();
+        }
         if (!render_pixel(sf, x, y, seed_begin + s, rgb, want_aov ? &aov : nullptr, &tstats[(size_t)tid * 4])) break;
         inside = true;
         float cur[4] = {rgb[0], rgb[1], rgb[2], 1};

@@ -76,7 +76,7 @@ struct sthip_ctx {
   uint64_t bvh_nodes = 0, bvh_tris = 0;
   // frame
   DevBuf<uint8_t> views;  // gViews | gViewTransforms | gPrevViews | gPrevInverseViewTransforms
-  DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays;
+  DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays, light_vertices, conn;
   DevBuf<uint32_t> meta, queue0, queue1;
   DevBuf<unsigned long long> counters;
   DevBuf<float> distributions;  // gDistributions
@@ -201,6 +201,8 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->shadow_sum.release();
   ctx->accum.release();
   ctx->shadow_rays.release();
+  ctx->light_vertices.release();
+  ctx->conn.release();
   ctx->meta.release();
   ctx->queue0.release();
   ctx->queue1.release();
@@ -555,7 +557,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (scene_flags & (STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT))
     return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media / light-tracing scene flags are not part of the built hot path");
   const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) |
-                               (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
+                               (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
                                (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling) | (1u << STHIP_eSampleEnvironmentMapDirectly);
   if (sampling_flags & unsupported) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: a sampling flag outside the built hot path is set");
   if (pc->gMaxPathVertices > 60 || pc->gMaxDiffuseVertices > 60) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: path length limits above 60");
@@ -569,7 +571,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   const bool has_env = (scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) != 0, has_emissives = (scene_flags & STHIP_BDPT_FLAG_HAS_EMISSIVES) != 0;
   if (!has_env) pcn.gEnvironmentSampleProbability = 0;
   if (!has_emissives) pcn.gEnvironmentSampleProbability = 1;
-  if (!has_emissives && !has_env) sampling_flags &= ~((1u << STHIP_eNEE) | (1u << STHIP_eConnectToViews));
+  if (!has_emissives && !has_env) sampling_flags &= ~((1u << STHIP_eNEE) | (1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths));
   if (!(sampling_flags & (1u << STHIP_eNEE))) sampling_flags &= ~((1u << STHIP_eDeferShadowRays) | (1u << STHIP_ePresampleLights) | (1u << STHIP_eNEEReservoirs));
   pc = &pcn;
   if (has_env) {  // the Environment record (environment.h:17-22): ImageValue3, then 4 offsets into gDistributions when an image is bound
@@ -611,20 +613,32 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.path_count = batch * p.paths_per_seed;
   // light tracing (eConnectToViews, BDPT.cpp:653-667): sample_photons' padded dispatch, dispatch_over(W, ceil(gLightPathCount / W))
   const bool connect_views = (sampling_flags & (1u << STHIP_eConnectToViews)) != 0;
-  const bool light_tracing = connect_views && pc->gMaxPathVertices > 2;
-  if (connect_views) {
-    if (has_env) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eConnectToViews with an environment (upstream starts environment light paths from an unset position, bdpt.hlsl:109-113)");
-    if (sampling_flags & (1u << STHIP_eNEEReservoirs)) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eConnectToViews together with eNEEReservoirs is not built");
-    if (!frame->gInverseViewTransforms) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eConnectToViews needs gInverseViewTransforms");
+  const bool connect_paths = (sampling_flags & (1u << STHIP_eConnectToLightPaths)) != 0;  // light-subpath connections, no light vertex cache
+  const bool bdpt = connect_views || connect_paths;
+  const bool light_tracing = bdpt && pc->gMaxPathVertices > 2;
+  if (bdpt) {
+    if (has_env) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: light subpaths with an environment (upstream starts environment light paths from an unset position, bdpt.hlsl:109-113)");
+    if (sampling_flags & (1u << STHIP_eNEEReservoirs)) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: light subpaths together with eNEEReservoirs are not built");
+    if (!frame->gInverseViewTransforms) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eConnectToViews / eConnectToLightPaths need gInverseViewTransforms");
+    if (connect_paths && !(sampling_flags & (1u << STHIP_eRemapThreads)) && (W & 7u))
+      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eConnectToLightPaths without eRemapThreads needs a width that is a multiple of 8 (upstream's padding threads race on the vertex slots of the next row)");
+    if (connect_paths && pc->gMaxDiffuseVertices < 1) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eConnectToLightPaths needs gMaxDiffuseVertices >= 1");
   }
   const uint32_t light_rows = (pc->gLightPathCount + W - 1) / W;
   const uint32_t light_threads = light_tracing ? ((W + 7) / 8) * 8 * ((light_rows + 3) / 4) * 4 : 0;
   if ((uint64_t)light_threads * batch > 0x7FFFFFFFull || (light_tracing && (uint64_t)batch * W * H > 0x7FFFFFFFull)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many light paths in flight");
   const size_t P = std::max<size_t>(std::max<size_t>(1, p.path_count), (size_t)light_threads * batch);
   const size_t P0 = std::max<size_t>(1, p.paths_per_seed);
-  if (connect_views) {
+  const size_t vertices_per_seed = connect_paths ? (size_t)pc->gLightPathCount * pc->gMaxDiffuseVertices : 0;
+  const size_t conn_per_path = connect_paths ? pc->gMaxDiffuseVertices - 1 : 0;
+  if (bdpt) {
     HIP_TRY(ctx, ctx->bdpt.ensure(P));
-    if (light_tracing) HIP_TRY(ctx, ctx->light_trace.ensure((size_t)batch * W * H * 4));
+    if (light_tracing && connect_views) HIP_TRY(ctx, ctx->light_trace.ensure((size_t)batch * W * H * 4));
+    if (connect_paths) {
+      if ((uint64_t)P * std::max<size_t>(1, conn_per_path) >= 0x40000000ull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many connection entries in flight");
+      HIP_TRY(ctx, ctx->light_vertices.ensure(4 * std::max<size_t>(1, vertices_per_seed * batch)));
+      HIP_TRY(ctx, ctx->conn.ensure(std::max<size_t>(1, (size_t)p.path_count * conn_per_path)));
+    }
   }
 
   HIP_TRY(ctx, ctx->ray_o.ensure(P));
@@ -640,7 +654,10 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   const uint32_t shade_grid = std::max<uint32_t>(grid_for(ctx, P), QUEUE_SEGMENTS);
   const size_t seg_stride = (((P + QUEUE_SEGMENTS - 1) / QUEUE_SEGMENTS) + 63) & ~(size_t)63;
   if (seg_stride * QUEUE_SEGMENTS > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many paths in flight");
-  HIP_TRY(ctx, ctx->shadow_rays.ensure(3 * seg_stride * QUEUE_SEGMENTS));
+  // a vertex queues at most one NEE ray, plus one visibility ray per stored light vertex it connects to
+  const size_t shadow_stride = seg_stride * (1 + conn_per_path);
+  if (shadow_stride * QUEUE_SEGMENTS > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many shadow rays in flight");
+  HIP_TRY(ctx, ctx->shadow_rays.ensure(3 * shadow_stride * QUEUE_SEGMENTS));
   HIP_TRY(ctx, ctx->meta.ensure(P));
   HIP_TRY(ctx, ctx->queue0.ensure(seg_stride * QUEUE_SEGMENTS));
   HIP_TRY(ctx, ctx->queue1.ensure(seg_stride * QUEUE_SEGMENTS));
@@ -681,8 +698,10 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.prev_views = reinterpret_cast<const sthip_ViewData*>(ctx->views.p + 2 * vbytes);
   p.prev_inv_view_xf = reinterpret_cast<const sthip_TransformData*>(ctx->views.p + 3 * vbytes);
   p.inv_view_xf = reinterpret_cast<const sthip_TransformData*>(ctx->views.p + 4 * vbytes);
-  p.bdpt = connect_views ? ctx->bdpt.p : nullptr;
-  p.light_trace = light_tracing ? ctx->light_trace.p : nullptr;
+  p.bdpt = bdpt ? ctx->bdpt.p : nullptr;
+  p.light_trace = light_tracing && connect_views ? ctx->light_trace.p : nullptr;
+  p.light_vertices = connect_paths ? ctx->light_vertices.p : nullptr;
+  p.conn = connect_paths && conn_per_path ? ctx->conn.p : nullptr;
   p.light_threads = light_threads;
   p.light_trace_quantization = 65536;  // BDPT.hpp:55 mLightTraceQuantization
 
@@ -720,6 +739,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.counters = ctx->counters.p;
   p.qctl = ctx->qctl.p;
   p.seg_stride = (uint32_t)seg_stride;
+  p.shadow_stride = (uint32_t)shadow_stride;
   p.count_traversal = ctx->count_traversal ? 1u : 0u;
   p.refill_idle = ctx->refill_idle;
   p.inner_min_lanes = ctx->inner_min_lanes;
@@ -814,7 +834,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
 
   HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_TOTAL * sizeof(unsigned long long), st));
   const bool nee = (sampling_flags & (1u << STHIP_eNEE)) != 0;
-  const bool ext = ctx->has_spheres || has_env || connect_views || (sampling_flags & ((1u << STHIP_eNEEReservoirs) | (1u << STHIP_eShadingNormalShadowFix)));
+  const bool ext = ctx->has_spheres || has_env || bdpt || (sampling_flags & ((1u << STHIP_eNEEReservoirs) | (1u << STHIP_eShadingNormalShadowFix)));
   for (uint32_t s = 0; s < seed_count; s += batch) {
     const uint32_t in_flight = std::min(batch, seed_count - s);
     p.seed = seed_begin + s;
@@ -885,8 +905,12 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       return STHIP_OK;
     };
 
+    if (connect_paths) {  // BDPT.cpp:655-659; `conn` holds no pending entries when a pass starts
+      HIP_TRY(ctx, hipMemsetAsync(ctx->light_vertices.p, 0, std::max<size_t>(1, vertices_per_seed * in_flight) * 64, st));
+      if (p.conn) HIP_TRY(ctx, hipMemsetAsync(ctx->conn.p, 0, (size_t)in_flight * p.paths_per_seed * conn_per_path * 16, st));
+    }
     if (light_tracing) {  // sample_photons before the view paths, BDPT.cpp:653-667
-      HIP_TRY(ctx, hipMemsetAsync(ctx->light_trace.p, 0, (size_t)in_flight * W * H * 16, st));
+      if (connect_views) HIP_TRY(ctx, hipMemsetAsync(ctx->light_trace.p, 0, (size_t)in_flight * W * H * 16, st));
       p.light_pass = 1;
       p.path_count = in_flight * light_threads;
       rc = reset_queues();
@@ -931,8 +955,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       });
       if (rc) return rc;
     }
-    rc = run_rounds(false, nee, [&](uint32_t depth) {
-      if (connect_views) {
+    rc = run_rounds(false, nee || connect_paths, [&](uint32_t depth) {
+      if (bdpt) {
         if (ctx->textured)
           hipLaunchKernelGGL((k_shade<true, true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
         else

@@ -65,11 +65,15 @@ struct FrameParams {
   uint32_t light_pass;        // this pass traces light subpaths (sample_photons)
   uint32_t light_threads;     // threads of sample_photons' padded dispatch per seed
   uint32_t light_trace_quantization;
+  // light-subpath connections (eConnectToLightPaths)
+  float4* light_vertices;     // gLightPathVertices: per seed in flight gLightPathCount * gMaxDiffuseVertices PathVertex records of 4 x float4 (bdpt.h:108-121)
+  float4* conn;               // per view path gMaxDiffuseVertices - 1 pending connection contributions of the last vertex shaded
+  uint32_t shadow_stride;     // entries between the segments of shadow_rays (a vertex may queue gMaxDiffuseVertices records)
   float4* presampled;   // gPresampledLights (ePresampleLights): per seed in flight, 2 x float4 per point: (position, bits(packed normal)) (Le, pdfA)
   float4* shadow_rays;  // 3 x float4 per entry: (origin, distance) (direction, bits(slot)) (contribution, 0)
   unsigned long long* counters;  // CNT_* (64-bit each)
   unsigned long long* qctl;      // queue control lines, queue_ctl(): [path | shadow][depth < 64][QUEUE_SEGMENTS] x 128 B
-  uint32_t seg_stride;           // entries between the segments of queue[] / shadow_rays
+  uint32_t seg_stride;           // entries between the segments of queue[]
   uint32_t rounds;               // bounce rounds of this render (<= 63)
   // outputs (device pointers; may be null)
   float4* out_radiance;
@@ -260,7 +264,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
         }
       }
       if (work_c.exhausted && !work_s.exhausted) {
-        const uint32_t idx = work_s.take(!busy, ctl_s, p.seg_stride, 0);
+        const uint32_t idx = work_s.take(!busy, ctl_s, p.shadow_stride, 0);
         if (idx != 0xFFFFFFFFu) {
           const float4 s0 = p.shadow_rays[3 * (size_t)idx], s1 = p.shadow_rays[3 * (size_t)idx + 1], s2 = p.shadow_rays[3 * (size_t)idx + 2];
           slot = __float_as_uint(s1.w);
@@ -310,6 +314,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
             }
           }
           if (overflow) atomicOr(&lt[3], overflow);
+        } else if (slot & 0x40000000u) {  // a light-subpath connection: its own entry, folded into gRadiance in order later
+          p.conn[slot & 0x3FFFFFFFu] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
         } else {  // NEE: each pixel has at most one shadow ray per bounce
           float4 c = target[slot];
           c.x = c.x + contribution.x;
@@ -689,6 +695,17 @@ __global__ void k_count_rays(FrameParams p) {
   p.counters[CNT_RAYS_SHADOW] += shadow;
 }
 
+// path_weight, path.hlsli:16-28: one over the number of ways upstream counts for a path of this many vertices
+DEV float path_weight(const FrameParams& p, uint32_t view_length, uint32_t light_length) {
+  const uint32_t nv = view_length + light_length;
+  if (nv <= 2) return 1;
+  uint32_t ways = 1;
+  if (flag(p, STHIP_eNEE)) ways++;
+  if (flag(p, STHIP_eConnectToViews) && nv <= p.pc.gMaxPathVertices + 1) ways++;
+  if (flag(p, STHIP_eConnectToLightPaths)) ways += min(p.pc.gMaxPathVertices, nv - 2);
+  return 1.f / (float)ways;
+}
+
 template <bool TEXTURED, bool EXT>
 __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, uint32_t depth) {
   const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
@@ -705,10 +722,11 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
   const uint32_t step = ((gridDim.x - seg + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) * blockDim.x;
   const uint32_t* queue_in = p.queue[depth & 1u] + seg_base;
   uint32_t* queue_out = p.queue[(depth + 1) & 1u] + seg_base;
-  float4* shadow_out = p.shadow_rays + 3 * (size_t)seg_base;
+  float4* shadow_out = p.shadow_rays + 3 * (size_t)seg * p.shadow_stride;
   unsigned long long* queue_size = &queue_ctl(p.qctl, 0, depth + 1, seg)[QCTL_SIZE];
   unsigned long long* shadow_size = &queue_ctl(p.qctl, 1, depth, seg)[QCTL_SIZE];
   const uint32_t W = p.pc.gOutputExtent[0], H = p.pc.gOutputExtent[1];
+  const bool connect_views = flag(p, STHIP_eConnectToViews), connect_paths = flag(p, STHIP_eConnectToLightPaths);
   for (uint32_t i = first; i < n; i += step) {
     const uint32_t slot = depth == 0 ? slot0 + i : queue_in[i];
     const uint32_t meta = p.meta[slot];
@@ -775,7 +793,23 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
       if (!m.is_specular()) {
         diffuse_vertices++;
         if (diffuse_vertices > p.pc.gMaxDiffuseVertices) break;
-        do {  // connect_view, path.hlsli:533-613
+        if (connect_paths && path_length + 2 <= p.pc.gMaxPathVertices && diffuse_vertices < p.pc.gMaxDiffuseVertices) {
+          // vertex() / store_light_vertex(), path.hlsli:491-531: slot light_vertex_index(path_index, diffuse_vertices) (:64)
+          const size_t per_seed = (size_t)p.pc.gLightPathCount * p.pc.gMaxDiffuseVertices;
+          const size_t idx = (size_t)W * H * (diffuse_vertices - 1) + path_index;
+          if (idx < per_seed) {
+            float4* lv = p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
+            const uint32_t vflags = 2u | (prev_specular ? 8u : 0u);  // IS_BACKGROUND as upstream sets it, IS_PREV_DELTA
+            const uint32_t pb0 = det_f32tof16(beta.x) | (det_f32tof16(beta.y) << 16);
+            const uint32_t pb1 = det_f32tof16(beta.z) | ((path_length & 0x7Fu) << 16) | ((diffuse_vertices & 0x1Fu) << 23) | (vflags << 28);
+            lv[0] = make_float4(sd.position.x, sd.position.y, sd.position.z, __uint_as_float(sd.packed_geometry_normal));
+            lv[1] = make_float4(__uint_as_float(in.material_address()), __uint_as_float(pack_normal_octahedron(local_dir_in)), __uint_as_float(sd.packed_shading_normal),
+                                __uint_as_float(sd.packed_tangent));
+            lv[2] = make_float4(sd.u, sd.v, __uint_as_float(pb0), __uint_as_float(pb1));
+            lv[3] = make_float4(dVC, prev_cos_out / len_sqr(origin - sd.position), bsdf_pdf * G, path_pdf);
+          }
+        }
+        if (connect_views) do {  // connect_view, path.hlsli:533-613
           uint32_t view_index = 0;
           if (p.pc.gViewCount > 1) view_index = (uint32_t)fminf(rng.next_float() * (float)p.pc.gViewCount, (float)(p.pc.gViewCount - 1));
           const sthip_ViewData& view = p.views[view_index];
@@ -809,13 +843,12 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
           if (all_le0(contribution)) break;
           float weight;
           if (flag(p, STHIP_eMIS)) {
-            weight = prev_specular ? 1.0f : mis2(true, path_pdf, 1.0f * path_pdf_rev * (ev.pdf_rev * G_rev));
-          } else {  // path_weight(1, path_length), path.hlsli:16-28
-            const uint32_t nv = 1 + path_length;
-            uint32_t ways = 1;
-            if (flag(p, STHIP_eNEE)) ways++;
-            if (nv <= p.pc.gMaxPathVertices + 1) ways++;
-            weight = nv <= 2 ? 1.0f : 1.f / (float)ways;
+            if (connect_paths)  // dL_1, path.hlsli:591-596
+              weight = 1 / (1 + connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular) * pow2f(1.0f));
+            else
+              weight = prev_specular ? 1.0f : mis2(true, path_pdf, 1.0f * path_pdf_rev * (ev.pdf_rev * G_rev));
+          } else {
+            weight = path_weight(p, 1, path_length);
           }
           const f3 c = contribution * weight;
           // the splat lands on pixel (ix, iy) of this seed's image; a sharded renderer keeps only its own pixels
@@ -914,7 +947,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
   const uint32_t step = ((gridDim.x - seg + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) * blockDim.x;
   const uint32_t* queue_in = p.queue[depth & 1u] + seg_base;
   uint32_t* queue_out = p.queue[(depth + 1) & 1u] + seg_base;
-  float4* shadow_out = p.shadow_rays + 3 * (size_t)seg_base;
+  float4* shadow_out = p.shadow_rays + 3 * (size_t)seg * p.shadow_stride;
   unsigned long long* queue_size = &queue_ctl(p.qctl, 0, depth + 1, seg)[QCTL_SIZE];
   unsigned long long* shadow_size = &queue_ctl(p.qctl, 1, depth, seg)[QCTL_SIZE];
   const bool use_nee = flag(p, STHIP_eNEE);
@@ -952,6 +985,19 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
     }
     const uint32_t ip = __float_as_uint(hh.w);
     f3 radiance = depth == 0 ? F3s(0.0f) : xyz(p.radiance[slot]);
+    const bool connect_paths = LT && flag(p, STHIP_eConnectToLightPaths);
+    if (connect_paths && depth > 0) {
+      // connect_light_subpath's accumulate_contribution calls of the previous vertex (path.hlsli:802-822), whose
+      // visibility rays k_trace has resolved by now: added here, in i order, before anything this vertex adds
+      float4* cn = p.conn + (size_t)slot * (p.pc.gMaxDiffuseVertices - 1);
+      for (uint32_t k = 0; k + 1 < p.pc.gMaxDiffuseVertices; k++) {
+        const float4 c = cn[k];
+        if (c.x != 0 || c.y != 0 || c.z != 0) {
+          radiance = radiance + xyz(c);
+          cn[k] = make_float4(0, 0, 0, 0);
+        }
+      }
+    }
     const size_t pixel = (size_t)py * p.pc.gOutputExtent[0] + px;
     bool alive = false;
     float rd_radius = 0, rd_spread = 0;  // RayDifferential of this path (TEXTURED only)
@@ -1073,15 +1119,15 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
         }
         float weight = 1;
         if (path_length > 2) {
-          if (LT) {  // path.hlsli:870-880 (no light-subpath connections)
+          if (LT) {  // path.hlsli:870-880
             if (use_mis) {
               const float p_rev_k = cosine_hemisphere_pdfW(fabsf(cos_theta_light)) * (fabsf(prev_cos_out) / len_sqr(origin - sd.position));
-              weight = prev_specular ? 0.0f : mis2(true, path_pdf, path_pdf_rev * p_rev_k * light_pdfA);
-            } else {  // path_weight(path_length, 0)
-              uint32_t ways = 1;
-              if (use_nee) ways++;
-              if (path_length <= p.pc.gMaxPathVertices + 1) ways++;
-              weight = 1.f / (float)ways;
+              if (connect_paths)
+                weight = 1 / (1 + connection_dVC(dVC, p_rev_k, bsdf_pdf * G, prev_specular) * pow2f(light_pdfA));
+              else
+                weight = prev_specular ? 0.0f : mis2(true, path_pdf, path_pdf_rev * p_rev_k * light_pdfA);
+            } else {
+              weight = path_weight(p, path_length, 0);
             }
           } else if (use_nee)
             weight = (EXT && flag(p, STHIP_eNEEReservoirs)) ? 0.5f : mis2(use_mis, bsdf_pdf * G, light_pdfA);  // path.hlsli:881-886
@@ -1247,11 +1293,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
                 const float G_rev = prev_cos_out / len_sqr(origin - sd.position);
                 const float dE = connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular);
                 weight = 1 / (1 + dE * pow2f(emission_pdfA) + dL * pow2f(pdfA_fwd));
-              } else {  // path_weight(path_length, 1)
-                const uint32_t nv = path_length + 1;
-                uint32_t ways = 2;  // this is a connection to a light: gConnectToLights is on
-                if (nv <= p.pc.gMaxPathVertices + 1) ways++;
-                weight = nv <= 2 ? 1.0f : 1.f / (float)ways;
+              } else {
+                weight = path_weight(p, path_length, 1);
               }
             } else if (sample_bsdfs)
               weight = reservoirs ? 1 - 0.5f : mis2(use_mis, pdfA, pdfA_fwd);  // reservoir_bsdf_mis, :175-177
@@ -1275,6 +1318,96 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
             shadow_out[3 * (size_t)k + 1] = make_float4(to_light.x, to_light.y, to_light.z, __uint_as_float(slot));
             shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
           } while (0);
+        }
+        if (connect_paths) {
+          // connect_light_subpath, path.hlsli:802-822: this vertex to the stored vertices of the light subpath with the
+          // same path index. Each connection that survives queues a visibility ray whose contribution lands in this
+          // path's entry i - 1 of `conn`; a slot beyond the buffer reads as a zero vertex (robust buffer access).
+          uint32_t path_index;  // map_pixel_coord, bdpt_util.hlsli:76-83
+          if (flag(p, STHIP_eRemapThreads))
+            path_index = ((py >> 2) * ((p.pc.gOutputExtent[0] + 7u) >> 3) + (px >> 3)) * 32u + (py & 3u) * 8u + (px & 7u);
+          else
+            path_index = py * p.pc.gOutputExtent[0] + px;
+          const size_t per_seed = (size_t)p.pc.gLightPathCount * p.pc.gMaxDiffuseVertices;
+          const size_t level = (size_t)p.pc.gOutputExtent[0] * p.pc.gOutputExtent[1];
+          for (uint32_t li = 1; li < p.pc.gMaxDiffuseVertices; li++) {
+            const size_t idx = level * (li - 1) + path_index;
+            if (idx >= per_seed) break;
+            const float4* lvp = p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
+            const float4 v2 = lvp[2];
+            const uint32_t pb0 = __float_as_uint(v2.z), pb1 = __float_as_uint(v2.w);
+            const f3 lv_beta = F3(det_f16tof32(pb0 & 0xFFFFu), det_f16tof32(pb0 >> 16), det_f16tof32(pb1 & 0xFFFFu));
+            const uint32_t lv_length = (pb1 >> 16) & 0x7Fu, lv_diffuse = (pb1 >> 23) & 0x1Fu;
+            if (lv_length + path_length > p.pc.gMaxPathVertices || lv_diffuse + diffuse_vertices > p.pc.gMaxDiffuseVertices || all_le0(lv_beta)) break;
+            const float4 v0 = lvp[0], v1 = lvp[1], v3 = lvp[3];
+            // connect_light_vertex, path.hlsli:618-680
+            f3 contrib = lv_beta;
+            if (any_nan(contrib)) continue;
+            f3 ray_direction = xyz(v0) - sd.position;
+            float ray_distance = length3(ray_direction);
+            const float rcp_dist = 1 / ray_distance;
+            ray_direction = ray_direction * rcp_dist;
+            const float rcp_dist2 = pow2f(rcp_dist);
+            contrib = contrib * rcp_dist2;
+            float connection_G_fwd = rcp_dist2;
+            ray_distance = ray_distance * 0.999f;  // visibility_distance_epsilon
+            // eval_bsdf(PathVertex, -ray_direction, adjoint), path.hlsli:100-123: the material is loaded again at the stored
+            // uv with a zero footprint; a normal map perturbs the stored (already perturbed) frame once more, as upstream
+            uint32_t lv_ns = __float_as_uint(v1.z), lv_tg = __float_as_uint(v1.w);
+            DisneyMaterial lm;
+            if (TEXTURED)
+              lm.load_textured(p.scene, __float_as_uint(v1.x), v2.x, v2.y, 0.0f, lv_ns, lv_tg, p.sampling_flags);
+            else
+              lm.load(p.scene, __float_as_uint(v1.x));
+            if (lm.is_specular()) continue;
+            Frame3 lf;
+            lf.n = unpack_normal_octahedron(lv_ns);
+            lf.t = unpack_normal_octahedron(lv_tg);
+            lf.b = cross3(lf.n, lf.t) * (((pb1 >> 28) & 1u) ? -1.0f : 1.0f);
+            const f3 lv_dir_in = unpack_normal_octahedron(__float_as_uint(v1.y));
+            const f3 lv_dir_out = normalize3(lf.to_local(-ray_direction));
+            MaterialEvalRecord lev;
+            lm.eval(lev, lv_dir_in, lv_dir_out, true);
+            if (lev.pdf_fwd < 1e-6f) continue;
+            const f3 lv_ng = unpack_normal_octahedron(__float_as_uint(v0.w));
+            const float cos_theta_light = dot3(lv_ng, -ray_direction);
+            lev.f = lev.f * shading_normal_correction(lv_dir_in.z, lv_dir_out.z, dot3(lv_ng, normalize3(lf.to_world(lv_dir_in))), cos_theta_light, dot3(lv_ng, lf.n),
+                                                      flag(p, STHIP_eShadingNormalShadowFix), true);
+            contrib = contrib * lev.f;
+            connection_G_fwd *= fabsf(cos_theta_light);
+            const float dL = connection_dVC(v3.x, lev.pdf_rev * v3.y, v3.z, ((pb1 >> 28) & 8u) != 0);
+            float pdfA_rev = lev.pdf_fwd * rcp_dist2;
+            if (all_le0(contrib) || any_nan(contrib)) continue;
+            const f3 local_to_light = normalize3(frame.to_local(ray_direction));
+            const float ngdotout = dot3(gn, ray_direction);
+            const f3 ray_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
+            pdfA_rev *= fabsf(ngdotout);
+            contrib = contrib * shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, dot3(gn, sd.shading_normal()), flag(p, STHIP_eShadingNormalShadowFix), false);
+            MaterialEvalRecord ev;
+            m.eval(ev, local_dir_in, local_to_light, false);
+            if (ev.pdf_fwd < 1e-6f) continue;
+            contrib = contrib * ev.f;
+            if (all_le0(contrib)) continue;
+            float weight;
+            if (use_mis) {
+              const float G_rev = prev_cos_out / len_sqr(origin - sd.position);
+              const float dE = connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular);
+              weight = 1 / (1 + dE * pow2f(pdfA_rev) + dL * pow2f(ev.pdf_fwd * connection_G_fwd));
+            } else
+              weight = path_weight(p, path_length, lv_length);
+            contrib = beta * contrib;
+            if (all_le0(contrib) || weight <= 0) continue;
+            const f3 c = contrib * weight;
+            const uint32_t entry = slot * (p.pc.gMaxDiffuseVertices - 1) + (li - 1);
+            if (!(ray_distance > 1e-6f)) {  // trace_visibility_ray's loop never runs: visible, no ray
+              p.conn[entry] = make_float4(c.x, c.y, c.z, 0.0f);
+              continue;
+            }
+            const uint32_t k = (uint32_t)atomicAdd(shadow_size, 1ull);
+            shadow_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
+            shadow_out[3 * (size_t)k + 1] = make_float4(ray_direction.x, ray_direction.y, ray_direction.z, __uint_as_float(0x40000000u | entry));
+            shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+          }
         }
       }
       if (!sample_bsdfs) break;
@@ -1345,7 +1478,19 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
     // the seeds in flight are folded in seed order, so the result does not depend on how many were in flight
     for (uint32_t s = 0; s < p.seeds_in_flight; s++) {
       const uint32_t slot = s * p.paths_per_seed + q;
-      const float4 r = p.radiance[slot], c = p.shadow_sum[slot];
+      float4 r = p.radiance[slot];
+      const float4 c = p.shadow_sum[slot];
+      if (p.conn) {  // the light-subpath connections of the path's last vertex (see k_shade)
+        const float4* cn = p.conn + (size_t)slot * (p.pc.gMaxDiffuseVertices - 1);
+        for (uint32_t k = 0; k + 1 < p.pc.gMaxDiffuseVertices; k++) {
+          const float4 e = cn[k];
+          if (e.x != 0 || e.y != 0 || e.z != 0) {
+            r.x = r.x + e.x;
+            r.y = r.y + e.y;
+            r.z = r.z + e.z;
+          }
+        }
+      }
       float4 cur = make_float4(r.x + c.x, r.y + c.y, r.z + c.z, 1.0f);
       if (p.light_trace) {  // add_light_trace, bdpt.hlsl:328-338 with load_light_sample, path.hlsli:38-46
         const uint4 v = *reinterpret_cast<const uint4*>(p.light_trace + 4 * ((size_t)s * p.pc.gOutputExtent[0] * p.pc.gOutputExtent[1] + (size_t)py * p.pc.gOutputExtent[0] + px));

@@ -289,7 +289,7 @@ def test_errors_are_reported_not_ignored(renderer, cornell):
     from stratum_amd.bdpt import BDPT
 
     sc, cam = cornell
-    r = BDPT(device=0, args={"bdptFlag": ["connecttolightpaths"]})
+    r = BDPT(device=0, args={"bdptFlag": ["lightvertexcache"]})
     try:
         r.update(sc)
         with pytest.raises(StratumHipError, match="outside the built hot path"):
@@ -626,6 +626,56 @@ def test_light_tracing_textured_and_sharded(renderer):
         renderer.set_flag("~connecttoviews")
 
 
+@pytest.mark.parametrize(
+    "flags",
+    [
+        ["connecttolightpaths"],
+        ["connecttolightpaths", "connecttoviews"],
+        ["connecttolightpaths", "~mis"],
+        ["connecttolightpaths", "~nee"],
+        ["connecttolightpaths", "connecttoviews", "~defershadowrays", "shadingnormalshadowfix"],
+    ],
+)
+def test_light_path_connections(flags):
+    """eConnectToLightPaths without the light vertex cache: light subpaths store their vertices (store_light_vertex,
+    path.hlsli:520-531), every view vertex connects to the stored vertices of the light path with its path index
+    (connect_light_subpath / connect_light_vertex, path.hlsli:618-680,802-822), contributions are added to gRadiance in
+    program order between the vertices' emission terms."""
+    sc, cam = scenes.cornell_box()
+    _compare_frame(sc, cam, flags, w=100, h=76, seeds=2, args={"maxDiffuseVertices": 4, "maxPathVertices": 7})  # not multiples of 8x4: slots alias / run out
+    _compare_frame(sc, cam, flags, w=96, h=64, seeds=1)  # default limits: one stored vertex per light path
+    sc, cam = scenes.spheres_room()
+    _compare_frame(sc, cam, flags + ["uniformspheresampling"], w=96, h=64, seeds=1, args={"maxDiffuseVertices": 3})
+
+
+def test_light_path_connections_textured_and_sharded(renderer):
+    from stratum_amd import _lib, shard
+
+    sc, cam = scenes.textured_box()  # textures, normal maps (applied again at the stored vertex), specular lobes
+    _compare_frame(sc, cam, ["connecttolightpaths"], w=96, h=80, seeds=1, args={"maxDiffuseVertices": 3})
+    sc, cam = scenes.cornell_box()
+    renderer.update(sc)
+    renderer.set_flag("connecttolightpaths")
+    renderer.mPushConstants.gMaxDiffuseVertices = 3
+    try:
+        frame = camera.Frame(96, 64, cam["fovy"], cam["eye"], cam["target"])
+        full = renderer.render(frame, 0, 2, aovs=False)["radiance"]
+        total = np.zeros_like(full)
+        for rank in range(3):  # every shard traces all light paths and connects its own pixels
+            renderer.set_shard(rank, 3, 16, 8)
+            total += renderer.render(frame, 0, 2, aovs=False)["radiance"]
+        assert np.array_equal(total.view(np.uint32), full.view(np.uint32))
+        renderer.set_shard(0, 1)
+        renderer.set_flag("~remapthreads")
+        with pytest.raises(_lib.StratumHipError, match="multiple of 8"):
+            renderer.render(camera.Frame(100, 64, cam["fovy"], cam["eye"], cam["target"]))
+    finally:
+        renderer.set_shard(0, 1)
+        renderer.set_flag("remapthreads")
+        renderer.set_flag("~connecttolightpaths")
+        renderer.mPushConstants.gMaxDiffuseVertices = 2
+
+
 def test_light_tracing_limits(renderer):
     from stratum_amd import _lib
 
@@ -633,7 +683,7 @@ def test_light_tracing_limits(renderer):
     renderer.update(sc)
     renderer.set_flag("connecttoviews")
     try:
-        with pytest.raises(_lib.StratumHipError, match="eConnectToViews with an environment"):
+        with pytest.raises(_lib.StratumHipError, match="light subpaths with an environment"):
             renderer.render(camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"]))
     finally:
         renderer.set_flag("~connecttoviews")
