@@ -211,11 +211,12 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel (k_trace: BVH traversal of closest-hit and shadow rays), this rank ----
         r.set_option("time_kernels", 1)
-        ms_trace, ms_shade, ms_total, launches = 0.0, 0.0, 0.0, 0
+        ms_trace, ms_primary, ms_shade, ms_total, launches = 0.0, 0.0, 0.0, 0.0, 0
         for i in range(args.steps):
             r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
             s = r.stats()
-            ms_trace += s["ms_trace"]
+            ms_trace += s["ms_trace"]  # k_trace alone: the first bounce runs in k_trace_primary (wave packets), timed apart
+            ms_primary += s["ms_trace_primary"]
             ms_shade += s["ms_shade"]
             ms_total += s["ms_total"]
             launches += s["launches_trace"]
@@ -225,8 +226,10 @@ def main():
         for i in range(args.steps):
             r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
             s = r.stats()
-            nodes += s["nodes_visited"]
-            tris += s["tris_tested"]
+            # the rays, node visits and triangle tests of k_trace: everything but the first bounce's packets
+            nodes += s["nodes_visited"] - s["nodes_visited_primary"]
+            tris += s["tris_tested"] - s["tris_tested_primary"]
+            rays_closest -= s["rays_primary_packets"]
             nodes_sh += s["nodes_visited_shadow"]
             tris_sh += s["tris_tested_shadow"]
             rays_closest += s["rays_path"]
@@ -253,12 +256,15 @@ def main():
             "bytes_per_ray": round(alg_bytes / max(rays, 1), 1),
             "kernel_ms_per_step": {
                 "trace": round(ms_trace / args.steps, 3),
+                "trace_primary": round(ms_primary / args.steps, 3),
                 "shade": round(ms_shade / args.steps, 3),
                 "all": round(ms_total / args.steps, 3),
             },
             "closest_nodes_per_ray": round(nodes / max(rays_closest, 1), 2),
             "shadow_nodes_per_ray": round(nodes_sh / max(rays_shadow, 1), 2),
-            "note": "achieved counts ALGORITHMIC bytes (48 B/ray + node and triangle bytes per visit, SURVEY 8d); most node "
+            "rays_per_launch": round(rays / max(launches, 1), 1),
+            "note": "k_trace = closest-hit rays of bounce >= 1 and all shadow rays (the first bounce runs as wave packets in "
+            "k_trace_primary and is not part of these figures); achieved counts ALGORITHMIC bytes (48 B/ray + node and triangle bytes per visit, SURVEY 8d); most node "
             "fetches hit L2 / Infinity Cache (compare traffic), so frac > 1 means the kernel runs above what HBM alone could "
             "feed: it is bound by dependent-load latency and lane divergence, see profiles/README.md",
         }

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STHIP_ABI_VERSION 3
+#define STHIP_ABI_VERSION 4
 
 typedef struct sthip_ctx sthip_ctx;
 
@@ -197,6 +197,14 @@ typedef struct sthip_stats {
   uint64_t tri_slots[2];
   uint64_t round_slots[2];
   uint64_t busy_rounds[2];
+  /* the first bounce runs as wave packets in a kernel of its own (k_trace_primary, "packet_primary" = 1): its share of
+   * rays_path / nodes_visited / tris_tested, its launches and its time, all of which are NOT part of ms_trace /
+   * launches_trace (so those describe k_trace alone) */
+  uint64_t rays_primary_packets;
+  uint64_t nodes_visited_primary;
+  uint64_t tris_tested_primary;
+  float ms_trace_primary;
+  uint32_t launches_primary;
 } sthip_stats;
 int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out);
 

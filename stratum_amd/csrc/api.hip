@@ -129,6 +129,8 @@ static void fill_counter_stats(sthip_ctx* ctx, const unsigned long long* c) {
     ctx->stats.round_slots[k] = c[CNT_ROUND_SLOTS + k];
     ctx->stats.busy_rounds[k] = c[CNT_BUSY_ROUNDS + k];
   }
+  ctx->stats.nodes_visited_primary = c[CNT_NODES_PRIMARY];
+  ctx->stats.tris_tested_primary = c[CNT_TRIS_PRIMARY];
 }
 
 static int fail(sthip_ctx* ctx, int code, const std::string& msg) {
@@ -816,8 +818,9 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (!ctx->has_specular) max_bounce_rounds = std::min(max_bounce_rounds, pc->gMaxDiffuseVertices + 1);
   p.rounds = max_bounce_rounds;
   const bool timing = ctx->time_kernels;
-  float ms_trace = 0, ms_shade = 0, ms_other = 0;
-  uint32_t launches_trace = 0;
+  float ms_trace = 0, ms_primary = 0, ms_shade = 0, ms_other = 0;
+  uint32_t launches_trace = 0, launches_primary = 0;
+  uint64_t rays_primary = 0;
   auto timed = [&](float& acc, auto&& launch) -> int {
     if (timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     launch();
@@ -865,11 +868,12 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     };
     // the first bounce as wave packets (k_trace_primary): one 8x8 pixel block per wave
     auto trace_primary = [&]() -> int {
-      launches_trace++;
+      launches_primary++;
+      rays_primary += (uint64_t)primary_rays * in_flight;
       const uint32_t packets = (p.path_count + 63) / 64;
       const unsigned pgrid = std::max(1u, std::min((packets + 3) / 4, (uint32_t)ctx->cu_count * 64u));
       const size_t plds = (size_t)ctx->bvh.stack_depth * (STHIP_BLOCK / 64) * sizeof(uint32_t);
-      return timed(ms_trace, [&]() {
+      return timed(ms_primary, [&]() {
         if (p.bvh.alpha_test) {
           if (ctx->count_traversal)
             hipLaunchKernelGGL((k_trace_primary<true, true>), dim3(pgrid), dim3(STHIP_BLOCK), plds, st, p);
@@ -997,9 +1001,12 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (timing) {
     ctx->stats.ms_trace = ms_trace;
     ctx->stats.ms_shade = ms_shade;
-    ctx->stats.ms_total = ms_trace + ms_shade + ms_other;
+    ctx->stats.ms_total = ms_trace + ms_primary + ms_shade + ms_other;
     ctx->stats.launches_trace = launches_trace;
+    ctx->stats.ms_trace_primary = ms_primary;
+    ctx->stats.launches_primary = launches_primary;
   }
+  ctx->stats.rays_primary_packets = rays_primary;
   return STHIP_OK;
 }
 

@@ -26,6 +26,8 @@ enum {
   CNT_TRI_SLOTS = 8,    // +1: shadow rays
   CNT_ROUND_SLOTS = 10, // +1: shadow rays: 64 per round of a persistent wave
   CNT_BUSY_ROUNDS = 12, // +1: shadow rays: lanes holding a ray, summed over rounds
+  CNT_NODES_PRIMARY = 14,  // the share of CNT_NODES / CNT_TRIS that k_trace_primary (first bounce as wave packets) counted
+  CNT_TRIS_PRIMARY = 15,
   CNT_TOTAL = 16
 };
 
@@ -493,6 +495,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_primary(FrameParams p) {
   if (COUNT) {
     wave_add(&p.counters[CNT_NODES], cnt.nodes);
     wave_add(&p.counters[CNT_TRIS], cnt.tris);
+    wave_add(&p.counters[CNT_NODES_PRIMARY], cnt.nodes);
+    wave_add(&p.counters[CNT_TRIS_PRIMARY], cnt.tris);
     wave_add(&p.counters[CNT_INNER_SLOTS], cnt.inner_slots);
     wave_add(&p.counters[CNT_TRI_SLOTS], cnt.tri_slots);
   }

@@ -783,6 +783,48 @@ class BDPT {
   ~BDPT() { sthip_destroy(mCtx); }
   BDPT(const BDPT&) = delete;
 
+  // the instance arguments BDPT's constructor reads (BDPT.cpp:78-127): `minPathVertices`, `maxPathVertices`,
+  // `maxDiffuseVertices`, `maxNullCollisions`, `environmentSampleProbability`, `lightPresampleTileSize`,
+  // `lightPresampleTileCount`, and `bdptFlag` = [~|!]name with the flag's display name lower-cased, spaces removed
+  void set_argument(const std::string& key, const std::string& value) {
+    if (key == "bdptFlag") return set_flag(value);
+    if (key == "environmentSampleProbability") {
+      mPushConstants.gEnvironmentSampleProbability = std::stof(value);
+      return;
+    }
+    static const std::pair<const char*, uint32_t BDPTPushConstants::*> fields[] = {
+        {"minPathVertices", &BDPTPushConstants::gMinPathVertices},
+        {"maxPathVertices", &BDPTPushConstants::gMaxPathVertices},
+        {"maxDiffuseVertices", &BDPTPushConstants::gMaxDiffuseVertices},
+        {"maxNullCollisions", &BDPTPushConstants::gMaxNullCollisions},
+        {"lightPresampleTileSize", &BDPTPushConstants::gLightPresampleTileSize},
+        {"lightPresampleTileCount", &BDPTPushConstants::gLightPresampleTileCount},
+    };
+    for (const auto& f : fields)
+      if (key == f.first) mPushConstants.*(f.second) = (uint32_t)std::stoul(value);
+  }
+  void set_flag(std::string arg) {
+    if (arg.empty()) return;
+    bool on = true;
+    if (arg[0] == '~' || arg[0] == '!') {
+      on = false;
+      arg = arg.substr(1);
+    }
+    for (char& c : arg) c = (char)std::tolower((unsigned char)c);
+    static const char* names[STHIP_eBDPTFlagCount] = {
+        "performancecounters", "remapthreads", "coherentrr", "coherentsampling", "fliptriangleuvs", "flipnormalmaps", "alphatest", "normalmaps",
+        "shadingnormalshadowfix", "raycones", "samplebsdfs", "nee", "neereservoirs", "neereservoirreuse", "mis", "samplelightpower",
+        "uniformspheresampling", "presamplelights", "defershadowrays", "connecttoviews", "connecttolightpaths", "lightvertexcache", "lvcreservoirs",
+        "lvcreservoirreuse", "jitterhashgridlookups", "sampleenvironmentmapdirectly"};
+    for (uint32_t i = 0; i < STHIP_eBDPTFlagCount; i++)
+      if (arg == names[i]) {  // unknown names are ignored, as upstream
+        if (on)
+          mSamplingFlags |= 1u << i;
+        else
+          mSamplingFlags &= ~(1u << i);
+      }
+  }
+
   Node& node() const { return mNode; }
   uint32_t& sampling_flags() { return mSamplingFlags; }
   BDPTPushConstants& push_constants() { return mPushConstants; }

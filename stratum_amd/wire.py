@@ -211,6 +211,11 @@ class Stats(C.Structure):
         ("tri_slots", C.c_uint64 * 2),
         ("round_slots", C.c_uint64 * 2),
         ("busy_rounds", C.c_uint64 * 2),
+        ("rays_primary_packets", C.c_uint64),
+        ("nodes_visited_primary", C.c_uint64),
+        ("tris_tested_primary", C.c_uint64),
+        ("ms_trace_primary", C.c_float),
+        ("launches_primary", C.c_uint32),
     ]
 
 

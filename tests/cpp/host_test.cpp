@@ -162,6 +162,11 @@ int main(int argc, char** argv) {
       const uint32_t seeds = (uint32_t)std::atoi(argv[4]);
       // init_renderer<BDPT>, main.cpp:59-66
       auto renderer = app.node().make_child("BDPT").make_component<BDPT>();
+      for (int a = 8; a < argc; a++) {  // instance arguments as --key=value (BDPT.cpp:78-127)
+        const std::string kv = argv[a];
+        const size_t eq = kv.find('=');
+        if (kv.rfind("--", 0) == 0 && eq != std::string::npos) renderer->set_argument(kv.substr(2, eq - 2), kv.substr(eq + 1));
+      }
       if (argc >= 8) {  // tone-map settings as the GUI would set them
         renderer->tonemap_mode() = (uint32_t)std::atoi(argv[5]);
         renderer->exposure() = (float)std::atof(argv[6]);

@@ -48,26 +48,35 @@ def test_scene_update_packs_like_the_reference_layouts(host_test, tmp_path, make
     assert out.returncode == 0 and out.stdout.startswith("PACK OK"), out.stdout + out.stderr
 
 
+def bidirectional_cornell():
+    return scenes.cornell_box()
+
+
+BDPT_ARGS = {bidirectional_cornell: {"bdptFlag": ["connectToLightPaths", "connecttoviews", "~deferShadowRays"], "maxDiffuseVertices": 3, "maxPathVertices": 6}}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("make", [scenes.cornell_box, shared_mesh_scene, scenes.textured_box, scenes.spheres_room, scenes.environment_scene, scenes.foliage])
+@pytest.mark.parametrize("make", [scenes.cornell_box, shared_mesh_scene, scenes.textured_box, scenes.spheres_room, scenes.environment_scene, scenes.foliage, bidirectional_cornell])
 def test_cpp_host_renders_what_the_python_host_renders(host_test, tmp_path, make):
     from stratum_amd.bdpt import BDPT
     from stratum_amd.post import Tonemapper, write_hdr
 
     sc, cam = make()
+    args = BDPT_ARGS.get(make, {})
+    argv = ["--%s=%s" % (k, x) for k, v in args.items() for x in (v if isinstance(v, list) else [v])]
     W, H, seeds = 96, 64, 3
     fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
     desc, outp = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
     dump_description(desc, sc, fr)
     hdr = str(tmp_path / "image.hdr")
-    out = subprocess.run([host_test, "render", desc, outp, str(seeds), str(wire.TONEMAP["ACES"]), "0.75", hdr], capture_output=True, text=True)
+    out = subprocess.run([host_test, "render", desc, outp, str(seeds), str(wire.TONEMAP["ACES"]), "0.75", hdr] + argv, capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("RENDER OK"), out.stdout + out.stderr
     raw = np.fromfile(outp, dtype=np.uint8)
     rad = raw[: W * H * 16].view(np.float32).reshape(H, W, 4)
     vis = raw[W * H * 16 : W * H * 24].view(wire.VisibilityInfo).reshape(H, W)
     rays = raw[W * H * 24 : W * H * 24 + 16].view(np.uint64)
     tm = raw[W * H * 24 + 16 :].view(np.float32).reshape(H, W, 4)
-    r = BDPT(device=0)
+    r = BDPT(device=0, args=args)
     try:
         r.update(sc)
         ref = r.render(fr, 0, seeds)
