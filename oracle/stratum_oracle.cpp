@@ -1356,7 +1356,94 @@ struct Environment {
     cartesian_to_spherical_uv(dir_out, u, v);
     return lookup(u, v) * value;
   }
-  v3 sample(float rx, float ry, v3& dir_out, float& pdf) const {
+  // sample_texel / sample_texel_pdf, bdpt_util.hlsli:85-180 (eSampleEnvironmentMapDirectly): a descent through the mip
+  // chain from the 2 x 1 level towards level 1 (at most 10 levels), at each level one of the 2 x 2 children in
+  // proportion to luminance x sin(theta). Texel loads outside a level return zero, as Texture2D::Load does.
+  float texel_weight(uint32_t level, uint32_t x, uint32_t y, float inv_h) const {
+    const OrcImage& im = sc->images[image_index];
+    if (x >= im.w[level] || y >= im.h[level]) return 0.0f * det_sin(DET_PI * ((float)y + 0.5f) * inv_h);
+    const float* t = &im.mip[level][4 * ((size_t)y * im.w[level] + x)];
+    return luminance(V3(t[0], t[1], t[2])) * det_sin(DET_PI * ((float)y + 0.5f) * inv_h);
+  }
+  static float det_sin(float x) {
+    float sn, cs;
+    det_sincosf(x, &sn, &cs);
+    return sn;
+  }
+  bool texel_level(uint32_t level, uint32_t cx, uint32_t cy, float p[4]) const {
+    const OrcImage& im = sc->images[image_index];
+    const float inv_h = 1 / (float)im.h[level];
+    p[0] = p[1] = p[2] = p[3] = 0;
+    if (im.w[level] > 1) {
+      p[0] = texel_weight(level, cx, cy, inv_h);
+      p[1] = texel_weight(level, cx + 1, cy, inv_h);
+    }
+    if (im.h[level] > 1) {
+      p[2] = texel_weight(level, cx, cy + 1, inv_h);
+      p[3] = texel_weight(level, cx + 1, cy + 1, inv_h);
+    }
+    const float sum = ((p[0] + p[1]) + p[2]) + p[3];  // dot(p, 1)
+    if (sum < 1e-6f) return false;
+    for (int j = 0; j < 4; j++) p[j] /= sum;
+    return true;
+  }
+  void sample_texel(float rx, float ry, float& pdf, float& u, float& v) const {
+    const OrcImage& im = sc->images[image_index];
+    const uint32_t level_count = (uint32_t)im.w.size();
+    pdf = 1;
+    uint32_t cx = 0, cy = 0, lw = 1, lh = 1;
+    for (uint32_t i = 1; i < std::min(10u + 1u, level_count - 1); i++) {
+      const uint32_t level = level_count - 1 - i;
+      const uint32_t w = im.w[level], h = im.h[level];
+      cx *= w / lw;
+      cy *= h / lh;
+      float p[4];
+      if (!texel_level(level, cx, cy, p)) continue;
+      for (int j = 0; j < 4; j++) {
+        if (rx < p[j]) {
+          cx += (uint32_t)(j & 1);
+          cy += (uint32_t)(j >> 1);
+          pdf *= p[j];
+          rx /= p[j];
+          break;
+        }
+        rx -= p[j];
+      }
+      lw = w;
+      lh = h;
+    }
+    pdf *= (float)(lw * lh);
+    u = ((float)cx + rx) / (float)lw;
+    v = ((float)cy + ry) / (float)lh;
+  }
+  float sample_texel_pdf(float u, float v) const {
+    const OrcImage& im = sc->images[image_index];
+    const uint32_t level_count = (uint32_t)im.w.size();
+    float pdf = 1;
+    uint32_t lw = 1, lh = 1;
+    for (uint32_t i = 1; i < std::min(10u + 1u, level_count - 1); i++) {
+      const uint32_t level = level_count - 1 - i;
+      const uint32_t w = im.w[level], h = im.h[level];
+      const uint32_t cx = (uint32_t)(floorf((float)w * u / 2) * 2), cy = (uint32_t)(floorf((float)h * v / 2) * 2);
+      float p[4];
+      if (!texel_level(level, cx, cy, p)) continue;
+      // saturate(uint2(uv * size) - coord): unsigned, clamped to 0 .. 1
+      const uint32_t dx = (uint32_t)(u * (float)w) - cx, dy = (uint32_t)(v * (float)h) - cy;
+      const uint32_t ox = dx > 1 ? 1 : dx, oy = dy > 1 ? 1 : dy;
+      pdf *= p[oy * 2 + ox];
+      lw = w;
+      lh = h;
+    }
+    return pdf * (float)(lw * lh);
+  }
+  v3 sample(float rx, float ry, v3& dir_out, float& pdf, bool direct = false) const {
+    if (has_image() && direct) {  // environment.h:66-67
+      float u, v;
+      sample_texel(rx, ry, pdf, u, v);
+      dir_out = spherical_uv_to_cartesian(u, v);
+      pdf /= (DET_2PI2 * sqrtf(1 - dir_out.y * dir_out.y));
+      return value * lookup(u, v);
+    }
     if (!has_image()) {
       // sample_uniform_sphere's (phi, theta) go through spherical_uv_to_cartesian as if they were uv (as upstream)
       dir_out = spherical_uv_to_cartesian(2 * DET_PI * ry, det_acosf(2 * rx - 1));
@@ -1371,10 +1458,11 @@ struct Environment {
     pdf /= (DET_2PI2 * sqrtf(1 - dir_out.y * dir_out.y));
     return value * lookup(u, v);
   }
-  float eval_pdf(v3 dir_out) const {
+  float eval_pdf(v3 dir_out, bool direct = false) const {
     if (!has_image()) return DET_INV_4PI;
     float u, v;
     cartesian_to_spherical_uv(dir_out, u, v);
+    if (direct) return sample_texel_pdf(u, v) / (DET_2PI2 * sqrtf(1 - dir_out.y * dir_out.y));  // environment.h:84-85
     const uint32_t w = sc->images[image_index].w[0], h = sc->images[image_index].h[0];
     const float pdf = dist2d_pdf(sc->distributions, marginal_pdf, row_pdf, w, h, u, v);
     return pdf / (DET_2PI2 * sqrtf(1 - dir_out.y * dir_out.y));
@@ -1458,7 +1546,7 @@ void sample_point_on_light(const Frame& fr, LightSampleRecord& ls, const float r
   if (has_environment(fr) && (!has_emissives(fr) || rnd[3] <= fr.pc.gEnvironmentSampleProbability)) {
     Environment env;
     env.load(sc, fr.pc.gEnvironmentMaterialAddress);
-    ls.radiance = env.sample(rnd[0], rnd[1], ls.to_light, ls.pdf);
+    ls.radiance = env.sample(rnd[0], rnd[1], ls.to_light, ls.pdf, fr.flag(STHIP_eSampleEnvironmentMapDirectly));
     if (has_emissives(fr)) ls.pdf *= fr.pc.gEnvironmentSampleProbability;
     ls.is_environment = true;
     ls.dist = POS_INF;
@@ -1562,7 +1650,7 @@ inline float point_on_light_pdf(const Frame& fr, const IntersectionVertex& isect
     if (!has_environment(fr)) return 0;
     Environment env;
     env.load(*fr.sc, fr.pc.gEnvironmentMaterialAddress);
-    float pdf = env.eval_pdf(direction);  // _isect.sd.position holds the ray direction on a miss (intersection.hlsli:183)
+    float pdf = env.eval_pdf(direction, fr.flag(STHIP_eSampleEnvironmentMapDirectly));  // _isect.sd.position holds the ray direction on a miss (intersection.hlsli:183)
     if (has_emissives(fr)) pdf *= fr.pc.gEnvironmentSampleProbability;
     return pdf;
   }
@@ -2554,7 +2642,7 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
   const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) |
                                (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
-                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling) | (1u << STHIP_eSampleEnvironmentMapDirectly);
+                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
   if (sampling_flags & unsupported) return STHIP_ERR_UNSUPPORTED;
   Frame fr;
   fr.sc = sc;

@@ -521,7 +521,7 @@ DEV void sample_point_on_light(const FrameParams& p, bool has_env, bool has_emis
   if (has_env && (!has_emissives || r3 <= p.pc.gEnvironmentSampleProbability)) {  // light.hlsli:38-48
     Environment env;
     env.load(p.scene, p.pc.gEnvironmentMaterialAddress);
-    ls.Le = env.sample(p.scene, r0, r1, ls.to_light, ls.pdf);
+    ls.Le = env.sample(p.scene, r0, r1, ls.to_light, ls.pdf, flag(p, STHIP_eSampleEnvironmentMapDirectly));
     if (has_emissives) ls.pdf *= p.pc.gEnvironmentSampleProbability;
     ls.is_env = true;
     ls.dist = __builtin_inff();
@@ -1040,7 +1040,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
           env.load(p.scene, p.pc.gEnvironmentMaterialAddress);
           const f3 eLe = env.eval(p.scene, direction);
           if (!all_le0(eLe)) {
-            float light_pdf = env.eval_pdf(p.scene, direction);
+            float light_pdf = env.eval_pdf(p.scene, direction, flag(p, STHIP_eSampleEnvironmentMapDirectly));
             if (has_emissives) light_pdf *= p.pc.gEnvironmentSampleProbability;
             float weight = 1;
             if (path_length > 2 && use_nee) weight = flag(p, STHIP_eNEEReservoirs) ? 0.5f : mis2(use_mis, bsdf_pdf, light_pdf);

@@ -696,7 +696,6 @@ DEV void dist2d_sample(const float* data, uint32_t cdf_marginals, uint32_t cdf_r
 
 // environment.h:8-95. Record in gMaterialData: ImageValue3 (float3 value, uint image_index) and, when an image is
 // bound, the offsets of marginal_pdf, row_pdf, marginal_cdf, row_cdf in gDistributions (:17-22,37-45).
-// eSampleEnvironmentMapDirectly (sample_texel) is not built (the ABI rejects the flag).
 struct Environment {
   f3 value;
   uint32_t image_index;
@@ -721,7 +720,88 @@ struct Environment {
     cartesian_to_spherical_uv(dir_out, u, v);
     return lookup(sc, u, v) * value;
   }
-  DEV f3 sample(const DeviceScene& sc, float rx, float ry, f3& dir_out, float& pdf) const {
+  // sample_texel / sample_texel_pdf, bdpt_util.hlsli:85-180 (eSampleEnvironmentMapDirectly): a descent through the mip
+  // chain from the 2 x 1 level towards level 1 (at most 10 levels), at each level one of the 2 x 2 children in
+  // proportion to luminance x sin(theta). Texel loads outside a level return zero, as Texture2D::Load does.
+  static DEV float texel_weight(const DeviceScene& sc, const DeviceImage& im, uint32_t level, uint32_t x, uint32_t y, float inv_h) {
+    float sn, cs;
+    det_sincosf(DET_PI * ((float)y + 0.5f) * inv_h, &sn, &cs);
+    if (x >= im.w[level] || y >= im.h[level]) return 0.0f * sn;
+    const float4 t = sc.image_texels[im.offset[level] + (size_t)y * im.w[level] + x];
+    return luminance3(F3(t.x, t.y, t.z)) * sn;
+  }
+  static DEV bool texel_level(const DeviceScene& sc, const DeviceImage& im, uint32_t level, uint32_t cx, uint32_t cy, float p[4]) {
+    const float inv_h = 1 / (float)im.h[level];
+    p[0] = p[1] = p[2] = p[3] = 0;
+    if (im.w[level] > 1) {
+      p[0] = texel_weight(sc, im, level, cx, cy, inv_h);
+      p[1] = texel_weight(sc, im, level, cx + 1, cy, inv_h);
+    }
+    if (im.h[level] > 1) {
+      p[2] = texel_weight(sc, im, level, cx, cy + 1, inv_h);
+      p[3] = texel_weight(sc, im, level, cx + 1, cy + 1, inv_h);
+    }
+    const float sum = ((p[0] + p[1]) + p[2]) + p[3];
+    if (sum < 1e-6f) return false;
+    for (int j = 0; j < 4; j++) p[j] /= sum;
+    return true;
+  }
+  DEV void sample_texel(const DeviceScene& sc, float rx, float ry, float& pdf, float& u, float& v) const {
+    const DeviceImage& im = sc.images[image_index];
+    const uint32_t level_count = im.levels;
+    pdf = 1;
+    uint32_t cx = 0, cy = 0, lw = 1, lh = 1;
+    for (uint32_t i = 1; i < min(10u + 1u, level_count - 1); i++) {
+      const uint32_t level = level_count - 1 - i;
+      const uint32_t w = im.w[level], h = im.h[level];
+      cx *= w / lw;
+      cy *= h / lh;
+      float p[4];
+      if (!texel_level(sc, im, level, cx, cy, p)) continue;
+      for (int j = 0; j < 4; j++) {
+        if (rx < p[j]) {
+          cx += (uint32_t)(j & 1);
+          cy += (uint32_t)(j >> 1);
+          pdf *= p[j];
+          rx /= p[j];
+          break;
+        }
+        rx -= p[j];
+      }
+      lw = w;
+      lh = h;
+    }
+    pdf *= (float)(lw * lh);
+    u = ((float)cx + rx) / (float)lw;
+    v = ((float)cy + ry) / (float)lh;
+  }
+  DEV float sample_texel_pdf(const DeviceScene& sc, float u, float v) const {
+    const DeviceImage& im = sc.images[image_index];
+    const uint32_t level_count = im.levels;
+    float pdf = 1;
+    uint32_t lw = 1, lh = 1;
+    for (uint32_t i = 1; i < min(10u + 1u, level_count - 1); i++) {
+      const uint32_t level = level_count - 1 - i;
+      const uint32_t w = im.w[level], h = im.h[level];
+      const uint32_t cx = (uint32_t)(floorf((float)w * u / 2) * 2), cy = (uint32_t)(floorf((float)h * v / 2) * 2);
+      float p[4];
+      if (!texel_level(sc, im, level, cx, cy, p)) continue;
+      const uint32_t dx = (uint32_t)(u * (float)w) - cx, dy = (uint32_t)(v * (float)h) - cy;  // saturate() of an unsigned: 0 .. 1
+      const uint32_t ox = dx > 1 ? 1 : dx, oy = dy > 1 ? 1 : dy;
+      pdf *= p[oy * 2 + ox];
+      lw = w;
+      lh = h;
+    }
+    return pdf * (float)(lw * lh);
+  }
+  DEV f3 sample(const DeviceScene& sc, float rx, float ry, f3& dir_out, float& pdf, bool direct = false) const {
+    if (direct && has_image(sc)) {  // environment.h:66-67
+      float u, v;
+      sample_texel(sc, rx, ry, pdf, u, v);
+      dir_out = spherical_uv_to_cartesian(u, v);
+      pdf /= (DET_2PI2 * sqrtf(1 - dir_out.y * dir_out.y));
+      return value * lookup(sc, u, v);
+    }
     if (!has_image(sc)) {
       // sample_uniform_sphere's (phi, theta) go through spherical_uv_to_cartesian as if they were uv (as upstream)
       dir_out = spherical_uv_to_cartesian(2 * DET_PI * ry, det_acosf(2 * rx - 1));
@@ -736,10 +816,11 @@ struct Environment {
     pdf /= (DET_2PI2 * sqrtf(1 - dir_out.y * dir_out.y));
     return value * lookup(sc, u, v);
   }
-  DEV float eval_pdf(const DeviceScene& sc, f3 dir_out) const {
+  DEV float eval_pdf(const DeviceScene& sc, f3 dir_out, bool direct = false) const {
     if (!has_image(sc)) return DET_INV_4PI;
     float u, v;
     cartesian_to_spherical_uv(dir_out, u, v);
+    if (direct) return sample_texel_pdf(sc, u, v) / (DET_2PI2 * sqrtf(1 - dir_out.y * dir_out.y));  // environment.h:84-85
     const uint32_t w = sc.images[image_index].w[0], h = sc.images[image_index].h[0];
     const float pdf = dist2d_pdf(sc.distributions, marginal_pdf, row_pdf, w, h, u, v);
     return pdf / (DET_2PI2 * sqrtf(1 - dir_out.y * dir_out.y));

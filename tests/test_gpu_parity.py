@@ -412,7 +412,7 @@ def test_sphere_instances_and_sphere_lights(flags):
 
 
 @pytest.mark.parametrize("image,emitter", [(True, True), (True, False), (False, True), (False, False)])
-@pytest.mark.parametrize("flags", [[], ["~mis"]])
+@pytest.mark.parametrize("flags", [[], ["~mis"], ["sampleenvironmentmapdirectly"]])
 def test_environment(image, emitter, flags):
     """Environment emission on misses, environment light sampling (dist2d tables of the lat-long image, or the
     image-less constant environment), and the environment / emitter choice (gEnvironmentSampleProbability)."""
@@ -428,10 +428,12 @@ def test_environment_errors(renderer):
     sc, cam = scenes.environment_scene(image=True, emitter=False)
     renderer.update(sc)
     frame = camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"])
-    renderer.set_flag("sampleenvironmentmapdirectly")
+    renderer.set_flag("lvcreservoirs")
+    renderer.set_flag("lightvertexcache")
     with pytest.raises(_lib.StratumHipError, match="sampling flag"):
         renderer.render(frame)
-    renderer.set_flag("~sampleenvironmentmapdirectly")
+    renderer.set_flag("~lightvertexcache")
+    renderer.set_flag("~lvcreservoirs")
     sc.distributions = sc.distributions[:-5]  # a table that runs past gDistributions
     renderer.update(sc)
     with pytest.raises(_lib.StratumHipError, match="gDistributions"):

@@ -556,6 +556,9 @@ def test_environment_estimators_agree():
         ("image light sampling", True, D & ~wire.flag_mask("eSampleBSDFs")),
         ("image bsdf sampling", True, D & ~wire.flag_mask("eNEE")),
         ("constant bsdf sampling", False, D & ~wire.flag_mask("eNEE")),
+        # eSampleEnvironmentMapDirectly: sample_texel's descent through the mip chain instead of the dist2d tables
+        ("image direct mis", True, D | wire.flag_mask("eSampleEnvironmentMapDirectly")),
+        ("image direct light sampling", True, (D | wire.flag_mask("eSampleEnvironmentMapDirectly")) & ~wire.flag_mask("eSampleBSDFs")),
     ):
         sc = sphere_under_sky(rho, (L, L, L), np.ones((8, 16, 4), np.float32) if image else None)
         pc = wire.default_push_constants(24, 24, sc.light_count)
@@ -701,3 +704,20 @@ def test_light_path_connections_against_path_tracing():
     few = o.render(fr, pc, D | L, 0, 4, aovs=False)
     base = o.render(fr, pc, D, 0, 4, aovs=False)
     assert few["ray_count"][0] > 1.5 * base["ray_count"][0]
+
+
+def test_sample_texel_agrees_with_the_distribution_tables():
+    """A sky with a sun (most of the energy in a few texels): light sampling alone through sample_texel / sample_texel_pdf
+    (bdpt_util.hlsli:85-180) and through the dist2d tables are two unbiased estimators of the same integral."""
+    sc = sphere_under_sky(0.6, (1.0, 1.0, 1.0), scenes.sky_image(64, 32))
+    fr = camera.Frame(24, 24, np.radians(35.0), (0.0, 0.0, 5.0), (0.0, 0.0, 0.0))
+    pc = wire.default_push_constants(24, 24, sc.light_count)
+    pc.gEnvironmentMaterialAddress = sc.environment_address
+    pc.gMaxDiffuseVertices = 1
+    f = wire.DEFAULT_SAMPLING_FLAGS & ~wire.flag_mask("eSampleBSDFs")
+    means = []
+    for flags in (f, f | wire.flag_mask("eSampleEnvironmentMapDirectly")):
+        out = orc.OracleScene(sc).render(fr, pc, flags, 0, 1024)
+        on = out["visibility"]["instance_primitive_index"] != wire.MISS
+        means.append(out["radiance"][..., :3].astype(np.float64)[on].mean())
+    assert means[0] > 0.05 and abs(means[1] / means[0] - 1) < 0.02, means
