@@ -269,6 +269,17 @@ def main():
             "feed: it is bound by dependent-load latency and lane divergence, see profiles/README.md",
         }
 
+        # ---- the same steps through HOST output pointers (what a caller without device buffers pays): the frame comes
+        # back over PCIe inside the call. Reported next to `value`, never as `value`.
+        host_rate = None
+        if world == 1:
+            r.render(frame, seed_begin=0, seed_count=1, aovs=False)
+            th = time.perf_counter()
+            hrays = 0
+            for i in range(args.steps):
+                hrays += int(r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, aovs=False)["ray_count"][0])
+            host_rate = round(hrays / (time.perf_counter() - th) / 1e6, 2)
+
         # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -317,6 +328,7 @@ def main():
                 "parallelism": "tile-shard x%d" % world if world > 1 else "single GPU",
                 "exchange": exchange,
             },
+            "host_output_value": host_rate,  # Mray/s with the radiance image copied to host memory inside every call
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
