@@ -261,3 +261,21 @@ def accumulate(frame_out, history, views, reprojection=True, demodulate_albedo=F
     lib().orc_accumulate(C.byref(d))
     return out_c, out_m
 
+
+
+def nvdb_probe(grid_bytes, coords, points):
+    """The oracle's NanoVDB reader on its own: (bbox_min, bbox_max, root_max, values at coords, maps of points)."""
+    L = lib()
+    grid = np.ascontiguousarray(grid_bytes, dtype=np.uint8)
+    coords = np.ascontiguousarray(coords, dtype=np.int32)
+    points = np.ascontiguousarray(points, dtype=np.float32)
+    n, m = coords.shape[0], points.shape[0]
+    values, header, maps = np.zeros(n, np.float32), np.zeros(8, np.int32), np.zeros((m, 4, 3), np.float32)
+    root_max = C.c_float()
+    rc = L.orc_nvdb_probe(
+        grid.ctypes.data_as(C.c_void_p), C.c_uint64(grid.size), coords.ctypes.data_as(C.c_void_p), n, values.ctypes.data_as(C.c_void_p),
+        header.ctypes.data_as(C.c_void_p), C.byref(root_max), points.ctypes.data_as(C.c_void_p), m, maps.ctypes.data_as(C.c_void_p),
+    )
+    if rc != 0:
+        raise RuntimeError("orc_nvdb_probe failed (%d)" % rc)
+    return header[:3].copy(), header[3:6].copy(), root_max.value, values, maps

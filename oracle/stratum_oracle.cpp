@@ -407,6 +407,75 @@ struct OrcImage {
   std::vector<std::vector<float>> mip;  // RGBA32F per level
 };
 
+// A NanoVDB float grid as bound to gVolumes[] (ByteAddressBuffer, bdpt.hlsl:35): the subset of PNanoVDB.h (NanoVDB
+// 32.3, the version the reference vendors under src/extern/nanovdb) that medium.hlsli:58-71,85-88 and
+// intersection.hlsli:93-113 call — root bounding box and maximum, the value at an index coordinate through
+// root tile -> upper (32^3) -> lower (16^3) -> leaf (8^3), and the grid's affine map. Layout constants from the
+// published format (PNanoVDB.h:702-711,761-777,904-916,964-1111 and the FLOAT row of pnanovdb_grid_type_constants).
+// Reads outside the buffer return zero. Pinned by tests/golden/fog_sphere.npz (answers of the reference's own reader).
+struct NvdbGrid {
+  std::vector<uint8_t> bytes;
+  size_t root = 0;
+  int32_t bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
+  float matf[9], invmatf[9], vecf[3];
+  template <class T>
+  T rd(size_t off) const {
+    T v{};
+    if (off + sizeof(T) <= bytes.size()) memcpy(&v, bytes.data() + off, sizeof(T));
+    return v;
+  }
+  bool init() {
+    if (bytes.size() < 672 + 64 + 64) return false;
+    if (rd<uint64_t>(0) != 0x304244566f6e614eull) return false;  // "NanoVDB0"
+    if (rd<uint32_t>(636) != 1u) return false;                    // GRID_TYPE_FLOAT
+    const size_t tree = 672;                                      // PNANOVDB_GRID_SIZE
+    root = tree + (size_t)rd<uint64_t>(tree + 24);                // TREE_OFF_NODE_OFFSET_ROOT
+    for (int k = 0; k < 3; k++) {
+      bbox_min[k] = rd<int32_t>(root + 4 * k);
+      bbox_max[k] = rd<int32_t>(root + 12 + 4 * k);
+      vecf[k] = rd<float>(296 + 72 + 4 * k);
+    }
+    for (int k = 0; k < 9; k++) {
+      matf[k] = rd<float>(296 + 4 * k);
+      invmatf[k] = rd<float>(296 + 36 + 4 * k);
+    }
+    return true;
+  }
+  float root_max() const { return rd<float>(root + 36); }
+  bool bit(size_t mask, uint32_t n) const { return (rd<uint32_t>(mask + 4 * (n >> 5)) >> (n & 31u)) & 1u; }
+  float value(int32_t x, int32_t y, int32_t z) const {
+    const uint64_t key = (uint64_t)((uint32_t)z >> 12) | ((uint64_t)((uint32_t)y >> 12) << 21) | ((uint64_t)((uint32_t)x >> 12) << 42);
+    const uint32_t tiles = rd<uint32_t>(root + 24);
+    for (uint32_t i = 0; i < tiles; i++) {
+      const size_t tile = root + 64 + 32 * (size_t)i;
+      if (rd<uint64_t>(tile) != key) continue;
+      const int64_t child = rd<int64_t>(tile + 8);
+      if (child == 0) return rd<float>(tile + 20);
+      const size_t upper = root + (size_t)child;
+      const uint32_t n = ((((uint32_t)x & 4095u) >> 7) << 10) + ((((uint32_t)y & 4095u) >> 7) << 5) + (((uint32_t)z & 4095u) >> 7);
+      if (!bit(upper + 4128, n)) return rd<float>(upper + 8256 + 8 * (size_t)n);
+      const size_t lower = upper + (size_t)rd<int64_t>(upper + 8256 + 8 * (size_t)n);
+      const uint32_t n2 = ((((uint32_t)x & 127u) >> 3) << 8) + ((((uint32_t)y & 127u) >> 3) << 4) + (((uint32_t)z & 127u) >> 3);
+      if (!bit(lower + 544, n2)) return rd<float>(lower + 1088 + 8 * (size_t)n2);
+      const size_t leaf = lower + (size_t)rd<int64_t>(lower + 1088 + 8 * (size_t)n2);
+      const uint32_t n3 = (((uint32_t)x & 7u) << 6) + (((uint32_t)y & 7u) << 3) + ((uint32_t)z & 7u);
+      return rd<float>(leaf + 96 + 4 * (size_t)n3);
+    }
+    return rd<float>(root + 28);  // background
+  }
+  // pnanovdb_map_apply / _inverse / _jacobi / _inverse_jacobi, PNanoVDB.h:1988-2034 (left-to-right sums)
+  v3 index_to_world(v3 s) const {
+    return V3(s.x * matf[0] + s.y * matf[1] + s.z * matf[2] + vecf[0], s.x * matf[3] + s.y * matf[4] + s.z * matf[5] + vecf[1], s.x * matf[6] + s.y * matf[7] + s.z * matf[8] + vecf[2]);
+  }
+  v3 index_to_world_dir(v3 s) const {
+    return V3(s.x * matf[0] + s.y * matf[1] + s.z * matf[2], s.x * matf[3] + s.y * matf[4] + s.z * matf[5], s.x * matf[6] + s.y * matf[7] + s.z * matf[8]);
+  }
+  v3 world_to_index_dir(v3 s) const {
+    return V3(s.x * invmatf[0] + s.y * invmatf[1] + s.z * invmatf[2], s.x * invmatf[3] + s.y * invmatf[4] + s.z * invmatf[5], s.x * invmatf[6] + s.y * invmatf[7] + s.z * invmatf[8]);
+  }
+  v3 world_to_index(v3 p) const { return world_to_index_dir(V3(p.x - vecf[0], p.y - vecf[1], p.z - vecf[2])); }
+};
+
 struct OrcImage1 {  // Texture2D<float>: one coverage value per texel (alpha masks)
   uint32_t w = 0, h = 0;
   std::vector<float> px;
@@ -2168,7 +2237,7 @@ struct PathIntegrator {
       const PathVertex lv = fr.light_vertices[idx];
       if (lv.subpath_length() + path_length > fr.pc.gMaxPathVertices || lv.diffuse_vertices() + diffuse_vertices > fr.pc.gMaxDiffuseVertices || all_le0(lv.beta())) break;
       v3 ray_origin, ray_direction;
-      float ray_distance, weight = 0;
+      float ray_distance = 0, weight = 0;
       const v3 contrib = beta * connect_light_vertex(m, lv, weight, ray_origin, ray_direction, ray_distance);
       if (all_le0(contrib) || weight <= 0) continue;
       if (occluded(ray_origin, ray_direction, ray_distance)) continue;
@@ -2867,6 +2936,30 @@ void orc_sample_light(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
     o[14] = ls.pdf_area_measure ? 1.0f : 0.0f;
     o[15] = ls.is_environment ? 1.0f : 0.0f;
   }
+}
+// the NanoVDB reader on its own: header[8] = bbox min, bbox max, grid ok, -; header_f[1] = root maximum; values at coords;
+// maps[m][4][3] = world_to_indexf, world_to_index_dirf of points[m], index_to_worldf of the first, index_to_world_dirf of the second
+int orc_nvdb_probe(const void* grid, uint64_t bytes, const int32_t* coords, uint32_t n, float* values, int32_t* header, float* root_max, const float* points, uint32_t m, float* maps) {
+  NvdbGrid g;
+  g.bytes.assign((const uint8_t*)grid, (const uint8_t*)grid + bytes);
+  if (!g.init()) return STHIP_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < 3; k++) {
+    header[k] = g.bbox_min[k];
+    header[3 + k] = g.bbox_max[k];
+  }
+  *root_max = g.root_max();
+  for (uint32_t i = 0; i < n; i++) values[i] = g.value(coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]);
+  for (uint32_t i = 0; i < m; i++) {
+    const v3 p = V3(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
+    const v3 a = g.world_to_index(p), b = g.world_to_index_dir(p), c = g.index_to_world(a), d = g.index_to_world_dir(b);
+    const v3 r[4] = {a, b, c, d};
+    for (int k = 0; k < 4; k++) {
+      maps[12 * i + 3 * k] = r[k].x;
+      maps[12 * i + 3 * k + 1] = r[k].y;
+      maps[12 * i + 3 * k + 2] = r[k].z;
+    }
+  }
+  return STHIP_OK;
 }
 void orc_atan2(const float* y, const float* x, float* out, uint32_t n) {
   for (uint32_t i = 0; i < n; i++) out[i] = det_atan2f(y[i], x[i]);

@@ -1,3 +1,4 @@
+import os
 """Pins of the CPU oracle (no GPU). The reference ships no tests or golden vectors (SURVEY.md §4), so
 the oracle is pinned by independent restatements of the integer code, by IEEE conversions that numpy
 implements on its own, and by analytic properties the estimator must have."""
@@ -721,3 +722,15 @@ def test_sample_texel_agrees_with_the_distribution_tables():
         on = out["visibility"]["instance_primitive_index"] != wire.MISS
         means.append(out["radiance"][..., :3].astype(np.float64)[on].mean())
     assert means[0] > 0.05 and abs(means[1] / means[0] - 1) < 0.02, means
+
+
+def test_nanovdb_reader_against_the_reference_accessor():
+    """tests/golden/fog_sphere.npz holds a NanoVDB 32.3 float grid made with the reference's vendored NanoVDB and 6000 values,
+    the root bounding box / maximum and the four map functions read from it by the reference's own PNanoVDB.h
+    (oracle/nvdb_ref.cpp). The oracle's restated reader returns the same bits."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fog_sphere.npz"))
+    bmin, bmax, root_max, values, maps = orc.nvdb_probe(g["grid"], g["coords"], g["map"][:, 0, :])
+    assert np.array_equal(bmin, g["bbox_min"]) and np.array_equal(bmax, g["bbox_max"]) and root_max == float(g["root_max"])
+    assert np.array_equal(values.view(np.uint32), g["values"].view(np.uint32))
+    assert (values > 0).sum() > 500 and (values == 0).sum() > 1000  # inside the fog, and background / inactive voxels
+    assert np.array_equal(maps.view(np.uint32), g["map"][:, 1:, :].view(np.uint32))
