@@ -46,6 +46,11 @@ typedef struct sthip_image_desc {
   uint32_t width, height;
 } sthip_image_desc;
 
+typedef struct sthip_volume_desc {
+  const void* data; /* the NanoVDB grid buffer */
+  uint64_t bytes;
+} sthip_volume_desc;
+
 /* gSceneParams (bdpt.hlsl:19-35) as produced by Scene::update (Scene.cpp:299-684,
  * Scene.hpp:46-69). All pointers are host pointers, borrowed for the call and copied to HBM. */
 typedef struct sthip_scene_desc {
@@ -81,6 +86,11 @@ typedef struct sthip_scene_desc {
    * May be NULL / 0. */
   const struct sthip_image_desc* gImage1s;
   uint32_t image1_count;
+  /* ByteAddressBuffer gVolumes[] (bdpt.hlsl:35): what InstanceData::volume_index (scene.h:46) and the Medium record's
+   * density / albedo volume indices (Material.hpp:80-87) refer to. Each entry is one NanoVDB grid of type float exactly
+   * as nanovdb::GridHandle holds it (format version 32.3, the NanoVDB the reference vendors). May be NULL / 0. */
+  const struct sthip_volume_desc* gVolumes;
+  uint32_t volume_count;
 } sthip_scene_desc;
 
 /* gFrameParams view arrays (bdpt.hlsl:37-43), filled by BDPT::render (BDPT.cpp:444-467).
@@ -92,6 +102,9 @@ typedef struct sthip_frame_desc {
   const sthip_ViewData* gPrevViews;
   const sthip_TransformData* gPrevInverseViewTransforms;
   uint32_t view_count;
+  /* gViewMediumInstances (bdpt.hlsl:43, filled at BDPT.cpp:456-466): per view the volume instance the camera is inside
+   * of, or 0xFFFF. May be NULL: every camera is outside every medium. */
+  const uint32_t* gViewMediumInstances;
 } sthip_frame_desc;
 
 /* Output images/buffers of the two passes (bdpt.hlsl:44-49, BDPT.cpp:553-558).

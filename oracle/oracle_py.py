@@ -91,6 +91,8 @@ class OracleScene:
             o.gVisibility = wire.ptr(out["visibility"])
             o.gDepth = wire.ptr(out["depth"])
             o.gPrevUVs = wire.ptr(out["prev_uv"])
+        if self.scene.volumes:
+            frame.view_medium_instances = self.scene.view_medium_instances(frame.view_transforms)
         fd = frame.desc()
         rc = lib().orc_render(
             self.h, C.byref(push_constants), sampling_flags, self.scene.scene_flags, C.byref(fd), seed_begin, seed_count, C.byref(o), threads, wire.ptr(out["stats"])

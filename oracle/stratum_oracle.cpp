@@ -228,6 +228,7 @@ struct Inst {
   uint32_t first_vertex() const { return d.packed[2]; }
   uint32_t indices_byte_offset() const { return d.packed[3]; }
   float radius() const { return det_u2f(d.packed[2]); }  // sphere instances, scene.h:43
+  uint32_t volume_index() const { return d.packed[2]; }  // volume instances, scene.h:46
 };
 
 struct Aabb {
@@ -491,6 +492,7 @@ struct orc_scene {
   std::vector<uint8_t> materials;
   std::vector<uint32_t> lights;
   std::vector<float> distributions;  // gDistributions (dist2.h tables of the environment map)
+  std::vector<NvdbGrid> volumes;     // gVolumes
   std::vector<Mesh> meshes;
   std::vector<uint32_t> inst_mesh;
   std::vector<uint8_t> inst_identity;
@@ -661,6 +663,29 @@ inline bool sphere_test(v3 o, v3 d, float r, float tmin, float tmax, float& t) {
   return true;
 }
 
+// Volume instances (intersection.hlsli:93-113), part of the traversal contract: the ray goes to the object space of the
+// instance, then to the index space of its NanoVDB grid (world_to_indexf / world_to_index_dirf); slabs of the root
+// bounding box [bbox_min, bbox_max + 1]; t is the entry if it lies beyond tmin, else the exit, and a hit needs
+// tmin < t < tmax. The reference runs this for every candidate the driver reports and never checks that the slabs
+// overlap (a ray whose bounding-box test was a conservative false positive would get a hit at the entry slab); the
+// contract requires entry <= exit. Its id is instance | INVALID_PRIMITIVE << 16. `axis_sign` returns the hit face:
+// (t == t1) - (t == t0) per axis, the index-space normal the reference packs into the shading data.
+inline bool volume_test(const NvdbGrid& g, v3 o, v3 d, float tmin, float tmax, float& t, v3* face = nullptr) {
+  const v3 io = g.world_to_index(o), id = g.world_to_index_dir(d);
+  const v3 lo = V3((float)g.bbox_min[0], (float)g.bbox_min[1], (float)g.bbox_min[2]);
+  const v3 hi = V3((float)(g.bbox_max[0] + 1), (float)(g.bbox_max[1] + 1), (float)(g.bbox_max[2] + 1));
+  const v3 t0 = V3((lo.x - io.x) / id.x, (lo.y - io.y) / id.y, (lo.z - io.z) / id.z);
+  const v3 t1 = V3((hi.x - io.x) / id.x, (hi.y - io.y) / id.y, (hi.z - io.z) / id.z);
+  const float near = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+  const float far = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+  if (!(near <= far)) return false;
+  const float tt = near > tmin ? near : far;
+  if (!(tt > tmin && tt < tmax)) return false;
+  t = tt;
+  if (face) *face = V3((tt == t1.x ? 1.0f : 0.0f) - (tt == t0.x ? 1.0f : 0.0f), (tt == t1.y ? 1.0f : 0.0f) - (tt == t0.y ? 1.0f : 0.0f), (tt == t1.z ? 1.0f : 0.0f) - (tt == t0.z ? 1.0f : 0.0f));
+  return true;
+}
+
 // The alpha test of a candidate triangle hit (intersection.hlsli:117-131): the mask of the instance's material
 // (MaterialRecord.alpha_mask_index, read at material_address + 60) sampled at the hit's uv
 // (make_triangle_shading_data's interpolation, shading_data.hlsli:2-6) at level 0 — bilinear, repeat addressing — must
@@ -697,6 +722,18 @@ bool trace_instance(const orc_scene& sc, uint32_t inst_index, const Ray& wr, Hit
     float t;
     n_tris++;
     if (!sphere_test(obj_point(sc.inv_xf[inst_index], wr.o), obj_vector(sc.inv_xf[inst_index], wr.d), in.radius(), wr.tmin, wr.tmax, t)) return false;
+    if (any_hit) {
+      h.ip = 0;
+      return true;
+    }
+    accept(h, t, 0.0f, 0.0f, inst_index | (STHIP_INVALID_PRIMITIVE << 16));
+    return false;
+  }
+  if (in.type() == STHIP_INSTANCE_TYPE_VOLUME) {
+    float t;
+    n_tris++;
+    if (in.volume_index() >= sc.volumes.size()) return false;
+    if (!volume_test(sc.volumes[in.volume_index()], obj_point(sc.inv_xf[inst_index], wr.o), obj_vector(sc.inv_xf[inst_index], wr.d), wr.tmin, wr.tmax, t)) return false;
     if (any_hit) {
       h.ip = 0;
       return true;
@@ -1576,6 +1613,21 @@ float trace_ray(const Frame& fr, v3 origin, v3 direction, float t_max, Intersect
         isect.shape_pdf = 1 / (DET_2PI * (1 - cos_elevation_max));
         isect.shape_pdf_area_measure = false;
       }
+    } else if (in.type() == STHIP_INSTANCE_TYPE_VOLUME) {  // intersection.hlsli:93-113,160-165; make_volume_shading_data, shading_data.hlsli:106-110
+      const uint32_t ii = isect.instance_index();
+      const sthip_TransformData& inv = fr.sc->inv_xf[ii];
+      const v3 oo = obj_point(inv, origin), od = obj_vector(inv, direction);
+      const NvdbGrid& g = fr.sc->volumes[in.volume_index()];
+      float tt;
+      v3 face = V3(0.0f);
+      volume_test(g, oo, od, 0.0f, POS_INF, tt, &face);  // the committed candidate again, for its face
+      const v3 vol_normal = normalize(transform_vector(fr.sc->xf[ii], g.index_to_world_dir(face)));
+      isect.sd.packed_geometry_normal = isect.sd.packed_shading_normal = pack_normal_octahedron(vol_normal);
+      isect.sd.position = transform_point(fr.sc->xf[ii], oo + od * h.t);
+      isect.sd.shape_area = 0;
+      isect.sd.uv_screen_size = 0;
+      isect.shape_pdf = 1;
+      isect.shape_pdf_area_measure = false;
     } else {
       make_triangle_shading_data(*fr.sc, isect.sd, isect.instance_index(), isect.primitive_index(), h.b1, h.b2, fr.flag(STHIP_eFlipTriangleUVs));
       isect.shape_pdf = 1 / (isect.sd.shape_area * (float)in.prim_count());
@@ -1607,6 +1659,7 @@ struct LightSampleRecord {
 };
 inline bool has_environment(const Frame& fr) { return (fr.scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) != 0; }
 inline bool has_emissives(const Frame& fr) { return (fr.scene_flags & STHIP_BDPT_FLAG_HAS_EMISSIVES) != 0; }
+inline bool has_media(const Frame& fr) { return (fr.scene_flags & STHIP_BDPT_FLAG_HAS_MEDIA) != 0; }
 void sample_point_on_light(const Frame& fr, LightSampleRecord& ls, const float rnd[4], v3 ref_pos) {
   const orc_scene& sc = *fr.sc;
   ls.is_environment = false;
@@ -1759,7 +1812,114 @@ inline void project_point(const sthip_ProjectionData& p, v3 v, float r[4]);
 inline float connection_dVC(float dVC, float pdfA_rev, float prev_pdfA_fwd, bool specular) { return ((specular ? 0.0f : 1.0f) + dVC * pow2(pdfA_rev)) / pow2(prev_pdfA_fwd); }
 
 // ---------------------------------------------------------------------------------------------
-// P1-P8 — PathIntegrator (path.hlsli:248-1075), view paths, no media, no environment
+// Medium (materials/medium.hlsli): a heterogeneous participating medium over NanoVDB grids — Henyey-Greenstein phase
+// function and delta tracking against the density grid's root maximum
+// ---------------------------------------------------------------------------------------------
+struct Medium {
+  v3 density_scale, albedo_scale;
+  float anisotropy, attenuation_unit;
+  uint32_t density_volume_index, albedo_volume_index;
+  void load(const orc_scene& sc, uint32_t address) {  // medium.hlsli:12-19, Material.hpp:80-87
+    float f[8];
+    uint32_t u[2];
+    memcpy(f, &sc.materials[address], 32);
+    memcpy(u, &sc.materials[address + 32], 8);
+    density_scale = V3(f[0], f[1], f[2]);
+    anisotropy = f[3];
+    albedo_scale = V3(f[4], f[5], f[6]);
+    attenuation_unit = f[7];
+    density_volume_index = u[0];
+    albedo_volume_index = u[1];
+  }
+  bool can_eval() const { return density_scale.x > 0 || density_scale.y > 0 || density_scale.z > 0; }
+  bool is_specular() const { return fabsf(anisotropy) > 0.999f; }
+  float phase(v3 dir_in, v3 dir_out) const {  // medium.hlsli:26-34
+    return DET_INV_4PI * (1 - anisotropy * anisotropy) / det_powf(1 + anisotropy * anisotropy + 2 * anisotropy * dot(dir_in, dir_out), 1.5f);
+  }
+  // medium.hlsli:35-56; returns dir_out (world space: dir_in is), pdf_fwd = pdf_rev = f
+  v3 sample(float r0, float r1, v3 dir_in, float& pdf, float& roughness) const {
+    v3 dir_out;
+    if (fabsf(anisotropy) < 1e-3f) {
+      const float z = 1 - 2 * r0;
+      const float phi = DET_2PI * r1;
+      float sn, cs;
+      det_sincosf(phi, &sn, &cs);
+      const float rr = sqrtf(fmaxf(0.0f, 1 - z * z));
+      dir_out = V3(rr * cs, rr * sn, z);
+    } else {
+      const float tmp = (anisotropy * anisotropy - 1) / (2 * r0 * anisotropy - (anisotropy + 1));
+      const float cos_elevation = (tmp * tmp - (1 + anisotropy * anisotropy)) / (2 * anisotropy);
+      const float sin_elevation = sqrtf(fmaxf(1 - cos_elevation * cos_elevation, 0.0f));
+      const float azimuth = DET_2PI * r1;
+      float sn, cs;
+      det_sincosf(azimuth, &sn, &cs);
+      v3 t, b;
+      make_orthonormal(dir_in, t, b);
+      dir_out = t * (sin_elevation * cs) + b * (sin_elevation * sn) + dir_in * cos_elevation;
+    }
+    pdf = phase(dir_in, dir_out);
+    roughness = 1 - fabsf(anisotropy);
+    return dir_out;
+  }
+  float density_at(const orc_scene& sc, v3 pos_index) const {
+    return sc.volumes[density_volume_index].value((int32_t)floorf(pos_index.x), (int32_t)floorf(pos_index.y), (int32_t)floorf(pos_index.z));
+  }
+  float albedo_at(const orc_scene& sc, v3 pos_index) const {
+    if (albedo_volume_index == 0xFFFFFFFFu) return 1;
+    return sc.volumes[albedo_volume_index].value((int32_t)floorf(pos_index.x), (int32_t)floorf(pos_index.y), (int32_t)floorf(pos_index.z));
+  }
+  // delta_track, medium.hlsli:74-127. origin / direction in the object space of the volume instance (= the grid's world
+  // space). Returns true with the scatter position (grid world space, as upstream returns it) when a real collision
+  // happens; a null collision ends the walk (upstream returns after the first one).
+  bool delta_track(const orc_scene& sc, Rng& rng, v3 origin, v3 direction, float t_max, v3& beta, v3& dir_pdf, v3& nee_pdf, bool can_scatter, uint32_t max_null_collisions, v3& scatter_p) const {
+    const NvdbGrid& g = sc.volumes[density_volume_index];
+    const v3 majorant = density_scale * g.root_max();
+    const uint32_t channel = rng.next_uint() % 3u;
+    const float maj_c = channel == 0 ? majorant.x : (channel == 1 ? majorant.y : majorant.z);
+    if (maj_c < 1e-6f) return false;
+    origin = g.world_to_index(origin);
+    direction = g.world_to_index_dir(direction);
+    for (uint32_t iteration = 0; iteration < max_null_collisions && any_gt0(beta); iteration++) {
+      const float r0 = rng.next_float(), r1 = rng.next_float();
+      const float t = attenuation_unit * -det_logf(1 - r0) / maj_c;
+      if (t < t_max) {
+        origin = origin + direction * t;
+        t_max -= t;
+        const v3 local_density = density_scale * density_at(sc, origin);
+        const v3 local_albedo = albedo_scale * albedo_at(sc, origin);
+        const v3 local_sigma_s = local_density * local_albedo;
+        const v3 local_sigma_a = local_density * (V3(1.0f) - local_albedo);
+        const v3 local_sigma_t = local_sigma_s + local_sigma_a;
+        const v3 real_prob = V3(local_sigma_t.x / majorant.x, local_sigma_t.y / majorant.y, local_sigma_t.z / majorant.z);
+        const float max_maj = fmaxf(fmaxf(majorant.x, majorant.y), majorant.z);
+        const v3 tr = V3(det_expf(-majorant.x * t), det_expf(-majorant.y * t), det_expf(-majorant.z * t)) / max_maj;
+        const float rp_c = channel == 0 ? real_prob.x : (channel == 1 ? real_prob.y : real_prob.z);
+        if (can_scatter && r1 < rp_c) {  // real particle
+          beta = beta * (tr * local_sigma_s);
+          dir_pdf = dir_pdf * (tr * majorant * real_prob);
+          scatter_p = g.index_to_world(origin);
+          return true;
+        } else {  // fake particle
+          beta = beta * (tr * (majorant - local_sigma_t));
+          dir_pdf = dir_pdf * (tr * majorant * (V3(1.0f) - real_prob));
+          nee_pdf = nee_pdf * (tr * majorant);
+          return false;
+        }
+      } else {  // transmitted without scattering
+        const v3 tr = V3(det_expf(-majorant.x * t_max), det_expf(-majorant.y * t_max), det_expf(-majorant.z * t_max));
+        beta = beta * tr;
+        nee_pdf = nee_pdf * tr;
+        dir_pdf = dir_pdf * tr;
+        break;
+      }
+    }
+    return false;
+  }
+};
+inline float average3(v3 x) { return (x.x + x.y + x.z) / 3; }
+
+// ---------------------------------------------------------------------------------------------
+// P1-P8 — PathIntegrator (path.hlsli:248-1075), view paths
 // ---------------------------------------------------------------------------------------------
 struct PathIntegrator {
   const Frame& fr;
@@ -1779,6 +1939,8 @@ struct PathIntegrator {
   float path_pdf, path_pdf_rev, dVC;
   bool prev_specular;
   bool trace_light;                         // gTraceLight: this is a light subpath (sample_photons)
+  uint32_t medium = STHIP_INVALID_INSTANCE; // _medium: the volume instance the path is inside of
+  float T_nee_pdf = 1;                      // path.hlsli:282
   v3 radiance;                              // accumulate_contribution target (path.hlsli:300-304)
   sthip_ShadowRayData shadow_rays[32];      // this pixel's gShadowRays slots (path.hlsli:65,355-364)
   uint32_t max_shadow;
@@ -1825,11 +1987,22 @@ struct PathIntegrator {
   // path.hlsli:1003-1044
   void trace() {
     rays_path++;
-    rays_total++;
-    trace_ray(fr, origin, direction, POS_INF, isect, false, counters);
-    if (all_le0(beta)) {
+    float T_dir_pdf = 1;
+    T_nee_pdf = 1;
+    if (has_media(fr)) {
+      trace_ray_media(T_dir_pdf);
+    } else {
+      rays_total++;
+      trace_ray(fr, origin, direction, POS_INF, isect, false, counters);
+    }
+    if (T_dir_pdf <= 0 || all_le0(beta)) {
       beta = V3(0.0f);
       return;
+    }
+    if (has_media(fr)) {  // path.hlsli:1009-1011 (T_dir_pdf = 1 without media)
+      beta = beta / T_dir_pdf;
+      if (!fr.flag(STHIP_eDeferShadowRays)) bsdf_pdf *= T_dir_pdf;
+      path_pdf *= T_dir_pdf;
     }
     path_length++;
     if (isect.instance_index() == STHIP_INVALID_INSTANCE) {
@@ -1843,9 +2016,83 @@ struct PathIntegrator {
       isect.sd.uv_screen_size *= rd_radius;
     }
     G = 1 / dist2;
-    ngdotin = -dot(direction, isect.sd.geometry_normal());
-    G *= fabsf(ngdotin);
+    if (has_media(fr) && isect.sd.shape_area == 0) {  // a vertex inside a medium, path.hlsli:1035-1036
+      ngdotin = 1;
+    } else {
+      ngdotin = -dot(direction, isect.sd.geometry_normal());
+      G *= fabsf(ngdotin);
+    }
     path_pdf *= bsdf_pdf * G;  // pdfWtoA, path.hlsli:1042
+  }
+
+  // the medium-aware trace_ray, intersection.hlsli:240-285: up to 64 segments between volume boundaries, delta tracking
+  // inside the current medium over each segment
+  void trace_ray_media(float& T_dir_pdf) {
+    v3 o = origin;
+    Medium m;
+    if (medium != STHIP_INVALID_INSTANCE) m.load(*fr.sc, fr.sc->instances[medium].material_address());
+    for (uint32_t steps = 0; steps < 64; steps++) {
+      rays_total++;
+      const float dt = trace_ray(fr, o, direction, POS_INF, isect, false, counters);
+      if (medium != STHIP_INVALID_INSTANCE) {
+        const sthip_TransformData& inv = fr.sc->inv_xf[medium];
+        v3 dir_pdf = V3(1.0f), nee_pdf = V3(1.0f), scatter_p;
+        const bool scattered = m.delta_track(*fr.sc, rng, transform_point(inv, o), transform_vector(inv, direction), dt, beta, dir_pdf, nee_pdf, true, fr.pc.gMaxNullCollisions, scatter_p);
+        T_dir_pdf *= average3(dir_pdf);
+        T_nee_pdf *= average3(nee_pdf);
+        if (scattered && std::isfinite(scatter_p.x) && std::isfinite(scatter_p.y) && std::isfinite(scatter_p.z)) {
+          isect.instance_primitive_index = medium | (STHIP_INVALID_PRIMITIVE << 16);
+          isect.sd.position = scatter_p;  // grid world space, as upstream stores it
+          isect.sd.shape_area = 0;
+          break;
+        }
+      }
+      if (isect.instance_index() == STHIP_INVALID_INSTANCE || steps == 63) break;
+      const Inst& in = fr.sc->instances[isect.instance_index()];
+      if (in.type() != STHIP_INSTANCE_TYPE_VOLUME) break;
+      if (isect.sd.flags & STHIP_SHADING_FLAG_FRONT_FACE) {  // entering the volume
+        medium = isect.instance_index();
+        m.load(*fr.sc, in.material_address());
+        o = ray_offset(isect.sd.position, -isect.sd.geometry_normal());
+      } else {  // leaving it
+        medium = STHIP_INVALID_INSTANCE;
+        o = ray_offset(isect.sd.position, isect.sd.geometry_normal());
+      }
+    }
+  }
+
+  // trace_visibility_ray with media, intersection.hlsli:192-239: surfaces block, volume boundaries are crossed, the
+  // medium in between attenuates (delta tracking that cannot scatter)
+  void trace_visibility_media(Rng& r, v3 o, v3 d, float t_max, uint32_t cur_medium, v3& contribution, float& T_nee) {
+    Medium m;
+    if (cur_medium != STHIP_INVALID_INSTANCE) m.load(*fr.sc, fr.sc->instances[cur_medium].material_address());
+    while (t_max > 1e-6f) {
+      IntersectionVertex sh = isect;  // a scratch vertex (its untouched fields do not matter)
+      rays_total++;
+      const float dt = trace_ray(fr, o, d, t_max, sh, false, counters);
+      if (!std::isinf(t_max)) t_max -= dt;
+      if (sh.instance_index() == STHIP_INVALID_INSTANCE) break;
+      const Inst& in = fr.sc->instances[sh.instance_index()];
+      if (in.type() != STHIP_INSTANCE_TYPE_VOLUME) {  // a surface
+        contribution = V3(0.0f);
+        T_nee = 0;
+        break;
+      }
+      if (cur_medium != STHIP_INVALID_INSTANCE) {
+        const sthip_TransformData& inv = fr.sc->inv_xf[cur_medium];
+        v3 dir_pdf = V3(1.0f), nee_pdf = V3(1.0f), scatter_p;
+        m.delta_track(*fr.sc, r, transform_point(inv, o), transform_vector(inv, d), dt, contribution, dir_pdf, nee_pdf, false, fr.pc.gMaxNullCollisions, scatter_p);
+        T_nee *= average3(nee_pdf);
+      }
+      if (sh.sd.flags & STHIP_SHADING_FLAG_FRONT_FACE) {
+        cur_medium = sh.instance_index();
+        m.load(*fr.sc, in.material_address());
+        o = ray_offset(sh.sd.position, -sh.sd.geometry_normal());
+      } else {
+        cur_medium = STHIP_INVALID_INSTANCE;
+        o = ray_offset(sh.sd.position, sh.sd.geometry_normal());
+      }
+    }
   }
 
   // path.hlsli:847-894
@@ -1988,7 +2235,7 @@ struct PathIntegrator {
         rd.ray_origin[0] = ray_origin.x;
         rd.ray_origin[1] = ray_origin.y;
         rd.ray_origin[2] = ray_origin.z;
-        rd.medium = STHIP_INVALID_INSTANCE;
+        rd.medium = medium;
         rd.ray_direction[0] = ray_direction.x;
         rd.ray_direction[1] = ray_direction.y;
         rd.ray_direction[2] = ray_direction.z;
@@ -2124,6 +2371,74 @@ struct PathIntegrator {
     }
     if (fr.flag(STHIP_eSampleBSDFs) || trace_light) return sample_direction(m);
     return false;
+  }
+
+  // next_vertex(BSDF) for a Medium, path.hlsli:955-998: no emission; stop tests; RR; NEE with the phase function; a
+  // phase-function bounce
+  bool next_vertex_medium(const Medium& m) {
+    if (!m.can_eval() || path_length >= fr.pc.gMaxPathVertices) return false;
+    if (!m.is_specular()) {
+      diffuse_vertices++;
+      if (diffuse_vertices > fr.pc.gMaxDiffuseVertices) return false;
+      if (path_length >= fr.pc.gMinPathVertices)
+        if (!russian_roulette()) return false;
+      if (fr.flag(STHIP_eNEE)) connect_light_medium(m);
+    }
+    if (!fr.flag(STHIP_eSampleBSDFs)) return false;
+    // sample_direction, path.hlsli:898-952, medium branch
+    const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float();
+    (void)r2;
+    float pdf, roughness;
+    const v3 dir_out = m.sample(r0, r1, local_dir_in, pdf, roughness);
+    if (pdf < 1e-6f) {
+      beta = V3(0.0f);
+      return false;
+    }
+    // eta = -1: eta_scale /= 1. Ray cones: RayDifferential::refract with eta = -1 and the (stale) mean curvature of the
+    // last surface hit; pinned to mean_curvature = 0 for a medium vertex
+    if (fr.flag(STHIP_eRayCones)) rd_spread = fmaxf(0.0f, lerpf((rd_spread + 2 * 0.0f * rd_radius) / -1.0f, 0.2f, roughness));
+    {
+      const float G_rev = prev_cos_out / len_sqr(origin - isect.sd.position);
+      if (trace_light || path_length > 2) path_pdf_rev *= pdf * G_rev;
+      dVC = connection_dVC(dVC, pdf * G_rev, bsdf_pdf * G, m.is_specular());
+      prev_specular = m.is_specular();
+    }
+    bsdf_pdf = pdf;
+    origin = isect.sd.position;
+    prev_cos_out = 1;
+    direction = dir_out;
+    return true;
+  }
+
+  // connect_light at a medium vertex, path.hlsli:311-366 with DirectLightSample::setup's medium branch (:207-212):
+  // no ray offset, no distance epsilon, no shading-normal terms; the phase function is f and both pdfs
+  void connect_light_medium(const Medium& m) {
+    const bool presampled = fr.flag(STHIP_ePresampleLights);
+    const LightCandidate cand = light_candidate(presampled, presampled ? rng.next_uint() : 0u);
+    if (all_le0(cand.Le) && cand.pdfA < 1e-6f) return;
+    const float f = m.phase(local_dir_in, cand.ray_direction);
+    const float pdfA_fwd = f * cand.G;
+    if (pdfA_fwd < 1e-6f) return;
+    const v3 contrib = cand.Le * f * cand.G / cand.pdfA;
+    if (all_le0(contrib)) return;
+    float weight = 1;
+    if (fr.flag(STHIP_eSampleBSDFs)) weight = mis2(fr, cand.pdfA, pdfA_fwd);
+    const v3 c = beta * contrib * weight;
+    if (diffuse_vertices >= 1 && diffuse_vertices <= max_shadow) {
+      sthip_ShadowRayData& rd = shadow_rays[diffuse_vertices - 1];
+      rd.contribution[0] = c.x;
+      rd.contribution[1] = c.y;
+      rd.contribution[2] = c.z;
+      rd.rng_offset = rng.v[3];
+      rd.ray_origin[0] = isect.sd.position.x;
+      rd.ray_origin[1] = isect.sd.position.y;
+      rd.ray_origin[2] = isect.sd.position.z;
+      rd.medium = medium;
+      rd.ray_direction[0] = cand.ray_direction.x;
+      rd.ray_direction[1] = cand.ray_direction.y;
+      rd.ray_direction[2] = cand.ray_direction.z;
+      rd.ray_distance = cand.ray_distance;
+    }
   }
 
   // path_weight, path.hlsli:16-28
@@ -2318,6 +2633,17 @@ struct PathIntegrator {
       return;
     }
     const uint32_t material_address = fr.sc->instances[isect.instance_index()].material_address();
+    if (has_media(fr) && isect.sd.shape_area == 0) {  // path.hlsli:1062-1066
+      Medium mm;
+      mm.load(*fr.sc, material_address);
+      local_dir_in = -direction;
+      if (!next_vertex_medium(mm)) {
+        beta = V3(0.0f);
+        return;
+      }
+      trace();
+      return;
+    }
     DisneyMaterial m;
     m.load(*fr.sc, material_address, isect.sd, fr.sampling_flags);
     local_dir_in = normalize(isect.sd.to_local(-direction));
@@ -2408,6 +2734,7 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
     path.rd_spread = fminf(length(dir_dx / dir_dx.z - l), length(dir_dy / dir_dy.z - l));
   }
   path.beta = V3(1.0f);
+  path.medium = (has_media(fr) && fr.fd.gViewMediumInstances) ? fr.fd.gViewMediumInstances[view_index] : STHIP_INVALID_INSTANCE;  // bdpt.hlsl:208
   path.trace();
   path.path_pdf = 1;  // bdpt.hlsl:213-220
   path.path_pdf_rev = 1;
@@ -2435,7 +2762,7 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
       path.eval_emission(env.eval(path.direction));
     }
   } else {
-    {
+    if (!has_media(fr) || path.isect.sd.shape_area > 0) {  // bdpt.hlsl:245: a vertex inside a medium has no albedo / emission
       DisneyMaterial m;
       ShadingData tmp_sd = path.isect.sd;  // bdpt.hlsl:246-251: the first-hit lookup works on a copy
       m.load(*fr.sc, fr.sc->instances[path.isect.instance_index()].material_address(), tmp_sd, fr.sampling_flags);
@@ -2449,6 +2776,8 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
         aov->albedo[3] = 1;
       }
     }
+    const bool medium_vertex = has_media(fr) && path.isect.sd.shape_area == 0;
+    if (medium_vertex) vis.packed_normal = 0;  // upstream stores the stale normal of the last query here; pinned to 0
     if (aov) {
       aov->vis = vis;
       const sthip_TransformData& prev_inv_view = fr.fd.gPrevInverseViewTransforms ? fr.fd.gPrevInverseViewTransforms[view_index] : fr.fd.gInverseViewTransforms[view_index];
@@ -2461,6 +2790,7 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
       aov->depth.dz_dxy[0] = ray_plane(path.origin - path.isect.sd.position, dir_x, gn) - aov->depth.z;
       const v3 dir_y = primary_dir(view, t, (float)x, (float)(y + 1), nullptr);
       aov->depth.dz_dxy[1] = ray_plane(path.origin - path.isect.sd.position, dir_y, gn) - aov->depth.z;
+      if (medium_vertex) aov->depth.dz_dxy[0] = aov->depth.dz_dxy[1] = 0;  // ... and the stale geometry normal here; pinned to 0
       float pc[4];
       project_point(prev_view.projection, prev_cam_pos, pc);
       pc[1] = -pc[1];
@@ -2478,7 +2808,17 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
     const sthip_ShadowRayData& rd = path.shadow_rays[i - 1];
     v3 contribution = V3(rd.contribution[0], rd.contribution[1], rd.contribution[2]);
     if (all_le0(contribution)) continue;
-    if (path.occluded(V3(rd.ray_origin[0], rd.ray_origin[1], rd.ray_origin[2]), V3(rd.ray_direction[0], rd.ray_direction[1], rd.ray_direction[2]), rd.ray_distance))
+    if (has_media(fr)) {
+      Rng r;  // rng_init(pixel_coord, rd.rng_offset), bdpt.hlsl:315
+      r.v[0] = x;
+      r.v[1] = y;
+      r.v[2] = seed;
+      r.v[3] = rd.rng_offset;
+      float nee_pdf = 1;
+      path.trace_visibility_media(r, V3(rd.ray_origin[0], rd.ray_origin[1], rd.ray_origin[2]), V3(rd.ray_direction[0], rd.ray_direction[1], rd.ray_direction[2]), rd.ray_distance, rd.medium,
+                                  contribution, nee_pdf);
+      if (nee_pdf > 0) contribution = contribution / nee_pdf;
+    } else if (path.occluded(V3(rd.ray_origin[0], rd.ray_origin[1], rd.ray_origin[2]), V3(rd.ray_direction[0], rd.ray_direction[1], rd.ray_direction[2]), rd.ray_distance))
       contribution = V3(0.0f);
     c = c + contribution;
   }
@@ -2586,6 +2926,17 @@ orc_scene* orc_scene_create(const sthip_scene_desc* d) {
     sc->images.push_back(std::move(im));
   }
 
+  for (uint32_t i = 0; i < d->volume_count; i++) {  // gVolumes: NanoVDB float grids
+    NvdbGrid g;
+    const uint8_t* b = (const uint8_t*)d->gVolumes[i].data;
+    g.bytes.assign(b, b + d->gVolumes[i].bytes);
+    if (!g.init()) {
+      delete sc;
+      return nullptr;
+    }
+    sc->volumes.push_back(std::move(g));
+  }
+
   // one BLAS per unique mesh range
   std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t> mesh_of;
   sc->inst_mesh.assign(d->instance_count, 0);
@@ -2602,6 +2953,25 @@ orc_scene* orc_scene_create(const sthip_scene_desc* d) {
         const float pad = 1e-3f * r + 1e-5f * fabsf(c);
         inst_boxes[i].lo[a] = c - r - pad;
         inst_boxes[i].hi[a] = c + r + pad;
+      }
+      continue;
+    }
+    if (in.type() == STHIP_INSTANCE_TYPE_VOLUME) {  // the world box of the grid's root bounding box, padded (volume_test decides)
+      if (in.volume_index() >= sc->volumes.size()) {
+        delete sc;
+        return nullptr;
+      }
+      const NvdbGrid& g = sc->volumes[in.volume_index()];
+      for (int c = 0; c < 8; c++) {
+        const v3 ip = V3((float)((c & 1) ? g.bbox_max[0] + 1 : g.bbox_min[0]), (float)((c & 2) ? g.bbox_max[1] + 1 : g.bbox_min[1]), (float)((c & 4) ? g.bbox_max[2] + 1 : g.bbox_min[2]));
+        const v3 wp = transform_point(sc->xf[i], g.index_to_world(ip));
+        const float w[3] = {wp.x, wp.y, wp.z};
+        inst_boxes[i].grow(w);
+      }
+      for (int a = 0; a < 3; a++) {
+        const float pad = 1e-3f * (inst_boxes[i].hi[a] - inst_boxes[i].lo[a]) + 1e-5f * std::max(fabsf(inst_boxes[i].lo[a]), fabsf(inst_boxes[i].hi[a]));
+        inst_boxes[i].lo[a] -= pad;
+        inst_boxes[i].hi[a] += pad;
       }
       continue;
     }
@@ -2707,7 +3077,13 @@ void trace_light_paths(const Frame& fr, uint32_t seed, int threads, uint64_t* ts
 int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin,
                uint32_t seed_count, const sthip_outputs* out, int threads, uint64_t* stats_out) {
   if (!sc || !pc || !frame || !out || !out->gRadiance || !frame->gViews || !frame->gViewTransforms) return STHIP_ERR_INVALID_ARGUMENT;
-  if (scene_flags & (STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT)) return STHIP_ERR_UNSUPPORTED;
+  if (scene_flags & STHIP_BDPT_FLAG_TRACE_LIGHT) return STHIP_ERR_UNSUPPORTED;
+  if (scene_flags & STHIP_BDPT_FLAG_HAS_MEDIA) {
+    // with media every visibility ray draws random numbers: inline ones (NEE without eDeferShadowRays, the connections of
+    // eConnectToViews / eConnectToLightPaths) would advance the path's own stream mid-vertex; only the deferred form is restated
+    if ((sampling_flags & (1u << STHIP_eNEE)) && !(sampling_flags & (1u << STHIP_eDeferShadowRays))) return STHIP_ERR_UNSUPPORTED;
+    if (sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eNEEReservoirs))) return STHIP_ERR_UNSUPPORTED;
+  }
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
   const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) |
                                (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
@@ -2797,6 +3173,7 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
       for (uint32_t s = 0; s < seed_count; s++) {
         float rgb[3];
         PixelAOV aov;
+        memset(&aov, 0, sizeof(aov));  // fields a first vertex inside a medium leaves unwritten (albedo) read as zero
         const bool want_aov = (s == 0) && (out->gAlbedo || out->gVisibility || out->gDepth || out->gPrevUVs);
         Frame sf = fr;
         if (fr.flag(STHIP_eConnectToViews)) sf.light_trace = light_images[s].data();

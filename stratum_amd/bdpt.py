@@ -140,7 +140,8 @@ class BDPT:
             pc.gEnvironmentSampleProbability = 0.0
         if pc.gLightCount == 0:
             pc.gEnvironmentSampleProbability = 1.0
-        pc.gMaxNullCollisions = 0
+        if not (self._scene.scene_flags & wire.BDPT_FLAG_HAS_MEDIA):  # BDPT.cpp:497-500
+            pc.gMaxNullCollisions = 0
         return pc
 
     # ---- BDPT::render ----
@@ -152,6 +153,8 @@ class BDPT:
         if self._scene is None:
             raise StratumHipError("BDPT.render before BDPT.update(scene)")
         pc = self.push_constants(frame)
+        if self._scene.volumes:  # gViewMediumInstances, BDPT.cpp:456-466
+            frame.view_medium_instances = self._scene.view_medium_instances(frame.view_transforms)
         fd = frame.desc()
         o = wire.Outputs()
         out = None

@@ -106,4 +106,6 @@ class Frame:
         d.gPrevViews = wire.ptr(self.prev.views) if self.prev is not None else None
         d.gPrevInverseViewTransforms = wire.ptr(self.prev.inverse_view_transforms) if self.prev is not None else None
         d.view_count = self.views.shape[0]
+        self._view_media = getattr(self, "view_medium_instances", None)
+        d.gViewMediumInstances = wire.ptr(self._view_media) if self._view_media is not None else None
         return d

@@ -54,6 +54,10 @@ struct sthip_ctx {
   bool textured = false;      // some material binds an image: k_shade<true> (ray cones, image values, normal maps)
   bool has_alpha = false;     // some triangle material has an alpha mask (gImage1s)
   bool has_spheres = false;   // some instance is a sphere: k_shade<., true>
+  bool has_volumes = false;   // some instance is a volume (a Medium): the media instantiations
+  uint32_t volume_count = 0, volume_instances = 0;
+  DevBuf<uint32_t> volume_words;
+  DevBuf<DeviceVolume> volumes;
   std::vector<uint8_t> materials_host;                    // gMaterialData as uploaded (validation of the environment record)
   std::vector<std::pair<uint32_t, uint32_t>> image_dims;  // (width, height) of gImages
   uint32_t distribution_count = 0;
@@ -76,7 +80,8 @@ struct sthip_ctx {
   uint64_t bvh_nodes = 0, bvh_tris = 0;
   // frame
   DevBuf<uint8_t> views;  // gViews | gViewTransforms | gPrevViews | gPrevInverseViewTransforms
-  DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays, light_vertices, conn;
+  DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays, light_vertices, conn, media_state, shadow_hit, shadow_ext, shadow_result;
+  DevBuf<uint32_t> view_medium;
   DevBuf<uint32_t> meta, queue0, queue1;
   DevBuf<unsigned long long> counters;
   DevBuf<float> distributions;  // gDistributions
@@ -117,7 +122,7 @@ struct sthip_ctx {
 
 static void fill_counter_stats(sthip_ctx* ctx, const unsigned long long* c) {
   ctx->stats.rays_total = c[CNT_RAYS_CLOSEST] + c[CNT_RAYS_SHADOW];
-  ctx->stats.rays_path = c[CNT_RAYS_CLOSEST];
+  ctx->stats.rays_path = c[CNT_RAYS_CLOSEST] - c[CNT_CROSSINGS];
   ctx->stats.rays_shadow = c[CNT_RAYS_SHADOW];
   ctx->stats.nodes_visited = c[CNT_NODES];
   ctx->stats.tris_tested = c[CNT_TRIS];
@@ -181,6 +186,8 @@ void sthip_destroy(sthip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   ctx->vertices.release();
+  ctx->volume_words.release();
+  ctx->volumes.release();
   ctx->indices.release();
   ctx->instances.release();
   ctx->xf.release();
@@ -204,6 +211,11 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->accum.release();
   ctx->shadow_rays.release();
   ctx->light_vertices.release();
+  ctx->media_state.release();
+  ctx->shadow_hit.release();
+  ctx->shadow_ext.release();
+  ctx->shadow_result.release();
+  ctx->view_medium.release();
   ctx->conn.release();
   ctx->meta.release();
   ctx->queue0.release();
@@ -309,6 +321,13 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   // materials: constant values or image values over gImages (image_value.h:183-207)
   for (uint32_t i = 0; i < s->instance_count; i++) {
     const uint32_t addr = s->gInstances[i].packed[0] >> 4;
+    if ((s->gInstances[i].packed[0] & 0xF) == STHIP_INSTANCE_TYPE_VOLUME) {  // a Medium record (Material.hpp:80-87), 40 bytes
+      if ((size_t)addr + 40 > s->material_bytes || (addr & 3)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: medium material_address out of range");
+      uint32_t vol[2];
+      memcpy(vol, (const uint8_t*)s->gMaterialData + addr + 32, 8);
+      if (vol[0] >= s->volume_count || (vol[1] != 0xFFFFFFFFu && vol[1] >= s->volume_count)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: a medium refers to a volume that is not in gVolumes");
+      continue;
+    }
     if ((size_t)addr + sizeof(sthip_MaterialRecord) > s->material_bytes) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: material_address out of range");
     sthip_MaterialRecord rec;
     memcpy(&rec, (const uint8_t*)s->gMaterialData + addr, sizeof(rec));
@@ -332,6 +351,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->textured = any_image;
   if (s->image_count && !s->gImages) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: image_count > 0 but gImages is NULL");
   if (s->image1_count && !s->gImage1s) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: image1_count > 0 but gImage1s is NULL");
+  if (s->volume_count && !s->gVolumes) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: volume_count > 0 but gVolumes is NULL");
   sthip::BuiltBvh built;
   std::string err;
   const auto t_build0 = std::chrono::steady_clock::now();
@@ -455,6 +475,28 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     ctx->bvh.alpha_test = 0;
     ctx->bvh.flip_uvs = 0;
   }
+  {  // gVolumes: the grids back to back as 32-bit words, and their parsed headers
+    size_t words = 0;
+    for (uint32_t i = 0; i < s->volume_count; i++) {
+      built.volumes[i].first_word = (uint32_t)words;
+      words += (size_t)(s->gVolumes[i].bytes / 4);
+    }
+    if (words > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: gVolumes exceed 16 GiB");
+    HIP_TRY(ctx, ctx->volume_words.ensure(std::max<size_t>(1, words)));
+    HIP_TRY(ctx, ctx->volumes.ensure(std::max<size_t>(1, built.volumes.size())));
+    for (uint32_t i = 0; i < s->volume_count; i++)
+      HIP_TRY(ctx, hipMemcpy(ctx->volume_words.p + built.volumes[i].first_word, s->gVolumes[i].data, (size_t)s->gVolumes[i].bytes, hipMemcpyHostToDevice));
+    if (!built.volumes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->volumes.p, built.volumes.data(), built.volumes.size() * sizeof(DeviceVolume), hipMemcpyHostToDevice));
+    ctx->volume_count = s->volume_count;
+    ctx->has_volumes = false;
+    ctx->volume_instances = 0;
+    for (uint32_t i = 0; i < n; i++)
+      if ((s->gInstances[i].packed[0] & 0xF) == STHIP_INSTANCE_TYPE_VOLUME) {
+        ctx->has_volumes = true;
+        ctx->volume_instances++;
+      }
+    ctx->bvh.volumes = ctx->volumes.p;
+  }
   ctx->bvh.nodes = reinterpret_cast<const float4*>(ctx->nodes.p);
   ctx->bvh.tris = reinterpret_cast<const float4*>(ctx->tris.p);
   ctx->bvh.entries = ctx->entries.p;
@@ -555,9 +597,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (pc->gViewCount != frame->view_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: gViewCount != frame.view_count");
   if ((out->gDepth || out->gPrevUVs) && !frame->gInverseViewTransforms && !frame->gPrevInverseViewTransforms)
     return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: depth / prev-uv outputs need gInverseViewTransforms");
-  // Outside the built hot path: media, light tracing, reservoirs, ...
-  if (scene_flags & (STHIP_BDPT_FLAG_HAS_MEDIA | STHIP_BDPT_FLAG_TRACE_LIGHT))
-    return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media / light-tracing scene flags are not part of the built hot path");
+  // BDPT_FLAG_TRACE_LIGHT is a per-kernel specialisation of the reference (sample_photons), never a caller's choice
+  if (scene_flags & STHIP_BDPT_FLAG_TRACE_LIGHT) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: BDPT_FLAG_TRACE_LIGHT is not a scene flag a caller sets");
   const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) |
                                (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
                                (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
@@ -591,6 +632,19 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     }
   }
 
+  // participating media (BDPT_FLAG_HAS_MEDIA, BDPT.cpp:497-500)
+  if (ctx->has_volumes && !(scene_flags & STHIP_BDPT_FLAG_HAS_MEDIA)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: the scene has volume instances but BDPT_FLAG_HAS_MEDIA is not set");
+  const bool media = ctx->has_volumes;
+  if (media) {
+    // with media every visibility ray draws random numbers; an inline one (NEE without eDeferShadowRays, the connections
+    // of eConnectToViews / eConnectToLightPaths) advances the path's own stream in the middle of a vertex: only the deferred form is built
+    if ((sampling_flags & (1u << STHIP_eNEE)) && !(sampling_flags & (1u << STHIP_eDeferShadowRays)))
+      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media need eDeferShadowRays (inline visibility rays through media are not built)");
+    if (sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eNEEReservoirs)))
+      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media together with light subpaths or NEE reservoirs are not built");
+  } else {
+    pcn.gMaxNullCollisions = 0;
+  }
   const uint32_t W = pc->gOutputExtent[0], H = pc->gOutputExtent[1];
   if (W == 0 || H == 0) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: empty output extent");
   const size_t pixels = (size_t)W * H;
@@ -659,7 +713,16 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   // a vertex queues at most one NEE ray, plus one visibility ray per stored light vertex it connects to
   const size_t shadow_stride = seg_stride * (1 + conn_per_path);
   if (shadow_stride * QUEUE_SEGMENTS > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many shadow rays in flight");
-  HIP_TRY(ctx, ctx->shadow_rays.ensure(3 * shadow_stride * QUEUE_SEGMENTS));
+  const size_t shadow_entries = shadow_stride * QUEUE_SEGMENTS;  // per round; media ping-pong between two such regions
+  HIP_TRY(ctx, ctx->shadow_rays.ensure(3 * shadow_entries * (media ? 2 : 1)));
+  if (media) {
+    if (2 * shadow_entries > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many shadow rays in flight");
+    HIP_TRY(ctx, ctx->media_state.ensure(2 * P));
+    HIP_TRY(ctx, ctx->shadow_hit.ensure(2 * shadow_entries));
+    HIP_TRY(ctx, ctx->shadow_ext.ensure(2 * shadow_entries));
+    HIP_TRY(ctx, ctx->shadow_result.ensure(P * std::max(1u, pc->gMaxDiffuseVertices)));
+    HIP_TRY(ctx, ctx->view_medium.ensure(std::max(1u, frame->view_count)));
+  }
   HIP_TRY(ctx, ctx->meta.ensure(P));
   HIP_TRY(ctx, ctx->queue0.ensure(seg_stride * QUEUE_SEGMENTS));
   HIP_TRY(ctx, ctx->queue1.ensure(seg_stride * QUEUE_SEGMENTS));
@@ -725,6 +788,9 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.scene.image_count = ctx->image_count;
   p.scene.distributions = ctx->distributions.p;
   p.scene.distribution_count = ctx->distribution_count;
+  p.scene.volume_words = ctx->volume_words.p;
+  p.scene.volumes = ctx->volumes.p;
+  p.scene.volume_count = ctx->volume_count;
   p.ray_o = ctx->ray_o.p;
   p.ray_d = ctx->ray_d.p;
   p.hit = ctx->hit.p;
@@ -742,6 +808,20 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.qctl = ctx->qctl.p;
   p.seg_stride = (uint32_t)seg_stride;
   p.shadow_stride = (uint32_t)shadow_stride;
+  p.media = media ? 1u : 0u;
+  if (media) {
+    p.shadow_alt = (uint32_t)shadow_entries;
+    p.media_state = ctx->media_state.p;
+    p.shadow_hit = ctx->shadow_hit.p;
+    p.shadow_ext = ctx->shadow_ext.p;
+    p.shadow_result = ctx->shadow_result.p;
+    p.view_medium = nullptr;
+    if (frame->gViewMediumInstances) {
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->view_medium.p, frame->gViewMediumInstances, (size_t)frame->view_count * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      p.view_medium = ctx->view_medium.p;
+    }
+  }
   p.count_traversal = ctx->count_traversal ? 1u : 0u;
   p.refill_idle = ctx->refill_idle;
   p.inner_min_lanes = ctx->inner_min_lanes;
@@ -816,7 +896,15 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   // rounds beyond that would only be empty launches
   uint32_t max_bounce_rounds = pc->gMaxPathVertices >= 2 ? pc->gMaxPathVertices - 1 : 0;
   if (!ctx->has_specular) max_bounce_rounds = std::min(max_bounce_rounds, pc->gMaxDiffuseVertices + 1);
-  p.rounds = max_bounce_rounds;
+  // media: a trace() call walks from volume boundary to volume boundary, one k_trace round per segment (up to 2 per
+  // volume instance and ray); a shadow ray likewise, so its last segments need rounds of their own after the last bounce.
+  // The queue control words exist for 64 rounds; paths / shadow rays still walking after that are dropped.
+  uint32_t drain_rounds = 0;
+  if (media) {
+    drain_rounds = std::min(8u, 2 * ctx->volume_instances + 1);
+    max_bounce_rounds = std::min<uint64_t>(62 - drain_rounds, (uint64_t)max_bounce_rounds * (1 + 2 * ctx->volume_instances));
+  }
+  p.rounds = max_bounce_rounds + drain_rounds;
   const bool timing = ctx->time_kernels;
   float ms_trace = 0, ms_primary = 0, ms_shade = 0, ms_other = 0;
   uint32_t launches_trace = 0, launches_primary = 0;
@@ -847,15 +935,15 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     // queue sizes and heads are per pass; the ray / traversal counters run over the whole call
     auto reset_queues = [&]() -> int {
       const size_t per_depth = (size_t)QUEUE_SEGMENTS * QCTL_STRIDE * sizeof(unsigned long long);
-      HIP_TRY(ctx, hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 0, 0), 0, (max_bounce_rounds + 1) * per_depth, st));  // the last round's shade appends to depth + 1
-      HIP_TRY(ctx, hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 1, 0), 0, max_bounce_rounds * per_depth, st));
+      HIP_TRY(ctx, hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 0, 0), 0, (max_bounce_rounds + drain_rounds + 1) * per_depth, st));  // the last round's shade appends to depth + 1; k_resolve sums p.rounds of them
+      HIP_TRY(ctx, hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 1, 0), 0, (max_bounce_rounds + drain_rounds + 1) * per_depth, st));
       return STHIP_OK;
     };
     auto trace = [&](uint32_t dc, uint32_t ds) -> int {
       if (dc == TRACE_NONE && ds == TRACE_NONE) return STHIP_OK;
       launches_trace++;
       return timed(ms_trace, [&]() {
-        if (p.bvh.alpha_test) {  // scenes with alpha masks under eAlphaTest: the instantiation that carries the mask lookup
+        if (p.bvh.alpha_test || ctx->has_volumes) {  // alpha masks under eAlphaTest, volume instances: the instantiation that carries them
           if (ctx->count_traversal)
             hipLaunchKernelGGL((k_trace<true, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
           else
@@ -893,7 +981,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
         const uint32_t dc = depth < max_bounce_rounds ? depth : TRACE_NONE;
         const uint32_t ds = depth >= 1 && shadow_rays ? depth - 1 : TRACE_NONE;
         int r;
-        if (!light && depth == 0 && dc == 0 && ctx->packet_primary) {
+        if (!light && depth == 0 && dc == 0 && ctx->packet_primary && !ctx->has_volumes) {
           r = trace_primary();
         } else if (ctx->fuse_trace) {
           r = trace(dc, ds);
@@ -902,10 +990,20 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
           if (!r) r = trace(dc, TRACE_NONE);
         }
         if (r) return r;
+        if (media && ds != TRACE_NONE) {
+          r = timed(ms_shade, [&]() { hipLaunchKernelGGL(k_shadow_media, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, ds); });
+          if (r) return r;
+        }
         if (dc == TRACE_NONE) break;
         r = timed(ms_shade, [&]() { shade(depth); });
         if (r) return r;
       }
+      if (media && shadow_rays)  // the shadow rays still walking after the last bounce
+        for (uint32_t ds = max_bounce_rounds; ds < max_bounce_rounds + drain_rounds; ds++) {
+          int r = trace(TRACE_NONE, ds);
+          if (!r) r = timed(ms_shade, [&]() { hipLaunchKernelGGL(k_shadow_media, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, ds); });
+          if (r) return r;
+        }
       return STHIP_OK;
     };
 
@@ -960,7 +1058,12 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       if (rc) return rc;
     }
     rc = run_rounds(false, nee || connect_paths, [&](uint32_t depth) {
-      if (bdpt) {
+      if (media) {
+        if (ctx->textured)
+          hipLaunchKernelGGL((k_shade<true, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else
+          hipLaunchKernelGGL((k_shade<false, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+      } else if (bdpt) {
         if (ctx->textured)
           hipLaunchKernelGGL((k_shade<true, true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
         else
@@ -990,7 +1093,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (out->gRayCount) {
       out->gRayCount[0] = c[CNT_RAYS_CLOSEST] + c[CNT_RAYS_SHADOW];
-      out->gRayCount[1] = c[CNT_RAYS_CLOSEST];
+      out->gRayCount[1] = c[CNT_RAYS_CLOSEST] - c[CNT_CROSSINGS];
     }
     fill_counter_stats(ctx, c);
     ctx->stats_pending = false;

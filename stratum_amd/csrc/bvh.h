@@ -48,6 +48,7 @@ struct BvhTriUv {
 #define TLAS_ENTRY_TRANSFORMED 0u
 #define TLAS_ENTRY_IDENTITY 1u
 #define TLAS_ENTRY_SPHERE 2u
+#define TLAS_ENTRY_VOLUME 3u  // root = index into DeviceBvh::volumes; tested in place by the instantiations that carry it
 struct TlasEntry {
   float inv[12];      // gInstanceInverseTransforms[instance], row-major 3x4
   uint32_t root;      // index of the BLAS root (always an inner node); unused for a sphere
@@ -56,6 +57,18 @@ struct TlasEntry {
   uint32_t pad;
   float center[3];    // object-space bounding sphere of the mesh: sizes the per-ray box padding
   float radius;       // ... or the radius of the sphere instance (InstanceData::radius, scene.h:43)
+};
+
+// The header of one NanoVDB float grid of gVolumes[], parsed on the host at upload (media.h reads the tree through it)
+struct DeviceVolume {
+  uint32_t first_word;  // the grid's first 32-bit word in DeviceVolumes::words
+  uint32_t bytes;
+  uint32_t root;        // byte address of the root node inside the grid
+  uint32_t pad;
+  int32_t bbox_min[3], bbox_max[3];
+  float root_max, pad1;
+  float matf[9], invmatf[9], vecf[3];
+  float pad2[3];
 };
 
 #ifdef __cplusplus

@@ -260,7 +260,39 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
   out = BuiltBvh();
   const uint32_t BLAS_DEPTH_CAP = 22, TLAS_DEPTH_CAP = 18;
   // ---- validate + classify ----
-  std::vector<uint32_t> merged, separate, spheres;
+  std::vector<uint32_t> merged, separate, spheres, volumes;
+  // gVolumes: NanoVDB float grids, format 32.x (PNanoVDB.h:761-777,904-916,964-968, FLOAT row of the type constants)
+  for (uint32_t i = 0; i < s.volume_count; i++) {
+    const uint8_t* b = (const uint8_t*)s.gVolumes[i].data;
+    const uint64_t n = s.gVolumes[i].bytes;
+    auto rd32 = [&](uint64_t off) { uint32_t v = 0; if (off + 4 <= n) memcpy(&v, b + off, 4); return v; };
+    auto rd64 = [&](uint64_t off) { uint64_t v = 0; if (off + 8 <= n) memcpy(&v, b + off, 8); return v; };
+    auto rdf = [&](uint64_t off) { float v = 0; if (off + 4 <= n) memcpy(&v, b + off, 4); return v; };
+    if (!b || n < 672 + 64 + 64 || n > 0xFFFFFFF0ull || (n & 3) || rd64(0) != 0x304244566f6e614eull || rd32(636) != 1u) {
+      err = "gVolumes entry is not a NanoVDB float grid (magic / grid type / size)";
+      return false;
+    }
+    DeviceVolume v;
+    memset(&v, 0, sizeof(v));
+    v.bytes = (uint32_t)n;
+    const uint64_t root = 672 + rd64(672 + 24);
+    if (root + 64 > n) {
+      err = "gVolumes entry: the root node lies outside the buffer";
+      return false;
+    }
+    v.root = (uint32_t)root;
+    for (int k = 0; k < 3; k++) {
+      v.bbox_min[k] = (int32_t)rd32(root + 4 * k);
+      v.bbox_max[k] = (int32_t)rd32(root + 12 + 4 * k);
+      v.vecf[k] = rdf(296 + 72 + 4 * k);
+    }
+    v.root_max = rdf(root + 36);
+    for (int k = 0; k < 9; k++) {
+      v.matf[k] = rdf(296 + 4 * k);
+      v.invmatf[k] = rdf(296 + 36 + 4 * k);
+    }
+    out.volumes.push_back(v);
+  }
   for (uint32_t i = 0; i < s.instance_count; i++) {
     const InstView in = view(s.gInstances[i]);
     if (in.type == STHIP_INSTANCE_TYPE_SPHERE) {
@@ -277,8 +309,20 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       spheres.push_back(i);
       continue;
     }
+    if (in.type == STHIP_INSTANCE_TYPE_VOLUME) {
+      if (s.gInstances[i].packed[2] >= s.volume_count) {
+        err = "volume instance refers to a volume that is not in gVolumes";
+        return false;
+      }
+      if ((size_t)in.material_address + 40 > s.material_bytes) {
+        err = "instance material_address exceeds gMaterialData";
+        return false;
+      }
+      volumes.push_back(i);
+      continue;
+    }
     if (in.type != STHIP_INSTANCE_TYPE_TRIANGLES) {
-      err = "only triangle and sphere instances are built (volume instances are SURVEY.md §8f N4)";
+      err = "unknown instance type";
       return false;
     }
     if (in.stride != 2 && in.stride != 4) {
@@ -513,6 +557,36 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       const float pad = 1e-3f * r + 1e-5f * fabsf(c);
       wb.lo[a] = c - r - pad;
       wb.hi[a] = c + r + pad;
+    }
+    out.entries.push_back(e);
+    entry_boxes.push_back(wb);
+    scene_box.grow(wb);
+  }
+
+  // volume instances (Scene.cpp:556-590): one top-level entry each, tested in place (volume_test, media.h). The box is
+  // the world box of the grid's root bounding box, padded: volume_test alone decides what is hit.
+  for (uint32_t i : volumes) {
+    TlasEntry e;
+    memset(&e, 0, sizeof(e));
+    memcpy(e.inv, &s.gInstanceInverseTransforms[i], 48);
+    e.root = s.gInstances[i].packed[2];
+    e.id_bits = i;
+    e.identity = TLAS_ENTRY_VOLUME;
+    const DeviceVolume& v = out.volumes[e.root];
+    const sthip_TransformData& xf = s.gInstanceTransforms[i];
+    Box wb;
+    wb.reset();
+    for (int c = 0; c < 8; c++) {
+      const float ip[3] = {(float)((c & 1) ? v.bbox_max[0] + 1 : v.bbox_min[0]), (float)((c & 2) ? v.bbox_max[1] + 1 : v.bbox_min[1]), (float)((c & 4) ? v.bbox_max[2] + 1 : v.bbox_min[2])};
+      float gw[3], wp[3];
+      for (int a = 0; a < 3; a++) gw[a] = ip[0] * v.matf[3 * a] + ip[1] * v.matf[3 * a + 1] + ip[2] * v.matf[3 * a + 2] + v.vecf[a];
+      for (int a = 0; a < 3; a++) wp[a] = xf.m[a][0] * gw[0] + xf.m[a][1] * gw[1] + xf.m[a][2] * gw[2] + xf.m[a][3];
+      wb.grow(wp);
+    }
+    for (int a = 0; a < 3; a++) {
+      const float pad = 1e-3f * (wb.hi[a] - wb.lo[a]) + 1e-5f * std::max(fabsf(wb.lo[a]), fabsf(wb.hi[a]));
+      wb.lo[a] -= pad;
+      wb.hi[a] += pad;
     }
     out.entries.push_back(e);
     entry_boxes.push_back(wb);

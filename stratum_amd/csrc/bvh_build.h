@@ -16,6 +16,7 @@ struct BuiltBvh {
   std::vector<BvhTriUv> tri_uvs;  // parallel to tris when some material has an alpha mask, else empty
   std::vector<uint32_t> inst_alpha;  // per instance: gImage1s index of its material's alpha mask or BVH_NO_ALPHA
   std::vector<TlasEntry> entries;
+  std::vector<DeviceVolume> volumes;  // parsed headers of gVolumes (first_word is filled by the uploader)
   uint32_t root_ref = BVH_INVALID_REF;  // inner-node index traversal starts at; BVH_INVALID_REF: empty scene
   uint32_t top_is_world_blas = 1;       // 1: root_ref is the merged world-space mesh, no top level
   uint32_t stack_depth = 4;             // upper bound of the traversal stack height

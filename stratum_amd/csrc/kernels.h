@@ -12,6 +12,7 @@
 #pragma once
 
 #include "shading.h"
+#include "medium.h"
 #include "traverse.h"
 
 #define STHIP_BLOCK 256
@@ -28,7 +29,8 @@ enum {
   CNT_BUSY_ROUNDS = 12, // +1: shadow rays: lanes holding a ray, summed over rounds
   CNT_NODES_PRIMARY = 14,  // the share of CNT_NODES / CNT_TRIS that k_trace_primary (first bounce as wave packets) counted
   CNT_TRIS_PRIMARY = 15,
-  CNT_TOTAL = 16
+  CNT_CROSSINGS = 16,  // media: closest-hit queries that only carried a path across a volume boundary (no new trace() call)
+  CNT_TOTAL = 20
 };
 
 struct FrameParams {
@@ -71,6 +73,14 @@ struct FrameParams {
   float4* light_vertices;     // gLightPathVertices: per seed in flight gLightPathCount * gMaxDiffuseVertices PathVertex records of 4 x float4 (bdpt.h:108-121)
   float4* conn;               // per view path gMaxDiffuseVertices - 1 pending connection contributions of the last vertex shaded
   uint32_t shadow_stride;     // entries between the segments of shadow_rays (a vertex may queue gMaxDiffuseVertices records)
+  // participating media (BDPT_FLAG_HAS_MEDIA): see the MEDIA instantiation of k_shade and k_shadow_media
+  uint32_t media;
+  uint32_t shadow_alt;        // entries: the shadow records of odd rounds start here in shadow_rays / shadow_ext (ping-pong)
+  float4* media_state;        // per path 2 x float4: (vertex origin xyz, T_dir_pdf) (T_nee_pdf, bits(medium), bits(segments), 0)
+  float4* shadow_hit;         // per shadow record of the round in flight: its closest hit (t, b1, b2, bits(ip))
+  float4* shadow_ext;         // per shadow record: (bits(rng counter), nee_pdf, bits(result entry), 0)
+  float4* shadow_result;      // per path gMaxDiffuseVertices entries: what the NEE ray of diffuse vertex i adds (trace_shadows' c += ...)
+  const uint32_t* view_medium;  // gViewMediumInstances
   float4* presampled;   // gPresampledLights (ePresampleLights): per seed in flight, 2 x float4 per point: (position, bits(packed normal)) (Le, pdfA)
   float4* shadow_rays;  // 3 x float4 per entry: (origin, distance) (direction, bits(slot)) (contribution, 0)
   unsigned long long* counters;  // CNT_* (64-bit each)
@@ -205,6 +215,11 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
     p.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
     p.beta[slot] = make_float4(1, 1, 1, __uint_as_float(0u));
     p.meta[slot] = 1u;  // path_length = 1, diffuse_vertices = 0
+    if (p.media) {  // bdpt.hlsl:208: the medium the camera sits in
+      p.media_state[2 * (size_t)slot] = make_float4(t.r0.w, t.r1.w, t.r2.w, 1.0f);
+      p.media_state[2 * (size_t)slot + 1] = make_float4(1.0f, __uint_as_float(p.view_medium ? p.view_medium[view_index] : 0xFFFFu), __uint_as_float(0u), 0.0f);
+      for (uint32_t k = 0; k < p.pc.gMaxDiffuseVertices; k++) p.shadow_result[(size_t)slot * p.pc.gMaxDiffuseVertices + k] = make_float4(0, 0, 0, 0);
+    }
     if (p.bdpt) p.bdpt[slot] = make_float4(1, 1, 1, fabsf(local_dir.z));  // bdpt.hlsl:172,213-220: path_pdf, path_pdf_rev, dVC, prev_cos_out
   }
 }
@@ -248,6 +263,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
   uint32_t slot = 0;
   f3 contribution = F3s(0.0f);
   bool busy = false;  // this lane holds a ray whose result is not stored yet
+  bool shadow_lane = false;  // ... and it came from the shadow queue
   for (;;) {
     const unsigned long long idle = __ballot(!busy);
     if ((uint32_t)__popcll(idle) >= p.refill_idle || idle == ~0ull) {
@@ -262,18 +278,24 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
             tr.any = false;
             tr.start(p.bvh, stack, xyz(ro), xyz(rd), 0.0f, __builtin_inff());
             busy = true;
+            shadow_lane = false;
           }
         }
       }
       if (work_c.exhausted && !work_s.exhausted) {
-        const uint32_t idx = work_s.take(!busy, ctl_s, p.shadow_stride, 0);
+        uint32_t idx = work_s.take(!busy, ctl_s, p.shadow_stride, 0);
         if (idx != 0xFFFFFFFFu) {
+          if (ALPHA && p.media && (depth_shadow & 1u)) idx += p.shadow_alt;
           const float4 s0 = p.shadow_rays[3 * (size_t)idx], s1 = p.shadow_rays[3 * (size_t)idx + 1], s2 = p.shadow_rays[3 * (size_t)idx + 2];
           slot = __float_as_uint(s1.w);
           contribution = xyz(s2);
-          tr.any = true;
+          // with media a visibility ray is a walk from volume boundary to volume boundary (trace_visibility_ray,
+          // intersection.hlsli:192-239): each segment is a closest-hit query whose result k_shadow_media consumes
+          tr.any = !(ALPHA && p.media);
+          if (ALPHA && p.media) slot = idx;
           tr.start(p.bvh, stack, xyz(s0), xyz(s1), 0.0f, s0.w);
           busy = true;
+          shadow_lane = true;
         }
       }
       if (!__any(busy)) {
@@ -298,7 +320,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
       tr.round(p.bvh, stack, p.inner_min_lanes, cnt[0]);
     }
     if (busy && !tr.active()) {
-      if (!tr.any) {
+      if (ALPHA && p.media && shadow_lane) {
+        p.shadow_hit[slot] = make_float4(tr.hit.t, tr.hit.b1, tr.hit.b2, __uint_as_float(tr.hit.ip));
+      } else if (!tr.any) {
         p.hit[slot] = make_float4(tr.hit.t, tr.hit.b1, tr.hit.b2, __uint_as_float(tr.hit.ip));
       } else if (tr.hit.ip == 0xFFFFFFFFu) {  // unoccluded
         if (slot & 0x80000000u) {
@@ -931,7 +955,13 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
 // emission and environment light sampling. Scenes without them run the instantiation that carries none of it.
 // LT: eConnectToViews is on: the view path carries the BDPT quantities (path_pdf, path_pdf_rev, dVC, prev_specular) and
 // uses the weights of path.hlsli:341-351,870-880 (only instantiated with EXT).
-template <bool TEXTURED, bool EXT, bool LT = false>
+// MEDIA: the scene has volume instances (BDPT_FLAG_HAS_MEDIA). A path's trace() is then a walk from volume boundary to
+// volume boundary (the medium-aware trace_ray, intersection.hlsli:240-285): every k_trace round delivers one segment's
+// closest hit, and this kernel first runs that segment's delta tracking and boundary logic — the path either crosses a
+// boundary (it is queued again with its new origin and medium, no vertex), scatters inside the medium (a medium vertex:
+// phase function instead of a material), or arrives at a surface / leaves the scene as before. Only instantiated with
+// EXT and without LT.
+template <bool TEXTURED, bool EXT, bool LT = false, bool MEDIA = false>
 __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_t depth) {
   // Workgroup b works on segment b % 8 (its XCD's) of the incoming queue and appends to the same segment of the
   // outgoing queues, so a segment never grows. In the first bounce a segment is a contiguous eighth of the slots
@@ -951,7 +981,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
   const uint32_t step = ((gridDim.x - seg + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) * blockDim.x;
   const uint32_t* queue_in = p.queue[depth & 1u] + seg_base;
   uint32_t* queue_out = p.queue[(depth + 1) & 1u] + seg_base;
-  float4* shadow_out = p.shadow_rays + 3 * (size_t)seg * p.shadow_stride;
+  const size_t shadow_base = (size_t)seg * p.shadow_stride + ((MEDIA && (depth & 1u)) ? p.shadow_alt : 0u);
+  float4* shadow_out = p.shadow_rays + 3 * shadow_base;
   unsigned long long* queue_size = &queue_ctl(p.qctl, 0, depth + 1, seg)[QCTL_SIZE];
   unsigned long long* shadow_size = &queue_ctl(p.qctl, 1, depth, seg)[QCTL_SIZE];
   const bool use_nee = flag(p, STHIP_eNEE);
@@ -966,7 +997,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
     uint32_t px, py;
     slot_to_pixel(p, slot, px, py);
     const float4 ro = p.ray_o[slot], rd = p.ray_d[slot], hh = p.hit[slot], bb = p.beta[slot];
-    const f3 origin = xyz(ro), direction = xyz(rd);
+    const f3 seg_origin = xyz(ro), direction = xyz(rd);  // the ray k_trace traced
+    f3 origin = seg_origin;                              // the previous vertex (differs from seg_origin only with MEDIA)
     float bsdf_pdf = ro.w;
     float eta_scale = rd.w;
     f3 beta = xyz(bb);
@@ -988,7 +1020,62 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
       prev_specular = (meta >> 16) & 1u;
     }
     const uint32_t ip = __float_as_uint(hh.w);
-    f3 radiance = depth == 0 ? F3s(0.0f) : xyz(p.radiance[slot]);
+    const bool primary = MEDIA ? path_length == 1 : depth == 0;  // this vertex is the first one of the path
+    uint32_t medium = 0xFFFFu;   // _medium: the volume instance the path is inside of
+    float T_dir_pdf = 1;
+    bool medium_vertex = false;  // the vertex is a scattering event inside `medium`
+    f3 scatter_p = F3s(0.0f);
+    if (MEDIA) {
+      // one step of the medium-aware trace_ray, intersection.hlsli:246-283
+      const float4 m0 = p.media_state[2 * (size_t)slot], m1 = p.media_state[2 * (size_t)slot + 1];
+      origin = xyz(m0);
+      T_dir_pdf = m0.w;
+      float T_nee_pdf = m1.x;
+      medium = __float_as_uint(m1.y);
+      const uint32_t segments = __float_as_uint(m1.z);
+      if (medium != 0xFFFFu) {
+        Medium mm;
+        mm.load(p.scene, load_inst(p.scene, medium).material_address());
+        const Xf inv = load_xf(p.scene.inv_xf, medium);
+        const float im[12] = {inv.r0.x, inv.r0.y, inv.r0.z, inv.r0.w, inv.r1.x, inv.r1.y, inv.r1.z, inv.r1.w, inv.r2.x, inv.r2.y, inv.r2.z, inv.r2.w};
+        f3 dir_pdf = F3s(1.0f), nee_pdf = F3s(1.0f);
+        // transform_point / transform_vector of the inverse instance transform, as the reference writes them
+        const bool scattered = mm.delta_track(p.scene, rng, xf_point(inv, seg_origin), xf_vector(inv, direction), hh.x, beta, dir_pdf, nee_pdf, true, p.pc.gMaxNullCollisions, scatter_p);
+        (void)im;
+        T_dir_pdf *= average3(dir_pdf);
+        T_nee_pdf *= average3(nee_pdf);
+        medium_vertex = scattered && isfinite(scatter_p.x) && isfinite(scatter_p.y) && isfinite(scatter_p.z);
+      }
+      if (!medium_vertex && ip != 0xFFFFFFFFu) {
+        const uint32_t hit_inst = ip & 0xFFFFu;
+        const Inst hin = load_inst(p.scene, hit_inst);
+        if (hin.type() == STHIP_INSTANCE_TYPE_VOLUME) {
+          // a volume boundary: enter or leave, and walk on from the other side of it; no vertex
+          if (segments >= 62u) continue;  // the reference gives up after 64 segments; the rounds of a render end before that
+          f3 bpos;
+          uint32_t bn;
+          volume_boundary(p.scene, hit_inst, hin, seg_origin, direction, hh.x, bpos, bn);
+          const f3 bgn = unpack_normal_octahedron(bn);
+          f3 next_origin;
+          if (dot3(direction, bgn) < 0) {  // SHADING_FLAG_FRONT_FACE: entering
+            medium = hit_inst;
+            next_origin = ray_offset(bpos, -bgn);
+          } else {
+            medium = 0xFFFFu;
+            next_origin = ray_offset(bpos, bgn);
+          }
+          p.ray_o[slot] = make_float4(next_origin.x, next_origin.y, next_origin.z, bsdf_pdf);
+          p.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(rng.counter));
+          p.media_state[2 * (size_t)slot] = make_float4(origin.x, origin.y, origin.z, T_dir_pdf);
+          p.media_state[2 * (size_t)slot + 1] = make_float4(T_nee_pdf, __uint_as_float(medium), __uint_as_float(segments + 1u), 0.0f);
+          const uint32_t k = (uint32_t)atomicAdd(queue_size, 1ull);
+          queue_out[k] = slot;
+          atomicAdd(&p.counters[CNT_CROSSINGS], 1ull);
+          continue;
+        }
+      }
+    }
+    f3 radiance = (!MEDIA && depth == 0) ? F3s(0.0f) : xyz(p.radiance[slot]);
     const bool connect_paths = LT && flag(p, STHIP_eConnectToLightPaths);
     if (connect_paths && depth > 0) {
       // connect_light_subpath's accumulate_contribution calls of the previous vertex (path.hlsli:802-822), whose
@@ -1009,11 +1096,144 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
 
     do {
       // trace(), path.hlsli:1009-1010: the ray was traced (and counted) even if beta died meanwhile
-      if (all_le0(beta)) break;
+      if ((MEDIA && T_dir_pdf <= 0) || all_le0(beta)) break;
+      if (MEDIA) beta = beta / T_dir_pdf;  // path.hlsli:1009 (bsdf_pdf keeps its value with eDeferShadowRays, :1010)
       path_length++;
+      if (MEDIA && medium_vertex) {
+        // ---- a vertex inside a medium: trace()'s tail (path.hlsli:1033-1043) and next_vertex(Medium) (:955-998,1062-1066) ----
+        const uint32_t maddr = load_inst(p.scene, medium).material_address();
+        Medium mm;
+        mm.load(p.scene, maddr);
+        const float dist2 = len_sqr(scatter_p - origin);
+        float G = 1 / dist2;
+        if (primary) {  // bdpt.hlsl:213-220,245-296: no albedo / emission for a medium vertex; the visibility normal and
+          bsdf_pdf = 1;   // the depth derivatives read the stale surface of the last query upstream and are pinned to 0
+          G = 1;
+          if (p.write_aov && seed_index == 0) {
+            const int view_index = get_view_index(p, px, py);
+            if (p.out_visibility) {
+              sthip_VisibilityInfo vis;
+              vis.instance_primitive_index = medium | 0xFFFF0000u;
+              vis.packed_normal = 0;
+              p.out_visibility[pixel] = vis;
+            }
+            const Xf prev_inv_view = load_xf(p.prev_inv_view_xf, (uint32_t)view_index);
+            const f3 prev_cam_pos = xf_point(xf_mul(prev_inv_view, load_xf(p.scene.motion_xf, medium)), scatter_p);
+            if (p.out_depth) {
+              sthip_DepthInfo dpt;
+              dpt.z = length3(scatter_p - origin);
+              dpt.prev_z = length3(prev_cam_pos);
+              dpt.dz_dxy[0] = dpt.dz_dxy[1] = 0;
+              p.out_depth[pixel] = dpt;
+            }
+            if (p.out_prev_uv) {
+              float4 pc4 = project_point(p.prev_views[view_index].projection, prev_cam_pos);
+              pc4.y = -pc4.y;
+              pc4.x = pc4.x / pc4.w;
+              pc4.y = pc4.y / pc4.w;
+              p.out_prev_uv[pixel] = make_float2(pc4.x * .5f + .5f, pc4.y * .5f + .5f);
+            }
+          }
+        }
+        if (!(any_gt0(beta) && !any_nan(beta))) break;
+        const f3 local_dir_in = -direction;
+        if (!mm.can_eval() || path_length >= p.pc.gMaxPathVertices) break;
+        if (!mm.is_specular()) {
+          diffuse_vertices++;
+          if (diffuse_vertices > p.pc.gMaxDiffuseVertices) break;
+          if (path_length >= p.pc.gMinPathVertices) {
+            const float rr = luminance3(beta) / eta_scale * 0.95f;
+            if (!(rr >= 1)) {
+              if (rng.next_float() > rr) break;
+              beta = beta / rr;
+            }
+          }
+          if (use_nee) do {
+            // connect_light at a medium vertex, path.hlsli:311-366 with DirectLightSample::setup's medium branch (:207-212):
+            // no ray offset, no distance epsilon, no shading-normal terms; the phase function is f and both pdfs
+            f3 cLe, c_dir;
+            float c_pdfA, c_dist, c_G;
+            if (flag(p, STHIP_ePresampleLights)) {
+              const uint32_t ti = rng.next_uint();
+              uint32_t path_index;
+              if (flag(p, STHIP_eRemapThreads))
+                path_index = ((py >> 2) * ((p.pc.gOutputExtent[0] + 7u) >> 3) + (px >> 3)) * 32u + (py & 3u) * 8u + (px & 7u);
+              else
+                path_index = py * p.pc.gOutputExtent[0] + px;
+              const uint32_t tile_size = p.pc.gLightPresampleTileSize;
+              const uint32_t tile_offset = ((path_index / tile_size) % p.pc.gLightPresampleTileCount) * tile_size;
+              const float4* lp = p.presampled + 2 * ((size_t)seed_index * tile_size * p.pc.gLightPresampleTileCount + tile_offset + ti % tile_size);
+              const float4 l0 = lp[0], l1 = lp[1];
+              cLe = xyz(l1);
+              c_pdfA = l1.w;
+              c_dir = xyz(l0) - scatter_p;
+              const float d2 = len_sqr(c_dir);
+              c_dist = sqrtf(d2);
+              c_dir = c_dir / c_dist;
+              c_G = fabsf(dot3(c_dir, unpack_normal_octahedron(__float_as_uint(l0.w)))) / d2;
+            } else {
+              const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float(), r3 = rng.next_float();
+              LightSample ls;
+              sample_point_on_light<TEXTURED, EXT>(p, has_env, has_emissives, r0, r1, r2, r3, scatter_p, ls);
+              cLe = ls.Le;
+              c_dir = ls.to_light;
+              c_dist = ls.dist;
+              c_pdfA = ls.pdf;
+              if (ls.is_env) {
+                c_G = 1;
+              } else {
+                c_G = fabsf(dot3(c_dir, ls.normal)) / pow2f(c_dist);
+                if (!ls.area_measure) c_pdfA = c_pdfA * c_G;
+              }
+            }
+            if (all_le0(cLe) && c_pdfA < 1e-6f) break;
+            const float f = mm.phase(local_dir_in, c_dir);
+            const float pdfA_fwd = f * c_G;
+            if (pdfA_fwd < 1e-6f) break;
+            const f3 contrib = cLe * f * c_G / c_pdfA;
+            if (all_le0(contrib)) break;
+            float weight = 1;
+            if (sample_bsdfs) weight = mis2(use_mis, c_pdfA, pdfA_fwd);
+            const f3 c = beta * contrib * weight;
+            if (all_le0(c)) break;
+            const uint32_t entry = slot * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
+            if (!(c_dist > 1e-6f)) {  // trace_visibility_ray's loop never runs
+              p.shadow_result[entry] = make_float4(c.x, c.y, c.z, 0.0f);
+              break;
+            }
+            const uint32_t k = (uint32_t)atomicAdd(shadow_size, 1ull);
+            shadow_out[3 * (size_t)k] = make_float4(scatter_p.x, scatter_p.y, scatter_p.z, c_dist);
+            shadow_out[3 * (size_t)k + 1] = make_float4(c_dir.x, c_dir.y, c_dir.z, __uint_as_float(slot));
+            shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, __uint_as_float(medium));
+            p.shadow_ext[shadow_base + k] = make_float4(__uint_as_float(rng.counter), 1.0f, __uint_as_float(entry), 0.0f);
+          } while (0);
+        }
+        if (!sample_bsdfs) break;
+        // sample_direction, path.hlsli:898-952, with the phase function
+        const float s0 = rng.next_float(), s1 = rng.next_float(), s2 = rng.next_float();
+        (void)s2;
+        float ppdf, proughness;
+        const f3 dir_out = mm.sample(s0, s1, local_dir_in, ppdf, proughness);
+        if (ppdf < 1e-6f) break;
+        // eta = -1: eta_scale /= 1; RayDifferential::refract with eta = -1 (mean curvature pinned to 0 for a medium vertex)
+        if (TEXTURED) {
+          const float2 cone = p.cone[slot];
+          rd_radius = cone.x;
+          rd_spread = cone.y;
+          if (flag(p, STHIP_eRayCones)) {
+            rd_radius += rd_spread * sqrtf(dist2);  // path.hlsli:1026-1029
+            rd_spread = fmaxf(0.0f, lerp1((rd_spread + 2 * 0.0f * rd_radius) / -1.0f, 0.2f, proughness));
+          }
+        }
+        bsdf_pdf = ppdf;
+        new_origin = scatter_p;
+        new_direction = dir_out;
+        alive = true;
+        break;
+      }
       if (ip == 0xFFFFFFFFu) {
         // miss: bdpt.hlsl:231-242 at depth 0, path.hlsli:1049-1058 later (no environment)
-        if (depth == 0 && p.write_aov && seed_index == 0) {
+        if (primary && p.write_aov && seed_index == 0) {
           const int view_index = get_view_index(p, px, py);
           const sthip_ViewData& view = p.views[view_index];
           const float ex = (float)(view.image_max[0] - view.image_min[0]), ey = (float)(view.image_max[1] - view.image_min[1]);
@@ -1057,7 +1277,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
       if (EXT && in.type() == STHIP_INSTANCE_TYPE_SPHERE) {  // intersection.hlsli:140-159
         const Xf inv = load_xf(p.scene.inv_xf, inst_index);
         const float im[12] = {inv.r0.x, inv.r0.y, inv.r0.z, inv.r0.w, inv.r1.x, inv.r1.y, inv.r1.z, inv.r1.w, inv.r2.x, inv.r2.y, inv.r2.z, inv.r2.w};
-        const f3 local_hit_pos = obj_point(im, origin) + obj_vector(im, direction) * hh.x;
+        const f3 local_hit_pos = obj_point(im, seg_origin) + obj_vector(im, direction) * hh.x;
         make_sphere_shading_data(p.scene, sd, inst_index, in, local_hit_pos);
         if (flag(p, STHIP_eUniformSphereSampling)) {
           shape_pdf = 1 / sd.shape_area;
@@ -1080,7 +1300,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
       const float ngdotin = -dot3(direction, gn);
       G *= fabsf(ngdotin);
       if (LT) path_pdf *= bsdf_pdf * G;  // path.hlsli:1042
-      if (depth == 0) {  // bdpt.hlsl:213-220
+      if (primary) {  // bdpt.hlsl:213-220
         bsdf_pdf = 1;
         G = 1;
         if (LT) path_pdf = path_pdf_rev = dVC = 1;
@@ -1095,7 +1315,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
           rd_radius += rd_spread * sqrtf(dist2);
           sd.uv_screen_size *= rd_radius;
         }
-        if (depth == 0) {
+        if (primary) {
           // bdpt.hlsl:246-253: the first-hit lookup (emission, albedo, visibility normal) works on a copy of sd,
           // next_vertex() then loads the material again into the real one (path.hlsli:1068): same values
           uint32_t n_copy = sd.packed_shading_normal, t_copy = sd.packed_tangent;
@@ -1139,7 +1359,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
         radiance = radiance + contrib * weight;
       };
 
-      if (depth == 0) {
+      if (primary) {
         eval_emission();  // bdpt.hlsl:253
         if (p.write_aov && seed_index == 0) {
           const int view_index = get_view_index(p, px, py);
@@ -1305,6 +1525,19 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
             const f3 c = beta * contrib * weight;
             // a zero/negative contribution never adds light (bdpt.hlsl:313) and needs no ray
             if (all_le0(c)) break;
+            if (MEDIA) {  // the record of a walk through the media (k_shadow_media); its result lands in its own entry
+              const uint32_t entry = slot * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
+              if (!(ray_distance > 1e-6f)) {
+                p.shadow_result[entry] = make_float4(c.x, c.y, c.z, 0.0f);
+                break;
+              }
+              const uint32_t k = (uint32_t)atomicAdd(shadow_size, 1ull);
+              shadow_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
+              shadow_out[3 * (size_t)k + 1] = make_float4(to_light.x, to_light.y, to_light.z, __uint_as_float(slot));
+              shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, __uint_as_float(medium));
+              p.shadow_ext[shadow_base + k] = make_float4(__uint_as_float(rng.counter), 1.0f, __uint_as_float(entry), 0.0f);
+              break;
+            }
             if (!(ray_distance > 1e-6f)) {
               // trace_visibility_ray's `while (t_max > 1e-6f)` (intersection.hlsli:195) never runs: unoccluded,
               // no ray. This stage sits between shadow stage depth-1 and depth, so adding here keeps the order.
@@ -1452,8 +1685,94 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
       p.meta[slot] = path_length | (diffuse_vertices << 8) | ((LT && prev_specular) ? 1u << 16 : 0u);
       if (LT) p.bdpt[slot] = make_float4(path_pdf, path_pdf_rev, dVC, prev_cos_out);
       if (TEXTURED) p.cone[slot] = make_float2(rd_radius, rd_spread);
+      if (MEDIA) {  // a new trace() starts at this vertex: T_dir_pdf = T_nee_pdf = 1, no segment walked yet
+        p.media_state[2 * (size_t)slot] = make_float4(new_origin.x, new_origin.y, new_origin.z, 1.0f);
+        p.media_state[2 * (size_t)slot + 1] = make_float4(1.0f, __uint_as_float(medium), __uint_as_float(0u), 0.0f);
+      }
       const uint32_t k = (uint32_t)atomicAdd(queue_size, 1ull);
       queue_out[k] = slot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shadow_media: one step of trace_visibility_ray with media (intersection.hlsli:192-239) for every shadow record of
+// round `depth`, after k_trace stored the closest hit of its current segment: a surface ends the walk with nothing,
+// a volume boundary is crossed (delta tracking that cannot scatter over the segment if it ran inside a medium) and the
+// record is queued again for round depth + 1, the end of the ray (or a miss) finishes it: contribution / nee_pdf goes to
+// the record's own entry of shadow_result, which k_resolve sums in the order of trace_shadows (bdpt.hlsl:311-325).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(STHIP_BLOCK) k_shadow_media(FrameParams p, uint32_t depth) {
+  const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
+  const uint32_t n = (uint32_t)queue_ctl(p.qctl, 1, depth, seg)[QCTL_SIZE];
+  const uint32_t first = (blockIdx.x / QUEUE_SEGMENTS) * blockDim.x + threadIdx.x;
+  const uint32_t step = ((gridDim.x - seg + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) * blockDim.x;
+  const size_t in_base = (size_t)seg * p.shadow_stride + ((depth & 1u) ? p.shadow_alt : 0u);
+  const size_t out_base = (size_t)seg * p.shadow_stride + (((depth + 1u) & 1u) ? p.shadow_alt : 0u);
+  unsigned long long* out_size = &queue_ctl(p.qctl, 1, depth + 1, seg)[QCTL_SIZE];
+  for (uint32_t i = first; i < n; i += step) {
+    const size_t r = in_base + i;
+    const float4 s0 = p.shadow_rays[3 * r], s1 = p.shadow_rays[3 * r + 1], s2 = p.shadow_rays[3 * r + 2], ext = p.shadow_ext[r], hh = p.shadow_hit[r];
+    f3 o = xyz(s0);
+    float t_max = s0.w;
+    const f3 d = xyz(s1);
+    const uint32_t slot = __float_as_uint(s1.w);
+    f3 contribution = xyz(s2);
+    uint32_t cur_medium = __float_as_uint(s2.w);
+    float nee_pdf = ext.y;
+    const uint32_t entry = __float_as_uint(ext.z);
+    uint32_t px, py;
+    slot_to_pixel(p, slot, px, py);
+    Rng rng;  // rng_init(pixel_coord, rd.rng_offset), bdpt.hlsl:315
+    rng.x = px;
+    rng.y = py;
+    rng.seed = p.seed + slot / p.paths_per_seed;
+    rng.counter = __float_as_uint(ext.x);
+    const float dt = hh.x;
+    const uint32_t ip = __float_as_uint(hh.w);
+    if (!isinf(t_max)) t_max -= dt;
+    bool done = false;
+    if (ip == 0xFFFFFFFFu) {
+      done = true;
+    } else {
+      const uint32_t hit_inst = ip & 0xFFFFu;
+      const Inst hin = load_inst(p.scene, hit_inst);
+      if (hin.type() != STHIP_INSTANCE_TYPE_VOLUME) {  // a surface: occluded
+        contribution = F3s(0.0f);
+        nee_pdf = 0;
+        done = true;
+      } else {
+        if (cur_medium != 0xFFFFu) {
+          Medium mm;
+          mm.load(p.scene, load_inst(p.scene, cur_medium).material_address());
+          const Xf inv = load_xf(p.scene.inv_xf, cur_medium);
+          f3 dir_pdf = F3s(1.0f), nee3 = F3s(1.0f), scatter_p;
+          mm.delta_track(p.scene, rng, xf_point(inv, o), xf_vector(inv, d), dt, contribution, dir_pdf, nee3, false, p.pc.gMaxNullCollisions, scatter_p);
+          nee_pdf *= average3(nee3);
+        }
+        f3 bpos;
+        uint32_t bn;
+        volume_boundary(p.scene, hit_inst, hin, o, d, dt, bpos, bn);
+        const f3 bgn = unpack_normal_octahedron(bn);
+        if (dot3(d, bgn) < 0) {  // entering
+          cur_medium = hit_inst;
+          o = ray_offset(bpos, -bgn);
+        } else {
+          cur_medium = 0xFFFFu;
+          o = ray_offset(bpos, bgn);
+        }
+        if (!(t_max > 1e-6f)) done = true;
+      }
+    }
+    if (done) {
+      if (nee_pdf > 0) contribution = contribution / nee_pdf;
+      p.shadow_result[entry] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+    } else {
+      const size_t k = out_base + (uint32_t)atomicAdd(out_size, 1ull);
+      p.shadow_rays[3 * k] = make_float4(o.x, o.y, o.z, t_max);
+      p.shadow_rays[3 * k + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(slot));
+      p.shadow_rays[3 * k + 2] = make_float4(contribution.x, contribution.y, contribution.z, __uint_as_float(cur_medium));
+      p.shadow_ext[k] = make_float4(__uint_as_float(rng.counter), nee_pdf, __uint_as_float(entry), 0.0f);
     }
   }
 }
@@ -1483,7 +1802,16 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
     for (uint32_t s = 0; s < p.seeds_in_flight; s++) {
       const uint32_t slot = s * p.paths_per_seed + q;
       float4 r = p.radiance[slot];
-      const float4 c = p.shadow_sum[slot];
+      float4 c = p.shadow_sum[slot];
+      if (p.media) {  // trace_shadows, bdpt.hlsl:311-325: c += the result of the walk of diffuse vertex i, i = 1..gMaxDiffuseVertices
+        c = make_float4(0, 0, 0, 0);
+        for (uint32_t k = 0; k < p.pc.gMaxDiffuseVertices; k++) {
+          const float4 e = p.shadow_result[(size_t)slot * p.pc.gMaxDiffuseVertices + k];
+          c.x = c.x + e.x;
+          c.y = c.y + e.y;
+          c.z = c.z + e.z;
+        }
+      }
       if (p.conn) {  // the light-subpath connections of the path's last vertex (see k_shade)
         const float4* cn = p.conn + (size_t)slot * (p.pc.gMaxDiffuseVertices - 1);
         for (uint32_t k = 0; k + 1 < p.pc.gMaxDiffuseVertices; k++) {
@@ -1525,7 +1853,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
 // gRayCount[0] = every trace_ray call, [1] = path (closest-hit) rays; intersection.hlsli:66, path.hlsli:1006
 __global__ void k_write_ray_count(const unsigned long long* counters, unsigned long long* out) {
   out[0] = counters[CNT_RAYS_CLOSEST] + counters[CNT_RAYS_SHADOW];
-  out[1] = counters[CNT_RAYS_CLOSEST];
+  out[1] = counters[CNT_RAYS_CLOSEST] - counters[CNT_CROSSINGS];  // one per trace() call (path.hlsli:1006), however many segments it walked
 }
 
 // plain ray batches: the traversal contract on its own (sthip_trace_rays)

@@ -24,6 +24,9 @@ struct DeviceScene {
   uint32_t image_count;
   const float* distributions;  // StructuredBuffer<float> gDistributions (environment map tables, dist2.h)
   uint32_t distribution_count;
+  const uint32_t* volume_words;  // ByteAddressBuffer gVolumes[]: the NanoVDB grids back to back
+  const DeviceVolume* volumes;   // their parsed headers (media.h)
+  uint32_t volume_count;
 };
 
 #define STHIP_MAX_MIPS 16

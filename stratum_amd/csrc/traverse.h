@@ -18,6 +18,7 @@
 
 #include "bvh.h"
 #include "device_math.h"
+#include "media.h"
 
 struct DeviceBvh {
   const float4* nodes;  // BvhNode = 4 x float4
@@ -34,6 +35,7 @@ struct DeviceBvh {
   const float* image1_texels;
   uint32_t alpha_test;
   uint32_t flip_uvs;            // gFlipTriangleUVs for the mask lookup
+  const DeviceVolume* volumes;  // gVolumes headers (volume instances are top-level entries tested in place, like spheres)
 };
 struct DeviceImage1 {
   uint32_t offset, w, h, pad;
@@ -291,6 +293,28 @@ struct Traversal {
               return;
             }
             const uint32_t ip = info.y | 0xFFFF0000u;  // instance | INVALID_PRIMITIVE << 16
+            if (t < hit.t || (t == hit.t && hit.ip != 0xFFFFFFFFu && hit_key(ip) < hit_key(hit.ip))) {
+              hit.t = t;
+              hit.b1 = hit.b2 = 0.0f;
+              hit.ip = ip;
+            }
+          }
+          pop(stack);
+          return;
+        }
+        if (ALPHA && info.z == TLAS_ENTRY_VOLUME) {  // a volume instance: the slabs of its grid's bounding box (intersection.hlsli:93-113)
+          if (COUNT) {
+            cnt.tris++;
+            if (first_active_lane()) cnt.tri_slots += 64;
+          }
+          float t;
+          if (volume_test(bvh.volumes[info.x], obj_point(m, o), obj_vector(m, d), tmin, tmax, t)) {
+            if (is_any()) {
+              hit.ip = 0;
+              ref = TRAV_DONE;
+              return;
+            }
+            const uint32_t ip = info.y | 0xFFFF0000u;
             if (t < hit.t || (t == hit.t && hit.ip != 0xFFFFFFFFu && hit_key(ip) < hit_key(hit.ip))) {
               hit.t = t;
               hit.b1 = hit.b2 = 0.0f;

@@ -98,6 +98,7 @@ class SceneData:
         self.images1 = []  # float32 arrays (H, W): Texture2D<float> gImage1s[] (alpha masks)
         self.distributions = np.zeros(0, np.float32)  # StructuredBuffer<float> gDistributions
         self.environment_address = 0xFFFFFFFF  # SceneData::mEnvironmentMaterialAddress, Scene.cpp:631-640
+        self.volumes = []  # uint8 arrays: ByteAddressBuffer gVolumes[] (NanoVDB float grids)
 
     @property
     def light_count(self):
@@ -112,7 +113,23 @@ class SceneData:
         f = wire.BDPT_FLAG_HAS_EMISSIVES if self.light_count else 0
         if self.environment_address != 0xFFFFFFFF:
             f |= wire.BDPT_FLAG_HAS_ENVIRONMENT
+        if self.volumes:  # BDPT.cpp:441,459-460,497-500: any Medium component in the scene
+            f |= wire.BDPT_FLAG_HAS_MEDIA
         return f
+
+    def view_medium_instances(self, view_transforms):
+        """gViewMediumInstances (BDPT.cpp:456-466): per view the volume instance whose grid world box contains the camera."""
+        out = np.full(view_transforms.shape[0], wire.INVALID_INSTANCE, np.uint32)
+        kinds = self.instances["packed"][:, 0] & 0xF
+        for i in np.nonzero(kinds == wire.INSTANCE_TYPE_VOLUME)[0]:
+            grid = self.volumes[int(self.instances["packed"][i, 2])]
+            box = grid[560:608].view(np.float64)  # GridData::mWorldBBox (PNANOVDB_GRID_OFF_WORLD_BBOX)
+            inv = self.inverse_transforms["m"][i].astype(np.float64)
+            for v in range(view_transforms.shape[0]):
+                p = inv[:, :3] @ view_transforms["m"][v][:, 3].astype(np.float64) + inv[:, 3]
+                if np.all(p >= box[:3]) and np.all(p <= box[3:]):
+                    out[v] = i
+        return out
 
     def desc(self):
         d = wire.SceneDesc()
@@ -148,6 +165,13 @@ class SceneData:
         if self.distributions.size:
             d.gDistributions = wire.ptr(self.distributions)
             d.distribution_count = self.distributions.size
+        if self.volumes:
+            self._volume_descs = (wire.VolumeDesc * len(self.volumes))()
+            for i, g in enumerate(self.volumes):
+                self._volume_descs[i].data = wire.ptr(g)
+                self._volume_descs[i].bytes = g.nbytes
+            d.gVolumes = C.cast(self._volume_descs, C.c_void_p)
+            d.volume_count = len(self.volumes)
         return d
 
 
@@ -265,12 +289,30 @@ class SceneBuilder:
         self._spheres.append((material, m, float(radius)))
         return len(self._instances) + len(self._spheres) - 1
 
+    def add_volume(self, grid_bytes):
+        """A NanoVDB float grid (the bytes of a nanovdb::GridHandle) for Medium::density_buffer / albedo_buffer."""
+        if not hasattr(self, "_volumes"):
+            self._volumes, self._media, self._medium_instances = [], [], []
+        self._volumes.append(np.ascontiguousarray(np.frombuffer(bytes(grid_bytes), dtype=np.uint8) if not isinstance(grid_bytes, np.ndarray) else grid_bytes.astype(np.uint8)))
+        return len(self._volumes) - 1
+
+    def add_medium(self, density_volume, density_scale=(1, 1, 1), albedo_scale=(1, 1, 1), anisotropy=0.0, attenuation_unit=1.0, albedo_volume=None, transform=None):
+        """A Medium component (Material.hpp:72-87) on a node: one volume instance of the scene (Scene.cpp:556-590)."""
+        m = np.eye(4) if transform is None else np.asarray(transform, dtype=np.float64)
+        if m.shape == (3, 4):
+            m = np.vstack([m, [0, 0, 0, 1]])
+        rec = (tuple(float(x) for x in density_scale), float(anisotropy), tuple(float(x) for x in albedo_scale), float(attenuation_unit), int(density_volume), albedo_volume)
+        self._media.append(rec)
+        self._medium_instances.append((len(self._media) - 1, m))
+        return len(self._medium_instances) - 1
+
     def set_environment(self, value, image=None):
         """Environment component: constant radiance `value`, or `value` times a lat-long image (environment.h)."""
         self._environment = (np.asarray(value, dtype=np.float32).reshape(3), image)
 
     def build(self):
-        n = len(self._instances) + len(self._spheres)
+        media = getattr(self, "_medium_instances", [])
+        n = len(self._instances) + len(self._spheres) + len(media)
         inst = np.zeros(n, dtype=wire.InstanceData)
         xf = np.zeros(n, dtype=wire.TransformData)
         inv = np.zeros(n, dtype=wire.TransformData)
@@ -351,8 +393,37 @@ class SceneBuilder:
             mot["m"][i] = tmul(t32, inv["m"][i])
         vertices = np.concatenate(self._verts) if self._verts else np.zeros(0, wire.PackedVertexData)
         indices = np.frombuffer(b"".join(self._index_chunks), dtype=np.uint8).copy()
-        # environment material, Scene.cpp:631-640: appended after every instance material, only if its value is not zero
         mat_bytes = np.ascontiguousarray(mats).view(np.uint8).reshape(-1)
+        # media, Scene.cpp:556-590, after every mesh and sphere: Medium::store appends 40 bytes (Material.hpp:80-87), the
+        # volumes get their gVolumes index the first time a stored medium refers to them (density, then albedo)
+        volume_index_of, volume_order = {}, []
+
+        def volume_index(handle):
+            if handle is None:
+                return 0xFFFFFFFF
+            if handle not in volume_index_of:
+                volume_index_of[handle] = len(volume_order)
+                volume_order.append(handle)
+            return volume_index_of[handle]
+
+        for k, (medium, m) in enumerate(media):
+            i = len(self._instances) + len(self._spheres) + k
+            density_scale, anisotropy, albedo_scale, attenuation_unit, density_volume, albedo_volume = self._media[medium]
+            address = mat_bytes.size
+            rec = np.zeros(10, np.uint32)
+            rec[:3] = np.array(density_scale, np.float32).view(np.uint32)
+            rec[3] = np.array([anisotropy], np.float32).view(np.uint32)[0]
+            rec[4:7] = np.array(albedo_scale, np.float32).view(np.uint32)
+            rec[7] = np.array([attenuation_unit], np.float32).view(np.uint32)[0]
+            rec[8] = volume_index(density_volume)
+            rec[9] = volume_index(albedo_volume)
+            mat_bytes = np.concatenate([mat_bytes, rec.view(np.uint8)])
+            m32 = m[:3, :].astype(np.float32)
+            inst["packed"][i] = [(wire.INSTANCE_TYPE_VOLUME | (address << 4)) & 0xFFFFFFFF, 0xFFF, int(rec[8]), 0]  # make_instance_volume, scene.h:71-79
+            xf["m"][i] = m32
+            inv["m"][i] = transform_inverse(m32)
+            mot["m"][i] = tmul(m32, inv["m"][i])
+        # environment material, Scene.cpp:631-640: appended after every instance material, only if its value is not zero
         env_address, dist = 0xFFFFFFFF, np.zeros(0, np.float32)
         if self._environment is not None and np.any(self._environment[0] != 0):
             value, image = self._environment
@@ -386,6 +457,7 @@ class SceneBuilder:
         sd.images1 = [self._images1[h] for h in image1_order]
         sd.distributions = dist
         sd.environment_address = env_address
+        sd.volumes = [self._volumes[h] for h in volume_order]
         return sd
 
 

@@ -73,8 +73,10 @@ def add_chunked(b, part, material, transform=None, index_stride=4, max_tris=MAX_
 # ---------------------------------------------------------------------------------------------
 # config 1/2 — Cornell box (SURVEY.md §8d "Config 1")
 # ---------------------------------------------------------------------------------------------
-def cornell_box():
-    b = SceneBuilder("cornell_box")
+def cornell_box(fog=None, fog_transform=None, density=(3.0, 3.0, 3.0), albedo=(0.9, 0.9, 0.9), anisotropy=0.0):
+    """fog: the bytes of a NanoVDB float grid (e.g. tests/golden/fog_sphere.npz["grid"]) placed in the box as a
+    Medium component: the Cornell box with a cloud in it."""
+    b = SceneBuilder("cornell_box" if fog is None else "foggy_cornell_box")
     white = b.add_material((0.73, 0.73, 0.73))
     red = b.add_material((0.65, 0.05, 0.05))
     green = b.add_material((0.12, 0.45, 0.15))
@@ -105,6 +107,8 @@ def cornell_box():
 
     # ceiling light, slightly below the ceiling, facing down
     wall((-0.24, 0.995, -0.2), (0.24, 0.995, -0.2), (0.24, 0.995, 0.18), (-0.24, 0.995, 0.18), (0, -1, 0), light)
+    if fog is not None:
+        b.add_medium(b.add_volume(fog), density_scale=density, albedo_scale=albedo, anisotropy=anisotropy, transform=fog_transform)
     sc = b.build()
     assert sc.triangle_count == 32
     return sc, {"eye": (0.0, 0.0, 3.9), "target": (0.0, 0.0, 0.0), "fovy": np.radians(39.3)}

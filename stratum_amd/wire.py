@@ -157,7 +157,13 @@ class SceneDesc(C.Structure):
         ("distribution_count", C.c_uint32),
         ("gImage1s", C.c_void_p),
         ("image1_count", C.c_uint32),
+        ("gVolumes", C.c_void_p),
+        ("volume_count", C.c_uint32),
     ]
+
+
+class VolumeDesc(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("bytes", C.c_uint64)]
 
 
 class ImageDesc(C.Structure):
@@ -172,6 +178,7 @@ class FrameDesc(C.Structure):
         ("gPrevViews", C.c_void_p),
         ("gPrevInverseViewTransforms", C.c_void_p),
         ("view_count", C.c_uint32),
+        ("gViewMediumInstances", C.c_void_p),
     ]
 
 
@@ -242,7 +249,7 @@ def default_push_constants(width, height, light_count, view_count=1):
     pc.gMinPathVertices = 4
     pc.gMaxPathVertices = 8
     pc.gMaxDiffuseVertices = 2
-    pc.gMaxNullCollisions = 0
+    pc.gMaxNullCollisions = 64  # BDPT.cpp:62; BDPT::render zeroes it for scenes without media (:497-500)
     pc.gLightPresampleTileSize = 1024
     pc.gLightPresampleTileCount = 128
     pc.gLightPathCount = width * height

@@ -734,3 +734,37 @@ def test_nanovdb_reader_against_the_reference_accessor():
     assert np.array_equal(values.view(np.uint32), g["values"].view(np.uint32))
     assert (values > 0).sum() > 500 and (values == 0).sum() > 1000  # inside the fog, and background / inactive voxels
     assert np.array_equal(maps.view(np.uint32), g["map"][:, 1:, :].view(np.uint32))
+
+
+def _fog_grid():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "fog_sphere.npz"))["grid"]
+
+
+def test_media_furnace():
+    """A cloud with albedo 1 inside a closed cube whose walls all emit L: with BSDF (phase-function) sampling every pixel
+    is exactly L whatever the density and anisotropy — delta tracking, the spectral pdf bookkeeping (T_dir_pdf) and the
+    phase-function sampling conserve energy. An absorbing cloud is darker. With NEE the reference loses energy: a visibility
+    ray from a vertex inside the medium gets no distance epsilon (DirectLightSample::setup, path.hlsli:207-212) and hits
+    the emitter it aims at about every other time; that, and delta tracking ending at its first null collision
+    (medium.hlsli:104-110), are restated, not fixed."""
+    for density, albedo, aniso in ((1.0, 1.0, 0.0), (2.0, 1.0, 0.6), (2.0, 0.5, -0.4)):
+        sc0, _ = scenes.furnace_box(albedo=0.5, emission=1.0)
+        b = sc0.builder
+        b.add_medium(b.add_volume(_fog_grid()), density_scale=(density,) * 3, albedo_scale=(albedo,) * 3, anisotropy=aniso)
+        sc = b.build()
+        o = orc.OracleScene(sc)
+        fr = camera.Frame(24, 24, np.radians(40), (0, 0, 0.95), (0, 0, -1))
+        pc = wire.default_push_constants(24, 24, sc.light_count)
+        pc.gMaxNullCollisions = 64
+        pc.gMaxDiffuseVertices, pc.gMaxPathVertices, pc.gMinPathVertices = 40, 50, 60
+        out = o.render(fr, pc, wire.DEFAULT_SAMPLING_FLAGS & ~wire.flag_mask("eNEE"), 0, 16)
+        r = out["radiance"][..., :3]
+        in_fog = (out["visibility"]["instance_primitive_index"] & 0xFFFF) == sc.instances.shape[0] - 1
+        assert in_fog.mean() > 0.5
+        if albedo == 1.0:
+            assert np.abs(r - 1).max() < 1e-5
+        else:
+            assert r[in_fog].mean() < 0.9
+        nee = o.render(fr, pc, wire.DEFAULT_SAMPLING_FLAGS, 0, 16)["radiance"][..., :3]
+        if albedo == 1.0:
+            assert 0.7 < nee.mean() < 0.95  # the reference's NEE from inside a medium, see above
