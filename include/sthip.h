@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STHIP_ABI_VERSION 4
+#define STHIP_ABI_VERSION 5
 
 typedef struct sthip_ctx sthip_ctx;
 

@@ -384,6 +384,14 @@ struct MaterialResources {
     image1s.push_back(image.get());
     return (uint32_t)image1s.size() - 1;
   }
+  std::vector<const std::vector<uint8_t>*> volumes;  // volume_data_map: NanoVDB buffers in first-use order (gVolumes)
+  uint32_t get_index(const std::shared_ptr<std::vector<uint8_t>>& buffer) {  // image_value.h:49-55
+    if (!buffer) return ~0u;
+    for (size_t i = 0; i < volumes.size(); i++)
+      if (volumes[i] == buffer.get()) return (uint32_t)i;
+    volumes.push_back(buffer.get());
+    return (uint32_t)volumes.size() - 1;
+  }
   std::vector<std::pair<const std::vector<float>*, uint32_t>> distribution_data_map;  // table -> offset in gDistributions
   uint32_t distribution_data_size = 0;
   uint32_t get_index(const component_ptr<Image>& image) {
@@ -452,6 +460,29 @@ struct MeshPrimitive {
 struct SpherePrimitive {  // Scene.hpp:34-37
   component_ptr<Material> mMaterial;
   float mRadius = 1;
+};
+// Material.hpp:72-87: a heterogeneous medium over NanoVDB float grids; the buffers are the bytes of a nanovdb::GridHandle
+struct Medium {
+  float density_scale[3] = {1, 1, 1};
+  float anisotropy = 0;
+  float albedo_scale[3] = {1, 1, 1};
+  float attenuation_unit = 1;
+  std::shared_ptr<std::vector<uint8_t>> density_buffer, albedo_buffer;
+  void store(std::vector<uint32_t>& bytes, MaterialResources& pool) const {
+    auto f = [&](float v) { uint32_t u; std::memcpy(&u, &v, 4); bytes.push_back(u); };
+    for (float v : density_scale) f(v);
+    f(anisotropy);
+    for (float v : albedo_scale) f(v);
+    f(attenuation_unit);
+    bytes.push_back(pool.get_index(density_buffer));
+    bytes.push_back(pool.get_index(albedo_buffer));
+  }
+  // GridData::mWorldBBox (6 doubles at byte 560 of the grid): what worldBBox() returns
+  bool world_bbox(double box[6]) const {
+    if (!density_buffer || density_buffer->size() < 608) return false;
+    std::memcpy(box, density_buffer->data() + 560, 48);
+    return true;
+  }
 };
 
 // dist2.h:80-154 build_distributions for a lat-long RGBA32F image: f(x, y) = luminance * sin(pi (y + 0.5) / H) is a
@@ -591,6 +622,8 @@ class Scene {
     std::vector<Node*> mInstanceNodes;
     MaterialResources mResources;
     std::vector<sthip_image_desc> mImageDescs, mImage1Descs;
+    std::vector<sthip_volume_desc> mVolumeDescs;                          // gVolumes
+    std::vector<std::pair<const Medium*, uint32_t>> mMediumInstances;     // Medium component -> its volume instance (mInstanceTransformMap)
     std::vector<float> mDistributionData;  // gDistributions, Scene.cpp:670-683
     uint32_t mEnvironmentMaterialAddress = ~0u;
     uint32_t mMaterialCount = 0;
@@ -616,6 +649,8 @@ class Scene {
       d.image1_count = (uint32_t)mImage1Descs.size();
       d.gDistributions = mDistributionData.empty() ? nullptr : mDistributionData.data();
       d.distribution_count = (uint32_t)mDistributionData.size();
+      d.gVolumes = mVolumeDescs.empty() ? nullptr : mVolumeDescs.data();
+      d.volume_count = (uint32_t)mVolumeDescs.size();
       return d;
     }
   };
@@ -720,6 +755,26 @@ class Scene {
       sd->mInstanceInverseTransforms.push_back(inv);
       sd->mInstanceMotionTransforms.push_back(tmul(t, inv));
     });
+    // media, Scene.cpp:556-590 (after every sphere): one volume instance per Medium component
+    mNode.root().for_each_descendant<Medium>([&](const component_ptr<Medium>& vol) {
+      if (!vol || !vol->density_buffer) return;
+      const uint32_t material_address = (uint32_t)(sd->mMaterialData.size() * sizeof(uint32_t));
+      sd->mMaterialCount++;
+      vol->store(sd->mMaterialData, sd->mResources);
+      InstanceData inst{};  // make_instance_volume, scene.h:71-79
+      inst.packed[0] = STHIP_INSTANCE_TYPE_VOLUME | (material_address << 4);
+      inst.packed[1] = 0xFFFu;
+      inst.packed[2] = sd->mResources.get_index(vol->density_buffer);
+      const TransformData transform = node_to_world(vol.node());
+      sd->mMediumInstances.emplace_back(vol.get(), (uint32_t)sd->mInstances.size());
+      sd->mInstances.push_back(inst);
+      sd->mInstanceNodes.push_back(&vol.node());
+      const TransformData inv = inverse(transform);
+      sd->mInstanceTransforms.push_back(transform);
+      sd->mInstanceInverseTransforms.push_back(inv);
+      sd->mInstanceMotionTransforms.push_back(tmul(transform, inv));
+    });
+    for (const auto* v : sd->mResources.volumes) sd->mVolumeDescs.push_back(sthip_volume_desc{v->data(), (uint64_t)v->size()});
     // environment material, Scene.cpp:631-640: the first Environment whose value is not zero
     mNode.root().for_each_descendant<Environment>([&](const component_ptr<Environment>& environment) {
       if (environment && !environment->is_zero() && sd->mEnvironmentMaterialAddress == ~0u) {
@@ -849,6 +904,7 @@ class BDPT {
     const sthip_scene_desc d = scene->data()->desc();
     if (sthip_scene_upload(mCtx, &d) != STHIP_OK) throw std::runtime_error(std::string("sthip_scene_upload: ") + sthip_last_error(mCtx));
     mBound = scene->data().get();
+    mBoundData = scene->data();
     mPushConstants.gLightCount = d.light_count;                    // BDPT.cpp:396
     mPushConstants.gEnvironmentMaterialAddress = scene->data()->mEnvironmentMaterialAddress;  // BDPT.cpp:393
   }
@@ -884,7 +940,25 @@ class BDPT {
       scene_flags |= STHIP_BDPT_FLAG_HAS_EMISSIVES;
     else
       pc.gEnvironmentSampleProbability = 1;
-    pc.gMaxNullCollisions = 0;
+    // media: BDPT.cpp:456-466 (the volume instance each camera is inside of) and :497-500
+    std::vector<uint32_t> view_media(views.size(), 0xFFFFu);
+    if (!mBoundData->mMediumInstances.empty()) {
+      scene_flags |= STHIP_BDPT_FLAG_HAS_MEDIA;
+      for (const auto& mi : mBoundData->mMediumInstances) {
+        double box[6];
+        if (!mi.first->world_bbox(box)) continue;
+        const TransformData& inv = mBoundData->mInstanceInverseTransforms[mi.second];
+        for (size_t i = 0; i < views.size(); i++) {
+          const TransformData& vt = views[i].second;
+          double p[3];
+          for (int a = 0; a < 3; a++) p[a] = (double)inv.m[a][0] * vt.m[0][3] + (double)inv.m[a][1] * vt.m[1][3] + (double)inv.m[a][2] * vt.m[2][3] + inv.m[a][3];
+          if (p[0] >= box[0] && p[1] >= box[1] && p[2] >= box[2] && p[0] <= box[3] && p[1] <= box[4] && p[2] <= box[5]) view_media[i] = mi.second;
+        }
+      }
+      f.gViewMediumInstances = view_media.data();
+    } else {
+      pc.gMaxNullCollisions = 0;
+    }
     Frame fr;
     fr.width = width;
     fr.height = height;
@@ -929,6 +1003,7 @@ class BDPT {
   Node& mNode;
   sthip_ctx* mCtx = nullptr;
   const void* mBound = nullptr;
+  std::shared_ptr<Scene::SceneData> mBoundData;
   uint32_t mSamplingFlags = 0;
   BDPTPushConstants mPushConstants;
   uint32_t mFrameNumber = 0;

@@ -549,6 +549,16 @@ def dump_description(path, scene, frame):
             f.write(struct.pack("<I", 1 if image is None else 2))
             f.write(value.astype("<f4").tobytes())
             f.write(struct.pack("<I", 0xFFFFFFFF if image is None else int(image)))
+        volumes, media = getattr(builder, "_volumes", []), getattr(builder, "_medium_instances", [])
+        f.write(struct.pack("<I", len(volumes)))
+        for g in volumes:
+            f.write(struct.pack("<Q", g.nbytes))
+            f.write(g.tobytes())
+        f.write(struct.pack("<I", len(media)))
+        for medium, m in media:
+            density_scale, anisotropy, albedo_scale, attenuation_unit, density_volume, albedo_volume = builder._media[medium]
+            f.write(struct.pack("<3ff3ffII", *density_scale, anisotropy, *albedo_scale, attenuation_unit, density_volume, 0xFFFFFFFF if albedo_volume is None else albedo_volume))
+            f.write(m[:3, :].astype("<f4").tobytes())
         f.write(frame.views.tobytes())
         f.write(frame.view_transforms.tobytes())
         f.write(struct.pack("<II", frame.width, frame.height))

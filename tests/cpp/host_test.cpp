@@ -120,6 +120,28 @@ int main(int argc, char** argv) {
       const uint32_t image = r.get<uint32_t>();
       scene_node.make_child("environment").make_component<Environment>(make_environment(env_kind == 2 ? images.at(image) : component_ptr<Image>(), value[0], value[1], value[2]));
     }
+    // media (Material.hpp:72-87): NanoVDB buffers and one Medium component per volume instance
+    std::vector<std::shared_ptr<std::vector<uint8_t>>> volumes;
+    const uint32_t n_vol = r.get<uint32_t>();
+    for (uint32_t i = 0; i < n_vol; i++) {
+      const uint64_t bytes = r.get<uint64_t>();
+      volumes.push_back(std::make_shared<std::vector<uint8_t>>(r.vec<uint8_t>((size_t)bytes)));
+    }
+    const uint32_t n_med = r.get<uint32_t>();
+    for (uint32_t i = 0; i < n_med; i++) {
+      Medium med;
+      for (float& v : med.density_scale) v = r.get<float>();
+      med.anisotropy = r.get<float>();
+      for (float& v : med.albedo_scale) v = r.get<float>();
+      med.attenuation_unit = r.get<float>();
+      const uint32_t dv = r.get<uint32_t>(), av = r.get<uint32_t>();
+      med.density_buffer = volumes.at(dv);
+      if (av != 0xFFFFFFFFu) med.albedo_buffer = volumes.at(av);
+      const TransformData t = r.get<TransformData>();
+      Node& n = scene_node.make_child("medium" + std::to_string(i));
+      n.make_component<TransformData>(t);
+      n.make_component<Medium>(med);
+    }
     const ViewData view = r.get<ViewData>();
     const TransformData view_xf = r.get<TransformData>();
     const uint32_t W = r.get<uint32_t>(), H = r.get<uint32_t>();
