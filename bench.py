@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bdpt-flag", action="append", default=[], help="as the reference's --bdptFlag (e.g. connecttolightpaths, ~nee); not the headline configuration")
+    ap.add_argument("--max-diffuse-vertices", type=int, default=None)
     args = ap.parse_args()
 
     import torch
@@ -105,7 +107,10 @@ def main():
     W, H = args.width, args.height
     sc, cam = scenes.SCENES[args.scene]()
     frame = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
-    r = BDPT(device=local_rank)
+    bargs = {"bdptFlag": args.bdpt_flag}
+    if args.max_diffuse_vertices is not None:
+        bargs["maxDiffuseVertices"] = args.max_diffuse_vertices
+    r = BDPT(device=local_rank, args=bargs)
     r.update(sc)
     r.set_shard(rank, world, 64, 32)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -322,8 +327,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "procedural %s, %d triangles, %dx%d, %d sample(s)/pixel/step, default BDPT flags, pixel-tile shard 64x32 over %d GPU(s)"
-                % (args.scene, sc.triangle_count, W, H, seeds_per_step, world),
+                "workload": "procedural %s, %d triangles, %dx%d, %d sample(s)/pixel/step, %s, pixel-tile shard 64x32 over %d GPU(s)"
+                % (args.scene, sc.triangle_count, W, H, seeds_per_step, "default BDPT flags" if not (args.bdpt_flag or args.max_diffuse_vertices) else "flags %s maxDiffuseVertices %s" % (args.bdpt_flag, args.max_diffuse_vertices), world),
                 "rays_per_step": int(rays_all / args.steps),
                 "parallelism": "tile-shard x%d" % world if world > 1 else "single GPU",
                 "exchange": exchange,
