@@ -768,3 +768,21 @@ def test_media_furnace():
         nee = o.render(fr, pc, wire.DEFAULT_SAMPLING_FLAGS, 0, 16)["radiance"][..., :3]
         if albedo == 1.0:
             assert 0.7 < nee.mean() < 0.95  # the reference's NEE from inside a medium, see above
+
+
+def test_nanovdb_fixture_is_what_the_reference_build_makes(tmp_path):
+    """Where oracle/_ref/nvdb_ref exists (built from the reference's vendored NanoVDB by `make -C oracle ref`), it
+    reproduces the committed fixture byte for byte."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "nvdb_ref")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/nvdb_ref is only built where /root/reference exists")
+    grid, probe = str(tmp_path / "fog.nvdb"), str(tmp_path / "probe.bin")
+    subprocess.check_call([exe, "10", "0.08", "3", grid, probe], stdout=subprocess.DEVNULL)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fog_sphere.npz"))
+    assert np.array_equal(np.fromfile(grid, dtype=np.uint8), g["grid"])
+    raw = np.fromfile(probe, dtype=np.int32)
+    ni, nf, n, m = raw[:4]
+    floats = raw[4 + ni : 4 + ni + nf].view(np.float32)
+    assert np.array_equal(floats[1 : 1 + n].view(np.uint32), g["values"].view(np.uint32))
