@@ -141,7 +141,18 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* scene);
 /* ---- frame: replaces the dispatch sequence of BDPT::render (BDPT.cpp:607-720) ----
  * Renders seeds seed_begin .. seed_begin+seed_count-1 (gRandomSeed = seed, BDPT.cpp:480), one
  * sample per pixel centre per seed (bdpt.hlsl:167), and averages them with the running mean of
- * temporal_accumulation.hlsl:118-131. push_constants->gRandomSeed is ignored. */
+ * temporal_accumulation.hlsl:118-131. push_constants->gRandomSeed is ignored.
+ *
+ * sampling_flags are BDPTFlagBits (bdpt.h:12-44), scene_flags BDPT_FLAG_HAS_* (bdpt.h:46-49) as BDPT::render
+ * resolves them (BDPT.cpp:486-541). Built: the default view-path integrator and, per flag, eAlphaTest, eNormalMaps,
+ * eRayCones, eFlip*, eShadingNormalShadowFix, eUniformSphereSampling, eSampleEnvironmentMapDirectly, ePresampleLights,
+ * eNEEReservoirs (without reuse), eConnectToViews (sample_photons + add_light_trace), eConnectToLightPaths (without
+ * the light vertex cache), and BDPT_FLAG_HAS_MEDIA (volume instances over gVolumes). Rejected with
+ * STHIP_ERR_UNSUPPORTED, never ignored: eLVC*, eNEEReservoirReuse (their results depend on the order of atomics
+ * upstream), eSampleLightPower (reads an uninitialised table upstream), eCoherentSampling, and the combinations
+ * DESIGN.md section 7 lists (media need eDeferShadowRays; light subpaths exclude environments and reservoirs).
+ * eCoherentRR and ePerformanceCounters do not change results here; eRemapThreads only through the path index
+ * (map_pixel_coord, bdpt_util.hlsli:76-83) that ePresampleLights and the light subpaths key on. */
 int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* push_constants, uint32_t sampling_flags,
                  uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin, uint32_t seed_count,
                  const sthip_outputs* outputs);
