@@ -1104,11 +1104,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_
         const uint32_t maddr = load_inst(p.scene, medium).material_address();
         Medium mm;
         mm.load(p.scene, maddr);
-        const float dist2 = len_sqr(scatter_p - origin);
-        float G = 1 / dist2;
+        const float dist2 = len_sqr(scatter_p - origin);  // G = 1 / dist2 (no cosine, path.hlsli:1035-1036) only feeds the BDPT quantities
         if (primary) {  // bdpt.hlsl:213-220,245-296: no albedo / emission for a medium vertex; the visibility normal and
           bsdf_pdf = 1;   // the depth derivatives read the stale surface of the last query upstream and are pinned to 0
-          G = 1;
           if (p.write_aov && seed_index == 0) {
             const int view_index = get_view_index(p, px, py);
             if (p.out_visibility) {
