@@ -56,6 +56,7 @@ struct sthip_ctx {
   bool has_spheres = false;   // some instance is a sphere: k_shade<., true>
   bool has_volumes = false;   // some instance is a volume (a Medium): the media instantiations
   uint32_t volume_count = 0, volume_instances = 0;
+  std::vector<uint8_t> instance_is_volume;
   DevBuf<uint32_t> volume_words;
   DevBuf<DeviceVolume> volumes;
   std::vector<uint8_t> materials_host;                    // gMaterialData as uploaded (validation of the environment record)
@@ -490,10 +491,12 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     ctx->volume_count = s->volume_count;
     ctx->has_volumes = false;
     ctx->volume_instances = 0;
+    ctx->instance_is_volume.assign(n, 0);
     for (uint32_t i = 0; i < n; i++)
       if ((s->gInstances[i].packed[0] & 0xF) == STHIP_INSTANCE_TYPE_VOLUME) {
         ctx->has_volumes = true;
         ctx->volume_instances++;
+        ctx->instance_is_volume[i] = 1;
       }
     ctx->bvh.volumes = ctx->volumes.p;
   }
@@ -817,6 +820,11 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     p.shadow_result = ctx->shadow_result.p;
     p.view_medium = nullptr;
     if (frame->gViewMediumInstances) {
+      for (uint32_t v = 0; v < frame->view_count; v++) {
+        const uint32_t mi = frame->gViewMediumInstances[v];
+        if (mi != 0xFFFFu && (mi >= ctx->instance_count || !ctx->instance_is_volume[mi]))
+          return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: gViewMediumInstances entry is not a volume instance");
+      }
       HIP_TRY(ctx, hipMemcpyAsync(ctx->view_medium.p, frame->gViewMediumInstances, (size_t)frame->view_count * 4, hipMemcpyHostToDevice, st));
       HIP_TRY(ctx, hipStreamSynchronize(st));
       p.view_medium = ctx->view_medium.p;

@@ -281,6 +281,11 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       return false;
     }
     v.root = (uint32_t)root;
+    const uint64_t tiles = rd32(root + 24);  // the device reader walks the root's tile table linearly
+    if (tiles > 65536 || root + 64 + 32 * tiles > n) {
+      err = "gVolumes entry: the root tile table lies outside the buffer";
+      return false;
+    }
     for (int k = 0; k < 3; k++) {
       v.bbox_min[k] = (int32_t)rd32(root + 4 * k);
       v.bbox_max[k] = (int32_t)rd32(root + 12 + 4 * k);

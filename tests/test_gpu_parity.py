@@ -751,6 +751,19 @@ def test_media_camera_inside_and_moved_volume(renderer):
 def test_media_limits(renderer):
     from stratum_amd import _lib
 
+    bad = _fog().copy()
+    bad[0] ^= 0xFF  # not a NanoVDB grid any more
+    sc, cam = scenes.cornell_box(fog=bad)
+    with pytest.raises(_lib.StratumHipError, match="NanoVDB"):
+        renderer.update(sc)
+    truncated = _fog()[: 672 + 64 + 64 + 4096].copy()  # the header survives, the tree does not: reads outside return zero
+    sc, cam = scenes.cornell_box(fog=truncated)
+    try:
+        renderer.update(sc)
+        renderer.render(camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"]))
+    except _lib.StratumHipError:
+        pass
+
     sc, cam = scenes.cornell_box(fog=_fog())
     renderer.update(sc)
     frame = camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"])
