@@ -233,6 +233,21 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
 
 
 #define TRACE_NONE 0xFFFFFFFFu
+#ifndef PRIMARY_BLOCKS
+#define PRIMARY_BLOCKS 6  // measured: 0.418 ms at 4 blocks per CU, 0.380 at 5, 0.373 at 6, 0.378 at 8 (latency bound: occupancy pays, spills do not hurt)
+#endif
+#define UNIFORM_CONST __attribute__((address_space(4)))
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+// 16 bytes from a wave-uniform address through the scalar cache (the constant address space selects s_load)
+DEV float4 uniform_load4(const void* base, size_t byte) {
+  const f4v v = *(const UNIFORM_CONST f4v*)((const char*)base + byte);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+DEV uint2 uniform_load2u(const void* base, size_t byte) {
+  const u2v v = *(const UNIFORM_CONST u2v*)((const char*)base + byte);
+  return make_uint2(v.x, v.y);
+}
 // One persistent kernel serves both ray kinds. A wave first feeds its idle lanes from the path queue of bounce
 // `depth_closest` (trace_ray, intersection.hlsli:65-191) and, once that queue is dry, from the shadow-ray queue of
 // bounce `depth_shadow` (trace_visibility_ray without media, intersection.hlsli:192-239, and the per-pixel sum of
@@ -375,7 +390,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
 // bit-identical to k_trace's.
 // ---------------------------------------------------------------------------------------------
 template <bool COUNT, bool ALPHA>
-__global__ void __launch_bounds__(STHIP_BLOCK) k_trace_primary(FrameParams p) {
+__global__ void __launch_bounds__(STHIP_BLOCK, PRIMARY_BLOCKS) k_trace_primary(FrameParams p) {
   extern __shared__ uint32_t lds_stack[];
   const uint32_t wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   uint32_t* stack = lds_stack + wave_in_block * p.bvh.stack_depth;  // one stack per wave
@@ -408,9 +423,11 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_primary(FrameParams p) {
     while (ref != TRAV_DONE) {
       ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
       if (!(ref & BVH_LEAF_BIT)) {
-        const float4* n = reinterpret_cast<const float4*>(nbase + ((size_t)ref << 6));
-        const float4 n0 = n[0], n1 = n[1], nz = n[2];
-        const uint2 cr = *reinterpret_cast<const uint2*>(n + 3);
+        // wave-uniform address in the constant address space: scalar loads (the node lands in SGPRs through the scalar
+        // cache instead of occupying 14 VGPRs of all 64 lanes and a texture-addresser slot per lane)
+        const size_t nb = (size_t)ref << 6;
+        const float4 n0 = uniform_load4(nbase, nb), n1 = uniform_load4(nbase, nb + 16), nz = uniform_load4(nbase, nb + 32);
+        const uint2 cr = uniform_load2u(nbase, nb + 48);
         if (COUNT && lane == 0) {
           cnt.nodes++;
           cnt.inner_slots += 64;
@@ -486,8 +503,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_primary(FrameParams p) {
       const uint32_t first = (ref & 0x3FFFFFFFu) >> 2;
       const uint32_t count = (ref & 3u) + 1u;
       for (uint32_t i = 0; i < count; i++) {
-        const float4* tv = reinterpret_cast<const float4*>(tbase + (size_t)((first + i) * 48u));
-        const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+        const size_t tb = (size_t)((first + i) * 48u);
+        const float4 v0 = uniform_load4(tbase, tb), v1 = uniform_load4(tbase, tb + 16), v2 = uniform_load4(tbase, tb + 32);
         if (COUNT && lane == 0) {
           cnt.tris++;
           cnt.tri_slots += 64;
