@@ -233,6 +233,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
 
 
 #define TRACE_NONE 0xFFFFFFFFu
+#ifndef SHADE_BLOCKS
+#define SHADE_BLOCKS 3
+#endif
 #ifndef PRIMARY_BLOCKS
 #define PRIMARY_BLOCKS 6  // measured: 0.418 ms at 4 blocks per CU, 0.380 at 5, 0.373 at 6, 0.378 at 8 (latency bound: occupancy pays, spills do not hurt)
 #endif
@@ -979,7 +982,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
 // phase function instead of a material), or arrives at a surface / leaves the scene as before. Only instantiated with
 // EXT and without LT.
 template <bool TEXTURED, bool EXT, bool LT = false, bool MEDIA = false>
-__global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade(FrameParams p, uint32_t depth) {
+__global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams p, uint32_t depth) {
   // Workgroup b works on segment b % 8 (its XCD's) of the incoming queue and appends to the same segment of the
   // outgoing queues, so a segment never grows. In the first bounce a segment is a contiguous eighth of the slots
   // (the same split WaveWork uses): an XCD keeps one part of the image, and the part of the scene seen from it,
