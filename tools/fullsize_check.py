@@ -1,0 +1,24 @@
+"""Full-size runs of the non-default paths (GPU box): they complete, stay finite, and report their rates."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from stratum_amd import camera, scenes
+from stratum_amd.bdpt import BDPT
+
+fog = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "fog_sphere.npz"))["grid"]
+W, H = 1920, 1080
+for name, (sc, cam), args in (
+    ("foggy cornell, default flags", scenes.cornell_box(fog=fog), {"maxDiffuseVertices": 4}),
+    ("foggy cornell, forward scattering, dense", scenes.cornell_box(fog=fog, anisotropy=0.7, density=(8, 8, 8)), {"maxDiffuseVertices": 8, "maxPathVertices": 12}),
+    ("cornell, bidirectional", scenes.cornell_box(), {"bdptFlag": ["connecttolightpaths", "connecttoviews"], "maxDiffuseVertices": 4}),
+):
+    r = BDPT(0, args=args)
+    r.update(sc)
+    fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+    r.render(fr, 0, 1, aovs=False)
+    t = time.perf_counter()
+    out = r.render(fr, 1, 8, aovs=False)
+    dt = time.perf_counter() - t
+    rad = out["radiance"][..., :3]
+    print("%-45s %6.1f ms / 8 spp, %7.1f Mray/s, mean %.4f, finite %s" % (name, dt * 1e3, out["ray_count"][0] / dt / 1e6, rad.mean(), bool(np.isfinite(rad).all())))
+    r.close()
