@@ -97,7 +97,10 @@ struct Builder {
     const uint32_t n = hi - lo;
     if (n <= leaf_max) return idx;
 
-    const int NB = 32;
+#ifndef SAH_BINS
+#define SAH_BINS 32
+#endif
+    const int NB = SAH_BINS;
     float best_cost = INFINITY;
     int best_axis = -1, best_bin = -1;
     for (int axis = 0; axis < 3; axis++) {
