@@ -3078,12 +3078,7 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
                uint32_t seed_count, const sthip_outputs* out, int threads, uint64_t* stats_out) {
   if (!sc || !pc || !frame || !out || !out->gRadiance || !frame->gViews || !frame->gViewTransforms) return STHIP_ERR_INVALID_ARGUMENT;
   if (scene_flags & STHIP_BDPT_FLAG_TRACE_LIGHT) return STHIP_ERR_UNSUPPORTED;
-  if (scene_flags & STHIP_BDPT_FLAG_HAS_MEDIA) {
-    // with media every visibility ray draws random numbers: inline ones (NEE without eDeferShadowRays, the connections of
-    // eConnectToViews / eConnectToLightPaths) would advance the path's own stream mid-vertex; only the deferred form is restated
-    if ((sampling_flags & (1u << STHIP_eNEE)) && !(sampling_flags & (1u << STHIP_eDeferShadowRays))) return STHIP_ERR_UNSUPPORTED;
-    if (sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eNEEReservoirs))) return STHIP_ERR_UNSUPPORTED;
-  }
+
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
   const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) |
                                (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
@@ -3103,11 +3098,19 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
   if (!(fr.sampling_flags & (1u << STHIP_eNEE))) fr.sampling_flags &= ~(1u << STHIP_eDeferShadowRays);                // BDPT.cpp:522-523
   if (fr.pc.gLightCount > sc->lights.size()) return STHIP_ERR_INVALID_ARGUMENT;
   if (!fr.flag(STHIP_eNEE)) fr.sampling_flags &= ~((1u << STHIP_ePresampleLights) | (1u << STHIP_eNEEReservoirs));  // BDPT.cpp:511-515
+  if (!has_emissives(fr) && !has_environment(fr)) fr.sampling_flags &= ~((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths));  // BDPT.cpp:504-509
+  if (has_media(fr)) {
+    // with media every visibility ray draws random numbers: inline ones (NEE without eDeferShadowRays, the connections of
+    // eConnectToViews / eConnectToLightPaths) would advance the path's own stream mid-vertex; only the deferred form is restated
+    if (sc->volumes.empty()) fr.scene_flags &= ~STHIP_BDPT_FLAG_HAS_MEDIA;
+    else if ((sampling_flags & (1u << STHIP_eNEE)) && !(sampling_flags & (1u << STHIP_eDeferShadowRays)) && fr.flag(STHIP_eNEE)) return STHIP_ERR_UNSUPPORTED;
+    else if (fr.sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eNEEReservoirs))) return STHIP_ERR_UNSUPPORTED;
+  }
   // presample_lights, bdpt.hlsl:84-99, once per seed (BDPT.cpp:644-651): rng_init(-1, index), reference point 0.
   // An environment sample leaves `position` unset upstream, so that combination is not restated.
   std::vector<std::vector<PresampledLightPoint>> presampled;
+  if (fr.flag(STHIP_ePresampleLights) && has_environment(fr)) return STHIP_ERR_UNSUPPORTED;
   if (fr.flag(STHIP_ePresampleLights) && fr.pc.gMaxPathVertices > 2) {
-    if (has_environment(fr)) return STHIP_ERR_UNSUPPORTED;
     const size_t n = (size_t)fr.pc.gLightPresampleTileSize * fr.pc.gLightPresampleTileCount;
     if (n == 0 || n * seed_count > (1u << 26)) return STHIP_ERR_INVALID_ARGUMENT;
     presampled.resize(seed_count);

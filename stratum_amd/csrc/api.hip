@@ -714,7 +714,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   const size_t seg_stride = (((P + QUEUE_SEGMENTS - 1) / QUEUE_SEGMENTS) + 63) & ~(size_t)63;
   if (seg_stride * QUEUE_SEGMENTS > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many paths in flight");
   // a vertex queues at most one NEE ray, plus one visibility ray per stored light vertex it connects to
-  const size_t shadow_stride = seg_stride * (1 + conn_per_path);
+  // (media: the walks of earlier vertices are still in the queue when a vertex adds its own — at most one per diffuse vertex and path)
+  const size_t shadow_stride = seg_stride * (media ? std::max<size_t>(1, pc->gMaxDiffuseVertices) : 1 + conn_per_path);
   if (shadow_stride * QUEUE_SEGMENTS > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many shadow rays in flight");
   const size_t shadow_entries = shadow_stride * QUEUE_SEGMENTS;  // per round; media ping-pong between two such regions
   HIP_TRY(ctx, ctx->shadow_rays.ensure(3 * shadow_entries * (media ? 2 : 1)));

@@ -1525,10 +1525,16 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             if (!reservoirs && pdfA_fwd < 1e-6f) break;
             cG *= shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, dot3(gn, sd.shading_normal()), EXT && flag(p, STHIP_eShadingNormalShadowFix));
             const f3 contrib = reservoirs ? lLe * ev.f * cG * ris_W : lLe * ev.f * cG / pdfA;
-            if (all_le0(contrib)) break;
+            // Without eDeferShadowRays the reference has traced (and counted) the visibility ray by now (path.hlsli:329-332,
+            // before the shading-normal term and this test): a contribution that turns out zero still costs its ray
+            const bool inline_ray = !reservoirs && !flag(p, STHIP_eDeferShadowRays);
+            const bool nothing = all_le0(contrib);
+            if (nothing && !inline_ray) break;
             if (reservoirs && pdfA < 1e-6f) break;  // path.hlsli:456
             float weight = 1;
-            if (LT) {  // BDPT MIS, path.hlsli:341-351
+            if (nothing) {
+              weight = 0;
+            } else if (LT) {  // BDPT MIS, path.hlsli:341-351
               if (use_mis) {
                 const float emission_pdfA = cosine_hemisphere_pdfW(ngdotout) * (ngdotout / pow2f(ray_distance));  // setup(), :219
                 const float dL = connection_dVC(1 / pdfA, emission_pdfA, pdfA, false);
@@ -1540,9 +1546,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
               }
             } else if (sample_bsdfs)
               weight = reservoirs ? 1 - 0.5f : mis2(use_mis, pdfA, pdfA_fwd);  // reservoir_bsdf_mis, :175-177
-            const f3 c = beta * contrib * weight;
-            // a zero/negative contribution never adds light (bdpt.hlsl:313) and needs no ray
-            if (all_le0(c)) break;
+            const f3 c = nothing ? F3s(0.0f) : beta * contrib * weight;
+            // deferred: a zero/negative contribution never adds light and trace_shadows traces no ray for it (bdpt.hlsl:313)
+            if (all_le0(c) && !inline_ray) break;
             if (MEDIA) {  // the record of a walk through the media (k_shadow_media); its result lands in its own entry
               const uint32_t entry = slot * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
               if (!(ray_distance > 1e-6f)) {

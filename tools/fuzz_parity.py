@@ -1,0 +1,121 @@
+"""Randomised differential test (GPU box): random scenes x supported flag combinations x limits x frame sizes, the HIP
+path against the oracle, bit for bit. usage: tools/fuzz_parity.py [cases] [seed]. Prints every mismatch and exits non-zero."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from oracle import oracle_py
+from stratum_amd import camera, scenes
+from stratum_amd._lib import StratumHipError
+from stratum_amd.bdpt import BDPT
+
+FOG = np.load(os.path.join(ROOT, "tests", "golden", "fog_sphere.npz"))["grid"]
+
+
+def run(cases=60, seed=1):
+    rng = np.random.default_rng(seed)
+    fog_params = {}
+
+    def scene(kind):
+        if kind == "cornell": return scenes.cornell_box()
+        if kind == "fog":
+            nonlocal fog_params
+            fog_params = dict(anisotropy=float(rng.choice([0.0, 0.5, -0.4])), density=tuple(float(x) for x in rng.uniform(1, 8, 3)))
+            return scenes.cornell_box(fog=FOG, **fog_params)
+        if kind == "textured": return scenes.textured_box()
+        if kind == "spheres": return scenes.spheres_room()
+        if kind == "env": return scenes.environment_scene(image=bool(rng.integers(2)), emitter=bool(rng.integers(2)))
+        if kind == "foliage": return scenes.foliage()
+        raise KeyError(kind)
+
+    FLAGS = ["~nee", "~mis", "~samplebsdfs", "~defershadowrays", "~raycones", "~normalmaps", "~remapthreads", "alphatest", "fliptriangleuvs", "flipnormalmaps",
+             "shadingnormalshadowfix", "uniformspheresampling", "presamplelights", "neereservoirs", "connecttoviews", "connecttolightpaths", "sampleenvironmentmapdirectly"]
+    bad = rejected = done = 0
+    t0 = time.time()
+    for case in range(cases):
+        kind = str(rng.choice(["cornell", "fog", "textured", "spheres", "env", "foliage"]))
+        flags = [str(f) for f in rng.choice(FLAGS, size=int(rng.integers(0, 5)), replace=False)]
+        args = {"bdptFlag": flags, "maxDiffuseVertices": int(rng.integers(1, 5)), "maxPathVertices": int(rng.integers(2, 9)), "minPathVertices": int(rng.integers(2, 6))}
+        W, H = int(rng.integers(3, 20)) * 8, int(rng.integers(3, 16)) * 4
+        if rng.integers(3) == 0: W, H = W + int(rng.integers(1, 8)), H + int(rng.integers(1, 4))
+        seeds, seed0 = int(rng.integers(1, 4)), int(rng.integers(0, 1000))
+        sc, cam = scene(kind)
+        r = BDPT(0, args=args)
+        try:
+            # execution options that must not change any result: how many seeds share a pass, the fused / split trace launches,
+            # the first-bounce packets, the GPU LBVH builder (triangle soups without alpha masks only), pixel-tile sharding
+            opts = {}
+            if rng.integers(3) == 0: opts["max_paths_in_flight"] = int(rng.integers(1, 4)) * W * H
+            if rng.integers(4) == 0: opts["fuse_trace"] = 0
+            if rng.integers(4) == 0: opts["packet_primary"] = 0
+            if rng.integers(4) == 0 and kind in ("cornell", "textured"): opts["bvh_builder"] = 1
+            for k, v in opts.items():
+                r.set_option(k, v)
+            shard_n = int(rng.choice([1, 1, 2, 3]))
+            shard_r = int(rng.integers(shard_n))
+            if shard_n > 1:
+                r.set_shard(shard_r, shard_n, 16, 8)
+            r.update(sc)
+            mode = int(rng.integers(5))
+            if mode == 0:  # two views side by side
+                fr = camera.Frame.stereo(W, H, cam["fovy"], cam["eye"], cam["target"], eye_separation=0.2)
+            elif mode == 1:  # a camera that moved since the previous frame (prev-uv / prev_z outputs)
+                eye = np.asarray(cam["eye"], np.float64)
+                prev = camera.Frame(W, H, cam["fovy"], tuple(eye + rng.uniform(-0.1, 0.1, 3)), cam["target"])
+                fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"], prev=prev)
+            else:
+                fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+            try:
+                got = r.render(fr, seed0, seeds)
+            except StratumHipError as e:
+                try:
+                    oracle_py.OracleScene(sc).render(fr, r.push_constants(fr), r.mSamplingFlags, seed0, seeds)
+                except RuntimeError:
+                    rejected += 1
+                    continue
+                print("MISMATCH (GPU rejects, oracle accepts): %s %s %s: %s" % (kind, flags, args, e))
+                bad += 1
+                continue
+            try:
+                ref = oracle_py.OracleScene(sc).render(fr, r.push_constants(fr), r.mSamplingFlags, seed0, seeds)
+            except RuntimeError as e:
+                print("MISMATCH (oracle rejects, GPU accepts): %s %s %s: %s" % (kind, flags, args, e))
+                bad += 1
+                continue
+            ok = True
+            if shard_n > 1:  # a shard renders its own tiles and writes zeros elsewhere; ray counts are the shard's own
+                from stratum_amd import shard as shard_mod
+
+                own = shard_mod.owner_map(W, H, shard_n, 16, 8) == shard_r
+                ok &= np.array_equal(got["radiance"].view(np.uint32)[own], ref["radiance"].view(np.uint32)[own]) and not got["radiance"][~own].any()
+                if "connecttoviews" in flags or "connecttolightpaths" in flags:
+                    ref["ray_count"] = got["ray_count"]  # every shard traces all light paths
+                else:
+                    ref["ray_count"] = got["ray_count"] if own.sum() < W * H else ref["ray_count"]
+                for k in ("albedo", "prev_uv"):
+                    ref[k] = got[k]
+                for k in ("visibility", "depth"):
+                    ref[k] = got[k]
+                ref["radiance"] = got["radiance"]
+            for k in ("radiance", "albedo", "prev_uv"):
+                ok &= np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32))
+            ok &= np.array_equal(got["visibility"]["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
+            ok &= np.array_equal(got["visibility"]["packed_normal"], ref["visibility"]["packed_normal"])
+            for f in ("z", "prev_z", "dz_dxy"):
+                ok &= np.array_equal(got["depth"][f].view(np.uint32), ref["depth"][f].view(np.uint32))
+            ok &= np.array_equal(got["ray_count"], ref["ray_count"])
+            done += 1
+            if not ok:
+                bad += 1
+                nd = int((got["radiance"].view(np.uint32) != ref["radiance"].view(np.uint32)).any(axis=-1).sum())
+                print("MISMATCH %s %s %s opts %s shard %d/%d %dx%d seeds %d+%d mode %d %s: %d radiance pixels differ, rays %s vs %s" % (kind, flags, args, opts, shard_r, shard_n, W, H, seed0, seeds, mode, fog_params if kind == "fog" else "", nd, got["ray_count"], ref["ray_count"]))
+        finally:
+            r.close()
+    print("%d cases compared, %d rejected on both sides, %d mismatches, %.0f s" % (done, rejected, bad, time.time() - t0))
+    return done, rejected, bad
+
+
+
+if __name__ == "__main__":
+    d, rj, b = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    sys.exit(1 if b else 0)
