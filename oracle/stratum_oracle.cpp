@@ -274,6 +274,18 @@ struct Bvh {
   };
   std::vector<Node> nodes;
   std::vector<uint32_t> order;
+  // 4e-6 x (largest coordinate magnitude + diagonal) of the root box: the absolute padding of box_test in this space
+  float abs_pad() const {
+    if (nodes.empty()) return 0;
+    const Aabb& b = nodes[0].box;
+    float m = 0, d = 0;
+    for (int a = 0; a < 3; a++) {
+      if (!(b.hi[a] >= b.lo[a])) continue;
+      m = std::max(m, std::max(fabsf(b.lo[a]), fabsf(b.hi[a])));
+      d += b.hi[a] - b.lo[a];
+    }
+    return 4e-6f * (m + d) + 1e-30f;
+  }
 
   void build(const std::vector<Aabb>& boxes, uint32_t leaf_size) {
     const uint32_t n = (uint32_t)boxes.size();
@@ -609,10 +621,18 @@ inline bool tri_test(v3 o, const RayShear& s, v3 p0, v3 p1, v3 p2, float tmin, f
 }
 
 // conservative slab test against a padded box; NaNs (0*inf) fall out of fminf/fmaxf
-inline bool box_test(const Aabb& b, v3 o, v3 inv_d, float tmin, float tmax, float& tn) {
-  const float tx0 = (b.lo[0] - o.x) * inv_d.x, tx1 = (b.hi[0] - o.x) * inv_d.x;
-  const float ty0 = (b.lo[1] - o.y) * inv_d.y, ty1 = (b.hi[1] - o.y) * inv_d.y;
-  const float tz0 = (b.lo[2] - o.z) * inv_d.z, tz1 = (b.hi[2] - o.z) * inv_d.z;
+// The box is padded per axis by 1e-5 of the coordinates involved: the triangle test accepts hits whose rounded t lies a
+// few ulp off the plane (e.g. a ray that starts exactly on a flat, axis-aligned mesh with a tiny direction), and the
+// acceleration structure must never lose a hit the contract accepts (tools/fuzz_parity.py rays found that case).
+// `abs_pad` = 4e-6 x the size of the space being traversed (Bvh::abs_pad): the position error of an accepted hit does not
+// shrink with the coordinates (a ray lying in the plane y = 0 of a mesh around the origin).
+inline bool box_test(const Aabb& b, v3 o, v3 inv_d, float tmin, float tmax, float& tn, float abs_pad) {
+  const float px = 1e-5f * (fabsf(o.x) + fmaxf(fabsf(b.lo[0]), fabsf(b.hi[0]))) + abs_pad;
+  const float py = 1e-5f * (fabsf(o.y) + fmaxf(fabsf(b.lo[1]), fabsf(b.hi[1]))) + abs_pad;
+  const float pz = 1e-5f * (fabsf(o.z) + fmaxf(fabsf(b.lo[2]), fabsf(b.hi[2]))) + abs_pad;
+  const float tx0 = (b.lo[0] - px - o.x) * inv_d.x, tx1 = (b.hi[0] + px - o.x) * inv_d.x;
+  const float ty0 = (b.lo[1] - py - o.y) * inv_d.y, ty1 = (b.hi[1] + py - o.y) * inv_d.y;
+  const float tz0 = (b.lo[2] - pz - o.z) * inv_d.z, tz1 = (b.hi[2] + pz - o.z) * inv_d.z;
   float t0 = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
   float t1 = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
   tn = t0;
@@ -778,7 +798,7 @@ bool trace_instance(const orc_scene& sc, uint32_t inst_index, const Ray& wr, Hit
     const Bvh::Node& nd = mesh.bvh.nodes[stack[--sp]];
     float tn;
     n_nodes++;
-    if (!box_test(nd.box, o, inv_d, wr.tmin, std::min(wr.tmax, h.t), tn)) continue;
+    if (!box_test(nd.box, o, inv_d, wr.tmin, std::min(wr.tmax, h.t), tn, mesh.bvh.abs_pad())) continue;
     if (nd.left < 0) {
       for (uint32_t i = 0; i < nd.count; i++)
         if (test_prim(mesh.bvh.order[nd.first + i])) return true;
@@ -820,7 +840,7 @@ Hit trace(const orc_scene& sc, const Ray& r, bool any_hit, bool brute, uint64_t*
       const Bvh::Node& nd = sc.tlas.nodes[stack[--sp]];
       float tn;
       nn++;
-      if (!box_test(nd.box, r.o, inv_d, r.tmin, std::min(r.tmax, h.t), tn)) continue;
+      if (!box_test(nd.box, r.o, inv_d, r.tmin, std::min(r.tmax, h.t), tn, sc.tlas.abs_pad())) continue;
       if (nd.left < 0) {
         for (uint32_t i = 0; i < nd.count && !done; i++) done = trace_instance(sc, sc.tlas.order[nd.first + i], r, h, any_hit, false, nn, nt);
       } else {

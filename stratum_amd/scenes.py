@@ -137,7 +137,8 @@ def furnace_box(albedo=0.5, emission=1.0):
 def _hash01(ix, iy, seed):
     """pcg-style integer hash -> [0,1); deterministic across platforms."""
     h = (ix.astype(np.uint64) * np.uint64(73856093)) ^ (iy.astype(np.uint64) * np.uint64(19349663)) ^ np.uint64(seed * 83492791 + 12345)
-    h = (h * np.uint64(747796405) + np.uint64(2891336453)) & np.uint64(0xFFFFFFFF)
+    with np.errstate(over="ignore"):  # the wrap-around is the hash
+        h = (h * np.uint64(747796405) + np.uint64(2891336453)) & np.uint64(0xFFFFFFFF)
     h = (((h >> ((h >> np.uint64(28)) + np.uint64(4))) ^ h) * np.uint64(277803737)) & np.uint64(0xFFFFFFFF)
     h = ((h >> np.uint64(22)) ^ h) & np.uint64(0xFFFFFFFF)
     return h.astype(np.float64) / 4294967296.0

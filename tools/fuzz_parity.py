@@ -21,11 +21,17 @@ def run(cases=60, seed=1):
         if kind == "fog":
             nonlocal fog_params
             fog_params = dict(anisotropy=float(rng.choice([0.0, 0.5, -0.4])), density=tuple(float(x) for x in rng.uniform(1, 8, 3)))
+            if rng.integers(2):  # a moved / rotated / stretched cloud (the scatter position stays in the grid's world space upstream)
+                from stratum_amd.scene import rotate_y, scale, translate
+
+                fog_params["fog_transform"] = translate(tuple(rng.uniform(-0.3, 0.3, 3))) @ rotate_y(float(rng.uniform(-1, 1))) @ scale(tuple(rng.uniform(0.6, 1.3, 3)))
             return scenes.cornell_box(fog=FOG, **fog_params)
         if kind == "textured": return scenes.textured_box()
         if kind == "spheres": return scenes.spheres_room()
         if kind == "env": return scenes.environment_scene(image=bool(rng.integers(2)), emitter=bool(rng.integers(2)))
         if kind == "foliage": return scenes.foliage()
+        if kind == "atrium": return scenes.atrium(target_tris=int(rng.integers(5000, 40000)))
+        if kind == "forest": return scenes.forest(n_instances=int(rng.integers(5, 60)), tree_tris=int(rng.integers(200, 1500)), tree_kinds=int(rng.integers(1, 4)))
         raise KeyError(kind)
 
     FLAGS = ["~nee", "~mis", "~samplebsdfs", "~defershadowrays", "~raycones", "~normalmaps", "~remapthreads", "alphatest", "fliptriangleuvs", "flipnormalmaps",
@@ -33,7 +39,7 @@ def run(cases=60, seed=1):
     bad = rejected = done = 0
     t0 = time.time()
     for case in range(cases):
-        kind = str(rng.choice(["cornell", "fog", "textured", "spheres", "env", "foliage"]))
+        kind = str(rng.choice(["cornell", "fog", "fog", "textured", "spheres", "env", "foliage", "atrium", "forest"]))
         flags = [str(f) for f in rng.choice(FLAGS, size=int(rng.integers(0, 5)), replace=False)]
         args = {"bdptFlag": flags, "maxDiffuseVertices": int(rng.integers(1, 5)), "maxPathVertices": int(rng.integers(2, 9)), "minPathVertices": int(rng.integers(2, 6))}
         W, H = int(rng.integers(3, 20)) * 8, int(rng.integers(3, 16)) * 4
@@ -48,7 +54,7 @@ def run(cases=60, seed=1):
             if rng.integers(3) == 0: opts["max_paths_in_flight"] = int(rng.integers(1, 4)) * W * H
             if rng.integers(4) == 0: opts["fuse_trace"] = 0
             if rng.integers(4) == 0: opts["packet_primary"] = 0
-            if rng.integers(4) == 0 and kind in ("cornell", "textured"): opts["bvh_builder"] = 1
+            if rng.integers(4) == 0 and kind in ("cornell", "textured", "atrium", "forest"): opts["bvh_builder"] = 1
             for k, v in opts.items():
                 r.set_option(k, v)
             shard_n = int(rng.choice([1, 1, 2, 3]))
@@ -116,6 +122,70 @@ def run(cases=60, seed=1):
 
 
 
+def run_rays(cases=40, seed=1, n=20000):
+    """The traversal contract on awkward rays: axis-aligned and zero direction components, unnormalised and tiny / huge
+    directions, origins on surfaces and far away, tmin > 0, tmin >= tmax, finite tmax; closest hit and any hit against
+    the oracle's brute force, bit for bit."""
+    from stratum_amd import wire
+
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for case in range(cases):
+        kind = str(rng.choice(["cornell", "fog", "spheres", "foliage", "forest", "textured"]))
+        if kind == "fog": sc, _ = scenes.cornell_box(fog=FOG)
+        elif kind == "forest": sc, _ = scenes.forest(n_instances=12, tree_tris=400, tree_kinds=2)
+        elif kind == "spheres": sc, _ = scenes.spheres_room()
+        elif kind == "foliage": sc, _ = scenes.foliage()
+        elif kind == "textured": sc, _ = scenes.textured_box()
+        else: sc, _ = scenes.cornell_box()
+        lo = np.minimum.reduce([v for v in sc.vertices["position"]]) if sc.vertices.shape[0] else np.array([-2.0, -2, -2])
+        hi = np.maximum.reduce([v for v in sc.vertices["position"]]) if sc.vertices.shape[0] else np.array([2.0, 2, 2])
+        rays = np.zeros(n, wire.Ray)
+        o = rng.uniform(lo - 0.3 * (hi - lo), hi + 0.3 * (hi - lo), (n, 3))
+        d = rng.normal(size=(n, 3))
+        style = rng.integers(0, 8, n)
+        d[style == 1, int(rng.integers(3))] = 0.0                      # one zero component
+        z = style == 2
+        d[z] = 0.0
+        d[z, rng.integers(0, 3, z.sum())] = rng.choice([-1.0, 1.0], z.sum())  # axis-aligned
+        d[style == 3] *= 1e-6                                          # tiny, unnormalised
+        d[style == 4] *= 1e5                                           # huge
+        d[style == 5] = 0.0                                            # no direction at all
+        o[style == 6] *= 50.0                                          # far away
+        if sc.vertices.shape[0]:                                        # origins exactly on vertices
+            on = style == 7
+            o[on] = sc.vertices["position"][rng.integers(0, sc.vertices.shape[0], on.sum())]
+        rays["origin"], rays["direction"] = o.astype(np.float32), d.astype(np.float32)
+        rays["tmin"] = np.where(rng.integers(0, 4, n) == 0, rng.uniform(0, 1, n), 0).astype(np.float32)
+        rays["tmax"] = np.where(rng.integers(0, 3, n) == 0, rng.uniform(0, 3, n), np.inf).astype(np.float32)
+        alpha = bool(rng.integers(2)) and kind == "foliage"
+        r = BDPT(0)
+        try:
+            r.update(sc)
+            orc = oracle_py.OracleScene(sc)
+            got = r.trace(rays, alpha_test=alpha)
+            ref, _ = orc.trace(rays, brute=True, alpha_test=alpha)
+            same = all(np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)) for f in ("instance_primitive_index", "t", "b1", "b2"))
+            ga = r.trace(rays, any_hit=True, alpha_test=alpha)["instance_primitive_index"] != wire.MISS
+            ra = orc.trace(rays, any_hit=True, brute=True, alpha_test=alpha)[0]["instance_primitive_index"] != wire.MISS
+            rb = orc.trace(rays, any_hit=True, alpha_test=alpha)[0]["instance_primitive_index"] != wire.MISS
+            same_any = np.array_equal(ga, ra)
+            if not np.array_equal(ra, rb):
+                w = np.nonzero(ra != rb)[0]
+                print("  (the oracle's own BVH any-hit differs from its brute force on %d rays, styles %s, closest-hit says %s, tmin %s tmax %s)" % (w.size, style[w], ref["instance_primitive_index"][w] != wire.MISS, rays["tmin"][w], rays["tmax"][w]))
+            if not (same and same_any):
+                bad += 1
+                diff = np.nonzero(got["instance_primitive_index"] != ref["instance_primitive_index"])[0]
+                w = np.nonzero(ga != ra)[0]
+                print("RAY MISMATCH %s alpha %s: closest %s (%d differ, styles %s), any-hit %s (%d differ: styles %s gpu %s closest-hit says %s tmin %s tmax %s)" % (kind, alpha, same, diff.size, np.unique(style[diff]), same_any, w.size, style[w], ga[w], ref["instance_primitive_index"][w] != wire.MISS, rays["tmin"][w], rays["tmax"][w]))
+        finally:
+            r.close()
+    print("%d ray batches of %d, %d mismatches" % (cases, n, bad))
+    return bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rays":
+        sys.exit(1 if run_rays(int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 1) else 0)
     d, rj, b = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     sys.exit(1 if b else 0)
