@@ -184,7 +184,48 @@ def run_rays(cases=40, seed=1, n=20000):
     return bad
 
 
+def run_post(cases=200, seed=1):
+    """The step after the path (tonemap, ImageComparer metric) on hostile images: negatives, zeros, huge values, NaN and
+    Inf, all eleven curves, exposure, gamma, albedo modulation; odd extents. Against the oracle, bit for bit."""
+    from stratum_amd import wire
+    from stratum_amd.post import ImageComparer, Tonemapper
+
+    rng = np.random.default_rng(seed)
+    r = BDPT(0)
+    bad = 0
+    try:
+        for case in range(cases):
+            W, H = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+            def image():
+                img = (rng.normal(size=(H, W, 4)) * 10.0 ** rng.uniform(-3, 4)).astype(np.float32)
+                kind = rng.integers(0, 5)
+                if kind == 0: img = np.abs(img)
+                if kind == 1: img[rng.random((H, W)) < 0.05] = np.nan
+                if kind == 2: img[rng.random((H, W)) < 0.05] = np.inf
+                if kind == 3: img[rng.random((H, W)) < 0.3] = 0
+                return img
+            a, b, alb = image(), image(), np.abs(image())
+            mode = str(rng.choice(wire.TONEMAP_MODES))
+            mod = bool(rng.integers(2))
+            tm = Tonemapper(r, mode, float(rng.uniform(-4, 4)), bool(rng.integers(2)))
+            got, gmax = tm(a, alb if mod else None, mod, return_max=True)
+            ref, rmax = oracle_py.tonemap(a, alb if mod else None, wire.TONEMAP[mode], mod, tm.gamma_correction, tm.exposure)
+            ok = np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and np.array_equal(gmax.view(np.uint32), np.asarray(rmax, np.float32).view(np.uint32))
+            metric = str(rng.choice(wire.COMPARE_MODES))
+            q = int(rng.choice([1, 64, 1024, 65536]))
+            ok2 = ImageComparer(r, metric, q).raw(a, b) == oracle_py.image_compare(a, b, wire.COMPARE[metric], q)
+            if not (ok and ok2):
+                bad += 1
+                print("POST MISMATCH %dx%d tonemap %s (mod %s gamma %s exp %.2f): %s; compare %s q %d: %s" % (W, H, mode, mod, tm.gamma_correction, tm.exposure, ok, metric, q, ok2))
+    finally:
+        r.close()
+    print("%d post cases, %d mismatches" % (cases, bad))
+    return bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "post":
+        sys.exit(1 if run_post(int(sys.argv[2]) if len(sys.argv) > 2 else 200, int(sys.argv[3]) if len(sys.argv) > 3 else 1) else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "rays":
         sys.exit(1 if run_rays(int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 1) else 0)
     d, rj, b = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
