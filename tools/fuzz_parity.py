@@ -46,6 +46,9 @@ def run(cases=60, seed=1):
         if rng.integers(3) == 0: W, H = W + int(rng.integers(1, 8)), H + int(rng.integers(1, 4))
         seeds, seed0 = int(rng.integers(1, 4)), int(rng.integers(0, 1000))
         sc, cam = scene(kind)
+        if rng.integers(4) == 0:  # objects that moved since the previous frame (gInstanceMotionTransforms feeds prev-uv / prev_z)
+            m = sc.motion_transforms["m"]
+            m += rng.normal(scale=0.02, size=m.shape).astype(np.float32)
         r = BDPT(0, args=args)
         try:
             # execution options that must not change any result: how many seeds share a pass, the fused / split trace launches,
