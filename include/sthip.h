@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STHIP_ABI_VERSION 5
+#define STHIP_ABI_VERSION 6
 
 typedef struct sthip_ctx sthip_ctx;
 
@@ -300,11 +300,15 @@ typedef struct sthip_tonemap_desc {
   uint32_t gamma_correction;
   float exposure;
   uint32_t device_ptrs; /* gInput/gAlbedo/gOutput are device pointers */
-  uint32_t _pad;
+  float exposure_alpha; /* gExposureAlpha (tonemap.hlsl:169-178): in (0, 1) the maxima the curves use are blended with the
+                           previous frame's, lerp(prev, cur, alpha) (the luminance moments with sqrt(alpha)); needs exposure_state */
   const float* gInput;
   const float* gAlbedo; /* may be NULL when modulate_albedo == 0 */
   float* gOutput;
   float* out_max;
+  /* host, in/out, may be NULL: what the reference keeps at bytes 16..39 of gMax / reads from gPrevMax — the (blended)
+   * maxima r, g, b, luminance and the two luminance moments of the previous call; all zero before the first frame */
+  float* exposure_state;
 } sthip_tonemap_desc;
 int sthip_tonemap(sthip_ctx* ctx, const sthip_tonemap_desc* desc);
 

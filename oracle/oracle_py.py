@@ -226,6 +226,19 @@ def disney_sample(material_record, dir_in, rnd):
 
 
 # ---- steps after the path (post_oracle.cpp) ----
+def tonemap_state(radiance, state, albedo=None, mode=0, modulate_albedo=False, gamma_correction=True, exposure=0.0, exposure_alpha=0.0):
+    """orc_tonemap_state: `state` (6 floats) is read as the previous frame's and overwritten with this frame's."""
+    img = np.ascontiguousarray(radiance, np.float32)
+    alb = np.ascontiguousarray(albedo, np.float32) if albedo is not None else None
+    out = np.empty_like(img)
+    mx = np.zeros(4, np.float32)
+    lib().orc_tonemap_state(
+        wire.ptr(img), wire.ptr(alb) if alb is not None else None, wire.ptr(out), C.c_uint32(img.shape[1]), C.c_uint32(img.shape[0]), C.c_uint32(mode),
+        C.c_uint32(1 if modulate_albedo else 0), C.c_uint32(1 if gamma_correction else 0), C.c_float(exposure), wire.ptr(mx), C.c_float(exposure_alpha), wire.ptr(state),
+    )
+    return out, mx
+
+
 def tonemap(radiance, albedo=None, mode=0, modulate_albedo=False, gamma_correction=True, exposure=0.0):
     img = np.ascontiguousarray(radiance, np.float32)
     alb = np.ascontiguousarray(albedo, np.float32) if albedo is not None else None

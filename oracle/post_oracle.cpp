@@ -151,7 +151,14 @@ void orc_accumulate(const sthip_accumulate_desc* d) {
 }
 
 // gInput/gAlbedo/gOutput: RGBA32F of width*height; out_max[4] = the maxima main() sees
+void orc_tonemap_state(const float* input, const float* albedo, float* output, uint32_t width, uint32_t height, uint32_t mode, uint32_t modulate, uint32_t gamma, float exposure, float* out_max,
+                       float exposure_alpha, float* exposure_state);
 void orc_tonemap(const float* input, const float* albedo, float* output, uint32_t width, uint32_t height, uint32_t mode, uint32_t modulate, uint32_t gamma, float exposure, float* out_max) {
+  orc_tonemap_state(input, albedo, output, width, height, mode, modulate, gamma, exposure, out_max, 0.0f, nullptr);
+}
+// exposure_state: in = gPrevMax bytes 16..39 (the previous frame's blended maxima and luminance moments), out = this frame's
+void orc_tonemap_state(const float* input, const float* albedo, float* output, uint32_t width, uint32_t height, uint32_t mode, uint32_t modulate, uint32_t gamma, float exposure, float* out_max,
+                       float exposure_alpha, float* exposure_state) {
   const size_t n = (size_t)width * height;
   uint32_t mx[4] = {0, 0, 0, 0};
   {
@@ -172,6 +179,24 @@ void orc_tonemap(const float* input, const float* albedo, float* output, uint32_
   float cmax[4];
   for (int c = 0; c < 4; c++) cmax[c] = (float)mx[c] / 16384.0f;
   if (out_max) memcpy(out_max, cmax, sizeof(cmax));
+  {  // tonemap.hlsl:168-182: exposure smoothing over frames
+    float m0 = cmax[3], m1 = cmax[3] * cmax[3];
+    if (exposure_state && exposure_alpha > 0 && exposure_alpha < 1) {
+      const float* pv = exposure_state;
+      if (pv[4] == pv[4] && pv[5] == pv[5] && pv[4] > 0) {
+        const float sa = sqrtf(exposure_alpha);
+        m0 = pv[4] + sa * (m0 - pv[4]);
+        m1 = pv[5] + sa * (m1 - pv[5]);
+      }
+      if (pv[0] == pv[0] && pv[1] == pv[1] && pv[2] == pv[2] && pv[3] == pv[3] && pv[3] > 0)
+        for (int c = 0; c < 4; c++) cmax[c] = pv[c] + exposure_alpha * (cmax[c] - pv[c]);
+    }
+    if (exposure_state) {
+      memcpy(exposure_state, cmax, 16);
+      exposure_state[4] = m0;
+      exposure_state[5] = m1;
+    }
+  }
   const float gain = det_expf(exposure * 0.693147180559945f);
   for (size_t i = 0; i < n; i++) {  // main
     float r[3] = {input[4 * i], input[4 * i + 1], input[4 * i + 2]};

@@ -1257,11 +1257,15 @@ int sthip_tonemap(sthip_ctx* ctx, const sthip_tonemap_desc* d) {
       alb = balb.p;
     }
   }
-  HIP_TRY(ctx, ctx->post_scratch.ensure(4));
+  HIP_TRY(ctx, ctx->post_scratch.ensure(16));  // 4 quantised maxima, then the 6 floats of the exposure state
   HIP_TRY(ctx, hipMemsetAsync(ctx->post_scratch.p, 0, 16, st));
+  TonemapState prev;
+  for (int k = 0; k < 6; k++) prev.v[k] = d->exposure_state ? d->exposure_state[k] : 0.0f;
+  float* state_out = d->exposure_state ? reinterpret_cast<float*>(ctx->post_scratch.p + 4) : nullptr;
   const uint32_t grid = (uint32_t)std::min<size_t>(((size_t)n + 255) / 256, (size_t)ctx->cu_count * 16);
   hipLaunchKernelGGL(k_tonemap_reduce_max, dim3(grid), dim3(256), 0, st, in, alb, n, d->modulate_albedo, ctx->post_scratch.p);
-  hipLaunchKernelGGL(k_tonemap, dim3(grid), dim3(256), 0, st, in, alb, out, n, d->mode, d->modulate_albedo, d->gamma_correction, d->exposure, ctx->post_scratch.p);
+  hipLaunchKernelGGL(k_tonemap, dim3(grid), dim3(256), 0, st, in, alb, out, n, d->mode, d->modulate_albedo, d->gamma_correction, d->exposure, ctx->post_scratch.p,
+                     d->exposure_state ? d->exposure_alpha : 0.0f, prev, state_out);
   HIP_TRY(ctx, hipGetLastError());
   if (!d->device_ptrs) HIP_TRY(ctx, hipMemcpyAsync(d->gOutput, bout.p, (size_t)n * 16, hipMemcpyDeviceToHost, st));
   if (d->out_max) {
@@ -1270,6 +1274,10 @@ int sthip_tonemap(sthip_ctx* ctx, const sthip_tonemap_desc* d) {
     HIP_TRY(ctx, hipStreamSynchronize(st));
     for (int k = 0; k < 4; k++) d->out_max[k] = (float)m[k] / TONEMAP_MAX_QUANTIZATION;
   } else if (!d->device_ptrs) {
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+  }
+  if (d->exposure_state) {  // the state goes back to the caller: this form of the call synchronises
+    HIP_TRY(ctx, hipMemcpyAsync(d->exposure_state, state_out, 24, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
   }
   return STHIP_OK;

@@ -108,9 +108,34 @@ __global__ void k_tonemap_reduce_max(const float4* input, const float4* albedo, 
 }
 
 // main, tonemap.hlsl:155-226
-__global__ void k_tonemap(const float4* input, const float4* albedo, float4* output, uint32_t n, uint32_t mode, uint32_t modulate, uint32_t gamma, float exposure, const uint32_t* gmax) {
-  const f3 cur_max = F3((float)gmax[0] / TONEMAP_MAX_QUANTIZATION, (float)gmax[1] / TONEMAP_MAX_QUANTIZATION, (float)gmax[2] / TONEMAP_MAX_QUANTIZATION);
-  const float cur_max_l = (float)gmax[3] / TONEMAP_MAX_QUANTIZATION;
+// prev: the previous call's state (max r, g, b, luminance; luminance moments), state_out: this call's (gMax bytes 16..39)
+struct TonemapState {
+  float v[6];
+};
+__global__ void k_tonemap(const float4* input, const float4* albedo, float4* output, uint32_t n, uint32_t mode, uint32_t modulate, uint32_t gamma, float exposure, const uint32_t* gmax,
+                          float exposure_alpha, TonemapState prev, float* state_out) {
+  f3 cur_max = F3((float)gmax[0] / TONEMAP_MAX_QUANTIZATION, (float)gmax[1] / TONEMAP_MAX_QUANTIZATION, (float)gmax[2] / TONEMAP_MAX_QUANTIZATION);
+  float cur_max_l = (float)gmax[3] / TONEMAP_MAX_QUANTIZATION;
+  float m0 = cur_max_l, m1 = cur_max_l * cur_max_l;  // cur_moments, tonemap.hlsl:168
+  if (exposure_alpha > 0 && exposure_alpha < 1) {     // :169-178
+    if (prev.v[4] == prev.v[4] && prev.v[5] == prev.v[5] && prev.v[4] > 0) {
+      const float sa = sqrtf(exposure_alpha);
+      m0 = lerp1(prev.v[4], m0, sa);
+      m1 = lerp1(prev.v[5], m1, sa);
+    }
+    if (prev.v[0] == prev.v[0] && prev.v[1] == prev.v[1] && prev.v[2] == prev.v[2] && prev.v[3] == prev.v[3] && prev.v[3] > 0) {
+      cur_max = F3(lerp1(prev.v[0], cur_max.x, exposure_alpha), lerp1(prev.v[1], cur_max.y, exposure_alpha), lerp1(prev.v[2], cur_max.z, exposure_alpha));
+      cur_max_l = lerp1(prev.v[3], cur_max_l, exposure_alpha);
+    }
+  }
+  if (state_out && blockIdx.x == 0 && threadIdx.x == 0) {
+    state_out[0] = cur_max.x;
+    state_out[1] = cur_max.y;
+    state_out[2] = cur_max.z;
+    state_out[3] = cur_max_l;
+    state_out[4] = m0;
+    state_out[5] = m1;
+  }
   const float scale = det_expf(exposure * 0.693147180559945f);  // pow(2, gExposure)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     f3 radiance = xyz(input[i]);

@@ -887,6 +887,7 @@ class BDPT {
   // tone-map state the reference keeps on its pipeline objects (BDPT.cpp:44-54,190-193,304-309)
   uint32_t& tonemap_mode() { return mTonemapMode; }
   float& exposure() { return mExposure; }
+  float& exposure_alpha() { return mExposureAlpha; }
   bool& gamma_correction() { return mGammaCorrection; }
   // "Export" -> "Save" (BDPT.cpp:313-337): the last frame's radiance as a Radiance .hdr file
   void export_hdr(const std::string& path) const {
@@ -987,6 +988,8 @@ class BDPT {
     tm.modulate_albedo = 0;
     tm.gamma_correction = mGammaCorrection ? 1u : 0u;
     tm.exposure = mExposure;
+    tm.exposure_alpha = mExposureAlpha;       // gExposureAlpha, BDPT.cpp:51,192,307
+    tm.exposure_state = mTonemapState;        // mPrevFrame->mTonemapMax bytes 16..39 -> gPrevMax, BDPT.cpp:810-811
     tm.gInput = fr.mRadiance.data();
     tm.gAlbedo = fr.mAlbedo.data();
     tm.gOutput = fr.mTonemapResult.data();
@@ -1009,6 +1012,8 @@ class BDPT {
   uint32_t mFrameNumber = 0;
   uint32_t mTonemapMode = STHIP_TONEMAP_RAW;  // BDPT.cpp:48
   float mExposure = 0;
+  float mExposureAlpha = 0;
+  float mTonemapState[6] = {0, 0, 0, 0, 0, 0};
   bool mGammaCorrection = true;
   std::vector<ViewData> mPrevViews;
   std::vector<TransformData> mPrevInverseViewTransforms;

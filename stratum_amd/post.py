@@ -94,11 +94,13 @@ class TemporalAccumulation:
 class Tonemapper:
     """The tone-map state BDPT keeps (BDPT.cpp:44-54,190-196,304-309): mode, exposure, gamma correction."""
 
-    def __init__(self, bdpt, mode="Raw", exposure=0.0, gamma_correction=True):
+    def __init__(self, bdpt, mode="Raw", exposure=0.0, gamma_correction=True, exposure_alpha=0.0):
         self._bdpt = bdpt
         self.mode = mode
         self.exposure = float(exposure)
         self.gamma_correction = bool(gamma_correction)
+        self.exposure_alpha = float(exposure_alpha)  # gExposureAlpha: blend the maxima with the previous frame's (BDPT.cpp:51,192)
+        self.state = np.zeros(6, np.float32)  # what the reference keeps in mTonemapMax from frame to frame
 
     def __call__(self, radiance, albedo=None, modulate_albedo=False, return_max=False):
         img = _rgba(radiance, "radiance")
@@ -115,11 +117,12 @@ class Tonemapper:
             int(self.gamma_correction),
             self.exposure,
             0,
-            0,
+            self.exposure_alpha,
             img.ctypes.data,
             alb.ctypes.data if alb is not None else None,
             out.ctypes.data,
             mx.ctypes.data,
+            self.state.ctypes.data,
         )
         self._bdpt._check(_lib.lib().sthip_tonemap(self._bdpt._h, C.byref(d)), "sthip_tonemap")
         return (out, mx) if return_max else out
@@ -127,7 +130,7 @@ class Tonemapper:
     def device(self, width, height, input_ptr, albedo_ptr, output_ptr, modulate_albedo=False):
         """Device-pointer form (RGBA32F buffers in HBM); enqueues on the context's stream and returns."""
         d = wire.TonemapDesc(
-            width, height, _mode(wire.TONEMAP, self.mode), int(bool(modulate_albedo)), int(self.gamma_correction), self.exposure, 1, 0, input_ptr, albedo_ptr, output_ptr, None
+            width, height, _mode(wire.TONEMAP, self.mode), int(bool(modulate_albedo)), int(self.gamma_correction), self.exposure, 1, 0.0, input_ptr, albedo_ptr, output_ptr, None, None
         )
         self._bdpt._check(_lib.lib().sthip_tonemap(self._bdpt._h, C.byref(d)), "sthip_tonemap")
 

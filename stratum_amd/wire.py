@@ -290,11 +290,12 @@ class TonemapDesc(C.Structure):
         ("gamma_correction", C.c_uint32),
         ("exposure", C.c_float),
         ("device_ptrs", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("exposure_alpha", C.c_float),
         ("gInput", C.c_void_p),
         ("gAlbedo", C.c_void_p),
         ("gOutput", C.c_void_p),
         ("out_max", C.c_void_p),
+        ("exposure_state", C.c_void_p),
     ]
 
 

@@ -423,3 +423,48 @@ def test_gpu_accumulation_errors(gpu_ctx):
         TemporalAccumulation(gpu_ctx, reprojection=False, demodulate_albedo=True)(out, frames[0].views)
     c, _ = TemporalAccumulation(gpu_ctx, reprojection=False)(out, frames[0].views)
     assert np.array_equal(c, outs[0]["radiance"])
+
+
+@pytest.mark.gpu
+def test_exposure_smoothing_over_frames():
+    """gExposureAlpha (tonemap.hlsl:168-182): the maxima the extended curves use are blended with the previous frame's
+    (the state the reference keeps in gMax / gPrevMax); three frames of changing brightness against the oracle."""
+    from oracle import oracle_py
+    from stratum_amd.bdpt import BDPT
+    from stratum_amd.post import Tonemapper
+
+    rng = np.random.default_rng(5)
+    r = BDPT(device=0)
+    try:
+        tm = Tonemapper(r, "ReinhardLuminanceExtended", 0.5, True, exposure_alpha=0.3)
+        state = np.zeros(6, np.float32)
+        for k, gain in enumerate((1.0, 20.0, 0.2)):
+            img = (np.abs(rng.normal(size=(40, 56, 4))) * gain).astype(np.float32)
+            got, gmax = tm(img, return_max=True)
+            ref, rmax = oracle_py.tonemap_state(img, state, None, wire.TONEMAP["ReinhardLuminanceExtended"], False, True, 0.5, 0.3)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), k
+            assert np.array_equal(tm.state.view(np.uint32), state.view(np.uint32)), k
+        raw = Tonemapper(r, "ReinhardLuminanceExtended", 0.5, True)(img)
+        assert not np.array_equal(raw, got)  # the third frame is dark: its own maximum alone gives another image
+        assert gmax[3] < state[3]  # ... because the blended maximum still remembers the bright frame
+    finally:
+        r.close()
+
+
+def test_exposure_smoothing_arithmetic():
+    img = np.full((4, 4, 4), 2.0, np.float32)
+    state = np.zeros(6, np.float32)
+    orc_out, _ = oracle_py_tonemap_state(img, state, 0.25)
+    lum = np.float32(2.0) * np.float32(0.2126) + np.float32(2.0) * np.float32(0.7152) + np.float32(2.0) * np.float32(0.0722)
+    assert abs(state[3] - lum) < 1e-3 and abs(state[5] - lum * lum) < 1e-2  # first frame: nothing to blend with
+    img2 = np.full((4, 4, 4), 4.0, np.float32)
+    prev = state.copy()
+    oracle_py_tonemap_state(img2, state, 0.25)
+    assert abs(state[3] - (prev[3] + 0.25 * (2 * prev[3] - prev[3]))) < 1e-3  # lerp(prev, cur, alpha), cur = 2 x prev
+    assert abs(state[4] - (prev[4] + 0.5 * (2 * prev[4] - prev[4]))) < 1e-3  # moments with sqrt(alpha)
+
+
+def oracle_py_tonemap_state(img, state, alpha):
+    from oracle import oracle_py
+
+    return oracle_py.tonemap_state(img, state, None, wire.TONEMAP["Reinhard"], False, True, 0.0, alpha)
