@@ -138,6 +138,15 @@ int sthip_set_stream(sthip_ctx* ctx, void* hip_stream);
 /* ---- scene: replaces BLAS/TLAS build + descriptor writes (Scene.cpp:429-509,614-629; BDPT.cpp:341-421) ---- */
 int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* scene);
 
+/* Instances moved, nothing else changed (Scene::update with cached BLASes, Scene.cpp:435-459,614-629: only the TLAS is
+ * rebuilt): new gInstanceTransforms / gInstanceInverseTransforms / gInstanceMotionTransforms (may be NULL: identity) for
+ * the instance_count instances of the last sthip_scene_upload. The bottom levels stay in HBM, the top level is rebuilt
+ * over the new world boxes. Instances whose transform was the identity at upload are part of one merged world-space
+ * mesh and must stay at the identity: if one of them moved the call returns STHIP_ERR_UNSUPPORTED and changes nothing —
+ * upload the scene again. */
+int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* gInstanceTransforms, const sthip_TransformData* gInstanceInverseTransforms,
+                                  const sthip_TransformData* gInstanceMotionTransforms, uint32_t instance_count);
+
 /* ---- frame: replaces the dispatch sequence of BDPT::render (BDPT.cpp:607-720) ----
  * Renders seeds seed_begin .. seed_begin+seed_count-1 (gRandomSeed = seed, BDPT.cpp:480), one
  * sample per pixel centre per seed (bdpt.hlsl:167), and averages them with the running mean of

@@ -22,6 +22,7 @@ EXPORTS = [
     "sthip_last_error",
     "sthip_set_stream",
     "sthip_scene_upload",
+    "sthip_scene_update_transforms",
     "sthip_render",
     "sthip_set_shard",
     "sthip_trace_rays",

@@ -117,6 +117,16 @@ class BDPT:
         self._check(self._lib.sthip_scene_upload(self._h, C.byref(d)), "sthip_scene_upload")
         self._scene = scene
 
+    def update_transforms(self, scene):
+        """Only instance transforms changed since update(scene) (SceneData.set_instance_transform): the top level of the
+        acceleration structure is rebuilt, the bottom levels stay in HBM (the reference's cached BLASes, Scene.cpp:435-459).
+        Raises StratumHipError (unsupported) if an instance of the merged identity-transform mesh moved: call update()."""
+        rc = self._lib.sthip_scene_update_transforms(
+            self._h, wire.ptr(scene.transforms), wire.ptr(scene.inverse_transforms), wire.ptr(scene.motion_transforms), scene.instances.shape[0]
+        )
+        self._check(rc, "sthip_scene_update_transforms")
+        self._scene = scene
+
     def set_stream(self, stream_handle):
         self._check(self._lib.sthip_set_stream(self._h, C.c_void_p(stream_handle)), "sthip_set_stream")
 

@@ -57,6 +57,8 @@ struct sthip_ctx {
   bool has_volumes = false;   // some instance is a volume (a Medium): the media instantiations
   uint32_t volume_count = 0, volume_instances = 0;
   std::vector<uint8_t> instance_is_volume;
+  sthip::TopLevelState top;  // what sthip_scene_update_transforms rebuilds the top level from
+  size_t nodes_capacity = 0;
   DevBuf<uint32_t> volume_words;
   DevBuf<DeviceVolume> volumes;
   std::vector<uint8_t> materials_host;                    // gMaterialData as uploaded (validation of the environment record)
@@ -442,7 +444,8 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     ctx->image_count = s->image_count;
   }
 
-  HIP_TRY(ctx, ctx->nodes.ensure(std::max<size_t>(1, built.nodes.size())));
+  // headroom: a transforms-only update may build a top level with more inner nodes than this one (at most 2 per entry)
+  HIP_TRY(ctx, ctx->nodes.ensure(std::max<size_t>(1, built.top.blas_nodes + 2 * built.entries.size() + 2)));
   HIP_TRY(ctx, ctx->tris.ensure(std::max<size_t>(1, built.tris.size())));
   HIP_TRY(ctx, ctx->entries.ensure(std::max<size_t>(1, built.entries.size())));
   if (!built.nodes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->nodes.p, built.nodes.data(), built.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
@@ -512,6 +515,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->bvh.scene_radius = built.scene_radius;
   ctx->bvh_nodes = built.nodes.size();
   ctx->bvh_tris = built.tris.size();
+  ctx->top = std::move(built.top);
   ctx->has_scene = true;
   if (getenv("STHIP_VERBOSE")) {
     int per_cu = 0;
@@ -588,6 +592,46 @@ int sthip_trace_rays(sthip_ctx* ctx, const sthip_ray* rays, uint32_t ray_count, 
     rb.release();
     hb.release();
   }
+  return STHIP_OK;
+}
+
+int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf, const sthip_TransformData* inv, const sthip_TransformData* motion, uint32_t instance_count) {
+  if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
+  if (!ctx->has_scene) return fail(ctx, STHIP_ERR_NO_SCENE, "sthip_scene_update_transforms before sthip_scene_upload");
+  if (!xf || !inv) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_scene_update_transforms: transforms and inverse transforms are required");
+  if (instance_count != ctx->instance_count) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: the instance count changed: upload the scene again");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  sthip::TopLevelState next = ctx->top;  // nothing changes unless everything succeeds
+  std::vector<BvhNode> tlas;
+  uint32_t root_ref = 0, top_is_world = 1, stack_depth = 4;
+  float center[3] = {ctx->bvh.scene_cx, ctx->bvh.scene_cy, ctx->bvh.scene_cz}, radius = ctx->bvh.scene_radius;
+  std::string err;
+  if (!sthip::rebuild_top_level(next, xf, inv, instance_count, tlas, root_ref, top_is_world, stack_depth, center, radius, err)) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: " + err);
+  if ((size_t)stack_depth * STHIP_BLOCK * sizeof(uint32_t) > 64 * 1024) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: the new top level is too deep for the LDS traversal stack");
+  if ((size_t)next.blas_nodes + tlas.size() > ctx->nodes.n) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: the new top level does not fit: upload the scene again");
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still read the old top level
+  const uint32_t n = instance_count;
+  HIP_TRY(ctx, hipMemcpy(ctx->xf.p, xf, (size_t)n * 48, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->inv_xf.p, inv, (size_t)n * 48, hipMemcpyHostToDevice));
+  if (motion) {
+    HIP_TRY(ctx, hipMemcpy(ctx->motion_xf.p, motion, (size_t)n * 48, hipMemcpyHostToDevice));
+  } else {
+    std::vector<sthip_TransformData> I(n);
+    memset(I.data(), 0, (size_t)n * 48);
+    for (auto& t : I) t.m[0][0] = t.m[1][1] = t.m[2][2] = 1;
+    HIP_TRY(ctx, hipMemcpy(ctx->motion_xf.p, I.data(), (size_t)n * 48, hipMemcpyHostToDevice));
+  }
+  if (!next.entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->entries.p, next.entries.data(), next.entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
+  if (!tlas.empty()) HIP_TRY(ctx, hipMemcpy(ctx->nodes.p + next.blas_nodes, tlas.data(), tlas.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+  ctx->bvh.root_ref = root_ref;
+  ctx->bvh.top_is_world_blas = top_is_world;
+  ctx->bvh.stack_depth = stack_depth;
+  ctx->bvh.scene_cx = center[0];
+  ctx->bvh.scene_cy = center[1];
+  ctx->bvh.scene_cz = center[2];
+  ctx->bvh.scene_radius = radius;
+  ctx->bvh_nodes = next.blas_nodes + tlas.size();
+  ctx->top = std::move(next);
   return STHIP_OK;
 }
 

@@ -601,6 +601,29 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
     scene_box.grow(wb);
   }
 
+  // ---- what a transforms-only update needs later ----
+  out.top.entries = out.entries;
+  out.top.volumes = out.volumes;
+  out.top.instance_count = s.instance_count;
+  out.top.merged.assign(s.instance_count, 0);
+  for (uint32_t i : merged) out.top.merged[i] = 1;
+  out.top.blas_nodes = (uint32_t)out.nodes.size();
+  out.top.blas_depth = blas_depth;
+  out.top.obj_box.assign(6 * out.entries.size(), 0.f);
+  for (size_t k = 0; k < out.entries.size(); k++) {
+    const TlasEntry& e = out.entries[k];
+    if (e.identity == TLAS_ENTRY_IDENTITY) {
+      out.top.has_merged = true;
+      memcpy(out.top.merged_box, entry_boxes[k].lo, 12);
+      memcpy(out.top.merged_box + 3, entry_boxes[k].hi, 12);
+    } else if (e.identity == TLAS_ENTRY_TRANSFORMED) {
+      const InstView in = view(s.gInstances[e.id_bits]);
+      const Box& ob = meshes.at(std::make_tuple(in.first_vertex, in.indices_byte_offset, in.prim_count, in.stride)).bounds;
+      memcpy(&out.top.obj_box[6 * k], ob.lo, 12);
+      memcpy(&out.top.obj_box[6 * k + 3], ob.hi, 12);
+    }
+  }
+
   // ---- top level ----
   uint32_t tlas_depth = 0;
   if (out.entries.empty()) {
@@ -631,6 +654,100 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
   }
   if (any_alpha) out.tri_uvs.resize(out.tris.size());
   out.inst_alpha = inst_alpha;
+  return true;
+}
+
+bool rebuild_top_level(TopLevelState& st, const sthip_TransformData* xf, const sthip_TransformData* inv, uint32_t instance_count, std::vector<BvhNode>& tlas_nodes, uint32_t& root_ref,
+                       uint32_t& top_is_world_blas, uint32_t& stack_depth, float scene_center[3], float& scene_radius, std::string& err) {
+  const uint32_t TLAS_DEPTH_CAP = 18;
+  if (instance_count != st.instance_count) {
+    err = "the instance count changed: upload the scene again";
+    return false;
+  }
+  for (uint32_t i = 0; i < instance_count; i++)
+    if (st.merged[i] && !(is_identity(xf[i]) && is_identity(inv[i]))) {
+      err = "an instance of the merged world-space mesh (identity transform at upload) moved: upload the scene again";
+      return false;
+    }
+  Box scene_box;
+  scene_box.reset();
+  std::vector<Box> entry_boxes(st.entries.size());
+  for (size_t k = 0; k < st.entries.size(); k++) {
+    TlasEntry& e = st.entries[k];
+    Box wb;
+    wb.reset();
+    if (e.identity == TLAS_ENTRY_IDENTITY) {
+      memcpy(wb.lo, st.merged_box, 12);
+      memcpy(wb.hi, st.merged_box + 3, 12);
+    } else {
+      const uint32_t i = e.id_bits;
+      memcpy(e.inv, &inv[i], 48);
+      const sthip_TransformData& M = xf[i];
+      if (e.identity == TLAS_ENTRY_SPHERE) {
+        const float r = fabsf(e.radius);
+        for (int a = 0; a < 3; a++) {
+          const float c = M.m[a][3];
+          const float pad = 1e-3f * r + 1e-5f * fabsf(c);
+          wb.lo[a] = c - r - pad;
+          wb.hi[a] = c + r + pad;
+        }
+      } else {
+        float corners[8][3];
+        if (e.identity == TLAS_ENTRY_VOLUME) {
+          const DeviceVolume& v = st.volumes[e.root];
+          for (int c = 0; c < 8; c++) {
+            const float ip[3] = {(float)((c & 1) ? v.bbox_max[0] + 1 : v.bbox_min[0]), (float)((c & 2) ? v.bbox_max[1] + 1 : v.bbox_min[1]), (float)((c & 4) ? v.bbox_max[2] + 1 : v.bbox_min[2])};
+            for (int a = 0; a < 3; a++) corners[c][a] = ip[0] * v.matf[3 * a] + ip[1] * v.matf[3 * a + 1] + ip[2] * v.matf[3 * a + 2] + v.vecf[a];
+          }
+        } else {  // a transformed mesh: the corners of its object-space bounds (conservative; the full build uses every vertex)
+          const float* ob = &st.obj_box[6 * k];
+          for (int c = 0; c < 8; c++)
+            for (int a = 0; a < 3; a++) corners[c][a] = ((c >> a) & 1) ? ob[3 + a] : ob[a];
+        }
+        for (int c = 0; c < 8; c++) {
+          float w[3];
+          for (int r = 0; r < 3; r++) w[r] = M.m[r][0] * corners[c][0] + M.m[r][1] * corners[c][1] + M.m[r][2] * corners[c][2] + M.m[r][3];
+          wb.grow(w);
+        }
+        for (int a = 0; a < 3; a++) {
+          const float m = std::max(std::max(fabsf(wb.lo[a]), fabsf(wb.hi[a])), wb.hi[a] - wb.lo[a]);
+          const float pad = e.identity == TLAS_ENTRY_VOLUME ? 1e-3f * (wb.hi[a] - wb.lo[a]) + 1e-5f * std::max(fabsf(wb.lo[a]), fabsf(wb.hi[a])) : 2e-5f * m;
+          wb.lo[a] -= pad;
+          wb.hi[a] += pad;
+        }
+      }
+    }
+    entry_boxes[k] = wb;
+    scene_box.grow(wb);
+  }
+  tlas_nodes.clear();
+  uint32_t tlas_depth = 0;
+  if (st.entries.empty()) {
+    root_ref = BVH_INVALID_REF;
+    top_is_world_blas = 1;
+  } else if (st.entries.size() == 1 && st.entries[0].identity == TLAS_ENTRY_IDENTITY) {
+    root_ref = st.entries[0].root;
+    top_is_world_blas = 1;
+  } else {
+    Builder b(entry_boxes, 1, TLAS_DEPTH_CAP);
+    tlas_depth = b.max_depth + 1;
+    root_ref = flatten(b, 0, tlas_nodes, [&](uint32_t first, uint32_t) { return BVH_LEAF_BIT | BVH_INST_BIT | b.order[first]; });
+    if (root_ref & BVH_LEAF_BIT) {
+      root_ref = wrap_leaf(tlas_nodes, entry_boxes[0], root_ref);
+      tlas_depth += 1;
+    }
+    for (BvhNode& nd : tlas_nodes)  // the nodes go behind the bottom levels
+      for (int c = 0; c < 2; c++)
+        if (!(nd.ref[c] & BVH_LEAF_BIT)) nd.ref[c] += st.blas_nodes;
+    root_ref += st.blas_nodes;
+    top_is_world_blas = 0;
+  }
+  stack_depth = tlas_depth + st.blas_depth + 3;
+  if (scene_box.lo[0] <= scene_box.hi[0]) {
+    for (int a = 0; a < 3; a++) scene_center[a] = 0.5f * (scene_box.lo[a] + scene_box.hi[a]);
+    scene_radius = 0.5f * sqrtf((scene_box.hi[0] - scene_box.lo[0]) * (scene_box.hi[0] - scene_box.lo[0]) + (scene_box.hi[1] - scene_box.lo[1]) * (scene_box.hi[1] - scene_box.lo[1]) +
+                                (scene_box.hi[2] - scene_box.lo[2]) * (scene_box.hi[2] - scene_box.lo[2]));
+  }
   return true;
 }
 

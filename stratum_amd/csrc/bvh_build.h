@@ -10,6 +10,20 @@
 
 namespace sthip {
 
+// What a transforms-only update needs from the last full build (kept by the uploader): the bottom levels stay as they
+// are in HBM, the top level is rebuilt over new world boxes. The analogue of the reference's BLAS cache (Scene.cpp:435-459).
+struct TopLevelState {
+  std::vector<TlasEntry> entries;
+  std::vector<float> obj_box;       // 6 per entry: object-space bounds of a transformed mesh (unused for the other kinds)
+  std::vector<uint8_t> merged;      // per instance: part of the merged world-space mesh — its transform must stay the identity
+  std::vector<DeviceVolume> volumes;
+  uint32_t instance_count = 0;
+  uint32_t blas_nodes = 0;          // nodes [0, blas_nodes) are bottom-level nodes; the top level follows
+  uint32_t blas_depth = 0;
+  float merged_box[6] = {0, 0, 0, 0, 0, 0};  // world box of the merged mesh's entry
+  bool has_merged = false;
+};
+
 struct BuiltBvh {
   std::vector<BvhNode> nodes;
   std::vector<BvhTri> tris;
@@ -23,6 +37,7 @@ struct BuiltBvh {
   float scene_center[3] = {0, 0, 0};
   float scene_radius = 0;
   float gpu_build_ms = 0;  // device time of the LBVH kernels (0 for the host builder)
+  TopLevelState top;
 };
 
 enum BvhBuilderKind { BVH_BUILDER_SAH_HOST = 0, BVH_BUILDER_LBVH_GPU = 1 };
@@ -30,6 +45,12 @@ enum BvhBuilderKind { BVH_BUILDER_SAH_HOST = 0, BVH_BUILDER_LBVH_GPU = 1 };
 // Validates the scene arrays and builds. Returns false and sets `err` on malformed input.
 // `builder`: binned SAH on the host (default; best traversal) or LBVH on the GPU (fastest build; lbvh.hip).
 bool build_scene_bvh(const sthip_scene_desc& scene, BuiltBvh& out, std::string& err, int builder = BVH_BUILDER_SAH_HOST);
+
+// Transforms-only update: new entry matrices and world boxes, a new top level. `tlas_nodes` come out with their child
+// references already offset by st.blas_nodes (they go to nodes[st.blas_nodes ...]). Fails (false) when an instance of the
+// merged world-space mesh no longer has the identity transform: that needs a full build.
+bool rebuild_top_level(TopLevelState& st, const sthip_TransformData* xf, const sthip_TransformData* inv, uint32_t instance_count, std::vector<BvhNode>& tlas_nodes, uint32_t& root_ref,
+                       uint32_t& top_is_world_blas, uint32_t& stack_depth, float scene_center[3], float& scene_radius, std::string& err);
 
 // GPU LBVH of one mesh (lbvh.hip): appends nodes and leaf-ordered triangles to the outputs.
 bool lbvh_build_gpu(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhTri>& tris_out, uint32_t& root_ref, uint32_t& stack_need, float& gpu_ms,

@@ -665,6 +665,15 @@ class Scene {
   // Scene.cpp:299-684 for MeshPrimitive instances: same traversal order (breadth-first), same packing
   void update(CommandBuffer&, float) {
     if (!mDirty && mSceneData) return;
+    // the previous frame's object-to-world transform of every instance's node (mInstanceTransformMap, Scene.cpp:398-427):
+    // the motion transform is prev_object_to_world x world_to_object (make_instance_motion_transform, scene.h:49)
+    std::unordered_map<const Node*, TransformData> prevTransforms;
+    if (mSceneData)
+      for (size_t i = 0; i < mSceneData->mInstanceNodes.size(); i++) prevTransforms.emplace(mSceneData->mInstanceNodes[i], mSceneData->mInstanceTransforms[i]);
+    auto prev_of = [&](const Node& node, const TransformData& current) {
+      auto it = prevTransforms.find(&node);
+      return it == prevTransforms.end() ? current : it->second;
+    };
     auto sd = std::make_shared<SceneData>();
     std::unordered_map<const Material*, uint32_t> materialMap;
     std::unordered_map<const Mesh*, std::pair<uint32_t, uint32_t>> meshMap;  // first_vertex, indices_byte_offset (shared by instances of one mesh)
@@ -719,7 +728,7 @@ class Scene {
       const TransformData inv = inverse(transform);
       sd->mInstanceTransforms.push_back(transform);
       sd->mInstanceInverseTransforms.push_back(inv);
-      sd->mInstanceMotionTransforms.push_back(tmul(transform, inv));  // make_instance_motion_transform(inv, prev = current), scene.h:49
+      sd->mInstanceMotionTransforms.push_back(tmul(prev_of(prim.node(), transform), inv));  // make_instance_motion_transform(inv, prevObjectToWorld), scene.h:49
     });
     // sphere instances, Scene.cpp:511-553 (after every mesh instance)
     mNode.root().for_each_descendant<SpherePrimitive>([&](const component_ptr<SpherePrimitive>& prim) {
@@ -753,7 +762,7 @@ class Scene {
       const TransformData inv = inverse(t);
       sd->mInstanceTransforms.push_back(t);
       sd->mInstanceInverseTransforms.push_back(inv);
-      sd->mInstanceMotionTransforms.push_back(tmul(t, inv));
+      sd->mInstanceMotionTransforms.push_back(tmul(prev_of(prim.node(), t), inv));
     });
     // media, Scene.cpp:556-590 (after every sphere): one volume instance per Medium component
     mNode.root().for_each_descendant<Medium>([&](const component_ptr<Medium>& vol) {
@@ -772,7 +781,7 @@ class Scene {
       const TransformData inv = inverse(transform);
       sd->mInstanceTransforms.push_back(transform);
       sd->mInstanceInverseTransforms.push_back(inv);
-      sd->mInstanceMotionTransforms.push_back(tmul(transform, inv));
+      sd->mInstanceMotionTransforms.push_back(tmul(prev_of(vol.node(), transform), inv));
     });
     for (const auto* v : sd->mResources.volumes) sd->mVolumeDescs.push_back(sthip_volume_desc{v->data(), (uint64_t)v->size()});
     // environment material, Scene.cpp:631-640: the first Environment whose value is not zero
@@ -884,6 +893,7 @@ class BDPT {
   uint32_t& sampling_flags() { return mSamplingFlags; }
   BDPTPushConstants& push_constants() { return mPushConstants; }
   const Frame& prev_result() const { return mPrevFrame; }  // BDPT.hpp:18
+  bool last_update_was_transforms_only() const { return mLastUpdateWasTransformsOnly; }
   // tone-map state the reference keeps on its pipeline objects (BDPT.cpp:44-54,190-193,304-309)
   uint32_t& tonemap_mode() { return mTonemapMode; }
   float& exposure() { return mExposure; }
@@ -903,7 +913,18 @@ class BDPT {
     if (!scene || !scene->data() || scene->data().get() == mBound) return;
     (void)sthip_set_stream(mCtx, cb.hip_stream);
     const sthip_scene_desc d = scene->data()->desc();
-    if (sthip_scene_upload(mCtx, &d) != STHIP_OK) throw std::runtime_error(std::string("sthip_scene_upload: ") + sthip_last_error(mCtx));
+    // Only instances moved since the bound SceneData (same geometry, materials, images, volumes): the bottom levels in HBM
+    // are still right, as the reference's cached BLASes are (Scene.cpp:435-459); rebuild the top level only.
+    bool updated = false;
+    if (mBoundData && same_geometry(*mBoundData, *scene->data())) {
+      const int rc = sthip_scene_update_transforms(mCtx, d.gInstanceTransforms, d.gInstanceInverseTransforms, d.gInstanceMotionTransforms, d.instance_count);
+      if (rc == STHIP_OK)
+        updated = true;
+      else if (rc != STHIP_ERR_UNSUPPORTED)
+        throw std::runtime_error(std::string("sthip_scene_update_transforms: ") + sthip_last_error(mCtx));
+    }
+    mLastUpdateWasTransformsOnly = updated;
+    if (!updated && sthip_scene_upload(mCtx, &d) != STHIP_OK) throw std::runtime_error(std::string("sthip_scene_upload: ") + sthip_last_error(mCtx));
     mBound = scene->data().get();
     mBoundData = scene->data();
     mPushConstants.gLightCount = d.light_count;                    // BDPT.cpp:396
@@ -1007,6 +1028,18 @@ class BDPT {
   sthip_ctx* mCtx = nullptr;
   const void* mBound = nullptr;
   std::shared_ptr<Scene::SceneData> mBoundData;
+  bool mLastUpdateWasTransformsOnly = false;
+  template <typename T>
+  static bool same_bytes(const std::vector<T>& a, const std::vector<T>& b) {
+    return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0);
+  }
+  static bool same_geometry(const Scene::SceneData& a, const Scene::SceneData& b) {
+    if (!same_bytes(a.mVertices, b.mVertices) || !same_bytes(a.mIndices, b.mIndices) || !same_bytes(a.mInstances, b.mInstances) || !same_bytes(a.mMaterialData, b.mMaterialData) ||
+        !same_bytes(a.mLightInstanceMap, b.mLightInstanceMap) || !same_bytes(a.mDistributionData, b.mDistributionData))
+      return false;
+    if (a.mResources.image4s != b.mResources.image4s || a.mResources.image1s != b.mResources.image1s || a.mResources.volumes != b.mResources.volumes) return false;  // the same objects
+    return a.mEnvironmentMaterialAddress == b.mEnvironmentMaterialAddress;
+  }
   uint32_t mSamplingFlags = 0;
   BDPTPushConstants mPushConstants;
   uint32_t mFrameNumber = 0;

@@ -117,6 +117,17 @@ class SceneData:
             f |= wire.BDPT_FLAG_HAS_MEDIA
         return f
 
+    def set_instance_transform(self, index, transform):
+        """Move instance `index` to a new object-to-world transform (4x4 or 3x4): the arrays Scene::update refreshes every
+        frame (Scene.cpp:398-427) — transform, its inverse, and the motion transform prev_object_to_world x world_to_object
+        (make_instance_motion_transform, scene.h:49)."""
+        m = np.asarray(transform, dtype=np.float64)
+        m32 = m[:3, :].astype(np.float32)
+        prev = self.transforms["m"][index].copy()
+        self.transforms["m"][index] = m32
+        self.inverse_transforms["m"][index] = transform_inverse(m32)
+        self.motion_transforms["m"][index] = tmul(prev, self.inverse_transforms["m"][index])
+
     def view_medium_instances(self, view_transforms):
         """gViewMediumInstances (BDPT.cpp:456-466): per view the volume instance whose grid world box contains the camera."""
         out = np.full(view_transforms.shape[0], wire.INVALID_INSTANCE, np.uint32)

@@ -203,6 +203,29 @@ int main(int argc, char** argv) {
       out.write((const char*)fr.mTonemapResult.data(), fr.mTonemapResult.size() * 4);
       if (argc >= 8) renderer->export_hdr(argv[7]);
       std::printf("RENDER OK %ux%u rays %llu\n", W, H, (unsigned long long)fr.mRayCount[0]);
+      // --move=dx,dy,dz (must come last): every node whose transform is not the identity moves, the scene is marked
+      // dirty, and a second frame is rendered: Scene::update makes a new SceneData (motion transforms from the previous
+      // one), BDPT::update sees that only transforms changed and rebuilds the top level alone
+      for (int a = 8; a < argc; a++) {
+        const std::string kv = argv[a];
+        if (kv.rfind("--move=", 0) != 0) continue;
+        float dx = 0, dy = 0, dz = 0;
+        std::sscanf(kv.c_str() + 7, "%f,%f,%f", &dx, &dy, &dz);
+        scene_node.for_each_descendant<TransformData>([&](const component_ptr<TransformData>& t) {
+          static const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+          if (std::memcmp(t.get(), I, sizeof(I)) == 0) return;
+          t->m[0][3] += dx;
+          t->m[1][3] += dy;
+          t->m[2][3] += dz;
+        });
+        scene->mark_dirty();
+        app->run_frame(cb);
+        const auto& fr2 = renderer->prev_result();
+        std::ofstream out2(std::string(argv[3]) + ".moved", std::ios::binary);
+        out2.write((const char*)fr2.mRadiance.data(), fr2.mRadiance.size() * 4);
+        out2.write((const char*)fr2.mPrevUVs.data(), fr2.mPrevUVs.size() * 4);
+        std::printf("MOVED transforms_only=%d\n", renderer->last_update_was_transforms_only() ? 1 : 0);
+      }
       return 0;
     }
     std::fprintf(stderr, "bad arguments\n");

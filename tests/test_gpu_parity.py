@@ -808,3 +808,51 @@ def test_randomised_differential():
     spec.loader.exec_module(mod)
     done, rejected, bad = mod.run(cases=250, seed=11)
     assert bad == 0 and done > 150
+
+
+def test_transforms_only_update(renderer):
+    """sthip_scene_update_transforms: instances move, the bottom levels stay in HBM, the top level is rebuilt. Frames equal
+    the oracle's on the moved scene and what a full upload gives; an instance of the merged identity mesh may not move."""
+    from oracle import oracle_py
+    from stratum_amd import _lib
+    from stratum_amd.bdpt import BDPT
+    from stratum_amd.scene import rotate_y, scale, translate
+
+    cases = [
+        (scenes.cornell_box(), [(5, translate((0.1, -1.0, 0.45)) @ rotate_y(0.6) @ scale((0.5, 0.7, 0.5))), (6, translate((-0.5, -1.0, -0.2)) @ rotate_y(-0.4) @ scale((0.5, 1.4, 0.5)))], {}),
+        (scenes.spheres_room(), None, {"maxDiffuseVertices": 3}),
+        (scenes.forest(n_instances=30, tree_tris=600, tree_kinds=2), None, {}),
+        (scenes.cornell_box(fog=_fog()), "fog", {"maxDiffuseVertices": 3}),
+    ]
+    for (sc, cam), moves, args in cases:
+        kinds = sc.instances["packed"][:, 0] & 0xF
+        if moves is None:  # move every instance that is not part of the merged identity mesh
+            ident = np.array([np.array_equal(m, np.eye(4, dtype=np.float32)[:3]) for m in sc.transforms["m"]])
+            moves = [(int(i), np.vstack([sc.transforms["m"][i], [0, 0, 0, 1]]).astype(np.float64)) for i in np.nonzero(~ident)[0][:12]]
+            moves = [(i, translate((0.07 * ((k % 3) - 1), 0.0 if kinds[i] == wire.INSTANCE_TYPE_TRIANGLES else 0.05, -0.05 * (k % 2))) @ m) for k, (i, m) in enumerate(moves)]
+        elif moves == "fog":
+            moves = [(sc.instances.shape[0] - 1, translate((0.25, 0.1, -0.2)) @ scale((0.8, 1.1, 0.9)))]
+        r = BDPT(device=0, args=args)
+        try:
+            r.update(sc)
+            frame = camera.Frame(96, 64, cam["fovy"], cam["eye"], cam["target"])
+            before = r.render(frame, 0, 2)["radiance"].copy()
+            for i, m in moves:
+                sc.set_instance_transform(i, m)
+            r.update_transforms(sc)
+            got = r.render(frame, 0, 2)
+            ref = oracle_py.OracleScene(sc).render(frame, r.push_constants(frame), r.mSamplingFlags, 0, 2)
+            for k in ("radiance", "albedo", "prev_uv"):
+                assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (sc.name, k)
+            assert np.array_equal(got["visibility"]["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
+            assert np.array_equal(got["ray_count"], ref["ray_count"])
+            assert not np.array_equal(before, got["radiance"])
+            r.update(sc)  # the full upload of the moved scene gives the same frame
+            assert np.array_equal(r.render(frame, 0, 2)["radiance"].view(np.uint32), got["radiance"].view(np.uint32))
+        finally:
+            r.close()
+    sc, cam = scenes.cornell_box()
+    renderer.update(sc)
+    sc.set_instance_transform(0, translate((0.0, 0.1, 0.0)))  # the floor: part of the merged world-space mesh
+    with pytest.raises(_lib.StratumHipError, match="upload the scene again"):
+        renderer.update_transforms(sc)

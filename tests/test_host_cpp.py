@@ -95,3 +95,38 @@ def test_cpp_host_renders_what_the_python_host_renders(host_test, tmp_path, make
     assert np.array_equal(rad.view(np.uint32), ref["radiance"].view(np.uint32))
     assert np.array_equal(vis["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
     assert np.array_equal(rays, ref["ray_count"])
+
+
+@pytest.mark.gpu
+def test_cpp_host_moves_instances_with_a_top_level_rebuild(host_test, tmp_path):
+    """Nodes move between two frames: Scene::update repacks (motion transforms from the previous frame's), BDPT::update
+    finds only transforms changed and calls sthip_scene_update_transforms; the second frame and its prev-uv output equal
+    what the Python host gets from SceneData.set_instance_transform + BDPT.update_transforms."""
+    from stratum_amd.bdpt import BDPT
+    from stratum_amd.scene import translate
+
+    sc, cam = scenes.cornell_box()
+    W, H, seeds = 96, 64, 2
+    fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+    desc, outp = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    dump_description(desc, sc, fr)
+    out = subprocess.run([host_test, "render", desc, outp, str(seeds), "0", "0", str(tmp_path / "x.hdr"), "--move=0.1,0.0,-0.15"], capture_output=True, text=True)
+    assert out.returncode == 0 and "MOVED transforms_only=1" in out.stdout, out.stdout + out.stderr
+    raw = np.fromfile(outp + ".moved", dtype=np.float32)
+    rad, prev_uv = raw[: W * H * 4].reshape(H, W, 4), raw[W * H * 4 :].reshape(H, W, 2)
+    r = BDPT(device=0)
+    try:
+        r.update(sc)
+        r.render(fr, 0, seeds)
+        moved = [i for i in range(sc.instances.shape[0]) if not np.array_equal(sc.transforms["m"][i], np.eye(4, dtype=np.float32)[:3])]
+        assert len(moved) == 2  # the two blocks
+        for i in moved:
+            m = sc.transforms["m"][i].copy()
+            m[:, 3] += np.array([0.1, 0.0, -0.15], np.float32)  # float32 adds, as the C++ node transform is moved
+            sc.set_instance_transform(i, m)
+        r.update_transforms(sc)
+        ref = r.render(fr, seeds, seeds)  # the C++ host's frame number went on: seeds `seeds` .. 2 seeds - 1
+    finally:
+        r.close()
+    assert np.array_equal(rad.view(np.uint32), ref["radiance"].view(np.uint32))
+    assert np.array_equal(prev_uv.view(np.uint32), ref["prev_uv"].view(np.uint32))
