@@ -65,6 +65,15 @@ def run(cases=60, seed=1):
             if shard_n > 1:
                 r.set_shard(shard_r, shard_n, 16, 8)
             r.update(sc)
+            if rng.integers(4) == 0:  # instances move after the upload: the transforms-only update (top level rebuilt)
+                ident = np.array([np.array_equal(m, np.eye(4, dtype=np.float32)[:3]) for m in sc.transforms["m"]])
+                movers = np.nonzero(~ident)[0]
+                if movers.size:
+                    for i in rng.choice(movers, size=min(movers.size, int(rng.integers(1, 6))), replace=False):
+                        m = sc.transforms["m"][i].copy()
+                        m[:, 3] += rng.uniform(-0.15, 0.15, 3).astype(np.float32)
+                        sc.set_instance_transform(int(i), m)
+                    r.update_transforms(sc)
             mode = int(rng.integers(5))
             if mode == 0:  # two views side by side
                 fr = camera.Frame.stereo(W, H, cam["fovy"], cam["eye"], cam["target"], eye_separation=0.2)
