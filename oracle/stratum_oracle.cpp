@@ -17,12 +17,20 @@
 //   materials/disney_*.hlsli      DisneyMaterial load/eval/sample and its four lobes
 //   microfacet.h, common.h, transform.h, bitfield.h, scene.h, bdpt.h, shading_data.h
 //   kernels/temporal_accumulation.hlsl:102-131  running mean that defines N samples per pixel
+//   and, from SURVEY.md §8f: environment.h / dist2.h, light.hlsli sphere lights, image_value.h, alpha test
+//   (intersection.hlsli:117-131), presample_lights / sample_photons / add_light_trace (bdpt.hlsl:84-147,328-338),
+//   connect_view / connect_light_subpath / connect_light_vertex / connect_light_reservoir (path.hlsli:368-822),
+//   sample_texel (bdpt_util.hlsli:85-180), materials/medium.hlsli + the medium-aware trace_ray / trace_visibility_ray
+//   (intersection.hlsli:192-285) over NanoVDB grids (the PNanoVDB.h subset those call)
 //
 // PARITY PINNING: the reference ships no tests, golden vectors or fixtures,
 // cannot be built here (needs Vulkan, Eigen, Slang fetched from the network) and has no CPU
 // path. This oracle is therefore pinned by (i) published known answers for the integer
 // hashes, (ii) analytic checks (furnace test, BSDF/pdf consistency, brute-force traversal),
-// see tests/. The BVH build, ray/triangle test, texture filtering and the transcendental
+// (iii) the two pieces of the reference that DO compile from their own sources here (oracle/_ref,
+// `make -C oracle ref`): the vendored stb_image_write (HDR export, byte-identical files) and the
+// vendored NanoVDB 32.3 (the grid reader: 6000 values, bounds, maxima and the map functions read back
+// through the reference's own PNanoVDB.h; tests/golden/fog_sphere.npz) — see tests/. The BVH build, ray/triangle test, texture filtering and the transcendental
 // intrinsics live in the Vulkan driver / shader compiler and are "parity unpinned" against
 // the reference; for those the contract is the one written here and in include/sthip_detmath.h.
 //
