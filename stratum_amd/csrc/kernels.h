@@ -5,7 +5,9 @@
 // (bdpt.hlsl:298-299). Here the same per-path state machine is cut at every trace() into stages that
 // run as separate launches over compacted queues, so that the divergent BVH traversal runs with full
 // waves and the shading stage with coherent memory access:
-//     generate -> [ trace_closest -> shade -> trace_shadow ] x bounces -> resolve
+//     generate -> [ trace (closest hits of bounce d + shadow rays of bounce d - 1) -> shade ] x bounces -> resolve
+// (with the section 8f estimators: presample_lights / a light pass of the same shape in front, k_shadow_media between
+// trace and shade for scenes with volume instances)
 // Results do not depend on scheduling: the RNG is counter based per (pixel, seed) (rng.hlsli:35-47),
 // every pixel owns its outputs, and per-pixel sums keep the reference's order (emission in path
 // order, then the deferred shadow-ray sum i = 1..gMaxDiffuseVertices, bdpt.hlsl:311-325).
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// trace_closest: trace_ray (intersection.hlsli:65-191) for every queued path.
+// trace: trace_ray (intersection.hlsli:65-191) for every queued path, trace_visibility_ray for every shadow record.
 // Persistent waves: the grid only fills the machine; each wave keeps pulling rays from the queue and
 // re-packs its lanes — whenever REFILL_IDLE or more lanes have finished their ray, those lanes fetch
 // new rays (ballot + popcount ranking, WaveWork) while the others keep their traversal state.
