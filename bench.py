@@ -5,26 +5,40 @@
 
 Workload (BASELINE.json configs[2]): the procedural ~1M-triangle atrium, 1920x1080, one sample per
 pixel per GPU per step, default reference flags (NEE + MIS + BSDF sampling + deferred shadow rays,
-4/8 path vertices, 2 diffuse vertices). A step = one pass of the hot path (generate, trace, shade,
-shadow, resolve) over that batch; scene, BVH and all buffers are resident in HBM before the timed
-region. With N > 1 GPUs the frame is cut into 64x32 pixel tiles dealt round-robin to the ranks; a step
-renders N seeds of the frame (each rank: its tiles x N seeds = one frame's worth of paths, so per-GPU
-work is fixed: weak scaling) and ends with the RCCL sum-reduce of the RGBA32F framebuffer to rank 0.
+4/8 path vertices, 2 diffuse vertices), every output of sample_visibility written (gRadiance and the
+G-buffer AOVs: albedo, VisibilityInfo, DepthInfo, previous-frame uv — bdpt.hlsl:222-296). A step = one
+pass of the hot path (generate, trace, shade, shadow, resolve) over that batch; scene, BVH and all
+buffers are resident in HBM before the timed region. With N > 1 GPUs the frame is cut into 64x32
+pixel tiles dealt round-robin to the ranks; a step renders N seeds of the frame (each rank: its tiles
+x N seeds = one frame's worth of paths, so per-GPU work is fixed: weak scaling) and ends with the RCCL
+gather of the ranks' packed tiles to rank 0.
 
-value = rays of all ranks / max-over-ranks wall time; a ray is one trace_ray invocation, shadow rays
-included (gRayCount[0], src/Shaders/common/intersection.hlsli:66).
+Ranks: under torchrun (WORLD_SIZE set) this process is one rank. Started as plain `python bench.py
+--gpus N` with N > 1 it spawns its own N ranks (one child process per GPU, before anything in the
+parent touches the GPU) and exits with the first non-zero child code.
+
+value = rays of all ranks / max-over-ranks wall time of K steps (median over --reps repetitions of the
+K-step timed region, each bracketed by barrier + synchronize); a ray is one trace_ray invocation,
+shadow rays included (gRayCount[0], src/Shaders/common/intersection.hlsli:66).
 
 The JSON line also carries
-  roofline      for the dominant kernel (k_trace): algorithmic bytes per launch
-                (48 B ray+hit, + node bytes x nodes visited, + 48 B x triangles tested) over the
-                kernel's mean launch duration, measured here with HIP events on the launch stream;
-  cpu_baseline  the CPU oracle (a port of the reference shaders; the reference has no CPU path) timed on
-                the host cores on a bounded sample of the same workload, plus the rel-L2 between the GPU
-                and the oracle on that sample.
+  roofline      for the dominant kernel (k_trace): algorithmic bytes per launch (48 B ray+hit, + node
+                bytes x nodes visited, + 48 B x triangles tested) over the kernel's mean
+                launch duration measured here with HIP events on the launch stream, against the HBM
+                peak AND against ceilings measured in this run on this box
+                (sthip_measure_ceiling: stream triad; the traversal's own 64-byte node fetch at random
+                nodes without dependence, served from the whole BVH / from L2 / from L1). `frac` is
+                against the tightest ceiling the kernel does not exceed, named in `bound_detail`;
+  cpu_baseline  the CPU oracle (a port of the reference shaders; the reference has no CPU path), built
+                -O3 -march=native on this box, timed on the host cores on a bounded sample of the same
+                workload (median of 3 runs) and on one thread, plus the rel-L2 between the GPU and the
+                oracle on that sample and the oracle's own node / triangle counts per ray.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,7 +48,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 bandwidth
 
 
 def host_threads():
@@ -49,46 +64,106 @@ def host_threads():
     return n
 
 
-def measured_traffic():
-    """HBM-side bytes per live k_trace launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in
-    their own rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes; tools/pmc.sh + tools/traffic.py).
-    Counters cannot be read from inside this process, so this is the value of the newest committed profile."""
+def committed_profile():
+    """Counter-derived figures of the newest committed profile (profiles/rNN/counters.json or traffic.json): PMC
+    counters cannot be read from inside this process, so these are NOT measurements of this run and are labelled so."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")))
-    if not files:
-        return None
-    try:
-        return round(json.load(open(files[-1]))["bytes_per_launch"], 1)
-    except (OSError, ValueError, KeyError):
-        return None
+    out = {}
+    for name in ("traffic.json", "counters.json"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", name)))
+        if files:
+            try:
+                d = json.load(open(files[-1]))
+                d["source"] = os.path.relpath(files[-1], ROOT)
+                out[name[:-5]] = d
+            except (OSError, ValueError):
+                pass
+    return out
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region; value = their median")
     ap.add_argument("--scene", default="atrium")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ceilings", action="store_true", help="skip the measured ceilings (profiling runs)")
+    ap.add_argument("--radiance-only", action="store_true", help="do not write the G-buffer AOVs (not the headline configuration)")
     ap.add_argument("--bdpt-flag", action="append", default=[], help="as the reference's --bdptFlag (e.g. connecttolightpaths, ~nee); not the headline configuration")
     ap.add_argument("--max-diffuse-vertices", type=int, default=None)
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    import torch
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU. Nothing in this (parent)
+    process has touched the GPU — torch is not even imported — and no process is replaced: children are ordinary
+    subprocesses. The first child that fails ends the run with its exit code (the others are terminated by PID)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    code = 0
+    live = list(procs)
+    while live and code == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            rc = p.poll()
+            if rc is not None:
+                live.remove(p)
+                if rc != 0:
+                    code = rc
+    for p in live:  # a rank failed: the others would wait in a collective for ever
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    if code != 0:
+        sys.stderr.write("bench: a rank exited with code %d\n" % code)
+    return code if code >= 0 else 1
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    # The CPU-baseline library is compiled for THIS box's cores (-march=native) and before the GPU is initialised:
+    # make / g++ are children of a process that has not touched the GPU yet.
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    if want_cpu:
+        from oracle import oracle_py
+
+        oracle_py.build()
+        oracle_py.build_native()
+
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     # rehearsal on a one-GPU box (several ranks sharing device 0 over gloo): STHIP_BENCH_ONE_DEVICE=1 STHIP_BENCH_BACKEND=gloo
-    if os.environ.get("STHIP_BENCH_ONE_DEVICE") == "1":
+    one_device = os.environ.get("STHIP_BENCH_ONE_DEVICE") == "1"
+    if one_device:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d but only %d GPU(s) are visible" % (world, torch.cuda.device_count()))
     backend = os.environ.get("STHIP_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
     torch.cuda.set_device(local_rank)
     dist = None
@@ -115,7 +190,17 @@ def main():
     r.set_shard(rank, world, 64, 32)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     radiance = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-    dev_out = {"radiance": radiance.data_ptr()}
+    # the G-buffer the reference's sample_visibility always writes (bdpt.hlsl:222-296); every rank writes its own pixels
+    aov = {}
+    if not args.radiance_only:
+        aov = {
+            "albedo": torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"),
+            "visibility": torch.zeros((H, W, 2), dtype=torch.int32, device="cuda"),  # VisibilityInfo, 8 B
+            "depth": torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"),  # DepthInfo, 16 B
+            "prev_uv": torch.zeros((H, W, 2), dtype=torch.float32, device="cuda"),
+        }
+    aov_ptrs = {k: v.data_ptr() for k, v in aov.items()}
+    dev_out = dict(aov_ptrs, radiance=radiance.data_ptr())
     seeds_per_step = world  # weak scaling: every rank renders one frame's worth of paths per step
 
     if world == 1:
@@ -126,10 +211,12 @@ def main():
         def drain():
             pass
 
+        exchange = "none"
     else:
         # Sharded frame: every rank renders only its tiles (packed, 1 / world of the frame) and the one exchange of the
         # path is a gather of those to rank 0, which scatters them into the image (sthip_assemble_tiles). The gather of
-        # step i runs on RCCL's stream while step i + 1 renders into the other buffer.
+        # step i runs on RCCL's stream while step i + 1 renders into the other buffer. A failure of the exchange is a
+        # failure of the run: nothing here falls back to another form.
         stride = shard.slot_count(W, H, 0, world)  # rank 0 owns the most tiles: equal-size messages
         packed = [torch.zeros((stride, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
         gathered = [torch.zeros((world, stride, 4), dtype=torch.float32, device="cuda") if rank == 0 else None for _ in range(2)]
@@ -151,7 +238,7 @@ def main():
         def step(i):
             k = i & 1
             finish(k)  # buffer k is free again once its gather has been consumed
-            r.render(frame, seed_begin=i * seeds_per_step, seed_count=seeds_per_step, device_outputs={"radiance": packed[k].data_ptr()}, packed_tiles=True)
+            r.render(frame, seed_begin=i * seeds_per_step, seed_count=seeds_per_step, device_outputs=dict(aov_ptrs, radiance=packed[k].data_ptr()), packed_tiles=True)
             if host_staged:
                 src = packed[k].cpu()
                 g_cpu = torch.zeros((world, stride, 4)) if rank == 0 else None
@@ -165,58 +252,54 @@ def main():
             finish(0)
             finish(1)
 
+        exchange = "gather of packed tiles to rank 0 (%s), pipelined behind the next step" % ("RCCL" if backend == "nccl" else backend)
+
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    exchange = "none" if world == 1 else "gather of packed tiles, pipelined"
-    try:
-        for i in range(args.warmup):
-            step(i)
-        drain()
-        barrier()
-    except Exception as e:  # harness plumbing only: the zero-padded reduce is the other documented exchange form
-        if world == 1:
-            raise
-        sys.stderr.write("bench: packed gather failed (%s); using the sum-reduce of zero-padded frames\n" % e)
-        exchange = "sum-reduce of zero-padded frames"
-
-        def step(i):  # noqa: F811
-            r.render(frame, seed_begin=i * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
-            shard.reduce_framebuffer(radiance, dist, dst=0)
-
-        def drain():  # noqa: F811
-            pass
-
-        for i in range(args.warmup):
-            step(i)
-        barrier()
-    t0 = time.perf_counter()
-    rays_local = 0
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(args.warmup):
+        step(i)
     drain()
     barrier()
-    dt = time.perf_counter() - t0
-    # rays of the timed region: re-run the same steps with the counters read back (untimed)
+    # ---- the timed region: EXACTLY K steps between barrier + synchronize on both sides, `reps` times ----
+    rep_dt = []
+    for _ in range(max(1, args.reps)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        drain()
+        barrier()
+        rep_dt.append(time.perf_counter() - t0)
+    # rays of the timed region: the same steps again with the counters read back (untimed; every repetition traces
+    # the same seeds, hence the same rays)
+    rays_local = 0
     for i in range(args.steps):
         r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
         rays_local += r.stats()["rays_total"]
-    t = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device="cuda")
+    t = torch.tensor(rep_dt + [float(rays_local)], dtype=torch.float64, device="cuda")
+    devices = [{"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank)}]
     if dist is not None:
         tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)  # per repetition: the slowest rank
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt_all, rays_all = float(tmax[0]), float(t[1])
+        rep_all, rays_all = [float(x) for x in tmax[:-1]], float(t[-1])
+        gathered_devices = [None] * world
+        dist.all_gather_object(gathered_devices, devices[0])
+        devices = gathered_devices
+        world_seen, backend_seen = dist.get_world_size(), dist.get_backend()
     else:
-        dt_all, rays_all = float(t[0]), float(t[1])
+        rep_all, rays_all = [float(x) for x in t[:-1]], float(t[-1])
+        world_seen, backend_seen = 1, "none"
+    dt_all = float(np.median(rep_all))
 
     result = None
     if rank == 0:
         # ---- roofline of the dominant kernel (k_trace: BVH traversal of closest-hit and shadow rays), this rank ----
         r.set_option("time_kernels", 1)
-        ms_trace, ms_primary, ms_shade, ms_total, launches = 0.0, 0.0, 0.0, 0.0, 0
+        ms_trace, ms_primary, ms_shade, ms_total, launches, launches_primary = 0.0, 0.0, 0.0, 0.0, 0, 0
         for i in range(args.steps):
             r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
             s = r.stats()
@@ -225,34 +308,71 @@ def main():
             ms_shade += s["ms_shade"]
             ms_total += s["ms_total"]
             launches += s["launches_trace"]
+            launches_primary += s["launches_primary"]
         r.set_option("time_kernels", 0)
         r.set_option("count_traversal", 1)
-        nodes = tris = rays_closest = rays_shadow = nodes_sh = tris_sh = 0
+        nodes = tris = rays_closest = rays_shadow = nodes_sh = tris_sh = nodes_pr = tris_pr = rays_pr = 0
+        lanes = {"inner": [0, 0], "tri": [0, 0]}
         for i in range(args.steps):
             r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
             s = r.stats()
             # the rays, node visits and triangle tests of k_trace: everything but the first bounce's packets
             nodes += s["nodes_visited"] - s["nodes_visited_primary"]
             tris += s["tris_tested"] - s["tris_tested_primary"]
+            nodes_pr += s["nodes_visited_primary"]
+            tris_pr += s["tris_tested_primary"]
+            rays_pr += s["rays_primary_packets"]
             rays_closest -= s["rays_primary_packets"]
             nodes_sh += s["nodes_visited_shadow"]
             tris_sh += s["tris_tested_shadow"]
             rays_closest += s["rays_path"]
             rays_shadow += s["rays_shadow"]
+            lanes["inner"][0] += s["nodes_visited"] - s["nodes_visited_primary"] + s["nodes_visited_shadow"]
+            lanes["inner"][1] += s["inner_slots"][0] + s["inner_slots"][1]
+            lanes["tri"][0] += s["tris_tested"] - s["tris_tested_primary"] + s["tris_tested_shadow"]
+            lanes["tri"][1] += s["tri_slots"][0] + s["tri_slots"][1]
         r.set_option("count_traversal", 0)
         node_bytes, tri_bytes = s["bvh_node_bytes"], s["bvh_tri_bytes"]
         rays = rays_closest + rays_shadow
         # B_ray = 48 (ray in + hit out; a shadow record is 48 B too) + node bytes * nodes + triangle bytes * tris
-        alg_bytes = 48.0 * rays + float(node_bytes) * (nodes + nodes_sh) + float(tri_bytes) * (tris + tris_sh)
+        node_alg_bytes = float(node_bytes) * (nodes + nodes_sh)
+        alg_bytes = 48.0 * rays + node_alg_bytes + float(tri_bytes) * (tris + tris_sh)
         achieved = alg_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else 0.0
+        node_rate = node_alg_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else 0.0
+        # ---- ceilings measured now, on this box (sthip_measure_ceiling) ----
+        ceilings = {"hbm_spec": {"peak": HBM_PEAK_GBS, "frac": round(achieved / HBM_PEAK_GBS, 4), "what": "algorithmic bytes of k_trace / HBM3E spec peak (SURVEY 8d)"}}
+        if not args.no_ceilings:
+            triad = r.measure_ceiling("triad")
+            ceilings["hbm_triad_measured"] = {"peak": round(triad, 1), "frac": round(achieved / triad, 4), "what": "algorithmic bytes / stream triad measured in this run"}
+            for key, what in (
+                ("node_gather_table", "k_trace's node bytes / rate of independent random 64-B node fetches over this BVH's node array (L2 + Infinity Cache)"),
+                ("node_gather_l2", "k_trace's node bytes / the same fetch over a 2 MiB prefix (L2 hits)"),
+                ("node_gather_l1", "k_trace's node bytes / the same fetch over a 16 KiB prefix (vector-memory front end)"),
+            ):
+                g = r.measure_ceiling(key)
+                ceilings[key] = {"peak": round(g, 1), "frac": round(node_rate / g, 4) if g > 0 else None, "what": what}
+        # the binding ceiling: the tightest one the kernel does not exceed (a "ceiling" it runs above is not one for
+        # its access pattern: most node fetches are served above that level of the hierarchy)
+        binding = None
+        for key, c in ceilings.items():
+            if c["frac"] is not None and c["frac"] <= 1.0 and (binding is None or c["frac"] > ceilings[binding]["frac"]):
+                binding = key
+        bound_key = binding or "hbm_spec"
+        prof = committed_profile()
         roofline = {
-            "bound": "hbm",
+            "bound": "hbm",  # memory-side (no MFMA on this path); which level binds: bound_detail
+            "bound_detail": bound_key,
             "kernel": "k_trace",
-            "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS,
+            "achieved": round(node_rate if bound_key.startswith("node_gather") else achieved, 2),
+            "peak": ceilings[bound_key]["peak"],
             "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": measured_traffic(),
+            "frac": ceilings[bound_key]["frac"],
+            "traffic": prof.get("traffic", {}).get("bytes_per_launch"),
+            "traffic_source": prof.get("traffic", {}).get("source", None),  # a committed profile, NOT this run (PMC needs rocprofv3)
+            "algorithmic_gbs": round(achieved, 2),
+            "node_fetch_gbs": round(node_rate, 2),
+            "ceilings": ceilings,
+            "counters": prof.get("counters"),
             "bytes_per_launch": round(alg_bytes / max(launches, 1), 1),
             "launch_ms": round(ms_trace / max(launches, 1), 4),
             "launches_per_step": round(launches / args.steps, 2),
@@ -268,10 +388,28 @@ def main():
             "closest_nodes_per_ray": round(nodes / max(rays_closest, 1), 2),
             "shadow_nodes_per_ray": round(nodes_sh / max(rays_shadow, 1), 2),
             "rays_per_launch": round(rays / max(launches, 1), 1),
-            "note": "k_trace = closest-hit rays of bounce >= 1 and all shadow rays (the first bounce runs as wave packets in "
-            "k_trace_primary and is not part of these figures); achieved counts ALGORITHMIC bytes (48 B/ray + node and triangle bytes per visit, SURVEY 8d); most node "
-            "fetches hit L2 / Infinity Cache (compare traffic), so frac > 1 means the kernel runs above what HBM alone could "
-            "feed: it is bound by dependent-load latency and lane divergence, see profiles/README.md",
+            "lane_utilisation": {"node_loop": round(lanes["inner"][0] / max(lanes["inner"][1], 1), 3), "triangle_loop": round(lanes["tri"][0] / max(lanes["tri"][1], 1), 3)},
+            # the other kernels of a step, priced the same way (HIP events of this run)
+            "other_kernels": {
+                "k_trace_primary": {
+                    "ms_per_launch": round(ms_primary / max(launches_primary, 1), 4),
+                    "rays_per_launch": round(rays_pr / max(launches_primary, 1), 1),
+                    "nodes_per_packet": round(nodes_pr / max(rays_pr / 64.0, 1), 1),
+                    "tris_per_packet": round(tris_pr / max(rays_pr / 64.0, 1), 1),
+                    "mray_per_s": round(rays_pr / max(ms_primary, 1e-9) / 1e3, 1),
+                    "note": "first bounce as 8x8-pixel wave packets: one wave-uniform (scalar) node fetch serves 64 rays, so the bound is the dependent scalar-load latency per packet step, not bytes",
+                },
+                "k_shade": {
+                    "ms_per_step": round(ms_shade / args.steps, 4),
+                    "algorithmic_bytes_per_vertex": 244 + 208,
+                    "achieved_gbs": round((244 + 208) * float(rays_closest + rays_pr) / max(ms_shade * 1e-3, 1e-12) / 1e9, 1),
+                    "peak_gbs": HBM_PEAK_GBS,
+                    "note": "per path vertex 244 B of gathers (3 vertices, indices, instance, transform, material; SURVEY 8d) + 104 B of path state read and written; bound: HBM",
+                },
+            },
+            "note": "k_trace = closest-hit rays of bounce >= 1 and all shadow rays (the first bounce runs as wave packets in k_trace_primary: other_kernels). "
+            "algorithmic_gbs counts 48 B/ray + node and triangle bytes per visit (SURVEY 8d); the BVH lives in L2 / Infinity Cache, so that figure can exceed the HBM peak "
+            "(ceilings.hbm_spec.frac > 1): HBM does not bind this kernel. frac is node_fetch_gbs against the tightest measured node-gather ceiling it does not exceed.",
         }
 
         # ---- the same steps through HOST output pointers (what a caller without device buffers pays): the frame comes
@@ -287,37 +425,61 @@ def main():
 
         # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if want_cpu:
             from oracle import oracle_py
 
-            sw, sh, nseed = W, H, 8  # the same workload: full frame, eight samples per pixel (about 10 s of CPU work on 16 cores)
+            sw, sh, nseed = W, H, 4  # the same workload: full frame, four samples per pixel (a few seconds on the box's cores)
             sframe = camera.Frame(sw, sh, cam["fovy"], cam["eye"], cam["target"])
             r.set_shard(0, 1, 64, 32)
+            r.set_option("count_traversal", 1)
             got = r.render(sframe, 0, nseed, aovs=False)
-            o = oracle_py.OracleScene(sc)
+            gs = r.stats()
+            r.set_option("count_traversal", 0)
+            o = oracle_py.OracleScene(sc, native=True)
             threads = host_threads()
             pc = r.push_constants(sframe)
             wframe = camera.Frame(sw // 8, sh // 8, cam["fovy"], cam["eye"], cam["target"])
             o.render(wframe, r.push_constants(wframe), r.mSamplingFlags, 0, 1, threads=threads, aovs=False)  # warm-up
+            runs = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                ref = o.render(sframe, pc, r.mSamplingFlags, 0, nseed, threads=threads, aovs=False)
+                runs.append(time.perf_counter() - t1)
+            cdt = float(np.median(runs))
+            # one thread, on 1/16 of the frame (same camera, 480x270) and the same seeds
             t1 = time.perf_counter()
-            ref = o.render(sframe, pc, r.mSamplingFlags, 0, nseed, threads=threads, aovs=False)
-            cdt = time.perf_counter() - t1
+            ref1 = o.render(camera.Frame(sw // 4, sh // 4, cam["fovy"], cam["eye"], cam["target"]), r.push_constants(camera.Frame(sw // 4, sh // 4, cam["fovy"], cam["eye"], cam["target"])), r.mSamplingFlags, 0, nseed, threads=1, aovs=False)
+            cdt1 = time.perf_counter() - t1
             a = got["radiance"][..., :3].astype(np.float64)
             b = ref["radiance"][..., :3].astype(np.float64)
             rel = float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b**2).sum()), 1e-300))
+            orays = float(ref["ray_count"][0])
+            gnodes = gs["nodes_visited"] + gs["nodes_visited_shadow"]
+            gtris = gs["tris_tested"] + gs["tris_tested_shadow"]
             cpu = {
-                "value": round(float(ref["ray_count"][0]) / cdt / 1e6, 3),
+                "value": round(orays / cdt / 1e6, 3),
                 "unit": "Mray/s",
                 "cores": threads,
                 "kind": "port",
-                "sample": "%s %dx%d x %d samples, default flags (%d rays, %.2f s)" % (args.scene, sw, sh, nseed, int(ref["ray_count"][0]), cdt),
+                "sample": "%s %dx%d x %d samples, default flags (%d rays; median of 3 runs: %s s); oracle built -O3 -march=native on this box"
+                % (args.scene, sw, sh, nseed, int(orays), ", ".join("%.2f" % x for x in runs)),
+                "single_thread_value": round(float(ref1["ray_count"][0]) / cdt1 / 1e6, 3),
+                "single_thread_sample": "%dx%d x %d samples (%d rays, %.2f s)" % (sw // 4, sh // 4, nseed, int(ref1["ray_count"][0]), cdt1),
                 "rel_l2_gpu_vs_oracle": rel,
+                # SURVEY 8d's shared figure counted by the oracle (its own binned-SAH BVH2, exact boxes, one ray at a time)
+                # on the same rays, next to what the GPU's kernels visited for them (padded boxes, packets for bounce 0)
+                "oracle_nodes_per_ray": round(float(ref["stats"][2]) / orays, 2),
+                "oracle_tris_per_ray": round(float(ref["stats"][3]) / orays, 2),
+                "gpu_nodes_per_ray": round(gnodes / max(gs["rays_total"], 1), 2),
+                "gpu_tris_per_ray": round(gtris / max(gs["rays_total"], 1), 2),
+                "gpu_over_oracle_node_visits": round(gnodes / max(float(ref["stats"][2]), 1.0), 3),
             }
+        flags_text = "default BDPT flags" if not (args.bdpt_flag or args.max_diffuse_vertices) else "flags %s maxDiffuseVertices %s" % (args.bdpt_flag, args.max_diffuse_vertices)
         result = {
             "metric": "Mray/s at 1920x1080x1spp (1M-tri scene)",
             "value": round(rays_all / dt_all / 1e6, 2),
             "unit": "Mray/s",
-            "n_gpus": world,
+            "n_gpus": world_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt_all / args.steps * 1e3, 3),
@@ -327,12 +489,16 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "procedural %s, %d triangles, %dx%d, %d sample(s)/pixel/step, %s, pixel-tile shard 64x32 over %d GPU(s)"
-                % (args.scene, sc.triangle_count, W, H, seeds_per_step, "default BDPT flags" if not (args.bdpt_flag or args.max_diffuse_vertices) else "flags %s maxDiffuseVertices %s" % (args.bdpt_flag, args.max_diffuse_vertices), world),
+                "workload": "procedural %s, %d triangles, %dx%d, %d sample(s)/pixel/step, %s, %s, pixel-tile shard 64x32 over %d GPU(s)"
+                % (args.scene, sc.triangle_count, W, H, seeds_per_step, flags_text, "radiance only" if args.radiance_only else "radiance + albedo/visibility/depth/prev-uv AOVs written", world),
                 "rays_per_step": int(rays_all / args.steps),
                 "parallelism": "tile-shard x%d" % world if world > 1 else "single GPU",
                 "exchange": exchange,
+                "world_size": world_seen,
+                "backend": backend_seen,
+                "devices": devices,
             },
+            "repetitions": {"n": len(rep_all), "ms_per_step": [round(x / args.steps * 1e3, 3) for x in rep_all], "value_is": "median"},
             "host_output_value": host_rate,  # Mray/s with the radiance image copied to host memory inside every call
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STHIP_ABI_VERSION 6
+#define STHIP_ABI_VERSION 7
 
 typedef struct sthip_ctx sthip_ctx;
 
@@ -135,7 +135,10 @@ const char* sthip_last_error(const sthip_ctx* ctx); /* ctx may be NULL: error of
  * enqueues. */
 int sthip_set_stream(sthip_ctx* ctx, void* hip_stream);
 
-/* ---- scene: replaces BLAS/TLAS build + descriptor writes (Scene.cpp:429-509,614-629; BDPT.cpp:341-421) ---- */
+/* ---- scene: replaces BLAS/TLAS build + descriptor writes (Scene.cpp:429-509,614-629; BDPT.cpp:341-421) ----
+ * Both scene calls first wait for the work already enqueued on the context's stream (frames of the previous scene that
+ * were rendered with device output pointers), then replace the resident arrays: a caller never has to synchronise
+ * before re-uploading. */
 int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* scene);
 
 /* Instances moved, nothing else changed (Scene::update with cached BLASes, Scene.cpp:435-459,614-629: only the TLAS is
@@ -240,6 +243,17 @@ typedef struct sthip_stats {
   uint32_t launches_primary;
 } sthip_stats;
 int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out);
+
+/* Measured memory-system ceilings for the roofline of the traversal kernel (bench.py): the rate, in GB/s, of
+ *   STHIP_CEILING_TRIAD             a float4 stream triad over 3 x 512 MiB (the measured HBM figure SURVEY.md 8d asks for)
+ *   STHIP_CEILING_NODE_GATHER_TABLE the traversal's own node fetch (64-byte BVH node per lane, 4 vector loads) at
+ *                                   uniformly random nodes of the resident acceleration structure, with no dependence
+ *                                   between fetches and no arithmetic: what L2 + Infinity Cache deliver to such gathers
+ *   STHIP_CEILING_NODE_GATHER_L2    the same over a 2 MiB prefix of the node array (L2-hit rate)
+ *   STHIP_CEILING_NODE_GATHER_L1    the same over a 16 KiB prefix (the vector-memory front end: nothing beats it)
+ * counting 64 bytes per node fetch, as the algorithmic figure does. Synchronous; the gather kinds need a scene. */
+enum { STHIP_CEILING_TRIAD = 0, STHIP_CEILING_NODE_GATHER_TABLE = 1, STHIP_CEILING_NODE_GATHER_L2 = 2, STHIP_CEILING_NODE_GATHER_L1 = 3 };
+int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s);
 
 /* named integer options: "count_traversal" (0/1), "time_kernels" (0/1); scheduler tuning of the persistent
  * trace kernels: "refill_idle" (1..64, default 16), "inner_min_lanes" (1..64, default 24),

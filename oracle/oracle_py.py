@@ -23,12 +23,39 @@ def build(force=False):
     return _LIB_PATH
 
 
+_NATIVE_PATH = os.path.join(_HERE, "_build", "liboracle_native.so")
+_native = None
+
+
+def build_native():
+    """The -O3 -march=native build bench.py's cpu_baseline times. Compiled on the box it runs on; call
+    this BEFORE the process initialises the GPU (it starts make / g++ as children)."""
+    # always rebuilt (-B): a copy compiled for another machine's -march=native may have travelled with the tree
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])
+    return _NATIVE_PATH
+
+
+def lib_native():
+    """The native build, already built by build_native(); never builds by itself."""
+    global _native
+    if _native is None:
+        if not os.path.exists(_NATIVE_PATH):
+            raise RuntimeError("liboracle_native.so is missing: call oracle_py.build_native() first")
+        _native = _bind(C.CDLL(_NATIVE_PATH))
+    return _native
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
+        _lib = _bind(C.CDLL(_LIB_PATH))
+    return _lib
+
+
+def _bind(L):
+    if True:
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.POINTER(wire.SceneDesc)]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
@@ -51,21 +78,21 @@ def lib():
         L.orc_pcg.argtypes = [C.c_uint32]
         L.orc_xxhash32.restype = C.c_uint32
         L.orc_xxhash32.argtypes = [C.c_uint32]
-        _lib = L
-    return _lib
+    return L
 
 
 class OracleScene:
-    def __init__(self, scene):
+    def __init__(self, scene, native=False):
         self.scene = scene  # keep the arrays alive
+        self._L = lib_native() if native else lib()
         d = scene.desc()
-        self.h = lib().orc_scene_create(C.byref(d))
+        self.h = self._L.orc_scene_create(C.byref(d))
         if not self.h:
             raise RuntimeError("orc_scene_create failed")
 
     def close(self):
-        if getattr(self, "h", None) and _lib is not None:
-            _lib.orc_scene_destroy(self.h)
+        if getattr(self, "h", None) and getattr(self, "_L", None) is not None:
+            self._L.orc_scene_destroy(self.h)
         self.h = None
 
     def __del__(self):
@@ -94,7 +121,7 @@ class OracleScene:
         if self.scene.volumes:
             frame.view_medium_instances = self.scene.view_medium_instances(frame.view_transforms)
         fd = frame.desc()
-        rc = lib().orc_render(
+        rc = self._L.orc_render(
             self.h, C.byref(push_constants), sampling_flags, self.scene.scene_flags, C.byref(fd), seed_begin, seed_count, C.byref(o), threads, wire.ptr(out["stats"])
         )
         if rc != 0:
@@ -105,7 +132,7 @@ class OracleScene:
         rays = np.ascontiguousarray(rays, dtype=wire.Ray)
         hits = np.zeros(rays.shape[0], wire.Hit)
         counters = np.zeros(2, np.uint64)
-        rc = lib().orc_trace_rays(self.h, wire.ptr(rays), rays.shape[0], wire.ptr(hits), (1 if any_hit else 0) | (2 if brute else 0) | (4 if alpha_test else 0) | (8 if flip_uvs else 0), threads, wire.ptr(counters))
+        rc = self._L.orc_trace_rays(self.h, wire.ptr(rays), rays.shape[0], wire.ptr(hits), (1 if any_hit else 0) | (2 if brute else 0) | (4 if alpha_test else 0) | (8 if flip_uvs else 0), threads, wire.ptr(counters))
         if rc != 0:
             raise RuntimeError("orc_trace_rays failed: %d" % rc)
         return hits, counters
@@ -115,7 +142,7 @@ class OracleScene:
         rnd4 = np.ascontiguousarray(rnd4, np.float32).reshape(-1, 4)
         ref_pos = np.ascontiguousarray(np.broadcast_to(np.asarray(ref_pos, np.float32), (rnd4.shape[0], 3)))
         out = np.zeros((rnd4.shape[0], 16), np.float32)
-        lib().orc_sample_light(C.c_void_p(self.h), C.byref(push_constants), C.c_uint32(sampling_flags), C.c_uint32(self.scene.scene_flags), wire.ptr(rnd4), wire.ptr(ref_pos), wire.ptr(out), C.c_uint32(rnd4.shape[0]))
+        self._L.orc_sample_light(C.c_void_p(self.h), C.byref(push_constants), C.c_uint32(sampling_flags), C.c_uint32(self.scene.scene_flags), wire.ptr(rnd4), wire.ptr(ref_pos), wire.ptr(out), C.c_uint32(rnd4.shape[0]))
         return {
             "radiance": out[:, 0:3],
             "pdf": out[:, 3],
@@ -130,14 +157,14 @@ class OracleScene:
     def sample_image(self, index, uv_size, ray_cones=True):
         q = np.ascontiguousarray(uv_size, np.float32).reshape(-1, 3)
         out = np.zeros((q.shape[0], 4), np.float32)
-        lib().orc_sample_image(C.c_void_p(self.h), C.c_uint32(index), wire.ptr(q), C.c_uint32(1 if ray_cones else 0), wire.ptr(out), C.c_uint32(q.shape[0]))
+        self._L.orc_sample_image(C.c_void_p(self.h), C.c_uint32(index), wire.ptr(q), C.c_uint32(1 if ray_cones else 0), wire.ptr(out), C.c_uint32(q.shape[0]))
         return out
 
     def shading_data(self, inst_prim, bary):
         inst_prim = np.ascontiguousarray(inst_prim, np.uint32)
         bary = np.ascontiguousarray(bary, np.float32)
         out = np.zeros(inst_prim.shape[0], wire.ShadingData)
-        lib().orc_shading_data(C.c_void_p(self.h), wire.ptr(inst_prim), wire.ptr(bary), wire.ptr(out), C.c_uint32(inst_prim.shape[0]))
+        self._L.orc_shading_data(C.c_void_p(self.h), wire.ptr(inst_prim), wire.ptr(bary), wire.ptr(out), C.c_uint32(inst_prim.shape[0]))
         return out
 
 

@@ -34,6 +34,7 @@ EXPORTS = [
     "sthip_tonemap",
     "sthip_image_compare",
     "sthip_write_hdr",
+    "sthip_measure_ceiling",
 ]
 
 _lib = None
@@ -116,5 +117,7 @@ def lib():
     L.sthip_image_compare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.sthip_write_hdr.restype = C.c_int
     L.sthip_write_hdr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.sthip_measure_ceiling.restype = C.c_int
+    L.sthip_measure_ceiling.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
     _lib = L
     return L

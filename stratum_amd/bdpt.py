@@ -133,6 +133,14 @@ class BDPT:
     def set_option(self, name, value):
         self._check(self._lib.sthip_set_option(self._h, name.encode(), int(value)), "sthip_set_option")
 
+    CEILINGS = {"triad": 0, "node_gather_table": 1, "node_gather_l2": 2, "node_gather_l1": 3}
+
+    def measure_ceiling(self, kind):
+        """Measured memory-system ceiling in GB/s (include/sthip.h: sthip_measure_ceiling)."""
+        v = C.c_double(0.0)
+        self._check(self._lib.sthip_measure_ceiling(self._h, self.CEILINGS[kind], C.byref(v)), "sthip_measure_ceiling")
+        return float(v.value)
+
     def stats(self):
         s = wire.Stats()
         self._check(self._lib.sthip_get_stats(self._h, C.byref(s)), "sthip_get_stats")

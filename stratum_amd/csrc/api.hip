@@ -18,6 +18,7 @@
 #include "bvh_build.h"
 #include "kernels.h"
 #include "post.h"
+#include "ceilings.h"
 
 namespace {
 thread_local std::string g_create_error;
@@ -26,6 +27,10 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }  // an early return (HIP_TRY) must not leak a local staging buffer
   hipError_t ensure(size_t count) {
     if (count <= n && p) return hipSuccess;
     if (p) (void)hipFree(p);
@@ -97,6 +102,8 @@ struct sthip_ctx {
   DevBuf<uint32_t> inst_alpha;
   DevBuf<unsigned long long> qctl;  // queue control lines (queue_ctl)
   DevBuf<uint32_t> post_scratch;  // maxima / metric accumulator of post.h
+  DevBuf<sthip_ray> ray_staging;  // sthip_trace_rays with host pointers
+  DevBuf<sthip_hit> hit_staging;
   DevBuf<float4> out_radiance, out_albedo;
   DevBuf<sthip_VisibilityInfo> out_visibility;
   DevBuf<sthip_DepthInfo> out_depth;
@@ -317,10 +324,58 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (s->instance_count > 0xFFFF) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: more than 65535 instances (16-bit instance index, scene.h:23)");
   if (s->light_count && !s->gLightInstances) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: light_count > 0 but gLightInstances is NULL");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // frames of the previous scene may still be in flight on the caller's stream (device output pointers: sthip_render only
+  // enqueues), and the copies below go through the null stream, which a non-blocking stream does not wait for
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->has_scene = false;
   for (uint32_t i = 0; i < s->light_count; i++)
     if (s->gLightInstances[i] >= s->instance_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: gLightInstances entry out of range");
   bool any_specular = false, any_image = false, any_alpha = false;
+  if (s->image_count && !s->gImages) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: image_count > 0 but gImages is NULL");
+  // Per-channel extremes of an image (level 0; every mip level is an average of it, and bilinear / trilinear taps are
+  // convex combinations, so a sampled value lies between them). Scanned on first use: the device multiplies the
+  // constant by the texel (image_value.h:194-198), so whether a material can be specular depends on the texels.
+  std::vector<int> scanned(s->image_count, 0);
+  std::vector<float> tex_min((size_t)s->image_count * 4, 0.0f), tex_max((size_t)s->image_count * 4, 0.0f);
+  auto image_range = [&](uint32_t index, int channel, float& lo, float& hi) {
+    if (!scanned[index]) {
+      const float* px = s->gImages[index].pixels;
+      const size_t count = (size_t)s->gImages[index].width * s->gImages[index].height;
+      for (int c = 0; c < 4; c++) {
+        float a = __builtin_inff(), b = -__builtin_inff();
+        bool nan = false;
+        for (size_t k = 0; px && k < count; k++) {
+          const float t = px[4 * k + c];
+          if (t != t) nan = true;
+          a = std::min(a, t);
+          b = std::max(b, t);
+        }
+        if (nan || !px || !count) a = -__builtin_inff(), b = __builtin_inff();  // unknown: everything is possible
+        tex_min[(size_t)index * 4 + c] = a;
+        tex_max[(size_t)index * 4 + c] = b;
+      }
+      scanned[index] = 1;
+    }
+    lo = tex_min[(size_t)index * 4 + channel];
+    hi = tex_max[(size_t)index * 4 + channel];
+  };
+  // bounds of one component of an image value: constant, or constant * texel (zero when no component of the constant is positive)
+  auto value_range = [&](const sthip_MaterialRecord& rec, int k, int channel, float& lo, float& hi) {
+    const float c = rec.values[k].value[channel];
+    lo = hi = c;
+    const uint32_t index = rec.values[k].image_index;
+    if (index >= STHIP_IMAGE_COUNT || index >= s->image_count) return;
+    const float* v = rec.values[k].value;
+    if (!(v[0] > 0 || v[1] > 0 || v[2] > 0 || v[3] > 0)) {
+      lo = hi = 0.0f;
+      return;
+    }
+    float a, b;
+    image_range(index, channel, a, b);
+    lo = std::min(c * a, c * b);
+    hi = std::max(c * a, c * b);
+    if (lo != lo || hi != hi) lo = -__builtin_inff(), hi = __builtin_inff();
+  };
   // materials: constant values or image values over gImages (image_value.h:183-207)
   for (uint32_t i = 0; i < s->instance_count; i++) {
     const uint32_t addr = s->gInstances[i].packed[0] >> 4;
@@ -329,6 +384,9 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
       uint32_t vol[2];
       memcpy(vol, (const uint8_t*)s->gMaterialData + addr + 32, 8);
       if (vol[0] >= s->volume_count || (vol[1] != 0xFFFFFFFFu && vol[1] >= s->volume_count)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: a medium refers to a volume that is not in gVolumes");
+      float anisotropy;
+      memcpy(&anisotropy, (const uint8_t*)s->gMaterialData + addr + 12, 4);
+      if (!(fabsf(anisotropy) <= 0.999f)) any_specular = true;  // Medium::is_specular (medium.hlsli:22): its vertices are not diffuse vertices
       continue;
     }
     if ((size_t)addr + sizeof(sthip_MaterialRecord) > s->material_bytes) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: material_address out of range");
@@ -347,8 +405,13 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
       if (rec.alpha_mask_index >= s->image1_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: a material refers to an alpha mask that is not in gImage1s");
       any_alpha = true;
     }
-    const float metallic = rec.values[1].value[0], roughness = rec.values[1].value[1], transmission = rec.values[2].value[2];
-    if ((metallic > 0.999f || transmission > 0.999f) && roughness <= 1e-2f) any_specular = true;
+    // DisneyMaterial::is_specular (disney_material.hlsli:125) is evaluated per hit on value * texel, so the host test is
+    // over what the product can reach: conservative (a "maybe" only costs bounce rounds that find empty queues)
+    float lo, metallic_hi, roughness_lo, transmission_hi;
+    value_range(rec, 1, 0, lo, metallic_hi);
+    value_range(rec, 1, 1, roughness_lo, lo);
+    value_range(rec, 2, 2, lo, transmission_hi);
+    if ((metallic_hi > 0.999f || transmission_hi > 0.999f) && roughness_lo <= 1e-2f) any_specular = true;
   }
   ctx->has_specular = any_specular;
   ctx->textured = any_image;
@@ -551,8 +614,8 @@ int sthip_trace_rays(sthip_ctx* ctx, const sthip_ray* rays, uint32_t ray_count, 
   if (ray_count == 0) return STHIP_OK;
   const sthip_ray* d_rays = rays;
   sthip_hit* d_hits = hits;
-  DevBuf<sthip_ray> rb;
-  DevBuf<sthip_hit> hb;
+  DevBuf<sthip_ray>& rb = ctx->ray_staging;  // kept in the context: no hipMalloc / hipFree per call
+  DevBuf<sthip_hit>& hb = ctx->hit_staging;
   if (!device_ptrs) {
     HIP_TRY(ctx, rb.ensure(ray_count));
     HIP_TRY(ctx, hb.ensure(ray_count));
@@ -589,8 +652,6 @@ int sthip_trace_rays(sthip_ctx* ctx, const sthip_ray* rays, uint32_t ray_count, 
     ctx->stats.tris_tested = c[CNT_TRIS];
     ctx->stats.nodes_visited_shadow = c[CNT_NODES + 1];
     ctx->stats.tris_tested_shadow = c[CNT_TRIS + 1];
-    rb.release();
-    hb.release();
   }
   return STHIP_OK;
 }
@@ -1355,6 +1416,59 @@ int sthip_image_compare(sthip_ctx* ctx, const float* image1, const float* image2
   HIP_TRY(ctx, hipStreamSynchronize(st));
   *sum_out = r[0];
   if (overflow_out) *overflow_out = r[1];
+  return STHIP_OK;
+}
+
+// ---- measured ceilings for the roofline (ceilings.h) ----
+int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s) {
+  if (!ctx || !gbytes_per_s) return STHIP_ERR_INVALID_ARGUMENT;
+  *gbytes_per_s = 0.0;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const uint32_t blocks = (uint32_t)ctx->cu_count * 8u;  // 2048 threads per CU: every wave slot
+  float best_ms = 0.0f;
+  double bytes = 0.0;
+  if (kind == STHIP_CEILING_TRIAD) {
+    const size_t n = (size_t)32 << 20;  // 3 arrays of 512 MiB: far beyond the 256 MiB Infinity Cache
+    DevBuf<float4> a, b, c;
+    HIP_TRY(ctx, a.ensure(n));
+    HIP_TRY(ctx, b.ensure(n));
+    HIP_TRY(ctx, c.ensure(n));
+    HIP_TRY(ctx, hipMemsetAsync(a.p, 0, n * 16, st));
+    HIP_TRY(ctx, hipMemsetAsync(b.p, 0, n * 16, st));
+    bytes = 3.0 * 16.0 * (double)n;
+    for (int rep = 0; rep < 4; rep++) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+      hipLaunchKernelGGL(k_ceiling_triad, dim3(blocks), dim3(256), 0, st, a.p, b.p, c.p, 0.5f, n);
+      HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+      HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
+      float ms = 0;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+      if (rep > 0 && (best_ms == 0.0f || ms < best_ms)) best_ms = ms;
+    }
+  } else if (kind == STHIP_CEILING_NODE_GATHER_TABLE || kind == STHIP_CEILING_NODE_GATHER_L2 || kind == STHIP_CEILING_NODE_GATHER_L1) {
+    if (!ctx->has_scene || !ctx->bvh_nodes) return fail(ctx, STHIP_ERR_NO_SCENE, "sthip_measure_ceiling: the node-gather ceilings read the resident acceleration structure: upload a scene first");
+    uint32_t count = (uint32_t)std::min<uint64_t>(ctx->bvh_nodes, 0xFFFFFFFFull);
+    if (kind == STHIP_CEILING_NODE_GATHER_L2) count = std::min<uint32_t>(count, (2u << 20) / 64u);
+    if (kind == STHIP_CEILING_NODE_GATHER_L1) count = std::min<uint32_t>(count, (16u << 10) / 64u);
+    const uint32_t iterations = 64;
+    DevBuf<float> sink;
+    HIP_TRY(ctx, sink.ensure((size_t)blocks * 256));
+    bytes = 64.0 * (double)blocks * 256.0 * iterations * CEIL_UNROLL;
+    for (int rep = 0; rep < 4; rep++) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+      hipLaunchKernelGGL(k_ceiling_node_gather, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->nodes.p), count, iterations, sink.p);
+      HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+      HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
+      float ms = 0;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+      if (rep > 0 && (best_ms == 0.0f || ms < best_ms)) best_ms = ms;
+    }
+  } else {
+    return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_measure_ceiling: unknown kind");
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  if (best_ms > 0.0f) *gbytes_per_s = bytes / ((double)best_ms * 1e-3) / 1e9;
   return STHIP_OK;
 }
 

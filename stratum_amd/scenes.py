@@ -420,14 +420,20 @@ def _bump_image(n, cells):
     return np.concatenate([nrm * 0.5 + 0.5, np.ones((n, n, 1))], -1).astype(np.float32)
 
 
-def textured_box():
+def textured_box(mirror_map=False):
     """Cornell-like box: checker floor with a normal map, noise-textured walls, a textured emitter, metal block
-    with a roughness map. Exercises image values, mip selection through ray cones, normal maps."""
+    with a roughness map. Exercises image values, mip selection through ray cones, normal maps.
+    mirror_map: the roughness map is a checker whose dark squares are 0, so the metal ball (constant roughness 0.6, not
+    specular by its constants) IS specular at those texels (is_specular is evaluated on value * texel,
+    disney_material.hlsli:125 after image_value.h:194-198) and paths run on past gMaxDiffuseVertices there."""
     b = SceneBuilder("textured_box")
     img_checker = b.add_image(_checker(256, 8, (0.9, 0.9, 0.9), (0.15, 0.2, 0.6)))
     img_noise = b.add_image(_noise_image(128, 5, (0.3, 0.3, 0.3), (1.0, 1.0, 1.0)))
     img_bump = b.add_image(_bump_image(128, 8))
-    img_rough = b.add_image(_noise_image(64, 9, (1.0, 0.05, 0.0, ), (1.0, 1.0, 0.0), freq=4.0))
+    if mirror_map:
+        img_rough = b.add_image(_checker(64, 4, (1.0, 0.0, 0.0), (1.0, 1.0, 0.0)))
+    else:
+        img_rough = b.add_image(_noise_image(64, 9, (1.0, 0.05, 0.0, ), (1.0, 1.0, 0.0), freq=4.0))
     img_light = b.add_image(_checker(16, 4, (1.0, 1.0, 1.0), (0.3, 0.3, 0.3)))
 
     floor = b.add_material((1.0, 1.0, 1.0), roughness=0.4)

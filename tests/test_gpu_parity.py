@@ -357,6 +357,17 @@ def test_textured_scene(flags):
         r.close()
 
 
+def test_roughness_map_reaching_zero_makes_specular_chains(renderer):
+    """A material that is specular only through its texture (metallic 1, roughness constant 0.6 times a map whose dark
+    squares are 0): the host must not cap the bounce rounds at gMaxDiffuseVertices + 1 from the constants alone, or
+    the radiance of the mirror chains (up to gMaxPathVertices - 1 rays) is lost. Bit-exact ids and ray counts."""
+    sc, cam = scenes.textured_box(mirror_map=True)
+    got = _compare_frame(sc, cam, [], w=192, h=160, seeds=2, args={"maxPathVertices": 8, "maxDiffuseVertices": 2})
+    # the chains beyond gMaxDiffuseVertices + 1 rays exist in this scene: cutting the path length at 4 vertices loses rays
+    short = _compare_frame(sc, cam, [], w=192, h=160, seeds=2, args={"maxPathVertices": 4, "maxDiffuseVertices": 2})
+    assert int(got["ray_count"][1]) > int(short["ray_count"][1])
+
+
 # ---- SURVEY.md §8f N2: sphere instances / sphere lights / environment maps ----
 def _compare_frame(sc, cam, flags, w=176, h=128, seeds=2, args=None):
     from oracle import oracle_py
