@@ -72,6 +72,8 @@ def _bind(L):
             C.c_int,
             C.c_void_p,
         ]
+        L.orc_render_window.restype = C.c_int
+        L.orc_render_window.argtypes = L.orc_render.argtypes + [C.c_void_p]
         L.orc_trace_rays.restype = C.c_int
         L.orc_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_pcg.restype = C.c_uint32
@@ -98,7 +100,9 @@ class OracleScene:
     def __del__(self):
         self.close()
 
-    def render(self, frame, push_constants, sampling_flags=wire.DEFAULT_SAMPLING_FLAGS, seed_begin=0, seed_count=1, threads=0, aovs=True):
+    def render(self, frame, push_constants, sampling_flags=wire.DEFAULT_SAMPLING_FLAGS, seed_begin=0, seed_count=1, threads=0, aovs=True, window=None):
+        """window = (x0, y0, x1, y1): render only that rectangle of the frame (the same pixels the whole frame has there);
+        the arrays returned are still W x H, zero outside the window."""
         W, H = frame.width, frame.height
         out = {
             "radiance": np.zeros((H, W, 4), np.float32),
@@ -121,8 +125,10 @@ class OracleScene:
         if self.scene.volumes:
             frame.view_medium_instances = self.scene.view_medium_instances(frame.view_transforms)
         fd = frame.desc()
-        rc = self._L.orc_render(
-            self.h, C.byref(push_constants), sampling_flags, self.scene.scene_flags, C.byref(fd), seed_begin, seed_count, C.byref(o), threads, wire.ptr(out["stats"])
+        win = np.asarray(window, np.uint32) if window is not None else None
+        rc = self._L.orc_render_window(
+            self.h, C.byref(push_constants), sampling_flags, self.scene.scene_flags, C.byref(fd), seed_begin, seed_count, C.byref(o), threads, wire.ptr(out["stats"]),
+            wire.ptr(win) if win is not None else None,
         )
         if rc != 0:
             raise RuntimeError("orc_render failed: %d" % rc)

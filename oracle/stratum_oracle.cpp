@@ -3102,8 +3102,17 @@ void trace_light_paths(const Frame& fr, uint32_t seed, int threads, uint64_t* ts
 }
 
 // stats_out[4]: rays_total (gRayCount[0]), rays_path (gRayCount[1]), nodes visited, triangles tested
+int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin,
+                      uint32_t seed_count, const sthip_outputs* out, int threads, uint64_t* stats_out, const uint32_t* window);
 int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin,
                uint32_t seed_count, const sthip_outputs* out, int threads, uint64_t* stats_out) {
+  return orc_render_window(sc, pc, sampling_flags, scene_flags, frame, seed_begin, seed_count, out, threads, stats_out, nullptr);
+}
+// window = {x0, y0, x1, y1} (may be NULL: the whole frame): only the pixels of that rectangle of the W x H frame are
+// rendered — exactly the pixels the full frame has there (same pixel coordinates, hence the same rays and RNG keys); the
+// others are left as the caller passed them. For the parity tests of frames too large for the oracle to render whole.
+int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin,
+                      uint32_t seed_count, const sthip_outputs* out, int threads, uint64_t* stats_out, const uint32_t* window) {
   if (!sc || !pc || !frame || !out || !out->gRadiance || !frame->gViews || !frame->gViewTransforms) return STHIP_ERR_INVALID_ARGUMENT;
   if (scene_flags & STHIP_BDPT_FLAG_TRACE_LIGHT) return STHIP_ERR_UNSUPPORTED;
 
@@ -3195,8 +3204,12 @@ int orc_render(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t sampli
       if (light_tracing) trace_light_paths(lf, seed_begin + s, threads, tstats.data());
     }
   }
-  parallel_rows(H, threads, [&](uint32_t y, int tid) {
-    for (uint32_t x = 0; x < W; x++) {
+  const uint32_t wx0 = window ? std::min(window[0], W) : 0u, wy0 = window ? std::min(window[1], H) : 0u;
+  const uint32_t wx1 = window ? std::min(window[2], W) : W, wy1 = window ? std::min(window[3], H) : H;
+  if (window && fr.bdpt()) return STHIP_ERR_UNSUPPORTED;  // light subpaths are a whole-frame pass
+  parallel_rows(wy1 > wy0 ? wy1 - wy0 : 0u, threads, [&](uint32_t row, int tid) {
+    const uint32_t y = wy0 + row;
+    for (uint32_t x = wx0; x < wx1; x++) {
       const size_t p = (size_t)y * W + x;
       // temporal_accumulation.hlsl:102-131: running mean, NaN/Inf samples are dropped
       float acc[4] = {0, 0, 0, 0};

@@ -32,6 +32,8 @@
 #include <utility>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "../../include/sthip.h"
 
 namespace stm {
@@ -1052,5 +1054,57 @@ class BDPT {
   std::vector<TransformData> mPrevInverseViewTransforms;
   Frame mPrevFrame;
 };
+
+// ---------------------------------------------------------------------------------------------
+// Plugin loading: the component main.cpp attaches per `--plugin=<lib>;<fn>;<fn>...` argument
+// (src/main.cpp:11-24,148-149) over src/Common/dynamic_library.hpp:7-59. Same contract: the library is opened
+// with RTLD_NOW when the component is made and stays loaded for the component's life; invoke<R, Args...>(name, args...)
+// resolves `name` once (cached) and calls it as R(*)(Args...); a library that does not load throws runtime_error, a
+// missing symbol invalid_argument.
+// ---------------------------------------------------------------------------------------------
+class dynamic_library {
+ public:
+  // RTLD_NODELETE: components a plugin function makes carry deleters whose code lives in the plugin, and a node graph
+  // destroys its components in no particular order — dlclose() then only drops the handle, the code stays mapped
+  explicit dynamic_library(const std::string& filename) : mHandle(dlopen(filename.c_str(), RTLD_NOW | RTLD_NODELETE)) {
+    if (!mHandle) {
+      const char* why = dlerror();
+      throw std::runtime_error("Failed to load " + filename + (why ? std::string(": ") + why : std::string()));
+    }
+  }
+  dynamic_library(const dynamic_library&) = delete;
+  dynamic_library& operator=(const dynamic_library&) = delete;
+  ~dynamic_library() {
+    if (mHandle) dlclose(mHandle);
+  }
+  template <typename return_t, typename... Args>
+  return_t invoke(const std::string& name, Args... args) {
+    auto it = mFunctionPtrs.find(name);
+    if (it == mFunctionPtrs.end()) it = mFunctionPtrs.emplace(name, dlsym(mHandle, name.c_str())).first;
+    if (!it->second) throw std::invalid_argument("Could not find function " + name);
+    using fn_t = return_t (*)(Args...);
+    return reinterpret_cast<fn_t>(it->second)(std::forward<Args>(args)...);
+  }
+
+ private:
+  void* mHandle;
+  std::unordered_map<std::string, void*> mFunctionPtrs;
+};
+
+// `plugin_info` = "<library>;<function>;<function>...": a child node named after the library's stem under `dst` carries the
+// dynamic_library component, and every named function is called with that child node (main.cpp:11-24)
+inline void load_plugins(const std::string& plugin_info, Node& dst) {
+  const size_t first = plugin_info.find(';');
+  const std::string filename = plugin_info.substr(0, first);
+  std::string stem = filename.substr(filename.find_last_of('/') == std::string::npos ? 0 : filename.find_last_of('/') + 1);
+  if (stem.find_last_of('.') != std::string::npos && stem.find_last_of('.') > 0) stem = stem.substr(0, stem.find_last_of('.'));
+  auto plugin = dst.make_child(stem).make_component<dynamic_library>(filename);
+  for (size_t at = first; at != std::string::npos;) {
+    const size_t next = plugin_info.find(';', at + 1);
+    const std::string fn = plugin_info.substr(at + 1, next == std::string::npos ? std::string::npos : next - at - 1);
+    plugin->invoke<void, Node&>(fn, plugin.node());
+    at = next;
+  }
+}
 
 }  // namespace stm

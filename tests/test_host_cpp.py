@@ -130,3 +130,40 @@ def test_cpp_host_moves_instances_with_a_top_level_rebuild(host_test, tmp_path):
         r.close()
     assert np.array_equal(rad.view(np.uint32), ref["radiance"].view(np.uint32))
     assert np.array_equal(prev_uv.view(np.uint32), ref["prev_uv"].view(np.uint32))
+
+
+# ---- the plugin boundary: `--plugin=libstratum_hip_plugin.so;stratum_hip_register` (main.cpp:11-24,148-149) ----
+def _plugin_host(built, spec):
+    import __graft_entry__ as g
+
+    g.build_plugin()
+    return subprocess.run([g.PLUGIN_HOST, spec], capture_output=True, text=True)
+
+
+def test_plugin_loads_and_its_entry_point_runs(built):
+    """dlopen(RTLD_NOW) of the plugin resolves every symbol (it links libstratum_hip.so by $ORIGIN), dlsym finds the entry
+    point, and calling it with a stm::Node& constructs the renderer — which needs a HIP device: on a box without one the
+    only acceptable outcome is the sthip_create error (exit 3), never a load failure or a missing symbol."""
+    import __graft_entry__ as g
+
+    out = _plugin_host(built, g.PLUGIN + ";stratum_hip_register")
+    assert out.returncode in (0, 3), out.stdout + out.stderr
+    assert ("PLUGIN OK" in out.stdout) if out.returncode == 0 else ("sthip_create" in out.stdout)
+
+
+def test_plugin_loader_errors_are_the_references(built):
+    """dynamic_library.hpp:29,50: a library that does not load throws runtime_error, a missing symbol invalid_argument."""
+    import __graft_entry__ as g
+
+    out = _plugin_host(built, g.PLUGIN + ";no_such_entry_point")
+    assert out.returncode == 4 and "Could not find function no_such_entry_point" in out.stdout
+    out = _plugin_host(built, "/nonexistent/libnope.so;stratum_hip_register")
+    assert out.returncode == 5 and "Failed to load /nonexistent/libnope.so" in out.stdout
+
+
+@pytest.mark.gpu
+def test_plugin_installs_the_renderer_on_a_gpu(built):
+    import __graft_entry__ as g
+
+    out = _plugin_host(built, g.PLUGIN + ";stratum_hip_register")
+    assert out.returncode == 0 and "PLUGIN OK" in out.stdout, out.stdout + out.stderr

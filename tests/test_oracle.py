@@ -59,6 +59,28 @@ def test_pcg_and_xxhash_scalar():
         assert orc.lib().orc_xxhash32(v) == xx(v)
 
 
+def test_xxhash32_against_the_xxhash_library():
+    """A known answer from OUTSIDE this repository: rng.hlsli:6-15 is the Shadertoy shortening of XXH32 for one 32-bit
+    word (cited there: github.com/Cyan4973/xxHash) — the library's 4-byte path is
+        h = seed + PRIME5 + len;  h += word * PRIME3;  h = rotl(h, 17) * PRIME4;  avalanche(h)
+    and the shader keeps the rotate, PRIME4 and the avalanche but starts from h = p + PRIME5. So for every p there is a
+    word x with PRIME5 + 4 + x * PRIME3 == p + PRIME5 (PRIME3 is odd, hence invertible mod 2^32), and
+    xxhash32(p) must equal the real XXH32 of that word with seed 0, computed by the xxhash package (C reference code)."""
+    import struct
+
+    xxhash = pytest.importorskip("xxhash")
+    P3 = 3266489917
+    inv = pow(P3, -1, 1 << 32)
+    assert (P3 * inv) & 0xFFFFFFFF == 1
+    rng = np.random.RandomState(7)
+    values = [0, 1, 4, 5, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF] + [int(v) for v in rng.randint(0, 2**32, 2000, dtype=np.uint64)]
+    for p in values:
+        x = ((p - 4) * inv) & 0xFFFFFFFF
+        assert orc.lib().orc_xxhash32(p) == xxhash.xxh32(struct.pack("<I", x), seed=0).intdigest(), hex(p)
+    # and the library itself answers its published test value for the empty input (xxHash README / xxhsum self-test)
+    assert xxhash.xxh32(b"", seed=0).intdigest() == 0x02CC5D05
+
+
 def test_rng_stream_is_counter_based():
     """rng.hlsli:35-47: counter++ THEN hash; float = asfloat(0x3f800000 | u >> 9) - 1 in [0, 1)."""
     f = orc.rng_floats(17, 4, 9, 0, 64)
