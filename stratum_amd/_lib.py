@@ -68,6 +68,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    if os.environ.get("STHIP_LIB"):  # development: A/B of kernel variants built side by side (tools/ab_variants.py)
+        LIB_PATH = os.environ["STHIP_LIB"]
     if not os.path.exists(LIB_PATH):
         raise StratumHipError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

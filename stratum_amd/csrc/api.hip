@@ -81,11 +81,16 @@ struct sthip_ctx {
   uint32_t image_count = 0;
   DevBuf<float2> cone;
   uint32_t instance_count = 0, light_count = 0;
-  DevBuf<BvhNode> nodes;
+  DevBuf<BvhNodePacked> nodes;
   DevBuf<BvhTri> tris;
   DevBuf<TlasEntry> entries;
   DeviceBvh bvh{};
   uint64_t bvh_nodes = 0, bvh_tris = 0;
+  // treetop (bvh_build.h): rebuilt whenever the top level changes; needs the nodes on the host
+  std::vector<BvhNode> nodes_host;
+  DevBuf<BvhNodePacked> top_nodes;
+  DevBuf<TlasEntry> top_entries;
+  bool use_treetop = true;
   // frame
   DevBuf<uint8_t> views;  // gViews | gViewTransforms | gPrevViews | gPrevInverseViewTransforms
   DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays, light_vertices, conn, media_state, shadow_hit, shadow_ext, shadow_result;
@@ -185,7 +190,7 @@ int sthip_create(int device, sthip_ctx** out_ctx) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
   (void)hipEventCreate(&ctx->ev[0]);
   (void)hipEventCreate(&ctx->ev[1]);
-  ctx->stats.bvh_node_bytes = sizeof(BvhNode);
+  ctx->stats.bvh_node_bytes = sizeof(BvhNodePacked);
   ctx->stats.bvh_tri_bytes = sizeof(BvhTri);
   *out_ctx = ctx;
   return STHIP_OK;
@@ -288,6 +293,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->max_paths_in_flight = (uint64_t)std::max<int64_t>(1, value);
   else if (!strcmp(name, "trace_blocks_per_cu"))
     ctx->trace_blocks_per_cu = (uint32_t)std::min<int64_t>(16, std::max<int64_t>(0, value));
+  else if (!strcmp(name, "treetop"))  // takes effect at the next sthip_scene_upload / sthip_scene_update_transforms
+    ctx->use_treetop = value != 0;
   else if (!strcmp(name, "inner_min_lanes"))
     ctx->inner_min_lanes = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
   else
@@ -306,7 +313,7 @@ int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out) {
     ctx->stats_pending = false;
   }
   *out = ctx->stats;
-  out->bvh_node_bytes = sizeof(BvhNode);
+  out->bvh_node_bytes = sizeof(BvhNodePacked);
   out->bvh_tri_bytes = sizeof(BvhTri);
   out->bvh_nodes = ctx->bvh_nodes;
   out->bvh_tris = ctx->bvh_tris;
@@ -314,6 +321,7 @@ int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out) {
 }
 
 static size_t stack_bytes(const sthip_ctx* ctx);
+static int refresh_treetop(sthip_ctx* ctx);
 
 int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
@@ -511,7 +519,11 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   HIP_TRY(ctx, ctx->nodes.ensure(std::max<size_t>(1, built.top.blas_nodes + 2 * built.entries.size() + 2)));
   HIP_TRY(ctx, ctx->tris.ensure(std::max<size_t>(1, built.tris.size())));
   HIP_TRY(ctx, ctx->entries.ensure(std::max<size_t>(1, built.entries.size())));
-  if (!built.nodes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->nodes.p, built.nodes.data(), built.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+  if (!built.nodes.empty()) {
+    std::vector<BvhNodePacked> packed;
+    sthip::pack_nodes(built.nodes.data(), built.nodes.size(), packed);
+    HIP_TRY(ctx, hipMemcpy(ctx->nodes.p, packed.data(), packed.size() * sizeof(BvhNodePacked), hipMemcpyHostToDevice));
+  }
   if (!built.tris.empty()) HIP_TRY(ctx, hipMemcpy(ctx->tris.p, built.tris.data(), built.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
   if (!built.entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->entries.p, built.entries.data(), built.entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
   {  // alpha masks: one-channel images and the per-triangle uvs the traversal interpolates
@@ -579,12 +591,18 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->bvh_nodes = built.nodes.size();
   ctx->bvh_tris = built.tris.size();
   ctx->top = std::move(built.top);
+  ctx->nodes_host = std::move(built.nodes);
+  ctx->nodes_host.resize(std::max<size_t>(ctx->nodes_host.size(), ctx->nodes.n));  // room for a rebuilt top level
+  {
+    const int rc = refresh_treetop(ctx);
+    if (rc != STHIP_OK) return rc;
+  }
   ctx->has_scene = true;
   if (getenv("STHIP_VERBOSE")) {
     int per_cu = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false>, STHIP_BLOCK, stack_bytes(ctx));
     fprintf(stderr, "[sthip] bvh (%s): %zu nodes, %zu tris, %zu top-level entries, stack depth %u (%zu B LDS / block), %d trace blocks / CU, build %.1f ms (GPU kernels %.2f ms)\n",
-            ctx->bvh_builder ? "lbvh/gpu" : "sah/host", built.nodes.size(), built.tris.size(), built.entries.size(), built.stack_depth, stack_bytes(ctx), per_cu, ctx->stats.bvh_build_ms,
+            ctx->bvh_builder ? "lbvh/gpu" : "sah/host", (size_t)ctx->bvh_nodes, built.tris.size(), built.entries.size(), built.stack_depth, stack_bytes(ctx), per_cu, ctx->stats.bvh_build_ms,
             ctx->stats.bvh_build_gpu_ms);
   }
   return STHIP_OK;
@@ -606,6 +624,48 @@ static uint32_t trace_grid(sthip_ctx* ctx, size_t lds_bytes) {
   return (uint32_t)(ctx->cu_count * per_cu);
 }
 static size_t stack_bytes(const sthip_ctx* ctx) { return (size_t)ctx->bvh.stack_depth * STHIP_BLOCK * sizeof(uint32_t); }
+
+// LDS of one k_trace block: the per-lane stacks and, behind them, the treetop
+static size_t trace_lds_bytes(const sthip_ctx* ctx) { return stack_bytes(ctx) + (size_t)ctx->bvh.top_count * sizeof(BvhNodePacked); }
+
+// (Re)builds the treetop for the current top level: as many nodes as fit into the LDS the stacks leave free at the
+// occupancy the kernel's registers allow anyway (the treetop must not cost a resident block).
+static int refresh_treetop(sthip_ctx* ctx) {
+  ctx->bvh.top_nodes = nullptr;
+  ctx->bvh.top_entries = ctx->bvh.entries;
+  ctx->bvh.top_root_ref = ctx->bvh.root_ref;
+  ctx->bvh.top_count = 0;
+  if (!ctx->use_treetop || ctx->nodes_host.empty()) return STHIP_OK;
+  int per_cu = 0;
+  const size_t stack = stack_bytes(ctx);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false>, STHIP_BLOCK, stack) != hipSuccess || per_cu < 1) return STHIP_OK;
+  if (ctx->trace_blocks_per_cu) per_cu = (int)ctx->trace_blocks_per_cu;
+  const size_t lds_per_cu = 160 * 1024, per_block = lds_per_cu / (size_t)per_cu;
+  if (per_block < stack + 2048) return STHIP_OK;
+  uint32_t capacity = (uint32_t)std::min<size_t>((per_block - stack - 1024) / sizeof(BvhNodePacked), 2048);
+  while (capacity >= 16) {  // the allocation granularity is the runtime's: ask it
+    int got = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, k_trace<false, false>, STHIP_BLOCK, stack + (size_t)capacity * sizeof(BvhNodePacked)) == hipSuccess && got >= per_cu) break;
+    capacity -= 16;
+  }
+  if (capacity < 16) return STHIP_OK;
+  sthip::Treetop tt;
+  sthip::build_treetop(ctx->nodes_host.data(), (size_t)ctx->bvh_nodes, ctx->top.entries, ctx->bvh.root_ref, capacity, tt);
+  if (tt.nodes.empty()) return STHIP_OK;
+  HIP_TRY(ctx, ctx->top_nodes.ensure(tt.nodes.size()));
+  HIP_TRY(ctx, ctx->top_entries.ensure(std::max<size_t>(1, tt.entries.size())));
+  {
+    std::vector<BvhNodePacked> packed;
+    sthip::pack_nodes(tt.nodes.data(), tt.nodes.size(), packed);
+    HIP_TRY(ctx, hipMemcpy(ctx->top_nodes.p, packed.data(), packed.size() * sizeof(BvhNodePacked), hipMemcpyHostToDevice));
+  }
+  if (!tt.entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->top_entries.p, tt.entries.data(), tt.entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
+  ctx->bvh.top_nodes = reinterpret_cast<const float4*>(ctx->top_nodes.p);
+  ctx->bvh.top_entries = ctx->top_entries.p;
+  ctx->bvh.top_root_ref = tt.root_ref;
+  ctx->bvh.top_count = (uint32_t)tt.nodes.size();
+  return STHIP_OK;
+}
 
 int sthip_trace_rays(sthip_ctx* ctx, const sthip_ray* rays, uint32_t ray_count, sthip_hit* hits, uint32_t any_hit, uint32_t device_ptrs) {
   if (!ctx || !rays || !hits) return STHIP_ERR_INVALID_ARGUMENT;
@@ -683,7 +743,11 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
     HIP_TRY(ctx, hipMemcpy(ctx->motion_xf.p, I.data(), (size_t)n * 48, hipMemcpyHostToDevice));
   }
   if (!next.entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->entries.p, next.entries.data(), next.entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
-  if (!tlas.empty()) HIP_TRY(ctx, hipMemcpy(ctx->nodes.p + next.blas_nodes, tlas.data(), tlas.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+  if (!tlas.empty()) {
+    std::vector<BvhNodePacked> packed;
+    sthip::pack_nodes(tlas.data(), tlas.size(), packed);
+    HIP_TRY(ctx, hipMemcpy(ctx->nodes.p + next.blas_nodes, packed.data(), packed.size() * sizeof(BvhNodePacked), hipMemcpyHostToDevice));
+  }
   ctx->bvh.root_ref = root_ref;
   ctx->bvh.top_is_world_blas = top_is_world;
   ctx->bvh.stack_depth = stack_depth;
@@ -692,8 +756,9 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
   ctx->bvh.scene_cz = center[2];
   ctx->bvh.scene_radius = radius;
   ctx->bvh_nodes = next.blas_nodes + tlas.size();
+  if (ctx->nodes_host.size() >= (size_t)next.blas_nodes + tlas.size()) std::copy(tlas.begin(), tlas.end(), ctx->nodes_host.begin() + next.blas_nodes);
   ctx->top = std::move(next);
-  return STHIP_OK;
+  return refresh_treetop(ctx);
 }
 
 int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin,
@@ -1003,7 +1068,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     }
   }
   const uint32_t grid = shade_grid;
-  const size_t lds = stack_bytes(ctx);
+  const size_t lds = trace_lds_bytes(ctx);
   const uint32_t tgrid = std::min<uint32_t>(trace_grid(ctx, lds), (uint32_t)((P + STHIP_BLOCK - 1) / STHIP_BLOCK));
   // closest-hit rays per path <= gMaxPathVertices - 1 (path.hlsli:960); without specular materials every scattering
   // vertex counts as a diffuse vertex, so the path also ends after gMaxDiffuseVertices + 1 rays (path.hlsli:964-966):
@@ -1449,15 +1514,15 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s) {
   } else if (kind == STHIP_CEILING_NODE_GATHER_TABLE || kind == STHIP_CEILING_NODE_GATHER_L2 || kind == STHIP_CEILING_NODE_GATHER_L1) {
     if (!ctx->has_scene || !ctx->bvh_nodes) return fail(ctx, STHIP_ERR_NO_SCENE, "sthip_measure_ceiling: the node-gather ceilings read the resident acceleration structure: upload a scene first");
     uint32_t count = (uint32_t)std::min<uint64_t>(ctx->bvh_nodes, 0xFFFFFFFFull);
-    if (kind == STHIP_CEILING_NODE_GATHER_L2) count = std::min<uint32_t>(count, (2u << 20) / 64u);
-    if (kind == STHIP_CEILING_NODE_GATHER_L1) count = std::min<uint32_t>(count, (16u << 10) / 64u);
+    if (kind == STHIP_CEILING_NODE_GATHER_L2) count = std::min<uint32_t>(count, (2u << 20) / (uint32_t)sizeof(BvhNodePacked));
+    if (kind == STHIP_CEILING_NODE_GATHER_L1) count = std::min<uint32_t>(count, (16u << 10) / (uint32_t)sizeof(BvhNodePacked));
     const uint32_t iterations = 64;
     DevBuf<float> sink;
     HIP_TRY(ctx, sink.ensure((size_t)blocks * 256));
-    bytes = 64.0 * (double)blocks * 256.0 * iterations * CEIL_UNROLL;
+    bytes = (double)sizeof(BvhNodePacked) * (double)blocks * 256.0 * iterations * CEIL_UNROLL;
     for (int rep = 0; rep < 4; rep++) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-      hipLaunchKernelGGL(k_ceiling_node_gather, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->nodes.p), count, iterations, sink.p);
+      hipLaunchKernelGGL(k_ceiling_node_gather, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->nodes.p), count, (uint32_t)sizeof(BvhNodePacked), iterations, sink.p);
       HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
       HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
       float ms = 0;

@@ -1,9 +1,9 @@
 // bvh.h — acceleration-structure layout in HBM (product-internal; replaces the driver-built
 // BLAS/TLAS of src/Core/AccelerationStructure.cpp:5-27 and src/Node/Scene.cpp:435-459,614-629).
 //
-// One flat array of 64-byte BVH2 nodes holds the top level and every bottom level. A node stores
-// the boxes of its two children in the Aila-Laine arrangement so that one lane fetches a node with
-// four 16-byte loads from one 64-byte segment:
+// One flat array of BVH2 nodes holds the top level and every bottom level. The builders work on the 64-byte BvhNode
+// below; what is uploaded is its 48-byte packed form (BvhNodePacked further down). A node stores
+// the boxes of its two children in the Aila-Laine arrangement:
 //     n0xy = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y)
 //     n1xy = (c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y)
 //     nz   = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)
@@ -19,6 +19,7 @@
 
 #define BVH_LEAF_BIT 0x80000000u
 #define BVH_INST_BIT 0x40000000u
+#define BVH_TOP_BIT 0x40000000u  // on an INNER reference (bit31 = 0): index into the treetop copy (bvh_build.h), not the node array
 #define BVH_MAX_LEAF_TRIS 2  // measured on the 1M-triangle atrium: 2 beats 1, 3 and 4 (the leaf reference can encode up to 4)
 #define BVH_INVALID_REF 0xFFFFFFFFu  // empty child (never intersected: box is inverted)
 
@@ -37,6 +38,19 @@ struct BvhTri {
   float v2[3];
   uint32_t pad2;
 };
+// The node as it lies in HBM (and in the LDS treetop): 48 bytes = three float4, so a lane fetches it with THREE 16-byte
+// loads. The traversal kernel is bound by the rate at which the vector-memory front end takes divergent lane loads
+// (about one lane-instruction per clock and CU, whatever its width), so the fourth load that a 64-byte node needs for
+// its two child references costs a quarter of the node bandwidth. Here the references ride in the low mantissa byte of
+// the eight x / y planes: byte k of ref[0] is the low byte of n0xy[k], byte k of ref[1] the low byte of n1xy[k]. The
+// planes are used as they are, reference byte included: pack_node() (bvh_build.h) rounds every plane outward far enough
+// (<= 511 ulp, 6e-5 relative) that the box stays conservative whatever that byte holds. z planes are exact.
+struct BvhNodePacked {
+  float n0xy[4];
+  float n1xy[4];
+  float nz[4];
+};
+#define BVH_NODE_BYTES 48u
 #define BVH_NO_ALPHA 0xFFFFFFFFu  // DeviceBvh::inst_alpha entry of an instance whose material has no alpha mask
 // uv of the three vertices of a leaf triangle, in leaf order next to BvhTri; only built for scenes with alpha masks
 struct BvhTriUv {
@@ -73,6 +87,7 @@ struct DeviceVolume {
 
 #ifdef __cplusplus
 static_assert(sizeof(BvhNode) == 64, "BvhNode");
+static_assert(sizeof(BvhNodePacked) == BVH_NODE_BYTES, "BvhNodePacked");
 static_assert(sizeof(BvhTri) == 48, "BvhTri");
 static_assert(sizeof(TlasEntry) == 80, "TlasEntry");
 #endif

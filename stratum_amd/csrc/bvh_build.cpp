@@ -13,7 +13,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <limits>
 #include <map>
+#include <queue>
+#include <unordered_map>
 #include <tuple>
 
 namespace sthip {
@@ -749,6 +752,82 @@ bool rebuild_top_level(TopLevelState& st, const sthip_TransformData* xf, const s
                                 (scene_box.hi[2] - scene_box.lo[2]) * (scene_box.hi[2] - scene_box.lo[2]));
   }
   return true;
+}
+
+namespace {
+inline float child_area(const BvhNode& n, int c) {
+  const float dx = c == 0 ? n.n0xy[1] - n.n0xy[0] : n.n1xy[1] - n.n1xy[0];
+  const float dy = c == 0 ? n.n0xy[3] - n.n0xy[2] : n.n1xy[3] - n.n1xy[2];
+  const float dz = c == 0 ? n.nz[1] - n.nz[0] : n.nz[3] - n.nz[2];
+  if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0.0f;  // inverted (empty) box
+  return dx * dy + dy * dz + dz * dx;
+}
+inline float own_area(const BvhNode& n) {  // of the union of the two child boxes
+  const float lo[3] = {std::min(n.n0xy[0], n.n1xy[0]), std::min(n.n0xy[2], n.n1xy[2]), std::min(n.nz[0], n.nz[2])};
+  const float hi[3] = {std::max(n.n0xy[1], n.n1xy[1]), std::max(n.n0xy[3], n.n1xy[3]), std::max(n.nz[1], n.nz[3])};
+  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0.0f;
+  return dx * dy + dy * dz + dz * dx;
+}
+}  // namespace
+
+void build_treetop(const BvhNode* nodes, size_t node_count, const std::vector<TlasEntry>& entries, uint32_t root_ref, uint32_t capacity, Treetop& out) {
+  out.nodes.clear();
+  out.entries = entries;
+  out.root_ref = root_ref;
+  if (capacity == 0 || root_ref == BVH_INVALID_REF || (root_ref & BVH_LEAF_BIT) || root_ref >= node_count) return;
+  // greedy: always take the candidate with the largest (world-space) box area — the chance that a ray visits a node
+  // grows with it. `scale` turns an object-space area of a transformed bottom level into a world-space one.
+  struct Cand {
+    float priority;
+    uint32_t node;
+    float scale;
+    bool operator<(const Cand& o) const { return priority < o.priority || (priority == o.priority && node > o.node); }
+  };
+  std::priority_queue<Cand> heap;
+  std::unordered_map<uint32_t, uint32_t> slot;  // node index -> treetop index
+  std::vector<uint32_t> taken;
+  heap.push({std::numeric_limits<float>::infinity(), root_ref, 1.0f});
+  while (!heap.empty() && taken.size() < capacity) {
+    const Cand c = heap.top();
+    heap.pop();
+    if (slot.count(c.node)) continue;  // a bottom level shared by several entries
+    slot.emplace(c.node, (uint32_t)taken.size());
+    taken.push_back(c.node);
+    const BvhNode& n = nodes[c.node];
+    for (int k = 0; k < 2; k++) {
+      const uint32_t ref = n.ref[k];
+      const float area = child_area(n, k) * c.scale;
+      if (!(ref & BVH_LEAF_BIT)) {
+        if (ref < node_count) heap.push({area, ref, c.scale});
+      } else if ((ref & BVH_INST_BIT) && ref < 0xFFFFFFFEu) {
+        const uint32_t e = ref & 0xFFFFu;
+        if (e >= entries.size()) continue;
+        const TlasEntry& en = entries[e];
+        if (en.identity != TLAS_ENTRY_TRANSFORMED && en.identity != TLAS_ENTRY_IDENTITY) continue;
+        if ((en.root & BVH_LEAF_BIT) || en.root >= node_count) continue;
+        const float obj = own_area(nodes[en.root]);
+        const float sc = en.identity == TLAS_ENTRY_IDENTITY ? 1.0f : (obj > 0 ? area / obj : 0.0f);
+        heap.push({area, en.root, sc});
+      }
+    }
+  }
+  out.nodes.resize(taken.size());
+  for (size_t t = 0; t < taken.size(); t++) {
+    BvhNode n = nodes[taken[t]];
+    for (int k = 0; k < 2; k++)
+      if (!(n.ref[k] & BVH_LEAF_BIT)) {
+        auto it = slot.find(n.ref[k]);
+        if (it != slot.end()) n.ref[k] = BVH_TOP_BIT | it->second;
+      }
+    out.nodes[t] = n;
+  }
+  for (TlasEntry& en : out.entries)
+    if ((en.identity == TLAS_ENTRY_TRANSFORMED || en.identity == TLAS_ENTRY_IDENTITY) && !(en.root & BVH_LEAF_BIT)) {
+      auto it = slot.find(en.root);
+      if (it != slot.end()) en.root = BVH_TOP_BIT | it->second;
+    }
+  out.root_ref = BVH_TOP_BIT | 0u;
 }
 
 }  // namespace sthip

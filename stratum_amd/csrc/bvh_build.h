@@ -1,6 +1,7 @@
 // bvh_build.h — host-side acceleration-structure build (see bvh.h for the layout)
 #pragma once
 #include <stdint.h>
+#include <string.h>
 
 #include <string>
 #include <vector>
@@ -51,6 +52,67 @@ bool build_scene_bvh(const sthip_scene_desc& scene, BuiltBvh& out, std::string& 
 // merged world-space mesh no longer has the identity transform: that needs a full build.
 bool rebuild_top_level(TopLevelState& st, const sthip_TransformData* xf, const sthip_TransformData* inv, uint32_t instance_count, std::vector<BvhNode>& tlas_nodes, uint32_t& root_ref,
                        uint32_t& top_is_world_blas, uint32_t& stack_depth, float scene_center[3], float& scene_radius, std::string& err);
+
+// The "treetop": a copy of the inner nodes a ray is most likely to visit (greedy by box surface area from the root down,
+// through top-level entries into the bottom levels they refer to), at most `capacity` of them, in an index space of its
+// own. The persistent trace kernel keeps it in LDS: a visit to one of these nodes costs an LDS read instead of four
+// divergent vector loads. Child references between treetop nodes carry BVH_TOP_BIT | treetop index; every other
+// reference is unchanged (it leaves the treetop for the node array in HBM). `entries` is a copy of the entry table whose
+// `root` is redirected into the treetop where that bottom-level root was taken. The node array itself is not touched.
+struct Treetop {
+  std::vector<BvhNode> nodes;
+  std::vector<TlasEntry> entries;
+  uint32_t root_ref = BVH_INVALID_REF;  // BVH_TOP_BIT | 0 when the treetop is not empty, else the scene's root_ref
+};
+void build_treetop(const BvhNode* nodes, size_t node_count, const std::vector<TlasEntry>& entries, uint32_t root_ref, uint32_t capacity, Treetop& out);
+
+// BvhNode -> BvhNodePacked (bvh.h). A plane whose low mantissa byte is replaced by an arbitrary byte b reads
+// sign * (M + b) in units of its ulp, M being the stored magnitude with a zero low byte. A lower plane must stay <= the true
+// one for every b, an upper plane >= it:
+//   lower, v >= 0: M = (m - 255) & ~255 (for m < 255: -0 with M = 0, i.e. values in [-255 ulp, -0]);  lower, v < 0: M = (m + 255) & ~255
+//   upper: mirrored.  Infinite / NaN planes (empty children) are clamped to +-3.4e38 first so that no byte makes a NaN.
+inline uint32_t pack_plane(float v, bool upper, uint32_t byte) {
+  if (!(v > -3.0e38f)) v = -3.0e38f;  // also NaN
+  if (v > 3.0e38f) v = 3.0e38f;
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  const bool negative = (u >> 31) != 0;
+  const uint32_t m = u & 0x7FFFFFFFu;
+  uint32_t sign, M;
+  const bool outward_grows = upper != negative;  // rounding away from the box means a larger magnitude
+  if (outward_grows) {
+    sign = negative ? 0x80000000u : 0u;
+    M = (m + 255u) & ~255u;
+  } else if (m >= 255u) {
+    sign = negative ? 0x80000000u : 0u;
+    M = (m - 255u) & ~255u;
+  } else {  // within 255 ulp of zero: step across zero, every byte then lies on the safe side
+    sign = negative ? 0u : 0x80000000u;
+    M = 0u;
+  }
+  return sign | M | (byte & 0xFFu);
+}
+inline BvhNodePacked pack_node(const BvhNode& n) {
+  BvhNodePacked q;
+  uint32_t w[8];
+  for (int k = 0; k < 4; k++) {
+    w[k] = pack_plane(n.n0xy[k], (k & 1) != 0, n.ref[0] >> (8 * k));      // lo.x, hi.x, lo.y, hi.y of child 0
+    w[4 + k] = pack_plane(n.n1xy[k], (k & 1) != 0, n.ref[1] >> (8 * k));  // of child 1
+  }
+  memcpy(q.n0xy, w, 16);
+  memcpy(q.n1xy, w + 4, 16);
+  for (int k = 0; k < 4; k++) {  // z planes are exact; only non-finite ones are clamped (they must not turn into NaN in the slab test)
+    float z = n.nz[k];
+    if (!(z > -3.0e38f)) z = -3.0e38f;
+    if (z > 3.0e38f) z = 3.0e38f;
+    q.nz[k] = z;
+  }
+  return q;
+}
+inline void pack_nodes(const BvhNode* in, size_t count, std::vector<BvhNodePacked>& out) {
+  out.resize(count);
+  for (size_t i = 0; i < count; i++) out[i] = pack_node(in[i]);
+}
 
 // GPU LBVH of one mesh (lbvh.hip): appends nodes and leaf-ordered triangles to the outputs.
 bool lbvh_build_gpu(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhTri>& tris_out, uint32_t& root_ref, uint32_t& stack_need, float& gpu_ms,

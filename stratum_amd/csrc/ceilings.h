@@ -2,10 +2,10 @@
 //
 // SURVEY.md section 8(d) prices k_trace against the HBM peak, but the acceleration structure of the bench scene (26 MB of
 // nodes + 38 MB of leaf triangles) lives in L2 + Infinity Cache, so HBM is not what a node fetch waits for. What binds a
-// divergent traversal is the rate at which the vector-memory path delivers 64-byte nodes to 64 lanes that each ask for a
+// divergent traversal is the rate at which the vector-memory path delivers nodes to 64 lanes that each ask for a
 // different one. That rate is a property of the chip and of where the table is served from, and it can be measured:
-// the kernels below issue the traversal's own node fetch (3 x global_load_dwordx4 + 1 x global_load_dwordx2 per lane
-// from one 64-byte node) at pseudo-random node indices with NO dependence between fetches (8 in flight per lane, full
+// the kernels below issue the traversal's own node fetch (3 x global_load_dwordx4 per lane from one 48-byte packed
+// node, bvh.h) at pseudo-random node indices with NO dependence between fetches (8 in flight per lane, full
 // occupancy), i.e. the same bytes through the same units with the latency chain and the arithmetic taken away.
 //   * over the whole resident node array        -> what L2 / Infinity Cache deliver to random node fetches
 //   * over a 2 MB prefix of it (fits one XCD L2) -> the L2-hit rate of the same access
@@ -25,8 +25,8 @@ __device__ __forceinline__ uint32_t ceil_pcg(uint32_t v) {  // Jarzynski & Olano
   return (word >> 22u) ^ word;
 }
 
-// nodes: the BVH node array (64-byte records); node_count: how many of them to spread the fetches over
-__global__ void __launch_bounds__(256) k_ceiling_node_gather(const float4* __restrict__ nodes, uint32_t node_count, uint32_t iterations, float* sink) {
+// nodes: the BVH node array (node_bytes-byte records); node_count: how many of them to spread the fetches over
+__global__ void __launch_bounds__(256) k_ceiling_node_gather(const float4* __restrict__ nodes, uint32_t node_count, uint32_t node_bytes, uint32_t iterations, float* sink) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t state = ceil_pcg(tid * 2654435761u + 12345u);
   float acc = 0.0f;
@@ -40,19 +40,17 @@ __global__ void __launch_bounds__(256) k_ceiling_node_gather(const float4* __res
       idx[u] = (uint32_t)(((uint64_t)state * node_count) >> 32);
     }
     float4 a[CEIL_UNROLL], b[CEIL_UNROLL], c[CEIL_UNROLL];
-    uint2 d[CEIL_UNROLL];
 #pragma unroll
     for (int u = 0; u < CEIL_UNROLL; u++) {
-      const float4* n = reinterpret_cast<const float4*>(base + ((size_t)idx[u] << 6));
+      const float4* n = reinterpret_cast<const float4*>(base + (size_t)idx[u] * node_bytes);
       a[u] = n[0];
       b[u] = n[1];
       c[u] = n[2];
-      d[u] = *reinterpret_cast<const uint2*>(n + 3);
     }
 #pragma unroll
     for (int u = 0; u < CEIL_UNROLL; u++) {
       acc += a[u].x + a[u].w + b[u].y + b[u].z + c[u].x + c[u].w;
-      acc_u ^= d[u].x + d[u].y;
+      acc_u ^= __float_as_uint(a[u].y) + __float_as_uint(b[u].x);
     }
   }
   if (acc == 123.456f && acc_u == 0x12345u) sink[tid] = acc;  // keeps the loads alive; practically never true

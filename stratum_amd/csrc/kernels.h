@@ -262,6 +262,15 @@ DEV uint2 uniform_load2u(const void* base, size_t byte) {
 template <bool COUNT, bool ALPHA>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t depth_closest, uint32_t depth_shadow) {
   extern __shared__ uint32_t lds_stack[];
+  // the treetop behind the stacks: copied once per (persistent) block
+  float4* top_lds = reinterpret_cast<float4*>(lds_stack + (size_t)p.bvh.stack_depth * STHIP_BLOCK);
+  for (uint32_t i = threadIdx.x; i < p.bvh.top_count * 3u; i += STHIP_BLOCK) top_lds[i] = p.bvh.top_nodes[i];
+  __syncthreads();
+  DeviceBvh bvh = p.bvh;  // k_trace's view: the entry table whose roots point into the treetop, and the treetop's root
+  if (p.bvh.top_count) {
+    bvh.entries = p.bvh.top_entries;
+    bvh.root_ref = p.bvh.top_root_ref;
+  }
   const bool first = depth_closest == 0;        // first bounce: every slot, no queue
   const uint32_t* queue = p.queue[depth_closest & 1u];
   unsigned long long* ctl_c = queue_ctl(p.qctl, 0, depth_closest == TRACE_NONE ? 0u : depth_closest, 0);
@@ -272,7 +281,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
   cnt[0].clear();
   cnt[1].clear();
   uint32_t round_slots[2] = {0, 0}, busy_rounds[2] = {0, 0};
-  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA> tr;
+  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, true> tr;
+  tr.top_lds = (const LdsFloat4*)top_lds;
   tr.reset();
   tr.any = false;
   WaveWork work_c, work_s;
@@ -296,7 +306,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
           } else {
             const float4 ro = p.ray_o[slot], rd = p.ray_d[slot];
             tr.any = false;
-            tr.start(p.bvh, stack, xyz(ro), xyz(rd), 0.0f, __builtin_inff());
+            tr.start(bvh, stack, xyz(ro), xyz(rd), 0.0f, __builtin_inff());
             busy = true;
             shadow_lane = false;
           }
@@ -306,14 +316,16 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
         uint32_t idx = work_s.take(!busy, ctl_s, p.shadow_stride, 0);
         if (idx != 0xFFFFFFFFu) {
           if (ALPHA && p.media && (depth_shadow & 1u)) idx += p.shadow_alt;
-          const float4 s0 = p.shadow_rays[3 * (size_t)idx], s1 = p.shadow_rays[3 * (size_t)idx + 1], s2 = p.shadow_rays[3 * (size_t)idx + 2];
+          const float4 s0 = p.shadow_rays[3 * (size_t)idx], s1 = p.shadow_rays[3 * (size_t)idx + 1];
+          // the record's index stands in for the slot while the ray is traced: what an unoccluded ray adds (and where) is
+          // read again when it finishes — three registers per lane for the whole traversal are worth two loads at its end
           slot = __float_as_uint(s1.w);
-          contribution = xyz(s2);
+          contribution = xyz(p.shadow_rays[3 * (size_t)idx + 2]);
+          if (ALPHA && p.media) slot = idx;
           // with media a visibility ray is a walk from volume boundary to volume boundary (trace_visibility_ray,
           // intersection.hlsli:192-239): each segment is a closest-hit query whose result k_shadow_media consumes
           tr.any = !(ALPHA && p.media);
-          if (ALPHA && p.media) slot = idx;
-          tr.start(p.bvh, stack, xyz(s0), xyz(s1), 0.0f, s0.w);
+          tr.start(bvh, stack, xyz(s0), xyz(s1), 0.0f, s0.w);
           busy = true;
           shadow_lane = true;
         }
@@ -331,13 +343,13 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
       const uint32_t n0 = cnt[k].inner_slots, t0 = cnt[k].tri_slots;
       TraverseCounters c;
       c.clear();
-      tr.round(p.bvh, stack, p.inner_min_lanes, c);
+      tr.round(bvh, stack, p.inner_min_lanes, c);
       cnt[tr.any ? 1 : 0].nodes += c.nodes;
       cnt[tr.any ? 1 : 0].tris += c.tris;
       cnt[k].inner_slots = n0 + c.inner_slots;
       cnt[k].tri_slots = t0 + c.tri_slots;
     } else {
-      tr.round(p.bvh, stack, p.inner_min_lanes, cnt[0]);
+      tr.round(bvh, stack, p.inner_min_lanes, cnt[0]);
     }
     if (busy && !tr.active()) {
       if (ALPHA && p.media && shadow_lane) {
@@ -430,9 +442,11 @@ __global__ void __launch_bounds__(STHIP_BLOCK, PRIMARY_BLOCKS) k_trace_primary(F
       if (!(ref & BVH_LEAF_BIT)) {
         // wave-uniform address in the constant address space: scalar loads (the node lands in SGPRs through the scalar
         // cache instead of occupying 14 VGPRs of all 64 lanes and a texture-addresser slot per lane)
-        const size_t nb = (size_t)ref << 6;
+        const size_t nb = (size_t)ref * BVH_NODE_BYTES;
         const float4 n0 = uniform_load4(nbase, nb), n1 = uniform_load4(nbase, nb + 16), nz = uniform_load4(nbase, nb + 32);
-        const uint2 cr = uniform_load2u(nbase, nb + 48);
+        // the child references: low bytes of the x / y planes (bvh.h); wave-uniform, so this is scalar arithmetic
+        const uint2 cr = make_uint2((__float_as_uint(n0.x) & 0xFFu) | ((__float_as_uint(n0.y) & 0xFFu) << 8) | ((__float_as_uint(n0.z) & 0xFFu) << 16) | (__float_as_uint(n0.w) << 24),
+                                    (__float_as_uint(n1.x) & 0xFFu) | ((__float_as_uint(n1.y) & 0xFFu) << 8) | ((__float_as_uint(n1.z) & 0xFFu) << 16) | (__float_as_uint(n1.w) << 24));
         if (COUNT && lane == 0) {
           cnt.nodes++;
           cnt.inner_slots += 64;

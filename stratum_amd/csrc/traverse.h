@@ -21,7 +21,7 @@
 #include "media.h"
 
 struct DeviceBvh {
-  const float4* nodes;  // BvhNode = 4 x float4
+  const float4* nodes;  // BvhNodePacked = 3 x float4 (48 bytes; the child references ride in the low bytes of the x / y planes)
   const float4* tris;   // BvhTri = 3 x float4
   const TlasEntry* entries;
   uint32_t root_ref;
@@ -36,6 +36,13 @@ struct DeviceBvh {
   uint32_t alpha_test;
   uint32_t flip_uvs;            // gFlipTriangleUVs for the mask lookup
   const DeviceVolume* volumes;  // gVolumes headers (volume instances are top-level entries tested in place, like spheres)
+  // the treetop (bvh_build.h): the most-visited inner nodes as a copy of their own that the persistent trace kernel holds
+  // in LDS; a reference with BVH_TOP_BIT indexes it. Only k_trace follows these (it starts at top_root_ref and reads
+  // top_entries); every other kernel walks the node array from root_ref and never sees the bit.
+  const float4* top_nodes;
+  const TlasEntry* top_entries;
+  uint32_t top_root_ref;
+  uint32_t top_count;
 };
 struct DeviceImage1 {
   uint32_t offset, w, h, pad;
@@ -52,6 +59,20 @@ DEV float sample_image1(const DeviceBvh& bvh, uint32_t index, float u, float v) 
   const float* t = bvh.image1_texels + im.offset;
   const float a = lerp1(t[(size_t)ya * w + xa], t[(size_t)ya * w + xb], fx), b = lerp1(t[(size_t)yb * w + xa], t[(size_t)yb * w + xb], fx);
   return lerp1(a, b, fy);
+}
+
+// a float4 in LDS, typed as such: a pointer that keeps its address space makes the treetop read a ds_read_b128; a generic
+// one would merge with the global path into flat loads, which take the vector-memory path the treetop exists to avoid
+typedef float lds_f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) lds_f4v LdsFloat4;
+DEV float4 lds_load4(const LdsFloat4* p) {
+  const lds_f4v v = *p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// child reference k of a packed node: the low bytes of the four floats of n0xy (k = 0) or n1xy (k = 1), bvh.h
+DEV uint32_t packed_ref(float4 q) {
+  return __builtin_amdgcn_perm(__float_as_uint(q.y), __float_as_uint(q.x), 0x0c0c0400u) | __builtin_amdgcn_perm(__float_as_uint(q.w), __float_as_uint(q.z), 0x04000c0cu);
 }
 
 struct RayHit {
@@ -74,7 +95,7 @@ struct RaySpace {
   f3 idir;            // 1 / d, |d| clamped away from 0
   f3 noodL, noodH;    // -(o + P) * idir and -(o - P) * idir: slab distance = fma(plane, idir, nood)
   float Sx, Sy, Sz;   // watertight shear constants
-  int kx, ky, kz;
+  int k;              // kx | ky << 2 | kz << 4: the watertight test's axis permutation in one register
 };
 
 DEV float safe_rcp_dir(float d) {
@@ -108,9 +129,7 @@ DEV void setup_space(RaySpace& s, f3 o, f3 d, float cx, float cy, float cz, floa
     kx = ky;
     ky = t;
   }
-  s.kx = kx;
-  s.ky = ky;
-  s.kz = kz;
+  s.k = kx | (ky << 2) | (kz << 4);
   s.Sx = comp3(d, kx) / dz;
   s.Sy = comp3(d, ky) / dz;
   s.Sz = 1.0f / dz;
@@ -151,10 +170,11 @@ DEV uint32_t hit_key(uint32_t ip) { return (ip << 16) | (ip >> 16); }
 // products rounded separately (no fma) so that a shared edge evaluates antisymmetrically.
 DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax, float& t, float& b1, float& b2) {
   const f3 A = p0 - s.o, B = p1 - s.o, C = p2 - s.o;
-  const float Akz = comp3(A, s.kz), Bkz = comp3(B, s.kz), Ckz = comp3(C, s.kz);
-  const float Ax = fmaf(-s.Sx, Akz, comp3(A, s.kx)), Ay = fmaf(-s.Sy, Akz, comp3(A, s.ky));
-  const float Bx = fmaf(-s.Sx, Bkz, comp3(B, s.kx)), By = fmaf(-s.Sy, Bkz, comp3(B, s.ky));
-  const float Cx = fmaf(-s.Sx, Ckz, comp3(C, s.kx)), Cy = fmaf(-s.Sy, Ckz, comp3(C, s.ky));
+  const int kx = s.k & 3, ky = (s.k >> 2) & 3, kz = s.k >> 4;
+  const float Akz = comp3(A, kz), Bkz = comp3(B, kz), Ckz = comp3(C, kz);
+  const float Ax = fmaf(-s.Sx, Akz, comp3(A, kx)), Ay = fmaf(-s.Sy, Akz, comp3(A, ky));
+  const float Bx = fmaf(-s.Sx, Bkz, comp3(B, kx)), By = fmaf(-s.Sy, Bkz, comp3(B, ky));
+  const float Cx = fmaf(-s.Sx, Ckz, comp3(C, kx)), Cy = fmaf(-s.Sy, Ckz, comp3(C, ky));
   const float U = Cx * By - Cy * Bx;
   const float V = Ax * Cy - Ay * Cx;
   const float W = Bx * Ay - By * Ax;
@@ -185,8 +205,10 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
 #define TRAV_CLOSEST 0  // closest hit
 #define TRAV_ANY 1      // occlusion: stop at the first accepted triangle (hit.ip = 0)
 #define TRAV_MIXED 2    // per lane, member `any` (the persistent kernel feeds closest-hit and shadow rays to one wave)
-template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
+// TOP: inner references may point into the treetop held in LDS at `top_lds` (BVH_TOP_BIT), see DeviceBvh
+template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
 struct Traversal {
+  const LdsFloat4* top_lds;  // TOP only
   bool any;  // TRAV_MIXED only
   DEV bool is_any() const { return MODE == TRAV_ANY || (MODE == TRAV_MIXED && any); }
   f3 o, d;  // world-space ray
@@ -228,9 +250,19 @@ struct Traversal {
     // at least `min_lanes` lanes (>= 1) still hold an inner node: one wave-uniform test per step.
     for (;;) {
       if (!(ref & BVH_LEAF_BIT)) {
-      const float4* n = reinterpret_cast<const float4*>(base + ((size_t)ref << 6));
-      const float4 n0 = n[0], n1 = n[1], nz = n[2];
-      const uint2 cr = *reinterpret_cast<const uint2*>(n + 3);
+      float4 n0, n1, nz;
+      if (TOP && (ref & BVH_TOP_BIT)) {  // a treetop node: three LDS reads instead of three divergent vector loads
+        const LdsFloat4* n = top_lds + (ref & ~BVH_TOP_BIT) * 3u;
+        n0 = lds_load4(n);
+        n1 = lds_load4(n + 1);
+        nz = lds_load4(n + 2);
+      } else {
+        const float4* n = reinterpret_cast<const float4*>(base + (size_t)ref * BVH_NODE_BYTES);
+        n0 = n[0];
+        n1 = n[1];
+        nz = n[2];
+      }
+      const uint2 cr = make_uint2(packed_ref(n0), packed_ref(n1));
       const uint32_t popped = stack[top - STRIDE];
       if (COUNT) {
         cnt.nodes++;
@@ -447,6 +479,8 @@ struct WaveWork {
         if (len) {
           unsigned long long b = 0;
           if (lane == 0) b = atomicAdd(&line[QCTL_HEAD], (unsigned long long)WORK_CHUNK);
+          // take() runs in wave-uniform control flow (all 64 lanes), so the first lane is lane 0; a scalar keeps the
+          // chunk bounds out of the vector registers
           const uint32_t b32 = (uint32_t)__shfl((int)(uint32_t)(b > 0xFFFFFFFFull ? 0xFFFFFFFFull : b), 0, 64);
           if (b32 < len) got = b32;
         }

@@ -896,3 +896,27 @@ def test_estimators_converge_to_the_same_image(renderer):
     for name, img in images.items():
         assert abs(img.mean() / ref.mean() - 1) < 0.01, (name, img.mean() / ref.mean())
         assert np.sqrt(((img - ref) ** 2).sum() / (ref**2).sum()) < (0.08 if "BSDF sampling only" in name else 0.03), name
+
+
+def test_treetop_and_packed_nodes_do_not_change_results(atrium_scene):
+    """The LDS treetop (bvh_build.h) and the 48-byte packed nodes (bvh.h) only change where a node is read from and how
+    wide its box is (conservatively): frames with and without the treetop are bit-identical, on the merged world mesh +
+    transformed instances of the atrium and on the two-level forest (treetop through the top level into shared meshes)."""
+    from stratum_amd.bdpt import BDPT
+
+    for make, args in ((lambda: atrium_scene, {}), (lambda: scenes.forest(n_instances=60, tree_tris=800), {"maxDiffuseVertices": 4, "maxPathVertices": 6})):
+        sc, cam = make()
+        frame = camera.Frame(320, 192, cam["fovy"], cam["eye"], cam["target"])
+        frames = []
+        for treetop in (1, 0):
+            r = BDPT(device=0, args=args)
+            try:
+                r.set_option("treetop", treetop)
+                r.update(sc)
+                frames.append(r.render(frame, 0, 2))
+            finally:
+                r.close()
+        a, b = frames
+        assert np.array_equal(a["radiance"].view(np.uint32), b["radiance"].view(np.uint32))
+        assert np.array_equal(a["visibility"]["instance_primitive_index"], b["visibility"]["instance_primitive_index"])
+        assert np.array_equal(a["ray_count"], b["ray_count"])

@@ -167,3 +167,13 @@ def test_plugin_installs_the_renderer_on_a_gpu(built):
 
     out = _plugin_host(built, g.PLUGIN + ";stratum_hip_register")
     assert out.returncode == 0 and "PLUGIN OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_packed_node_planes_are_conservative(tmp_path):
+    """The 48-byte node (bvh.h: BvhNodePacked) keeps its child references in the low mantissa byte of eight planes;
+    tests/cpp/pack_test.cpp checks that pack_plane's outward rounding keeps every plane conservative for EVERY byte value,
+    finite, within 511 ulp, and that references round-trip (200 k random + special values, host only)."""
+    exe = str(tmp_path / "pack_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "tests", "cpp", "pack_test.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("PACK OK"), out.stdout + out.stderr
