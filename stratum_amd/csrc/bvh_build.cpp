@@ -13,9 +13,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <limits>
 #include <map>
 #include <queue>
+#include <thread>
 #include <unordered_map>
 #include <tuple>
 
@@ -73,8 +75,55 @@ struct Builder {
       for (int a = 0; a < 3; a++) cen[3 * i + a] = 0.5f * (boxes[i].lo[a] + boxes[i].hi[a]);
     }
     nodes.reserve(2 * n / std::max(1u, leaf) + 16);
-    if (n) build(0, (uint32_t)n, 0);
+    if (!n) return;
+    // Large builds run on several host threads: the top of the tree is built here, and every subtree small enough
+    // (<= n / (8 * threads) primitives) becomes a task that builds into a node vector of its own over its own
+    // (disjoint) range of `order`; the pieces are then appended with their indices shifted. The tree is the one the
+    // single-threaded build makes (same splits, same order), only the numbering of TmpNode differs, and flatten()
+    // renumbers depth-first anyway.
+    unsigned threads = std::thread::hardware_concurrency();
+    if (const char* e = getenv("STHIP_BUILD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
+    threads = std::min(threads, 32u);
+    if (n < 50000 || threads <= 1) {
+      build(nodes, max_depth, nullptr, 0, (uint32_t)n, 0);
+      return;
+    }
+    std::vector<Task> tasks;
+    task_size = (uint32_t)std::max<size_t>(4096, n / (8 * (size_t)threads));
+    build(nodes, max_depth, &tasks, 0, (uint32_t)n, 0);
+    std::vector<std::vector<TmpNode>> parts(tasks.size());
+    std::vector<uint32_t> depths(tasks.size(), 0);
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; t++)
+      pool.emplace_back([&]() {
+        for (;;) {
+          const size_t k = next.fetch_add(1);
+          if (k >= tasks.size()) break;
+          parts[k].reserve(2 * (tasks[k].hi - tasks[k].lo) / std::max(1u, leaf_max) + 16);
+          build(parts[k], depths[k], nullptr, tasks[k].lo, tasks[k].hi, tasks[k].depth);
+        }
+      });
+    for (auto& th : pool) th.join();
+    for (size_t k = 0; k < tasks.size(); k++) {
+      const int32_t base = (int32_t)nodes.size();
+      for (TmpNode tn : parts[k]) {
+        if (tn.left >= 0) {
+          tn.left += base;
+          tn.right += base;
+        }
+        nodes.push_back(tn);
+      }
+      (tasks[k].right_child ? nodes[tasks[k].parent].right : nodes[tasks[k].parent].left) = base;  // a task's root is its node 0
+      max_depth = std::max(max_depth, depths[k]);
+    }
   }
+  struct Task {
+    uint32_t lo, hi, depth;
+    int32_t parent;
+    bool right_child;
+  };
+  uint32_t task_size = 0;
 
   // largest primitive count a subtree rooted at `depth` may hold
   uint64_t capacity(uint32_t depth) const {
@@ -82,7 +131,9 @@ struct Builder {
     return (uint64_t)leaf_max << std::min(rem, 40u);
   }
 
-  int32_t build(uint32_t lo, uint32_t hi, uint32_t depth) {
+  // builds the subtree over order[lo, hi) into `nodes` (indices relative to that vector). With `tasks`, subtrees of at
+  // most task_size primitives below the root are not built but recorded (their parent's link is patched later).
+  int32_t build(std::vector<TmpNode>& nodes, uint32_t& max_depth, std::vector<Task>* tasks, uint32_t lo, uint32_t hi, uint32_t depth) {
     const int32_t idx = (int32_t)nodes.size();
     nodes.push_back(TmpNode());
     max_depth = std::max(max_depth, depth);
@@ -172,8 +223,15 @@ struct Builder {
       std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi,
                        [&](uint32_t a, uint32_t b) { return cen[3 * (size_t)a + axis] < cen[3 * (size_t)b + axis]; });
     }
-    const int32_t l = build(lo, mid, depth + 1);
-    const int32_t r = build(mid, hi, depth + 1);
+    auto child = [&](uint32_t a, uint32_t b, bool right) -> int32_t {
+      if (tasks && b - a <= task_size && b - a > leaf_max) {
+        tasks->push_back(Task{a, b, depth + 1, idx, right});
+        return 0;  // patched when the task's nodes are appended
+      }
+      return build(nodes, max_depth, tasks, a, b, depth + 1);
+    };
+    const int32_t l = child(lo, mid, false);
+    const int32_t r = child(mid, hi, true);
     nodes[idx].left = l;
     nodes[idx].right = r;
     nodes[idx].count = 0;

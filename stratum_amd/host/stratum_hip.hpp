@@ -846,7 +846,7 @@ class BDPT {
     if (auto app = node.find_in_ancestor<Application>())
       app->OnUpdate.add_listener(node, [this](CommandBuffer& cb, float dt) { update(cb, dt); }, Node::EventPriority::eAlmostLast);  // BDPT.cpp:38
   }
-  ~BDPT() { sthip_destroy(mCtx); }
+  virtual ~BDPT() { sthip_destroy(mCtx); }
   BDPT(const BDPT&) = delete;
 
   // the instance arguments BDPT's constructor reads (BDPT.cpp:78-127): `minPathVertices`, `maxPathVertices`,
@@ -909,7 +909,7 @@ class BDPT {
   }
 
   // BDPT::update (BDPT.cpp:341-421): (re)bind the scene when Scene::update produced new SceneData
-  void update(CommandBuffer& cb, float) {
+  virtual void update(CommandBuffer& cb, float) {
     auto scene = mNode.find_in_ancestor<Scene>();
     if (!scene) scene = mNode.root().find_in_descendants<Scene>();
     if (!scene || !scene->data() || scene->data().get() == mBound) return;
@@ -933,29 +933,40 @@ class BDPT {
     mPushConstants.gEnvironmentMaterialAddress = scene->data()->mEnvironmentMaterialAddress;  // BDPT.cpp:393
   }
 
-  // BDPT::render (BDPT.cpp:423-838) for the hot path: one sample per pixel per call, seed = frame number (:480)
-  void render(CommandBuffer& cb, uint32_t width, uint32_t height, const std::vector<std::pair<ViewData, TransformData>>& views, uint32_t seed_count = 1) {
-    if (!mBound) throw std::runtime_error("BDPT::render: no scene bound (Scene::update / BDPT::update have not run)");
+  // what a frame hands to sthip_render: the view arrays, the push constants and the scene flags as BDPT::render resolves
+  // them (BDPT.cpp:444-503). Shared by the single-device render below and the multi-device one (stratum_hip_multi.hpp).
+  struct FrameSetup {
     std::vector<ViewData> v;
     std::vector<TransformData> t, ti;
+    std::vector<uint32_t> view_media;
+    sthip_frame_desc f{};
+    BDPTPushConstants pc{};
+    uint32_t scene_flags = 0;
+  };
+  void prepare_frame(uint32_t width, uint32_t height, const std::vector<std::pair<ViewData, TransformData>>& views, FrameSetup& fs) const {
+    if (!mBound) throw std::runtime_error("BDPT::render: no scene bound (Scene::update / BDPT::update have not run)");
+    std::vector<ViewData>& v = fs.v;
+    std::vector<TransformData>&t = fs.t, &ti = fs.ti;
     for (const auto& p : views) {
       v.push_back(p.first);
       t.push_back(p.second);
       ti.push_back(inverse(p.second));  // BDPT.cpp:448-452
     }
-    sthip_frame_desc f{};
+    sthip_frame_desc& f = fs.f;
     f.gViews = v.data();
     f.gViewTransforms = t.data();
     f.gInverseViewTransforms = ti.data();
     f.gPrevViews = mPrevViews.size() == v.size() ? mPrevViews.data() : nullptr;
     f.gPrevInverseViewTransforms = mPrevInverseViewTransforms.size() == ti.size() ? mPrevInverseViewTransforms.data() : nullptr;
     f.view_count = (uint32_t)views.size();
-    BDPTPushConstants pc = mPushConstants;
+    BDPTPushConstants& pc = fs.pc;
+    pc = mPushConstants;
     pc.gOutputExtent[0] = width;
     pc.gOutputExtent[1] = height;
     pc.gViewCount = f.view_count;
     pc.gLightPathCount = width * height;  // BDPT.cpp:469-470
-    uint32_t scene_flags = 0;             // BDPT.cpp:486-503
+    uint32_t& scene_flags = fs.scene_flags;  // BDPT.cpp:486-503
+    scene_flags = 0;
     if (pc.gEnvironmentMaterialAddress != ~0u)
       scene_flags |= STHIP_BDPT_FLAG_HAS_ENVIRONMENT;
     else
@@ -965,7 +976,8 @@ class BDPT {
     else
       pc.gEnvironmentSampleProbability = 1;
     // media: BDPT.cpp:456-466 (the volume instance each camera is inside of) and :497-500
-    std::vector<uint32_t> view_media(views.size(), 0xFFFFu);
+    std::vector<uint32_t>& view_media = fs.view_media;
+    view_media.assign(views.size(), 0xFFFFu);
     if (!mBoundData->mMediumInstances.empty()) {
       scene_flags |= STHIP_BDPT_FLAG_HAS_MEDIA;
       for (const auto& mi : mBoundData->mMediumInstances) {
@@ -983,6 +995,15 @@ class BDPT {
     } else {
       pc.gMaxNullCollisions = 0;
     }
+  }
+
+  // BDPT::render (BDPT.cpp:423-838) for the hot path: one sample per pixel per call, seed = frame number (:480)
+  virtual void render(CommandBuffer& cb, uint32_t width, uint32_t height, const std::vector<std::pair<ViewData, TransformData>>& views, uint32_t seed_count = 1) {
+    FrameSetup fs;
+    prepare_frame(width, height, views, fs);
+    const sthip_frame_desc& f = fs.f;
+    const BDPTPushConstants& pc = fs.pc;
+    const uint32_t scene_flags = fs.scene_flags;
     Frame fr;
     fr.width = width;
     fr.height = height;
@@ -1002,6 +1023,19 @@ class BDPT {
     (void)sthip_set_stream(mCtx, cb.hip_stream);
     if (sthip_render(mCtx, &pc, mSamplingFlags, scene_flags, &f, mFrameNumber, seed_count, &o) != STHIP_OK)
       throw std::runtime_error(std::string("sthip_render: ") + sthip_last_error(mCtx));
+    finish_frame(std::move(fr), fs, seed_count);
+  }
+
+ protected:
+  uint32_t frame_number() const { return mFrameNumber; }
+  uint32_t sampling_flags() const { return mSamplingFlags; }
+  // what follows the path in BDPT::render: the tone map block and the frame bookkeeping
+  void finish_frame(Frame fr, const FrameSetup& fs, uint32_t seed_count) {
+    const uint32_t width = fr.width, height = fr.height;
+    const size_t n = (size_t)width * height;
+    const std::vector<ViewData>& v = fs.v;
+    const std::vector<TransformData>& ti = fs.ti;
+    if (fr.mAlbedo.size() != 4 * n) fr.mAlbedo.assign(4 * n, 0.f);
     // tone map (BDPT.cpp:783-815); without a denoiser gModulateAlbedo stays off (:779-780 only run when one exists)
     fr.mTonemapResult.assign(4 * n, 0.f);
     sthip_tonemap_desc tm{};
@@ -1023,9 +1057,11 @@ class BDPT {
     mPrevInverseViewTransforms = ti;
     mPrevFrame = std::move(fr);
   }
+
+ public:
   void reset_frame_number(uint32_t n = 0) { mFrameNumber = n; }
 
- private:
+ protected:
   Node& mNode;
   sthip_ctx* mCtx = nullptr;
   const void* mBound = nullptr;

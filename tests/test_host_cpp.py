@@ -177,3 +177,57 @@ def test_packed_node_planes_are_conservative(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "tests", "cpp", "pack_test.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("PACK OK"), out.stdout + out.stderr
+
+
+# ---- the multi-GPU driver of the C++ host (host/stratum_hip_multi.hpp) ----
+def _multi_host(built):
+    import __graft_entry__ as g
+
+    return g.build_multi_host()
+
+
+@pytest.mark.parametrize("w,h,world,tw,th", [(1920, 1080, 8, 64, 32), (100, 70, 3, 16, 8), (64, 32, 4, 64, 32), (3840, 2160, 8, 64, 32)])
+def test_cpp_shard_layout_is_the_python_and_device_layout(built, w, h, world, tw, th):
+    """stm::ShardLayout (owner rule, slot -> pixel, host assembly) against stratum_amd.shard, the mirror the device
+    kernels are tested against: same slot counts, same pixel per slot; packing by ownership and assembling is lossless.
+    This is the N-rank logic of MultiDeviceBDPT without N GPUs."""
+    from stratum_amd import shard
+
+    out = subprocess.run([_multi_host(built), "layout", str(w), str(h), str(world), str(tw), str(th)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("LAYOUT OK"), out.stdout + out.stderr
+    lines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("rank")]
+    assert len(lines) == world
+    for rank, ln in enumerate(lines):
+        assert int(ln[3]) == shard.slot_count(w, h, rank, world, tw, th)
+        xy = shard.slot_pixels(w, h, rank, world, tw, th)
+        s = 0
+        for x, y in xy:  # the same FNV-style fold the program prints
+            s = (s * 1099511628211 + (int(y) * w + int(x) + 1 if x >= 0 else 0)) & 0xFFFFFFFFFFFFFFFF
+        assert int(ln[5]) == s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("make", [scenes.cornell_box, shared_mesh_scene])
+def test_cpp_multi_device_driver_on_one_gpu(built, tmp_path, make):
+    """MultiDeviceBDPT with the one GPU of this box: its whole path runs (one thread per rank, packed tiles, the RCCL
+    send / recv group, sthip_assemble_tiles on rank 0) and the frame equals the single-device renderer's bit for bit."""
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = make()
+    W, H, seeds = 192, 96, 3
+    fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+    desc, outp = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    dump_description(desc, sc, fr)
+    out = subprocess.run([_multi_host(built), "render", desc, outp, str(seeds), "0"], capture_output=True, text=True)
+    assert out.returncode == 0 and "RENDER OK world 1" in out.stdout, out.stdout + out.stderr
+    raw = np.fromfile(outp, dtype=np.uint8)
+    rad = raw[: W * H * 16].view(np.float32).reshape(H, W, 4)
+    rays = raw[W * H * 16 : W * H * 16 + 16].view(np.uint64)
+    r = BDPT(device=0)
+    try:
+        r.update(sc)
+        ref = r.render(fr, 0, seeds)
+    finally:
+        r.close()
+    assert np.array_equal(rad.view(np.uint32), ref["radiance"].view(np.uint32))
+    assert np.array_equal(rays, ref["ray_count"])
