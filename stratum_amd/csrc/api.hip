@@ -126,6 +126,11 @@ struct sthip_ctx {
   hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
+// The traversal stack is stack_depth x 1 KB of dynamic LDS per 256-thread block. Up to 64 KB needs nothing; beyond it
+// (deep LBVH trees of clustered scenes) the kernels must be told (hipFuncAttributeMaxDynamicSharedMemorySize), and the
+// CU holds fewer blocks. 152 KB leaves room for the runtime's own LDS use.
+#define STHIP_MAX_STACK_LDS ((size_t)152 * 1024)
+
 #define HIP_TRY(ctx, expr)                                                                            \
   do {                                                                                                \
     hipError_t _e = (expr);                                                                           \
@@ -190,6 +195,17 @@ int sthip_create(int device, sthip_ctx** out_ctx) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
   (void)hipEventCreate(&ctx->ev[0]);
   (void)hipEventCreate(&ctx->ev[1]);
+  {  // dynamic LDS beyond the 64 KB default for the kernels that carry the traversal stack
+    const int lds_max = 160 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+  }
   ctx->stats.bvh_node_bytes = sizeof(BvhNodePacked);
   ctx->stats.bvh_tri_bytes = sizeof(BvhTri);
   *out_ctx = ctx;
@@ -431,7 +447,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   const auto t_build0 = std::chrono::steady_clock::now();
   if (!sthip::build_scene_bvh(*s, built, err, ctx->bvh_builder)) return fail(ctx, err.find("only triangle") != std::string::npos ? STHIP_ERR_UNSUPPORTED : STHIP_ERR_INVALID_ARGUMENT, "scene: " + err);
 
-  if ((size_t)built.stack_depth * STHIP_BLOCK * sizeof(uint32_t) > 64 * 1024)
+  if ((size_t)built.stack_depth * STHIP_BLOCK * sizeof(uint32_t) > STHIP_MAX_STACK_LDS)
     return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: the acceleration structure is too deep for the LDS traversal stack (use the SAH builder)");
   ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
   ctx->stats.bvh_build_gpu_ms = built.gpu_build_ms;
@@ -728,7 +744,7 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
   float center[3] = {ctx->bvh.scene_cx, ctx->bvh.scene_cy, ctx->bvh.scene_cz}, radius = ctx->bvh.scene_radius;
   std::string err;
   if (!sthip::rebuild_top_level(next, xf, inv, instance_count, tlas, root_ref, top_is_world, stack_depth, center, radius, err)) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: " + err);
-  if ((size_t)stack_depth * STHIP_BLOCK * sizeof(uint32_t) > 64 * 1024) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: the new top level is too deep for the LDS traversal stack");
+  if ((size_t)stack_depth * STHIP_BLOCK * sizeof(uint32_t) > STHIP_MAX_STACK_LDS) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: the new top level is too deep for the LDS traversal stack");
   if ((size_t)next.blas_nodes + tlas.size() > ctx->nodes.n) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: the new top level does not fit: upload the scene again");
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still read the old top level
   const uint32_t n = instance_count;

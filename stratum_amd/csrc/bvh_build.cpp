@@ -322,7 +322,7 @@ inline void load_tri(const sthip_scene_desc& s, const InstView& in, uint32_t pri
 
 bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err, int builder) {
   out = BuiltBvh();
-  const uint32_t BLAS_DEPTH_CAP = 22, TLAS_DEPTH_CAP = 18;
+  const uint32_t BLAS_DEPTH_CAP = 22, TLAS_DEPTH_CAP = 18, LBVH_MAX_HEIGHT = 120;
   // ---- validate + classify ----
   std::vector<uint32_t> merged, separate, spheres, volumes;
   // gVolumes: NanoVDB float grids, format 32.x (PNanoVDB.h:761-777,904-916,964-968, FLOAT row of the type constants)
@@ -466,9 +466,15 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       }
       uint32_t root = 0;
       float ms = 0;
+      const size_t nodes_before = out.nodes.size(), tris_before = out.tris.size();
       if (!lbvh_build_gpu(tin, out.nodes, out.tris, root, depth, ms, gpu_err)) return BVH_INVALID_REF;
       out.gpu_build_ms += ms;
-      return root;
+      // The height of a radix tree is not bounded by log2(n): a run of equal Morton codes below a long common prefix
+      // can reach ~96 levels. The traversal stack takes 1 KB of LDS per level and block; beyond what the LDS holds the
+      // mesh is built with the (depth-capped) SAH builder instead.
+      if (depth <= LBVH_MAX_HEIGHT) return root;
+      out.nodes.resize(nodes_before);
+      out.tris.resize(tris_before);
     }
     std::vector<Box> boxes(prims.size());
     bounds.reset();

@@ -9,6 +9,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "bvh_build.h"
 
 namespace sthip {
@@ -160,7 +162,19 @@ __global__ void k_lbvh_emit(int n, uint32_t node_base, uint32_t tri_base, const 
     xy[3] = b.hi[1];
     out.nz[2 * k] = b.lo[2];
     out.nz[2 * k + 1] = b.hi[2];
-    out.ref[k] = leaf ? (BVH_LEAF_BIT | ((tri_base + idx) << 2)) : (node_base + idx);  // one triangle per leaf
+    if (leaf) {
+      out.ref[k] = BVH_LEAF_BIT | ((tri_base + idx) << 2);  // one triangle
+    } else {
+      // An internal child whose own children are both leaves covers two CONSECUTIVE sorted triangles (a radix-tree node
+      // spans a contiguous key range): reference it as one two-triangle leaf, as the SAH builder's leaves are
+      // (BVH_MAX_LEAF_TRIS), and the ray saves a node visit at the bottom of every descent. The skipped node stays
+      // in the array, unreferenced (the root is never skipped: kernels start at an inner node).
+      const uint32_t gl = left[idx], gr = right[idx];
+      if ((gl & 0x80000000u) && (gr & 0x80000000u))
+        out.ref[k] = BVH_LEAF_BIT | ((tri_base + (gl & 0x7FFFFFFFu)) << 2) | 1u;
+      else
+        out.ref[k] = node_base + idx;
+    }
   }
   nodes[i] = out;
 }
@@ -168,6 +182,18 @@ __global__ void k_lbvh_emit(int n, uint32_t node_base, uint32_t tri_base, const 
 __global__ void k_lbvh_gather(const BvhTri* in, const uint32_t* sorted, uint32_t n, BvhTri* out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[sorted[i]];
+}
+
+// scratch arena of lbvh_build_gpu, kept for the life of the process (one build at a time: the mutex)
+struct Arena {
+  char* base = nullptr;
+  size_t bytes = 0;
+  int device = -1;
+  std::mutex mutex;
+};
+Arena& arena(int device) {  // one per GPU: contexts on different GPUs build concurrently (the multi-GPU host uploads in parallel)
+  static Arena a[64];
+  return a[device & 63];
 }
 
 #define LB_TRY(expr)                                                            \
@@ -197,27 +223,57 @@ bool lbvh_build_gpu(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& no
   void* d_tmp = nullptr;
   size_t tmp_bytes = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::unique_lock<std::mutex> arena_lock;
   const uint32_t grid = (n + LB_BLOCK - 1) / LB_BLOCK;
   uint32_t passes = 0;
   {
-    LB_TRY(hipMalloc((void**)&d_in, (size_t)n * sizeof(BvhTri)));
-    LB_TRY(hipMalloc((void**)&d_out, (size_t)n * sizeof(BvhTri)));
-    LB_TRY(hipMalloc((void**)&d_leaf, (size_t)n * sizeof(LBox)));
-    LB_TRY(hipMalloc((void**)&d_node, (size_t)n * sizeof(LBox)));
-    LB_TRY(hipMalloc((void**)&d_cb, 8 * sizeof(uint32_t)));
-    LB_TRY(hipMalloc((void**)&d_keys, (size_t)n * 8));
-    LB_TRY(hipMalloc((void**)&d_keys_sorted, (size_t)n * 8));
-    LB_TRY(hipMalloc((void**)&d_vals, (size_t)n * 4));
-    LB_TRY(hipMalloc((void**)&d_sorted, (size_t)n * 4));
-    LB_TRY(hipMalloc((void**)&d_left, (size_t)n * 4));
-    LB_TRY(hipMalloc((void**)&d_right, (size_t)n * 4));
-    LB_TRY(hipMalloc((void**)&d_pi, (size_t)n * 4));
-    LB_TRY(hipMalloc((void**)&d_pl, (size_t)n * 4));
-    LB_TRY(hipMalloc((void**)&d_done, (size_t)n * 4));
-    LB_TRY(hipMalloc((void**)&d_rem, 4));
-    LB_TRY(hipMalloc((void**)&d_nodes, (size_t)n * sizeof(BvhNode)));
-    LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_vals, d_sorted, (int)n, 0, 63));
-    LB_TRY(hipMalloc(&d_tmp, tmp_bytes));
+    // every scratch array comes out of one arena that is kept between builds (grown when a larger mesh arrives):
+    // a rebuild then costs no hipMalloc / hipFree at all (18 of them used to dominate the wall time of a 7 ms build)
+    size_t tmp_need = 0;
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_need, d_keys, d_keys_sorted, d_vals, d_sorted, (int)n, 0, 63));
+    tmp_bytes = tmp_need;
+    {
+      int dev = 0;
+      LB_TRY(hipGetDevice(&dev));
+      Arena& A = arena(dev);
+      arena_lock = std::unique_lock<std::mutex>(A.mutex);  // held until the results have been copied out
+      size_t total = 0;
+      auto reserve = [&](size_t bytes) {
+        const size_t at = total;
+        total += (bytes + 255) & ~(size_t)255;
+        return at;
+      };
+      const size_t o_in = reserve((size_t)n * sizeof(BvhTri)), o_out = reserve((size_t)n * sizeof(BvhTri)), o_leaf = reserve((size_t)n * sizeof(LBox)), o_node = reserve((size_t)n * sizeof(LBox));
+      const size_t o_cb = reserve(8 * 4), o_keys = reserve((size_t)n * 8), o_keys2 = reserve((size_t)n * 8), o_vals = reserve((size_t)n * 4), o_sorted = reserve((size_t)n * 4);
+      const size_t o_left = reserve((size_t)n * 4), o_right = reserve((size_t)n * 4), o_pi = reserve((size_t)n * 4), o_pl = reserve((size_t)n * 4), o_done = reserve((size_t)n * 4), o_rem = reserve(4);
+      const size_t o_nodes = reserve((size_t)n * sizeof(BvhNode)), o_tmp = reserve(tmp_bytes);
+      if (A.device != dev || A.bytes < total) {
+        if (A.base) (void)hipFree(A.base);
+        A.base = nullptr;
+        A.bytes = 0;
+        LB_TRY(hipMalloc((void**)&A.base, total));
+        A.bytes = total;
+        A.device = dev;
+      }
+      char* b = A.base;
+      d_in = (BvhTri*)(b + o_in);
+      d_out = (BvhTri*)(b + o_out);
+      d_leaf = (LBox*)(b + o_leaf);
+      d_node = (LBox*)(b + o_node);
+      d_cb = (uint32_t*)(b + o_cb);
+      d_keys = (unsigned long long*)(b + o_keys);
+      d_keys_sorted = (unsigned long long*)(b + o_keys2);
+      d_vals = (uint32_t*)(b + o_vals);
+      d_sorted = (uint32_t*)(b + o_sorted);
+      d_left = (uint32_t*)(b + o_left);
+      d_right = (uint32_t*)(b + o_right);
+      d_pi = (uint32_t*)(b + o_pi);
+      d_pl = (uint32_t*)(b + o_pl);
+      d_done = (uint32_t*)(b + o_done);
+      d_rem = (uint32_t*)(b + o_rem);
+      d_nodes = (BvhNode*)(b + o_nodes);
+      d_tmp = b + o_tmp;
+    }
     LB_TRY(hipMemcpy(d_in, tris_in.data(), (size_t)n * sizeof(BvhTri), hipMemcpyHostToDevice));
     LB_TRY(hipEventCreate(&e0));
     LB_TRY(hipEventCreate(&e1));
@@ -259,23 +315,6 @@ bool lbvh_build_gpu(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& no
     LB_TRY(hipMemcpy(&stack_need, d_done, 4, hipMemcpyDeviceToHost));
   }
 done:
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
-  (void)hipFree(d_leaf);
-  (void)hipFree(d_node);
-  (void)hipFree(d_cb);
-  (void)hipFree(d_keys);
-  (void)hipFree(d_keys_sorted);
-  (void)hipFree(d_vals);
-  (void)hipFree(d_sorted);
-  (void)hipFree(d_left);
-  (void)hipFree(d_right);
-  (void)hipFree(d_pi);
-  (void)hipFree(d_pl);
-  (void)hipFree(d_done);
-  (void)hipFree(d_rem);
-  (void)hipFree(d_nodes);
-  (void)hipFree(d_tmp);
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   return ok;

@@ -387,6 +387,44 @@ def forest(n_instances=1000, tree_tris=10_000, tree_kinds=4):
     return b.build(), {"eye": (-0.55 * ext, 9.0, -0.55 * ext), "target": (0.0, 1.5, 0.0), "fovy": np.radians(55.0)}
 
 
+def clustered_box(n_coincident=60_000, n_cluster=40_000):
+    """A Cornell box holding a pathological mesh for a Morton-code builder: `n_coincident` triangles that are copies of ONE
+    triangle (equal centroids: one Morton code, told apart only by index) and `n_cluster` triangles packed into a ball of
+    1e-4 units (codes that share all but their last bits), plus the box walls far away on the same grid. A radix tree over
+    such keys is as deep as its longest common prefix allows; the traversal stack has to take it or the builder has to
+    give in (stratum_amd/csrc/bvh_build.cpp: LBVH_MAX_HEIGHT)."""
+    sc0, cam = cornell_box()
+    b = SceneBuilder("clustered_box")
+    white = b.add_material((0.73, 0.73, 0.73))
+    red = b.add_material((0.65, 0.05, 0.05))
+    light = b.add_emitter((17.0, 12.0, 4.0))
+
+    def wall(p0, p1, p2, p3, n, mat):
+        pos, nrm, uv, tri = _quad(p0, p1, p2, p3, n)
+        b.add_instance(b.add_mesh(pos, nrm, uv, tri), mat)
+
+    wall((-1, -1, 1), (1, -1, 1), (1, -1, -1), (-1, -1, -1), (0, 1, 0), white)
+    wall((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1), (0, -1, 0), white)
+    wall((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (0, 0, 1), white)
+    wall((-1, -1, 1), (-1, -1, -1), (-1, 1, -1), (-1, 1, 1), (1, 0, 0), red)
+    wall((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1), (-1, 0, 0), white)
+    wall((-0.24, 0.995, -0.2), (0.24, 0.995, -0.2), (0.24, 0.995, 0.18), (-0.24, 0.995, 0.18), (0, -1, 0), light)
+    rng = np.random.RandomState(11)
+    # the coincident fan: every triangle has the same three corners (a visible 0.5-unit triangle facing the camera)
+    base = np.array([[-0.3, -0.6, 0.1], [0.3, -0.6, 0.1], [0.0, -0.1, 0.1]], np.float32)
+    pos = [np.tile(base, (n_coincident, 1))]
+    # the cluster: tiny triangles inside a 1e-4 ball
+    c = np.array([0.45, -0.2, -0.3], np.float32)
+    pos.append((c + rng.normal(size=(n_cluster * 3, 3)) * 3e-5).astype(np.float32))
+    pos = np.concatenate(pos)
+    n_tri = n_coincident + n_cluster
+    tri = np.arange(n_tri * 3).reshape(n_tri, 3)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (pos.shape[0], 1))
+    uv = np.zeros((pos.shape[0], 2), np.float32)
+    add_chunked(b, (pos, nrm, uv, tri), red)
+    return b.build(), cam
+
+
 SCENES = {"cornell_box": cornell_box, "atrium": atrium, "forest": forest, "furnace": furnace_box}
 
 

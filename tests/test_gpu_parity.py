@@ -331,6 +331,39 @@ def test_gpu_lbvh_builder_gives_the_same_image(atrium_scene):
     assert b[2]["bvh_build_gpu_ms"] > 0
 
 
+def test_gpu_lbvh_builder_on_coincident_and_clustered_triangles():
+    """100 k triangles that defeat a Morton-code builder — 60 k exact copies of one triangle and 40 k inside a 1e-4 ball,
+    next to walls metres away: the radix tree is deep (equal codes are split by index below a long common prefix), the
+    traversal stack grows with it (more LDS per block, fewer blocks per CU), and the frame is still the SAH tree's frame,
+    bit for bit, and the oracle's."""
+    from oracle import oracle_py
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = scenes.clustered_box()
+    assert sc.triangle_count >= 100_000
+    frame = camera.Frame(160, 160, cam["fovy"], cam["eye"], cam["target"])
+    rays = random_rays(20000, 9, -0.99, 0.99)
+    res = {}
+    for kind in (0, 1):
+        r = BDPT(device=0)
+        try:
+            r.set_option("bvh_builder", kind)
+            r.update(sc)
+            res[kind] = (r.render(frame, 0, 1), r.trace(rays), r.stats())
+            flags, pc = r.mSamplingFlags, r.push_constants(frame)
+        finally:
+            r.close()
+    a, b = res[0], res[1]
+    assert np.array_equal(a[0]["radiance"].view(np.uint32), b[0]["radiance"].view(np.uint32))
+    assert np.array_equal(a[0]["visibility"]["instance_primitive_index"], b[0]["visibility"]["instance_primitive_index"])
+    for f in ("instance_primitive_index", "t", "b1", "b2"):
+        assert np.array_equal(a[1][f].view(np.uint32), b[1][f].view(np.uint32)), f
+    ref = oracle_py.OracleScene(sc).render(frame, pc, flags, 0, 1)
+    assert np.array_equal(b[0]["visibility"]["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
+    assert rel_l2(b[0]["radiance"], ref["radiance"]) <= 1e-4
+    print("clustered: lbvh build %.1f ms (gpu %.2f), sah %.1f ms" % (b[2]["bvh_build_ms"], b[2]["bvh_build_gpu_ms"], a[2]["bvh_build_ms"]))
+
+
 @pytest.mark.parametrize("flags", [[], ["~raycones"], ["flipnormalmaps", "fliptriangleuvs"], ["~normalmaps"], ["shadingnormalshadowfix"]])
 def test_textured_scene(flags):
     """Image values (base colour, roughness/metallic maps, textured emitter), mip selection through ray cones,
