@@ -1376,6 +1376,22 @@ struct PresampledLightPoint {  // bdpt.h:92-100
   float pdfA;  // negative for environment map samples
 };
 // PathVertex, bdpt.h:102-155: a stored light-subpath vertex (eConnectToLightPaths), 64 bytes
+// reservoir.h:4-27
+struct Reservoir {
+  float total_weight;
+  uint32_t M;
+  float W(float sample_target_pdf) const { return (sample_target_pdf > 0 && M > 0) ? total_weight / ((float)M * sample_target_pdf) : 0.0f; }
+  void init() {
+    total_weight = 0;
+    M = 0;
+  }
+  bool update(float rnd, float w) {
+    M++;
+    total_weight += w;
+    return rnd * total_weight <= w;
+  }
+};
+
 struct PathVertex {
   float position[3];
   uint32_t packed_geometry_normal;
@@ -1403,6 +1419,14 @@ struct Frame {
   // before sample_photons (BDPT.cpp:569-572,655-659)
   PathVertex* light_vertices = nullptr;
   size_t light_vertex_count = 0;
+  // eLVC (the light vertex cache, path.hlsli:523-527,683-800). Upstream hands out cache slots with an atomic counter, so
+  // its cache order — and with it which vertex `li % n` names — depends on thread scheduling. The order DEFINED here is
+  // one upstream's scheduler may produce: light paths in path-index order, each path's vertices in the order it stores
+  // them. While the light paths are traced the vertices go to lvc_staging[path_index * (gMaxDiffuseVertices - 1) +
+  // diffuse_vertices - 1]; compacting that array gives gLightPathVertices, lvc_count = gLightPathVertexCount[0].
+  PathVertex* lvc_staging = nullptr;
+  uint32_t lvc_count = 0;
+  bool lvc() const { return flag(STHIP_eConnectToLightPaths) && flag(STHIP_eLVC); }
   bool bdpt() const { return flag(STHIP_eConnectToViews) || flag(STHIP_eConnectToLightPaths); }
   const orc_scene* sc;
   sthip_BDPTPushConstants pc;
@@ -1966,6 +1990,7 @@ struct PathIntegrator {
   // BDPT quantities (path.hlsli:262-267), used when eConnectToViews is on
   float path_pdf, path_pdf_rev, dVC;
   bool prev_specular;
+  v3 path_contrib = V3(1.0f);  // the light path's unweighted contribution (path.hlsli:258,901,1043): what eLVCReservoirs store instead of beta
   bool trace_light;                         // gTraceLight: this is a light subpath (sample_photons)
   uint32_t medium = STHIP_INVALID_INSTANCE; // _medium: the volume instance the path is inside of
   float T_nee_pdf = 1;                      // path.hlsli:282
@@ -2051,6 +2076,7 @@ struct PathIntegrator {
       G *= fabsf(ngdotin);
     }
     path_pdf *= bsdf_pdf * G;  // pdfWtoA, path.hlsli:1042
+    path_contrib = path_contrib * G;  // path.hlsli:1043
   }
 
   // the medium-aware trace_ray, intersection.hlsli:240-285: up to 64 segments between volume boundaries, delta tracking
@@ -2349,7 +2375,7 @@ struct PathIntegrator {
   bool sample_direction(const DisneyMaterial& m) {
     const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float();
     MaterialSampleRecord ms;
-    m.sample(ms, V3(r0, r1, r2), local_dir_in, beta, trace_light);
+    path_contrib = path_contrib * m.sample(ms, V3(r0, r1, r2), local_dir_in, beta, trace_light);  // path.hlsli:901
     if (ms.pdf_fwd < 1e-6f) {
       beta = V3(0.0f);
       return false;
@@ -2394,7 +2420,12 @@ struct PathIntegrator {
         if (path_length >= fr.pc.gMinPathVertices)
           if (!russian_roulette()) return false;
         if (fr.flag(STHIP_eNEE)) connect_light(m);
-        if (fr.flag(STHIP_eConnectToLightPaths)) connect_light_subpath(m);
+        if (fr.flag(STHIP_eConnectToLightPaths)) {
+          if (fr.flag(STHIP_eLVC))
+            connect_lvc(m);
+          else
+            connect_light_subpath(m);
+        }
       }
     }
     if (fr.flag(STHIP_eSampleBSDFs) || trace_light) return sample_direction(m);
@@ -2500,11 +2531,15 @@ struct PathIntegrator {
     v.packed_tangent = isect.sd.packed_tangent;
     v.uv[0] = isect.sd.u;
     v.uv[1] = isect.sd.v;
-    v.pack_beta(beta, path_length, diffuse_vertices, flags);
+    v.pack_beta(fr.flag(STHIP_eLVCReservoirs) ? path_contrib : beta, path_length, diffuse_vertices, flags);  // path.hlsli:513
     v.prev_dVC = dVC;
     v.G_rev = prev_cos_out / len_sqr(origin - isect.sd.position);
     v.prev_pdfA_fwd = bsdf_pdf * G;
     v.path_pdf = path_pdf;
+    if (fr.lvc()) {  // the cache: staged per (path, vertex), compacted in that order after the light pass (see Frame)
+      fr.lvc_staging[(size_t)path_index() * (fr.pc.gMaxDiffuseVertices - 1) + (diffuse_vertices - 1)] = v;
+      return;
+    }
     const size_t idx = (size_t)fr.pc.gOutputExtent[0] * fr.pc.gOutputExtent[1] * (diffuse_vertices - 1) + path_index();
     if (idx < fr.light_vertex_count) fr.light_vertices[idx] = v;
   }
@@ -2585,6 +2620,70 @@ struct PathIntegrator {
       if (all_le0(contrib) || weight <= 0) continue;
       if (occluded(ray_origin, ray_direction, ray_distance)) continue;
       radiance = radiance + contrib * weight;
+    }
+  }
+
+  // connect_lvc, path.hlsli:683-800 without the reservoir reuse through the hash grid: this view vertex to ONE vertex of the
+  // light vertex cache, picked uniformly (li % n) or, with eLVCReservoirs, by resampled importance sampling over
+  // gReservoirM uniform picks with target luminance(contribution). The cache order is the defined one (see Frame). An
+  // empty cache (n = 0) is a division by zero upstream; here the random numbers are drawn and nothing connects. With
+  // eDeferShadowRays the record goes to this vertex's gShadowRays slot — the slot connect_light has just written, as upstream.
+  void connect_lvc(const DisneyMaterial& m) {
+    const uint32_t n = std::min<uint64_t>(fr.lvc_count, (uint64_t)fr.pc.gLightPathCount * fr.pc.gMaxDiffuseVertices);
+    const uint32_t li = rng.next_uint();
+    const PathVertex zero{};
+    auto fits = [&](const PathVertex& v) {
+      return !(v.subpath_length() + path_length > fr.pc.gMaxPathVertices || v.diffuse_vertices() + diffuse_vertices > fr.pc.gMaxDiffuseVertices || all_le0(v.beta()));
+    };
+    PathVertex lv = n ? fr.light_vertices[li % n] : zero;
+    v3 contrib = V3(0.0f), ray_origin = V3(0.0f), ray_direction = V3(0.0f);
+    float weight = 1, ray_distance = 0;
+    if (fr.flag(STHIP_eLVCReservoirs)) {
+      Reservoir r;
+      r.init();
+      float r_target_pdf = 0;  // (uninitialised upstream when no candidate is taken; W() of it then multiplies a zero contribution)
+      for (uint32_t i = 0; i < fr.pc.gReservoirM; i++) {
+        const uint32_t pick = rng.next_uint();
+        const PathVertex lv_i = n ? fr.light_vertices[pick % n] : zero;
+        if (!fits(lv_i)) continue;
+        v3 ro_i = V3(0.0f), rd_i = V3(0.0f);
+        float dist_i = 0, weight_i = 0;
+        const v3 contrib_i = connect_light_vertex(m, lv_i, weight_i, ro_i, rd_i, dist_i);
+        const float target_pdf_i = luminance(contrib_i);
+        if (r.update(rng.next_float(), target_pdf_i / lv_i.path_pdf)) {
+          contrib = contrib_i;
+          weight = weight_i;
+          ray_origin = ro_i;
+          ray_direction = rd_i;
+          ray_distance = dist_i;
+          r_target_pdf = target_pdf_i;
+          lv = lv_i;
+        }
+      }
+      contrib = contrib * r.W(r_target_pdf);
+    } else if (fits(lv)) {
+      contrib = connect_light_vertex(m, lv, weight, ray_origin, ray_direction, ray_distance);
+    }
+    contrib = contrib * (float)(fr.pc.gMaxDiffuseVertices - 1);
+    contrib = contrib * beta;
+    if (fr.flag(STHIP_eDeferShadowRays)) {
+      if (!(diffuse_vertices >= 1 && diffuse_vertices <= max_shadow)) return;
+      sthip_ShadowRayData& rd = shadow_rays[diffuse_vertices - 1];
+      const v3 c = contrib * weight;
+      rd.contribution[0] = c.x;
+      rd.contribution[1] = c.y;
+      rd.contribution[2] = c.z;
+      rd.rng_offset = rng.v[3];
+      rd.ray_origin[0] = ray_origin.x;
+      rd.ray_origin[1] = ray_origin.y;
+      rd.ray_origin[2] = ray_origin.z;
+      rd.medium = medium;
+      rd.ray_direction[0] = ray_direction.x;
+      rd.ray_direction[1] = ray_direction.y;
+      rd.ray_direction[2] = ray_direction.z;
+      rd.ray_distance = ray_distance;
+    } else if (any_gt0(contrib) && weight > 0) {
+      if (!occluded(ray_origin, ray_direction, ray_distance)) radiance = radiance + contrib * weight;
     }
   }
 
@@ -3074,6 +3173,7 @@ void trace_light_paths(const Frame& fr, uint32_t seed, int threads, uint64_t* ts
       path.isect.sd.position = ls.position;
       path.isect.sd.packed_geometry_normal = pack_normal_octahedron(ls.normal);
       path.isect.sd.shape_area = 1;
+      path.path_contrib = ls.radiance;  // bdpt.hlsl:120
       path.beta = ls.radiance / ls.pdf;
       path.path_pdf = ls.pdf;
       path.path_pdf_rev = 1;
@@ -3085,6 +3185,7 @@ void trace_light_paths(const Frame& fr, uint32_t seed, int threads, uint64_t* ts
       const v3 local_dir_out = sample_cos_hemisphere(u1, u2);
       path.bsdf_pdf = cosine_hemisphere_pdfW(local_dir_out.z);
       path.beta = path.beta * (local_dir_out.z / path.bsdf_pdf);
+      path.path_contrib = path.path_contrib * local_dir_out.z;  // bdpt.hlsl:135
       path.prev_cos_out = local_dir_out.z;
       v3 T, B;
       make_orthonormal(ls.normal, T, B);
@@ -3117,8 +3218,7 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (scene_flags & STHIP_BDPT_FLAG_TRACE_LIGHT) return STHIP_ERR_UNSUPPORTED;
 
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
-  const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) |
-                               (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
+  const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_eLVCReservoirReuse) |
                                (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
   if (sampling_flags & unsupported) return STHIP_ERR_UNSUPPORTED;
   Frame fr;
@@ -3132,10 +3232,13 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (!has_environment(fr)) fr.pc.gEnvironmentSampleProbability = 0;
   if (!has_emissives(fr)) fr.pc.gEnvironmentSampleProbability = 1;
   if (!has_emissives(fr) && !has_environment(fr)) fr.sampling_flags &= ~(1u << STHIP_eNEE);
-  if (!(fr.sampling_flags & (1u << STHIP_eNEE))) fr.sampling_flags &= ~(1u << STHIP_eDeferShadowRays);                // BDPT.cpp:522-523
+
   if (fr.pc.gLightCount > sc->lights.size()) return STHIP_ERR_INVALID_ARGUMENT;
   if (!fr.flag(STHIP_eNEE)) fr.sampling_flags &= ~((1u << STHIP_ePresampleLights) | (1u << STHIP_eNEEReservoirs));  // BDPT.cpp:511-515
   if (!has_emissives(fr) && !has_environment(fr)) fr.sampling_flags &= ~((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths));  // BDPT.cpp:504-509
+  if (!fr.flag(STHIP_eLVC)) fr.sampling_flags &= ~((1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse));  // BDPT.cpp:517-520
+  if (!fr.flag(STHIP_eConnectToLightPaths)) fr.sampling_flags &= ~((1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs));  // the cache is only read by connect_lvc
+  if (!fr.flag(STHIP_eNEE) && !fr.flag(STHIP_eLVC)) fr.sampling_flags &= ~(1u << STHIP_eDeferShadowRays);  // BDPT.cpp:522-523
   if (has_media(fr)) {
     // with media every visibility ray draws random numbers: inline ones (NEE without eDeferShadowRays, the connections of
     // eConnectToViews / eConnectToLightPaths) would advance the path's own stream mid-vertex; only the deferred form is restated
@@ -3181,6 +3284,7 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   const bool light_tracing = fr.bdpt() && fr.pc.gMaxPathVertices > 2;
   std::vector<std::vector<std::atomic<uint32_t>>> light_images;
   std::vector<std::vector<PathVertex>> light_vertices;
+  std::vector<uint32_t> lvc_counts(seed_count, 0);
   if (fr.bdpt()) {
     if (has_environment(fr) || fr.flag(STHIP_eNEEReservoirs)) return STHIP_ERR_UNSUPPORTED;  // env light paths start from an unset position upstream
     if (!frame->gInverseViewTransforms) return STHIP_ERR_INVALID_ARGUMENT;
@@ -3196,12 +3300,24 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
       for (auto& a : light_images[s]) a.store(0, std::memory_order_relaxed);
       Frame lf = fr;
       lf.light_trace = light_images[s].data();
+      std::vector<PathVertex> staging;
       if (fr.flag(STHIP_eConnectToLightPaths)) {  // BDPT.cpp:569-572
         light_vertices[s].assign((size_t)fr.pc.gLightPathCount * fr.pc.gMaxDiffuseVertices, PathVertex{});
         lf.light_vertices = light_vertices[s].data();
         lf.light_vertex_count = light_vertices[s].size();
+        if (fr.lvc()) {
+          if (fr.pc.gMaxDiffuseVertices < 2 || (uint64_t)fr.pc.gLightPathCount * fr.pc.gMaxDiffuseVertices > (1ull << 28)) return STHIP_ERR_INVALID_ARGUMENT;
+          staging.assign((size_t)fr.pc.gLightPathCount * (fr.pc.gMaxDiffuseVertices - 1), PathVertex{});
+          lf.lvc_staging = staging.data();
+        }
       }
       if (light_tracing) trace_light_paths(lf, seed_begin + s, threads, tstats.data());
+      if (fr.lvc()) {  // the cache in its defined order: paths by index, a path's vertices as it stored them
+        uint32_t n = 0;
+        for (const PathVertex& v : staging)
+          if (v.packed_beta[1] != 0) light_vertices[s][n++] = v;  // a stored vertex has subpath_length >= 2 in these bits
+        lvc_counts[s] = n;
+      }
     }
   }
   const uint32_t wx0 = window ? std::min(window[0], W) : 0u, wy0 = window ? std::min(window[1], H) : 0u;
@@ -3224,6 +3340,7 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
         if (fr.flag(STHIP_eConnectToLightPaths)) {
           sf.light_vertices = light_vertices[s].data();
           sf.light_vertex_count = light_vertices[s].size();
+          sf.lvc_count = lvc_counts[s];
         }
         if (!render_pixel(sf, x, y, seed_begin + s, rgb, want_aov ? &aov : nullptr, &tstats[(size_t)tid * 4])) break;
         inside = true;

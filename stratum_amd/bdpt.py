@@ -73,6 +73,11 @@ class BDPT:
             ("maxNullCollisions", "gMaxNullCollisions"),
             ("lightPresampleTileSize", "gLightPresampleTileSize"),
             ("lightPresampleTileCount", "gLightPresampleTileCount"),
+            ("lightPathCount", "gLightPathCount"),
+            ("reservoirM", "gReservoirM"),
+            ("reservoirMaxM", "gReservoirMaxM"),
+            ("reservoirSpatialM", "gReservoirSpatialM"),
+            ("hashGridBucketCount", "gHashGridBucketCount"),
         ):
             if key in args:
                 setattr(self.mPushConstants, field, int(args[key]))
@@ -151,7 +156,8 @@ class BDPT:
         pc.gOutputExtent[0], pc.gOutputExtent[1] = frame.width, frame.height
         pc.gViewCount = frame.views.shape[0]
         pc.gLightCount = self._scene.light_count
-        pc.gLightPathCount = frame.width * frame.height  # BDPT.cpp:469-470
+        if not (self.mSamplingFlags >> wire.FLAG_NAMES.index("eLVC")) & 1:  # BDPT.cpp:469-470: with the cache on it stays the user's value
+            pc.gLightPathCount = frame.width * frame.height
         # BDPT.cpp:393,486-496
         pc.gEnvironmentMaterialAddress = self._scene.environment_address
         if self._scene.environment_address == 0xFFFFFFFF:

@@ -20,6 +20,11 @@
 #include "post.h"
 #include "ceilings.h"
 
+namespace sthip {
+hipError_t lvc_compact(const float4* staging, uint32_t slots_per_seed, uint32_t seeds, uint32_t vertices_per_seed, float4* cache, uint32_t* counts, uint32_t* flags, uint32_t* offsets,
+                       void* tmp, size_t& tmp_bytes, hipStream_t stream);  // lvc.hip
+}
+
 namespace {
 thread_local std::string g_create_error;
 
@@ -100,6 +105,9 @@ struct sthip_ctx {
   DevBuf<float> distributions;  // gDistributions
   DevBuf<float4> presampled;    // gPresampledLights
   DevBuf<float4> bdpt;          // BDPT quantities per path (eConnectToViews)
+  DevBuf<float4> lvc_staging, path_contrib;  // eLVC: staged light vertices, the light paths' path_contrib (eLVCReservoirs)
+  DevBuf<uint32_t> lvc_count, lvc_flags, lvc_offsets;
+  DevBuf<uint8_t> lvc_tmp;
   DevBuf<uint32_t> light_trace; // gLightTraceSamples
   DevBuf<DeviceImage1> images1;  // gImage1s (alpha masks)
   DevBuf<float> image1_texels;
@@ -788,8 +796,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: depth / prev-uv outputs need gInverseViewTransforms");
   // BDPT_FLAG_TRACE_LIGHT is a per-kernel specialisation of the reference (sample_photons), never a caller's choice
   if (scene_flags & STHIP_BDPT_FLAG_TRACE_LIGHT) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: BDPT_FLAG_TRACE_LIGHT is not a scene flag a caller sets");
-  const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) |
-                               (1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse) |
+  const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_eLVCReservoirReuse) |
                                (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
   if (sampling_flags & unsupported) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: a sampling flag outside the built hot path is set");
   if (pc->gMaxPathVertices > 60 || pc->gMaxDiffuseVertices > 60) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: path length limits above 60");
@@ -804,7 +811,10 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (!has_env) pcn.gEnvironmentSampleProbability = 0;
   if (!has_emissives) pcn.gEnvironmentSampleProbability = 1;
   if (!has_emissives && !has_env) sampling_flags &= ~((1u << STHIP_eNEE) | (1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths));
-  if (!(sampling_flags & (1u << STHIP_eNEE))) sampling_flags &= ~((1u << STHIP_eDeferShadowRays) | (1u << STHIP_ePresampleLights) | (1u << STHIP_eNEEReservoirs));
+  if (!(sampling_flags & (1u << STHIP_eNEE))) sampling_flags &= ~((1u << STHIP_ePresampleLights) | (1u << STHIP_eNEEReservoirs));
+  if (!(sampling_flags & (1u << STHIP_eLVC))) sampling_flags &= ~((1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse));  // BDPT.cpp:517-520
+  if (!(sampling_flags & (1u << STHIP_eConnectToLightPaths))) sampling_flags &= ~((1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs));  // only connect_lvc reads the cache
+  if (!(sampling_flags & ((1u << STHIP_eNEE) | (1u << STHIP_eLVC)))) sampling_flags &= ~(1u << STHIP_eDeferShadowRays);  // BDPT.cpp:522-523
   pc = &pcn;
   if (has_env) {  // the Environment record (environment.h:17-22): ImageValue3, then 4 offsets into gDistributions when an image is bound
     const size_t addr = pcn.gEnvironmentMaterialAddress;
@@ -869,6 +879,13 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eConnectToLightPaths without eRemapThreads needs a width that is a multiple of 8 (upstream's padding threads race on the vertex slots of the next row)");
     if (connect_paths && pc->gMaxDiffuseVertices < 1) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eConnectToLightPaths needs gMaxDiffuseVertices >= 1");
   }
+  const bool lvc = connect_paths && (sampling_flags & (1u << STHIP_eLVC));
+  const bool lvc_reservoirs = lvc && (sampling_flags & (1u << STHIP_eLVCReservoirs));
+  if (lvc) {
+    if (pc->gMaxDiffuseVertices < 2) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eLVC needs gMaxDiffuseVertices >= 2 (a light path stores vertices 1 .. gMaxDiffuseVertices - 1)");
+    if (pc->gLightPathCount == 0 || (uint64_t)pc->gLightPathCount * pc->gMaxDiffuseVertices > (1ull << 28)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eLVC needs 0 < gLightPathCount * gMaxDiffuseVertices <= 2^28");
+    if (media) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eLVC with media is not built");
+  }
   const uint32_t light_rows = (pc->gLightPathCount + W - 1) / W;
   const uint32_t light_threads = light_tracing ? ((W + 7) / 8) * 8 * ((light_rows + 3) / 4) * 4 : 0;
   if ((uint64_t)light_threads * batch > 0x7FFFFFFFull || (light_tracing && (uint64_t)batch * W * H > 0x7FFFFFFFull)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many light paths in flight");
@@ -883,6 +900,18 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       if ((uint64_t)P * std::max<size_t>(1, conn_per_path) >= 0x40000000ull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many connection entries in flight");
       HIP_TRY(ctx, ctx->light_vertices.ensure(4 * std::max<size_t>(1, vertices_per_seed * batch)));
       HIP_TRY(ctx, ctx->conn.ensure(std::max<size_t>(1, (size_t)p.path_count * conn_per_path)));
+    }
+    if (lvc) {
+      const size_t slots = (size_t)pc->gLightPathCount * (pc->gMaxDiffuseVertices - 1) * batch;
+      if (slots > 0x7FFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many light-vertex-cache slots in flight");
+      HIP_TRY(ctx, ctx->lvc_staging.ensure(4 * slots));
+      HIP_TRY(ctx, ctx->lvc_flags.ensure(slots));
+      HIP_TRY(ctx, ctx->lvc_offsets.ensure(slots));
+      HIP_TRY(ctx, ctx->lvc_count.ensure(batch));
+      size_t tmp_bytes = 0;
+      HIP_TRY(ctx, sthip::lvc_compact(nullptr, (uint32_t)(slots / batch), batch, 0, nullptr, nullptr, ctx->lvc_flags.p, ctx->lvc_offsets.p, nullptr, tmp_bytes, ctx->stream));
+      HIP_TRY(ctx, ctx->lvc_tmp.ensure(std::max<size_t>(16, tmp_bytes)));
+      if (lvc_reservoirs) HIP_TRY(ctx, ctx->path_contrib.ensure(P));
     }
   }
 
@@ -957,6 +986,9 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.light_trace = light_tracing && connect_views ? ctx->light_trace.p : nullptr;
   p.light_vertices = connect_paths ? ctx->light_vertices.p : nullptr;
   p.conn = connect_paths && conn_per_path ? ctx->conn.p : nullptr;
+  p.lvc_staging = lvc ? ctx->lvc_staging.p : nullptr;
+  p.lvc_count = lvc ? ctx->lvc_count.p : nullptr;
+  p.path_contrib = lvc_reservoirs ? ctx->path_contrib.p : nullptr;
   p.light_threads = light_threads;
   p.light_trace_quantization = 65536;  // BDPT.hpp:55 mLightTraceQuantization
 
@@ -1204,6 +1236,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
 
     if (connect_paths) {  // BDPT.cpp:655-659; `conn` holds no pending entries when a pass starts
       HIP_TRY(ctx, hipMemsetAsync(ctx->light_vertices.p, 0, std::max<size_t>(1, vertices_per_seed * in_flight) * 64, st));
+      if (lvc) HIP_TRY(ctx, hipMemsetAsync(ctx->lvc_staging.p, 0, (size_t)in_flight * pc->gLightPathCount * (pc->gMaxDiffuseVertices - 1) * 64, st));
       if (p.conn) HIP_TRY(ctx, hipMemsetAsync(ctx->conn.p, 0, (size_t)in_flight * p.paths_per_seed * conn_per_path * 16, st));
     }
     if (light_tracing) {  // sample_photons before the view paths, BDPT.cpp:653-667
@@ -1230,6 +1263,15 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_count_rays, dim3(1), dim3(1), 0, st, p); });
       if (rc) return rc;
       p.light_pass = 0;
+    }
+    if (lvc) {  // the cache in its defined order: compact the staged vertices of every seed in flight (lvc.hip)
+      const uint32_t slots_per_seed = pc->gLightPathCount * (pc->gMaxDiffuseVertices - 1);
+      size_t tmp_bytes = ctx->lvc_tmp.n;
+      if (light_tracing)
+        HIP_TRY(ctx, sthip::lvc_compact(ctx->lvc_staging.p, slots_per_seed, in_flight, (uint32_t)vertices_per_seed, ctx->light_vertices.p, ctx->lvc_count.p, ctx->lvc_flags.p, ctx->lvc_offsets.p,
+                                        ctx->lvc_tmp.p, tmp_bytes, st));
+      else
+        HIP_TRY(ctx, hipMemsetAsync(ctx->lvc_count.p, 0, (size_t)in_flight * 4, st));
     }
 
     p.path_count = in_flight * p.paths_per_seed;

@@ -73,6 +73,13 @@ struct FrameParams {
   uint32_t light_trace_quantization;
   // light-subpath connections (eConnectToLightPaths)
   float4* light_vertices;     // gLightPathVertices: per seed in flight gLightPathCount * gMaxDiffuseVertices PathVertex records of 4 x float4 (bdpt.h:108-121)
+  // the light vertex cache (eLVC, path.hlsli:523-527,683-800). Upstream hands out cache slots with an atomic counter; the
+  // order defined here is light paths by path index, a path's vertices as it stores them (one order upstream's scheduler
+  // may produce): k_shade_light stages a vertex at [path_index * (gMaxDiffuseVertices - 1) + diffuse_vertices - 1], a
+  // scan compacts the stage into light_vertices (api.hip), lvc_count[seed in flight] = gLightPathVertexCount[0]
+  float4* lvc_staging;
+  const uint32_t* lvc_count;
+  float4* path_contrib;       // per light path: path_contrib (path.hlsli:258,901,1043), what eLVCReservoirs store instead of beta
   float4* conn;               // per view path gMaxDiffuseVertices - 1 pending connection contributions of the last vertex shaded
   uint32_t shadow_stride;     // entries between the segments of shadow_rays (a vertex may queue gMaxDiffuseVertices records)
   // participating media (BDPT_FLAG_HAS_MEDIA): see the MEDIA instantiation of k_shade and k_shadow_media
@@ -740,6 +747,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate_light(FrameParams p) {
     p.ray_d[slot] = make_float4(direction.x, direction.y, direction.z, 1.0f);
     p.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(rng.counter));
     p.bdpt[slot] = make_float4(ls.pdf, 1.0f, 1 / ls.pdf, local_dir_out.z);  // path_pdf, path_pdf_rev, dVC, prev_cos_out
+    if (p.path_contrib) {  // bdpt.hlsl:120,135
+      const f3 pcb = ls.Le * local_dir_out.z;
+      p.path_contrib[slot] = make_float4(pcb.x, pcb.y, pcb.z, 0.0f);
+    }
     p.meta[slot] = 1u;
     if (TEXTURED) p.cone[slot] = make_float2(0.0f, 0.0f);
     live++;
@@ -804,6 +815,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
     f3 beta = xyz(bb);
     float path_pdf = bd.x, path_pdf_rev = bd.y, dVC = bd.z, prev_cos_out = bd.w;
     bool prev_specular = (meta >> 16) & 1u;
+    f3 path_contrib = p.path_contrib ? xyz(p.path_contrib[slot]) : F3s(0.0f);
     Rng rng;
     rng.x = tx;
     rng.y = ty;
@@ -834,6 +846,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
       const float ngdotin = -dot3(direction, gn);
       G *= fabsf(ngdotin);
       path_pdf *= bsdf_pdf * G;  // path.hlsli:1042
+      if (p.path_contrib) path_contrib = path_contrib * G;  // path.hlsli:1043
       DisneyMaterial m;
       float rd_radius = 0, rd_spread = 0;  // RayDifferential of the light path: starts at (0, 0), bounces spread it (path.hlsli:911-916)
       if (TEXTURED) {
@@ -861,11 +874,14 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
           // vertex() / store_light_vertex(), path.hlsli:491-531: slot light_vertex_index(path_index, diffuse_vertices) (:64)
           const size_t per_seed = (size_t)p.pc.gLightPathCount * p.pc.gMaxDiffuseVertices;
           const size_t idx = (size_t)W * H * (diffuse_vertices - 1) + path_index;
-          if (idx < per_seed) {
-            float4* lv = p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
+          if (p.lvc_staging || idx < per_seed) {
+            // eLVC: staged per (path, vertex) and compacted in that order afterwards (see FrameParams::lvc_staging)
+            float4* lv = p.lvc_staging ? p.lvc_staging + 4 * (((size_t)seed_index * p.pc.gLightPathCount + path_index) * (p.pc.gMaxDiffuseVertices - 1) + (diffuse_vertices - 1))
+                                       : p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
             const uint32_t vflags = 2u | (prev_specular ? 8u : 0u);  // IS_BACKGROUND as upstream sets it, IS_PREV_DELTA
-            const uint32_t pb0 = det_f32tof16(beta.x) | (det_f32tof16(beta.y) << 16);
-            const uint32_t pb1 = det_f32tof16(beta.z) | ((path_length & 0x7Fu) << 16) | ((diffuse_vertices & 0x1Fu) << 23) | (vflags << 28);
+            const f3 stored = flag(p, STHIP_eLVCReservoirs) ? path_contrib : beta;  // path.hlsli:513
+            const uint32_t pb0 = det_f32tof16(stored.x) | (det_f32tof16(stored.y) << 16);
+            const uint32_t pb1 = det_f32tof16(stored.z) | ((path_length & 0x7Fu) << 16) | ((diffuse_vertices & 0x1Fu) << 23) | (vflags << 28);
             lv[0] = make_float4(sd.position.x, sd.position.y, sd.position.z, __uint_as_float(sd.packed_geometry_normal));
             lv[1] = make_float4(__uint_as_float(in.material_address()), __uint_as_float(pack_normal_octahedron(local_dir_in)), __uint_as_float(sd.packed_shading_normal),
                                 __uint_as_float(sd.packed_tangent));
@@ -942,7 +958,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
       // sample_direction with the adjoint BSDF, path.hlsli:898-952
       const float s0 = rng.next_float(), s1 = rng.next_float(), s2 = rng.next_float();
       MaterialSampleRecord ms;
-      m.sample(ms, F3(s0, s1, s2), local_dir_in, beta, true);
+      const f3 sampled_f = m.sample(ms, F3(s0, s1, s2), local_dir_in, beta, true);
+      if (p.path_contrib) path_contrib = path_contrib * sampled_f;  // path.hlsli:901
       if (ms.pdf_fwd < 1e-6f) break;
       if (ms.eta != 0) eta_scale /= pow2f(ms.eta);
       if (TEXTURED && flag(p, STHIP_eRayCones)) {
@@ -973,6 +990,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
       p.ray_d[slot] = make_float4(new_direction.x, new_direction.y, new_direction.z, eta_scale);
       p.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(rng.counter));
       p.bdpt[slot] = make_float4(path_pdf, path_pdf_rev, dVC, prev_cos_out);
+      if (p.path_contrib) p.path_contrib[slot] = make_float4(path_contrib.x, path_contrib.y, path_contrib.z, 0.0f);
       if (TEXTURED) p.cone[slot] = cone_out;
       p.meta[slot] = path_length | (diffuse_vertices << 8) | (prev_specular ? 1u << 16 : 0u);
       const uint32_t k = (uint32_t)atomicAdd(queue_size, 1ull);
@@ -1565,6 +1583,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             const f3 c = nothing ? F3s(0.0f) : beta * contrib * weight;
             // deferred: a zero/negative contribution never adds light and trace_shadows traces no ray for it (bdpt.hlsl:313)
             if (all_le0(c) && !inline_ray) break;
+            // eLVC with eDeferShadowRays: connect_lvc stores its record into the SAME gShadowRays slot right after this one
+            // (path.hlsli:775-783 after :355-364), unconditionally, so upstream never traces this record: neither do we
+            if (LT && flag(p, STHIP_eLVC) && flag(p, STHIP_eConnectToLightPaths) && flag(p, STHIP_eDeferShadowRays)) break;
             if (MEDIA) {  // the record of a walk through the media (k_shadow_media); its result lands in its own entry
               const uint32_t entry = slot * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
               if (!(ray_distance > 1e-6f)) {
@@ -1607,21 +1628,26 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             path_index = py * p.pc.gOutputExtent[0] + px;
           const size_t per_seed = (size_t)p.pc.gLightPathCount * p.pc.gMaxDiffuseVertices;
           const size_t level = (size_t)p.pc.gOutputExtent[0] * p.pc.gOutputExtent[1];
-          for (uint32_t li = 1; li < p.pc.gMaxDiffuseVertices; li++) {
-            const size_t idx = level * (li - 1) + path_index;
-            if (idx >= per_seed) break;
-            const float4* lvp = p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
+          // PathVertex fields of a stored vertex (bdpt.h:108-156): fits() = the three tests in front of every connection
+          auto vertex_fits = [&](const float4* lvp) {
             const float4 v2 = lvp[2];
             const uint32_t pb0 = __float_as_uint(v2.z), pb1 = __float_as_uint(v2.w);
             const f3 lv_beta = F3(det_f16tof32(pb0 & 0xFFFFu), det_f16tof32(pb0 >> 16), det_f16tof32(pb1 & 0xFFFFu));
             const uint32_t lv_length = (pb1 >> 16) & 0x7Fu, lv_diffuse = (pb1 >> 23) & 0x1Fu;
-            if (lv_length + path_length > p.pc.gMaxPathVertices || lv_diffuse + diffuse_vertices > p.pc.gMaxDiffuseVertices || all_le0(lv_beta)) break;
-            const float4 v0 = lvp[0], v1 = lvp[1], v3 = lvp[3];
-            // connect_light_vertex, path.hlsli:618-680
-            f3 contrib = lv_beta;
-            if (any_nan(contrib)) continue;
-            f3 ray_direction = xyz(v0) - sd.position;
-            float ray_distance = length3(ray_direction);
+            return !(lv_length + path_length > p.pc.gMaxPathVertices || lv_diffuse + diffuse_vertices > p.pc.gMaxDiffuseVertices || all_le0(lv_beta));
+          };
+          // connect_light_vertex, path.hlsli:618-680: the contribution (without beta) of connecting this vertex to the stored
+          // light vertex, zero when the connection fails; weight and the visibility ray come out with it
+          auto connect_light_vertex = [&](const float4* lvp, float& weight, f3& ray_origin, f3& ray_direction, float& ray_distance) -> f3 {
+            const float4 v0 = lvp[0], v1 = lvp[1], v2 = lvp[2], v3 = lvp[3];
+            const uint32_t pb0 = __float_as_uint(v2.z), pb1 = __float_as_uint(v2.w);
+            const uint32_t lv_length = (pb1 >> 16) & 0x7Fu;
+            f3 contrib = F3(det_f16tof32(pb0 & 0xFFFFu), det_f16tof32(pb0 >> 16), det_f16tof32(pb1 & 0xFFFFu));
+            const f3 none = F3s(0.0f);
+            if (all_le0(contrib) || any_nan(contrib)) return none;
+            ray_origin = sd.position;
+            ray_direction = xyz(v0) - sd.position;
+            ray_distance = length3(ray_direction);
             const float rcp_dist = 1 / ray_distance;
             ray_direction = ray_direction * rcp_dist;
             const float rcp_dist2 = pow2f(rcp_dist);
@@ -1636,7 +1662,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
               lm.load_textured(p.scene, __float_as_uint(v1.x), v2.x, v2.y, 0.0f, lv_ns, lv_tg, p.sampling_flags);
             else
               lm.load(p.scene, __float_as_uint(v1.x));
-            if (lm.is_specular()) continue;
+            if (lm.is_specular()) return none;
             Frame3 lf;
             lf.n = unpack_normal_octahedron(lv_ns);
             lf.t = unpack_normal_octahedron(lv_tg);
@@ -1645,7 +1671,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             const f3 lv_dir_out = normalize3(lf.to_local(-ray_direction));
             MaterialEvalRecord lev;
             lm.eval(lev, lv_dir_in, lv_dir_out, true);
-            if (lev.pdf_fwd < 1e-6f) continue;
+            if (lev.pdf_fwd < 1e-6f) return none;
             const f3 lv_ng = unpack_normal_octahedron(__float_as_uint(v0.w));
             const float cos_theta_light = dot3(lv_ng, -ray_direction);
             lev.f = lev.f * shading_normal_correction(lv_dir_in.z, lv_dir_out.z, dot3(lv_ng, normalize3(lf.to_world(lv_dir_in))), cos_theta_light, dot3(lv_ng, lf.n),
@@ -1654,36 +1680,106 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             connection_G_fwd *= fabsf(cos_theta_light);
             const float dL = connection_dVC(v3.x, lev.pdf_rev * v3.y, v3.z, ((pb1 >> 28) & 8u) != 0);
             float pdfA_rev = lev.pdf_fwd * rcp_dist2;
-            if (all_le0(contrib) || any_nan(contrib)) continue;
+            if (all_le0(contrib) || any_nan(contrib)) return none;
             const f3 local_to_light = normalize3(frame.to_local(ray_direction));
             const float ngdotout = dot3(gn, ray_direction);
-            const f3 ray_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
+            ray_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
             pdfA_rev *= fabsf(ngdotout);
             contrib = contrib * shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, dot3(gn, sd.shading_normal()), flag(p, STHIP_eShadingNormalShadowFix), false);
             MaterialEvalRecord ev;
             m.eval(ev, local_dir_in, local_to_light, false);
-            if (ev.pdf_fwd < 1e-6f) continue;
+            if (ev.pdf_fwd < 1e-6f) return none;
             contrib = contrib * ev.f;
-            if (all_le0(contrib)) continue;
-            float weight;
+            if (all_le0(contrib)) return none;
             if (use_mis) {
               const float G_rev = prev_cos_out / len_sqr(origin - sd.position);
               const float dE = connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular);
               weight = 1 / (1 + dE * pow2f(pdfA_rev) + dL * pow2f(ev.pdf_fwd * connection_G_fwd));
             } else
               weight = path_weight(p, path_length, lv_length);
-            contrib = beta * contrib;
-            if (all_le0(contrib) || weight <= 0) continue;
-            const f3 c = contrib * weight;
-            const uint32_t entry = slot * (p.pc.gMaxDiffuseVertices - 1) + (li - 1);
+            return contrib;
+          };
+          // a connection that survived: its visibility ray; the contribution lands in entry `entry` of `conn`
+          auto queue_connection = [&](f3 c, uint32_t entry, f3 ray_origin, f3 ray_direction, float ray_distance) {
             if (!(ray_distance > 1e-6f)) {  // trace_visibility_ray's loop never runs: visible, no ray
               p.conn[entry] = make_float4(c.x, c.y, c.z, 0.0f);
-              continue;
+              return;
             }
             const uint32_t k = (uint32_t)atomicAdd(shadow_size, 1ull);
             shadow_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
             shadow_out[3 * (size_t)k + 1] = make_float4(ray_direction.x, ray_direction.y, ray_direction.z, __uint_as_float(0x40000000u | entry));
             shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+          };
+          if (flag(p, STHIP_eLVC)) {
+            // connect_lvc, path.hlsli:683-800 (without the reuse through the hash grid): ONE vertex of the cache, picked
+            // uniformly or, with eLVCReservoirs, by resampled importance sampling over gReservoirM uniform picks. An empty
+            // cache is a division by zero upstream; here the random numbers are drawn and nothing connects.
+            const size_t per_seed_lvc = (size_t)p.pc.gLightPathCount * p.pc.gMaxDiffuseVertices;
+            const float4* cache = p.light_vertices + 4 * (size_t)seed_index * per_seed_lvc;
+            const uint32_t n = (uint32_t)min((unsigned long long)p.lvc_count[seed_index], (unsigned long long)per_seed_lvc);
+            const uint32_t li0 = rng.next_uint();
+            f3 contrib = F3s(0.0f), ray_origin = F3s(0.0f), ray_direction = F3s(0.0f);
+            float weight = 1, ray_distance = 0;
+            if (flag(p, STHIP_eLVCReservoirs)) {
+              float total_weight = 0, r_target_pdf = 0;  // Reservoir, reservoir.h:4-27
+              uint32_t M = 0;
+              for (uint32_t ri = 0; ri < p.pc.gReservoirM; ri++) {
+                const uint32_t pick = rng.next_uint();
+                if (!n) continue;
+                const float4* lvp = cache + 4 * (size_t)(pick % n);
+                if (!vertex_fits(lvp)) continue;
+                f3 ro_i = F3s(0.0f), rd_i = F3s(0.0f);
+                float dist_i = 0, weight_i = 0;
+                const f3 contrib_i = connect_light_vertex(lvp, weight_i, ro_i, rd_i, dist_i);
+                const float target_pdf_i = luminance3(contrib_i);
+                const float w = target_pdf_i / lvp[3].w;  // / lv_i.path_pdf
+                M++;
+                total_weight += w;
+                if (rng.next_float() * total_weight <= w) {
+                  contrib = contrib_i;
+                  weight = weight_i;
+                  ray_origin = ro_i;
+                  ray_direction = rd_i;
+                  ray_distance = dist_i;
+                  r_target_pdf = target_pdf_i;
+                }
+              }
+              contrib = contrib * ((r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0.0f);
+            } else if (n) {
+              const float4* lvp = cache + 4 * (size_t)(li0 % n);
+              if (vertex_fits(lvp)) contrib = connect_light_vertex(lvp, weight, ray_origin, ray_direction, ray_distance);
+            }
+            contrib = contrib * (float)(p.pc.gMaxDiffuseVertices - 1);
+            contrib = contrib * beta;
+            const f3 c = contrib * weight;
+            if (flag(p, STHIP_eDeferShadowRays)) {
+              // the record takes this vertex's gShadowRays slot (the one connect_light wrote, which is why that record was
+              // not queued above); trace_shadows skips a record whose contribution is <= 0 (bdpt.hlsl:313)
+              if (!all_le0(c)) {
+                if (!(ray_distance > 1e-6f)) {
+                  float4 acc = p.shadow_sum[slot];
+                  p.shadow_sum[slot] = make_float4(acc.x + c.x, acc.y + c.y, acc.z + c.z, 0.0f);
+                } else {
+                  const uint32_t k = (uint32_t)atomicAdd(shadow_size, 1ull);
+                  shadow_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
+                  shadow_out[3 * (size_t)k + 1] = make_float4(ray_direction.x, ray_direction.y, ray_direction.z, __uint_as_float(slot));
+                  shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+                }
+              }
+            } else if (any_gt0(contrib) && weight > 0) {
+              queue_connection(c, slot * (p.pc.gMaxDiffuseVertices - 1), ray_origin, ray_direction, ray_distance);
+            }
+          } else
+          for (uint32_t li = 1; li < p.pc.gMaxDiffuseVertices; li++) {
+            const size_t idx = level * (li - 1) + path_index;
+            if (idx >= per_seed) break;
+            const float4* lvp = p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
+            if (!vertex_fits(lvp)) break;
+            f3 ray_origin = F3s(0.0f), ray_direction = F3s(0.0f);
+            float ray_distance = 0, weight = 0;
+            const f3 contrib = beta * connect_light_vertex(lvp, weight, ray_origin, ray_direction, ray_distance);
+            if (all_le0(contrib) || weight <= 0) continue;
+            queue_connection(contrib * weight, slot * (p.pc.gMaxDiffuseVertices - 1) + (li - 1), ray_origin, ray_direction, ray_distance);
           }
         }
       }

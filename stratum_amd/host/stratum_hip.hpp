@@ -865,6 +865,11 @@ class BDPT {
         {"maxNullCollisions", &BDPTPushConstants::gMaxNullCollisions},
         {"lightPresampleTileSize", &BDPTPushConstants::gLightPresampleTileSize},
         {"lightPresampleTileCount", &BDPTPushConstants::gLightPresampleTileCount},
+        {"lightPathCount", &BDPTPushConstants::gLightPathCount},
+        {"reservoirM", &BDPTPushConstants::gReservoirM},
+        {"reservoirMaxM", &BDPTPushConstants::gReservoirMaxM},
+        {"reservoirSpatialM", &BDPTPushConstants::gReservoirSpatialM},
+        {"hashGridBucketCount", &BDPTPushConstants::gHashGridBucketCount},
     };
     for (const auto& f : fields)
       if (key == f.first) mPushConstants.*(f.second) = (uint32_t)std::stoul(value);
@@ -964,7 +969,7 @@ class BDPT {
     pc.gOutputExtent[0] = width;
     pc.gOutputExtent[1] = height;
     pc.gViewCount = f.view_count;
-    pc.gLightPathCount = width * height;  // BDPT.cpp:469-470
+    if (!((mSamplingFlags >> STHIP_eLVC) & 1u)) pc.gLightPathCount = width * height;  // BDPT.cpp:469-470: with the cache on it stays the user's value
     uint32_t& scene_flags = fs.scene_flags;  // BDPT.cpp:486-503
     scene_flags = 0;
     if (pc.gEnvironmentMaterialAddress != ~0u)

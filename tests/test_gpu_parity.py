@@ -648,6 +648,52 @@ def test_light_tracing(flags):
     _compare_frame(sc, cam, flags + ["uniformspheresampling"], w=96, h=64, seeds=1, args={"maxDiffuseVertices": 3})
 
 
+@pytest.mark.parametrize(
+    "flags,args",
+    [
+        (["connecttolightpaths", "lightvertexcache"], {"lightPathCount": 4000}),
+        (["connecttolightpaths", "lightvertexcache", "~defershadowrays"], {"lightPathCount": 7600}),
+        (["connecttolightpaths", "lightvertexcache", "~nee"], {"lightPathCount": 3000}),
+        (["connecttolightpaths", "lightvertexcache", "lvcreservoirs"], {"lightPathCount": 5000, "reservoirM": 6}),
+        (["connecttolightpaths", "lightvertexcache", "lvcreservoirs", "~defershadowrays", "~mis"], {"lightPathCount": 2500, "reservoirM": 3}),
+        (["connecttolightpaths", "lightvertexcache", "connecttoviews"], {"lightPathCount": 6000}),
+        (["connecttolightpaths", "lightvertexcache"], {"lightPathCount": 1}),  # a cache that may well stay empty
+    ],
+)
+def test_light_vertex_cache(flags, args):
+    """eLVC (+ eLVCReservoirs): light subpaths store their vertices in a cache, a view vertex connects to ONE cache entry
+    (path.hlsli:491-531,683-800). Upstream allots cache slots with an atomic counter; the order defined here (paths by
+    index, a path's vertices in storing order) is one a serial run of upstream produces — under it the frame is the
+    oracle's, bit for bit in ids and ray counts. gLightPathCount is the caller's with the cache on (BDPT.cpp:469-470)."""
+    sc, cam = scenes.cornell_box()
+    a = dict(args, maxDiffuseVertices=3, maxPathVertices=6)
+    _compare_frame(sc, cam, flags, w=100, h=76, seeds=2, args=a)
+
+
+def test_light_vertex_cache_textured_and_limits(renderer):
+    sc, cam = scenes.textured_box()
+    _compare_frame(sc, cam, ["connecttolightpaths", "lightvertexcache", "lvcreservoirs"], w=96, h=80, seeds=1, args={"lightPathCount": 3000, "maxDiffuseVertices": 3, "reservoirM": 4})
+    # the cache needs at least one storable vertex level, and a sane size
+    sc, cam = scenes.cornell_box()
+    renderer.update(sc)
+    frame = camera.Frame(64, 64, cam["fovy"], cam["eye"], cam["target"])
+    renderer.set_flag("connecttolightpaths")
+    renderer.set_flag("lightvertexcache")
+    old = (renderer.mPushConstants.gMaxDiffuseVertices, renderer.mPushConstants.gLightPathCount)
+    try:
+        renderer.mPushConstants.gMaxDiffuseVertices = 1
+        with pytest.raises(Exception, match="eLVC needs gMaxDiffuseVertices >= 2"):
+            renderer.render(frame, 0, 1)
+        renderer.mPushConstants.gMaxDiffuseVertices = 2
+        renderer.mPushConstants.gLightPathCount = 0
+        with pytest.raises(Exception, match="gLightPathCount"):
+            renderer.render(frame, 0, 1)
+    finally:
+        renderer.mPushConstants.gMaxDiffuseVertices, renderer.mPushConstants.gLightPathCount = old
+        renderer.set_flag("~connecttolightpaths")
+        renderer.set_flag("~lightvertexcache")
+
+
 def test_light_tracing_textured_and_sharded(renderer):
     from stratum_amd import shard
 
