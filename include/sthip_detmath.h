@@ -96,6 +96,12 @@ STHIP_HD float det_logf(float x) {
 
 /* log2 of a positive normal float (texture LOD, image_value.h:86,94) */
 STHIP_HD float det_log2f(float x) { return det_logf(x) * 1.44269504088896341f; }
+// tan as the quotient of the pinned sin and cos (only the hash grid's cell size needs it, hashgrid.hlsli:12)
+STHIP_HD float det_tanf(float x) {
+  float s, c;
+  det_sincosf(x, &s, &c);
+  return s / c;
+}
 
 /* e^x for |x| < 87 (Cephes expf) */
 STHIP_HD float det_expf(float x) {

@@ -1392,6 +1392,90 @@ struct Reservoir {
   }
 };
 
+// NEEReservoir, bdpt.h:157-165 (48 bytes): what a view vertex appends to the NEE hash grid
+struct NEEReservoir {
+  Reservoir r;
+  uint32_t packed_geometry_normal;
+  float W;
+  PresampledLightPoint y;
+};
+static_assert(sizeof(NEEReservoir) == 48, "NEEReservoir is 48 bytes");
+
+// hashgrid.hlsli:22-89. Upstream builds the grid with atomics (compare-exchange probing, per-bucket counters, a global
+// append counter), so which bucket a cell gets when two cells compete, and the order of a bucket's records, depend on
+// thread scheduling. DEFINED here: records are appended in (path index, diffuse vertex) order — the result of a serial
+// run of upstream's kernel. Probing does not wrap upstream (it runs off the buffer, where robust buffer access turns
+// the operations into no-ops of unspecified effect); here the table simply has 32 slots more than gHashGridBucketCount.
+struct HashGridTable {
+  uint32_t bucket_count = 0;
+  std::vector<uint32_t> checksums, counters, indices;
+  void reset(uint32_t n) {
+    bucket_count = n;
+    checksums.assign((size_t)n + 32, 0u);
+    counters.assign((size_t)n + 32, 0u);
+    indices.assign((size_t)n + 32, 0u);
+  }
+  static uint32_t f2u_sat(float f) {  // float -> uint as the hardware converts: NaN and negatives to 0, too large to 0xFFFFFFFF
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+  }
+  // hashgrid_bucket_index, hashgrid.hlsli:15-21
+  uint32_t bucket_index(v3 pos, float cell_size, uint32_t& checksum) const {
+    const float q[3] = {floorf(pos.x / cell_size) + 0.5f, floorf(pos.y / cell_size) + 0.5f, floorf(pos.z / cell_size) + 0.5f};
+    int32_t pi[3];
+    for (int k = 0; k < 3; k++) pi[k] = q[k] >= 2147483648.0f ? 0x7FFFFFFF : (q[k] <= -2147483648.0f ? (int32_t)0x80000000 : (q[k] == q[k] ? (int32_t)q[k] : 0));
+    const uint32_t px = (uint32_t)pi[0], py = (uint32_t)pi[1], pz = (uint32_t)pi[2];
+    checksum = std::max(1u, xxhash32(f2u_sat(cell_size + (float)xxhash32(pz + xxhash32(py + xxhash32(px))))));
+    return pcg(f2u_sat(cell_size + (float)pcg(pz + pcg(py + pcg(px))))) % bucket_count;
+  }
+  uint32_t find(v3 pos, float cell_size) const {
+    uint32_t checksum;
+    uint32_t b = bucket_index(pos, cell_size, checksum);
+    for (uint32_t i = 0; i < 32; i++, b++)
+      if (checksums[b] == checksum) return b;
+    return 0xFFFFFFFFu;
+  }
+  uint32_t find_or_insert(v3 pos, float cell_size) {
+    uint32_t checksum;
+    uint32_t b = bucket_index(pos, cell_size, checksum);
+    for (uint32_t i = 0; i < 32; i++, b++) {
+      if (checksums[b] == 0) checksums[b] = checksum;
+      if (checksums[b] == checksum) return b;
+    }
+    return 0xFFFFFFFFu;
+  }
+};
+template <typename T>
+struct HashGridOf {
+  HashGridTable table;
+  std::vector<T> data;
+  // one frame's appends, in the defined order: (position, cell size, record); builds counters, indices and data
+  struct Append {
+    v3 pos;
+    float cell_size;
+    T y;
+  };
+  void build(uint32_t bucket_count, const std::vector<Append>& appends) {
+    table.reset(bucket_count);
+    std::vector<std::pair<uint32_t, uint32_t>> where;  // (bucket, index in bucket) of every stored append
+    std::vector<const T*> what;
+    for (const Append& a : appends) {
+      const uint32_t b = table.find_or_insert(a.pos, a.cell_size);
+      if (b == 0xFFFFFFFFu) continue;  // 32 probes without a free or matching slot: the record is dropped (hashgrid.hlsli:56-58)
+      where.emplace_back(b, table.counters[b]++);
+      what.push_back(&a.y);
+    }
+    uint32_t running = 0;  // compute_indices, hashgrid.hlsli:72-79 (upstream: in whatever order the atomics land; here by bucket index)
+    for (size_t b = 0; b < table.counters.size(); b++) {
+      table.indices[b] = running;
+      running += table.counters[b];
+    }
+    data.assign(running, T{});
+    for (size_t k = 0; k < where.size(); k++) data[table.indices[where[k].first] + where[k].second] = *what[k];  // swizzle, :81-88
+  }
+};
+
 struct PathVertex {
   float position[3];
   uint32_t packed_geometry_normal;
@@ -1426,6 +1510,11 @@ struct Frame {
   // diffuse_vertices - 1]; compacting that array gives gLightPathVertices, lvc_count = gLightPathVertexCount[0].
   PathVertex* lvc_staging = nullptr;
   uint32_t lvc_count = 0;
+  // eNEEReservoirReuse: the previous seed's grid (null for the first seed of a call: gReservoirSpatialM = 0 then,
+  // BDPT.cpp:482-483) and this seed's appends, staged at [path_index * gMaxDiffuseVertices + diffuse_vertices - 1]
+  const HashGridOf<NEEReservoir>* prev_nee_grid = nullptr;
+  HashGridOf<NEEReservoir>::Append* nee_appends = nullptr;
+  uint8_t* nee_append_valid = nullptr;
   bool lvc() const { return flag(STHIP_eConnectToLightPaths) && flag(STHIP_eLVC); }
   bool bdpt() const { return flag(STHIP_eConnectToViews) || flag(STHIP_eConnectToLightPaths); }
   const orc_scene* sc;
@@ -2196,7 +2285,34 @@ struct PathIntegrator {
   struct LightCandidate {
     v3 Le, ray_direction;
     float pdfA, ray_distance, G;
+    v3 position;                      // DirectLightSample::p.position / packed_geometry_normal: what a reservoir stores
+    uint32_t packed_geometry_normal;
   };
+  // DirectLightSample(_isect, PresampledLightPoint), path.hlsli:184-201 (surface points: environment samples are not reused)
+  LightCandidate light_candidate_from(const PresampledLightPoint& lp) const {
+    LightCandidate c;
+    c.Le = lp.Le;
+    c.pdfA = lp.pdfA;
+    c.position = lp.position;
+    c.packed_geometry_normal = lp.packed_geometry_normal;
+    c.ray_direction = lp.position - isect.sd.position;
+    const float dist2 = len_sqr(c.ray_direction);
+    c.ray_distance = sqrtf(dist2);
+    c.ray_direction = c.ray_direction / c.ray_distance;
+    c.G = fabsf(dot(c.ray_direction, unpack_normal_octahedron(lp.packed_geometry_normal))) / dist2;
+    return c;
+  }
+  // hashgrid_cell_size, hashgrid.hlsli:4-14
+  float hashgrid_cell_size(v3 pos) const {
+    if (fr.pc.gHashGridBucketPixelRadius < 0) return fr.pc.gHashGridMinBucketRadius;
+    const sthip_TransformData& t = fr.fd.gViewTransforms[0];
+    const float dist = length(pos - V3(t.m[0][3], t.m[1][3], t.m[2][3]));
+    const sthip_ViewData& view = fr.fd.gViews[0];
+    const float ex = (float)(view.image_max[0] - view.image_min[0]), ey = (float)(view.image_max[1] - view.image_min[1]);
+    const float step = dist * det_tanf(fr.pc.gHashGridBucketPixelRadius * view.projection.vertical_fov * fmaxf(1 / ey, ey / pow2(ex)));
+    const uint32_t level = std::min(HashGridTable::f2u_sat(det_log2f(step / fr.pc.gHashGridMinBucketRadius)), 31u);
+    return fr.pc.gHashGridMinBucketRadius * (float)(int32_t)(1u << level);
+  }
   // presampled = true: `ti` picks the tile's point; else four randoms are drawn (sample_Le, path.hlsli:141-164)
   LightCandidate light_candidate(bool presampled, uint32_t ti) {
     LightCandidate c;
@@ -2207,6 +2323,8 @@ struct PathIntegrator {
       const PresampledLightPoint& lp = fr.presampled[seed - fr.seed_begin][tile_offset + ti % tile_size];
       c.Le = lp.Le;
       c.pdfA = lp.pdfA;
+      c.position = lp.position;
+      c.packed_geometry_normal = lp.packed_geometry_normal;
       c.ray_direction = lp.position - isect.sd.position;
       const float dist2 = len_sqr(c.ray_direction);
       c.ray_distance = sqrtf(dist2);
@@ -2222,6 +2340,8 @@ struct PathIntegrator {
       sample_point_on_light(fr, ls, rnd, isect.sd.position);
       c.Le = ls.radiance;
       c.pdfA = ls.pdf;
+      c.position = ls.position;
+      c.packed_geometry_normal = pack_normal_octahedron(ls.normal);
       c.ray_direction = ls.to_light;
       c.ray_distance = ls.dist;
       if (ls.is_environment) {  // sample_Le, path.hlsli:156-162
@@ -2326,8 +2446,67 @@ struct PathIntegrator {
         c_local_to_light = local_to_light;
       }
     }
+    // spatial reuse through the previous frame's hash grid, path.hlsli:402-428
+    const bool reuse = fr.flag(STHIP_eNEEReservoirReuse);
+    v3 t = V3(0.0f), b = V3(0.0f);
+    float cell_size = 0;
+    auto jittered = [&]() {  // the position a lookup / an append hashes: jittered in the tangent plane with eHashGridJitter
+      const float phi = rng.next_float() * 2 * DET_PI;
+      if (!fr.flag(STHIP_eHashGridJitter)) return isect.sd.position;
+      const float radius = cell_size * rng.next_float();
+      float sn, cs;
+      det_sincosf(phi, &sn, &cs);
+      return isect.sd.position + (t * cs + b * sn) * radius;
+    };
+    if (reuse) {
+      make_orthonormal(geometry_normal, t, b);
+      cell_size = hashgrid_cell_size(isect.sd.position);
+      if (fr.prev_nee_grid && fr.pc.gReservoirSpatialM > 0) {
+        const v3 at = jittered();
+        const uint32_t bucket = fr.prev_nee_grid->table.find(at, cell_size);
+        if (bucket != 0xFFFFFFFFu) {
+          const uint32_t bucket_start = fr.prev_nee_grid->table.indices[bucket], bucket_size = fr.prev_nee_grid->table.counters[bucket];
+          uint32_t Msum = M;
+          for (uint32_t i = 0; i < fr.pc.gReservoirSpatialM; i++) {
+            const NEEReservoir& prev = fr.prev_nee_grid->data[bucket_start + rng.next_uint() % bucket_size];
+            const LightCandidate c_i = light_candidate_from(prev.y);
+            if (c_i.pdfA <= 0 || all_le0(c_i.Le)) continue;
+            Msum += prev.r.M;
+            const v3 local_to_light = normalize(isect.sd.to_local(c_i.ray_direction));
+            const float target_pdf_i = luminance(c_i.Le) * c_i.G * fabsf(local_to_light.z);
+            const float w = target_pdf_i * prev.W * (float)prev.r.M;
+            M++;
+            total_weight += w;
+            if (rng.next_float() * total_weight <= w) {
+              r_target_pdf = target_pdf_i;
+              c = c_i;
+              c_local_to_light = local_to_light;
+            }
+          }
+          M = Msum;
+        }
+      }
+    }
     const float W = (r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0;  // reservoir.h:8-13
     if (W <= 1e-6f || W != W) return;
+    if (reuse) {  // path.hlsli:434-439: this vertex's reservoir goes into the grid the NEXT frame looks up
+      const v3 at = jittered();
+      const size_t k = (size_t)path_index() * fr.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
+      if (fr.nee_appends && diffuse_vertices >= 1 && diffuse_vertices <= fr.pc.gMaxDiffuseVertices) {
+        HashGridOf<NEEReservoir>::Append& a = fr.nee_appends[k];
+        a.pos = at;
+        a.cell_size = cell_size;
+        a.y.r.total_weight = total_weight;
+        a.y.r.M = std::min(M, fr.pc.gReservoirMaxM);
+        a.y.packed_geometry_normal = isect.sd.packed_geometry_normal;
+        a.y.W = W;
+        a.y.y.position = c.position;
+        a.y.y.packed_geometry_normal = c.packed_geometry_normal;
+        a.y.y.Le = c.Le;
+        a.y.y.pdfA = c.pdfA;
+        fr.nee_append_valid[k] = 1;
+      }
+    }
     // setup() of the chosen candidate
     const float ngdotout = dot(geometry_normal, c.ray_direction);
     const v3 ray_origin = ray_offset(isect.sd.position, ngdotout > 0 ? geometry_normal : -geometry_normal);
@@ -3218,8 +3397,7 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (scene_flags & STHIP_BDPT_FLAG_TRACE_LIGHT) return STHIP_ERR_UNSUPPORTED;
 
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
-  const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_eLVCReservoirReuse) |
-                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
+  const uint32_t unsupported = (1u << STHIP_eLVCReservoirReuse) | (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
   if (sampling_flags & unsupported) return STHIP_ERR_UNSUPPORTED;
   Frame fr;
   fr.sc = sc;
@@ -3234,7 +3412,9 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (!has_emissives(fr) && !has_environment(fr)) fr.sampling_flags &= ~(1u << STHIP_eNEE);
 
   if (fr.pc.gLightCount > sc->lights.size()) return STHIP_ERR_INVALID_ARGUMENT;
-  if (!fr.flag(STHIP_eNEE)) fr.sampling_flags &= ~((1u << STHIP_ePresampleLights) | (1u << STHIP_eNEEReservoirs));  // BDPT.cpp:511-515
+  if (!fr.flag(STHIP_eNEE)) fr.sampling_flags &= ~((1u << STHIP_ePresampleLights) | (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse));  // BDPT.cpp:511-515
+  if (!fr.flag(STHIP_eNEEReservoirs)) fr.sampling_flags &= ~(1u << STHIP_eNEEReservoirReuse);  // only connect_light_reservoir touches the grid
+  if (fr.flag(STHIP_eNEEReservoirReuse) && has_environment(fr)) return STHIP_ERR_UNSUPPORTED;  // a stored environment sample is re-read as a surface point upstream (sample_Le leaves pdfA positive)
   if (!has_emissives(fr) && !has_environment(fr)) fr.sampling_flags &= ~((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths));  // BDPT.cpp:504-509
   if (!fr.flag(STHIP_eLVC)) fr.sampling_flags &= ~((1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse));  // BDPT.cpp:517-520
   if (!fr.flag(STHIP_eConnectToLightPaths)) fr.sampling_flags &= ~((1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs));  // the cache is only read by connect_lvc
@@ -3323,46 +3503,78 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   const uint32_t wx0 = window ? std::min(window[0], W) : 0u, wy0 = window ? std::min(window[1], H) : 0u;
   const uint32_t wx1 = window ? std::min(window[2], W) : W, wy1 = window ? std::min(window[3], H) : H;
   if (window && fr.bdpt()) return STHIP_ERR_UNSUPPORTED;  // light subpaths are a whole-frame pass
+  // one sample of one pixel folded into that pixel's running mean (temporal_accumulation.hlsl:102-131: NaN/Inf samples
+  // are dropped); returns false for a pixel outside every view
+  auto sample_pixel = [&](const Frame& base, uint32_t x, uint32_t y, uint32_t s, float acc[4], int tid) -> bool {
+    const size_t p = (size_t)y * W + x;
+    float rgb[3];
+    PixelAOV aov;
+    memset(&aov, 0, sizeof(aov));  // fields a first vertex inside a medium leaves unwritten (albedo) read as zero
+    const bool want_aov = (s == 0) && (out->gAlbedo || out->gVisibility || out->gDepth || out->gPrevUVs);
+    Frame sf = base;
+    if (fr.flag(STHIP_eConnectToViews)) sf.light_trace = light_images[s].data();
+    if (fr.flag(STHIP_eConnectToLightPaths)) {
+      sf.light_vertices = light_vertices[s].data();
+      sf.light_vertex_count = light_vertices[s].size();
+      sf.lvc_count = lvc_counts[s];
+    }
+    if (!render_pixel(sf, x, y, seed_begin + s, rgb, want_aov ? &aov : nullptr, &tstats[(size_t)tid * 4])) return false;
+    float cur[4] = {rgb[0], rgb[1], rgb[2], 1};
+    if (std::isinf(cur[0]) || std::isinf(cur[1]) || std::isinf(cur[2]) || cur[0] != cur[0] || cur[1] != cur[1] || cur[2] != cur[2]) cur[0] = cur[1] = cur[2] = cur[3] = 0;
+    if (acc[3] > 0) {
+      const float n = acc[3] + cur[3];
+      const float alpha = fminf(fmaxf(cur[3] / n, 0.0f), 1.0f);
+      for (int c = 0; c < 3; c++) acc[c] = lerpf(acc[c], cur[c], alpha);
+      acc[3] = n;
+    } else {
+      for (int c = 0; c < 4; c++) acc[c] = cur[c];
+    }
+    if (want_aov) {
+      if (out->gAlbedo) memcpy(out->gAlbedo + 4 * p, aov.albedo, 16);
+      if (out->gVisibility) out->gVisibility[p] = aov.vis;
+      if (out->gDepth) out->gDepth[p] = aov.depth;
+      if (out->gPrevUVs) memcpy(out->gPrevUVs + 2 * p, aov.prev_uv, 8);
+    }
+    return true;
+  };
+  if (fr.flag(STHIP_eNEEReservoirReuse)) {
+    // Reservoir reuse couples the seeds of a call: seed s looks into the hash grid that seed s - 1 built (the reference's
+    // frame and previous frame; the first seed of a call has no previous frame: gReservoirSpatialM = 0, BDPT.cpp:482-483).
+    // So the frame is rendered seed by seed, and after each seed its appends — staged per (path, vertex) — are put into
+    // the grid in that order (see HashGridTable).
+    if (window) return STHIP_ERR_UNSUPPORTED;
+    if (fr.pc.gHashGridBucketCount == 0 || fr.pc.gHashGridBucketCount > (1u << 28) || !(fr.pc.gHashGridMinBucketRadius > 0)) return STHIP_ERR_INVALID_ARGUMENT;
+    const size_t path_slots = (size_t)((W + 7) / 8) * ((H + 3) / 4) * 32;  // covers both map_pixel_coord forms (bdpt_util.hlsli:76-83)
+    const uint32_t D = std::max(1u, fr.pc.gMaxDiffuseVertices);
+    std::vector<HashGridOf<NEEReservoir>::Append> staged(path_slots * D);
+    std::vector<uint8_t> valid(path_slots * D);
+    HashGridOf<NEEReservoir> grids[2];
+    const HashGridOf<NEEReservoir>* prev = nullptr;
+    std::vector<float> accs((size_t)W * H * 4, 0.0f);
+    for (uint32_t s = 0; s < seed_count; s++) {
+      std::fill(valid.begin(), valid.end(), 0);
+      Frame base = fr;
+      base.prev_nee_grid = prev;
+      base.nee_appends = staged.data();
+      base.nee_append_valid = valid.data();
+      parallel_rows(H, threads, [&](uint32_t y, int tid) {
+        for (uint32_t x = 0; x < W; x++) sample_pixel(base, x, y, s, &accs[4 * ((size_t)y * W + x)], tid);
+      });
+      std::vector<HashGridOf<NEEReservoir>::Append> appends;
+      for (size_t k = 0; k < staged.size(); k++)
+        if (valid[k]) appends.push_back(staged[k]);
+      grids[s & 1].build(fr.pc.gHashGridBucketCount, appends);
+      prev = &grids[s & 1];
+    }
+    memcpy(out->gRadiance, accs.data(), accs.size() * 4);
+  } else
   parallel_rows(wy1 > wy0 ? wy1 - wy0 : 0u, threads, [&](uint32_t row, int tid) {
     const uint32_t y = wy0 + row;
     for (uint32_t x = wx0; x < wx1; x++) {
-      const size_t p = (size_t)y * W + x;
-      // temporal_accumulation.hlsl:102-131: running mean, NaN/Inf samples are dropped
       float acc[4] = {0, 0, 0, 0};
-      bool inside = false;
-      for (uint32_t s = 0; s < seed_count; s++) {
-        float rgb[3];
-        PixelAOV aov;
-        memset(&aov, 0, sizeof(aov));  // fields a first vertex inside a medium leaves unwritten (albedo) read as zero
-        const bool want_aov = (s == 0) && (out->gAlbedo || out->gVisibility || out->gDepth || out->gPrevUVs);
-        Frame sf = fr;
-        if (fr.flag(STHIP_eConnectToViews)) sf.light_trace = light_images[s].data();
-        if (fr.flag(STHIP_eConnectToLightPaths)) {
-          sf.light_vertices = light_vertices[s].data();
-          sf.light_vertex_count = light_vertices[s].size();
-          sf.lvc_count = lvc_counts[s];
-        }
-        if (!render_pixel(sf, x, y, seed_begin + s, rgb, want_aov ? &aov : nullptr, &tstats[(size_t)tid * 4])) break;
-        inside = true;
-        float cur[4] = {rgb[0], rgb[1], rgb[2], 1};
-        if (std::isinf(cur[0]) || std::isinf(cur[1]) || std::isinf(cur[2]) || cur[0] != cur[0] || cur[1] != cur[1] || cur[2] != cur[2]) cur[0] = cur[1] = cur[2] = cur[3] = 0;
-        if (acc[3] > 0) {
-          const float n = acc[3] + cur[3];
-          const float alpha = fminf(fmaxf(cur[3] / n, 0.0f), 1.0f);
-          for (int c = 0; c < 3; c++) acc[c] = lerpf(acc[c], cur[c], alpha);
-          acc[3] = n;
-        } else {
-          for (int c = 0; c < 4; c++) acc[c] = cur[c];
-        }
-        if (want_aov) {
-          if (out->gAlbedo) memcpy(out->gAlbedo + 4 * p, aov.albedo, 16);
-          if (out->gVisibility) out->gVisibility[p] = aov.vis;
-          if (out->gDepth) out->gDepth[p] = aov.depth;
-          if (out->gPrevUVs) memcpy(out->gPrevUVs + 2 * p, aov.prev_uv, 8);
-        }
-      }
-      (void)inside;
-      memcpy(out->gRadiance + 4 * p, acc, 16);
+      for (uint32_t s = 0; s < seed_count; s++)
+        if (!sample_pixel(fr, x, y, s, acc, tid)) break;
+      memcpy(out->gRadiance + 4 * ((size_t)y * W + x), acc, 16);
     }
   });
   uint64_t tot[4] = {0, 0, 0, 0};

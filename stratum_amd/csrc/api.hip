@@ -108,6 +108,11 @@ struct sthip_ctx {
   DevBuf<float4> lvc_staging, path_contrib;  // eLVC: staged light vertices, the light paths' path_contrib (eLVCReservoirs)
   DevBuf<uint32_t> lvc_count, lvc_flags, lvc_offsets;
   DevBuf<uint8_t> lvc_tmp;
+  // eNEEReservoirReuse: the append stage and its compaction, the keys / destinations of the host-side probing, the grid
+  DevBuf<float4> hg_appends, hg_compact, hg_data;
+  DevBuf<uint32_t> hg_count, hg_flags, hg_offsets, hg_dest, hg_checksums, hg_counters, hg_indices;
+  DevBuf<uint2> hg_keys;
+  DevBuf<uint8_t> hg_tmp;
   DevBuf<uint32_t> light_trace; // gLightTraceSamples
   DevBuf<DeviceImage1> images1;  // gImage1s (alpha masks)
   DevBuf<float> image1_texels;
@@ -796,8 +801,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: depth / prev-uv outputs need gInverseViewTransforms");
   // BDPT_FLAG_TRACE_LIGHT is a per-kernel specialisation of the reference (sample_photons), never a caller's choice
   if (scene_flags & STHIP_BDPT_FLAG_TRACE_LIGHT) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: BDPT_FLAG_TRACE_LIGHT is not a scene flag a caller sets");
-  const uint32_t unsupported = (1u << STHIP_eNEEReservoirReuse) | (1u << STHIP_eLVCReservoirReuse) |
-                               (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
+  const uint32_t unsupported = (1u << STHIP_eLVCReservoirReuse) | (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
   if (sampling_flags & unsupported) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: a sampling flag outside the built hot path is set");
   if (pc->gMaxPathVertices > 60 || pc->gMaxDiffuseVertices > 60) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: path length limits above 60");
   if (pc->gLightCount > ctx->light_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: gLightCount exceeds the uploaded light list");
@@ -811,7 +815,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (!has_env) pcn.gEnvironmentSampleProbability = 0;
   if (!has_emissives) pcn.gEnvironmentSampleProbability = 1;
   if (!has_emissives && !has_env) sampling_flags &= ~((1u << STHIP_eNEE) | (1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths));
-  if (!(sampling_flags & (1u << STHIP_eNEE))) sampling_flags &= ~((1u << STHIP_ePresampleLights) | (1u << STHIP_eNEEReservoirs));
+  if (!(sampling_flags & (1u << STHIP_eNEE))) sampling_flags &= ~((1u << STHIP_ePresampleLights) | (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse));
+  if (!(sampling_flags & (1u << STHIP_eNEEReservoirs))) sampling_flags &= ~(1u << STHIP_eNEEReservoirReuse);  // only connect_light_reservoir touches the grid
   if (!(sampling_flags & (1u << STHIP_eLVC))) sampling_flags &= ~((1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse));  // BDPT.cpp:517-520
   if (!(sampling_flags & (1u << STHIP_eConnectToLightPaths))) sampling_flags &= ~((1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs));  // only connect_lvc reads the cache
   if (!(sampling_flags & ((1u << STHIP_eNEE) | (1u << STHIP_eLVC)))) sampling_flags &= ~(1u << STHIP_eDeferShadowRays);  // BDPT.cpp:522-523
@@ -864,7 +869,10 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   // Seeds traced together in one pass. A shard of a frame is small (1/8 of 1080p = 259 K paths does not fill
   // 256 CUs of persistent waves), so several seeds of the owned pixels share the launches, up to ~4 M paths.
   const uint32_t max_in_flight = (uint32_t)std::max<uint64_t>(1, (ctx->max_paths_in_flight) / std::max(1u, p.paths_per_seed));
-  const uint32_t batch = std::min(seed_count, max_in_flight);
+  // Reservoir reuse couples the seeds of a call: seed s looks into the hash grid seed s - 1 built (the reference's frame
+  // and previous frame), so they are traced one at a time and the grid is built between them.
+  const bool nee_reuse = (sampling_flags & (1u << STHIP_eNEEReservoirReuse)) != 0;
+  const uint32_t batch = nee_reuse ? 1u : std::min(seed_count, max_in_flight);
   p.path_count = batch * p.paths_per_seed;
   // light tracing (eConnectToViews, BDPT.cpp:653-667): sample_photons' padded dispatch, dispatch_over(W, ceil(gLightPathCount / W))
   const bool connect_views = (sampling_flags & (1u << STHIP_eConnectToViews)) != 0;
@@ -913,6 +921,31 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       HIP_TRY(ctx, ctx->lvc_tmp.ensure(std::max<size_t>(16, tmp_bytes)));
       if (lvc_reservoirs) HIP_TRY(ctx, ctx->path_contrib.ensure(P));
     }
+  }
+
+  size_t hg_slots = 0;
+  const uint32_t hg_buckets = nee_reuse ? pc->gHashGridBucketCount + 32u : 0u;  // probing does not wrap (hashgrid.h)
+  if (nee_reuse) {
+    if (has_env) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eNEEReservoirReuse with an environment (a stored environment sample is read back as a surface point upstream: sample_Le leaves its pdfA positive)");
+    if (media) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eNEEReservoirReuse with media is not built");
+    if (ctx->shard_count > 1) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eNEEReservoirReuse on a pixel-tile shard (the grid is a whole-frame structure: render replicas and reduce)");
+    if (pc->gHashGridBucketCount == 0 || pc->gHashGridBucketCount > (1u << 28) || !(pc->gHashGridMinBucketRadius > 0)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eNEEReservoirReuse needs 0 < gHashGridBucketCount <= 2^28 and gHashGridMinBucketRadius > 0");
+    hg_slots = (size_t)((W + 7) / 8) * ((H + 3) / 4) * 32 * std::max(1u, pc->gMaxDiffuseVertices);  // covers both map_pixel_coord forms
+    if (hg_slots > 0x7FFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many hash-grid append slots");
+    HIP_TRY(ctx, ctx->hg_appends.ensure(4 * hg_slots));
+    HIP_TRY(ctx, ctx->hg_compact.ensure(4 * hg_slots));
+    HIP_TRY(ctx, ctx->hg_data.ensure(3 * hg_slots));
+    HIP_TRY(ctx, ctx->hg_flags.ensure(hg_slots));
+    HIP_TRY(ctx, ctx->hg_offsets.ensure(hg_slots));
+    HIP_TRY(ctx, ctx->hg_dest.ensure(hg_slots));
+    HIP_TRY(ctx, ctx->hg_keys.ensure(hg_slots));
+    HIP_TRY(ctx, ctx->hg_count.ensure(1));
+    HIP_TRY(ctx, ctx->hg_checksums.ensure(hg_buckets));
+    HIP_TRY(ctx, ctx->hg_counters.ensure(hg_buckets));
+    HIP_TRY(ctx, ctx->hg_indices.ensure(hg_buckets));
+    size_t tmp_bytes = 0;
+    HIP_TRY(ctx, sthip::lvc_compact(nullptr, (uint32_t)hg_slots, 1, 0, nullptr, nullptr, ctx->hg_flags.p, ctx->hg_offsets.p, nullptr, tmp_bytes, ctx->stream));
+    HIP_TRY(ctx, ctx->hg_tmp.ensure(std::max<size_t>(16, tmp_bytes)));
   }
 
   HIP_TRY(ctx, ctx->ray_o.ensure(P));
@@ -986,6 +1019,12 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.light_trace = light_tracing && connect_views ? ctx->light_trace.p : nullptr;
   p.light_vertices = connect_paths ? ctx->light_vertices.p : nullptr;
   p.conn = connect_paths && conn_per_path ? ctx->conn.p : nullptr;
+  p.hg_checksums = ctx->hg_checksums.p;
+  p.hg_counters = ctx->hg_counters.p;
+  p.hg_indices = ctx->hg_indices.p;
+  p.hg_data = ctx->hg_data.p;
+  p.hg_prev = 0;
+  p.hg_appends = nee_reuse ? ctx->hg_appends.p : nullptr;
   p.lvc_staging = lvc ? ctx->lvc_staging.p : nullptr;
   p.lvc_count = lvc ? ctx->lvc_count.p : nullptr;
   p.path_contrib = lvc_reservoirs ? ctx->path_contrib.p : nullptr;
@@ -1274,6 +1313,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
         HIP_TRY(ctx, hipMemsetAsync(ctx->lvc_count.p, 0, (size_t)in_flight * 4, st));
     }
 
+    if (nee_reuse) HIP_TRY(ctx, hipMemsetAsync(ctx->hg_appends.p, 0, hg_slots * 64, st));
     p.path_count = in_flight * p.paths_per_seed;
     rc = reset_queues();
     if (rc) return rc;
@@ -1317,6 +1357,46 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     if (rc) return rc;
     rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + in_flight == seed_count ? 1u : 0u, primary_rays * in_flight); });
     if (rc) return rc;
+    if (nee_reuse && s + in_flight < seed_count) {
+      // This seed's appends become the grid the next seed looks up (hashgrid.h): compact the stage in (path, vertex) order,
+      // hash the keys on the device, probe them on the host in that order exactly as find_or_insert does (hashgrid.hlsli:43-58
+      // run serially), prefix the bucket counters (compute_indices, :72-79) and scatter the records (swizzle, :81-88).
+      size_t tmp_bytes = ctx->hg_tmp.n;
+      HIP_TRY(ctx, sthip::lvc_compact(ctx->hg_appends.p, (uint32_t)hg_slots, 1, (uint32_t)hg_slots, ctx->hg_compact.p, ctx->hg_count.p, ctx->hg_flags.p, ctx->hg_offsets.p, ctx->hg_tmp.p, tmp_bytes, st));
+      hipLaunchKernelGGL(k_hg_keys, dim3((unsigned)((hg_slots + STHIP_BLOCK - 1) / STHIP_BLOCK)), dim3(STHIP_BLOCK), 0, st, ctx->hg_compact.p, ctx->hg_count.p, pc->gHashGridBucketCount, ctx->hg_keys.p);
+      uint32_t n_app = 0;
+      HIP_TRY(ctx, hipMemcpyAsync(&n_app, ctx->hg_count.p, 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      std::vector<uint2> keys(n_app);
+      if (n_app) HIP_TRY(ctx, hipMemcpy(keys.data(), ctx->hg_keys.p, (size_t)n_app * 8, hipMemcpyDeviceToHost));
+      std::vector<uint32_t> checksums(hg_buckets, 0u), counters(hg_buckets, 0u), indices(hg_buckets, 0u), dest(std::max<size_t>(1, n_app), 0xFFFFFFFFu), bucket_of(n_app), rank_of(n_app);
+      for (uint32_t k = 0; k < n_app; k++) {
+        uint32_t b = keys[k].x, found = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < 32; i++, b++) {
+          if (checksums[b] == 0) checksums[b] = keys[k].y;
+          if (checksums[b] == keys[k].y) {
+            found = b;
+            break;
+          }
+        }
+        bucket_of[k] = found;
+        if (found != 0xFFFFFFFFu) rank_of[k] = counters[found]++;
+      }
+      uint32_t running = 0;
+      for (uint32_t b = 0; b < hg_buckets; b++) {
+        indices[b] = running;
+        running += counters[b];
+      }
+      for (uint32_t k = 0; k < n_app; k++)
+        if (bucket_of[k] != 0xFFFFFFFFu) dest[k] = indices[bucket_of[k]] + rank_of[k];
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->hg_checksums.p, checksums.data(), (size_t)hg_buckets * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->hg_counters.p, counters.data(), (size_t)hg_buckets * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->hg_indices.p, indices.data(), (size_t)hg_buckets * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->hg_dest.p, dest.data(), dest.size() * 4, hipMemcpyHostToDevice, st));
+      if (n_app) hipLaunchKernelGGL(k_hg_scatter, dim3((n_app + STHIP_BLOCK - 1) / STHIP_BLOCK), dim3(STHIP_BLOCK), 0, st, ctx->hg_compact.p, n_app, ctx->hg_dest.p, ctx->hg_data.p);
+      HIP_TRY(ctx, hipStreamSynchronize(st));  // the host vectors above are the source of the copies
+      p.hg_prev = 1;
+    }
   }
 
   if (!dev) {

@@ -14,6 +14,7 @@
 #pragma once
 
 #include "shading.h"
+#include "hashgrid.h"
 #include "medium.h"
 #include "traverse.h"
 
@@ -80,6 +81,15 @@ struct FrameParams {
   float4* lvc_staging;
   const uint32_t* lvc_count;
   float4* path_contrib;       // per light path: path_contrib (path.hlsli:258,901,1043), what eLVCReservoirs store instead of beta
+  // eNEEReservoirReuse (hashgrid.h): the previous seed's grid (hg_prev = 0 for the first seed of a call: nothing to look
+  // up, BDPT.cpp:482-483) and the stage for this seed's appends, 4 x float4 per (path index, diffuse vertex):
+  // (position, r.total_weight) (bits(r.M), bits(packed_geometry_normal), W, y.pdfA) (y.position, bits(cell_size)) (y.Le, bits(y.packed_geometry_normal))
+  const uint32_t* hg_checksums;
+  const uint32_t* hg_counters;
+  const uint32_t* hg_indices;
+  const float4* hg_data;      // NEEReservoir (bdpt.h:157-165), 3 x float4: (r.total_weight, bits(r.M), bits(packed_geometry_normal), W) (y.position, bits(y.packed_geometry_normal)) (y.Le, y.pdfA)
+  uint32_t hg_prev;
+  float4* hg_appends;
   float4* conn;               // per view path gMaxDiffuseVertices - 1 pending connection contributions of the last vertex shaded
   uint32_t shadow_stride;     // entries between the segments of shadow_rays (a vertex may queue gMaxDiffuseVertices records)
   // participating media (BDPT_FLAG_HAS_MEDIA): see the MEDIA instantiation of k_shade and k_shadow_media
@@ -1474,7 +1484,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
           // connect_light, path.hlsli:311-366; sample_Le :141-164; sample_point_on_light, light.hlsli:37-152
           // one light candidate: DirectLightSample's two constructors (path.hlsli:179-201) in front of setup()
           const bool presampled = flag(p, STHIP_ePresampleLights);
-          auto light_candidate = [&](uint32_t ti, f3& cLe, float& c_pdfA, f3& c_dir, float& c_dist, float& c_G) {
+          auto light_candidate = [&](uint32_t ti, f3& cLe, float& c_pdfA, f3& c_dir, float& c_dist, float& c_G, f3& c_pos, uint32_t& c_pgn) {
             if (presampled) {
               // path.hlsli:313-320: one of the tile's presampled points; DirectLightSample(_isect, PresampledLightPoint) :184-201
               uint32_t path_index;  // map_pixel_coord, bdpt_util.hlsli:76-83, with the 8x4 groups of bdpt.hlsl:11-12
@@ -1488,6 +1498,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
               const float4 l0 = lp[0], l1 = lp[1];
               cLe = xyz(l1);
               c_pdfA = l1.w;
+              c_pos = xyz(l0);
+              c_pgn = __float_as_uint(l0.w);
               c_dir = xyz(l0) - sd.position;
               const float dist2 = len_sqr(c_dir);
               c_dist = sqrtf(dist2);
@@ -1501,6 +1513,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
               c_dir = ls.to_light;
               c_dist = ls.dist;
               c_pdfA = ls.pdf;
+              c_pos = ls.position;
+              c_pgn = pack_normal_octahedron(ls.normal);
               if (ls.is_env) {  // sample_Le, path.hlsli:156-162
                 c_G = 1;
               } else {
@@ -1521,11 +1535,14 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             lLe = to_light = F3s(0.0f);
             pdfA = cG = ls_dist = 0;
             uint32_t ti = rng.next_uint();
+            f3 y_pos = F3s(0.0f);  // the chosen candidate's PresampledLightPoint (what a reservoir stores)
+            uint32_t y_pgn = 0;
             for (uint32_t k = 0; k < p.pc.gReservoirM; k++) {
               if (presampled) ti = rng.next_uint();
-              f3 cLe, c_dir;
+              f3 cLe, c_dir, c_pos = F3s(0.0f);
               float c_pdfA, c_dist, c_G;
-              light_candidate(ti, cLe, c_pdfA, c_dir, c_dist, c_G);
+              uint32_t c_pgn = 0;
+              light_candidate(ti, cLe, c_pdfA, c_dir, c_dist, c_G, c_pos, c_pgn);
               if (c_pdfA <= 0 || all_le0(cLe)) continue;
               const f3 c_local = normalize3(frame.to_local(c_dir));
               const float target_pdf = luminance3(cLe) * c_G * fabsf(c_local.z);
@@ -1539,12 +1556,86 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
                 pdfA = c_pdfA;
                 cG = c_G;
                 ls_dist = c_dist;
+                y_pos = c_pos;
+                y_pgn = c_pgn;
+              }
+            }
+            // spatial reuse through the previous seed's hash grid, path.hlsli:402-428, and this vertex's append, :434-439
+            const bool reuse = p.hg_appends != nullptr;
+            f3 hg_t = F3s(0.0f), hg_b = F3s(0.0f);
+            float cell_size = 0;
+            auto jittered = [&]() {  // the position a lookup / an append hashes: jittered in the tangent plane with eHashGridJitter
+              const float phi = rng.next_float() * 2 * DET_PI;
+              if (!flag(p, STHIP_eHashGridJitter)) return sd.position;
+              const float radius = cell_size * rng.next_float();
+              float sn, cs;
+              det_sincosf(phi, &sn, &cs);
+              return sd.position + (hg_t * cs + hg_b * sn) * radius;
+            };
+            if (reuse) {
+              make_orthonormal(gn, hg_t, hg_b);
+              const Xf vt = load_xf(p.view_xf, 0);
+              cell_size = hashgrid_cell_size(p.pc, p.views[0], F3(vt.r0.w, vt.r1.w, vt.r2.w), sd.position);
+              if (p.hg_prev && p.pc.gReservoirSpatialM > 0) {
+                const f3 at = jittered();
+                const uint32_t bucket = hashgrid_find(p.hg_checksums, p.pc.gHashGridBucketCount, at, cell_size);
+                if (bucket != 0xFFFFFFFFu) {
+                  const uint32_t bucket_start = p.hg_indices[bucket], bucket_size = p.hg_counters[bucket];
+                  uint32_t Msum = M;
+                  for (uint32_t k = 0; k < p.pc.gReservoirSpatialM; k++) {
+                    const float4* pr = p.hg_data + 3 * (size_t)(bucket_start + rng.next_uint() % bucket_size);
+                    const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+                    // DirectLightSample(_isect, prev_reservoir.y), path.hlsli:184-201 (surface points only)
+                    const f3 cLe = xyz(q2);
+                    const float c_pdfA = q2.w;
+                    f3 c_dir = xyz(q1) - sd.position;
+                    const float dist2 = len_sqr(c_dir);
+                    const float c_dist = sqrtf(dist2);
+                    c_dir = c_dir / c_dist;
+                    const float c_G = fabsf(dot3(c_dir, unpack_normal_octahedron(__float_as_uint(q1.w)))) / dist2;
+                    if (c_pdfA <= 0 || all_le0(cLe)) continue;
+                    const uint32_t prev_M = __float_as_uint(q0.y);
+                    Msum += prev_M;
+                    const f3 c_local = normalize3(frame.to_local(c_dir));
+                    const float target_pdf = luminance3(cLe) * c_G * fabsf(c_local.z);
+                    const float w = target_pdf * q0.w * (float)prev_M;
+                    M++;
+                    total_weight += w;
+                    if (rng.next_float() * total_weight <= w) {
+                      r_target_pdf = target_pdf;
+                      lLe = cLe;
+                      to_light = c_dir;
+                      pdfA = c_pdfA;
+                      cG = c_G;
+                      ls_dist = c_dist;
+                      y_pos = xyz(q1);
+                      y_pgn = __float_as_uint(q1.w);
+                    }
+                  }
+                  M = Msum;
+                }
               }
             }
             ris_W = (r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0;
-            if (ris_W <= 1e-6f || ris_W != ris_W) lLe = F3s(0.0f), pdfA = 0;  // :440: nothing to connect
+            if (ris_W <= 1e-6f || ris_W != ris_W) {
+              lLe = F3s(0.0f), pdfA = 0;  // :440: nothing to connect (and nothing appended)
+            } else if (reuse) {
+              const f3 at = jittered();
+              uint32_t path_index;  // map_pixel_coord, bdpt_util.hlsli:76-83
+              if (flag(p, STHIP_eRemapThreads))
+                path_index = ((py >> 2) * ((p.pc.gOutputExtent[0] + 7u) >> 3) + (px >> 3)) * 32u + (py & 3u) * 8u + (px & 7u);
+              else
+                path_index = py * p.pc.gOutputExtent[0] + px;
+              float4* a = p.hg_appends + 4 * ((size_t)path_index * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1));
+              a[0] = make_float4(at.x, at.y, at.z, total_weight);
+              a[1] = make_float4(__uint_as_float(min(M, p.pc.gReservoirMaxM)), __uint_as_float(sd.packed_geometry_normal), ris_W, pdfA);
+              a[2] = make_float4(y_pos.x, y_pos.y, y_pos.z, cell_size);
+              a[3] = make_float4(lLe.x, lLe.y, lLe.z, __uint_as_float(y_pgn));
+            }
           } else {
-            light_candidate(presampled ? rng.next_uint() : 0u, lLe, pdfA, to_light, ls_dist, cG);
+            f3 unused_pos;
+            uint32_t unused_pgn;
+            light_candidate(presampled ? rng.next_uint() : 0u, lLe, pdfA, to_light, ls_dist, cG, unused_pos, unused_pgn);
           }
           // DirectLightSample::setup, path.hlsli:204-221
           const f3 local_to_light = normalize3(frame.to_local(to_light));
@@ -1987,6 +2078,27 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
 }
 
 // gRayCount[0] = every trace_ray call, [1] = path (closest-hit) rays; intersection.hlsli:66, path.hlsli:1006
+// ---- hash grid build (hashgrid.h): keys of the compacted appends, and the scatter into the bucket ranges ----
+__global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys(const float4* appends, const uint32_t* count, uint32_t bucket_count, uint2* keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *count) return;
+  const float4 a0 = appends[4 * (size_t)i], a2 = appends[4 * (size_t)i + 2];
+  uint32_t checksum;
+  const uint32_t home = hashgrid_bucket_index(xyz(a0), a2.w, bucket_count, checksum);
+  keys[i] = make_uint2(home, checksum);
+}
+// dest[i] = index into gNEEHashGrid.mData of append i, or 0xFFFFFFFF when its 32 probes found no slot (dropped, hashgrid.hlsli:56-58)
+__global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter(const float4* appends, uint32_t n, const uint32_t* dest, float4* data) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t d = dest[i];
+  if (d == 0xFFFFFFFFu) return;
+  const float4 a0 = appends[4 * (size_t)i], a1 = appends[4 * (size_t)i + 1], a2 = appends[4 * (size_t)i + 2], a3 = appends[4 * (size_t)i + 3];
+  data[3 * (size_t)d] = make_float4(a0.w, a1.x, a1.y, a1.z);      // r.total_weight, bits(r.M), bits(packed_geometry_normal), W
+  data[3 * (size_t)d + 1] = make_float4(a2.x, a2.y, a2.z, a3.w);  // y.position, bits(y.packed_geometry_normal)
+  data[3 * (size_t)d + 2] = make_float4(a3.x, a3.y, a3.z, a1.w);  // y.Le, y.pdfA
+}
+
 __global__ void k_write_ray_count(const unsigned long long* counters, unsigned long long* out) {
   out[0] = counters[CNT_RAYS_CLOSEST] + counters[CNT_RAYS_SHADOW];
   out[1] = counters[CNT_RAYS_CLOSEST] - counters[CNT_CROSSINGS];  // one per trace() call (path.hlsli:1006), however many segments it walked

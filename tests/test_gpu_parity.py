@@ -617,6 +617,25 @@ def test_nee_reservoirs(flags):
         _compare_frame(sc, cam, flags, seeds=1)
 
 
+@pytest.mark.parametrize(
+    "flags,args",
+    [
+        (["neereservoirs", "neereservoirreuse"], {"reservoirM": 4}),
+        (["neereservoirs", "neereservoirreuse", "jitterhashgridlookups"], {"reservoirM": 2, "reservoirSpatialM": 3}),
+        (["neereservoirs", "neereservoirreuse", "presamplelights", "~defershadowrays"], {"reservoirM": 3}),
+        (["neereservoirs", "neereservoirreuse"], {"reservoirM": 2, "hashGridBucketCount": 40}),  # cells compete: probing, dropped records
+        (["neereservoirs", "neereservoirreuse", "~remapthreads"], {"reservoirM": 1, "reservoirSpatialM": 8, "maxDiffuseVertices": 3}),
+    ],
+)
+def test_nee_reservoir_reuse(flags, args):
+    """eNEEReservoirReuse: every view vertex's light reservoir goes into a spatial hash grid, and the next frame's vertices
+    resample from the bucket they fall into (path.hlsli:396-439, hashgrid.hlsli). Frames are the seeds of a call: seed s
+    reads the grid of seed s - 1. Upstream builds the grid with atomics; under the defined order (appends in path order,
+    hashgrid.h) the four-seed frame is the oracle's, bit for bit in ids and ray counts."""
+    sc, cam = scenes.cornell_box()
+    _compare_frame(sc, cam, flags, w=100, h=76, seeds=4, args=args)
+
+
 def test_two_views_in_one_frame(renderer, cornell):
     """gViewCount = 2 (one ViewData per eye with its own image rectangle, scene.h:132-137): every output of both halves
     equals the oracle's; pixels outside every view (odd width: the last column) stay untouched."""
