@@ -1497,6 +1497,14 @@ struct PathVertex {
   bool flip_bitangent() const { return (packed_beta[1] >> 28) & 1u; }
 };
 static_assert(sizeof(PathVertex) == 64, "PathVertex is 64 bytes");
+// PathVertexReservoir, bdpt.h:166-174 (80 bytes): what a view vertex appends to the LVC hash grid
+struct PathVertexReservoir {
+  Reservoir r;
+  uint32_t packed_geometry_normal;
+  float W;
+  PathVertex y;
+};
+static_assert(sizeof(PathVertexReservoir) == 80, "PathVertexReservoir is 80 bytes");
 
 struct Frame {
   // gLightPathVertices of the seed being traced (eConnectToLightPaths): [diffuse_vertices - 1][W * H], zero-filled
@@ -1515,6 +1523,10 @@ struct Frame {
   const HashGridOf<NEEReservoir>* prev_nee_grid = nullptr;
   HashGridOf<NEEReservoir>::Append* nee_appends = nullptr;
   uint8_t* nee_append_valid = nullptr;
+  // eLVCReservoirReuse: the same for the reservoirs of connect_lvc (path.hlsli:727-768)
+  const HashGridOf<PathVertexReservoir>* prev_lvc_grid = nullptr;
+  HashGridOf<PathVertexReservoir>::Append* lvc_appends = nullptr;
+  uint8_t* lvc_append_valid = nullptr;
   bool lvc() const { return flag(STHIP_eConnectToLightPaths) && flag(STHIP_eLVC); }
   bool bdpt() const { return flag(STHIP_eConnectToViews) || flag(STHIP_eConnectToLightPaths); }
   const orc_scene* sc;
@@ -2517,7 +2529,14 @@ struct PathIntegrator {
     v3 contrib = c.Le * ev.f * cG * W;
     if (all_le0(contrib) || c.pdfA < 1e-6f) return;
     float weight = 1;
-    if (fr.flag(STHIP_eSampleBSDFs)) weight = 1 - 0.5f;  // DirectLightSample::reservoir_bsdf_mis, path.hlsli:175-177
+    if (fr.bdpt()) {  // path.hlsli:458-465 (no eMIS test upstream; c.G already carries the shading-normal term)
+      const float emission_pdfA = cosine_hemisphere_pdfW(ngdotout) * (ngdotout / pow2(ray_distance));  // setup(), :219
+      const float dL = connection_dVC(W, emission_pdfA, 1 / W, false);
+      const float G_rev = prev_cos_out / len_sqr(origin - isect.sd.position);
+      const float dE = connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular);
+      weight = 1 / (1 + dE * pow2(emission_pdfA) + dL * pow2(ev.pdf_fwd * cG));
+    } else if (fr.flag(STHIP_eSampleBSDFs))
+      weight = 1 - 0.5f;  // DirectLightSample::reservoir_bsdf_mis, path.hlsli:175-177
     if (fr.flag(STHIP_eDeferShadowRays)) {
       const v3 cc = beta * contrib * weight;
       if (diffuse_vertices >= 1 && diffuse_vertices <= max_shadow) {
@@ -2837,6 +2856,61 @@ struct PathIntegrator {
           ray_distance = dist_i;
           r_target_pdf = target_pdf_i;
           lv = lv_i;
+        }
+      }
+      if (fr.flag(STHIP_eLVCReservoirReuse)) {  // path.hlsli:727-768
+        v3 t, b;
+        make_orthonormal(isect.sd.geometry_normal(), t, b);
+        const float cell_size = hashgrid_cell_size(isect.sd.position);
+        auto jittered = [&]() {
+          const float phi = rng.next_float() * 2 * DET_PI;
+          if (!fr.flag(STHIP_eHashGridJitter)) return isect.sd.position;
+          const float radius = cell_size * rng.next_float();
+          float sn, cs;
+          det_sincosf(phi, &sn, &cs);
+          return isect.sd.position + (t * cs + b * sn) * radius;
+        };
+        if (fr.prev_lvc_grid && fr.pc.gReservoirSpatialM > 0) {
+          const v3 at = jittered();
+          const uint32_t bucket = fr.prev_lvc_grid->table.find(at, cell_size);
+          if (bucket != 0xFFFFFFFFu) {
+            const uint32_t bucket_start = fr.prev_lvc_grid->table.indices[bucket], bucket_size = fr.prev_lvc_grid->table.counters[bucket];
+            uint32_t M = r.M;
+            for (uint32_t i = 0; i < fr.pc.gReservoirSpatialM; i++) {
+              const PathVertexReservoir& prev = fr.prev_lvc_grid->data[bucket_start + rng.next_uint() % bucket_size];
+              const PathVertex lv_i = prev.y;
+              if (!fits(lv_i)) continue;
+              M += prev.r.M;
+              v3 ro_i = V3(0.0f), rd_i = V3(0.0f);
+              float dist_i = 0, weight_i = 0;
+              const v3 contrib_i = connect_light_vertex(m, lv_i, weight_i, ro_i, rd_i, dist_i);
+              const float target_pdf_i = luminance(contrib_i);
+              if (r.update(rng.next_float(), target_pdf_i / lv_i.path_pdf)) {
+                contrib = contrib_i;
+                weight = weight_i;
+                ray_origin = ro_i;
+                ray_direction = rd_i;
+                ray_distance = dist_i;
+                r_target_pdf = target_pdf_i;
+                lv = lv_i;
+              }
+            }
+            r.M = M;
+          }
+        }
+        const float W = r.W(r_target_pdf);
+        const v3 at = jittered();
+        r.M = std::min(r.M, fr.pc.gReservoirMaxM);
+        const size_t k = (size_t)path_index() * fr.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
+        if (fr.lvc_appends && diffuse_vertices >= 1 && diffuse_vertices <= fr.pc.gMaxDiffuseVertices) {
+          HashGridOf<PathVertexReservoir>::Append& a = fr.lvc_appends[k];
+          a.pos = at;
+          a.cell_size = cell_size;
+          a.y.r = r;
+          a.y.packed_geometry_normal = isect.sd.packed_geometry_normal;
+          a.y.W = W;
+          a.y.y = lv;
+          fr.lvc_append_valid[k] = 1;
         }
       }
       contrib = contrib * r.W(r_target_pdf);
@@ -3397,7 +3471,7 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (scene_flags & STHIP_BDPT_FLAG_TRACE_LIGHT) return STHIP_ERR_UNSUPPORTED;
 
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
-  const uint32_t unsupported = (1u << STHIP_eLVCReservoirReuse) | (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
+  const uint32_t unsupported = (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
   if (sampling_flags & unsupported) return STHIP_ERR_UNSUPPORTED;
   Frame fr;
   fr.sc = sc;
@@ -3417,7 +3491,8 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (fr.flag(STHIP_eNEEReservoirReuse) && has_environment(fr)) return STHIP_ERR_UNSUPPORTED;  // a stored environment sample is re-read as a surface point upstream (sample_Le leaves pdfA positive)
   if (!has_emissives(fr) && !has_environment(fr)) fr.sampling_flags &= ~((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths));  // BDPT.cpp:504-509
   if (!fr.flag(STHIP_eLVC)) fr.sampling_flags &= ~((1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse));  // BDPT.cpp:517-520
-  if (!fr.flag(STHIP_eConnectToLightPaths)) fr.sampling_flags &= ~((1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs));  // the cache is only read by connect_lvc
+  if (!fr.flag(STHIP_eConnectToLightPaths)) fr.sampling_flags &= ~((1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse));  // the cache is only read by connect_lvc
+  if (!fr.flag(STHIP_eLVCReservoirs)) fr.sampling_flags &= ~(1u << STHIP_eLVCReservoirReuse);  // the reuse sits inside the reservoir branch of connect_lvc
   if (!fr.flag(STHIP_eNEE) && !fr.flag(STHIP_eLVC)) fr.sampling_flags &= ~(1u << STHIP_eDeferShadowRays);  // BDPT.cpp:522-523
   if (has_media(fr)) {
     // with media every visibility ray draws random numbers: inline ones (NEE without eDeferShadowRays, the connections of
@@ -3466,7 +3541,7 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   std::vector<std::vector<PathVertex>> light_vertices;
   std::vector<uint32_t> lvc_counts(seed_count, 0);
   if (fr.bdpt()) {
-    if (has_environment(fr) || fr.flag(STHIP_eNEEReservoirs)) return STHIP_ERR_UNSUPPORTED;  // env light paths start from an unset position upstream
+    if (has_environment(fr)) return STHIP_ERR_UNSUPPORTED;  // env light paths start from an unset position upstream
     if (!frame->gInverseViewTransforms) return STHIP_ERR_INVALID_ARGUMENT;
     if ((uint64_t)seed_count * W * H > (1ull << 26)) return STHIP_ERR_INVALID_ARGUMENT;
     // without eRemapThreads the padding columns of sample_photons alias the next row's vertex slots (a write race upstream)
@@ -3537,7 +3612,7 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
     }
     return true;
   };
-  if (fr.flag(STHIP_eNEEReservoirReuse)) {
+  if (fr.flag(STHIP_eNEEReservoirReuse) || fr.flag(STHIP_eLVCReservoirReuse)) {
     // Reservoir reuse couples the seeds of a call: seed s looks into the hash grid that seed s - 1 built (the reference's
     // frame and previous frame; the first seed of a call has no previous frame: gReservoirSpatialM = 0, BDPT.cpp:482-483).
     // So the frame is rendered seed by seed, and after each seed its appends — staged per (path, vertex) — are put into
@@ -3546,25 +3621,46 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
     if (fr.pc.gHashGridBucketCount == 0 || fr.pc.gHashGridBucketCount > (1u << 28) || !(fr.pc.gHashGridMinBucketRadius > 0)) return STHIP_ERR_INVALID_ARGUMENT;
     const size_t path_slots = (size_t)((W + 7) / 8) * ((H + 3) / 4) * 32;  // covers both map_pixel_coord forms (bdpt_util.hlsli:76-83)
     const uint32_t D = std::max(1u, fr.pc.gMaxDiffuseVertices);
-    std::vector<HashGridOf<NEEReservoir>::Append> staged(path_slots * D);
-    std::vector<uint8_t> valid(path_slots * D);
+    const bool nee_reuse = fr.flag(STHIP_eNEEReservoirReuse), lvc_reuse = fr.flag(STHIP_eLVCReservoirReuse);
+    std::vector<HashGridOf<NEEReservoir>::Append> staged(nee_reuse ? path_slots * D : 0);
+    std::vector<HashGridOf<PathVertexReservoir>::Append> staged_lvc(lvc_reuse ? path_slots * D : 0);
+    std::vector<uint8_t> valid(staged.size()), valid_lvc(staged_lvc.size());
     HashGridOf<NEEReservoir> grids[2];
+    HashGridOf<PathVertexReservoir> grids_lvc[2];
     const HashGridOf<NEEReservoir>* prev = nullptr;
+    const HashGridOf<PathVertexReservoir>* prev_lvc = nullptr;
     std::vector<float> accs((size_t)W * H * 4, 0.0f);
     for (uint32_t s = 0; s < seed_count; s++) {
       std::fill(valid.begin(), valid.end(), 0);
+      std::fill(valid_lvc.begin(), valid_lvc.end(), 0);
       Frame base = fr;
-      base.prev_nee_grid = prev;
-      base.nee_appends = staged.data();
-      base.nee_append_valid = valid.data();
+      if (nee_reuse) {
+        base.prev_nee_grid = prev;
+        base.nee_appends = staged.data();
+        base.nee_append_valid = valid.data();
+      }
+      if (lvc_reuse) {
+        base.prev_lvc_grid = prev_lvc;
+        base.lvc_appends = staged_lvc.data();
+        base.lvc_append_valid = valid_lvc.data();
+      }
       parallel_rows(H, threads, [&](uint32_t y, int tid) {
         for (uint32_t x = 0; x < W; x++) sample_pixel(base, x, y, s, &accs[4 * ((size_t)y * W + x)], tid);
       });
-      std::vector<HashGridOf<NEEReservoir>::Append> appends;
-      for (size_t k = 0; k < staged.size(); k++)
-        if (valid[k]) appends.push_back(staged[k]);
-      grids[s & 1].build(fr.pc.gHashGridBucketCount, appends);
-      prev = &grids[s & 1];
+      if (nee_reuse) {
+        std::vector<HashGridOf<NEEReservoir>::Append> appends;
+        for (size_t k = 0; k < staged.size(); k++)
+          if (valid[k]) appends.push_back(staged[k]);
+        grids[s & 1].build(fr.pc.gHashGridBucketCount, appends);
+        prev = &grids[s & 1];
+      }
+      if (lvc_reuse) {
+        std::vector<HashGridOf<PathVertexReservoir>::Append> appends;
+        for (size_t k = 0; k < staged_lvc.size(); k++)
+          if (valid_lvc[k]) appends.push_back(staged_lvc[k]);
+        grids_lvc[s & 1].build(fr.pc.gHashGridBucketCount, appends);
+        prev_lvc = &grids_lvc[s & 1];
+      }
     }
     memcpy(out->gRadiance, accs.data(), accs.size() * 4);
   } else

@@ -22,7 +22,7 @@
 
 namespace sthip {
 hipError_t lvc_compact(const float4* staging, uint32_t slots_per_seed, uint32_t seeds, uint32_t vertices_per_seed, float4* cache, uint32_t* counts, uint32_t* flags, uint32_t* offsets,
-                       void* tmp, size_t& tmp_bytes, hipStream_t stream);  // lvc.hip
+                       void* tmp, size_t& tmp_bytes, hipStream_t stream, uint32_t rec = 4, uint32_t flag_at = 2);  // lvc.hip
 }
 
 namespace {
@@ -113,6 +113,8 @@ struct sthip_ctx {
   DevBuf<uint32_t> hg_count, hg_flags, hg_offsets, hg_dest, hg_checksums, hg_counters, hg_indices;
   DevBuf<uint2> hg_keys;
   DevBuf<uint8_t> hg_tmp;
+  DevBuf<float4> lg_appends, lg_compact, lg_data;  // eLVCReservoirReuse: the same for gLVCHashGrid (keys / flags / tmp are shared)
+  DevBuf<uint32_t> lg_checksums, lg_counters, lg_indices;
   DevBuf<uint32_t> light_trace; // gLightTraceSamples
   DevBuf<DeviceImage1> images1;  // gImage1s (alpha masks)
   DevBuf<float> image1_texels;
@@ -790,6 +792,59 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
   return refresh_treetop(ctx);
 }
 
+// One hash grid from one seed's staged appends (hashgrid.h): compact the stage in (path, vertex) order, hash the keys on
+// the device, probe them on the host in that order exactly as find_or_insert does (hashgrid.hlsli:43-58 run serially),
+// prefix the bucket counters (compute_indices, :72-79) and scatter the records into their bucket ranges (swizzle, :81-88).
+static int build_hash_grid(sthip_ctx* ctx, hipStream_t st, const float4* appends, float4* compact, float4* data, size_t slots, uint32_t rec, uint32_t flag_at, bool lvc_records,
+                           uint32_t bucket_count, DevBuf<uint32_t>& d_checksums, DevBuf<uint32_t>& d_counters, DevBuf<uint32_t>& d_indices) {
+  const uint32_t buckets = bucket_count + 32u;  // probing does not wrap
+  size_t tmp_bytes = ctx->hg_tmp.n;
+  HIP_TRY(ctx, sthip::lvc_compact(appends, (uint32_t)slots, 1, (uint32_t)slots, compact, ctx->hg_count.p, ctx->hg_flags.p, ctx->hg_offsets.p, ctx->hg_tmp.p, tmp_bytes, st, rec, flag_at));
+  const unsigned kgrid = (unsigned)((slots + STHIP_BLOCK - 1) / STHIP_BLOCK);
+  if (lvc_records)
+    hipLaunchKernelGGL(k_hg_keys_lvc, dim3(kgrid), dim3(STHIP_BLOCK), 0, st, compact, ctx->hg_count.p, bucket_count, ctx->hg_keys.p);
+  else
+    hipLaunchKernelGGL(k_hg_keys, dim3(kgrid), dim3(STHIP_BLOCK), 0, st, compact, ctx->hg_count.p, bucket_count, ctx->hg_keys.p);
+  uint32_t n_app = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&n_app, ctx->hg_count.p, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  std::vector<uint2> keys(n_app);
+  if (n_app) HIP_TRY(ctx, hipMemcpy(keys.data(), ctx->hg_keys.p, (size_t)n_app * 8, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> checksums(buckets, 0u), counters(buckets, 0u), indices(buckets, 0u), dest(std::max<size_t>(1, n_app), 0xFFFFFFFFu), bucket_of(n_app), rank_of(n_app);
+  for (uint32_t k = 0; k < n_app; k++) {
+    uint32_t b = keys[k].x, found = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < 32; i++, b++) {
+      if (checksums[b] == 0) checksums[b] = keys[k].y;
+      if (checksums[b] == keys[k].y) {
+        found = b;
+        break;
+      }
+    }
+    bucket_of[k] = found;
+    if (found != 0xFFFFFFFFu) rank_of[k] = counters[found]++;
+  }
+  uint32_t running = 0;
+  for (uint32_t b = 0; b < buckets; b++) {
+    indices[b] = running;
+    running += counters[b];
+  }
+  for (uint32_t k = 0; k < n_app; k++)
+    if (bucket_of[k] != 0xFFFFFFFFu) dest[k] = indices[bucket_of[k]] + rank_of[k];
+  HIP_TRY(ctx, hipMemcpyAsync(d_checksums.p, checksums.data(), (size_t)buckets * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_counters.p, counters.data(), (size_t)buckets * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_indices.p, indices.data(), (size_t)buckets * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->hg_dest.p, dest.data(), dest.size() * 4, hipMemcpyHostToDevice, st));
+  if (n_app) {
+    const unsigned sgrid = (n_app + STHIP_BLOCK - 1) / STHIP_BLOCK;
+    if (lvc_records)
+      hipLaunchKernelGGL(k_hg_scatter_lvc, dim3(sgrid), dim3(STHIP_BLOCK), 0, st, compact, n_app, ctx->hg_dest.p, data);
+    else
+      hipLaunchKernelGGL(k_hg_scatter, dim3(sgrid), dim3(STHIP_BLOCK), 0, st, compact, n_app, ctx->hg_dest.p, data);
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(st));  // the host vectors above are the source of the copies
+  return STHIP_OK;
+}
+
 int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin,
                  uint32_t seed_count, const sthip_outputs* out) {
   if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
@@ -801,7 +856,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: depth / prev-uv outputs need gInverseViewTransforms");
   // BDPT_FLAG_TRACE_LIGHT is a per-kernel specialisation of the reference (sample_photons), never a caller's choice
   if (scene_flags & STHIP_BDPT_FLAG_TRACE_LIGHT) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: BDPT_FLAG_TRACE_LIGHT is not a scene flag a caller sets");
-  const uint32_t unsupported = (1u << STHIP_eLVCReservoirReuse) | (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
+  const uint32_t unsupported = (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
   if (sampling_flags & unsupported) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: a sampling flag outside the built hot path is set");
   if (pc->gMaxPathVertices > 60 || pc->gMaxDiffuseVertices > 60) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: path length limits above 60");
   if (pc->gLightCount > ctx->light_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: gLightCount exceeds the uploaded light list");
@@ -818,7 +873,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (!(sampling_flags & (1u << STHIP_eNEE))) sampling_flags &= ~((1u << STHIP_ePresampleLights) | (1u << STHIP_eNEEReservoirs) | (1u << STHIP_eNEEReservoirReuse));
   if (!(sampling_flags & (1u << STHIP_eNEEReservoirs))) sampling_flags &= ~(1u << STHIP_eNEEReservoirReuse);  // only connect_light_reservoir touches the grid
   if (!(sampling_flags & (1u << STHIP_eLVC))) sampling_flags &= ~((1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse));  // BDPT.cpp:517-520
-  if (!(sampling_flags & (1u << STHIP_eConnectToLightPaths))) sampling_flags &= ~((1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs));  // only connect_lvc reads the cache
+  if (!(sampling_flags & (1u << STHIP_eConnectToLightPaths))) sampling_flags &= ~((1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse));  // only connect_lvc reads the cache
+  if (!(sampling_flags & (1u << STHIP_eLVCReservoirs))) sampling_flags &= ~(1u << STHIP_eLVCReservoirReuse);  // the reuse sits inside connect_lvc's reservoir branch
   if (!(sampling_flags & ((1u << STHIP_eNEE) | (1u << STHIP_eLVC)))) sampling_flags &= ~(1u << STHIP_eDeferShadowRays);  // BDPT.cpp:522-523
   pc = &pcn;
   if (has_env) {  // the Environment record (environment.h:17-22): ImageValue3, then 4 offsets into gDistributions when an image is bound
@@ -872,7 +928,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   // Reservoir reuse couples the seeds of a call: seed s looks into the hash grid seed s - 1 built (the reference's frame
   // and previous frame), so they are traced one at a time and the grid is built between them.
   const bool nee_reuse = (sampling_flags & (1u << STHIP_eNEEReservoirReuse)) != 0;
-  const uint32_t batch = nee_reuse ? 1u : std::min(seed_count, max_in_flight);
+  const bool lvc_reuse = (sampling_flags & (1u << STHIP_eLVCReservoirReuse)) != 0;
+  const uint32_t batch = (nee_reuse || lvc_reuse) ? 1u : std::min(seed_count, max_in_flight);
   p.path_count = batch * p.paths_per_seed;
   // light tracing (eConnectToViews, BDPT.cpp:653-667): sample_photons' padded dispatch, dispatch_over(W, ceil(gLightPathCount / W))
   const bool connect_views = (sampling_flags & (1u << STHIP_eConnectToViews)) != 0;
@@ -881,7 +938,6 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   const bool light_tracing = bdpt && pc->gMaxPathVertices > 2;
   if (bdpt) {
     if (has_env) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: light subpaths with an environment (upstream starts environment light paths from an unset position, bdpt.hlsl:109-113)");
-    if (sampling_flags & (1u << STHIP_eNEEReservoirs)) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: light subpaths together with eNEEReservoirs are not built");
     if (!frame->gInverseViewTransforms) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eConnectToViews / eConnectToLightPaths need gInverseViewTransforms");
     if (connect_paths && !(sampling_flags & (1u << STHIP_eRemapThreads)) && (W & 7u))
       return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eConnectToLightPaths without eRemapThreads needs a width that is a multiple of 8 (upstream's padding threads race on the vertex slots of the next row)");
@@ -924,17 +980,27 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   }
 
   size_t hg_slots = 0;
-  const uint32_t hg_buckets = nee_reuse ? pc->gHashGridBucketCount + 32u : 0u;  // probing does not wrap (hashgrid.h)
-  if (nee_reuse) {
+  const uint32_t hg_buckets = (nee_reuse || lvc_reuse) ? pc->gHashGridBucketCount + 32u : 0u;  // probing does not wrap (hashgrid.h)
+  if (nee_reuse || lvc_reuse) {
     if (has_env) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eNEEReservoirReuse with an environment (a stored environment sample is read back as a surface point upstream: sample_Le leaves its pdfA positive)");
     if (media) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eNEEReservoirReuse with media is not built");
     if (ctx->shard_count > 1) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eNEEReservoirReuse on a pixel-tile shard (the grid is a whole-frame structure: render replicas and reduce)");
     if (pc->gHashGridBucketCount == 0 || pc->gHashGridBucketCount > (1u << 28) || !(pc->gHashGridMinBucketRadius > 0)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eNEEReservoirReuse needs 0 < gHashGridBucketCount <= 2^28 and gHashGridMinBucketRadius > 0");
     hg_slots = (size_t)((W + 7) / 8) * ((H + 3) / 4) * 32 * std::max(1u, pc->gMaxDiffuseVertices);  // covers both map_pixel_coord forms
     if (hg_slots > 0x7FFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many hash-grid append slots");
-    HIP_TRY(ctx, ctx->hg_appends.ensure(4 * hg_slots));
-    HIP_TRY(ctx, ctx->hg_compact.ensure(4 * hg_slots));
-    HIP_TRY(ctx, ctx->hg_data.ensure(3 * hg_slots));
+    if (nee_reuse) {
+      HIP_TRY(ctx, ctx->hg_appends.ensure(4 * hg_slots));
+      HIP_TRY(ctx, ctx->hg_compact.ensure(4 * hg_slots));
+      HIP_TRY(ctx, ctx->hg_data.ensure(3 * hg_slots));
+    }
+    if (lvc_reuse) {
+      HIP_TRY(ctx, ctx->lg_appends.ensure(6 * hg_slots));
+      HIP_TRY(ctx, ctx->lg_compact.ensure(6 * hg_slots));
+      HIP_TRY(ctx, ctx->lg_data.ensure(5 * hg_slots));
+      HIP_TRY(ctx, ctx->lg_checksums.ensure(hg_buckets));
+      HIP_TRY(ctx, ctx->lg_counters.ensure(hg_buckets));
+      HIP_TRY(ctx, ctx->lg_indices.ensure(hg_buckets));
+    }
     HIP_TRY(ctx, ctx->hg_flags.ensure(hg_slots));
     HIP_TRY(ctx, ctx->hg_offsets.ensure(hg_slots));
     HIP_TRY(ctx, ctx->hg_dest.ensure(hg_slots));
@@ -1025,6 +1091,11 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.hg_data = ctx->hg_data.p;
   p.hg_prev = 0;
   p.hg_appends = nee_reuse ? ctx->hg_appends.p : nullptr;
+  p.lg_checksums = ctx->lg_checksums.p;
+  p.lg_counters = ctx->lg_counters.p;
+  p.lg_indices = ctx->lg_indices.p;
+  p.lg_data = ctx->lg_data.p;
+  p.lg_appends = lvc_reuse ? ctx->lg_appends.p : nullptr;
   p.lvc_staging = lvc ? ctx->lvc_staging.p : nullptr;
   p.lvc_count = lvc ? ctx->lvc_count.p : nullptr;
   p.path_contrib = lvc_reservoirs ? ctx->path_contrib.p : nullptr;
@@ -1314,6 +1385,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     }
 
     if (nee_reuse) HIP_TRY(ctx, hipMemsetAsync(ctx->hg_appends.p, 0, hg_slots * 64, st));
+    if (lvc_reuse) HIP_TRY(ctx, hipMemsetAsync(ctx->lg_appends.p, 0, hg_slots * 96, st));
     p.path_count = in_flight * p.paths_per_seed;
     rc = reset_queues();
     if (rc) return rc;
@@ -1357,44 +1429,16 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     if (rc) return rc;
     rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + in_flight == seed_count ? 1u : 0u, primary_rays * in_flight); });
     if (rc) return rc;
-    if (nee_reuse && s + in_flight < seed_count) {
-      // This seed's appends become the grid the next seed looks up (hashgrid.h): compact the stage in (path, vertex) order,
-      // hash the keys on the device, probe them on the host in that order exactly as find_or_insert does (hashgrid.hlsli:43-58
-      // run serially), prefix the bucket counters (compute_indices, :72-79) and scatter the records (swizzle, :81-88).
-      size_t tmp_bytes = ctx->hg_tmp.n;
-      HIP_TRY(ctx, sthip::lvc_compact(ctx->hg_appends.p, (uint32_t)hg_slots, 1, (uint32_t)hg_slots, ctx->hg_compact.p, ctx->hg_count.p, ctx->hg_flags.p, ctx->hg_offsets.p, ctx->hg_tmp.p, tmp_bytes, st));
-      hipLaunchKernelGGL(k_hg_keys, dim3((unsigned)((hg_slots + STHIP_BLOCK - 1) / STHIP_BLOCK)), dim3(STHIP_BLOCK), 0, st, ctx->hg_compact.p, ctx->hg_count.p, pc->gHashGridBucketCount, ctx->hg_keys.p);
-      uint32_t n_app = 0;
-      HIP_TRY(ctx, hipMemcpyAsync(&n_app, ctx->hg_count.p, 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(ctx, hipStreamSynchronize(st));
-      std::vector<uint2> keys(n_app);
-      if (n_app) HIP_TRY(ctx, hipMemcpy(keys.data(), ctx->hg_keys.p, (size_t)n_app * 8, hipMemcpyDeviceToHost));
-      std::vector<uint32_t> checksums(hg_buckets, 0u), counters(hg_buckets, 0u), indices(hg_buckets, 0u), dest(std::max<size_t>(1, n_app), 0xFFFFFFFFu), bucket_of(n_app), rank_of(n_app);
-      for (uint32_t k = 0; k < n_app; k++) {
-        uint32_t b = keys[k].x, found = 0xFFFFFFFFu;
-        for (uint32_t i = 0; i < 32; i++, b++) {
-          if (checksums[b] == 0) checksums[b] = keys[k].y;
-          if (checksums[b] == keys[k].y) {
-            found = b;
-            break;
-          }
-        }
-        bucket_of[k] = found;
-        if (found != 0xFFFFFFFFu) rank_of[k] = counters[found]++;
+    if ((nee_reuse || lvc_reuse) && s + in_flight < seed_count) {
+      // This seed's appends become the grids the next seed looks up (hashgrid.h)
+      if (nee_reuse) {
+        const int rc2 = build_hash_grid(ctx, st, ctx->hg_appends.p, ctx->hg_compact.p, ctx->hg_data.p, hg_slots, 4, 2, false, pc->gHashGridBucketCount, ctx->hg_checksums, ctx->hg_counters, ctx->hg_indices);
+        if (rc2) return rc2;
       }
-      uint32_t running = 0;
-      for (uint32_t b = 0; b < hg_buckets; b++) {
-        indices[b] = running;
-        running += counters[b];
+      if (lvc_reuse) {
+        const int rc2 = build_hash_grid(ctx, st, ctx->lg_appends.p, ctx->lg_compact.p, ctx->lg_data.p, hg_slots, 6, 0, true, pc->gHashGridBucketCount, ctx->lg_checksums, ctx->lg_counters, ctx->lg_indices);
+        if (rc2) return rc2;
       }
-      for (uint32_t k = 0; k < n_app; k++)
-        if (bucket_of[k] != 0xFFFFFFFFu) dest[k] = indices[bucket_of[k]] + rank_of[k];
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->hg_checksums.p, checksums.data(), (size_t)hg_buckets * 4, hipMemcpyHostToDevice, st));
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->hg_counters.p, counters.data(), (size_t)hg_buckets * 4, hipMemcpyHostToDevice, st));
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->hg_indices.p, indices.data(), (size_t)hg_buckets * 4, hipMemcpyHostToDevice, st));
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->hg_dest.p, dest.data(), dest.size() * 4, hipMemcpyHostToDevice, st));
-      if (n_app) hipLaunchKernelGGL(k_hg_scatter, dim3((n_app + STHIP_BLOCK - 1) / STHIP_BLOCK), dim3(STHIP_BLOCK), 0, st, ctx->hg_compact.p, n_app, ctx->hg_dest.p, ctx->hg_data.p);
-      HIP_TRY(ctx, hipStreamSynchronize(st));  // the host vectors above are the source of the copies
       p.hg_prev = 1;
     }
   }

@@ -90,6 +90,14 @@ struct FrameParams {
   const float4* hg_data;      // NEEReservoir (bdpt.h:157-165), 3 x float4: (r.total_weight, bits(r.M), bits(packed_geometry_normal), W) (y.position, bits(y.packed_geometry_normal)) (y.Le, y.pdfA)
   uint32_t hg_prev;
   float4* hg_appends;
+  // eLVCReservoirReuse: the same for connect_lvc's reservoirs. Stage: 6 x float4 per (path index, diffuse vertex):
+  // (position, cell_size) (r.total_weight, bits(r.M), bits(packed_geometry_normal), W) + the PathVertex; grid data:
+  // PathVertexReservoir (bdpt.h:166-174), 5 x float4: (r.total_weight, bits(r.M), bits(packed_geometry_normal), W) + the PathVertex
+  const uint32_t* lg_checksums;
+  const uint32_t* lg_counters;
+  const uint32_t* lg_indices;
+  const float4* lg_data;
+  float4* lg_appends;
   float4* conn;               // per view path gMaxDiffuseVertices - 1 pending connection contributions of the last vertex shaded
   uint32_t shadow_stride;     // entries between the segments of shadow_rays (a vertex may queue gMaxDiffuseVertices records)
   // participating media (BDPT_FLAG_HAS_MEDIA): see the MEDIA instantiation of k_shade and k_shadow_media
@@ -1659,6 +1667,12 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             float weight = 1;
             if (nothing) {
               weight = 0;
+            } else if (LT && reservoirs) {  // connect_light_reservoir's BDPT weight, path.hlsli:458-465 (no eMIS test upstream; c.G already carries the shading-normal term)
+              const float emission_pdfA = cosine_hemisphere_pdfW(ngdotout) * (ngdotout / pow2f(ray_distance));
+              const float dL = connection_dVC(ris_W, emission_pdfA, 1 / ris_W, false);
+              const float G_rev = prev_cos_out / len_sqr(origin - sd.position);
+              const float dE = connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular);
+              weight = 1 / (1 + dE * pow2f(emission_pdfA) + dL * pow2f(ev.pdf_fwd * cG));
             } else if (LT) {  // BDPT MIS, path.hlsli:341-351
               if (use_mis) {
                 const float emission_pdfA = cosine_hemisphere_pdfW(ngdotout) * (ngdotout / pow2f(ray_distance));  // setup(), :219
@@ -1814,11 +1828,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             if (flag(p, STHIP_eLVCReservoirs)) {
               float total_weight = 0, r_target_pdf = 0;  // Reservoir, reservoir.h:4-27
               uint32_t M = 0;
-              for (uint32_t ri = 0; ri < p.pc.gReservoirM; ri++) {
-                const uint32_t pick = rng.next_uint();
-                if (!n) continue;
-                const float4* lvp = cache + 4 * (size_t)(pick % n);
-                if (!vertex_fits(lvp)) continue;
+              const float4* chosen = n ? cache + 4 * (size_t)(li0 % n) : nullptr;  // `lv`: what the reuse appends (a zero vertex for an empty cache)
+              auto resample = [&](const float4* lvp) {  // one candidate of the RIS pass / of the reuse loop
                 f3 ro_i = F3s(0.0f), rd_i = F3s(0.0f);
                 float dist_i = 0, weight_i = 0;
                 const f3 contrib_i = connect_light_vertex(lvp, weight_i, ro_i, rd_i, dist_i);
@@ -1833,7 +1844,56 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
                   ray_direction = rd_i;
                   ray_distance = dist_i;
                   r_target_pdf = target_pdf_i;
+                  chosen = lvp;
                 }
+              };
+              for (uint32_t ri = 0; ri < p.pc.gReservoirM; ri++) {
+                const uint32_t pick = rng.next_uint();
+                if (!n) continue;
+                const float4* lvp = cache + 4 * (size_t)(pick % n);
+                if (!vertex_fits(lvp)) continue;
+                resample(lvp);
+              }
+              if (p.lg_appends) {  // eLVCReservoirReuse, path.hlsli:727-768
+                f3 hg_t, hg_b;
+                make_orthonormal(gn, hg_t, hg_b);
+                const Xf vt = load_xf(p.view_xf, 0);
+                const float cell_size = hashgrid_cell_size(p.pc, p.views[0], F3(vt.r0.w, vt.r1.w, vt.r2.w), sd.position);
+                auto jittered = [&]() {
+                  const float phi = rng.next_float() * 2 * DET_PI;
+                  if (!flag(p, STHIP_eHashGridJitter)) return sd.position;
+                  const float radius = cell_size * rng.next_float();
+                  float sn, cs;
+                  det_sincosf(phi, &sn, &cs);
+                  return sd.position + (hg_t * cs + hg_b * sn) * radius;
+                };
+                if (p.hg_prev && p.pc.gReservoirSpatialM > 0) {
+                  const f3 at = jittered();
+                  const uint32_t bucket = hashgrid_find(p.lg_checksums, p.pc.gHashGridBucketCount, at, cell_size);
+                  if (bucket != 0xFFFFFFFFu) {
+                    const uint32_t bucket_start = p.lg_indices[bucket], bucket_size = p.lg_counters[bucket];
+                    uint32_t Msum = M;
+                    for (uint32_t k = 0; k < p.pc.gReservoirSpatialM; k++) {
+                      const float4* pr = p.lg_data + 5 * (size_t)(bucket_start + rng.next_uint() % bucket_size);
+                      if (!vertex_fits(pr + 1)) continue;
+                      Msum += __float_as_uint(pr[0].y);
+                      resample(pr + 1);
+                    }
+                    M = Msum;
+                  }
+                }
+                const float W = (r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0.0f;
+                const f3 at = jittered();
+                M = min(M, p.pc.gReservoirMaxM);
+                uint32_t path_index;  // map_pixel_coord, bdpt_util.hlsli:76-83
+                if (flag(p, STHIP_eRemapThreads))
+                  path_index = ((py >> 2) * ((p.pc.gOutputExtent[0] + 7u) >> 3) + (px >> 3)) * 32u + (py & 3u) * 8u + (px & 7u);
+                else
+                  path_index = py * p.pc.gOutputExtent[0] + px;
+                float4* a = p.lg_appends + 6 * ((size_t)path_index * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1));
+                a[0] = make_float4(at.x, at.y, at.z, cell_size);
+                a[1] = make_float4(total_weight, __uint_as_float(M), __uint_as_float(sd.packed_geometry_normal), W);
+                for (int q = 0; q < 4; q++) a[2 + q] = chosen ? chosen[q] : make_float4(0, 0, 0, 0);
               }
               contrib = contrib * ((r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0.0f);
             } else if (n) {
@@ -2097,6 +2157,22 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter(const float4* append
   data[3 * (size_t)d] = make_float4(a0.w, a1.x, a1.y, a1.z);      // r.total_weight, bits(r.M), bits(packed_geometry_normal), W
   data[3 * (size_t)d + 1] = make_float4(a2.x, a2.y, a2.z, a3.w);  // y.position, bits(y.packed_geometry_normal)
   data[3 * (size_t)d + 2] = make_float4(a3.x, a3.y, a3.z, a1.w);  // y.Le, y.pdfA
+}
+
+__global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys_lvc(const float4* appends, const uint32_t* count, uint32_t bucket_count, uint2* keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *count) return;
+  const float4 a0 = appends[6 * (size_t)i];
+  uint32_t checksum;
+  const uint32_t home = hashgrid_bucket_index(xyz(a0), a0.w, bucket_count, checksum);
+  keys[i] = make_uint2(home, checksum);
+}
+__global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter_lvc(const float4* appends, uint32_t n, const uint32_t* dest, float4* data) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t d = dest[i];
+  if (d == 0xFFFFFFFFu) return;
+  for (int q = 0; q < 5; q++) data[5 * (size_t)d + q] = appends[6 * (size_t)i + 1 + q];
 }
 
 __global__ void k_write_ray_count(const unsigned long long* counters, unsigned long long* out) {

@@ -14,12 +14,13 @@ namespace sthip {
 namespace {
 
 // a staged PathVertex is 4 x float4; bits 16.. of its last word hold subpath_length >= 2, so that word is never zero
-__global__ void k_lvc_flags(const float4* staging, uint32_t total, uint32_t* flags) {
+// a record is `rec` float4 long; a staged one is told by the last word of its float4 number `flag_at` not being zero
+__global__ void k_lvc_flags(const float4* staging, uint32_t total, uint32_t rec, uint32_t flag_at, uint32_t* flags) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) flags[i] = __float_as_uint(staging[4 * (size_t)i + 2].w) != 0u ? 1u : 0u;
+  if (i < total) flags[i] = __float_as_uint(staging[rec * (size_t)i + flag_at].w) != 0u ? 1u : 0u;
 }
-__global__ void k_lvc_scatter(const float4* staging, const uint32_t* flags, const uint32_t* offsets, uint32_t slots_per_seed, uint32_t seeds, uint32_t vertices_per_seed, float4* cache,
-                              uint32_t* counts) {
+__global__ void k_lvc_scatter(const float4* staging, const uint32_t* flags, const uint32_t* offsets, uint32_t slots_per_seed, uint32_t seeds, uint32_t vertices_per_seed, uint32_t rec,
+                              float4* cache, uint32_t* counts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = slots_per_seed * seeds;
   if (i >= total) return;
@@ -28,12 +29,9 @@ __global__ void k_lvc_scatter(const float4* staging, const uint32_t* flags, cons
   if (flags[i]) {
     const uint32_t k = offsets[i] - base;
     if (k < vertices_per_seed) {
-      float4* dst = cache + 4 * ((size_t)seed * vertices_per_seed + k);
-      const float4* src = staging + 4 * (size_t)i;
-      dst[0] = src[0];
-      dst[1] = src[1];
-      dst[2] = src[2];
-      dst[3] = src[3];
+      float4* dst = cache + rec * ((size_t)seed * vertices_per_seed + k);
+      const float4* src = staging + rec * (size_t)i;
+      for (uint32_t q = 0; q < rec; q++) dst[q] = src[q];
     }
   }
   if (i - seed * slots_per_seed == slots_per_seed - 1) counts[seed] = offsets[i] + flags[i] - base;
@@ -41,18 +39,19 @@ __global__ void k_lvc_scatter(const float4* staging, const uint32_t* flags, cons
 
 }  // namespace
 
+// rec / flag_at: the record layout (a PathVertex or a NEE append: 4 float4, told by float4 2; an LVC append: 6, told by float4 0).
 // scratch: `flags` and `offsets` hold slots_per_seed * seeds uint32 each; `tmp` / `tmp_bytes` hipCUB's temporary storage
 // (query with tmp == nullptr). Everything is enqueued on `stream`.
 hipError_t lvc_compact(const float4* staging, uint32_t slots_per_seed, uint32_t seeds, uint32_t vertices_per_seed, float4* cache, uint32_t* counts, uint32_t* flags, uint32_t* offsets,
-                       void* tmp, size_t& tmp_bytes, hipStream_t stream) {
+                       void* tmp, size_t& tmp_bytes, hipStream_t stream, uint32_t rec, uint32_t flag_at) {
   const uint32_t total = slots_per_seed * seeds;
   if (!tmp) return hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, flags, offsets, (int)total, stream);
   if (!total) return hipSuccess;
   const uint32_t grid = (total + 255) / 256;
-  hipLaunchKernelGGL(k_lvc_flags, dim3(grid), dim3(256), 0, stream, staging, total, flags);
+  hipLaunchKernelGGL(k_lvc_flags, dim3(grid), dim3(256), 0, stream, staging, total, rec, flag_at, flags);
   hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flags, offsets, (int)total, stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_lvc_scatter, dim3(grid), dim3(256), 0, stream, staging, flags, offsets, slots_per_seed, seeds, vertices_per_seed, cache, counts);
+  hipLaunchKernelGGL(k_lvc_scatter, dim3(grid), dim3(256), 0, stream, staging, flags, offsets, slots_per_seed, seeds, vertices_per_seed, rec, cache, counts);
   return hipGetLastError();
 }
 

@@ -289,7 +289,7 @@ def test_errors_are_reported_not_ignored(renderer, cornell):
     from stratum_amd.bdpt import BDPT
 
     sc, cam = cornell
-    r = BDPT(device=0, args={"bdptFlag": ["lightvertexcache"]})
+    r = BDPT(device=0, args={"bdptFlag": ["samplelightpower"]})  # reads a table upstream never fills: rejected, not ignored
     try:
         r.update(sc)
         with pytest.raises(StratumHipError, match="outside the built hot path"):
@@ -472,12 +472,10 @@ def test_environment_errors(renderer):
     sc, cam = scenes.environment_scene(image=True, emitter=False)
     renderer.update(sc)
     frame = camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"])
-    renderer.set_flag("lvcreservoirs")
-    renderer.set_flag("lightvertexcache")
+    renderer.set_flag("coherentsampling")  # wave-scope sampling (path.hlsli:313-318): rejected, never ignored
     with pytest.raises(_lib.StratumHipError, match="sampling flag"):
         renderer.render(frame)
-    renderer.set_flag("~lightvertexcache")
-    renderer.set_flag("~lvcreservoirs")
+    renderer.set_flag("~coherentsampling")
     sc.distributions = sc.distributions[:-5]  # a table that runs past gDistributions
     renderer.update(sc)
     with pytest.raises(_lib.StratumHipError, match="gDistributions"):
@@ -687,6 +685,22 @@ def test_light_vertex_cache(flags, args):
     sc, cam = scenes.cornell_box()
     a = dict(args, maxDiffuseVertices=3, maxPathVertices=6)
     _compare_frame(sc, cam, flags, w=100, h=76, seeds=2, args=a)
+
+
+@pytest.mark.parametrize(
+    "flags,args",
+    [
+        (["connecttolightpaths", "lightvertexcache", "lvcreservoirs", "lvcreservoirreuse"], {"lightPathCount": 5000, "reservoirM": 4}),
+        (["connecttolightpaths", "lightvertexcache", "lvcreservoirs", "lvcreservoirreuse", "jitterhashgridlookups", "~defershadowrays"], {"lightPathCount": 3000, "reservoirM": 2, "reservoirSpatialM": 3}),
+        (["connecttolightpaths", "lightvertexcache", "lvcreservoirs", "lvcreservoirreuse", "neereservoirs", "neereservoirreuse"], {"lightPathCount": 4000, "reservoirM": 2, "hashGridBucketCount": 60}),
+        (["connecttolightpaths", "connecttoviews", "neereservoirs", "~defershadowrays"], {"reservoirM": 3}),  # connect_light_reservoir's BDPT weight (path.hlsli:458-465)
+    ],
+)
+def test_lvc_reservoir_reuse(flags, args):
+    """eLVCReservoirReuse: connect_lvc's reservoirs go through a hash grid of their own (path.hlsli:727-768), alone and
+    together with the NEE grid; four seeds, so three of them read a previous grid."""
+    sc, cam = scenes.cornell_box()
+    _compare_frame(sc, cam, flags, w=100, h=76, seeds=4, args=dict(args, maxDiffuseVertices=3, maxPathVertices=6))
 
 
 def test_light_vertex_cache_textured_and_limits(renderer):
