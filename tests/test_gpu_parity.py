@@ -1010,6 +1010,40 @@ def test_estimators_converge_to_the_same_image(renderer):
         assert np.sqrt(((img - ref) ** 2).sum() / (ref**2).sum()) < (0.08 if "BSDF sampling only" in name else 0.03), name
 
 
+def test_cache_and_reuse_estimators_stay_close_to_path_tracing(renderer):
+    """The estimators whose upstream result depends on scheduling (light vertex cache, reservoir reuse through the hash
+    grids) are defined here by an order (paths by index); what must hold whatever the order is that they estimate the same
+    image. 1024 samples per pixel on the Cornell box against the default path tracer: mean radiance within 3 % (upstream's
+    weights for NEE + connections do not sum to one, and reuse without visibility tests is slightly biased: restated, not
+    fixed; 10 % for the cache's reservoir reuse, see below), image within 6 % rel-L2."""
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = scenes.cornell_box()
+    frame = camera.Frame(64, 48, cam["fovy"], cam["eye"], cam["target"])
+    images = {}
+    for name, flags, args in (
+        ("path tracing, NEE + MIS", [], {}),
+        ("NEE reservoirs with reuse", ["neereservoirs", "neereservoirreuse"], {"reservoirM": 4}),
+        ("light vertex cache", ["connecttolightpaths", "lightvertexcache", "~defershadowrays"], {"lightPathCount": 64 * 48}),
+        ("light vertex cache, reservoirs with reuse", ["connecttolightpaths", "lightvertexcache", "lvcreservoirs", "lvcreservoirreuse", "~defershadowrays"], {"lightPathCount": 64 * 48, "reservoirM": 4}),
+    ):
+        r = BDPT(device=0, args=dict(args, bdptFlag=flags, maxDiffuseVertices=3))
+        try:
+            r.update(sc)
+            images[name] = r.render(frame, 0, 1024, aovs=False)["radiance"][..., :3].astype(np.float64)
+        finally:
+            r.close()
+    ref = images["path tracing, NEE + MIS"]
+    for name, img in images.items():
+        print("%-45s mean ratio %.4f rel-L2 %.4f" % (name, img.mean() / ref.mean(), np.sqrt(((img - ref) ** 2).sum() / (ref**2).sum())))
+        assert np.isfinite(img).all()
+        # connect_lvc's reuse loop weights a vertex taken from a neighbour's reservoir as if it were a fresh uniform pick
+        # (target / path_pdf, path.hlsli:748, where the NEE loop has target * W * M, :418): biased upstream, restated here
+        tol = 0.10 if "reservoirs with reuse" in name and "cache" in name else 0.03
+        assert abs(img.mean() / ref.mean() - 1) < tol, (name, img.mean() / ref.mean())
+        assert np.sqrt(((img - ref) ** 2).sum() / (ref**2).sum()) < 0.06, name
+
+
 def test_treetop_and_packed_nodes_do_not_change_results(atrium_scene):
     """The LDS treetop (bvh_build.h) and the 48-byte packed nodes (bvh.h) only change where a node is read from and how
     wide its box is (conservatively): frames with and without the treetop are bit-identical, on the merged world mesh +
