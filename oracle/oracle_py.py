@@ -250,6 +250,35 @@ def disney_eval(material_record, dir_in, dir_out):
     return out
 
 
+def disney_eval_adjoint(material_record, dir_in, dir_out, adjoint):
+    rec = np.ascontiguousarray(material_record, wire.MaterialRecord).reshape(1)
+    di, do = np.ascontiguousarray(dir_in, np.float32), np.ascontiguousarray(dir_out, np.float32)
+    out = np.zeros((di.shape[0], 5), np.float32)
+    lib().orc_disney_eval_adjoint(wire.ptr(rec), wire.ptr(di), wire.ptr(do), wire.ptr(out), C.c_uint32(di.shape[0]), C.c_uint32(1 if adjoint else 0))
+    return out
+
+
+def shading_normal_correction(rows5, shadow_fix=False, adjoint=False):
+    q = np.ascontiguousarray(rows5, np.float32).reshape(-1, 5)
+    out = np.zeros(q.shape[0], np.float32)
+    lib().orc_shading_normal_correction(wire.ptr(q), wire.ptr(out), C.c_uint32(q.shape[0]), C.c_uint32(1 if shadow_fix else 0), C.c_uint32(1 if adjoint else 0))
+    return out
+
+
+def connection_dvc(rows3, specular=False):
+    q = np.ascontiguousarray(rows3, np.float32).reshape(-1, 3)
+    out = np.zeros(q.shape[0], np.float32)
+    lib().orc_connection_dvc(wire.ptr(q), wire.ptr(out), C.c_uint32(q.shape[0]), C.c_uint32(1 if specular else 0))
+    return out
+
+
+def mis(rows2):
+    q = np.ascontiguousarray(rows2, np.float32).reshape(-1, 2)
+    out = np.zeros(q.shape[0], np.float32)
+    lib().orc_mis(wire.ptr(q), wire.ptr(out), C.c_uint32(q.shape[0]))
+    return out
+
+
 def disney_sample(material_record, dir_in, rnd):
     rec = np.ascontiguousarray(material_record, wire.MaterialRecord).reshape(1)
     di, r = np.ascontiguousarray(dir_in, np.float32), np.ascontiguousarray(rnd, np.float32)

@@ -3834,6 +3834,35 @@ void orc_disney_eval(const sthip_MaterialRecord* rec, const float* dir_in, const
     out5[5 * i + 4] = r.pdf_rev;
   }
 }
+// the same with the adjoint flag (light subpaths, connections)
+void orc_disney_eval_adjoint(const sthip_MaterialRecord* rec, const float* dir_in, const float* dir_out, float* out5, uint32_t n, uint32_t adjoint) {
+  DisneyMaterial m;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) m.data[i][j] = rec->values[i].value[j];
+  for (uint32_t i = 0; i < n; i++) {
+    MaterialEvalRecord r;
+    m.eval(r, V3(dir_in[3 * i], dir_in[3 * i + 1], dir_in[3 * i + 2]), V3(dir_out[3 * i], dir_out[3 * i + 1], dir_out[3 * i + 2]), adjoint != 0);
+    out5[5 * i] = r.f.x;
+    out5[5 * i + 1] = r.f.y;
+    out5[5 * i + 2] = r.f.z;
+    out5[5 * i + 3] = r.pdf_fwd;
+    out5[5 * i + 4] = r.pdf_rev;
+  }
+}
+// the scalar helpers of the integrator, for tests: in5 = (ndotin, ndotout, ngdotin, ngdotout, ngdotns) per row
+void orc_shading_normal_correction(const float* in5, float* out, uint32_t n, uint32_t shadow_fix, uint32_t adjoint) {
+  for (uint32_t i = 0; i < n; i++) out[i] = shading_normal_correction(in5[5 * i], in5[5 * i + 1], in5[5 * i + 2], in5[5 * i + 3], in5[5 * i + 4], shadow_fix != 0, adjoint != 0);
+}
+// in3 = (dVC, pdfA_rev, prev_pdfA_fwd) per row -> connection_dVC (path.hlsli:31-38); in2 = (a, b) -> mis(a, b) (:11-15)
+void orc_connection_dvc(const float* in3, float* out, uint32_t n, uint32_t specular) {
+  for (uint32_t i = 0; i < n; i++) out[i] = connection_dVC(in3[3 * i], in3[3 * i + 1], in3[3 * i + 2], specular != 0);
+}
+void orc_mis(const float* in2, float* out, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) {
+    const float a2 = pow2(in2[2 * i]), b2 = pow2(in2[2 * i + 1]);
+    out[i] = a2 / (a2 + b2);
+  }
+}
 // material + dir_in + rnd(3) -> dir_out(3), pdf_fwd, pdf_rev, eta, roughness, f(3), beta(3) (beta starts at 1)
 void orc_disney_sample(const sthip_MaterialRecord* rec, const float* dir_in, const float* rnd, float* out13, uint32_t n) {
   DisneyMaterial m;
