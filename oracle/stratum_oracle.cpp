@@ -41,6 +41,7 @@
 #include <math.h>
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <thread>
 #include <vector>
 #include <map>
@@ -2284,12 +2285,42 @@ struct PathIntegrator {
   }
 
   // path.hlsli:829-845, non-coherent form (eCoherentRR is wave-scope and implementation-defined)
+  // eCoherentRR (the reference's default, BDPT.cpp:58): p = WaveActiveMax(p), the decision is the first lane's
+  // (path.hlsli:831,836) — over the lanes of the 8x4 workgroup that execute this call in this iteration of the
+  // vertex loop (a wave of 32 on the hardware the reference targets; all live lanes of a group are at the same
+  // path_length). The group's (p_max, decision) per path length come from the driver (orc_render_window), which finds
+  // them by replaying the group's paths: a call that finds no decision for its path length records this lane's p and the
+  // random number it would draw, and ends the path. With media the non-coherent form stays (walks through volumes break
+  // the lockstep).
+  struct GroupRR {
+    bool valid = false;
+    float p_max = 0;
+    bool kill = false;
+  };
+  const GroupRR* group_rr = nullptr;  // indexed by path_length (null: not run as part of a group -> the non-coherent form)
+  int rr_missing_length = -1;         // the path length at which this path needed a group decision that is not known yet
+  float rr_missing_p = 0, rr_missing_rnd = 0;
   bool russian_roulette() {
-    const float p = luminance(beta) / eta_scale * 0.95f;
+    float p = luminance(beta) / eta_scale * 0.95f;
+    const bool coherent = fr.flag(STHIP_eCoherentRR) && !has_media(fr) && group_rr;
+    bool kill = false;
+    if (coherent) {
+      if (!group_rr[path_length].valid) {  // replay protocol: report and stop; the driver works the decision out and runs the group again
+        rr_missing_length = (int)path_length;
+        rr_missing_p = p;
+        Rng peek = rng;
+        rr_missing_rnd = peek.next_float();
+        beta = V3(0.0f);
+        return false;
+      }
+      p = group_rr[path_length].p_max;  // >= this lane's own p
+      kill = group_rr[path_length].kill;
+    }
     if (p >= 1) return true;
-    const bool v = rng.next_float() > p;
-    if (v) return false;
+    const bool v = rng.next_float() > p;  // every lane draws; with eCoherentRR only the first lane's comparison counts
+    if (coherent ? kill : v) return false;
     beta = beta / p;
+    path_pdf *= p;  // path.hlsli:842
     return true;
   }
 
@@ -3089,10 +3120,17 @@ inline v3 primary_dir(const sthip_ViewData& view, const sthip_TransformData& t, 
 
 // bdpt.hlsl:149-300 (sample_visibility) + :302-326 (trace_shadows) for one pixel and one seed.
 // Returns gRadiance[px] (rgb; alpha is 1) and, when aov != NULL, the AOVs of :222-296.
-bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float out_rgb[3], PixelAOV* aov, uint64_t stats[4]) {
+// rr: the group decisions of eCoherentRR (in) and what this pixel's path found missing (out); null = not part of a group
+struct RRControl {
+  const PathIntegrator::GroupRR* decisions = nullptr;
+  int missing_length = -1;
+  float missing_p = 0, missing_rnd = 0;
+};
+bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float out_rgb[3], PixelAOV* aov, uint64_t stats[4], RRControl* rr = nullptr) {
   const int view_index = get_view_index(fr, x, y);
   if (view_index < 0) return false;
   PathIntegrator path(fr, x, y, seed);
+  if (rr) path.group_rr = rr->decisions;
   out_rgb[0] = out_rgb[1] = out_rgb[2] = 0;
   if (fr.pc.gMaxPathVertices < 2) return true;
   const sthip_ViewData& view = fr.fd.gViews[view_index];
@@ -3220,6 +3258,11 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
   stats[1] += path.rays_path;
   stats[2] += path.counters[0];
   stats[3] += path.counters[1];
+  if (rr) {
+    rr->missing_length = path.rr_missing_length;
+    rr->missing_p = path.rr_missing_p;
+    rr->missing_rnd = path.rr_missing_rnd;
+  }
   return true;
 }
 
@@ -3580,12 +3623,7 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (window && fr.bdpt()) return STHIP_ERR_UNSUPPORTED;  // light subpaths are a whole-frame pass
   // one sample of one pixel folded into that pixel's running mean (temporal_accumulation.hlsl:102-131: NaN/Inf samples
   // are dropped); returns false for a pixel outside every view
-  auto sample_pixel = [&](const Frame& base, uint32_t x, uint32_t y, uint32_t s, float acc[4], int tid) -> bool {
-    const size_t p = (size_t)y * W + x;
-    float rgb[3];
-    PixelAOV aov;
-    memset(&aov, 0, sizeof(aov));  // fields a first vertex inside a medium leaves unwritten (albedo) read as zero
-    const bool want_aov = (s == 0) && (out->gAlbedo || out->gVisibility || out->gDepth || out->gPrevUVs);
+  auto seed_frame = [&](const Frame& base, uint32_t s) {
     Frame sf = base;
     if (fr.flag(STHIP_eConnectToViews)) sf.light_trace = light_images[s].data();
     if (fr.flag(STHIP_eConnectToLightPaths)) {
@@ -3593,7 +3631,10 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
       sf.light_vertex_count = light_vertices[s].size();
       sf.lvc_count = lvc_counts[s];
     }
-    if (!render_pixel(sf, x, y, seed_begin + s, rgb, want_aov ? &aov : nullptr, &tstats[(size_t)tid * 4])) return false;
+    return sf;
+  };
+  auto fold = [&](uint32_t x, uint32_t y, uint32_t s, float acc[4], const float rgb[3], const PixelAOV& aov) {
+    const size_t p = (size_t)y * W + x;
     float cur[4] = {rgb[0], rgb[1], rgb[2], 1};
     if (std::isinf(cur[0]) || std::isinf(cur[1]) || std::isinf(cur[2]) || cur[0] != cur[0] || cur[1] != cur[1] || cur[2] != cur[2]) cur[0] = cur[1] = cur[2] = cur[3] = 0;
     if (acc[3] > 0) {
@@ -3604,13 +3645,73 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
     } else {
       for (int c = 0; c < 4; c++) acc[c] = cur[c];
     }
-    if (want_aov) {
+    if (s == 0) {
       if (out->gAlbedo) memcpy(out->gAlbedo + 4 * p, aov.albedo, 16);
       if (out->gVisibility) out->gVisibility[p] = aov.vis;
       if (out->gDepth) out->gDepth[p] = aov.depth;
       if (out->gPrevUVs) memcpy(out->gPrevUVs + 2 * p, aov.prev_uv, 8);
     }
+  };
+  const bool want_aovs = out->gAlbedo || out->gVisibility || out->gDepth || out->gPrevUVs;
+  auto sample_pixel = [&](const Frame& base, uint32_t x, uint32_t y, uint32_t s, float acc[4], int tid) -> bool {
+    float rgb[3];
+    PixelAOV aov;
+    memset(&aov, 0, sizeof(aov));  // fields a first vertex inside a medium leaves unwritten (albedo) read as zero
+    const Frame sf = seed_frame(base, s);
+    if (!render_pixel(sf, x, y, seed_begin + s, rgb, (s == 0 && want_aovs) ? &aov : nullptr, &tstats[(size_t)tid * 4])) return false;
+    fold(x, y, s, acc, rgb, aov);
     return true;
+  };
+  // eCoherentRR: one sample of the 32 pixels of the reference's 8x4 workgroup (gx, gy), which share their Russian-roulette
+  // decisions (PathIntegrator::russian_roulette). The group is rendered with the decisions known so far; a path that
+  // needs one more reports it and stops; the decision is worked out from the lanes that reported — p = the largest p,
+  // the verdict of the first lane (lowest y * 8 + x in the group) — and the group is rendered again. With the usual
+  // limits on diffuse scenes no path ever reaches the roulette and the first rendering is the final one. acc_of(x, y)
+  // gives a pixel's running mean (or null: the pixel takes part in the decisions but is not an output of this call).
+  const bool coherent_rr = fr.flag(STHIP_eCoherentRR) && !has_media(fr);
+  auto sample_group = [&](const Frame& base, uint32_t gx, uint32_t gy, uint32_t s, const std::function<float*(uint32_t, uint32_t)>& acc_of, int tid) {
+    PathIntegrator::GroupRR decisions[256];
+    const Frame sf = seed_frame(base, s);
+    struct Lane {
+      bool inside;
+      float rgb[3];
+      PixelAOV aov;
+      uint64_t stats[4];
+    } lanes[32];
+    for (;;) {
+      int missing = -1;
+      RRControl ctl[32];
+      for (uint32_t l = 0; l < 32; l++) {
+        const uint32_t x = gx * 8 + (l & 7), y = gy * 4 + (l >> 3);
+        lanes[l].inside = false;
+        if (x >= W || y >= H) continue;
+        memset(&lanes[l].aov, 0, sizeof(PixelAOV));
+        memset(lanes[l].stats, 0, sizeof(lanes[l].stats));
+        ctl[l].decisions = decisions;
+        lanes[l].inside = render_pixel(sf, x, y, seed_begin + s, lanes[l].rgb, (s == 0 && want_aovs) ? &lanes[l].aov : nullptr, lanes[l].stats, &ctl[l]);
+        if (lanes[l].inside && ctl[l].missing_length >= 0 && (missing < 0 || ctl[l].missing_length < missing)) missing = ctl[l].missing_length;
+      }
+      if (missing < 0) break;
+      PathIntegrator::GroupRR d;
+      d.valid = true;
+      d.p_max = -1;
+      int first = -1;
+      for (uint32_t l = 0; l < 32; l++)
+        if (lanes[l].inside && ctl[l].missing_length == missing) {
+          if (first < 0) first = (int)l;
+          d.p_max = std::max(d.p_max, ctl[l].missing_p);  // WaveActiveMax
+        }
+      d.kill = d.p_max < 1 && ctl[first].missing_rnd > d.p_max;  // WaveReadLaneFirst(rnd > p)
+      decisions[missing & 255] = d;
+    }
+    for (uint32_t l = 0; l < 32; l++) {
+      if (!lanes[l].inside) continue;
+      const uint32_t x = gx * 8 + (l & 7), y = gy * 4 + (l >> 3);
+      float* acc = acc_of(x, y);
+      if (!acc) continue;
+      for (int k = 0; k < 4; k++) tstats[(size_t)tid * 4 + k] += lanes[l].stats[k];
+      fold(x, y, s, acc, lanes[l].rgb, lanes[l].aov);
+    }
   };
   if (fr.flag(STHIP_eNEEReservoirReuse) || fr.flag(STHIP_eLVCReservoirReuse)) {
     // Reservoir reuse couples the seeds of a call: seed s looks into the hash grid that seed s - 1 built (the reference's
@@ -3644,9 +3745,14 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
         base.lvc_appends = staged_lvc.data();
         base.lvc_append_valid = valid_lvc.data();
       }
-      parallel_rows(H, threads, [&](uint32_t y, int tid) {
-        for (uint32_t x = 0; x < W; x++) sample_pixel(base, x, y, s, &accs[4 * ((size_t)y * W + x)], tid);
-      });
+      if (coherent_rr)
+        parallel_rows((H + 3) / 4, threads, [&](uint32_t gy, int tid) {
+          for (uint32_t gx = 0; gx < (W + 7) / 8; gx++) sample_group(base, gx, gy, s, [&](uint32_t x, uint32_t y) { return &accs[4 * ((size_t)y * W + x)]; }, tid);
+        });
+      else
+        parallel_rows(H, threads, [&](uint32_t y, int tid) {
+          for (uint32_t x = 0; x < W; x++) sample_pixel(base, x, y, s, &accs[4 * ((size_t)y * W + x)], tid);
+        });
       if (nee_reuse) {
         std::vector<HashGridOf<NEEReservoir>::Append> appends;
         for (size_t k = 0; k < staged.size(); k++)
@@ -3663,6 +3769,22 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
       }
     }
     memcpy(out->gRadiance, accs.data(), accs.size() * 4);
+  } else if (coherent_rr) {
+    // group by group (the groups that touch the window; their pixels outside it take part in the decisions only)
+    const uint32_t gy0 = wy0 / 4, gy1 = (wy1 + 3) / 4, gx0 = wx0 / 8, gx1 = (wx1 + 7) / 8;
+    parallel_rows(gy1 > gy0 ? gy1 - gy0 : 0u, threads, [&](uint32_t row, int tid) {
+      const uint32_t gy = gy0 + row;
+      for (uint32_t gx = gx0; gx < gx1; gx++) {
+        float accs[32][4];
+        memset(accs, 0, sizeof(accs));
+        for (uint32_t s = 0; s < seed_count; s++)
+          sample_group(fr, gx, gy, s, [&](uint32_t x, uint32_t y) -> float* { return (x >= wx0 && x < wx1 && y >= wy0 && y < wy1) ? accs[(y - gy * 4) * 8 + (x - gx * 8)] : nullptr; }, tid);
+        for (uint32_t l = 0; l < 32; l++) {
+          const uint32_t x = gx * 8 + (l & 7), y = gy * 4 + (l >> 3);
+          if (x >= wx0 && x < wx1 && y >= wy0 && y < wy1) memcpy(out->gRadiance + 4 * ((size_t)y * W + x), accs[l], 16);
+        }
+      }
+    });
   } else
   parallel_rows(wy1 > wy0 ? wy1 - wy0 : 0u, threads, [&](uint32_t row, int tid) {
     const uint32_t y = wy0 + row;

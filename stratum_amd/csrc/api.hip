@@ -105,6 +105,7 @@ struct sthip_ctx {
   DevBuf<float> distributions;  // gDistributions
   DevBuf<float4> presampled;    // gPresampledLights
   DevBuf<float4> bdpt;          // BDPT quantities per path (eConnectToViews)
+  DevBuf<float4> rr;  // eCoherentRR: probes / group verdicts of the round in flight (FrameParams::rr)
   DevBuf<float4> lvc_staging, path_contrib;  // eLVC: staged light vertices, the light paths' path_contrib (eLVCReservoirs)
   DevBuf<uint32_t> lvc_count, lvc_flags, lvc_offsets;
   DevBuf<uint8_t> lvc_tmp;
@@ -1085,6 +1086,10 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.light_trace = light_tracing && connect_views ? ctx->light_trace.p : nullptr;
   p.light_vertices = connect_paths ? ctx->light_vertices.p : nullptr;
   p.conn = connect_paths && conn_per_path ? ctx->conn.p : nullptr;
+  // eCoherentRR takes effect in rounds in which a path can reach the roulette (see run below); never with media
+  const bool coherent_rr = (sampling_flags & (1u << STHIP_eCoherentRR)) && !media;
+  if (coherent_rr) HIP_TRY(ctx, ctx->rr.ensure(P));
+  p.rr = nullptr;
   p.hg_checksums = ctx->hg_checksums.p;
   p.hg_counters = ctx->hg_counters.p;
   p.hg_indices = ctx->hg_indices.p;
@@ -1407,6 +1412,30 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       if (rc) return rc;
     }
     rc = run_rounds(false, nee || connect_paths, [&](uint32_t depth) {
+      // eCoherentRR: a vertex shaded in round `depth` has path_length depth + 2; the roulette runs for
+      // gMinPathVertices <= path_length < gMaxPathVertices at a non-specular vertex that is within the diffuse budget —
+      // without specular materials that is vertex number depth + 1 of at most gMaxDiffuseVertices. In such a round the
+      // paths first report their p (k_shade<PROBE>), the 8x4 groups agree (k_rr_reduce), then the round proper runs.
+      p.rr = nullptr;
+      if (coherent_rr && depth + 2 >= pc->gMinPathVertices && depth + 2 < pc->gMaxPathVertices && (ctx->has_specular || depth + 1 <= pc->gMaxDiffuseVertices)) {
+        p.rr = ctx->rr.p;
+        (void)hipMemsetAsync(ctx->rr.p, 0, (size_t)p.path_count * 16, st);
+        FrameParams probe = p;  // no output of the round is written by the probe
+        probe.out_albedo = nullptr;
+        probe.out_visibility = nullptr;
+        probe.out_depth = nullptr;
+        probe.out_prev_uv = nullptr;
+        if (bdpt) {
+          if (ctx->textured)
+            hipLaunchKernelGGL((k_shade<true, true, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, probe, depth);
+          else
+            hipLaunchKernelGGL((k_shade<false, true, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, probe, depth);
+        } else if (ctx->textured)
+          hipLaunchKernelGGL((k_shade<true, true, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, probe, depth);
+        else
+          hipLaunchKernelGGL((k_shade<false, true, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, probe, depth);
+        hipLaunchKernelGGL(k_rr_reduce, dim3((unsigned)((p.path_count + STHIP_BLOCK - 1) / STHIP_BLOCK)), dim3(STHIP_BLOCK), 0, st, p);
+      }
       if (media) {
         if (ctx->textured)
           hipLaunchKernelGGL((k_shade<true, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);

@@ -98,6 +98,15 @@ struct FrameParams {
   const uint32_t* lg_indices;
   const float4* lg_data;
   float4* lg_appends;
+  // eCoherentRR (the reference's default, BDPT.cpp:58; path.hlsli:829-845): the survival probability of a Russian
+  // roulette is WaveActiveMax(p) and the verdict WaveReadLaneFirst(rnd > p) over the lanes of the 8x4 workgroup that
+  // execute the call in that iteration of the vertex loop. The paths of a group sit in 32 consecutive slots (rows 0-3
+  // or 4-7 of a wave's 8x8 pixel block), but k_shade runs over compacted queues, so a round in which the roulette can
+  // run is cut in two: k_shade<PROBE> stores (p, the random number the path would draw, 1, 0) here for every path that
+  // reaches the call, k_rr_reduce turns each group's entries into (p_max, verdict, 1, 0), and k_shade proper reads
+  // them. Null without the flag, with media (walks through volumes break the lockstep: the non-coherent form stays)
+  // and in rounds in which no path can reach the call.
+  float4* rr;
   float4* conn;               // per view path gMaxDiffuseVertices - 1 pending connection contributions of the last vertex shaded
   uint32_t shadow_stride;     // entries between the segments of shadow_rays (a vertex may queue gMaxDiffuseVertices records)
   // participating media (BDPT_FLAG_HAS_MEDIA): see the MEDIA instantiation of k_shade and k_shadow_media
@@ -1033,7 +1042,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
 // boundary (it is queued again with its new origin and medium, no vertex), scatters inside the medium (a medium vertex:
 // phase function instead of a material), or arrives at a surface / leaves the scene as before. Only instantiated with
 // EXT and without LT.
-template <bool TEXTURED, bool EXT, bool LT = false, bool MEDIA = false>
+// PROBE: the first half of a round with eCoherentRR (see FrameParams::rr): the same code up to the Russian roulette, where a
+// path records its p and the random number it would draw, and nothing else is written.
+template <bool TEXTURED, bool EXT, bool LT = false, bool MEDIA = false, bool PROBE = false>
 __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams p, uint32_t depth) {
   // Workgroup b works on segment b % 8 (its XCD's) of the incoming queue and appends to the same segment of the
   // outgoing queues, so a segment never grows. In the first bounce a segment is a contiguous eighth of the slots
@@ -1149,7 +1160,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
     }
     f3 radiance = (!MEDIA && depth == 0) ? F3s(0.0f) : xyz(p.radiance[slot]);
     const bool connect_paths = LT && flag(p, STHIP_eConnectToLightPaths);
-    if (connect_paths && depth > 0) {
+    if (connect_paths && depth > 0 && !PROBE) {
       // connect_light_subpath's accumulate_contribution calls of the previous vertex (path.hlsli:802-822), whose
       // visibility rays k_trace has resolved by now: added here, in i order, before anything this vertex adds
       float4* cn = p.conn + (size_t)slot * (p.pc.gMaxDiffuseVertices - 1);
@@ -1481,13 +1492,28 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
         diffuse_vertices++;
         if (diffuse_vertices > p.pc.gMaxDiffuseVertices) break;
         if (path_length >= p.pc.gMinPathVertices) {
-          // russian_roulette, path.hlsli:829-845, non-coherent form
-          const float rr = luminance3(beta) / eta_scale * 0.95f;
+          // russian_roulette, path.hlsli:829-845
+          float rr = luminance3(beta) / eta_scale * 0.95f;
+          const bool coherent = !MEDIA && p.rr != nullptr;
+          bool group_kills = false;
+          if (coherent) {
+            if (PROBE) {
+              Rng peek = rng;
+              p.rr[slot] = make_float4(rr, peek.next_float(), 1.0f, 0.0f);
+              break;
+            }
+            const float4 verdict = p.rr[slot];  // the group's: (WaveActiveMax(p), WaveReadLaneFirst(rnd > p))
+            rr = verdict.x;
+            group_kills = verdict.y != 0.0f;
+          }
           if (!(rr >= 1)) {
-            if (rng.next_float() > rr) break;
+            const float rnd = rng.next_float();  // every lane draws; with eCoherentRR only the first lane's comparison counts
+            if (coherent ? group_kills : rnd > rr) break;
             beta = beta / rr;
+            path_pdf *= rr;  // path.hlsli:842
           }
         }
+        if (PROBE) break;  // a path that passes the roulette's place without reaching it has nothing to report
         if (use_nee) {
           // connect_light, path.hlsli:311-366; sample_Le :141-164; sample_point_on_light, light.hlsli:37-152
           // one light candidate: DirectLightSample's two constructors (path.hlsli:179-201) in front of setup()
@@ -1963,6 +1989,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
       new_direction = dir_out;
       alive = true;
     } while (0);
+    if (PROBE) continue;
 
     p.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
     if (alive) {
@@ -2138,6 +2165,23 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
 }
 
 // gRayCount[0] = every trace_ray call, [1] = path (closest-hit) rays; intersection.hlsli:66, path.hlsli:1006
+// eCoherentRR: the probes of a round (FrameParams::rr) -> one verdict per 8x4 group. A wave covers 64 consecutive slots = one
+// 8x8 pixel block; its lanes 0-31 (rows 0-3) and 32-63 (rows 4-7) are the two reference workgroups in it, in the
+// workgroup's own thread order (y * 8 + x).
+__global__ void __launch_bounds__(STHIP_BLOCK) k_rr_reduce(FrameParams p) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u, half = lane >> 5;
+  const float4 v = slot < p.path_count ? p.rr[slot] : make_float4(0, 0, 0, 0);
+  const bool reached = v.z != 0.0f;
+  float pm = reached ? v.x : -1.0f;
+  for (int off = 16; off > 0; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off, 64));  // WaveActiveMax over the 32 lanes of the group
+  const unsigned long long all = __ballot(reached);
+  const uint32_t mine = (uint32_t)(all >> (half * 32u));
+  const int first = mine ? (int)(half * 32u) + (__ffs((int)mine) - 1) : (int)lane;
+  const float rnd_first = __shfl(v.y, first, 64);  // WaveReadLaneFirst
+  if (slot < p.path_count) p.rr[slot] = make_float4(pm, (mine && pm < 1.0f && rnd_first > pm) ? 1.0f : 0.0f, mine ? 1.0f : 0.0f, 0.0f);
+}
+
 // ---- hash grid build (hashgrid.h): keys of the compacted appends, and the scatter into the bucket ranges ----
 __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys(const float4* appends, const uint32_t* count, uint32_t bucket_count, uint2* keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -262,6 +262,54 @@ def test_all_disney_lobes_and_long_paths(renderer):
         r.close()
 
 
+@pytest.mark.parametrize("scene_name,args", [("materials", {"maxDiffuseVertices": 8, "maxPathVertices": 10, "minPathVertices": 4}), ("cornell", {"maxDiffuseVertices": 5, "maxPathVertices": 7, "minPathVertices": 2}),
+                                             ("textured", {"maxDiffuseVertices": 4, "maxPathVertices": 8, "minPathVertices": 3, "bdptFlag": ["connecttoviews"]})])
+def test_coherent_russian_roulette(scene_name, args):
+    """eCoherentRR, the reference's default (BDPT.cpp:58): the survival probability of a Russian roulette is the maximum over
+    the 8x4 workgroup's lanes that run it in that iteration, the verdict the first lane's (path.hlsli:829-845). The
+    oracle gets there by replaying each group until every decision is known, the HIP path by a probe pass, a group
+    reduction and the round proper; both agree bit for bit in ids and ray counts, the frame differs from the per-path
+    roulette's (~coherentrr), and pixel-tile shards (whole groups per tile) reproduce the unsharded frame."""
+    from oracle import oracle_py
+    from stratum_amd import shard
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = {"materials": material_scene, "cornell": scenes.cornell_box, "textured": scenes.textured_box}[scene_name]()
+    W, H, seeds = 104, 76, 2  # not multiples of the group size: partial groups at the right and bottom edges
+    frame = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+    r = BDPT(device=0, args=args)
+    try:
+        assert (r.mSamplingFlags >> wire.FLAG_NAMES.index("eCoherentRR")) & 1  # on by default
+        r.update(sc)
+        got = r.render(frame, 0, seeds)
+        ref = oracle_py.OracleScene(sc).render(frame, r.push_constants(frame), r.mSamplingFlags, 0, seeds)
+        assert np.array_equal(got["visibility"]["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
+        assert np.array_equal(got["ray_count"], ref["ray_count"])
+        d = rel_l2(got["radiance"], ref["radiance"])
+        nd = int((got["radiance"].view(np.uint32) != ref["radiance"].view(np.uint32)).any(axis=-1).sum())
+        print("coherent RR %s: rel-L2 %.3e, differing pixels %d, rays %s" % (scene_name, d, nd, got["ray_count"]))
+        assert d <= 1e-4
+        # it is a different estimator from the per-path roulette
+        r.set_flag("~coherentrr")
+        plain = r.render(frame, 0, seeds)
+        r.set_flag("coherentrr")
+        assert not np.array_equal(plain["ray_count"], got["ray_count"])
+        # shards: tiles are whole 8x8 blocks, so a group never straddles two ranks
+        if scene_name != "textured":
+            total = np.zeros_like(got["radiance"])
+            rays = np.zeros(2, np.uint64)
+            for rank in range(3):
+                r.set_shard(rank, 3, 16, 8)
+                part = r.render(frame, 0, seeds, aovs=False)
+                assert np.all(part["radiance"][shard.owner_map(W, H, 3, 16, 8) != rank] == 0)
+                total += part["radiance"]
+                rays += part["ray_count"]
+            assert np.array_equal(total.view(np.uint32), got["radiance"].view(np.uint32))
+            assert np.array_equal(rays, got["ray_count"])
+    finally:
+        r.close()
+
+
 def test_golden_fixtures(renderer, cornell):
     """The committed fixtures (tests/golden/make_golden.py) without the oracle in the loop."""
     import os
