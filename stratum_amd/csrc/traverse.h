@@ -481,7 +481,7 @@ struct WaveWork {
           if (lane == 0) b = atomicAdd(&line[QCTL_HEAD], (unsigned long long)WORK_CHUNK);
           // take() runs in wave-uniform control flow (all 64 lanes), so the first lane is lane 0; a scalar keeps the
           // chunk bounds out of the vector registers
-          const uint32_t b32 = (uint32_t)__shfl((int)(uint32_t)(b > 0xFFFFFFFFull ? 0xFFFFFFFFull : b), 0, 64);
+          const uint32_t b32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b > 0xFFFFFFFFull ? 0xFFFFFFFFull : b));
           if (b32 < len) got = b32;
         }
         if (got != 0xFFFFFFFFu) {
