@@ -158,12 +158,15 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* gIn
  * sampling_flags are BDPTFlagBits (bdpt.h:12-44), scene_flags BDPT_FLAG_HAS_* (bdpt.h:46-49) as BDPT::render
  * resolves them (BDPT.cpp:486-541). Built: the default view-path integrator and, per flag, eAlphaTest, eNormalMaps,
  * eRayCones, eFlip*, eShadingNormalShadowFix, eUniformSphereSampling, eSampleEnvironmentMapDirectly, ePresampleLights,
- * eNEEReservoirs (without reuse), eConnectToViews (sample_photons + add_light_trace), eConnectToLightPaths (without
- * the light vertex cache), and BDPT_FLAG_HAS_MEDIA (volume instances over gVolumes). Rejected with
- * STHIP_ERR_UNSUPPORTED, never ignored: eLVC*, eNEEReservoirReuse (their results depend on the order of atomics
- * upstream), eSampleLightPower (reads an uninitialised table upstream), eCoherentSampling, and the combinations
- * DESIGN.md section 7 lists (media need eDeferShadowRays; light subpaths exclude environments and reservoirs).
- * eCoherentRR and ePerformanceCounters do not change results here; eRemapThreads only through the path index
+ * eNEEReservoirs, eConnectToViews (sample_photons + add_light_trace), eConnectToLightPaths, and BDPT_FLAG_HAS_MEDIA
+ * (volume instances over gVolumes). The flags whose upstream result depends on the order threads run in are built
+ * with ONE defined order each ("Defined orders"): eLVC / eLVCReservoirs (cache filled in light-path
+ * index order), eNEEReservoirReuse / eLVCReservoirReuse (hash-grid appends in (path, vertex) order; the seeds of a call
+ * are then traced one at a time, seed s reading the grid of seed s - 1; not on a pixel-tile shard), eCoherentRR (the
+ * wave = the 8x4 pixel group). Rejected with STHIP_ERR_UNSUPPORTED, never ignored: eSampleLightPower (reads an
+ * uninitialised table upstream), eCoherentSampling, and the combinations DESIGN.md section 7 lists (media need
+ * eDeferShadowRays and exclude light subpaths / reservoirs; light subpaths and reuse exclude environments).
+ * ePerformanceCounters does not change results here; eRemapThreads only through the path index
  * (map_pixel_coord, bdpt_util.hlsli:76-83) that ePresampleLights and the light subpaths key on. */
 int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* push_constants, uint32_t sampling_flags,
                  uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin, uint32_t seed_count,

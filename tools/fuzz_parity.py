@@ -44,6 +44,19 @@ def run(cases=60, seed=1):
         args = {"bdptFlag": flags, "maxDiffuseVertices": int(rng.integers(1, 5)), "maxPathVertices": int(rng.integers(2, 9)), "minPathVertices": int(rng.integers(2, 6))}
         W, H = int(rng.integers(3, 20)) * 8, int(rng.integers(3, 16)) * 4
         if rng.integers(3) == 0: W, H = W + int(rng.integers(1, 8)), H + int(rng.integers(1, 4))
+        # the estimators with a defined order: light vertex cache, the two hash grids, coherent roulette
+        bundle = int(rng.integers(8))
+        if bundle == 0:
+            flags += ["connecttolightpaths", "lightvertexcache"] + (["lvcreservoirs"] if rng.integers(2) else []) + (["lvcreservoirs", "lvcreservoirreuse"] if rng.integers(3) == 0 else [])
+            args.update(maxDiffuseVertices=int(rng.integers(2, 5)), lightPathCount=int(rng.integers(max(1, W * H // 4), W * H + 1)), reservoirM=int(rng.integers(1, 5)))
+        elif bundle == 1:
+            flags += ["neereservoirs", "neereservoirreuse"]
+            args.update(reservoirM=int(rng.integers(1, 5)), reservoirSpatialM=int(rng.integers(1, 4)), hashGridBucketCount=int(rng.choice([64, 1000, 100000])))
+        elif bundle == 2:
+            flags += ["coherentrr"]
+            args.update(minPathVertices=int(rng.integers(2, 4)), maxPathVertices=int(rng.integers(4, 9)))
+        flags[:] = list(dict.fromkeys(f for f in flags if not (bundle <= 1 and f in ("~nee", "~remapthreads"))))
+        reuse = any(f.endswith("reuse") for f in flags)
         seeds, seed0 = int(rng.integers(1, 4)), int(rng.integers(0, 1000))
         sc, cam = scene(kind)
         if rng.integers(4) == 0:  # objects that moved since the previous frame (gInstanceMotionTransforms feeds prev-uv / prev_z)
@@ -58,9 +71,10 @@ def run(cases=60, seed=1):
             if rng.integers(4) == 0: opts["fuse_trace"] = 0
             if rng.integers(4) == 0: opts["packet_primary"] = 0
             if rng.integers(4) == 0 and kind in ("cornell", "textured", "atrium", "forest"): opts["bvh_builder"] = 1
+            if rng.integers(4) == 0: opts["treetop"] = 0
             for k, v in opts.items():
                 r.set_option(k, v)
-            shard_n = int(rng.choice([1, 1, 2, 3]))
+            shard_n = 1 if reuse else int(rng.choice([1, 1, 2, 3]))  # a hash grid is a whole-frame structure: rejected on a shard
             shard_r = int(rng.integers(shard_n))
             if shard_n > 1:
                 r.set_shard(shard_r, shard_n, 16, 8)
