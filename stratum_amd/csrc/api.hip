@@ -86,7 +86,7 @@ struct sthip_ctx {
   uint32_t image_count = 0;
   DevBuf<float2> cone;
   uint32_t instance_count = 0, light_count = 0;
-  DevBuf<BvhNodePacked> nodes;
+  DevBuf<BvhNodeSlot> nodes;
   DevBuf<BvhTri> tris;
   DevBuf<TlasEntry> entries;
   DeviceBvh bvh{};
@@ -354,6 +354,15 @@ int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out) {
 
 static size_t stack_bytes(const sthip_ctx* ctx);
 static int refresh_treetop(sthip_ctx* ctx);
+// packs `count` nodes and writes them into the node array from slot `first` on
+static hipError_t upload_nodes(sthip_ctx* ctx, size_t first, const BvhNode* nodes, size_t count) {
+  std::vector<BvhNodePacked> packed;
+  sthip::pack_nodes(nodes, count, packed);
+  std::vector<BvhNodeSlot> slots(count);
+  memset(slots.data(), 0, count * sizeof(BvhNodeSlot));
+  for (size_t i = 0; i < count; i++) slots[i].n = packed[i];
+  return hipMemcpy(ctx->nodes.p + first, slots.data(), count * sizeof(BvhNodeSlot), hipMemcpyHostToDevice);
+}
 
 int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
@@ -551,11 +560,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   HIP_TRY(ctx, ctx->nodes.ensure(std::max<size_t>(1, built.top.blas_nodes + 2 * built.entries.size() + 2)));
   HIP_TRY(ctx, ctx->tris.ensure(std::max<size_t>(1, built.tris.size())));
   HIP_TRY(ctx, ctx->entries.ensure(std::max<size_t>(1, built.entries.size())));
-  if (!built.nodes.empty()) {
-    std::vector<BvhNodePacked> packed;
-    sthip::pack_nodes(built.nodes.data(), built.nodes.size(), packed);
-    HIP_TRY(ctx, hipMemcpy(ctx->nodes.p, packed.data(), packed.size() * sizeof(BvhNodePacked), hipMemcpyHostToDevice));
-  }
+  if (!built.nodes.empty()) HIP_TRY(ctx, upload_nodes(ctx, 0, built.nodes.data(), built.nodes.size()));
   if (!built.tris.empty()) HIP_TRY(ctx, hipMemcpy(ctx->tris.p, built.tris.data(), built.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
   if (!built.entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->entries.p, built.entries.data(), built.entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
   {  // alpha masks: one-channel images and the per-triangle uvs the traversal interpolates
@@ -775,11 +780,7 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
     HIP_TRY(ctx, hipMemcpy(ctx->motion_xf.p, I.data(), (size_t)n * 48, hipMemcpyHostToDevice));
   }
   if (!next.entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->entries.p, next.entries.data(), next.entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
-  if (!tlas.empty()) {
-    std::vector<BvhNodePacked> packed;
-    sthip::pack_nodes(tlas.data(), tlas.size(), packed);
-    HIP_TRY(ctx, hipMemcpy(ctx->nodes.p + next.blas_nodes, packed.data(), packed.size() * sizeof(BvhNodePacked), hipMemcpyHostToDevice));
-  }
+  if (!tlas.empty()) HIP_TRY(ctx, upload_nodes(ctx, next.blas_nodes, tlas.data(), tlas.size()));
   ctx->bvh.root_ref = root_ref;
   ctx->bvh.top_is_world_blas = top_is_world;
   ctx->bvh.stack_depth = stack_depth;
@@ -1725,15 +1726,15 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s) {
   } else if (kind == STHIP_CEILING_NODE_GATHER_TABLE || kind == STHIP_CEILING_NODE_GATHER_L2 || kind == STHIP_CEILING_NODE_GATHER_L1) {
     if (!ctx->has_scene || !ctx->bvh_nodes) return fail(ctx, STHIP_ERR_NO_SCENE, "sthip_measure_ceiling: the node-gather ceilings read the resident acceleration structure: upload a scene first");
     uint32_t count = (uint32_t)std::min<uint64_t>(ctx->bvh_nodes, 0xFFFFFFFFull);
-    if (kind == STHIP_CEILING_NODE_GATHER_L2) count = std::min<uint32_t>(count, (2u << 20) / (uint32_t)sizeof(BvhNodePacked));
-    if (kind == STHIP_CEILING_NODE_GATHER_L1) count = std::min<uint32_t>(count, (16u << 10) / (uint32_t)sizeof(BvhNodePacked));
+    if (kind == STHIP_CEILING_NODE_GATHER_L2) count = std::min<uint32_t>(count, (2u << 20) / BVH_NODE_BYTES);
+    if (kind == STHIP_CEILING_NODE_GATHER_L1) count = std::min<uint32_t>(count, (16u << 10) / BVH_NODE_BYTES);
     const uint32_t iterations = 64;
     DevBuf<float> sink;
     HIP_TRY(ctx, sink.ensure((size_t)blocks * 256));
     bytes = (double)sizeof(BvhNodePacked) * (double)blocks * 256.0 * iterations * CEIL_UNROLL;
     for (int rep = 0; rep < 4; rep++) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-      hipLaunchKernelGGL(k_ceiling_node_gather, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->nodes.p), count, (uint32_t)sizeof(BvhNodePacked), iterations, sink.p);
+      hipLaunchKernelGGL(k_ceiling_node_gather, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->nodes.p), count, BVH_NODE_BYTES, iterations, sink.p);
       HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
       HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
       float ms = 0;

@@ -50,7 +50,18 @@ struct BvhNodePacked {
   float n1xy[4];
   float nz[4];
 };
-#define BVH_NODE_BYTES 48u
+// The slot a packed node occupies in HBM. 48: nodes back to back (a node then straddles a 64-byte boundary every other
+// time and a 128-byte line 3 times in 8). 64: one node per half line, 16 bytes of padding.
+#ifndef STHIP_NODE_STRIDE
+#define STHIP_NODE_STRIDE 48
+#endif
+#define BVH_NODE_BYTES ((unsigned)STHIP_NODE_STRIDE)
+struct BvhNodeSlot {
+  BvhNodePacked n;
+#if STHIP_NODE_STRIDE > 48
+  uint32_t pad[(STHIP_NODE_STRIDE - 48) / 4];
+#endif
+};
 #define BVH_NO_ALPHA 0xFFFFFFFFu  // DeviceBvh::inst_alpha entry of an instance whose material has no alpha mask
 // uv of the three vertices of a leaf triangle, in leaf order next to BvhTri; only built for scenes with alpha masks
 struct BvhTriUv {
@@ -87,7 +98,8 @@ struct DeviceVolume {
 
 #ifdef __cplusplus
 static_assert(sizeof(BvhNode) == 64, "BvhNode");
-static_assert(sizeof(BvhNodePacked) == BVH_NODE_BYTES, "BvhNodePacked");
+static_assert(sizeof(BvhNodePacked) == 48, "BvhNodePacked");
+static_assert(sizeof(BvhNodeSlot) == BVH_NODE_BYTES, "BvhNodeSlot");
 static_assert(sizeof(BvhTri) == 48, "BvhTri");
 static_assert(sizeof(TlasEntry) == 80, "TlasEntry");
 #endif
