@@ -52,6 +52,30 @@ struct DevBuf {
     n = 0;
   }
 };
+// The unpacked nodes the host keeps (treetop selection, top-level rebuilds): page-locked, so that the device-resident
+// builder's one node copy runs at PCIe speed, and never zero-filled
+struct PinnedNodes {
+  BvhNode* p = nullptr;
+  size_t n = 0, cap = 0;
+  PinnedNodes() = default;
+  PinnedNodes(const PinnedNodes&) = delete;
+  PinnedNodes& operator=(const PinnedNodes&) = delete;
+  ~PinnedNodes() {
+    if (p) (void)hipHostFree(p);
+  }
+  hipError_t ensure(size_t count) {  // capacity only; contents are lost when it grows
+    if (count <= cap && p) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = n = 0;
+    hipError_t e = hipHostMalloc((void**)&p, std::max<size_t>(1, count) * sizeof(BvhNode), hipHostMallocDefault);
+    if (e == hipSuccess) cap = std::max<size_t>(1, count);
+    return e;
+  }
+  bool empty() const { return n == 0; }
+  size_t size() const { return n; }
+  BvhNode* data() { return p; }
+};
 }  // namespace
 
 struct sthip_ctx {
@@ -92,7 +116,8 @@ struct sthip_ctx {
   DeviceBvh bvh{};
   uint64_t bvh_nodes = 0, bvh_tris = 0;
   // treetop (bvh_build.h): rebuilt whenever the top level changes; needs the nodes on the host
-  std::vector<BvhNode> nodes_host;
+  PinnedNodes nodes_host;
+  DevBuf<BvhNode> raw_nodes;  // device-resident build only: the unpacked nodes before their one copy to nodes_host
   DevBuf<BvhNodePacked> top_nodes;
   DevBuf<TlasEntry> top_entries;
   bool use_treetop = true;
@@ -469,25 +494,55 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (s->volume_count && !s->gVolumes) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: volume_count > 0 but gVolumes is NULL");
   sthip::BuiltBvh built;
   std::string err;
+  const uint32_t n = s->instance_count;
+  // The GPU builder works on the device-resident scene: vertices and indices go up BEFORE the build, and the bottom levels
+  // are written in place (lbvh.hip: lbvh_build_device). From here on the previous scene is gone, also when the call fails.
+  const bool device_build = ctx->bvh_builder == sthip::BVH_BUILDER_LBVH_GPU;
+  sthip::DeviceBuildTarget target;
+  if (device_build) {
+    ctx->has_scene = false;
+    HIP_TRY(ctx, ctx->vertices.ensure(std::max(1u, s->vertex_count)));
+    HIP_TRY(ctx, ctx->indices.ensure((size_t)s->indices_bytes + 8));
+    if (s->vertex_count) HIP_TRY(ctx, hipMemcpy(ctx->vertices.p, s->gVertices, (size_t)s->vertex_count * sizeof(sthip_PackedVertexData), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(ctx->indices.p + s->indices_bytes, 0, 8));
+    if (s->indices_bytes) HIP_TRY(ctx, hipMemcpy(ctx->indices.p, s->gIndices, s->indices_bytes, hipMemcpyHostToDevice));
+    target.vertices = ctx->vertices.p;
+    target.vertex_count = s->vertex_count;
+    target.indices = ctx->indices.p;
+    target.stream = ctx->stream;
+    target.user = ctx;
+    target.reserve = [](void* user, size_t node_capacity, size_t tri_capacity, sthip::DeviceBuildTarget& self) {
+      sthip_ctx* c = (sthip_ctx*)user;
+      if (c->nodes.ensure(node_capacity) != hipSuccess || c->raw_nodes.ensure(node_capacity) != hipSuccess || c->tris.ensure(tri_capacity) != hipSuccess) return false;
+      self.nodes = c->nodes.p;
+      self.raw_nodes = c->raw_nodes.p;
+      self.tris = c->tris.p;
+      return true;
+    };
+  }
   const auto t_build0 = std::chrono::steady_clock::now();
-  if (!sthip::build_scene_bvh(*s, built, err, ctx->bvh_builder)) return fail(ctx, err.find("only triangle") != std::string::npos ? STHIP_ERR_UNSUPPORTED : STHIP_ERR_INVALID_ARGUMENT, "scene: " + err);
+  if (!sthip::build_scene_bvh(*s, built, err, ctx->bvh_builder, device_build ? &target : nullptr))
+    return fail(ctx, err.find("only triangle") != std::string::npos ? STHIP_ERR_UNSUPPORTED : STHIP_ERR_INVALID_ARGUMENT, "scene: " + err);
 
   if ((size_t)built.stack_depth * STHIP_BLOCK * sizeof(uint32_t) > STHIP_MAX_STACK_LDS)
     return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: the acceleration structure is too deep for the LDS traversal stack (use the SAH builder)");
   ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
   ctx->stats.bvh_build_gpu_ms = built.gpu_build_ms;
-  const uint32_t n = s->instance_count;
-  HIP_TRY(ctx, ctx->vertices.ensure(std::max(1u, s->vertex_count)));
-  HIP_TRY(ctx, ctx->indices.ensure((size_t)s->indices_bytes + 8));
+  if (!device_build) {
+    HIP_TRY(ctx, ctx->vertices.ensure(std::max(1u, s->vertex_count)));
+    HIP_TRY(ctx, ctx->indices.ensure((size_t)s->indices_bytes + 8));
+  }
   HIP_TRY(ctx, ctx->instances.ensure(n));
   HIP_TRY(ctx, ctx->xf.ensure(n));
   HIP_TRY(ctx, ctx->inv_xf.ensure(n));
   HIP_TRY(ctx, ctx->motion_xf.ensure(n));
   HIP_TRY(ctx, ctx->materials.ensure(s->material_bytes));
   HIP_TRY(ctx, ctx->lights.ensure(std::max(1u, s->light_count)));
-  if (s->vertex_count) HIP_TRY(ctx, hipMemcpy(ctx->vertices.p, s->gVertices, (size_t)s->vertex_count * sizeof(sthip_PackedVertexData), hipMemcpyHostToDevice));
-  HIP_TRY(ctx, hipMemset(ctx->indices.p, 0, (size_t)s->indices_bytes + 8));
-  if (s->indices_bytes) HIP_TRY(ctx, hipMemcpy(ctx->indices.p, s->gIndices, s->indices_bytes, hipMemcpyHostToDevice));
+  if (!device_build) {
+    if (s->vertex_count) HIP_TRY(ctx, hipMemcpy(ctx->vertices.p, s->gVertices, (size_t)s->vertex_count * sizeof(sthip_PackedVertexData), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(ctx->indices.p, 0, (size_t)s->indices_bytes + 8));
+    if (s->indices_bytes) HIP_TRY(ctx, hipMemcpy(ctx->indices.p, s->gIndices, s->indices_bytes, hipMemcpyHostToDevice));
+  }
   HIP_TRY(ctx, hipMemcpy(ctx->instances.p, s->gInstances, (size_t)n * 16, hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(ctx->xf.p, s->gInstanceTransforms, (size_t)n * 48, hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(ctx->inv_xf.p, s->gInstanceInverseTransforms, (size_t)n * 48, hipMemcpyHostToDevice));
@@ -557,11 +612,17 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   }
 
   // headroom: a transforms-only update may build a top level with more inner nodes than this one (at most 2 per entry)
-  HIP_TRY(ctx, ctx->nodes.ensure(std::max<size_t>(1, built.top.blas_nodes + 2 * built.entries.size() + 2)));
-  HIP_TRY(ctx, ctx->tris.ensure(std::max<size_t>(1, built.tris.size())));
+  const size_t nodes_total = (size_t)built.dev_nodes + built.nodes.size(), tris_total = (size_t)built.dev_tris + built.tris.size();
+  const size_t nodes_needed = std::max<size_t>(1, built.top.blas_nodes + 2 * built.entries.size() + 2);
+  if (device_build && built.dev_nodes) {  // the device region is already in place: growing the arrays now would lose it
+    if (ctx->nodes.n < std::max(nodes_needed, nodes_total) || ctx->tris.n < std::max<size_t>(1, tris_total)) return fail(ctx, STHIP_ERR_HIP, "scene: the reserved device arrays are too small");
+  } else {
+    HIP_TRY(ctx, ctx->nodes.ensure(std::max(nodes_needed, nodes_total)));
+    HIP_TRY(ctx, ctx->tris.ensure(std::max<size_t>(1, tris_total)));
+  }
   HIP_TRY(ctx, ctx->entries.ensure(std::max<size_t>(1, built.entries.size())));
-  if (!built.nodes.empty()) HIP_TRY(ctx, upload_nodes(ctx, 0, built.nodes.data(), built.nodes.size()));
-  if (!built.tris.empty()) HIP_TRY(ctx, hipMemcpy(ctx->tris.p, built.tris.data(), built.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
+  if (!built.nodes.empty()) HIP_TRY(ctx, upload_nodes(ctx, built.dev_nodes, built.nodes.data(), built.nodes.size()));
+  if (!built.tris.empty()) HIP_TRY(ctx, hipMemcpy(ctx->tris.p + built.dev_tris, built.tris.data(), built.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
   if (!built.entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->entries.p, built.entries.data(), built.entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
   {  // alpha masks: one-channel images and the per-triangle uvs the traversal interpolates
     std::vector<DeviceImage1> table(s->image1_count);
@@ -625,11 +686,14 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->bvh.scene_cy = built.scene_center[1];
   ctx->bvh.scene_cz = built.scene_center[2];
   ctx->bvh.scene_radius = built.scene_radius;
-  ctx->bvh_nodes = built.nodes.size();
-  ctx->bvh_tris = built.tris.size();
+  ctx->bvh_nodes = nodes_total;
+  ctx->bvh_tris = tris_total;
   ctx->top = std::move(built.top);
-  ctx->nodes_host = std::move(built.nodes);
-  ctx->nodes_host.resize(std::max<size_t>(ctx->nodes_host.size(), ctx->nodes.n));  // room for a rebuilt top level
+  // the host's copy of the unpacked nodes, with room for a rebuilt top level
+  HIP_TRY(ctx, ctx->nodes_host.ensure(std::max<size_t>(nodes_total, ctx->nodes.n)));
+  if (built.dev_nodes) HIP_TRY(ctx, hipMemcpy(ctx->nodes_host.p, ctx->raw_nodes.p, (size_t)built.dev_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
+  if (!built.nodes.empty()) memcpy(ctx->nodes_host.p + built.dev_nodes, built.nodes.data(), built.nodes.size() * sizeof(BvhNode));
+  ctx->nodes_host.n = nodes_total;
   {
     const int rc = refresh_treetop(ctx);
     if (rc != STHIP_OK) return rc;
@@ -639,7 +703,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     int per_cu = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false>, STHIP_BLOCK, stack_bytes(ctx));
     fprintf(stderr, "[sthip] bvh (%s): %zu nodes, %zu tris, %zu top-level entries, stack depth %u (%zu B LDS / block), %d trace blocks / CU, build %.1f ms (GPU kernels %.2f ms)\n",
-            ctx->bvh_builder ? "lbvh/gpu" : "sah/host", (size_t)ctx->bvh_nodes, built.tris.size(), built.entries.size(), built.stack_depth, stack_bytes(ctx), per_cu, ctx->stats.bvh_build_ms,
+            ctx->bvh_builder ? "lbvh/gpu" : "sah/host", (size_t)ctx->bvh_nodes, (size_t)ctx->bvh_tris, built.entries.size(), built.stack_depth, stack_bytes(ctx), per_cu, ctx->stats.bvh_build_ms,
             ctx->stats.bvh_build_gpu_ms);
   }
   return STHIP_OK;
@@ -789,7 +853,10 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
   ctx->bvh.scene_cz = center[2];
   ctx->bvh.scene_radius = radius;
   ctx->bvh_nodes = next.blas_nodes + tlas.size();
-  if (ctx->nodes_host.size() >= (size_t)next.blas_nodes + tlas.size()) std::copy(tlas.begin(), tlas.end(), ctx->nodes_host.begin() + next.blas_nodes);
+  if (ctx->nodes_host.cap >= (size_t)next.blas_nodes + tlas.size()) {
+    if (!tlas.empty()) memcpy(ctx->nodes_host.p + next.blas_nodes, tlas.data(), tlas.size() * sizeof(BvhNode));
+    ctx->nodes_host.n = std::max(ctx->nodes_host.n, (size_t)next.blas_nodes + tlas.size());
+  }
   ctx->top = std::move(next);
   return refresh_treetop(ctx);
 }

@@ -320,8 +320,11 @@ inline void load_tri(const sthip_scene_desc& s, const InstView& in, uint32_t pri
 
 }  // namespace
 
-bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err, int builder) {
+bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err, int builder, DeviceBuildTarget* device) {
   out = BuiltBvh();
+  // device mode: bottom levels of >= DEVICE_MIN_PRIMS triangles are built in place on the GPU from the uploaded scene arrays
+  const bool dev_mode = device != nullptr && builder == BVH_BUILDER_LBVH_GPU;
+  const uint32_t DEVICE_MIN_PRIMS = 64;
   const uint32_t BLAS_DEPTH_CAP = 22, TLAS_DEPTH_CAP = 18, LBVH_MAX_HEIGHT = 120;
   // ---- validate + classify ----
   std::vector<uint32_t> merged, separate, spheres, volumes;
@@ -407,15 +410,16 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       err = "instance material_address exceeds gMaterialData";
       return false;
     }
-    for (uint32_t p = 0; p < in.prim_count; p++) {
-      uint32_t tri[3];
-      load_tri(s, in, p, tri);
-      for (int k = 0; k < 3; k++)
-        if (tri[k] >= s.vertex_count) {
-          err = "vertex index exceeds gVertices";
-          return false;
-        }
-    }
+    if (!dev_mode)  // (device mode: the fetch kernel checks the meshes it builds, add_blas the ones the host builds)
+      for (uint32_t p = 0; p < in.prim_count; p++) {
+        uint32_t tri[3];
+        load_tri(s, in, p, tri);
+        for (int k = 0; k < 3; k++)
+          if (tri[k] >= s.vertex_count) {
+            err = "vertex index exceeds gVertices";
+            return false;
+          }
+      }
     if (is_identity(s.gInstanceInverseTransforms[i]) && is_identity(s.gInstanceTransforms[i]))
       merged.push_back(i);
     else
@@ -445,9 +449,88 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
   }
 
   std::string gpu_err;
-  auto add_blas = [&](const std::vector<std::pair<uint32_t, uint32_t>>& prims /* (instance, prim) */, bool with_instance_bits, Box& bounds, uint32_t& depth) -> uint32_t {
-    if (builder == BVH_BUILDER_LBVH_GPU && prims.size() >= 64) {
-      // GPU path: hand the triangles over unsorted; the device sorts them along the Morton curve
+  // ---- device mode: the region the GPU builder fills is sized before anything is built ----
+  // A bottom level = the triangles of a list of instances (all merged ones, or the one that stands for a shared mesh).
+  auto prim_total = [&](const std::vector<uint32_t>& insts) {
+    size_t n = 0;
+    for (uint32_t i : insts) n += view(s.gInstances[i]).prim_count;
+    return n;
+  };
+  uint32_t dev_node_cursor = 0, dev_tri_cursor = 0;
+  if (dev_mode) {
+    size_t dev_nodes = 0, dev_tris = 0, all_prims = 0, meshes_n = 0;
+    auto account = [&](size_t n) {
+      if (n == 0) return;
+      all_prims += n;
+      meshes_n++;
+      if (n >= DEVICE_MIN_PRIMS) {
+        dev_nodes += n - 1;
+        dev_tris += n;
+      }
+    };
+    account(prim_total(merged));
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, int> seen;
+    for (uint32_t i : separate) {
+      const InstView in = view(s.gInstances[i]);
+      if (seen.emplace(std::make_tuple(in.first_vertex, in.indices_byte_offset, in.prim_count, in.stride), 0).second) account(in.prim_count);
+    }
+    if (all_prims >= (1u << 28)) {
+      err = "too many triangles";
+      return false;
+    }
+    out.dev_nodes = (uint32_t)dev_nodes;
+    out.dev_tris = (uint32_t)dev_tris;
+    // upper bounds of what the host adds behind the device region: a mesh of n triangles has at most max(n - 1, 1)
+    // nodes, the top level at most 2 per entry; + the headroom a transforms-only update may need
+    const size_t entries_upper = (merged.empty() ? 0 : 1) + separate.size() + spheres.size() + volumes.size();
+    if (!device->reserve || !device->reserve(device->user, all_prims + meshes_n + 4 * entries_upper + 8, all_prims + 1, *device)) {
+      err = "lbvh: could not reserve the device arrays";
+      return false;
+    }
+  }
+  auto add_blas = [&](const std::vector<uint32_t>& insts, bool with_instance_bits, Box& bounds, uint32_t& depth, bool& on_device) -> uint32_t {
+    on_device = false;
+    const size_t total = prim_total(insts);
+    if (dev_mode && total >= DEVICE_MIN_PRIMS) {
+      std::vector<MeshPiece> pieces;
+      uint32_t begin = 0;
+      for (uint32_t i : insts) {
+        const InstView in = view(s.gInstances[i]);
+        if (in.prim_count == 0) continue;
+        pieces.push_back(MeshPiece{with_instance_bits ? i : 0u, in.first_vertex, in.indices_byte_offset, in.stride, in.prim_count, begin});
+        begin += in.prim_count;
+      }
+      uint32_t root = 0;
+      float ms = 0, bb[6];
+      if (!lbvh_build_device(*device, pieces, dev_node_cursor, dev_tri_cursor, root, depth, bb, ms, gpu_err)) return BVH_INVALID_REF;
+      out.gpu_build_ms += ms;
+      if (depth <= LBVH_MAX_HEIGHT) {  // (else: the SAH builder below; the reserved stretch of the device region stays unused)
+        memcpy(bounds.lo, bb, 12);
+        memcpy(bounds.hi, bb + 3, 12);
+        dev_node_cursor += (uint32_t)total - 1;
+        dev_tri_cursor += (uint32_t)total;
+        on_device = true;
+        return root;
+      }
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> prims;  // (instance, prim)
+    prims.reserve(total);
+    for (uint32_t i : insts) {
+      const InstView in = view(s.gInstances[i]);
+      for (uint32_t p = 0; p < in.prim_count; p++) prims.emplace_back(i, p);
+    }
+    if (dev_mode)  // the index check the validation loop left to the builders
+      for (const auto& pr : prims) {
+        uint32_t tri[3];
+        load_tri(s, view(s.gInstances[pr.first]), pr.second, tri);
+        for (int k = 0; k < 3; k++)
+          if (tri[k] >= s.vertex_count) {
+            gpu_err = "vertex index exceeds gVertices";
+            return BVH_INVALID_REF;
+          }
+      }
+    if (!dev_mode && builder == BVH_BUILDER_LBVH_GPU && prims.size() >= 64) {
+      // GPU path through host vectors: hand the triangles over unsorted; the device sorts them along the Morton curve
       std::vector<BvhTri> tin(prims.size());
       bounds.reset();
       for (size_t k = 0; k < prims.size(); k++) {
@@ -526,27 +609,26 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
   uint32_t blas_depth = 0;
   std::vector<Box> entry_boxes;
 
+  std::vector<uint8_t> entry_root_local;  // device mode: the entry's root is an index into out.nodes (host-built), offset at the end
   if (!merged.empty()) {
-    std::vector<std::pair<uint32_t, uint32_t>> prims;
-    for (uint32_t i : merged) {
-      const InstView in = view(s.gInstances[i]);
-      for (uint32_t p = 0; p < in.prim_count; p++) prims.emplace_back(i, p);
-    }
-    if (!prims.empty()) {
-      if (prims.size() >= (1u << 28)) {
+    const size_t total = prim_total(merged);
+    if (total > 0) {
+      if (total >= (1u << 28)) {
         err = "too many triangles";
         return false;
       }
       Box bounds;
       uint32_t depth = 0;
+      bool on_device = false;
       TlasEntry e;
       memset(&e, 0, sizeof(e));
       e.inv[0] = e.inv[5] = e.inv[10] = 1.0f;
-      e.root = add_blas(prims, true, bounds, depth);
+      e.root = add_blas(merged, true, bounds, depth, on_device);
       if (e.root == BVH_INVALID_REF) {
         err = gpu_err;
         return false;
       }
+      entry_root_local.push_back(on_device ? 0 : 1);
       e.id_bits = 0;
       e.identity = TLAS_ENTRY_IDENTITY;
       for (int a = 0; a < 3; a++) e.center[a] = 0.5f * (bounds.lo[a] + bounds.hi[a]);
@@ -561,6 +643,7 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
   struct MeshInfo {
     uint32_t root;
     Box bounds;
+    bool on_device;
   };
   std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, MeshInfo> meshes;
   for (uint32_t i : separate) {
@@ -569,11 +652,9 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
     auto key = std::make_tuple(in.first_vertex, in.indices_byte_offset, in.prim_count, in.stride);
     auto it = meshes.find(key);
     if (it == meshes.end()) {
-      std::vector<std::pair<uint32_t, uint32_t>> prims;
-      for (uint32_t p = 0; p < in.prim_count; p++) prims.emplace_back(i, p);
       MeshInfo mi;
       uint32_t depth = 0;
-      mi.root = add_blas(prims, false, mi.bounds, depth);
+      mi.root = add_blas(std::vector<uint32_t>{i}, false, mi.bounds, depth, mi.on_device);
       if (mi.root == BVH_INVALID_REF) {
         err = gpu_err;
         return false;
@@ -595,14 +676,23 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
     Box wb;
     wb.reset();
     const sthip_TransformData& M = s.gInstanceTransforms[i];
-    for (uint32_t p = 0; p < in.prim_count; p++) {
-      uint32_t tri[3];
-      load_tri(s, in, p, tri);
-      for (int v = 0; v < 3; v++) {
-        const float* q = s.gVertices[tri[v]].position;
-        float w[3];
+    if (it->second.on_device) {  // the triangles never came to the host: the corners of the object box (as rebuild_top_level does)
+      for (int c = 0; c < 8; c++) {
+        float q[3], w[3];
+        for (int a = 0; a < 3; a++) q[a] = ((c >> a) & 1) ? ob.hi[a] : ob.lo[a];
         for (int r = 0; r < 3; r++) w[r] = M.m[r][0] * q[0] + M.m[r][1] * q[1] + M.m[r][2] * q[2] + M.m[r][3];
         wb.grow(w);
+      }
+    } else {
+      for (uint32_t p = 0; p < in.prim_count; p++) {
+        uint32_t tri[3];
+        load_tri(s, in, p, tri);
+        for (int v = 0; v < 3; v++) {
+          const float* q = s.gVertices[tri[v]].position;
+          float w[3];
+          for (int r = 0; r < 3; r++) w[r] = M.m[r][0] * q[0] + M.m[r][1] * q[1] + M.m[r][2] * q[2] + M.m[r][3];
+          wb.grow(w);
+        }
       }
     }
     for (int a = 0; a < 3; a++) {
@@ -611,6 +701,7 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       wb.hi[a] += 2e-5f * m;
     }
     out.entries.push_back(e);
+    entry_root_local.push_back(it->second.on_device ? 0 : 1);
     entry_boxes.push_back(wb);
     scene_box.grow(wb);
   }
@@ -668,13 +759,16 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
     scene_box.grow(wb);
   }
 
+  if (dev_mode)  // host-built bottom levels lie behind the device region
+    for (size_t k = 0; k < entry_root_local.size(); k++)
+      if (entry_root_local[k]) out.entries[k].root += out.dev_nodes;
   // ---- what a transforms-only update needs later ----
   out.top.entries = out.entries;
   out.top.volumes = out.volumes;
   out.top.instance_count = s.instance_count;
   out.top.merged.assign(s.instance_count, 0);
   for (uint32_t i : merged) out.top.merged[i] = 1;
-  out.top.blas_nodes = (uint32_t)out.nodes.size();
+  out.top.blas_nodes = out.dev_nodes + (uint32_t)out.nodes.size();
   out.top.blas_depth = blas_depth;
   out.top.obj_box.assign(6 * out.entries.size(), 0.f);
   for (size_t k = 0; k < out.entries.size(); k++) {
@@ -718,6 +812,17 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
     for (int a = 0; a < 3; a++) out.scene_center[a] = 0.5f * (scene_box.lo[a] + scene_box.hi[a]);
     out.scene_radius = 0.5f * sqrtf((scene_box.hi[0] - scene_box.lo[0]) * (scene_box.hi[0] - scene_box.lo[0]) + (scene_box.hi[1] - scene_box.lo[1]) * (scene_box.hi[1] - scene_box.lo[1]) +
                                     (scene_box.hi[2] - scene_box.lo[2]) * (scene_box.hi[2] - scene_box.lo[2]));
+  }
+  if (dev_mode) {  // out.nodes / out.tris start behind the device region: make their references final
+    const uint32_t node_off = out.dev_nodes, tri_off = out.dev_tris << 2;
+    for (BvhNode& nd : out.nodes)
+      for (int c = 0; c < 2; c++) {
+        if (!(nd.ref[c] & BVH_LEAF_BIT))
+          nd.ref[c] += node_off;
+        else if (!(nd.ref[c] & BVH_INST_BIT))
+          nd.ref[c] += tri_off;
+      }
+    if (!out.top_is_world_blas && out.root_ref != BVH_INVALID_REF) out.root_ref += node_off;  // the top level is host-built
   }
   if (any_alpha) out.tri_uvs.resize(out.tris.size());
   out.inst_alpha = inst_alpha;

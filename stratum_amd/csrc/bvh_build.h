@@ -9,6 +9,12 @@
 #include "../../include/sthip.h"
 #include "bvh.h"
 
+#if defined(__HIPCC__)
+#define STHIP_HD __host__ __device__
+#else
+#define STHIP_HD
+#endif
+
 namespace sthip {
 
 // What a transforms-only update needs from the last full build (kept by the uploader): the bottom levels stay as they
@@ -38,14 +44,49 @@ struct BuiltBvh {
   float scene_center[3] = {0, 0, 0};
   float scene_radius = 0;
   float gpu_build_ms = 0;  // device time of the LBVH kernels (0 for the host builder)
+  // Device-resident build (DeviceBuildTarget): the GPU builder has written nodes [0, dev_nodes) and triangles
+  // [0, dev_tris) of the final arrays in place; `nodes` / `tris` then hold only what the host built (small meshes, SAH
+  // fallbacks, the top level) and belong at [dev_nodes, ...) / [dev_tris, ...): their references are already final.
+  uint32_t dev_nodes = 0, dev_tris = 0;
   TopLevelState top;
 };
+
+// One run of triangles of a bottom level, as the scene arrays describe it (scene.h:139-161)
+struct MeshPiece {
+  uint32_t id_bits;              // OR-ed into BvhTri::id below the primitive index: the instance for the merged mesh, else 0
+  uint32_t first_vertex;
+  uint32_t indices_byte_offset;
+  uint32_t stride;               // 2 or 4
+  uint32_t prim_count;
+  uint32_t prim_begin;           // running sum of prim_count over the pieces before this one
+};
+
+// The device-resident arrays a GPU build reads (the scene, uploaded before the build) and writes in place (lbvh.hip):
+// no triangle or node crosses PCIe except the unpacked nodes the host keeps for the treetop / top-level rebuilds.
+struct DeviceBuildTarget {
+  const sthip_PackedVertexData* vertices = nullptr;  // device
+  uint32_t vertex_count = 0;
+  const uint8_t* indices = nullptr;                  // device, padded by 8 bytes
+  BvhNodeSlot* nodes = nullptr;                      // device: the packed node array the kernels traverse
+  BvhNode* raw_nodes = nullptr;                      // device: the same nodes unpacked (copied to the host once, pinned)
+  BvhTri* tris = nullptr;                            // device: leaf triangles
+  void* stream = nullptr;                            // hipStream_t
+  // called once the sizes are known, before the first build: makes nodes / raw_nodes / tris at least this large
+  bool (*reserve)(void* user, size_t node_capacity, size_t tri_capacity, DeviceBuildTarget& self) = nullptr;
+  void* user = nullptr;
+};
+// Builds one bottom level over `pieces` on the device: n - 1 nodes at [node_base, ...), n triangles at [tri_base, ...).
+// bounds[6] = lo xyz, hi xyz of the mesh; height = the stack the tree needs. false + err on a HIP error or a vertex index
+// outside gVertices.
+bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece>& pieces, uint32_t node_base, uint32_t tri_base, uint32_t& root_ref, uint32_t& height, float bounds[6],
+                       float& gpu_ms, std::string& err);
 
 enum BvhBuilderKind { BVH_BUILDER_SAH_HOST = 0, BVH_BUILDER_LBVH_GPU = 1 };
 
 // Validates the scene arrays and builds. Returns false and sets `err` on malformed input.
 // `builder`: binned SAH on the host (default; best traversal) or LBVH on the GPU (fastest build; lbvh.hip).
-bool build_scene_bvh(const sthip_scene_desc& scene, BuiltBvh& out, std::string& err, int builder = BVH_BUILDER_SAH_HOST);
+// With a DeviceBuildTarget (and the LBVH builder) bottom levels of >= 64 triangles are built in place on the device.
+bool build_scene_bvh(const sthip_scene_desc& scene, BuiltBvh& out, std::string& err, int builder = BVH_BUILDER_SAH_HOST, DeviceBuildTarget* device = nullptr);
 
 // Transforms-only update: new entry matrices and world boxes, a new top level. `tlas_nodes` come out with their child
 // references already offset by st.blas_nodes (they go to nodes[st.blas_nodes ...]). Fails (false) when an instance of the
@@ -71,7 +112,7 @@ void build_treetop(const BvhNode* nodes, size_t node_count, const std::vector<Tl
 // one for every b, an upper plane >= it:
 //   lower, v >= 0: M = (m - 255) & ~255 (for m < 255: -0 with M = 0, i.e. values in [-255 ulp, -0]);  lower, v < 0: M = (m + 255) & ~255
 //   upper: mirrored.  Infinite / NaN planes (empty children) are clamped to +-3.4e38 first so that no byte makes a NaN.
-inline uint32_t pack_plane(float v, bool upper, uint32_t byte) {
+STHIP_HD inline uint32_t pack_plane(float v, bool upper, uint32_t byte) {
   if (!(v > -3.0e38f)) v = -3.0e38f;  // also NaN
   if (v > 3.0e38f) v = 3.0e38f;
   uint32_t u;
@@ -92,7 +133,7 @@ inline uint32_t pack_plane(float v, bool upper, uint32_t byte) {
   }
   return sign | M | (byte & 0xFFu);
 }
-inline BvhNodePacked pack_node(const BvhNode& n) {
+STHIP_HD inline BvhNodePacked pack_node(const BvhNode& n) {
   BvhNodePacked q;
   uint32_t w[8];
   for (int k = 0; k < 4; k++) {

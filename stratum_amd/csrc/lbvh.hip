@@ -184,6 +184,180 @@ __global__ void k_lbvh_gather(const BvhTri* in, const uint32_t* sorted, uint32_t
   if (i < n) out[i] = in[sorted[i]];
 }
 
+
+// ---- the device-resident build (lbvh_build_device): triangles are fetched from the uploaded scene arrays ----
+
+__device__ __forceinline__ float wave_min(float v) {
+  for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// One thread per triangle of the mesh: finds its piece, reads the three indices (scene.h:139-161) and positions, writes
+// the BvhTri (unsorted), its box, and folds the centroid into the mesh's centroid bounds (one atomic per wave and
+// plane, not per triangle: 6 M atomics on six addresses would take longer than the rest of the build).
+__global__ void __launch_bounds__(LB_BLOCK) k_lbvh_fetch(const MeshPiece* pieces, uint32_t piece_count, const sthip_PackedVertexData* vertices, uint32_t vertex_count,
+                                                         const uint8_t* indices, uint32_t n, BvhTri* tris, LBox* boxes, uint32_t* cbounds, uint32_t* error) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  float c_lo[3] = {INFINITY, INFINITY, INFINITY}, c_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  if (i < n) {
+    uint32_t lo = 0, hi = piece_count - 1;  // the last piece with prim_begin <= i
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      if (pieces[mid].prim_begin <= i)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    const MeshPiece pc = pieces[lo];
+    const uint32_t prim = i - pc.prim_begin;
+    const uint8_t* ib = indices + (size_t)pc.indices_byte_offset + (size_t)prim * 3u * pc.stride;
+    uint32_t idx[3];
+    for (int k = 0; k < 3; k++) {  // byte loads: an index buffer's byte offset need not be aligned to its stride
+      const uint8_t* q = ib + (size_t)k * pc.stride;
+      idx[k] = pc.stride == 2 ? ((uint32_t)q[0] | (uint32_t)q[1] << 8) : ((uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24);
+      idx[k] += pc.first_vertex;
+      if (idx[k] >= vertex_count) {
+        atomicOr(error, 1u);
+        idx[k] = 0;
+      }
+    }
+    BvhTri t;
+    for (int a = 0; a < 3; a++) {
+      t.v0[a] = vertices[idx[0]].position[a];
+      t.v1[a] = vertices[idx[1]].position[a];
+      t.v2[a] = vertices[idx[2]].position[a];
+    }
+    t.id = (prim << 16) | pc.id_bits;
+    t.pad1 = t.pad2 = 0;
+    tris[i] = t;
+    LBox b;
+    for (int a = 0; a < 3; a++) {
+      b.lo[a] = fminf(fminf(t.v0[a], t.v1[a]), t.v2[a]);
+      b.hi[a] = fmaxf(fmaxf(t.v0[a], t.v1[a]), t.v2[a]);
+      c_lo[a] = c_hi[a] = 0.5f * (b.lo[a] + b.hi[a]);
+    }
+    boxes[i] = b;
+  }
+  for (int a = 0; a < 3; a++) {
+    const float mn = wave_min(c_lo[a]), mx = wave_max(c_hi[a]);
+    if ((threadIdx.x & 63u) == 0 && mn <= mx) {
+      atomicMin(&cbounds[a], f2ord(mn));
+      atomicMax(&cbounds[3 + a], f2ord(mx));
+    }
+  }
+}
+
+// Bottom-up boxes and heights in ONE launch: every leaf walks towards the root; at an internal node the first arrival
+// stops, the second one (both subtrees are complete then) takes the union and goes on. The counter is an acquire-release
+// atomic at device scope, which orders the box stores of one thread before the loads of the other. Unions are min / max:
+// the result does not depend on who arrives first.
+struct LNode {
+  float lo[3], hi[3];
+  uint32_t height, pad;
+};
+__global__ void __launch_bounds__(LB_BLOCK) k_lbvh_refit(int n, const uint32_t* left, const uint32_t* right, const uint32_t* parent_of_internal, const uint32_t* parent_of_leaf,
+                                                          const uint32_t* sorted, const LBox* leaf_boxes, LNode* node_boxes, uint32_t* visits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t cur = parent_of_leaf[i];
+  for (int guard = 0; guard < 4096; guard++) {  // a radix tree over 63-bit keys + 32 index bits is at most ~96 high
+    const uint32_t earlier = __hip_atomic_fetch_add(&visits[cur], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (earlier == 0) return;
+    const uint32_t L = left[cur], R = right[cur];
+    LNode u;
+    uint32_t hl = 0, hr = 0;
+    LBox a, b;
+    if (L & 0x80000000u) {
+      a = leaf_boxes[sorted[L & 0x7FFFFFFFu]];
+    } else {
+      const LNode t = node_boxes[L];
+      for (int k = 0; k < 3; k++) {
+        a.lo[k] = t.lo[k];
+        a.hi[k] = t.hi[k];
+      }
+      hl = t.height;
+    }
+    if (R & 0x80000000u) {
+      b = leaf_boxes[sorted[R & 0x7FFFFFFFu]];
+    } else {
+      const LNode t = node_boxes[R];
+      for (int k = 0; k < 3; k++) {
+        b.lo[k] = t.lo[k];
+        b.hi[k] = t.hi[k];
+      }
+      hr = t.height;
+    }
+    for (int k = 0; k < 3; k++) {
+      u.lo[k] = fminf(a.lo[k], b.lo[k]);
+      u.hi[k] = fmaxf(a.hi[k], b.hi[k]);
+    }
+    u.height = 1u + max(hl, hr);
+    u.pad = 0;
+    node_boxes[cur] = u;
+    if (cur == 0) return;
+    cur = parent_of_internal[cur];
+  }
+}
+
+// k_lbvh_emit for the device-resident build: the node goes out twice, unpacked (what the host keeps for the treetop and
+// top-level rebuilds) and packed into its slot of the array the kernels traverse (bvh_build.h: pack_node).
+__global__ void __launch_bounds__(LB_BLOCK) k_lbvh_emit_packed(int n, uint32_t node_base, uint32_t tri_base, const uint32_t* left, const uint32_t* right, const uint32_t* sorted,
+                                                                const LBox* leaf_boxes, const LNode* node_boxes, BvhNode* raw, BvhNodeSlot* packed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const uint32_t c[2] = {left[i], right[i]};
+  BvhNode out;
+  memset(&out, 0, sizeof(out));
+  for (int k = 0; k < 2; k++) {
+    const bool leaf = c[k] & 0x80000000u;
+    const uint32_t idx = c[k] & 0x7FFFFFFFu;
+    LBox b;
+    if (leaf) {
+      b = leaf_boxes[sorted[idx]];
+    } else {
+      const LNode t = node_boxes[idx];
+      for (int a = 0; a < 3; a++) {
+        b.lo[a] = t.lo[a];
+        b.hi[a] = t.hi[a];
+      }
+    }
+    float* xy = k == 0 ? out.n0xy : out.n1xy;
+    xy[0] = b.lo[0];
+    xy[1] = b.hi[0];
+    xy[2] = b.lo[1];
+    xy[3] = b.hi[1];
+    out.nz[2 * k] = b.lo[2];
+    out.nz[2 * k + 1] = b.hi[2];
+    if (leaf) {
+      out.ref[k] = BVH_LEAF_BIT | ((tri_base + idx) << 2);
+    } else {  // two sibling leaves become one two-triangle leaf (see k_lbvh_emit)
+      const uint32_t gl = left[idx], gr = right[idx];
+      if ((gl & 0x80000000u) && (gr & 0x80000000u))
+        out.ref[k] = BVH_LEAF_BIT | ((tri_base + (gl & 0x7FFFFFFFu)) << 2) | 1u;
+      else
+        out.ref[k] = node_base + idx;
+    }
+  }
+  raw[node_base + i] = out;
+  BvhNodeSlot slot;
+  memset(&slot, 0, sizeof(slot));
+  slot.n = pack_node(out);
+  packed[node_base + i] = slot;
+}
+
+struct LResult {
+  LNode root;
+  uint32_t error, pad[3];
+};
+__global__ void k_lbvh_result(const LNode* node_boxes, const uint32_t* error, LResult* out) {
+  out->root = node_boxes[0];
+  out->error = *error;
+}
+
 // scratch arena of lbvh_build_gpu, kept for the life of the process (one build at a time: the mutex)
 struct Arena {
   char* base = nullptr;
@@ -313,6 +487,110 @@ bool lbvh_build_gpu(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& no
     root_ref = node_base;  // internal node 0 is the root
     // done[root] is the pass in which the root was finished = the height of the tree = the bound of the stack
     LB_TRY(hipMemcpy(&stack_need, d_done, 4, hipMemcpyDeviceToHost));
+  }
+done:
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  return ok;
+}
+
+
+bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece>& pieces, uint32_t node_base, uint32_t tri_base, uint32_t& root_ref, uint32_t& height, float bounds[6],
+                       float& gpu_ms, std::string& err) {
+  uint32_t n = 0;
+  for (const MeshPiece& pc : pieces) n += pc.prim_count;
+  if (n < 2 || pieces.empty()) {
+    err = "lbvh: a device build needs at least two triangles";
+    return false;
+  }
+  bool ok = true;
+  hipStream_t st = (hipStream_t)tgt.stream;
+  BvhTri* d_in = nullptr;
+  LBox* d_leaf = nullptr;
+  LNode* d_node = nullptr;
+  uint32_t *d_cb = nullptr, *d_vals = nullptr, *d_sorted = nullptr, *d_left = nullptr, *d_right = nullptr, *d_pi = nullptr, *d_pl = nullptr, *d_visits = nullptr, *d_err = nullptr;
+  unsigned long long *d_keys = nullptr, *d_keys_sorted = nullptr;
+  MeshPiece* d_pieces = nullptr;
+  LResult* d_res = nullptr;
+  void* d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::unique_lock<std::mutex> arena_lock;
+  const uint32_t grid = (n + LB_BLOCK - 1) / LB_BLOCK;
+  {
+    size_t tmp_need = 0;
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_need, d_keys, d_keys_sorted, d_vals, d_sorted, (int)n, 0, 63, st));
+    tmp_bytes = tmp_need;
+    int dev = 0;
+    LB_TRY(hipGetDevice(&dev));
+    Arena& A = arena(dev);
+    arena_lock = std::unique_lock<std::mutex>(A.mutex);
+    size_t total = 0;
+    auto reserve = [&](size_t bytes) {
+      const size_t at = total;
+      total += (bytes + 255) & ~(size_t)255;
+      return at;
+    };
+    const size_t o_in = reserve((size_t)n * sizeof(BvhTri)), o_leaf = reserve((size_t)n * sizeof(LBox)), o_node = reserve((size_t)n * sizeof(LNode));
+    const size_t o_cb = reserve(8 * 4), o_keys = reserve((size_t)n * 8), o_keys2 = reserve((size_t)n * 8), o_vals = reserve((size_t)n * 4), o_sorted = reserve((size_t)n * 4);
+    const size_t o_left = reserve((size_t)n * 4), o_right = reserve((size_t)n * 4), o_pi = reserve((size_t)n * 4), o_pl = reserve((size_t)n * 4), o_visits = reserve((size_t)n * 4);
+    const size_t o_pieces = reserve(pieces.size() * sizeof(MeshPiece)), o_res = reserve(sizeof(LResult)), o_tmp = reserve(tmp_bytes);
+    if (A.device != dev || A.bytes < total) {
+      if (A.base) (void)hipFree(A.base);
+      A.base = nullptr;
+      A.bytes = 0;
+      LB_TRY(hipMalloc((void**)&A.base, total));
+      A.bytes = total;
+      A.device = dev;
+    }
+    char* b = A.base;
+    d_in = (BvhTri*)(b + o_in);
+    d_leaf = (LBox*)(b + o_leaf);
+    d_node = (LNode*)(b + o_node);
+    d_cb = (uint32_t*)(b + o_cb);
+    d_err = d_cb + 6;
+    d_keys = (unsigned long long*)(b + o_keys);
+    d_keys_sorted = (unsigned long long*)(b + o_keys2);
+    d_vals = (uint32_t*)(b + o_vals);
+    d_sorted = (uint32_t*)(b + o_sorted);
+    d_left = (uint32_t*)(b + o_left);
+    d_right = (uint32_t*)(b + o_right);
+    d_pi = (uint32_t*)(b + o_pi);
+    d_pl = (uint32_t*)(b + o_pl);
+    d_visits = (uint32_t*)(b + o_visits);
+    d_pieces = (MeshPiece*)(b + o_pieces);
+    d_res = (LResult*)(b + o_res);
+    d_tmp = b + o_tmp;
+    LB_TRY(hipEventCreate(&e0));
+    LB_TRY(hipEventCreate(&e1));
+    LB_TRY(hipEventRecord(e0, st));
+    const uint32_t init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0};  // centroid bounds (ordered), then the error word
+    LB_TRY(hipMemcpyAsync(d_cb, init, sizeof(init), hipMemcpyHostToDevice, st));
+    LB_TRY(hipMemcpyAsync(d_pieces, pieces.data(), pieces.size() * sizeof(MeshPiece), hipMemcpyHostToDevice, st));
+    LB_TRY(hipMemsetAsync(d_visits, 0, (size_t)n * 4, st));
+    hipLaunchKernelGGL(k_lbvh_fetch, dim3(grid), dim3(LB_BLOCK), 0, st, d_pieces, (uint32_t)pieces.size(), tgt.vertices, tgt.vertex_count, tgt.indices, n, d_in, d_leaf, d_cb, d_err);
+    hipLaunchKernelGGL(k_lbvh_morton, dim3(grid), dim3(LB_BLOCK), 0, st, d_leaf, n, d_cb, d_keys, d_vals);
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_vals, d_sorted, (int)n, 0, 63, st));
+    hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(grid), dim3(LB_BLOCK), 0, st, d_keys_sorted, (int)n, d_left, d_right, d_pi, d_pl);
+    hipLaunchKernelGGL(k_lbvh_refit, dim3(grid), dim3(LB_BLOCK), 0, st, (int)n, d_left, d_right, d_pi, d_pl, d_sorted, d_leaf, d_node, d_visits);
+    hipLaunchKernelGGL(k_lbvh_emit_packed, dim3(grid), dim3(LB_BLOCK), 0, st, (int)n, node_base, tri_base, d_left, d_right, d_sorted, d_leaf, d_node, tgt.raw_nodes, tgt.nodes);
+    hipLaunchKernelGGL(k_lbvh_gather, dim3(grid), dim3(LB_BLOCK), 0, st, d_in, d_sorted, n, tgt.tris + tri_base);
+    hipLaunchKernelGGL(k_lbvh_result, dim3(1), dim3(1), 0, st, d_node, d_err, d_res);
+    LB_TRY(hipEventRecord(e1, st));
+    LResult res;
+    LB_TRY(hipMemcpyAsync(&res, d_res, sizeof(res), hipMemcpyDeviceToHost, st));
+    LB_TRY(hipStreamSynchronize(st));
+    LB_TRY(hipGetLastError());
+    LB_TRY(hipEventElapsedTime(&gpu_ms, e0, e1));
+    if (res.error) {
+      err = "vertex index exceeds gVertices";
+      ok = false;
+      goto done;
+    }
+    root_ref = node_base;  // internal node 0 is the root
+    height = res.root.height;
+    memcpy(bounds, res.root.lo, 12);
+    memcpy(bounds + 3, res.root.hi, 12);
   }
 done:
   if (e0) (void)hipEventDestroy(e0);

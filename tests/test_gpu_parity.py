@@ -412,6 +412,111 @@ def test_gpu_lbvh_builder_on_coincident_and_clustered_triangles():
     print("clustered: lbvh build %.1f ms (gpu %.2f), sah %.1f ms" % (b[2]["bvh_build_ms"], b[2]["bvh_build_gpu_ms"], a[2]["bvh_build_ms"]))
 
 
+def test_gpu_lbvh_rebuild_is_device_resident(atrium_scene):
+    """bvh_builder = 1 builds in place from the uploaded scene arrays (lbvh.hip: lbvh_build_device): no triangle and no
+    node goes through the host except the one copy of the unpacked nodes the treetop selection reads. A REbuild (arena,
+    device arrays and the pinned host buffer exist) of the 1 M-triangle atrium must stay under 15 ms for the builder and
+    the frame must not change."""
+    import time
+
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = atrium_scene
+    frame = camera.Frame(160, 90, cam["fovy"], cam["eye"], cam["target"])
+    r = BDPT(device=0)
+    try:
+        r.set_option("bvh_builder", 1)
+        r.update(sc)
+        first = r.render(frame, 0, 1)
+        build_ms, call_ms = [], []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            r.update(sc)
+            call_ms.append((time.perf_counter() - t0) * 1e3)
+            build_ms.append(r.stats()["bvh_build_ms"])
+        again = r.render(frame, 0, 1)
+        st = r.stats()
+    finally:
+        r.close()
+    assert np.array_equal(first["radiance"].view(np.uint32), again["radiance"].view(np.uint32))
+    print("atrium %d triangles: rebuild %.1f ms (builder, min of 4; GPU kernels %.2f ms), whole sthip_scene_upload call %.1f ms" % (sc.triangle_count, min(build_ms), st["bvh_build_gpu_ms"], min(call_ms)))
+    assert min(build_ms) <= 15.0, build_ms
+
+
+def test_gpu_lbvh_device_and_host_regions():
+    """A scene whose bottom levels are split between the two builders in device mode: the forest's shared meshes (>= 64
+    triangles: built on the GPU in place) next to tiny meshes (< 64 triangles: host SAH, placed behind the device region
+    with their references offset), under a host-built top level — frames and ray batches equal the SAH build's, also
+    after instances moved (top level rebuilt through the host copy of the nodes)."""
+    from stratum_amd.bdpt import BDPT
+    from stratum_amd.scene import translate
+
+    sc, cam = scenes.forest(n_instances=40, tree_tris=900, tree_kinds=3)
+    sc2, _ = scenes.spheres_room()  # small boxes: meshes of 12 triangles, and spheres as top-level entries
+    for scene_, cam_ in ((sc, cam), (sc2, scenes.spheres_room()[1])):
+        frame = camera.Frame(192, 96, cam_["fovy"], cam_["eye"], cam_["target"])
+        rays = random_rays(20000, 4, -3.0, 3.0)
+        res = {}
+        for kind in (0, 1):
+            r = BDPT(device=0, args={"maxDiffuseVertices": 3})
+            try:
+                r.set_option("bvh_builder", kind)
+                r.update(scene_)
+                a = (r.render(frame, 1, 2), r.trace(rays))
+                kinds = scene_.instances["packed"][:, 0] & 0xF
+                ident = np.array([np.array_equal(m, np.eye(4, dtype=np.float32)[:3]) for m in scene_.transforms["m"]])
+                movers = np.nonzero((kinds == 0) & ~ident)[0]
+                moved = None
+                if movers.size:
+                    saved = scene_.transforms["m"][movers[0]].copy()
+                    m = saved.copy()
+                    m[:, 3] += np.float32(0.25)
+                    scene_.set_instance_transform(int(movers[0]), m)
+                    r.update_transforms(scene_)
+                    moved = r.render(frame, 1, 2)
+                    scene_.set_instance_transform(int(movers[0]), saved)
+                res[kind] = (a, moved)
+            finally:
+                r.close()
+        (a0, m0), (a1, m1) = res[0], res[1]
+        assert np.array_equal(a0[0]["radiance"].view(np.uint32), a1[0]["radiance"].view(np.uint32))
+        assert np.array_equal(a0[0]["ray_count"], a1[0]["ray_count"])
+        for f in ("instance_primitive_index", "t", "b1", "b2"):
+            assert np.array_equal(a0[1][f].view(np.uint32), a1[1][f].view(np.uint32)), f
+        if m0 is not None:
+            assert np.array_equal(m0["radiance"].view(np.uint32), m1["radiance"].view(np.uint32))
+            assert not np.array_equal(m0["radiance"], a0[0]["radiance"])
+
+
+def test_gpu_lbvh_rejects_a_bad_index():
+    """The index check moves into the fetch kernel in device mode: a vertex index outside gVertices is still an
+    STHIP_ERR_INVALID_ARGUMENT, and the context then has no scene."""
+    from stratum_amd import _lib
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = scenes.atrium(target_tris=3000)
+    good = sc.indices.copy()
+    tri_insts = np.nonzero((sc.instances["packed"][:, 0] & 0xF) == 0)[0]
+    last = max(tri_insts, key=lambda i: int(sc.instances["packed"][i, 3]))  # the instance whose indices end the buffer
+    stride, first_vertex = int(sc.instances["packed"][last, 1] >> 28), int(sc.instances["packed"][last, 2])
+    value = 0xFFFF if stride == 2 else 0x7FFFFFFF
+    assert first_vertex + value >= sc.vertices.shape[0]
+    r = BDPT(device=0)
+    try:
+        r.set_option("bvh_builder", 1)
+        r.update(sc)
+        sc.indices = good.copy()
+        sc.indices[-stride:] = np.frombuffer(value.to_bytes(stride, "little"), dtype=np.uint8)  # the last index of the last triangle
+        with pytest.raises(_lib.StratumHipError, match="vertex index exceeds gVertices"):
+            r.update(sc)
+        with pytest.raises(_lib.StratumHipError):
+            r.render(camera.Frame(32, 16, cam["fovy"], cam["eye"], cam["target"]))
+        sc.indices = good
+        r.update(sc)  # and the context recovers with a good scene
+        r.render(camera.Frame(32, 16, cam["fovy"], cam["eye"], cam["target"]))
+    finally:
+        r.close()
+
 @pytest.mark.parametrize("flags", [[], ["~raycones"], ["flipnormalmaps", "fliptriangleuvs"], ["~normalmaps"], ["shadingnormalshadowfix"]])
 def test_textured_scene(flags):
     """Image values (base colour, roughness/metallic maps, textured emitter), mip selection through ray cones,
