@@ -162,6 +162,7 @@ struct sthip_ctx {
   bool packet_primary = true;  // the first bounce is traced as wave packets (k_trace_primary)
   bool fuse_trace = true;  // closest-hit rays of a bounce and the shadow rays of the previous one in one launch
   int bvh_builder = 0;  // sthip::BvhBuilderKind
+  int lbvh_algorithm = 1, ploc_radius = 16;  // of the GPU builder (bvh_build.h: DeviceBuildTarget)
   sthip_stats stats{};
   bool stats_pending = false;  // ray / traversal counters of the last render still live on the device
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -346,6 +347,10 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->refill_idle = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
   else if (!strcmp(name, "bvh_builder"))
     ctx->bvh_builder = value == 1 ? 1 : 0;
+  else if (!strcmp(name, "lbvh_algorithm"))  // 0: Karras radix tree, 1: PLOC (default)
+    ctx->lbvh_algorithm = value == 0 ? 0 : 1;
+  else if (!strcmp(name, "ploc_radius"))
+    ctx->ploc_radius = (int)std::min<int64_t>(std::max<int64_t>(value, 1), 32);
   else if (!strcmp(name, "max_paths_in_flight"))
     ctx->max_paths_in_flight = (uint64_t)std::max<int64_t>(1, value);
   else if (!strcmp(name, "trace_blocks_per_cu"))
@@ -510,6 +515,8 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     target.vertex_count = s->vertex_count;
     target.indices = ctx->indices.p;
     target.stream = ctx->stream;
+    target.algorithm = ctx->lbvh_algorithm;
+    target.ploc_radius = ctx->ploc_radius;
     target.user = ctx;
     target.reserve = [](void* user, size_t node_capacity, size_t tri_capacity, sthip::DeviceBuildTarget& self) {
       sthip_ctx* c = (sthip_ctx*)user;

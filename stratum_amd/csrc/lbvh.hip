@@ -358,6 +358,197 @@ __global__ void k_lbvh_result(const LNode* node_boxes, const uint32_t* error, LR
   out->error = *error;
 }
 
+// ---- PLOC (Meister & Bittner 2018, "Parallel locally-ordered clustering"): agglomerative bottom-up construction ----
+// Clusters start as the triangles in Morton order. Every round each cluster looks `radius` places to either side for the
+// neighbour with which it makes the smallest box (surface area of the union); two clusters that choose each other merge
+// into a new node that takes the place of the lower one. The result is much closer to a SAH tree than the radix tree of
+// the Morton codes (which only ever splits at the spatial median): 0.95x instead of 0.875x of the SAH tree's trace rate
+// on the bench scene. Everything is deterministic: ties prefer the parity partner i ^ 1 (so a run of identical boxes —
+// 60 k copies of one triangle — pairs up completely every round instead of merging one pair per round), then the lower
+// index; new nodes are numbered by a prefix sum over the merging pairs, not by an atomic counter.
+struct PCluster {
+  float lo[3];
+  uint32_t id;  // 0x80000000 | sorted position of a triangle, or the index of an internal node
+  float hi[3];
+  uint32_t pad;
+};
+#define PLOC_MAX_RADIUS 32
+
+__global__ void __launch_bounds__(LB_BLOCK) k_ploc_init(uint32_t n, const uint32_t* sorted, const LBox* leaf_boxes, PCluster* cl) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const LBox b = leaf_boxes[sorted[i]];
+  PCluster c;
+  for (int a = 0; a < 3; a++) {
+    c.lo[a] = b.lo[a];
+    c.hi[a] = b.hi[a];
+  }
+  c.id = 0x80000000u | i;
+  c.pad = 0;
+  cl[i] = c;
+}
+
+__device__ __forceinline__ float union_area(const PCluster& a, const PCluster& b) {
+  const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
+  const float dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
+  const float dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+  return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void __launch_bounds__(LB_BLOCK) k_ploc_nn(const PCluster* cl, uint32_t c, int radius, uint32_t* nn) {
+  __shared__ PCluster tile[LB_BLOCK + 2 * PLOC_MAX_RADIUS];
+  const int base = (int)(blockIdx.x * blockDim.x) - radius;
+  for (int t = threadIdx.x; t < (int)blockDim.x + 2 * radius; t += blockDim.x) {
+    const int g = base + t;
+    if (g >= 0 && g < (int)c) tile[t] = cl[g];
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int)c) return;
+  const PCluster me = tile[threadIdx.x + radius];
+  float best = INFINITY;
+  int best_j = -1;
+  const int partner = i ^ 1;  // examined first: wins exact ties
+  if (partner < (int)c) {
+    best = union_area(me, tile[partner - base]);
+    best_j = partner;
+  }
+  const int lo = max(0, i - radius), hi = min((int)c - 1, i + radius);
+  for (int j = lo; j <= hi; j++) {
+    if (j == i || j == partner) continue;
+    const float d = union_area(me, tile[j - base]);
+    if (d < best) {
+      best = d;
+      best_j = j;
+    }
+  }
+  nn[i] = (uint32_t)best_j;
+}
+
+// keep: the slot survives the round (everything but the upper cluster of a merging pair); merge: the lower cluster of one
+__global__ void __launch_bounds__(LB_BLOCK) k_ploc_flags(const uint32_t* nn, uint32_t c, unsigned long long* flags) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const uint32_t j = nn[i];
+  const bool mutual = j < c && nn[j] == i;
+  const unsigned long long keep = !(mutual && i > j), merge = mutual && i < j;
+  flags[i] = keep | (merge << 32);
+}
+
+__global__ void __launch_bounds__(LB_BLOCK) k_ploc_apply(const PCluster* cl, uint32_t c, const uint32_t* nn, const unsigned long long* flags, const unsigned long long* ranks,
+                                                          uint32_t next_node, PCluster* out, uint32_t* left, uint32_t* right, LNode* nodes, uint32_t* parent_of_internal,
+                                                          uint32_t* parent_of_leaf, unsigned long long* totals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const unsigned long long f = flags[i], r = ranks[i];
+  if (i == c - 1) *totals = r + f;  // low half: clusters of the next round; high half: nodes made in this one
+  if (!(f & 1ull)) return;
+  const uint32_t pos = (uint32_t)(r & 0xFFFFFFFFull);
+  PCluster me = cl[i];
+  if (f >> 32) {
+    const PCluster other = cl[nn[i]];
+    const uint32_t k = next_node + (uint32_t)(r >> 32);
+    uint32_t h[2], cnt[2];
+    const uint32_t ids[2] = {me.id, other.id};
+    for (int s = 0; s < 2; s++) {
+      if (ids[s] & 0x80000000u) {
+        h[s] = 0;
+        cnt[s] = 1;
+        parent_of_leaf[ids[s] & 0x7FFFFFFFu] = k | ((uint32_t)s << 31);
+      } else {
+        h[s] = nodes[ids[s]].height;
+        cnt[s] = nodes[ids[s]].pad;
+        parent_of_internal[ids[s]] = k | ((uint32_t)s << 31);
+      }
+    }
+    left[k] = me.id;
+    right[k] = other.id;
+    LNode nd;
+    for (int a = 0; a < 3; a++) {
+      nd.lo[a] = me.lo[a] = fminf(me.lo[a], other.lo[a]);
+      nd.hi[a] = me.hi[a] = fmaxf(me.hi[a], other.hi[a]);
+    }
+    nd.height = 1u + max(h[0], h[1]);
+    nd.pad = cnt[0] + cnt[1];  // triangles below
+    nodes[k] = nd;
+    me.id = k;
+  }
+  out[pos] = me;
+}
+
+// Depth-first position of every leaf and first-leaf position of every internal node: walking up, every time the path
+// comes out of a RIGHT child the triangles of the left sibling lie before it. Makes the triangles of a subtree contiguous,
+// so a subtree of <= 2 triangles can be referenced as one leaf.
+__global__ void __launch_bounds__(LB_BLOCK) k_ploc_positions(uint32_t n, const uint32_t* left, const LNode* nodes, const uint32_t* parent_of_internal, const uint32_t* parent_of_leaf,
+                                                              uint32_t* leaf_pos, uint32_t* node_start) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * n - 1) return;
+  uint32_t link = t < n ? parent_of_leaf[t] : parent_of_internal[t - n];
+  uint32_t pos = 0;
+  for (int guard = 0; guard < 100000 && link != 0xFFFFFFFFu; guard++) {
+    const uint32_t p = link & 0x7FFFFFFFu;
+    if (link >> 31) {
+      const uint32_t l = left[p];
+      pos += (l & 0x80000000u) ? 1u : nodes[l].pad;
+    }
+    link = parent_of_internal[p];
+  }
+  if (t < n)
+    leaf_pos[t] = pos;
+  else
+    node_start[t - n] = pos;
+}
+
+__global__ void __launch_bounds__(LB_BLOCK) k_ploc_emit(uint32_t n, uint32_t node_base, uint32_t tri_base, const uint32_t* left, const uint32_t* right, const uint32_t* sorted,
+                                                         const LBox* leaf_boxes, const LNode* nodes, const uint32_t* leaf_pos, const uint32_t* node_start, BvhNode* raw, BvhNodeSlot* packed) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const uint32_t c[2] = {left[i], right[i]};
+  BvhNode out;
+  memset(&out, 0, sizeof(out));
+  for (int k = 0; k < 2; k++) {
+    const bool leaf = c[k] & 0x80000000u;
+    const uint32_t idx = c[k] & 0x7FFFFFFFu;
+    LBox b;
+    if (leaf) {
+      b = leaf_boxes[sorted[idx]];
+      out.ref[k] = BVH_LEAF_BIT | ((tri_base + leaf_pos[idx]) << 2);
+    } else {
+      const LNode t = nodes[idx];
+      for (int a = 0; a < 3; a++) {
+        b.lo[a] = t.lo[a];
+        b.hi[a] = t.hi[a];
+      }
+      if (t.pad <= BVH_MAX_LEAF_TRIS)  // (the skipped node stays in the array, unreferenced)
+        out.ref[k] = BVH_LEAF_BIT | ((tri_base + node_start[idx]) << 2) | (t.pad - 1u);
+      else
+        out.ref[k] = node_base + idx;
+    }
+    float* xy = k == 0 ? out.n0xy : out.n1xy;
+    xy[0] = b.lo[0];
+    xy[1] = b.hi[0];
+    xy[2] = b.lo[1];
+    xy[3] = b.hi[1];
+    out.nz[2 * k] = b.lo[2];
+    out.nz[2 * k + 1] = b.hi[2];
+  }
+  raw[node_base + i] = out;
+  BvhNodeSlot slot;
+  memset(&slot, 0, sizeof(slot));
+  slot.n = pack_node(out);
+  packed[node_base + i] = slot;
+}
+
+__global__ void __launch_bounds__(LB_BLOCK) k_ploc_gather(const BvhTri* in, const uint32_t* sorted, const uint32_t* leaf_pos, uint32_t n, BvhTri* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[leaf_pos[i]] = in[sorted[i]];
+}
+
+__global__ void k_ploc_result(const LNode* nodes, uint32_t root, const uint32_t* error, LResult* out) {
+  out->root = nodes[root];
+  out->error = *error;
+}
+
 // scratch arena of lbvh_build_gpu, kept for the life of the process (one build at a time: the mutex)
 struct Arena {
   char* base = nullptr;
@@ -512,6 +703,13 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
   unsigned long long *d_keys = nullptr, *d_keys_sorted = nullptr;
   MeshPiece* d_pieces = nullptr;
   LResult* d_res = nullptr;
+  PCluster* d_cl[2] = {nullptr, nullptr};
+  uint32_t *d_nn = nullptr, *d_leaf_pos = nullptr, *d_node_start = nullptr;
+  unsigned long long *d_flags = nullptr, *d_ranks = nullptr, *d_totals = nullptr;
+  void* d_scan_tmp = nullptr;
+  size_t scan_tmp_bytes = 0;
+  const bool ploc = tgt.algorithm == 1;
+  const int radius = std::min(std::max(tgt.ploc_radius, 1), PLOC_MAX_RADIUS);
   void* d_tmp = nullptr;
   size_t tmp_bytes = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -521,6 +719,7 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
     size_t tmp_need = 0;
     LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_need, d_keys, d_keys_sorted, d_vals, d_sorted, (int)n, 0, 63, st));
     tmp_bytes = tmp_need;
+    if (ploc) LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp_bytes, d_flags, d_ranks, (int)n, st));
     int dev = 0;
     LB_TRY(hipGetDevice(&dev));
     Arena& A = arena(dev);
@@ -535,6 +734,9 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
     const size_t o_cb = reserve(8 * 4), o_keys = reserve((size_t)n * 8), o_keys2 = reserve((size_t)n * 8), o_vals = reserve((size_t)n * 4), o_sorted = reserve((size_t)n * 4);
     const size_t o_left = reserve((size_t)n * 4), o_right = reserve((size_t)n * 4), o_pi = reserve((size_t)n * 4), o_pl = reserve((size_t)n * 4), o_visits = reserve((size_t)n * 4);
     const size_t o_pieces = reserve(pieces.size() * sizeof(MeshPiece)), o_res = reserve(sizeof(LResult)), o_tmp = reserve(tmp_bytes);
+    const size_t pn = ploc ? n : 0;
+    const size_t o_cl0 = reserve(pn * sizeof(PCluster)), o_cl1 = reserve(pn * sizeof(PCluster)), o_nn = reserve(pn * 4), o_flags = reserve(pn * 8), o_ranks = reserve(pn * 8), o_totals = reserve(8);
+    const size_t o_lpos = reserve(pn * 4), o_nstart = reserve(pn * 4), o_scan = reserve(ploc ? scan_tmp_bytes : 0);
     if (A.device != dev || A.bytes < total) {
       if (A.base) (void)hipFree(A.base);
       A.base = nullptr;
@@ -561,6 +763,15 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
     d_pieces = (MeshPiece*)(b + o_pieces);
     d_res = (LResult*)(b + o_res);
     d_tmp = b + o_tmp;
+    d_cl[0] = (PCluster*)(b + o_cl0);
+    d_cl[1] = (PCluster*)(b + o_cl1);
+    d_nn = (uint32_t*)(b + o_nn);
+    d_flags = (unsigned long long*)(b + o_flags);
+    d_ranks = (unsigned long long*)(b + o_ranks);
+    d_totals = (unsigned long long*)(b + o_totals);
+    d_leaf_pos = (uint32_t*)(b + o_lpos);
+    d_node_start = (uint32_t*)(b + o_nstart);
+    d_scan_tmp = b + o_scan;
     LB_TRY(hipEventCreate(&e0));
     LB_TRY(hipEventCreate(&e1));
     LB_TRY(hipEventRecord(e0, st));
@@ -571,11 +782,49 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
     hipLaunchKernelGGL(k_lbvh_fetch, dim3(grid), dim3(LB_BLOCK), 0, st, d_pieces, (uint32_t)pieces.size(), tgt.vertices, tgt.vertex_count, tgt.indices, n, d_in, d_leaf, d_cb, d_err);
     hipLaunchKernelGGL(k_lbvh_morton, dim3(grid), dim3(LB_BLOCK), 0, st, d_leaf, n, d_cb, d_keys, d_vals);
     LB_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_vals, d_sorted, (int)n, 0, 63, st));
-    hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(grid), dim3(LB_BLOCK), 0, st, d_keys_sorted, (int)n, d_left, d_right, d_pi, d_pl);
-    hipLaunchKernelGGL(k_lbvh_refit, dim3(grid), dim3(LB_BLOCK), 0, st, (int)n, d_left, d_right, d_pi, d_pl, d_sorted, d_leaf, d_node, d_visits);
-    hipLaunchKernelGGL(k_lbvh_emit_packed, dim3(grid), dim3(LB_BLOCK), 0, st, (int)n, node_base, tri_base, d_left, d_right, d_sorted, d_leaf, d_node, tgt.raw_nodes, tgt.nodes);
-    hipLaunchKernelGGL(k_lbvh_gather, dim3(grid), dim3(LB_BLOCK), 0, st, d_in, d_sorted, n, tgt.tris + tri_base);
-    hipLaunchKernelGGL(k_lbvh_result, dim3(1), dim3(1), 0, st, d_node, d_err, d_res);
+    uint32_t root_node = 0;  // Karras: internal node 0 is the root
+    if (!ploc) {
+      hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(grid), dim3(LB_BLOCK), 0, st, d_keys_sorted, (int)n, d_left, d_right, d_pi, d_pl);
+      hipLaunchKernelGGL(k_lbvh_refit, dim3(grid), dim3(LB_BLOCK), 0, st, (int)n, d_left, d_right, d_pi, d_pl, d_sorted, d_leaf, d_node, d_visits);
+      hipLaunchKernelGGL(k_lbvh_emit_packed, dim3(grid), dim3(LB_BLOCK), 0, st, (int)n, node_base, tri_base, d_left, d_right, d_sorted, d_leaf, d_node, tgt.raw_nodes, tgt.nodes);
+      hipLaunchKernelGGL(k_lbvh_gather, dim3(grid), dim3(LB_BLOCK), 0, st, d_in, d_sorted, n, tgt.tris + tri_base);
+      hipLaunchKernelGGL(k_lbvh_result, dim3(1), dim3(1), 0, st, d_node, d_err, d_res);
+    } else {
+      LB_TRY(hipMemsetAsync(d_pi, 0xFF, (size_t)n * 4, st));  // the root keeps "no parent"
+      hipLaunchKernelGGL(k_ploc_init, dim3(grid), dim3(LB_BLOCK), 0, st, n, d_sorted, d_leaf, d_cl[0]);
+      uint32_t c = n, next_node = 0;
+      int cur = 0;
+      for (uint32_t round = 0; c > 1; round++) {
+        if (round > 20000) {  // (a chain of ever closer neighbours merges one pair per round; never seen, bounded anyway)
+          err = "lbvh: PLOC did not converge";
+          ok = false;
+          goto done;
+        }
+        const uint32_t g = (c + LB_BLOCK - 1) / LB_BLOCK;
+        hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(LB_BLOCK), 0, st, d_cl[cur], c, radius, d_nn);
+        hipLaunchKernelGGL(k_ploc_flags, dim3(g), dim3(LB_BLOCK), 0, st, d_nn, c, d_flags);
+        size_t tb = scan_tmp_bytes;
+        LB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, tb, d_flags, d_ranks, (int)c, st));
+        hipLaunchKernelGGL(k_ploc_apply, dim3(g), dim3(LB_BLOCK), 0, st, d_cl[cur], c, d_nn, d_flags, d_ranks, next_node, d_cl[cur ^ 1], d_left, d_right, d_node, d_pi, d_pl, d_totals);
+        unsigned long long totals = 0;
+        LB_TRY(hipMemcpyAsync(&totals, d_totals, 8, hipMemcpyDeviceToHost, st));
+        LB_TRY(hipStreamSynchronize(st));
+        const uint32_t kept = (uint32_t)(totals & 0xFFFFFFFFull), made = (uint32_t)(totals >> 32);
+        if (made == 0 || kept + made != c) {
+          err = "lbvh: PLOC round made no progress";
+          ok = false;
+          goto done;
+        }
+        c = kept;
+        next_node += made;
+        cur ^= 1;
+      }
+      root_node = next_node - 1;  // = n - 2: the last node made
+      hipLaunchKernelGGL(k_ploc_positions, dim3((2 * n + LB_BLOCK - 1) / LB_BLOCK), dim3(LB_BLOCK), 0, st, n, d_left, d_node, d_pi, d_pl, d_leaf_pos, d_node_start);
+      hipLaunchKernelGGL(k_ploc_emit, dim3(grid), dim3(LB_BLOCK), 0, st, n, node_base, tri_base, d_left, d_right, d_sorted, d_leaf, d_node, d_leaf_pos, d_node_start, tgt.raw_nodes, tgt.nodes);
+      hipLaunchKernelGGL(k_ploc_gather, dim3(grid), dim3(LB_BLOCK), 0, st, d_in, d_sorted, d_leaf_pos, n, tgt.tris + tri_base);
+      hipLaunchKernelGGL(k_ploc_result, dim3(1), dim3(1), 0, st, d_node, root_node, d_err, d_res);
+    }
     LB_TRY(hipEventRecord(e1, st));
     LResult res;
     LB_TRY(hipMemcpyAsync(&res, d_res, sizeof(res), hipMemcpyDeviceToHost, st));
@@ -587,7 +836,7 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
       ok = false;
       goto done;
     }
-    root_ref = node_base;  // internal node 0 is the root
+    root_ref = node_base + root_node;
     height = res.root.height;
     memcpy(bounds, res.root.lo, 12);
     memcpy(bounds + 3, res.root.hi, 12);

@@ -352,9 +352,11 @@ def test_errors_are_reported_not_ignored(renderer, cornell):
         r.close()
 
 
-def test_gpu_lbvh_builder_gives_the_same_image(atrium_scene):
-    """The hit contract does not depend on the acceleration structure: the GPU LBVH (Karras radix tree) and the
-    host SAH tree give bit-identical frames and ray batches."""
+@pytest.mark.parametrize("algorithm", [0, 1])
+def test_gpu_lbvh_builder_gives_the_same_image(atrium_scene, algorithm):
+    """The hit contract does not depend on the acceleration structure: the GPU builders (0: Karras radix tree over the
+    Morton codes, 1: PLOC, agglomerative clustering along the Morton curve) and the host SAH tree give bit-identical
+    frames and ray batches."""
     from stratum_amd.bdpt import BDPT
 
     sc, cam = atrium_scene
@@ -365,6 +367,7 @@ def test_gpu_lbvh_builder_gives_the_same_image(atrium_scene):
         r = BDPT(device=0)
         try:
             r.set_option("bvh_builder", kind)
+            r.set_option("lbvh_algorithm", algorithm)
             r.update(sc)
             res[kind] = (r.render(frame, 3, 2), r.trace(rays), r.stats())
         finally:
@@ -379,7 +382,8 @@ def test_gpu_lbvh_builder_gives_the_same_image(atrium_scene):
     assert b[2]["bvh_build_gpu_ms"] > 0
 
 
-def test_gpu_lbvh_builder_on_coincident_and_clustered_triangles():
+@pytest.mark.parametrize("algorithm", [0, 1])
+def test_gpu_lbvh_builder_on_coincident_and_clustered_triangles(algorithm):
     """100 k triangles that defeat a Morton-code builder — 60 k exact copies of one triangle and 40 k inside a 1e-4 ball,
     next to walls metres away: the radix tree is deep (equal codes are split by index below a long common prefix), the
     traversal stack grows with it (more LDS per block, fewer blocks per CU), and the frame is still the SAH tree's frame,
@@ -396,6 +400,7 @@ def test_gpu_lbvh_builder_on_coincident_and_clustered_triangles():
         r = BDPT(device=0)
         try:
             r.set_option("bvh_builder", kind)
+            r.set_option("lbvh_algorithm", algorithm)
             r.update(sc)
             res[kind] = (r.render(frame, 0, 1), r.trace(rays), r.stats())
             flags, pc = r.mSamplingFlags, r.push_constants(frame)
@@ -409,10 +414,11 @@ def test_gpu_lbvh_builder_on_coincident_and_clustered_triangles():
     ref = oracle_py.OracleScene(sc).render(frame, pc, flags, 0, 1)
     assert np.array_equal(b[0]["visibility"]["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
     assert rel_l2(b[0]["radiance"], ref["radiance"]) <= 1e-4
-    print("clustered: lbvh build %.1f ms (gpu %.2f), sah %.1f ms" % (b[2]["bvh_build_ms"], b[2]["bvh_build_gpu_ms"], a[2]["bvh_build_ms"]))
+    print("clustered (algorithm %d): lbvh build %.1f ms (gpu %.2f), sah %.1f ms" % (algorithm, b[2]["bvh_build_ms"], b[2]["bvh_build_gpu_ms"], a[2]["bvh_build_ms"]))
 
 
-def test_gpu_lbvh_rebuild_is_device_resident(atrium_scene):
+@pytest.mark.parametrize("algorithm", [0, 1])
+def test_gpu_lbvh_rebuild_is_device_resident(atrium_scene, algorithm):
     """bvh_builder = 1 builds in place from the uploaded scene arrays (lbvh.hip: lbvh_build_device): no triangle and no
     node goes through the host except the one copy of the unpacked nodes the treetop selection reads. A REbuild (arena,
     device arrays and the pinned host buffer exist) of the 1 M-triangle atrium must stay under 15 ms for the builder and
@@ -426,6 +432,7 @@ def test_gpu_lbvh_rebuild_is_device_resident(atrium_scene):
     r = BDPT(device=0)
     try:
         r.set_option("bvh_builder", 1)
+        r.set_option("lbvh_algorithm", algorithm)
         r.update(sc)
         first = r.render(frame, 0, 1)
         build_ms, call_ms = [], []
@@ -439,7 +446,7 @@ def test_gpu_lbvh_rebuild_is_device_resident(atrium_scene):
     finally:
         r.close()
     assert np.array_equal(first["radiance"].view(np.uint32), again["radiance"].view(np.uint32))
-    print("atrium %d triangles: rebuild %.1f ms (builder, min of 4; GPU kernels %.2f ms), whole sthip_scene_upload call %.1f ms" % (sc.triangle_count, min(build_ms), st["bvh_build_gpu_ms"], min(call_ms)))
+    print("atrium %d triangles, algorithm %d, stack depth %d: rebuild %.1f ms (builder, min of 4; GPU kernels %.2f ms), whole sthip_scene_upload call %.1f ms" % (sc.triangle_count, algorithm, st.get("bvh_stack_depth", -1), min(build_ms), st["bvh_build_gpu_ms"], min(call_ms)))
     assert min(build_ms) <= 15.0, build_ms
 
 
