@@ -162,7 +162,15 @@ struct sthip_ctx {
   bool packet_primary = true;  // the first bounce is traced as wave packets (k_trace_primary)
   bool fuse_trace = true;  // closest-hit rays of a bounce and the shadow rays of the previous one in one launch
   int bvh_builder = 0;  // sthip::BvhBuilderKind
-  int lbvh_algorithm = 1, ploc_radius = 16;  // of the GPU builder (bvh_build.h: DeviceBuildTarget)
+  int lbvh_algorithm = 1, ploc_radius = 4;  // of the GPU builder (bvh_build.h: DeviceBuildTarget); radius measured: 4 traces fastest (2 .. 32 tried)
+  // levels of the per-lane LDS traversal stack at most; a higher tree runs the BOUNDED instantiations (traverse.h) with the
+  // full stack of an overflowing ray in global memory (spill)
+  // measured (atrium, PLOC tree 40 high): the bounded instantiation costs ~2.5 % per step, a fourth resident block is worth
+  // ~13 %, a treetop ~3 %: so the whole stack stays in LDS as long as four blocks of it fit (40 levels = 160 KB per CU)
+  uint32_t lds_stack_threshold = 40, lds_stack_cap = 32;
+  DevBuf<uint32_t> spill;
+  DevBuf<float4> deep_rays;  // rays that overflowed a bounded LDS stack (k_trace_deep), and their count
+  DevBuf<uint32_t> deep_count;
   sthip_stats stats{};
   bool stats_pending = false;  // ray / traversal counters of the last render still live on the device
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -172,6 +180,9 @@ struct sthip_ctx {
 // (deep LBVH trees of clustered scenes) the kernels must be told (hipFuncAttributeMaxDynamicSharedMemorySize), and the
 // CU holds fewer blocks. 152 KB leaves room for the runtime's own LDS use.
 #define STHIP_MAX_STACK_LDS ((size_t)152 * 1024)
+// Trees higher than the LDS cap (lds_stack_levels) keep only that many levels in LDS; the rare ray that needs more is traced
+// again with a global-memory stack of the tree's full height — bounded here so that the spill buffer stays small
+#define STHIP_MAX_STACK_DEPTH 512u
 
 #define HIP_TRY(ctx, expr)                                                                            \
   do {                                                                                                \
@@ -243,6 +254,10 @@ int sthip_create(int device, sthip_ctx** out_ctx) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -349,7 +364,9 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->bvh_builder = value == 1 ? 1 : 0;
   else if (!strcmp(name, "lbvh_algorithm"))  // 0: Karras radix tree, 1: PLOC (default)
     ctx->lbvh_algorithm = value == 0 ? 0 : 1;
-  else if (!strcmp(name, "ploc_radius"))
+  else if (!strcmp(name, "lds_stack_levels")) {  // takes effect at the next sthip_scene_upload / sthip_scene_update_transforms
+    ctx->lds_stack_cap = ctx->lds_stack_threshold = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 4), 150);
+  } else if (!strcmp(name, "ploc_radius"))
     ctx->ploc_radius = (int)std::min<int64_t>(std::max<int64_t>(value, 1), 32);
   else if (!strcmp(name, "max_paths_in_flight"))
     ctx->max_paths_in_flight = (uint64_t)std::max<int64_t>(1, value);
@@ -383,6 +400,9 @@ int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out) {
 }
 
 static size_t stack_bytes(const sthip_ctx* ctx);
+static size_t trace_lds_bytes(const sthip_ctx* ctx);
+static int trace_occupancy(const sthip_ctx* ctx, size_t lds_bytes);
+static int configure_stack(sthip_ctx* ctx);
 static int refresh_treetop(sthip_ctx* ctx);
 // packs `count` nodes and writes them into the node array from slot `first` on
 static hipError_t upload_nodes(sthip_ctx* ctx, size_t first, const BvhNode* nodes, size_t count) {
@@ -531,8 +551,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (!sthip::build_scene_bvh(*s, built, err, ctx->bvh_builder, device_build ? &target : nullptr))
     return fail(ctx, err.find("only triangle") != std::string::npos ? STHIP_ERR_UNSUPPORTED : STHIP_ERR_INVALID_ARGUMENT, "scene: " + err);
 
-  if ((size_t)built.stack_depth * STHIP_BLOCK * sizeof(uint32_t) > STHIP_MAX_STACK_LDS)
-    return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: the acceleration structure is too deep for the LDS traversal stack (use the SAH builder)");
+  if (built.stack_depth > STHIP_MAX_STACK_DEPTH) return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: the acceleration structure is too deep for the traversal stack (use the SAH builder)");
   ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
   ctx->stats.bvh_build_gpu_ms = built.gpu_build_ms;
   if (!device_build) {
@@ -702,15 +721,15 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (!built.nodes.empty()) memcpy(ctx->nodes_host.p + built.dev_nodes, built.nodes.data(), built.nodes.size() * sizeof(BvhNode));
   ctx->nodes_host.n = nodes_total;
   {
-    const int rc = refresh_treetop(ctx);
+    const int rc = configure_stack(ctx);
     if (rc != STHIP_OK) return rc;
   }
   ctx->has_scene = true;
   if (getenv("STHIP_VERBOSE")) {
     int per_cu = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false>, STHIP_BLOCK, stack_bytes(ctx));
-    fprintf(stderr, "[sthip] bvh (%s): %zu nodes, %zu tris, %zu top-level entries, stack depth %u (%zu B LDS / block), %d trace blocks / CU, build %.1f ms (GPU kernels %.2f ms)\n",
-            ctx->bvh_builder ? "lbvh/gpu" : "sah/host", (size_t)ctx->bvh_nodes, (size_t)ctx->bvh_tris, built.entries.size(), built.stack_depth, stack_bytes(ctx), per_cu, ctx->stats.bvh_build_ms,
+    per_cu = trace_occupancy(ctx, trace_lds_bytes(ctx));
+    fprintf(stderr, "[sthip] bvh (%s): %zu nodes, %zu tris, %zu top-level entries, stack depth %u (%zu B LDS / block%s, treetop %u nodes), %d trace blocks / CU, build %.1f ms (GPU kernels %.2f ms)\n",
+            ctx->bvh_builder ? "lbvh/gpu" : "sah/host", (size_t)ctx->bvh_nodes, (size_t)ctx->bvh_tris, built.entries.size(), built.stack_depth, stack_bytes(ctx), ctx->bvh.spill ? ", bounded" : "", ctx->bvh.top_count, per_cu, ctx->stats.bvh_build_ms,
             ctx->stats.bvh_build_gpu_ms);
   }
   return STHIP_OK;
@@ -725,16 +744,39 @@ static uint32_t grid_for(const sthip_ctx* ctx, size_t n) {
   return (uint32_t)std::max<size_t>(1, std::min(blocks, cap));
 }
 // Persistent trace kernels: as many blocks as are resident at once (LDS stack and VGPRs bound it).
-static uint32_t trace_grid(sthip_ctx* ctx, size_t lds_bytes) {
+static int trace_occupancy(const sthip_ctx* ctx, size_t lds_bytes) {  // resident k_trace blocks per CU with that much dynamic LDS
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false>, STHIP_BLOCK, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+  hipError_t e;
+  if (ctx->bvh.spill)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false, true>, STHIP_BLOCK, lds_bytes);
+  else
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false>, STHIP_BLOCK, lds_bytes);
+  return e == hipSuccess ? per_cu : 0;
+}
+static uint32_t trace_grid(sthip_ctx* ctx, size_t lds_bytes) {
+  int per_cu = trace_occupancy(ctx, lds_bytes);
+  if (per_cu < 1) per_cu = 2;
   if (ctx->trace_blocks_per_cu) per_cu = (int)ctx->trace_blocks_per_cu;
   return (uint32_t)(ctx->cu_count * per_cu);
 }
-static size_t stack_bytes(const sthip_ctx* ctx) { return (size_t)ctx->bvh.stack_depth * STHIP_BLOCK * sizeof(uint32_t); }
+static size_t stack_bytes(const sthip_ctx* ctx) { return (size_t)ctx->bvh.lds_levels * STHIP_BLOCK * sizeof(uint32_t); }
 
 // LDS of one k_trace block: the per-lane stacks and, behind them, the treetop
 static size_t trace_lds_bytes(const sthip_ctx* ctx) { return stack_bytes(ctx) + (size_t)ctx->bvh.top_count * sizeof(BvhNodePacked); }
+
+// Decides how the traversal stack of the current tree is held: all of it in LDS, or lds_stack_cap levels there and the
+// full height in global memory for the rays that overflow. Then the treetop takes the LDS that is left.
+static int configure_stack(sthip_ctx* ctx) {
+  const bool bounded = ctx->bvh.stack_depth > ctx->lds_stack_threshold;
+  ctx->bvh.lds_levels = bounded ? ctx->lds_stack_cap : ctx->bvh.stack_depth;
+  ctx->bvh.spill = nullptr;
+  if (bounded) {
+    // one column per lane of the largest grid a trace launch can have (persistent: resident blocks; ray batches use it too)
+    HIP_TRY(ctx, ctx->spill.ensure((size_t)ctx->cu_count * 8 * STHIP_BLOCK * ctx->bvh.stack_depth));
+    ctx->bvh.spill = ctx->spill.p;
+  }
+  return refresh_treetop(ctx);
+}
 
 // (Re)builds the treetop for the current top level: as many nodes as fit into the LDS the stacks leave free at the
 // occupancy the kernel's registers allow anyway (the treetop must not cost a resident block).
@@ -746,14 +788,16 @@ static int refresh_treetop(sthip_ctx* ctx) {
   if (!ctx->use_treetop || ctx->nodes_host.empty()) return STHIP_OK;
   int per_cu = 0;
   const size_t stack = stack_bytes(ctx);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false>, STHIP_BLOCK, stack) != hipSuccess || per_cu < 1) return STHIP_OK;
+  per_cu = trace_occupancy(ctx, stack);
+  if (per_cu < 1) return STHIP_OK;
   if (ctx->trace_blocks_per_cu) per_cu = (int)ctx->trace_blocks_per_cu;
   const size_t lds_per_cu = 160 * 1024, per_block = lds_per_cu / (size_t)per_cu;
   if (per_block < stack + 2048) return STHIP_OK;
   uint32_t capacity = (uint32_t)std::min<size_t>((per_block - stack - 1024) / sizeof(BvhNodePacked), 2048);
   while (capacity >= 16) {  // the allocation granularity is the runtime's: ask it
     int got = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, k_trace<false, false>, STHIP_BLOCK, stack + (size_t)capacity * sizeof(BvhNodePacked)) == hipSuccess && got >= per_cu) break;
+    got = trace_occupancy(ctx, stack + (size_t)capacity * sizeof(BvhNodePacked));
+    if (got >= per_cu) break;
     capacity -= 16;
   }
   if (capacity < 16) return STHIP_OK;
@@ -793,8 +837,9 @@ int sthip_trace_rays(sthip_ctx* ctx, const sthip_ray* rays, uint32_t ray_count, 
   }
   HIP_TRY(ctx, ctx->counters.ensure(CNT_TOTAL));
   HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_TOTAL * sizeof(unsigned long long), ctx->stream));
-  const uint32_t grid = grid_for(ctx, ray_count);
-  const size_t lds = stack_bytes(ctx);
+  // bounded stacks: the batch kernel walks with full-height stacks in global memory, one column per lane of a grid the spill buffer covers
+  const uint32_t grid = ctx->bvh.spill ? std::min<uint32_t>(grid_for(ctx, ray_count), (uint32_t)ctx->cu_count * 8u) : grid_for(ctx, ray_count);
+  const size_t lds = ctx->bvh.spill ? 0 : stack_bytes(ctx);
   DeviceBvh bvh = ctx->bvh;
   bvh.alpha_test = (ctx->has_alpha && (any_hit & 2u)) ? 1u : 0u;
   bvh.flip_uvs = (any_hit & 4u) ? 1u : 0u;
@@ -836,7 +881,7 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
   float center[3] = {ctx->bvh.scene_cx, ctx->bvh.scene_cy, ctx->bvh.scene_cz}, radius = ctx->bvh.scene_radius;
   std::string err;
   if (!sthip::rebuild_top_level(next, xf, inv, instance_count, tlas, root_ref, top_is_world, stack_depth, center, radius, err)) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: " + err);
-  if ((size_t)stack_depth * STHIP_BLOCK * sizeof(uint32_t) > STHIP_MAX_STACK_LDS) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: the new top level is too deep for the LDS traversal stack");
+  if (stack_depth > STHIP_MAX_STACK_DEPTH) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: the new top level is too deep for the traversal stack");
   if ((size_t)next.blas_nodes + tlas.size() > ctx->nodes.n) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: the new top level does not fit: upload the scene again");
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still read the old top level
   const uint32_t n = instance_count;
@@ -865,7 +910,7 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
     ctx->nodes_host.n = std::max(ctx->nodes_host.n, (size_t)next.blas_nodes + tlas.size());
   }
   ctx->top = std::move(next);
-  return refresh_treetop(ctx);
+  return configure_stack(ctx);
 }
 
 // One hash grid from one seed's staged appends (hashgrid.h): compact the stage in (path, vertex) order, hash the keys on
@@ -1109,6 +1154,10 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (shadow_stride * QUEUE_SEGMENTS > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many shadow rays in flight");
   const size_t shadow_entries = shadow_stride * QUEUE_SEGMENTS;  // per round; media ping-pong between two such regions
   HIP_TRY(ctx, ctx->shadow_rays.ensure(3 * shadow_entries * (media ? 2 : 1)));
+  if (ctx->bvh.spill) {  // bounded LDS stacks: room for every ray of a trace launch to overflow (4 x float4 each)
+    HIP_TRY(ctx, ctx->deep_rays.ensure(4 * (P + shadow_entries)));
+    HIP_TRY(ctx, ctx->deep_count.ensure(1));
+  }
   if (media) {
     if (2 * shadow_entries > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many shadow rays in flight");
     HIP_TRY(ctx, ctx->media_state.ensure(2 * P));
@@ -1215,6 +1264,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.queue[0] = ctx->queue0.p;
   p.queue[1] = ctx->queue1.p;
   p.shadow_rays = ctx->shadow_rays.p;
+  p.deep_rays = ctx->deep_rays.p;
+  p.deep_count = ctx->deep_count.p;
   p.presampled = ctx->presampled.p;
   p.counters = ctx->counters.p;
   p.qctl = ctx->qctl.p;
@@ -1307,7 +1358,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   }
   const uint32_t grid = shade_grid;
   const size_t lds = trace_lds_bytes(ctx);
-  const uint32_t tgrid = std::min<uint32_t>(trace_grid(ctx, lds), (uint32_t)((P + STHIP_BLOCK - 1) / STHIP_BLOCK));
+  uint32_t tgrid = std::min<uint32_t>(trace_grid(ctx, lds), (uint32_t)((P + STHIP_BLOCK - 1) / STHIP_BLOCK));
+  if (ctx->bvh.spill) tgrid = std::min<uint32_t>(tgrid, (uint32_t)ctx->cu_count * 8u);  // what the spill buffer has columns for (configure_stack)
   // closest-hit rays per path <= gMaxPathVertices - 1 (path.hlsli:960); without specular materials every scattering
   // vertex counts as a diffuse vertex, so the path also ends after gMaxDiffuseVertices + 1 rays (path.hlsli:964-966):
   // rounds beyond that would only be empty launches
@@ -1360,7 +1412,26 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       if (dc == TRACE_NONE && ds == TRACE_NONE) return STHIP_OK;
       launches_trace++;
       return timed(ms_trace, [&]() {
-        if (p.bvh.alpha_test || ctx->has_volumes) {  // alpha masks under eAlphaTest, volume instances: the instantiation that carries them
+        const bool alpha = p.bvh.alpha_test || ctx->has_volumes;  // alpha masks under eAlphaTest, volume instances: the instantiation that carries them
+        if (p.bvh.spill) {  // a tree higher than the LDS stack: the bounded instantiations, then the rays that overflowed
+          (void)hipMemsetAsync(p.deep_count, 0, 4, st);
+          const uint32_t dgrid = (uint32_t)ctx->cu_count * 8u;  // one spill column per thread (configure_stack)
+          if (alpha) {
+            if (ctx->count_traversal) {
+              hipLaunchKernelGGL((k_trace<true, true, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
+              hipLaunchKernelGGL((k_trace_deep<true, true>), dim3(dgrid), dim3(STHIP_BLOCK), 0, st, p);
+            } else {
+              hipLaunchKernelGGL((k_trace<false, true, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
+              hipLaunchKernelGGL((k_trace_deep<false, true>), dim3(dgrid), dim3(STHIP_BLOCK), 0, st, p);
+            }
+          } else if (ctx->count_traversal) {
+            hipLaunchKernelGGL((k_trace<true, false, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
+            hipLaunchKernelGGL((k_trace_deep<true, false>), dim3(dgrid), dim3(STHIP_BLOCK), 0, st, p);
+          } else {
+            hipLaunchKernelGGL((k_trace<false, false, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
+            hipLaunchKernelGGL((k_trace_deep<false, false>), dim3(dgrid), dim3(STHIP_BLOCK), 0, st, p);
+          }
+        } else if (alpha) {
           if (ctx->count_traversal)
             hipLaunchKernelGGL((k_trace<true, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
           else

@@ -72,7 +72,7 @@ struct DeviceBuildTarget {
   BvhTri* tris = nullptr;                            // device: leaf triangles
   void* stream = nullptr;                            // hipStream_t
   int algorithm = 1;                                 // 0: Karras radix tree over the Morton codes; 1: PLOC (better trees, ~2x the build time)
-  int ploc_radius = 16;                              // neighbours examined on either side (<= 32)
+  int ploc_radius = 4;                               // neighbours examined on either side (<= 32)
   // called once the sizes are known, before the first build: makes nodes / raw_nodes / tris at least this large
   bool (*reserve)(void* user, size_t node_capacity, size_t tri_capacity, DeviceBuildTarget& self) = nullptr;
   void* user = nullptr;

@@ -107,6 +107,9 @@ struct FrameParams {
   // them. Null without the flag, with media (walks through volumes break the lockstep: the non-coherent form stays)
   // and in rounds in which no path can reach the call.
   float4* rr;
+  // bounded LDS stacks (k_trace<., ., true>): the rays k_trace_deep traces again, 4 x float4 each, and their count
+  float4* deep_rays;
+  uint32_t* deep_count;
   float4* conn;               // per view path gMaxDiffuseVertices - 1 pending connection contributions of the last vertex shaded
   uint32_t shadow_stride;     // entries between the segments of shadow_rays (a vertex may queue gMaxDiffuseVertices records)
   // participating media (BDPT_FLAG_HAS_MEDIA): see the MEDIA instantiation of k_shade and k_shadow_media
@@ -293,11 +296,50 @@ DEV uint2 uniform_load2u(const void* base, size_t byte) {
 // trace_shadows, bdpt.hlsl:311-325) — the two are independent, and the shadow rays of the previous bounce fill the
 // lanes that would otherwise idle while the last, longest closest-hit rays of a launch finish. Either depth may be
 // TRACE_NONE.
-template <bool COUNT, bool ALPHA>
+// What a trace kernel does with a finished ray: a closest-hit query stores the hit for k_shade (or k_shadow_media, for a
+// segment of a walk through media); an unoccluded visibility ray adds what it carries where it belongs.
+template <bool ALPHA>
+DEV void finish_ray(const FrameParams& p, float4* target, uint32_t slot, bool shadow_lane, bool any, const RayHit& hit, f3 contribution) {
+  if (ALPHA && p.media && shadow_lane) {
+    p.shadow_hit[slot] = make_float4(hit.t, hit.b1, hit.b2, __uint_as_float(hit.ip));
+  } else if (!any) {
+    p.hit[slot] = make_float4(hit.t, hit.b1, hit.b2, __uint_as_float(hit.ip));
+  } else if (hit.ip == 0xFFFFFFFFu) {  // unoccluded
+    if (slot & 0x80000000u) {
+      // a light-path vertex seen by the camera: accumulate_light_contribution, path.hlsli:47-60 — quantised
+      // integer sums (order-independent, so the image does not depend on scheduling) + overflow bits
+      uint32_t* lt = p.light_trace + 4 * (size_t)(slot & 0x7FFFFFFFu);
+      const float q = (float)p.light_trace_quantization;
+      const float cf[3] = {fmaxf(0.0f, contribution.x) * q, fmaxf(0.0f, contribution.y) * q, fmaxf(0.0f, contribution.z) * q};
+      uint32_t overflow = 0;
+      for (int k = 0; k < 3; k++) {
+        const uint32_t ci = cf[k] >= 4294967296.0f ? 0xFFFFFFFFu : (cf[k] == cf[k] ? (uint32_t)cf[k] : 0u);
+        if (ci) {
+          const uint32_t prev = atomicAdd(&lt[k], ci);
+          if (ci > 0xFFFFFFFFu - prev) overflow |= 1u << k;
+        }
+      }
+      if (overflow) atomicOr(&lt[3], overflow);
+    } else if (slot & 0x40000000u) {  // a light-subpath connection: its own entry, folded into gRadiance in order later
+      p.conn[slot & 0x3FFFFFFFu] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+    } else {  // NEE: each pixel has at most one shadow ray per bounce
+      float4 c = target[slot];
+      c.x = c.x + contribution.x;
+      c.y = c.y + contribution.y;
+      c.z = c.z + contribution.z;
+      target[slot] = c;
+    }
+  }
+}
+
+// BOUNDED: the LDS stack has p.bvh.lds_levels < p.bvh.stack_depth levels (a tree too high for the LDS at full occupancy); a
+// ray that overflows it is handed to k_trace_deep, which traces it again with a full stack in global memory (p.bvh.spill) —
+// hits do not depend on the traversal order, so the result is the same as with an LDS stack of full height.
+template <bool COUNT, bool ALPHA, bool BOUNDED = false>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t depth_closest, uint32_t depth_shadow) {
   extern __shared__ uint32_t lds_stack[];
   // the treetop behind the stacks: copied once per (persistent) block
-  float4* top_lds = reinterpret_cast<float4*>(lds_stack + (size_t)p.bvh.stack_depth * STHIP_BLOCK);
+  float4* top_lds = reinterpret_cast<float4*>(lds_stack + (size_t)p.bvh.lds_levels * STHIP_BLOCK);
   for (uint32_t i = threadIdx.x; i < p.bvh.top_count * 3u; i += STHIP_BLOCK) top_lds[i] = p.bvh.top_nodes[i];
   __syncthreads();
   DeviceBvh bvh = p.bvh;  // k_trace's view: the entry table whose roots point into the treetop, and the treetop's root
@@ -315,8 +357,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
   cnt[0].clear();
   cnt[1].clear();
   uint32_t round_slots[2] = {0, 0}, busy_rounds[2] = {0, 0};
-  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, true> tr;
+  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, true, BOUNDED> tr;
   tr.top_lds = (const LdsFloat4*)top_lds;
+  if (BOUNDED) tr.limit = (p.bvh.lds_levels - 1u) * STHIP_BLOCK;
   tr.reset();
   tr.any = false;
   WaveWork work_c, work_s;
@@ -386,35 +429,17 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
       tr.round(bvh, stack, p.inner_min_lanes, cnt[0]);
     }
     if (busy && !tr.active()) {
-      if (ALPHA && p.media && shadow_lane) {
-        p.shadow_hit[slot] = make_float4(tr.hit.t, tr.hit.b1, tr.hit.b2, __uint_as_float(tr.hit.ip));
-      } else if (!tr.any) {
-        p.hit[slot] = make_float4(tr.hit.t, tr.hit.b1, tr.hit.b2, __uint_as_float(tr.hit.ip));
-      } else if (tr.hit.ip == 0xFFFFFFFFu) {  // unoccluded
-        if (slot & 0x80000000u) {
-          // a light-path vertex seen by the camera: accumulate_light_contribution, path.hlsli:47-60 — quantised
-          // integer sums (order-independent, so the image does not depend on scheduling) + overflow bits
-          uint32_t* lt = p.light_trace + 4 * (size_t)(slot & 0x7FFFFFFFu);
-          const float q = (float)p.light_trace_quantization;
-          const float cf[3] = {fmaxf(0.0f, contribution.x) * q, fmaxf(0.0f, contribution.y) * q, fmaxf(0.0f, contribution.z) * q};
-          uint32_t overflow = 0;
-          for (int k = 0; k < 3; k++) {
-            const uint32_t ci = cf[k] >= 4294967296.0f ? 0xFFFFFFFFu : (cf[k] == cf[k] ? (uint32_t)cf[k] : 0u);
-            if (ci) {
-              const uint32_t prev = atomicAdd(&lt[k], ci);
-              if (ci > 0xFFFFFFFFu - prev) overflow |= 1u << k;
-            }
-          }
-          if (overflow) atomicOr(&lt[3], overflow);
-        } else if (slot & 0x40000000u) {  // a light-subpath connection: its own entry, folded into gRadiance in order later
-          p.conn[slot & 0x3FFFFFFFu] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
-        } else {  // NEE: each pixel has at most one shadow ray per bounce
-          float4 c = target[slot];
-          c.x = c.x + contribution.x;
-          c.y = c.y + contribution.y;
-          c.z = c.z + contribution.z;
-          target[slot] = c;
-        }
+      if (BOUNDED && tr.overflowed) {
+        // the LDS stack was too short for this ray: its result is void. k_trace_deep traces it again with a stack as high as
+        // the tree (global memory) and does what would have been done here; hits do not depend on the traversal order
+        const uint32_t e = atomicAdd(p.deep_count, 1u);
+        float4* rec = p.deep_rays + 4 * (size_t)e;
+        rec[0] = make_float4(tr.o.x, tr.o.y, tr.o.z, tr.tmin);
+        rec[1] = make_float4(tr.d.x, tr.d.y, tr.d.z, tr.tmax);
+        rec[2] = make_float4(contribution.x, contribution.y, contribution.z, __uint_as_float(slot));
+        rec[3] = make_float4(__uint_as_float((shadow_lane ? 1u : 0u) | (tr.any ? 2u : 0u)), 0.0f, 0.0f, 0.0f);
+      } else {
+        finish_ray<ALPHA>(p, target, slot, shadow_lane, tr.any, tr.hit, contribution);
       }
       busy = false;
     }
@@ -427,6 +452,37 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
       wave_add(&p.counters[CNT_TRI_SLOTS + k], cnt[k].tri_slots);
       wave_add(&p.counters[CNT_ROUND_SLOTS + k], round_slots[k]);
       wave_add(&p.counters[CNT_BUSY_ROUNDS + k], busy_rounds[k]);
+    }
+  }
+}
+
+// The rays that overflowed the bounded LDS stacks of the k_trace launch before it (rare: a stack of 32 levels holds all
+// but pathological rays; tests force it with lds_stack_levels). A fixed grid, one full-height stack column per thread.
+template <bool COUNT, bool ALPHA>
+__global__ void __launch_bounds__(STHIP_BLOCK) k_trace_deep(FrameParams p) {
+  const uint32_t count = *p.deep_count;
+  const uint32_t tid = blockIdx.x * STHIP_BLOCK + threadIdx.x, threads = gridDim.x * STHIP_BLOCK;
+  uint32_t* column = p.bvh.spill + (size_t)tid * p.bvh.stack_depth;
+  float4* target = flag(p, STHIP_eDeferShadowRays) ? p.shadow_sum : p.radiance;
+  TraverseCounters cnt[2];
+  cnt[0].clear();
+  cnt[1].clear();
+  for (uint32_t e = tid; e < count; e += threads) {
+    const float4* rec = p.deep_rays + 4 * (size_t)e;
+    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+    const uint32_t bits = __float_as_uint(rec[3].x);
+    const bool any = (bits & 2u) != 0;
+    RayHit h;
+    if (any)
+      traverse<TRAV_ANY, COUNT, 1, ALPHA>(p.bvh, xyz(r0), xyz(r1), r0.w, r1.w, column, h, cnt[1]);
+    else
+      traverse<TRAV_CLOSEST, COUNT, 1, ALPHA>(p.bvh, xyz(r0), xyz(r1), r0.w, r1.w, column, h, cnt[0]);
+    finish_ray<ALPHA>(p, target, __float_as_uint(r2.w), (bits & 1u) != 0, any, h, xyz(r2));
+  }
+  if (COUNT) {
+    for (uint32_t k = 0; k < 2; k++) {
+      if (cnt[k].nodes) atomicAdd(&p.counters[CNT_NODES + k], (unsigned long long)cnt[k].nodes);
+      if (cnt[k].tris) atomicAdd(&p.counters[CNT_TRIS + k], (unsigned long long)cnt[k].tris);
     }
   }
 }
@@ -2234,7 +2290,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_batch(DeviceBvh bvh, cons
     const float4* r = reinterpret_cast<const float4*>(rays + i);
     const float4 a = r[0], b = r[1];
     RayHit h;
-    traverse<ANY_HIT ? TRAV_ANY : TRAV_CLOSEST, COUNT, STHIP_BLOCK, true>(bvh, xyz(a), xyz(b), a.w, b.w, lds_stack + threadIdx.x, h, cnt);
+    if (bvh.spill)  // bounded LDS stacks: the batch entry point walks with the full-height stack in global memory
+      traverse<ANY_HIT ? TRAV_ANY : TRAV_CLOSEST, COUNT, 1, true>(bvh, xyz(a), xyz(b), a.w, b.w, bvh.spill + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * bvh.stack_depth, h, cnt);
+    else
+      traverse<ANY_HIT ? TRAV_ANY : TRAV_CLOSEST, COUNT, STHIP_BLOCK, true>(bvh, xyz(a), xyz(b), a.w, b.w, lds_stack + threadIdx.x, h, cnt);
     sthip_hit out;
     out.t = h.t;
     out.b1 = h.b1;

@@ -362,8 +362,8 @@ __global__ void k_lbvh_result(const LNode* node_boxes, const uint32_t* error, LR
 // Clusters start as the triangles in Morton order. Every round each cluster looks `radius` places to either side for the
 // neighbour with which it makes the smallest box (surface area of the union); two clusters that choose each other merge
 // into a new node that takes the place of the lower one. The result is much closer to a SAH tree than the radix tree of
-// the Morton codes (which only ever splits at the spatial median): 0.95x instead of 0.875x of the SAH tree's trace rate
-// on the bench scene. Everything is deterministic: ties prefer the parity partner i ^ 1 (so a run of identical boxes —
+// the Morton codes (which only ever splits at the spatial median): 0.94x instead of 0.86x of the SAH tree's trace rate
+// on the bench scene (radius 4; larger radii lower the SAH cost a little but trace no faster). Everything is deterministic: ties prefer the parity partner i ^ 1 (so a run of identical boxes —
 // 60 k copies of one triangle — pairs up completely every round instead of merging one pair per round), then the lower
 // index; new nodes are numbered by a prefix sum over the merging pairs, not by an atomic counter.
 struct PCluster {
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(LB_BLOCK) k_ploc_flags(const uint32_t* nn, uin
 
 __global__ void __launch_bounds__(LB_BLOCK) k_ploc_apply(const PCluster* cl, uint32_t c, const uint32_t* nn, const unsigned long long* flags, const unsigned long long* ranks,
                                                           uint32_t next_node, PCluster* out, uint32_t* left, uint32_t* right, LNode* nodes, uint32_t* parent_of_internal,
-                                                          uint32_t* parent_of_leaf, unsigned long long* totals) {
+                                                          uint32_t* parent_of_leaf, uint32_t* eff, unsigned long long* totals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c) return;
   const unsigned long long f = flags[i], r = ranks[i];
@@ -448,19 +448,23 @@ __global__ void __launch_bounds__(LB_BLOCK) k_ploc_apply(const PCluster* cl, uin
   if (f >> 32) {
     const PCluster other = cl[nn[i]];
     const uint32_t k = next_node + (uint32_t)(r >> 32);
-    uint32_t h[2], cnt[2];
+    uint32_t h[2], cnt[2], ef[2];
     const uint32_t ids[2] = {me.id, other.id};
     for (int s = 0; s < 2; s++) {
       if (ids[s] & 0x80000000u) {
         h[s] = 0;
         cnt[s] = 1;
+        ef[s] = 0;
         parent_of_leaf[ids[s] & 0x7FFFFFFFu] = k | ((uint32_t)s << 31);
       } else {
         h[s] = nodes[ids[s]].height;
         cnt[s] = nodes[ids[s]].pad;
+        ef[s] = eff[ids[s]];
         parent_of_internal[ids[s]] = k | ((uint32_t)s << 31);
       }
     }
+    // nodes of the final array below (and including) this one: a subtree of <= BVH_MAX_LEAF_TRIS triangles becomes a leaf
+    eff[k] = ef[0] + ef[1] + (cnt[0] + cnt[1] > BVH_MAX_LEAF_TRIS ? 1u : 0u);
     left[k] = me.id;
     right[k] = other.id;
     LNode nd;
@@ -468,7 +472,8 @@ __global__ void __launch_bounds__(LB_BLOCK) k_ploc_apply(const PCluster* cl, uin
       nd.lo[a] = me.lo[a] = fminf(me.lo[a], other.lo[a]);
       nd.hi[a] = me.hi[a] = fmaxf(me.hi[a], other.hi[a]);
     }
-    nd.height = 1u + max(h[0], h[1]);
+    // the stack the subtree needs = its height in nodes of the final array (a subtree that becomes a leaf needs none)
+    nd.height = cnt[0] + cnt[1] > BVH_MAX_LEAF_TRIS ? 1u + max(h[0], h[1]) : 0u;
     nd.pad = cnt[0] + cnt[1];  // triangles below
     nodes[k] = nd;
     me.id = k;
@@ -476,33 +481,45 @@ __global__ void __launch_bounds__(LB_BLOCK) k_ploc_apply(const PCluster* cl, uin
   out[pos] = me;
 }
 
-// Depth-first position of every leaf and first-leaf position of every internal node: walking up, every time the path
-// comes out of a RIGHT child the triangles of the left sibling lie before it. Makes the triangles of a subtree contiguous,
-// so a subtree of <= 2 triangles can be referenced as one leaf.
-__global__ void __launch_bounds__(LB_BLOCK) k_ploc_positions(uint32_t n, const uint32_t* left, const LNode* nodes, const uint32_t* parent_of_internal, const uint32_t* parent_of_leaf,
-                                                              uint32_t* leaf_pos, uint32_t* node_start) {
+// Depth-first position of every leaf, first-leaf position and depth-first (pre-order) index of every internal node:
+// walking up, every time the path comes out of a RIGHT child the triangles (and nodes) of the left sibling lie before it.
+// Makes the triangles of a subtree contiguous, so a subtree of <= 2 triangles can be referenced as one leaf, and lays the
+// nodes out as the host SAH builder does — a node next to its left child, the skipped nodes (subtrees that became leaves)
+// not in the array at all: half the bytes and far better cache lines than the order the nodes were made in.
+__global__ void __launch_bounds__(LB_BLOCK) k_ploc_positions(uint32_t n, const uint32_t* left, const LNode* nodes, const uint32_t* eff, const uint32_t* parent_of_internal,
+                                                              const uint32_t* parent_of_leaf, uint32_t* leaf_pos, uint32_t* node_start, uint32_t* node_index) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * n - 1) return;
   uint32_t link = t < n ? parent_of_leaf[t] : parent_of_internal[t - n];
-  uint32_t pos = 0;
+  uint32_t pos = 0, index = 0;
   for (int guard = 0; guard < 100000 && link != 0xFFFFFFFFu; guard++) {
     const uint32_t p = link & 0x7FFFFFFFu;
+    index += 1;  // the ancestor itself comes before everything below it
     if (link >> 31) {
       const uint32_t l = left[p];
-      pos += (l & 0x80000000u) ? 1u : nodes[l].pad;
+      if (l & 0x80000000u) {
+        pos += 1u;
+      } else {
+        pos += nodes[l].pad;
+        index += eff[l];
+      }
     }
     link = parent_of_internal[p];
   }
-  if (t < n)
+  if (t < n) {
     leaf_pos[t] = pos;
-  else
+  } else {
     node_start[t - n] = pos;
+    node_index[t - n] = index;  // meaningful for nodes with more than BVH_MAX_LEAF_TRIS triangles (all their ancestors are such nodes too)
+  }
 }
 
 __global__ void __launch_bounds__(LB_BLOCK) k_ploc_emit(uint32_t n, uint32_t node_base, uint32_t tri_base, const uint32_t* left, const uint32_t* right, const uint32_t* sorted,
-                                                         const LBox* leaf_boxes, const LNode* nodes, const uint32_t* leaf_pos, const uint32_t* node_start, BvhNode* raw, BvhNodeSlot* packed) {
+                                                         const LBox* leaf_boxes, const LNode* nodes, const uint32_t* leaf_pos, const uint32_t* node_start, const uint32_t* node_index,
+                                                         BvhNode* raw, BvhNodeSlot* packed) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n - 1) return;
+  if (nodes[i].pad <= BVH_MAX_LEAF_TRIS) return;  // became a leaf of its parent
   const uint32_t c[2] = {left[i], right[i]};
   BvhNode out;
   memset(&out, 0, sizeof(out));
@@ -519,10 +536,10 @@ __global__ void __launch_bounds__(LB_BLOCK) k_ploc_emit(uint32_t n, uint32_t nod
         b.lo[a] = t.lo[a];
         b.hi[a] = t.hi[a];
       }
-      if (t.pad <= BVH_MAX_LEAF_TRIS)  // (the skipped node stays in the array, unreferenced)
+      if (t.pad <= BVH_MAX_LEAF_TRIS)
         out.ref[k] = BVH_LEAF_BIT | ((tri_base + node_start[idx]) << 2) | (t.pad - 1u);
       else
-        out.ref[k] = node_base + idx;
+        out.ref[k] = node_base + node_index[idx];
     }
     float* xy = k == 0 ? out.n0xy : out.n1xy;
     xy[0] = b.lo[0];
@@ -532,11 +549,12 @@ __global__ void __launch_bounds__(LB_BLOCK) k_ploc_emit(uint32_t n, uint32_t nod
     out.nz[2 * k] = b.lo[2];
     out.nz[2 * k + 1] = b.hi[2];
   }
-  raw[node_base + i] = out;
+  const uint32_t at = node_base + node_index[i];
+  raw[at] = out;
   BvhNodeSlot slot;
   memset(&slot, 0, sizeof(slot));
   slot.n = pack_node(out);
-  packed[node_base + i] = slot;
+  packed[at] = slot;
 }
 
 __global__ void __launch_bounds__(LB_BLOCK) k_ploc_gather(const BvhTri* in, const uint32_t* sorted, const uint32_t* leaf_pos, uint32_t n, BvhTri* out) {
@@ -704,7 +722,7 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
   MeshPiece* d_pieces = nullptr;
   LResult* d_res = nullptr;
   PCluster* d_cl[2] = {nullptr, nullptr};
-  uint32_t *d_nn = nullptr, *d_leaf_pos = nullptr, *d_node_start = nullptr;
+  uint32_t *d_nn = nullptr, *d_leaf_pos = nullptr, *d_node_start = nullptr, *d_node_index = nullptr, *d_eff = nullptr;
   unsigned long long *d_flags = nullptr, *d_ranks = nullptr, *d_totals = nullptr;
   void* d_scan_tmp = nullptr;
   size_t scan_tmp_bytes = 0;
@@ -736,7 +754,7 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
     const size_t o_pieces = reserve(pieces.size() * sizeof(MeshPiece)), o_res = reserve(sizeof(LResult)), o_tmp = reserve(tmp_bytes);
     const size_t pn = ploc ? n : 0;
     const size_t o_cl0 = reserve(pn * sizeof(PCluster)), o_cl1 = reserve(pn * sizeof(PCluster)), o_nn = reserve(pn * 4), o_flags = reserve(pn * 8), o_ranks = reserve(pn * 8), o_totals = reserve(8);
-    const size_t o_lpos = reserve(pn * 4), o_nstart = reserve(pn * 4), o_scan = reserve(ploc ? scan_tmp_bytes : 0);
+    const size_t o_lpos = reserve(pn * 4), o_nstart = reserve(pn * 4), o_nindex = reserve(pn * 4), o_eff = reserve(pn * 4), o_scan = reserve(ploc ? scan_tmp_bytes : 0);
     if (A.device != dev || A.bytes < total) {
       if (A.base) (void)hipFree(A.base);
       A.base = nullptr;
@@ -771,6 +789,8 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
     d_totals = (unsigned long long*)(b + o_totals);
     d_leaf_pos = (uint32_t*)(b + o_lpos);
     d_node_start = (uint32_t*)(b + o_nstart);
+    d_node_index = (uint32_t*)(b + o_nindex);
+    d_eff = (uint32_t*)(b + o_eff);
     d_scan_tmp = b + o_scan;
     LB_TRY(hipEventCreate(&e0));
     LB_TRY(hipEventCreate(&e1));
@@ -805,7 +825,7 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
         hipLaunchKernelGGL(k_ploc_flags, dim3(g), dim3(LB_BLOCK), 0, st, d_nn, c, d_flags);
         size_t tb = scan_tmp_bytes;
         LB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, tb, d_flags, d_ranks, (int)c, st));
-        hipLaunchKernelGGL(k_ploc_apply, dim3(g), dim3(LB_BLOCK), 0, st, d_cl[cur], c, d_nn, d_flags, d_ranks, next_node, d_cl[cur ^ 1], d_left, d_right, d_node, d_pi, d_pl, d_totals);
+        hipLaunchKernelGGL(k_ploc_apply, dim3(g), dim3(LB_BLOCK), 0, st, d_cl[cur], c, d_nn, d_flags, d_ranks, next_node, d_cl[cur ^ 1], d_left, d_right, d_node, d_pi, d_pl, d_eff, d_totals);
         unsigned long long totals = 0;
         LB_TRY(hipMemcpyAsync(&totals, d_totals, 8, hipMemcpyDeviceToHost, st));
         LB_TRY(hipStreamSynchronize(st));
@@ -820,8 +840,8 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
         cur ^= 1;
       }
       root_node = next_node - 1;  // = n - 2: the last node made
-      hipLaunchKernelGGL(k_ploc_positions, dim3((2 * n + LB_BLOCK - 1) / LB_BLOCK), dim3(LB_BLOCK), 0, st, n, d_left, d_node, d_pi, d_pl, d_leaf_pos, d_node_start);
-      hipLaunchKernelGGL(k_ploc_emit, dim3(grid), dim3(LB_BLOCK), 0, st, n, node_base, tri_base, d_left, d_right, d_sorted, d_leaf, d_node, d_leaf_pos, d_node_start, tgt.raw_nodes, tgt.nodes);
+      hipLaunchKernelGGL(k_ploc_positions, dim3((2 * n + LB_BLOCK - 1) / LB_BLOCK), dim3(LB_BLOCK), 0, st, n, d_left, d_node, d_eff, d_pi, d_pl, d_leaf_pos, d_node_start, d_node_index);
+      hipLaunchKernelGGL(k_ploc_emit, dim3(grid), dim3(LB_BLOCK), 0, st, n, node_base, tri_base, d_left, d_right, d_sorted, d_leaf, d_node, d_leaf_pos, d_node_start, d_node_index, tgt.raw_nodes, tgt.nodes);
       hipLaunchKernelGGL(k_ploc_gather, dim3(grid), dim3(LB_BLOCK), 0, st, d_in, d_sorted, d_leaf_pos, n, tgt.tris + tri_base);
       hipLaunchKernelGGL(k_ploc_result, dim3(1), dim3(1), 0, st, d_node, root_node, d_err, d_res);
     }
@@ -836,7 +856,7 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
       ok = false;
       goto done;
     }
-    root_ref = node_base + root_node;
+    root_ref = ploc ? node_base : node_base + root_node;  // PLOC lays its nodes out depth-first: the root comes first
     height = res.root.height;
     memcpy(bounds, res.root.lo, 12);
     memcpy(bounds + 3, res.root.hi, 12);

@@ -43,6 +43,11 @@ struct DeviceBvh {
   const TlasEntry* top_entries;
   uint32_t top_root_ref;
   uint32_t top_count;
+  // Bounded LDS stacks (trees higher than the LDS affords at full occupancy, e.g. Morton-built ones): the per-lane LDS stack
+  // has lds_levels levels (= stack_depth when unbounded); a ray that needs more is traced again with a stack of stack_depth
+  // words in global memory (`spill`: one column per resident lane of the persistent grid). nullptr: unbounded.
+  uint32_t lds_levels;
+  uint32_t* spill;
 };
 struct DeviceImage1 {
   uint32_t offset, w, h, pad;
@@ -206,9 +211,14 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
 #define TRAV_ANY 1      // occlusion: stop at the first accepted triangle (hit.ip = 0)
 #define TRAV_MIXED 2    // per lane, member `any` (the persistent kernel feeds closest-hit and shadow rays to one wave)
 // TOP: inner references may point into the treetop held in LDS at `top_lds` (BVH_TOP_BIT), see DeviceBvh
-template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
+// BOUNDED: the stack has fewer levels than the tree is high. `top` never passes `limit` (a push there lands in the spare
+// slot and is lost), `overflowed` records that it happened: the traversal still terminates (every reference on the stack is
+// one this ray wrote), but its result is void and the caller traces the ray again with a full-height stack.
+template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false, bool BOUNDED = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
 struct Traversal {
   const LdsFloat4* top_lds;  // TOP only
+  uint32_t limit;            // BOUNDED only: (levels - 1) * STRIDE
+  bool overflowed;           // BOUNDED only
   bool any;  // TRAV_MIXED only
   DEV bool is_any() const { return MODE == TRAV_ANY || (MODE == TRAV_MIXED && any); }
   f3 o, d;  // world-space ray
@@ -232,6 +242,7 @@ struct Traversal {
     hit.ip = 0xFFFFFFFFu;
     stack[0] = TRAV_DONE;
     top = STRIDE;
+    if (BOUNDED) overflowed = false;
     id_bits = 0;
     ref = bvh.root_ref;  // BVH_INVALID_REF == TRAV_DONE for an empty scene
     setup_space(sp, ro, rd, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
@@ -288,7 +299,13 @@ struct Traversal {
       const bool first1 = h1 && (!h0 || tn1 < tn0);  // descend into child 1 first
       stack[top] = first1 ? cr.x : cr.y;
       ref = (h0 || h1) ? (first1 ? cr.y : cr.x) : popped;
-      top = (h0 && h1) ? top + STRIDE : ((h0 || h1) ? top : top - STRIDE);
+      const uint32_t next_top = (h0 && h1) ? top + STRIDE : ((h0 || h1) ? top : top - STRIDE);
+      if (BOUNDED) {
+        overflowed |= next_top > limit;
+        top = min(next_top, limit);
+      } else {
+        top = next_top;
+      }
       }
       if ((uint32_t)__popcll(__ballot(!(ref & BVH_LEAF_BIT))) < min_lanes) break;
     }
@@ -359,7 +376,10 @@ struct Traversal {
         setup_space(sp, obj_point(m, o), obj_vector(m, d), sph.x, sph.y, sph.z, sph.w);
         id_bits = info.y;
         stack[top] = TRAV_EXIT_INSTANCE;
-        top += STRIDE;
+        if (BOUNDED && top + STRIDE > limit)
+          overflowed = true;
+        else
+          top += STRIDE;
       }
       // identity entry (the merged world-space mesh): same ray, same (larger, still conservative) padding,
       // id_bits stays 0 because its triangles carry their instance index themselves

@@ -450,6 +450,45 @@ def test_gpu_lbvh_rebuild_is_device_resident(atrium_scene, algorithm):
     assert min(build_ms) <= 15.0, build_ms
 
 
+@pytest.mark.parametrize("levels", [4, 7, 12])
+def test_bounded_lds_stack_gives_the_same_frames(levels):
+    """Trees higher than `lds_stack_levels` run k_trace<., ., BOUNDED>: the per-lane LDS stack has that many levels, a ray that
+    needs more is void and k_trace_deep traces it again with a full-height stack in global memory. Forced here with tiny
+    stacks on ordinary scenes (almost every ray overflows at 4 levels): frames, ray batches and ray counts must be those of
+    the unbounded kernel, bit for bit — closest hits and shadow rays, instances, light tracing and connections (the
+    visibility rays that splat or fill connection entries), media (segment walks), alpha masks."""
+    from stratum_amd.bdpt import BDPT
+
+    cases = [
+        (scenes.cornell_box(), [], {}),
+        (scenes.cornell_box(), ["connecttoviews", "connecttolightpaths"], {"maxDiffuseVertices": 3}),
+        (scenes.forest(n_instances=25, tree_tris=500, tree_kinds=2), ["~defershadowrays"], {}),
+        (scenes.spheres_room(), [], {"maxDiffuseVertices": 3}),
+        (scenes.cornell_box(fog=_fog()), [], {"maxDiffuseVertices": 3}),
+        (scenes.foliage(), ["alphatest"], {"maxDiffuseVertices": 3}),
+    ]
+    for (sc, cam), flags, args in cases:
+        frame = camera.Frame(96, 64, cam["fovy"], cam["eye"], cam["target"])
+        rays = random_rays(5000, 3, -2.5, 2.5)
+        out = {}
+        for cap in (None, levels):
+            r = BDPT(device=0, args=dict(args, bdptFlag=flags))
+            try:
+                if cap is not None:
+                    r.set_option("lds_stack_levels", cap)
+                r.update(sc)
+                out[cap] = (r.render(frame, 2, 2), r.trace(rays), r.trace(rays, any_hit=True))
+            finally:
+                r.close()
+        a, b = out[None], out[levels]
+        assert np.array_equal(a[0]["radiance"].view(np.uint32), b[0]["radiance"].view(np.uint32)), (sc.name, flags)
+        assert np.array_equal(a[0]["visibility"]["instance_primitive_index"], b[0]["visibility"]["instance_primitive_index"])
+        assert np.array_equal(a[0]["ray_count"], b[0]["ray_count"])
+        for k in (1, 2):
+            for f in ("instance_primitive_index", "t", "b1", "b2"):
+                assert np.array_equal(a[k][f].view(np.uint32), b[k][f].view(np.uint32)), (sc.name, f)
+
+
 def test_gpu_lbvh_device_and_host_regions():
     """A scene whose bottom levels are split between the two builders in device mode: the forest's shared meshes (>= 64
     triangles: built on the GPU in place) next to tiny meshes (< 64 triangles: host SAH, placed behind the device region
