@@ -121,6 +121,9 @@ struct sthip_ctx {
   DevBuf<BvhNodePacked> top_nodes;
   DevBuf<TlasEntry> top_entries;
   bool use_treetop = true;
+  // host builds: leaf triangles in the node array behind their parent (bvh_build.h: BuiltBvh::embedded). Measured on the
+  // bench scene: k_trace 2.30 ms either way (the leaf fetch is not what a step waits for), so off: two arrays are simpler
+  bool embed_leaves = false;
   // frame
   DevBuf<uint8_t> views;  // gViews | gViewTransforms | gPrevViews | gPrevInverseViewTransforms
   DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays, light_vertices, conn, media_state, shadow_hit, shadow_ext, shadow_result;
@@ -362,6 +365,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->refill_idle = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
   else if (!strcmp(name, "bvh_builder"))
     ctx->bvh_builder = value == 1 ? 1 : 0;
+  else if (!strcmp(name, "embed_leaves"))  // takes effect at the next sthip_scene_upload
+    ctx->embed_leaves = value != 0;
   else if (!strcmp(name, "lbvh_algorithm"))  // 0: Karras radix tree, 1: PLOC (default)
     ctx->lbvh_algorithm = value == 0 ? 0 : 1;
   else if (!strcmp(name, "lds_stack_levels")) {  // takes effect at the next sthip_scene_upload / sthip_scene_update_transforms
@@ -548,7 +553,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     };
   }
   const auto t_build0 = std::chrono::steady_clock::now();
-  if (!sthip::build_scene_bvh(*s, built, err, ctx->bvh_builder, device_build ? &target : nullptr))
+  if (!sthip::build_scene_bvh(*s, built, err, ctx->bvh_builder, device_build ? &target : nullptr, ctx->embed_leaves && STHIP_NODE_STRIDE == 48))
     return fail(ctx, err.find("only triangle") != std::string::npos ? STHIP_ERR_UNSUPPORTED : STHIP_ERR_INVALID_ARGUMENT, "scene: " + err);
 
   if (built.stack_depth > STHIP_MAX_STACK_DEPTH) return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: the acceleration structure is too deep for the traversal stack (use the SAH builder)");
@@ -644,11 +649,20 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     if (ctx->nodes.n < std::max(nodes_needed, nodes_total) || ctx->tris.n < std::max<size_t>(1, tris_total)) return fail(ctx, STHIP_ERR_HIP, "scene: the reserved device arrays are too small");
   } else {
     HIP_TRY(ctx, ctx->nodes.ensure(std::max(nodes_needed, nodes_total)));
-    HIP_TRY(ctx, ctx->tris.ensure(std::max<size_t>(1, tris_total)));
+    HIP_TRY(ctx, ctx->tris.ensure(built.embedded ? 1 : std::max<size_t>(1, tris_total)));
   }
   HIP_TRY(ctx, ctx->entries.ensure(std::max<size_t>(1, built.entries.size())));
-  if (!built.nodes.empty()) HIP_TRY(ctx, upload_nodes(ctx, built.dev_nodes, built.nodes.data(), built.nodes.size()));
-  if (!built.tris.empty()) HIP_TRY(ctx, hipMemcpy(ctx->tris.p + built.dev_tris, built.tris.data(), built.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
+  if (built.embedded) {  // one array: packed nodes, and the leaf triangles in the units behind their parents
+    std::vector<BvhNodePacked> packed;
+    sthip::pack_nodes(built.nodes.data(), built.nodes.size(), packed);
+    static_assert(sizeof(BvhNodePacked) == sizeof(BvhTri), "a leaf triangle takes one node unit");
+    for (size_t u = 0; u < built.unit_tri.size(); u++)
+      if (built.unit_tri[u] != 0xFFFFFFFFu) memcpy(&packed[u], &built.tris[built.unit_tri[u]], sizeof(BvhTri));
+    if (!packed.empty()) HIP_TRY(ctx, hipMemcpy(ctx->nodes.p, packed.data(), packed.size() * sizeof(BvhNodePacked), hipMemcpyHostToDevice));
+  } else {
+    if (!built.nodes.empty()) HIP_TRY(ctx, upload_nodes(ctx, built.dev_nodes, built.nodes.data(), built.nodes.size()));
+    if (!built.tris.empty()) HIP_TRY(ctx, hipMemcpy(ctx->tris.p + built.dev_tris, built.tris.data(), built.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
+  }
   if (!built.entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->entries.p, built.entries.data(), built.entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
   {  // alpha masks: one-channel images and the per-triangle uvs the traversal interpolates
     std::vector<DeviceImage1> table(s->image1_count);
@@ -703,7 +717,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     ctx->bvh.volumes = ctx->volumes.p;
   }
   ctx->bvh.nodes = reinterpret_cast<const float4*>(ctx->nodes.p);
-  ctx->bvh.tris = reinterpret_cast<const float4*>(ctx->tris.p);
+  ctx->bvh.tris = built.embedded ? reinterpret_cast<const float4*>(ctx->nodes.p) : reinterpret_cast<const float4*>(ctx->tris.p);
   ctx->bvh.entries = ctx->entries.p;
   ctx->bvh.root_ref = built.root_ref;
   ctx->bvh.top_is_world_blas = built.top_is_world_blas;

@@ -266,8 +266,13 @@ uint32_t flatten(const Builder& b, int32_t t, std::vector<BvhNode>& out, LeafRef
   const uint32_t my = (uint32_t)out.size();
   out.push_back(BvhNode());
   memset(&out[my], 0, sizeof(BvhNode));
-  const uint32_t l = flatten(b, tn.left, out, leaf_ref);
-  const uint32_t r = flatten(b, tn.right, out, leaf_ref);
+  // leaf children first: with embedded leaves their triangles take the units right behind this node
+  const bool lleaf = b.nodes[tn.left].left < 0, rleaf = b.nodes[tn.right].left < 0;
+  uint32_t l = 0, r = 0;
+  if (lleaf) l = flatten(b, tn.left, out, leaf_ref);
+  if (rleaf) r = flatten(b, tn.right, out, leaf_ref);
+  if (!lleaf) l = flatten(b, tn.left, out, leaf_ref);
+  if (!rleaf) r = flatten(b, tn.right, out, leaf_ref);
   set_child(out[my], 0, &b.nodes[tn.left].box, l);
   set_child(out[my], 1, &b.nodes[tn.right].box, r);
   return my;
@@ -320,11 +325,13 @@ inline void load_tri(const sthip_scene_desc& s, const InstView& in, uint32_t pri
 
 }  // namespace
 
-bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err, int builder, DeviceBuildTarget* device) {
+bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err, int builder, DeviceBuildTarget* device, bool embed_leaves) {
   out = BuiltBvh();
   // device mode: bottom levels of >= DEVICE_MIN_PRIMS triangles are built in place on the GPU from the uploaded scene arrays
   const bool dev_mode = device != nullptr && builder == BVH_BUILDER_LBVH_GPU;
   const uint32_t DEVICE_MIN_PRIMS = 64;
+  // embedded leaves need every bottom level in one array the host lays out: not with the device builder, not through lbvh_build_gpu
+  out.embedded = embed_leaves && builder == BVH_BUILDER_SAH_HOST;
   const uint32_t BLAS_DEPTH_CAP = 22, TLAS_DEPTH_CAP = 18, LBVH_MAX_HEIGHT = 120;
   // ---- validate + classify ----
   std::vector<uint32_t> merged, separate, spheres, volumes;
@@ -596,7 +603,17 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
         out.tri_uvs[tri_base + k] = uv;
       }
     }
-    const uint32_t root = flatten(b, 0, out.nodes, [&](uint32_t first, uint32_t count) { return BVH_LEAF_BIT | ((tri_base + first) << 2) | (count - 1); });
+    const uint32_t root = flatten(b, 0, out.nodes, [&](uint32_t first, uint32_t count) {
+      if (!out.embedded) return BVH_LEAF_BIT | ((tri_base + first) << 2) | (count - 1);
+      out.unit_tri.resize(out.nodes.size(), 0xFFFFFFFFu);
+      const uint32_t unit = (uint32_t)out.nodes.size();
+      for (uint32_t k = 0; k < count; k++) {
+        out.nodes.push_back(BvhNode());
+        memset(&out.nodes.back(), 0, sizeof(BvhNode));
+        out.unit_tri.push_back(tri_base + first + k);
+      }
+      return BVH_LEAF_BIT | (unit << 2) | (count - 1);
+    });
     if (root & BVH_LEAF_BIT) {  // a mesh of <= 4 triangles: give it a one-child root so kernels always start at an inner node
       depth = 1;
       return wrap_leaf(out.nodes, bounds, root);
@@ -825,6 +842,20 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
     if (!out.top_is_world_blas && out.root_ref != BVH_INVALID_REF) out.root_ref += node_off;  // the top level is host-built
   }
   if (any_alpha) out.tri_uvs.resize(out.tris.size());
+  if (out.embedded) {
+    out.unit_tri.resize(out.nodes.size(), 0xFFFFFFFFu);
+    if (out.nodes.size() >= (1u << 28)) {
+      err = "too many triangles";
+      return false;
+    }
+    if (any_alpha) {  // the uv side array follows the leaf references: by unit
+      std::vector<BvhTriUv> by_unit(out.nodes.size());
+      memset(by_unit.data(), 0, by_unit.size() * sizeof(BvhTriUv));
+      for (size_t u = 0; u < out.unit_tri.size(); u++)
+        if (out.unit_tri[u] != 0xFFFFFFFFu) by_unit[u] = out.tri_uvs[out.unit_tri[u]];
+      out.tri_uvs.swap(by_unit);
+    }
+  }
   out.inst_alpha = inst_alpha;
   return true;
 }

@@ -48,6 +48,12 @@ struct BuiltBvh {
   // [0, dev_tris) of the final arrays in place; `nodes` / `tris` then hold only what the host built (small meshes, SAH
   // fallbacks, the top level) and belong at [dev_nodes, ...) / [dev_tris, ...): their references are already final.
   uint32_t dev_nodes = 0, dev_tris = 0;
+  // Embedded leaves (host builds without a device target): the triangles of a leaf lie in the NODE array, in the 48-byte
+  // units right behind the node that refers to them, so the dependent fetch of a leaf visit goes to the cache line(s) the
+  // node itself just came from. unit_tri[u] = index into `tris` of the triangle in unit u, or 0xFFFFFFFF for a node;
+  // leaf references then count units of the node array (DeviceBvh::tris = nodes).
+  bool embedded = false;
+  std::vector<uint32_t> unit_tri;
   TopLevelState top;
 };
 
@@ -88,7 +94,7 @@ enum BvhBuilderKind { BVH_BUILDER_SAH_HOST = 0, BVH_BUILDER_LBVH_GPU = 1 };
 // Validates the scene arrays and builds. Returns false and sets `err` on malformed input.
 // `builder`: binned SAH on the host (default; best traversal) or LBVH on the GPU (fastest build; lbvh.hip).
 // With a DeviceBuildTarget (and the LBVH builder) bottom levels of >= 64 triangles are built in place on the device.
-bool build_scene_bvh(const sthip_scene_desc& scene, BuiltBvh& out, std::string& err, int builder = BVH_BUILDER_SAH_HOST, DeviceBuildTarget* device = nullptr);
+bool build_scene_bvh(const sthip_scene_desc& scene, BuiltBvh& out, std::string& err, int builder = BVH_BUILDER_SAH_HOST, DeviceBuildTarget* device = nullptr, bool embed_leaves = false);
 
 // Transforms-only update: new entry matrices and world boxes, a new top level. `tlas_nodes` come out with their child
 // references already offset by st.blas_nodes (they go to nodes[st.blas_nodes ...]). Fails (false) when an instance of the

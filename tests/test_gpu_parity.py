@@ -489,6 +489,32 @@ def test_bounded_lds_stack_gives_the_same_frames(levels):
                 assert np.array_equal(a[k][f].view(np.uint32), b[k][f].view(np.uint32)), (sc.name, f)
 
 
+def test_embedded_leaves_give_the_same_frames(atrium_scene):
+    """embed_leaves = 1: the host builder puts a leaf's triangles into the node array, in the units right behind the node that
+    refers to them (one array, leaf references count its units). A layout experiment (no faster: DESIGN.md 4) kept as an
+    option; frames, alpha-masked frames and ray batches must not change."""
+    from stratum_amd.bdpt import BDPT
+
+    for (sc, cam), flags in ((atrium_scene, []), (scenes.foliage(), ["alphatest"]), (scenes.forest(n_instances=20, tree_tris=400, tree_kinds=2), [])):
+        frame = camera.Frame(160, 90, cam["fovy"], cam["eye"], cam["target"])
+        rays = random_rays(20000, 8, -6.0, 6.0)
+        out = {}
+        for embed in (0, 1):
+            r = BDPT(device=0, args={"bdptFlag": flags, "maxDiffuseVertices": 3})
+            try:
+                r.set_option("embed_leaves", embed)
+                r.update(sc)
+                out[embed] = (r.render(frame, 0, 2), r.trace(rays), r.trace(rays, any_hit=True, alpha_test=bool(flags)))
+            finally:
+                r.close()
+        a, b = out[0], out[1]
+        assert np.array_equal(a[0]["radiance"].view(np.uint32), b[0]["radiance"].view(np.uint32))
+        assert np.array_equal(a[0]["ray_count"], b[0]["ray_count"])
+        for k in (1, 2):
+            for f in ("instance_primitive_index", "t", "b1", "b2"):
+                assert np.array_equal(a[k][f].view(np.uint32), b[k][f].view(np.uint32)), f
+
+
 def test_gpu_lbvh_device_and_host_regions():
     """A scene whose bottom levels are split between the two builders in device mode: the forest's shared meshes (>= 64
     triangles: built on the GPU in place) next to tiny meshes (< 64 triangles: host SAH, placed behind the device region
