@@ -228,7 +228,7 @@ typedef struct sthip_stats {
   uint64_t bvh_nodes;
   uint64_t bvh_tris;
   float bvh_build_ms;      /* wall time of the acceleration-structure build inside the last sthip_scene_upload */
-  float bvh_build_gpu_ms;  /* of which device time of the LBVH kernels ("bvh_builder" = 1) */
+  float bvh_build_gpu_ms;  /* of which device time of the GPU builder's kernels ("bvh_builder" = 1) */
   /* lane-occupancy diagnostics of the trace kernels, [0] closest-hit, [1] shadow rays (with "count_traversal"):
    * 64 per wave-level iteration of the node loop / the triangle loop / per scheduling round of a persistent wave, and
    * the number of lanes that held a ray summed over rounds: nodes_visited / inner_slots etc. are lane utilisations */
@@ -261,7 +261,12 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s);
 /* named integer options: "count_traversal" (0/1), "time_kernels" (0/1); scheduler tuning of the persistent
  * trace kernels: "refill_idle" (1..64, default 16), "inner_min_lanes" (1..64, default 24),
  * "max_paths_in_flight" (default 4194304: how many seeds of the owned pixels are traced together);
- * "bvh_builder": 0 = binned SAH on the host (default), 1 = LBVH on the GPU (set before sthip_scene_upload) */
+ * "bvh_builder": 0 = binned SAH on the host (default), 1 = the device-resident GPU builder (set before
+ * sthip_scene_upload; a failed upload with it leaves the context without a scene), with "lbvh_algorithm" 1 = PLOC
+ * (default) or 0 = Karras radix tree and "ploc_radius" (1..32, default 4);
+ * "treetop" (default 1), "embed_leaves" (default 0), "lds_stack_levels" (4..150: LDS levels of the traversal stack; a higher
+ * tree runs the bounded kernels, default: bounded at 32 levels beyond a height of 40): layout / scheduling options that
+ * never change results, read at the next sthip_scene_upload / sthip_scene_update_transforms */
 int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value);
 
 /* ---- after the path: display transform, image metric, HDR export ---- */
