@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
       tr.round(bvh, stack, p.inner_min_lanes, cnt[0]);
     }
     if (busy && !tr.active()) {
-      if (BOUNDED && tr.overflowed) {
+      if (BOUNDED && tr.overflowed(stack)) {
         // the LDS stack was too short for this ray: its result is void. k_trace_deep traces it again with a stack as high as
         // the tree (global memory) and does what would have been done here; hits do not depend on the traversal order
         const uint32_t e = atomicAdd(p.deep_count, 1u);

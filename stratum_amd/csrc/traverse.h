@@ -200,6 +200,7 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
 // stack sentinels (both carry the leaf bits, so the inner-node loop hands them to the leaf handler)
 #define TRAV_DONE 0xFFFFFFFFu           // bottom of the stack: the ray is finished
 #define TRAV_EXIT_INSTANCE 0xFFFFFFFEu  // pushed when a transformed instance is entered
+#define TRAV_CANARY 0xFFFFFFFDu         // never a reference (entry indices stay below 0xFFFE): marks an untouched slot, see BOUNDED
 
 // Per-lane traversal state machine. `ref` is the next thing to process: an inner-node index, a leaf
 // reference or a sentinel. It runs "while-while": every lane of the wave walks inner nodes until it
@@ -211,14 +212,17 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
 #define TRAV_ANY 1      // occlusion: stop at the first accepted triangle (hit.ip = 0)
 #define TRAV_MIXED 2    // per lane, member `any` (the persistent kernel feeds closest-hit and shadow rays to one wave)
 // TOP: inner references may point into the treetop held in LDS at `top_lds` (BVH_TOP_BIT), see DeviceBvh
-// BOUNDED: the stack has fewer levels than the tree is high. `top` never passes `limit` (a push there lands in the spare
-// slot and is lost), `overflowed` records that it happened: the traversal still terminates (every reference on the stack is
-// one this ray wrote), but its result is void and the caller traces the ray again with a full-height stack.
+// BOUNDED: the stack has fewer levels than the tree is high. `top` never passes `limit` (one v_min per step; a push there
+// lands in the spare slot and is lost). Whether that happened is read off a canary: start() puts TRAV_CANARY into the slot
+// at `limit`, and every step in which `top` stands there overwrites it with its speculative push — so overflowed() is true
+// for every ray that lost a push (and for the few that merely filled the stack to the brim). Such a traversal still
+// terminates (every reference on the stack is one this ray wrote), but its result is void: the caller traces the ray again
+// with a full-height stack.
 template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false, bool BOUNDED = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
 struct Traversal {
   const LdsFloat4* top_lds;  // TOP only
   uint32_t limit;            // BOUNDED only: (levels - 1) * STRIDE
-  bool overflowed;           // BOUNDED only
+  DEV bool overflowed(const uint32_t* stack) const { return BOUNDED && stack[limit] != TRAV_CANARY; }
   bool any;  // TRAV_MIXED only
   DEV bool is_any() const { return MODE == TRAV_ANY || (MODE == TRAV_MIXED && any); }
   f3 o, d;  // world-space ray
@@ -242,7 +246,7 @@ struct Traversal {
     hit.ip = 0xFFFFFFFFu;
     stack[0] = TRAV_DONE;
     top = STRIDE;
-    if (BOUNDED) overflowed = false;
+    if (BOUNDED) stack[limit] = TRAV_CANARY;
     id_bits = 0;
     ref = bvh.root_ref;  // BVH_INVALID_REF == TRAV_DONE for an empty scene
     setup_space(sp, ro, rd, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
@@ -300,12 +304,7 @@ struct Traversal {
       stack[top] = first1 ? cr.x : cr.y;
       ref = (h0 || h1) ? (first1 ? cr.y : cr.x) : popped;
       const uint32_t next_top = (h0 && h1) ? top + STRIDE : ((h0 || h1) ? top : top - STRIDE);
-      if (BOUNDED) {
-        overflowed |= next_top > limit;
-        top = min(next_top, limit);
-      } else {
-        top = next_top;
-      }
+      top = BOUNDED ? min(next_top, limit) : next_top;
       }
       if ((uint32_t)__popcll(__ballot(!(ref & BVH_LEAF_BIT))) < min_lanes) break;
     }
@@ -376,10 +375,7 @@ struct Traversal {
         setup_space(sp, obj_point(m, o), obj_vector(m, d), sph.x, sph.y, sph.z, sph.w);
         id_bits = info.y;
         stack[top] = TRAV_EXIT_INSTANCE;
-        if (BOUNDED && top + STRIDE > limit)
-          overflowed = true;
-        else
-          top += STRIDE;
+        top = BOUNDED ? min(top + STRIDE, limit) : top + STRIDE;
       }
       // identity entry (the merged world-space mesh): same ray, same (larger, still conservative) padding,
       // id_bits stays 0 because its triangles carry their instance index themselves
