@@ -2300,6 +2300,38 @@ struct PathIntegrator {
   const GroupRR* group_rr = nullptr;  // indexed by path_length (null: not run as part of a group -> the non-coherent form)
   int rr_missing_length = -1;         // the path length at which this path needed a group decision that is not known yet
   float rr_missing_p = 0, rr_missing_rnd = 0;
+  // eCoherentSampling (path.hlsli:317-318,378-387,688,703): an index drawn at random becomes WaveReadLaneFirst(index) +
+  // WaveGetLaneIndex(), i.e. the 32 lanes of a workgroup read 32 CONSECUTIVE presampled lights / cached light vertices. The
+  // wave is given the same defined meaning as for eCoherentRR: the 8x4 workgroup, lane = (y & 3) * 8 + (x & 7), lane count
+  // 32, "first lane" = the lowest lane whose path executes that statement at that path length. Two sites per vertex, in
+  // execution order: the NEE index (connect_light's tile index with ePresampleLights, or connect_light_reservoir's), then
+  // connect_lvc's. Same replay protocol as the roulette: a path that finds no group value reports its own draw and stops.
+  struct GroupValue {
+    bool valid = false;
+    uint32_t value = 0;
+  };
+  const GroupValue* group_nee = nullptr;  // indexed by path_length; null: not run as part of a group -> own draws
+  const GroupValue* group_lvc = nullptr;
+  uint32_t lane = 0;
+  int cs_missing_site = -1, cs_missing_length = -1;  // site: 0 = NEE index, 1 = connect_lvc's index
+  uint32_t cs_missing_value = 0;
+  bool aborted = false;  // the replay protocol stopped this path in the middle of a vertex
+  // own_draw -> the index this lane uses. False: the group's value is not known yet (reported; the path stops).
+  bool coherent_index(int site, uint32_t& index) {
+    const GroupValue* g = site == 0 ? group_nee : group_lvc;
+    if (!fr.flag(STHIP_eCoherentSampling) || !g) return true;
+    if (!g[path_length].valid) {
+      cs_missing_site = site;
+      cs_missing_length = (int)path_length;
+      cs_missing_value = index;
+      aborted = true;
+      beta = V3(0.0f);
+      return false;
+    }
+    index = g[path_length].value + lane;
+    return true;
+  }
+  bool coherent_sampling() const { return fr.flag(STHIP_eCoherentSampling) && group_nee != nullptr; }
   bool russian_roulette() {
     float p = luminance(beta) / eta_scale * 0.95f;
     const bool coherent = fr.flag(STHIP_eCoherentRR) && !has_media(fr) && group_rr;
@@ -2404,7 +2436,12 @@ struct PathIntegrator {
       return;
     }
     const bool presampled = fr.flag(STHIP_ePresampleLights);
-    const LightCandidate cand = light_candidate(presampled, presampled ? rng.next_uint() : 0u);
+    uint32_t ti = 0;
+    if (presampled) {
+      ti = rng.next_uint() % fr.pc.gLightPresampleTileSize;  // :316
+      if (!coherent_index(0, ti)) return;                  // :317-318 (light_candidate takes it modulo the tile size)
+    }
+    const LightCandidate cand = light_candidate(presampled, ti);
     v3 Le = cand.Le, ray_direction = cand.ray_direction;
     float pdfA = cand.pdfA, ray_distance = cand.ray_distance, cG = cand.G;
     // setup()
@@ -2474,9 +2511,12 @@ struct PathIntegrator {
     float total_weight = 0, r_target_pdf = 0;
     uint32_t M = 0;
     uint32_t ti = rng.next_uint();  // :378 (drawn in either mode)
+    const bool coherent = presampled && coherent_sampling();  // (without presampled lights the index is never used)
+    if (coherent && !coherent_index(0, ti)) return;  // :379-380
     for (uint32_t i = 0; i < fr.pc.gReservoirM; i++) {
-      if (presampled) ti = rng.next_uint();
+      if (presampled && !coherent) ti = rng.next_uint();  // :385
       const LightCandidate c_i = light_candidate(presampled, ti);
+      if (coherent) ti += 32;  // :387, WaveGetLaneCount()
       if (c_i.pdfA <= 0 || all_le0(c_i.Le)) continue;
       const v3 local_to_light = normalize(isect.sd.to_local(c_i.ray_direction));  // setup(), :209
       const float target_pdf_i = luminance(c_i.Le) * c_i.G * fabsf(local_to_light.z);
@@ -2649,12 +2689,14 @@ struct PathIntegrator {
         if (path_length >= fr.pc.gMinPathVertices)
           if (!russian_roulette()) return false;
         if (fr.flag(STHIP_eNEE)) connect_light(m);
+        if (aborted) return false;
         if (fr.flag(STHIP_eConnectToLightPaths)) {
           if (fr.flag(STHIP_eLVC))
             connect_lvc(m);
           else
             connect_light_subpath(m);
         }
+        if (aborted) return false;
       }
     }
     if (fr.flag(STHIP_eSampleBSDFs) || trace_light) return sample_direction(m);
@@ -2859,7 +2901,9 @@ struct PathIntegrator {
   // eDeferShadowRays the record goes to this vertex's gShadowRays slot — the slot connect_light has just written, as upstream.
   void connect_lvc(const DisneyMaterial& m) {
     const uint32_t n = std::min<uint64_t>(fr.lvc_count, (uint64_t)fr.pc.gLightPathCount * fr.pc.gMaxDiffuseVertices);
-    const uint32_t li = rng.next_uint();
+    uint32_t li = rng.next_uint();
+    const bool coherent = coherent_sampling();
+    if (coherent && !coherent_index(1, li)) return;  // :688
     const PathVertex zero{};
     auto fits = [&](const PathVertex& v) {
       return !(v.subpath_length() + path_length > fr.pc.gMaxPathVertices || v.diffuse_vertices() + diffuse_vertices > fr.pc.gMaxDiffuseVertices || all_le0(v.beta()));
@@ -2872,7 +2916,7 @@ struct PathIntegrator {
       r.init();
       float r_target_pdf = 0;  // (uninitialised upstream when no candidate is taken; W() of it then multiplies a zero contribution)
       for (uint32_t i = 0; i < fr.pc.gReservoirM; i++) {
-        const uint32_t pick = rng.next_uint();
+        const uint32_t pick = coherent ? li + (1 + i) * 32u : rng.next_uint();  // :703
         const PathVertex lv_i = n ? fr.light_vertices[pick % n] : zero;
         if (!fits(lv_i)) continue;
         v3 ro_i = V3(0.0f), rd_i = V3(0.0f);
@@ -3125,12 +3169,22 @@ struct RRControl {
   const PathIntegrator::GroupRR* decisions = nullptr;
   int missing_length = -1;
   float missing_p = 0, missing_rnd = 0;
+  // eCoherentSampling: the group's index values per site (in) and what the path found missing (out)
+  const PathIntegrator::GroupValue* nee = nullptr;
+  const PathIntegrator::GroupValue* lvc = nullptr;
+  int cs_site = -1, cs_length = -1;
+  uint32_t cs_value = 0;
 };
 bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float out_rgb[3], PixelAOV* aov, uint64_t stats[4], RRControl* rr = nullptr) {
   const int view_index = get_view_index(fr, x, y);
   if (view_index < 0) return false;
   PathIntegrator path(fr, x, y, seed);
-  if (rr) path.group_rr = rr->decisions;
+  if (rr) {
+    path.group_rr = rr->decisions;
+    path.group_nee = rr->nee;
+    path.group_lvc = rr->lvc;
+    path.lane = (y & 3u) * 8u + (x & 7u);
+  }
   out_rgb[0] = out_rgb[1] = out_rgb[2] = 0;
   if (fr.pc.gMaxPathVertices < 2) return true;
   const sthip_ViewData& view = fr.fd.gViews[view_index];
@@ -3262,6 +3316,9 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
     rr->missing_length = path.rr_missing_length;
     rr->missing_p = path.rr_missing_p;
     rr->missing_rnd = path.rr_missing_rnd;
+    rr->cs_site = path.cs_missing_site;
+    rr->cs_length = path.cs_missing_length;
+    rr->cs_value = path.cs_missing_value;
   }
   return true;
 }
@@ -3514,7 +3571,7 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (scene_flags & STHIP_BDPT_FLAG_TRACE_LIGHT) return STHIP_ERR_UNSUPPORTED;
 
   if ((scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) && (size_t)pc->gEnvironmentMaterialAddress + 16 > sc->materials.size()) return STHIP_ERR_INVALID_ARGUMENT;
-  const uint32_t unsupported = (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
+  const uint32_t unsupported = (1u << STHIP_eSampleLightPower);
   if (sampling_flags & unsupported) return STHIP_ERR_UNSUPPORTED;
   Frame fr;
   fr.sc = sc;
@@ -3537,6 +3594,9 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (!fr.flag(STHIP_eConnectToLightPaths)) fr.sampling_flags &= ~((1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse));  // the cache is only read by connect_lvc
   if (!fr.flag(STHIP_eLVCReservoirs)) fr.sampling_flags &= ~(1u << STHIP_eLVCReservoirReuse);  // the reuse sits inside the reservoir branch of connect_lvc
   if (!fr.flag(STHIP_eNEE) && !fr.flag(STHIP_eLVC)) fr.sampling_flags &= ~(1u << STHIP_eDeferShadowRays);  // BDPT.cpp:522-523
+  // eCoherentSampling only touches the index of a presampled light (path.hlsli:317,379) and connect_lvc's (:688,703)
+  if (!fr.flag(STHIP_ePresampleLights) && !fr.flag(STHIP_eLVC)) fr.sampling_flags &= ~(1u << STHIP_eCoherentSampling);
+  if (fr.flag(STHIP_eCoherentSampling) && (scene_flags & STHIP_BDPT_FLAG_HAS_MEDIA) && !sc->volumes.empty()) return STHIP_ERR_UNSUPPORTED;  // walks through volumes break the lockstep
   if (has_media(fr)) {
     // with media every visibility ray draws random numbers: inline ones (NEE without eDeferShadowRays, the connections of
     // eConnectToViews / eConnectToLightPaths) would advance the path's own stream mid-vertex; only the deferred form is restated
@@ -3668,9 +3728,10 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   // the verdict of the first lane (lowest y * 8 + x in the group) — and the group is rendered again. With the usual
   // limits on diffuse scenes no path ever reaches the roulette and the first rendering is the final one. acc_of(x, y)
   // gives a pixel's running mean (or null: the pixel takes part in the decisions but is not an output of this call).
-  const bool coherent_rr = fr.flag(STHIP_eCoherentRR) && !has_media(fr);
+  const bool coherent_rr = (fr.flag(STHIP_eCoherentRR) || fr.flag(STHIP_eCoherentSampling)) && !has_media(fr);  // rendered group by group
   auto sample_group = [&](const Frame& base, uint32_t gx, uint32_t gy, uint32_t s, const std::function<float*(uint32_t, uint32_t)>& acc_of, int tid) {
     PathIntegrator::GroupRR decisions[256];
+    PathIntegrator::GroupValue nee_values[256], lvc_values[256];  // eCoherentSampling: the first lane's index per site and path length
     const Frame sf = seed_frame(base, s);
     struct Lane {
       bool inside;
@@ -3687,22 +3748,45 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
         if (x >= W || y >= H) continue;
         memset(&lanes[l].aov, 0, sizeof(PixelAOV));
         memset(lanes[l].stats, 0, sizeof(lanes[l].stats));
-        ctl[l].decisions = decisions;
+        ctl[l].decisions = fr.flag(STHIP_eCoherentRR) ? decisions : nullptr;
+        ctl[l].nee = fr.flag(STHIP_eCoherentSampling) ? nee_values : nullptr;
+        ctl[l].lvc = fr.flag(STHIP_eCoherentSampling) ? lvc_values : nullptr;
         lanes[l].inside = render_pixel(sf, x, y, seed_begin + s, lanes[l].rgb, (s == 0 && want_aovs) ? &lanes[l].aov : nullptr, lanes[l].stats, &ctl[l]);
-        if (lanes[l].inside && ctl[l].missing_length >= 0 && (missing < 0 || ctl[l].missing_length < missing)) missing = ctl[l].missing_length;
       }
+      // the earliest statement some lane could not execute: by path length, then in the order of a vertex (roulette, NEE index,
+      // connect_lvc's index). A lane reports at most one.
+      int key = -1;
+      for (uint32_t l = 0; l < 32; l++) {
+        if (!lanes[l].inside) continue;
+        int k = -1;
+        if (ctl[l].missing_length >= 0) k = ctl[l].missing_length * 4;
+        if (ctl[l].cs_length >= 0) k = ctl[l].cs_length * 4 + 1 + ctl[l].cs_site;
+        if (k >= 0 && (key < 0 || k < key)) key = k;
+      }
+      missing = key < 0 ? -1 : key >> 2;
       if (missing < 0) break;
-      PathIntegrator::GroupRR d;
-      d.valid = true;
-      d.p_max = -1;
-      int first = -1;
-      for (uint32_t l = 0; l < 32; l++)
-        if (lanes[l].inside && ctl[l].missing_length == missing) {
-          if (first < 0) first = (int)l;
-          d.p_max = std::max(d.p_max, ctl[l].missing_p);  // WaveActiveMax
-        }
-      d.kill = d.p_max < 1 && ctl[first].missing_rnd > d.p_max;  // WaveReadLaneFirst(rnd > p)
-      decisions[missing & 255] = d;
+      const int what = key & 3;
+      if (what == 0) {
+        PathIntegrator::GroupRR d;
+        d.valid = true;
+        d.p_max = -1;
+        int first = -1;
+        for (uint32_t l = 0; l < 32; l++)
+          if (lanes[l].inside && ctl[l].missing_length == missing) {
+            if (first < 0) first = (int)l;
+            d.p_max = std::max(d.p_max, ctl[l].missing_p);  // WaveActiveMax
+          }
+        d.kill = d.p_max < 1 && ctl[first].missing_rnd > d.p_max;  // WaveReadLaneFirst(rnd > p)
+        decisions[missing & 255] = d;
+      } else {
+        PathIntegrator::GroupValue v;
+        for (uint32_t l = 0; l < 32 && !v.valid; l++)
+          if (lanes[l].inside && ctl[l].cs_length == missing && ctl[l].cs_site == what - 1) {
+            v.valid = true;
+            v.value = ctl[l].cs_value;  // WaveReadLaneFirst
+          }
+        (what == 1 ? nee_values : lvc_values)[missing & 255] = v;
+      }
     }
     for (uint32_t l = 0; l < 32; l++) {
       if (!lanes[l].inside) continue;

@@ -134,6 +134,7 @@ struct sthip_ctx {
   DevBuf<float4> presampled;    // gPresampledLights
   DevBuf<float4> bdpt;          // BDPT quantities per path (eConnectToViews)
   DevBuf<float4> rr;  // eCoherentRR: probes / group verdicts of the round in flight (FrameParams::rr)
+  DevBuf<uint2> cs_nee, cs_lvc;  // eCoherentSampling: probes / group values of the round in flight (FrameParams::cs_nee, cs_lvc)
   DevBuf<float4> lvc_staging, path_contrib;  // eLVC: staged light vertices, the light paths' path_contrib (eLVCReservoirs)
   DevBuf<uint32_t> lvc_count, lvc_flags, lvc_offsets;
   DevBuf<uint8_t> lvc_tmp;
@@ -991,7 +992,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: depth / prev-uv outputs need gInverseViewTransforms");
   // BDPT_FLAG_TRACE_LIGHT is a per-kernel specialisation of the reference (sample_photons), never a caller's choice
   if (scene_flags & STHIP_BDPT_FLAG_TRACE_LIGHT) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: BDPT_FLAG_TRACE_LIGHT is not a scene flag a caller sets");
-  const uint32_t unsupported = (1u << STHIP_eSampleLightPower) | (1u << STHIP_eCoherentSampling);
+  const uint32_t unsupported = (1u << STHIP_eSampleLightPower);
   if (sampling_flags & unsupported) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: a sampling flag outside the built hot path is set");
   if (pc->gMaxPathVertices > 60 || pc->gMaxDiffuseVertices > 60) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: path length limits above 60");
   if (pc->gLightCount > ctx->light_count) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: gLightCount exceeds the uploaded light list");
@@ -1011,6 +1012,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   if (!(sampling_flags & (1u << STHIP_eConnectToLightPaths))) sampling_flags &= ~((1u << STHIP_eLVC) | (1u << STHIP_eLVCReservoirs) | (1u << STHIP_eLVCReservoirReuse));  // only connect_lvc reads the cache
   if (!(sampling_flags & (1u << STHIP_eLVCReservoirs))) sampling_flags &= ~(1u << STHIP_eLVCReservoirReuse);  // the reuse sits inside connect_lvc's reservoir branch
   if (!(sampling_flags & ((1u << STHIP_eNEE) | (1u << STHIP_eLVC)))) sampling_flags &= ~(1u << STHIP_eDeferShadowRays);  // BDPT.cpp:522-523
+  // eCoherentSampling only touches the index of a presampled light (path.hlsli:317,379) and connect_lvc's (:688,703)
+  if (!(sampling_flags & ((1u << STHIP_ePresampleLights) | (1u << STHIP_eLVC)))) sampling_flags &= ~(1u << STHIP_eCoherentSampling);
   pc = &pcn;
   if (has_env) {  // the Environment record (environment.h:17-22): ImageValue3, then 4 offsets into gDistributions when an image is bound
     const size_t addr = pcn.gEnvironmentMaterialAddress;
@@ -1030,6 +1033,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   // participating media (BDPT_FLAG_HAS_MEDIA, BDPT.cpp:497-500)
   if (ctx->has_volumes && !(scene_flags & STHIP_BDPT_FLAG_HAS_MEDIA)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: the scene has volume instances but BDPT_FLAG_HAS_MEDIA is not set");
   const bool media = ctx->has_volumes;
+  if (media && (sampling_flags & (1u << STHIP_eCoherentSampling))) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eCoherentSampling with media (walks through volumes break the lockstep of a workgroup)");
   if (media) {
     // with media every visibility ray draws random numbers; an inline one (NEE without eDeferShadowRays, the connections
     // of eConnectToViews / eConnectToLightPaths) advances the path's own stream in the middle of a vertex: only the deferred form is built
@@ -1228,6 +1232,14 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   const bool coherent_rr = (sampling_flags & (1u << STHIP_eCoherentRR)) && !media;
   if (coherent_rr) HIP_TRY(ctx, ctx->rr.ensure(P));
   p.rr = nullptr;
+  // eCoherentSampling: one probe per site and round (FrameParams::cs_nee / cs_lvc)
+  const bool coherent_nee = (sampling_flags & (1u << STHIP_eCoherentSampling)) && (sampling_flags & (1u << STHIP_ePresampleLights)) && (sampling_flags & (1u << STHIP_eNEE));
+  const bool coherent_lvc = (sampling_flags & (1u << STHIP_eCoherentSampling)) && lvc;
+  if (coherent_nee) HIP_TRY(ctx, ctx->cs_nee.ensure(P));
+  if (coherent_lvc) HIP_TRY(ctx, ctx->cs_lvc.ensure(P));
+  p.cs_nee = nullptr;
+  p.cs_lvc = nullptr;
+  p.probe_kind = 0;
   p.hg_checksums = ctx->hg_checksums.p;
   p.hg_counters = ctx->hg_counters.p;
   p.hg_indices = ctx->hg_indices.p;
@@ -1576,11 +1588,10 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       // gMinPathVertices <= path_length < gMaxPathVertices at a non-specular vertex that is within the diffuse budget —
       // without specular materials that is vertex number depth + 1 of at most gMaxDiffuseVertices. In such a round the
       // paths first report their p (k_shade<PROBE>), the 8x4 groups agree (k_rr_reduce), then the round proper runs.
-      p.rr = nullptr;
-      if (coherent_rr && depth + 2 >= pc->gMinPathVertices && depth + 2 < pc->gMaxPathVertices && (ctx->has_specular || depth + 1 <= pc->gMaxDiffuseVertices)) {
-        p.rr = ctx->rr.p;
-        (void)hipMemsetAsync(ctx->rr.p, 0, (size_t)p.path_count * 16, st);
-        FrameParams probe = p;  // no output of the round is written by the probe
+      // A probe: the round's k_shade without any output, up to the statement `kind` names (FrameParams::probe_kind)
+      auto launch_probe = [&](uint32_t kind) {
+        FrameParams probe = p;
+        probe.probe_kind = kind;
         probe.out_albedo = nullptr;
         probe.out_visibility = nullptr;
         probe.out_depth = nullptr;
@@ -1594,7 +1605,30 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
           hipLaunchKernelGGL((k_shade<true, true, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, probe, depth);
         else
           hipLaunchKernelGGL((k_shade<false, true, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, probe, depth);
-        hipLaunchKernelGGL(k_rr_reduce, dim3((unsigned)((p.path_count + STHIP_BLOCK - 1) / STHIP_BLOCK)), dim3(STHIP_BLOCK), 0, st, p);
+      };
+      const unsigned reduce_grid = (unsigned)((p.path_count + STHIP_BLOCK - 1) / STHIP_BLOCK);
+      p.rr = nullptr;
+      if (coherent_rr && depth + 2 >= pc->gMinPathVertices && depth + 2 < pc->gMaxPathVertices && (ctx->has_specular || depth + 1 <= pc->gMaxDiffuseVertices)) {
+        p.rr = ctx->rr.p;
+        (void)hipMemsetAsync(ctx->rr.p, 0, (size_t)p.path_count * 16, st);
+        launch_probe(1);
+        hipLaunchKernelGGL(k_rr_reduce, dim3(reduce_grid), dim3(STHIP_BLOCK), 0, st, p);
+      }
+      // eCoherentSampling: the NEE index first (with the roulette's verdict known), then connect_lvc's (with the NEE index
+      // known: how many numbers a path draws in between depends on the candidates it looked at)
+      p.cs_nee = nullptr;
+      p.cs_lvc = nullptr;
+      if (coherent_nee) {
+        p.cs_nee = ctx->cs_nee.p;
+        (void)hipMemsetAsync(ctx->cs_nee.p, 0, (size_t)p.path_count * 8, st);
+        launch_probe(2);
+        hipLaunchKernelGGL(k_cs_reduce, dim3(reduce_grid), dim3(STHIP_BLOCK), 0, st, p.cs_nee, p.path_count);
+      }
+      if (coherent_lvc) {
+        p.cs_lvc = ctx->cs_lvc.p;
+        (void)hipMemsetAsync(ctx->cs_lvc.p, 0, (size_t)p.path_count * 8, st);
+        launch_probe(3);
+        hipLaunchKernelGGL(k_cs_reduce, dim3(reduce_grid), dim3(STHIP_BLOCK), 0, st, p.cs_lvc, p.path_count);
       }
       if (media) {
         if (ctx->textured)

@@ -107,6 +107,14 @@ struct FrameParams {
   // them. Null without the flag, with media (walks through volumes break the lockstep: the non-coherent form stays)
   // and in rounds in which no path can reach the call.
   float4* rr;
+  // eCoherentSampling (path.hlsli:317,379-387,688,703): index = WaveReadLaneFirst(index) + WaveGetLaneIndex() over the 8x4
+  // group, two sites per vertex (the NEE index of a presampled light; connect_lvc's). Same cut as for the roulette, one
+  // probe per site because the draws between the sites depend on the first one's outcome: k_shade<PROBE> with probe_kind 2
+  // stores (1, own draw) at the NEE site, k_cs_reduce turns a group's entries into (any, first lane's draw), probe_kind 3
+  // runs on with that value up to connect_lvc's draw; the round proper reads both. Null without the flag.
+  uint2* cs_nee;
+  uint2* cs_lvc;
+  uint32_t probe_kind;  // of a k_shade<PROBE> launch: 1 = the roulette, 2 = the NEE index, 3 = connect_lvc's index
   // bounded LDS stacks (k_trace<., ., true>): the rays k_trace_deep traces again, 4 x float4 each, and their count
   float4* deep_rays;
   uint32_t* deep_count;
@@ -1553,7 +1561,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
           const bool coherent = !MEDIA && p.rr != nullptr;
           bool group_kills = false;
           if (coherent) {
-            if (PROBE) {
+            if (PROBE && p.probe_kind == 1) {
               Rng peek = rng;
               p.rr[slot] = make_float4(rr, peek.next_float(), 1.0f, 0.0f);
               break;
@@ -1569,7 +1577,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             path_pdf *= rr;  // path.hlsli:842
           }
         }
-        if (PROBE) break;  // a path that passes the roulette's place without reaching it has nothing to report
+        if (PROBE && p.probe_kind == 1) break;  // a path that passes the roulette's place without reaching it has nothing to report
+        const uint32_t group_lane = (py & 3u) * 8u + (px & 7u);  // WaveGetLaneIndex() of the reference's 8x4 workgroup
         if (use_nee) {
           // connect_light, path.hlsli:311-366; sample_Le :141-164; sample_point_on_light, light.hlsli:37-152
           // one light candidate: DirectLightSample's two constructors (path.hlsli:179-201) in front of setup()
@@ -1625,14 +1634,24 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             lLe = to_light = F3s(0.0f);
             pdfA = cG = ls_dist = 0;
             uint32_t ti = rng.next_uint();
+            const bool coherent_ti = presampled && p.cs_nee != nullptr;  // path.hlsli:379-380,385-387
+            if (coherent_ti) {
+              if (PROBE && p.probe_kind == 2) {
+                p.cs_nee[slot] = make_uint2(1u, ti);
+                break;
+              }
+              ti = p.cs_nee[slot].y + group_lane;
+            }
             f3 y_pos = F3s(0.0f);  // the chosen candidate's PresampledLightPoint (what a reservoir stores)
             uint32_t y_pgn = 0;
             for (uint32_t k = 0; k < p.pc.gReservoirM; k++) {
-              if (presampled) ti = rng.next_uint();
+              if (presampled && !coherent_ti) ti = rng.next_uint();
+              const uint32_t ti_k = ti;
+              if (coherent_ti) ti += 32u;  // WaveGetLaneCount()
               f3 cLe, c_dir, c_pos = F3s(0.0f);
               float c_pdfA, c_dist, c_G;
               uint32_t c_pgn = 0;
-              light_candidate(ti, cLe, c_pdfA, c_dir, c_dist, c_G, c_pos, c_pgn);
+              light_candidate(ti_k, cLe, c_pdfA, c_dir, c_dist, c_G, c_pos, c_pgn);
               if (c_pdfA <= 0 || all_le0(cLe)) continue;
               const f3 c_local = normalize3(frame.to_local(c_dir));
               const float target_pdf = luminance3(cLe) * c_G * fabsf(c_local.z);
@@ -1710,29 +1729,43 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             if (ris_W <= 1e-6f || ris_W != ris_W) {
               lLe = F3s(0.0f), pdfA = 0;  // :440: nothing to connect (and nothing appended)
             } else if (reuse) {
-              const f3 at = jittered();
+              const f3 at = jittered();  // (draws: also in a probe)
               uint32_t path_index;  // map_pixel_coord, bdpt_util.hlsli:76-83
               if (flag(p, STHIP_eRemapThreads))
                 path_index = ((py >> 2) * ((p.pc.gOutputExtent[0] + 7u) >> 3) + (px >> 3)) * 32u + (py & 3u) * 8u + (px & 7u);
               else
                 path_index = py * p.pc.gOutputExtent[0] + px;
-              float4* a = p.hg_appends + 4 * ((size_t)path_index * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1));
-              a[0] = make_float4(at.x, at.y, at.z, total_weight);
-              a[1] = make_float4(__uint_as_float(min(M, p.pc.gReservoirMaxM)), __uint_as_float(sd.packed_geometry_normal), ris_W, pdfA);
-              a[2] = make_float4(y_pos.x, y_pos.y, y_pos.z, cell_size);
-              a[3] = make_float4(lLe.x, lLe.y, lLe.z, __uint_as_float(y_pgn));
+              if (!PROBE) {
+                float4* a = p.hg_appends + 4 * ((size_t)path_index * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1));
+                a[0] = make_float4(at.x, at.y, at.z, total_weight);
+                a[1] = make_float4(__uint_as_float(min(M, p.pc.gReservoirMaxM)), __uint_as_float(sd.packed_geometry_normal), ris_W, pdfA);
+                a[2] = make_float4(y_pos.x, y_pos.y, y_pos.z, cell_size);
+                a[3] = make_float4(lLe.x, lLe.y, lLe.z, __uint_as_float(y_pgn));
+              }
             }
           } else {
             f3 unused_pos;
             uint32_t unused_pgn;
-            light_candidate(presampled ? rng.next_uint() : 0u, lLe, pdfA, to_light, ls_dist, cG, unused_pos, unused_pgn);
+            uint32_t ti = 0;
+            if (presampled) {
+              ti = rng.next_uint() % p.pc.gLightPresampleTileSize;  // path.hlsli:316
+              if (p.cs_nee) {                                       // :317-318
+                if (PROBE && p.probe_kind == 2) {
+                  p.cs_nee[slot] = make_uint2(1u, ti);
+                  break;
+                }
+                ti = p.cs_nee[slot].y + group_lane;  // (light_candidate takes it modulo the tile size)
+              }
+            }
+            light_candidate(ti, lLe, pdfA, to_light, ls_dist, cG, unused_pos, unused_pgn);
           }
+          if (PROBE && p.probe_kind == 2) break;  // passed the NEE index without drawing one
           // DirectLightSample::setup, path.hlsli:204-221
           const f3 local_to_light = normalize3(frame.to_local(to_light));
           const float ngdotout = dot3(gn, to_light);
           const f3 ray_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
           const float ray_distance = ls_dist * 0.999f;
-          do {
+          if (!PROBE) do {  // (no draws from here to the end of connect_light: a probe for connect_lvc's index skips it)
             if (all_le0(lLe) && pdfA < 1e-6f) break;
             MaterialEvalRecord ev;
             m.eval(ev, local_dir_in, local_to_light, false);
@@ -1804,6 +1837,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
           } while (0);
         }
+        if (PROBE && p.probe_kind == 2) break;  // no NEE at this vertex: nothing to report
         if (connect_paths) {
           // connect_light_subpath, path.hlsli:802-822: this vertex to the stored vertices of the light subpath with the
           // same path index. Each connection that survives queues a visibility ray whose contribution lands in this
@@ -1904,7 +1938,15 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             const size_t per_seed_lvc = (size_t)p.pc.gLightPathCount * p.pc.gMaxDiffuseVertices;
             const float4* cache = p.light_vertices + 4 * (size_t)seed_index * per_seed_lvc;
             const uint32_t n = (uint32_t)min((unsigned long long)p.lvc_count[seed_index], (unsigned long long)per_seed_lvc);
-            const uint32_t li0 = rng.next_uint();
+            uint32_t li0 = rng.next_uint();
+            const bool coherent_li = p.cs_lvc != nullptr;  // path.hlsli:688,703
+            if (coherent_li) {
+              if (PROBE && p.probe_kind == 3) {
+                p.cs_lvc[slot] = make_uint2(1u, li0);
+                break;
+              }
+              li0 = p.cs_lvc[slot].y + group_lane;
+            }
             f3 contrib = F3s(0.0f), ray_origin = F3s(0.0f), ray_direction = F3s(0.0f);
             float weight = 1, ray_distance = 0;
             if (flag(p, STHIP_eLVCReservoirs)) {
@@ -1930,7 +1972,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
                 }
               };
               for (uint32_t ri = 0; ri < p.pc.gReservoirM; ri++) {
-                const uint32_t pick = rng.next_uint();
+                const uint32_t pick = coherent_li ? li0 + (1u + ri) * 32u : rng.next_uint();
                 if (!n) continue;
                 const float4* lvp = cache + 4 * (size_t)(pick % n);
                 if (!vertex_fits(lvp)) continue;
@@ -2236,6 +2278,18 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_rr_reduce(FrameParams p) {
   const int first = mine ? (int)(half * 32u) + (__ffs((int)mine) - 1) : (int)lane;
   const float rnd_first = __shfl(v.y, first, 64);  // WaveReadLaneFirst
   if (slot < p.path_count) p.rr[slot] = make_float4(pm, (mine && pm < 1.0f && rnd_first > pm) ? 1.0f : 0.0f, mine ? 1.0f : 0.0f, 0.0f);
+}
+
+// eCoherentSampling: WaveReadLaneFirst over the group's lanes that reached the site (entries (1, own draw) written by the probe)
+__global__ void __launch_bounds__(STHIP_BLOCK) k_cs_reduce(uint2* values, uint32_t path_count) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u, half = lane >> 5;
+  const uint2 v = slot < path_count ? values[slot] : make_uint2(0u, 0u);
+  const unsigned long long all = __ballot(v.x != 0u);
+  const uint32_t mine = (uint32_t)(all >> (half * 32u));
+  const int first = mine ? (int)(half * 32u) + (__ffs((int)mine) - 1) : (int)lane;
+  const uint32_t first_value = (uint32_t)__shfl((int)v.y, first, 64);
+  if (slot < path_count) values[slot] = make_uint2(mine ? 1u : 0u, first_value);
 }
 
 // ---- hash grid build (hashgrid.h): keys of the compacted appends, and the scatter into the bucket ranges ----

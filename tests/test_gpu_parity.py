@@ -262,6 +262,60 @@ def test_all_disney_lobes_and_long_paths(renderer):
         r.close()
 
 
+@pytest.mark.parametrize("flags,args", [
+    (["coherentsampling", "presamplelights"], {"lightPresampleTileSize": 64, "lightPresampleTileCount": 8}),
+    (["coherentsampling", "presamplelights", "neereservoirs", "~defershadowrays"], {"lightPresampleTileSize": 128, "lightPresampleTileCount": 4, "reservoirM": 4}),
+    (["coherentsampling", "connecttolightpaths", "lightvertexcache", "~defershadowrays"], {"maxDiffuseVertices": 3, "lightPathCount": 4000}),
+    (["coherentsampling", "presamplelights", "neereservoirs", "connecttolightpaths", "lightvertexcache", "lvcreservoirs", "~defershadowrays", "~coherentrr"],
+     {"maxDiffuseVertices": 3, "lightPathCount": 6000, "reservoirM": 3, "lightPresampleTileSize": 32, "lightPresampleTileCount": 16}),
+    (["coherentsampling", "presamplelights", "connecttolightpaths", "lightvertexcache", "lvcreservoirs", "~defershadowrays"],
+     {"maxDiffuseVertices": 4, "maxPathVertices": 7, "minPathVertices": 2, "lightPathCount": 5000, "reservoirM": 2}),
+])
+def test_coherent_sampling(flags, args):
+    """eCoherentSampling (path.hlsli:317-318,379-387,688,703): an index drawn at random becomes WaveReadLaneFirst(index) +
+    WaveGetLaneIndex(), so the lanes of a workgroup read consecutive presampled lights / cached light vertices. Defined over
+    the 8x4 pixel group like the coherent roulette: "first lane" = the lowest lane whose path executes that statement at that
+    path length. Oracle: group replay (a path that finds no group value reports its own draw and stops); HIP: one probe pass
+    and a half-wave reduction per site (the NEE index, then connect_lvc's, whose position in the random stream depends on the
+    first). Frames, ids and ray counts agree bit for bit, also together with the coherent roulette (last case: it runs from
+    the second vertex on) and on frame sizes with partial groups; and the flag does change the frame."""
+    from oracle import oracle_py
+    from stratum_amd.bdpt import BDPT
+
+    for make in (scenes.cornell_box, material_scene):
+        sc, cam = make()
+        W, H, seeds = 104, 76, 2
+        frame = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+        r = BDPT(device=0, args=dict(args, bdptFlag=flags))
+        try:
+            r.update(sc)
+            got = r.render(frame, 5, seeds)
+            ref = oracle_py.OracleScene(sc).render(frame, r.push_constants(frame), r.mSamplingFlags, 5, seeds)
+            assert np.array_equal(got["visibility"]["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
+            assert np.array_equal(got["ray_count"], ref["ray_count"])
+            nd = int((got["radiance"].view(np.uint32) != ref["radiance"].view(np.uint32)).any(axis=-1).sum())
+            assert nd == 0, (flags, nd, rel_l2(got["radiance"], ref["radiance"]))
+            r.set_flag("~coherentsampling")
+            plain = r.render(frame, 5, seeds)
+            assert not np.array_equal(plain["radiance"], got["radiance"])
+        finally:
+            r.close()
+
+
+def test_coherent_sampling_with_media_is_rejected():
+    from stratum_amd import _lib
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = scenes.cornell_box(fog=_fog())
+    r = BDPT(device=0, args={"bdptFlag": ["coherentsampling", "presamplelights"]})
+    try:
+        r.update(sc)
+        with pytest.raises(_lib.StratumHipError, match="eCoherentSampling with media"):
+            r.render(camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"]))
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("scene_name,args", [("materials", {"maxDiffuseVertices": 8, "maxPathVertices": 10, "minPathVertices": 4}), ("cornell", {"maxDiffuseVertices": 5, "maxPathVertices": 7, "minPathVertices": 2}),
                                              ("textured", {"maxDiffuseVertices": 4, "maxPathVertices": 8, "minPathVertices": 3, "bdptFlag": ["connecttoviews"]})])
 def test_coherent_russian_roulette(scene_name, args):
@@ -697,10 +751,10 @@ def test_environment_errors(renderer):
     sc, cam = scenes.environment_scene(image=True, emitter=False)
     renderer.update(sc)
     frame = camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"])
-    renderer.set_flag("coherentsampling")  # wave-scope sampling (path.hlsli:313-318): rejected, never ignored
+    renderer.set_flag("samplelightpower")  # reads a table upstream never fills: rejected, never ignored
     with pytest.raises(_lib.StratumHipError, match="sampling flag"):
         renderer.render(frame)
-    renderer.set_flag("~coherentsampling")
+    renderer.set_flag("~samplelightpower")
     sc.distributions = sc.distributions[:-5]  # a table that runs past gDistributions
     renderer.update(sc)
     with pytest.raises(_lib.StratumHipError, match="gDistributions"):

@@ -35,7 +35,8 @@ def run(cases=60, seed=1):
         raise KeyError(kind)
 
     FLAGS = ["~nee", "~mis", "~samplebsdfs", "~defershadowrays", "~raycones", "~normalmaps", "~remapthreads", "alphatest", "fliptriangleuvs", "flipnormalmaps",
-             "shadingnormalshadowfix", "uniformspheresampling", "presamplelights", "neereservoirs", "connecttoviews", "connecttolightpaths", "sampleenvironmentmapdirectly"]
+             "shadingnormalshadowfix", "uniformspheresampling", "presamplelights", "neereservoirs", "connecttoviews", "connecttolightpaths", "sampleenvironmentmapdirectly",
+             "coherentsampling"]
     bad = rejected = done = 0
     t0 = time.time()
     for case in range(cases):
@@ -52,10 +53,16 @@ def run(cases=60, seed=1):
         elif bundle == 1:
             flags += ["neereservoirs", "neereservoirreuse"]
             args.update(reservoirM=int(rng.integers(1, 5)), reservoirSpatialM=int(rng.integers(1, 4)), hashGridBucketCount=int(rng.choice([64, 1000, 100000])))
+        elif bundle == 3:  # coherent sampling where it has something to do: presampled lights and / or the light vertex cache
+            flags += ["coherentsampling"] + (["presamplelights"] if rng.integers(3) else []) + (["neereservoirs"] if rng.integers(2) else [])
+            if rng.integers(2):
+                flags += ["connecttolightpaths", "lightvertexcache"] + (["lvcreservoirs"] if rng.integers(2) else [])
+                args.update(maxDiffuseVertices=int(rng.integers(2, 5)), lightPathCount=int(rng.integers(max(1, W * H // 4), W * H + 1)))
+            args.update(reservoirM=int(rng.integers(1, 5)), lightPresampleTileSize=int(rng.choice([16, 64, 100])), lightPresampleTileCount=int(rng.choice([1, 4, 16])))
         elif bundle == 2:
             flags += ["coherentrr"]
             args.update(minPathVertices=int(rng.integers(2, 4)), maxPathVertices=int(rng.integers(4, 9)))
-        flags[:] = list(dict.fromkeys(f for f in flags if not (bundle <= 1 and f in ("~nee", "~remapthreads"))))
+        flags[:] = list(dict.fromkeys(f for f in flags if not (bundle in (0, 1, 3) and f in ("~nee", "~remapthreads"))))
         reuse = any(f.endswith("reuse") for f in flags)
         seeds, seed0 = int(rng.integers(1, 4)), int(rng.integers(0, 1000))
         sc, cam = scene(kind)
