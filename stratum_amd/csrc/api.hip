@@ -124,6 +124,7 @@ struct sthip_ctx {
   // host builds: leaf triangles in the node array behind their parent (bvh_build.h: BuiltBvh::embedded). Measured on the
   // bench scene: k_trace 2.30 ms either way (the leaf fetch is not what a step waits for), so off: two arrays are simpler
   bool embed_leaves = false;
+  bool lds_materials = true;  // k_shade stages gMaterialData in LDS when it fits 32 KB
   // frame
   DevBuf<uint8_t> views;  // gViews | gViewTransforms | gPrevViews | gPrevInverseViewTransforms
   DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays, light_vertices, conn, media_state, shadow_hit, shadow_ext, shadow_result;
@@ -366,6 +367,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->refill_idle = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
   else if (!strcmp(name, "bvh_builder"))
     ctx->bvh_builder = value == 1 ? 1 : 0;
+  else if (!strcmp(name, "lds_materials"))
+    ctx->lds_materials = value != 0;
   else if (!strcmp(name, "embed_leaves"))  // takes effect at the next sthip_scene_upload
     ctx->embed_leaves = value != 0;
   else if (!strcmp(name, "lbvh_algorithm"))  // 0: Karras radix tree, 1: PLOC (default)
@@ -1240,6 +1243,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.cs_nee = nullptr;
   p.cs_lvc = nullptr;
   p.probe_kind = 0;
+  p.lds_material_bytes = (ctx->lds_materials && !ctx->textured && ctx->materials_host.size() <= 32768) ? (uint32_t)(ctx->materials_host.size() & ~(size_t)3) : 0u;
+  const size_t shade_lds = p.lds_material_bytes;
   p.hg_checksums = ctx->hg_checksums.p;
   p.hg_counters = ctx->hg_counters.p;
   p.hg_indices = ctx->hg_indices.p;
@@ -1600,11 +1605,11 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
           if (ctx->textured)
             hipLaunchKernelGGL((k_shade<true, true, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, probe, depth);
           else
-            hipLaunchKernelGGL((k_shade<false, true, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, probe, depth);
+            hipLaunchKernelGGL((k_shade<false, true, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, probe, depth);
         } else if (ctx->textured)
           hipLaunchKernelGGL((k_shade<true, true, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, probe, depth);
         else
-          hipLaunchKernelGGL((k_shade<false, true, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, probe, depth);
+          hipLaunchKernelGGL((k_shade<false, true, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, probe, depth);
       };
       const unsigned reduce_grid = (unsigned)((p.path_count + STHIP_BLOCK - 1) / STHIP_BLOCK);
       p.rr = nullptr;
@@ -1634,20 +1639,20 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
         if (ctx->textured)
           hipLaunchKernelGGL((k_shade<true, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
         else
-          hipLaunchKernelGGL((k_shade<false, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+          hipLaunchKernelGGL((k_shade<false, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
       } else if (bdpt) {
         if (ctx->textured)
           hipLaunchKernelGGL((k_shade<true, true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
         else
-          hipLaunchKernelGGL((k_shade<false, true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+          hipLaunchKernelGGL((k_shade<false, true, true>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
       } else if (ctx->textured && ext)
         hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
       else if (ctx->textured)
         hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
       else if (ext)
-        hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
       else
-        hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
     });
     if (rc) return rc;
     rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + in_flight == seed_count ? 1u : 0u, primary_rays * in_flight); });

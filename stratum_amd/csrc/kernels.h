@@ -114,6 +114,7 @@ struct FrameParams {
   // runs on with that value up to connect_lvc's draw; the round proper reads both. Null without the flag.
   uint2* cs_nee;
   uint2* cs_lvc;
+  uint32_t lds_material_bytes;  // bytes of gMaterialData a k_shade block stages in LDS (0: none)
   uint32_t probe_kind;  // of a k_shade<PROBE> launch: 1 = the roulette, 2 = the NEE index, 3 = connect_lvc's index
   // bounded LDS stacks (k_trace<., ., true>): the rays k_trace_deep traces again, 4 x float4 each, and their count
   float4* deep_rays;
@@ -1110,6 +1111,14 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
 // path records its p and the random number it would draw, and nothing else is written.
 template <bool TEXTURED, bool EXT, bool LT = false, bool MEDIA = false, bool PROBE = false>
 __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams p, uint32_t depth) {
+  // gMaterialData staged in LDS (untextured instantiations; the table of a scene is a few KB): a vertex then reads its 72-byte
+  // record with LDS reads instead of a divergent gather. p.lds_material_bytes = 0 turns it off (table too large, option).
+  extern __shared__ uint32_t shade_lds[];
+  if (!TEXTURED && p.lds_material_bytes) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.scene.materials);
+    for (uint32_t i = threadIdx.x; i < (p.lds_material_bytes >> 2); i += STHIP_BLOCK) shade_lds[i] = src[i];
+    __syncthreads();
+  }
   // Workgroup b works on segment b % 8 (its XCD's) of the incoming queue and appends to the same segment of the
   // outgoing queues, so a segment never grows. In the first bounce a segment is a contiguous eighth of the slots
   // (the same split WaveWork uses): an XCD keeps one part of the image, and the part of the scene seen from it,
@@ -1468,6 +1477,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
           first_hit_normal = n_copy;
         }
         m.load_textured(p.scene, in.material_address(), sd.u, sd.v, sd.uv_screen_size, sd.packed_shading_normal, sd.packed_tangent, p.sampling_flags);
+      } else if (p.lds_material_bytes && in.material_address() + 72u <= p.lds_material_bytes) {
+        m.load_lds((DisneyMaterial::LdsFloat*)shade_lds, in.material_address());
       } else {
         m.load(p.scene, in.material_address());
       }

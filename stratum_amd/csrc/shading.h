@@ -389,6 +389,15 @@ struct DisneyMaterial {
     d2 = make_float4(p[10], p[11], p[12], p[13]);
   }
 
+  // the same record out of the copy of gMaterialData a k_shade block holds in LDS (kernels.h: shade_lds)
+  typedef __attribute__((address_space(3))) const float LdsFloat;
+  DEV void load_lds(const LdsFloat* table, uint32_t address) {
+    const LdsFloat* p = table + (address >> 2);
+    d0 = make_float4(p[0], p[1], p[2], p[3]);
+    d1 = make_float4(p[5], p[6], p[7], p[8]);
+    d2 = make_float4(p[10], p[11], p[12], p[13]);
+  }
+
   // sample_image, image_value.h:81-97: SampleLevel(gStaticSampler, uv, lod) as repeat addressing + trilinear
   // filtering over the box-filtered mip chain
   static DEV float4 texel(const DeviceScene& sc, const DeviceImage& im, uint32_t level, int x, int y) {
