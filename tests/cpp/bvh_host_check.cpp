@@ -1,0 +1,118 @@
+// bvh_host_check.cpp — the HOST side of the acceleration-structure build (stratum_amd/csrc/bvh_build.cpp: validation,
+// threaded binned-SAH bottom levels, embedded leaves, top level, transforms-only rebuild, treetop selection, node packing)
+// as a plain CPU program, so that it can run under AddressSanitizer / UndefinedBehaviorSanitizer / ThreadSanitizer (GPU
+// sanitizers are not available on the pool). Reads the raw scene arrays tests/test_host_cpp.py dumps:
+//   bvh_host_check <dir>   with <dir>/{vertices,indices,instances,xf,inv_xf,materials}.bin
+// Checks structural invariants of what comes out and prints one line. The GPU builder's entry points are never reached
+// with the SAH builder; they are defined here only to satisfy the linker.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../stratum_amd/csrc/bvh_build.h"
+
+namespace sthip {
+bool lbvh_build_gpu(const std::vector<BvhTri>&, std::vector<BvhNode>&, std::vector<BvhTri>&, uint32_t&, uint32_t&, float&, std::string& err) {
+  err = "no device in this harness";
+  return false;
+}
+bool lbvh_build_device(const DeviceBuildTarget&, const std::vector<MeshPiece>&, uint32_t, uint32_t, uint32_t&, uint32_t&, float*, float&, std::string& err) {
+  err = "no device in this harness";
+  return false;
+}
+}  // namespace sthip
+
+template <typename T>
+static std::vector<T> slurp(const std::string& path) {
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) {
+    std::fprintf(stderr, "cannot open %s\n", path.c_str());
+    std::exit(2);
+  }
+  const size_t n = (size_t)f.tellg();
+  std::vector<T> v(n / sizeof(T));
+  f.seekg(0);
+  f.read((char*)v.data(), v.size() * sizeof(T));
+  return v;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  const std::string d = argv[1];
+  auto vertices = slurp<sthip_PackedVertexData>(d + "/vertices.bin");
+  auto indices = slurp<uint8_t>(d + "/indices.bin");
+  auto instances = slurp<sthip_InstanceData>(d + "/instances.bin");
+  auto xf = slurp<sthip_TransformData>(d + "/xf.bin");
+  auto inv = slurp<sthip_TransformData>(d + "/inv_xf.bin");
+  auto materials = slurp<uint8_t>(d + "/materials.bin");
+  indices.resize(indices.size() + 8, 0);
+  sthip_scene_desc s{};
+  s.gVertices = vertices.data();
+  s.vertex_count = (uint32_t)vertices.size();
+  s.gIndices = indices.data();
+  s.indices_bytes = indices.size() - 8;
+  s.gInstances = instances.data();
+  s.gInstanceTransforms = xf.data();
+  s.gInstanceInverseTransforms = inv.data();
+  s.instance_count = (uint32_t)instances.size();
+  s.gMaterialData = materials.data();
+  s.material_bytes = materials.size();
+  size_t total_nodes = 0;
+  for (int embed = 0; embed < 2; embed++) {
+    sthip::BuiltBvh b;
+    std::string err;
+    if (!sthip::build_scene_bvh(s, b, err, sthip::BVH_BUILDER_SAH_HOST, nullptr, embed != 0)) {
+      std::printf("BUILD FAILED: %s\n", err.c_str());
+      return 1;
+    }
+    // every reference stays inside its array; every triangle is referenced exactly once
+    std::vector<uint32_t> seen(b.tris.size(), 0);
+    for (size_t i = 0; i < b.nodes.size(); i++) {
+      if (b.embedded && b.unit_tri[i] != 0xFFFFFFFFu) continue;  // a triangle's unit
+      for (int c = 0; c < 2; c++) {
+        const uint32_t r = b.nodes[i].ref[c];
+        if (r == BVH_INVALID_REF) continue;
+        if (!(r & BVH_LEAF_BIT)) {
+          if (r >= b.nodes.size()) return std::printf("FAIL: inner reference out of range\n"), 1;
+        } else if (r & BVH_INST_BIT) {
+          if ((r & 0xFFFFu) >= b.entries.size()) return std::printf("FAIL: entry reference out of range\n"), 1;
+        } else {
+          const uint32_t first = (r & 0x3FFFFFFFu) >> 2, count = (r & 3u) + 1;
+          for (uint32_t k = 0; k < count; k++) {
+            uint32_t t = first + k;
+            if (b.embedded) {
+              if (t >= b.unit_tri.size() || b.unit_tri[t] == 0xFFFFFFFFu) return std::printf("FAIL: leaf unit is not a triangle\n"), 1;
+              t = b.unit_tri[t];
+            }
+            if (t >= b.tris.size()) return std::printf("FAIL: triangle reference out of range\n"), 1;
+            seen[t]++;
+          }
+        }
+      }
+    }
+    size_t wrapped = 0;
+    for (uint32_t c : seen) {
+      if (c == 0) return std::printf("FAIL: a triangle is not referenced\n"), 1;
+      if (c > 1) wrapped++;  // a single-leaf mesh is wrapped with its leaf in both child slots
+    }
+    // the treetop and the packed nodes
+    sthip::Treetop tt;
+    sthip::build_treetop(b.nodes.data(), b.nodes.size(), b.entries, b.root_ref, 170, tt);
+    std::vector<BvhNodePacked> packed;
+    sthip::pack_nodes(b.nodes.data(), b.nodes.size(), packed);
+    sthip::pack_nodes(tt.nodes.data(), tt.nodes.size(), packed);
+    // a transforms-only rebuild of the top level with the same transforms
+    std::vector<BvhNode> tlas;
+    uint32_t root = 0, world = 0, depth = 0;
+    float center[3], radius = 0;
+    if (!sthip::rebuild_top_level(b.top, xf.data(), inv.data(), s.instance_count, tlas, root, world, depth, center, radius, err)) return std::printf("REBUILD FAILED: %s\n", err.c_str()), 1;
+    if (depth != b.stack_depth && !b.entries.empty()) return std::printf("FAIL: rebuilt top level has stack depth %u, build had %u\n", depth, b.stack_depth), 1;
+    total_nodes += b.nodes.size();
+    std::printf("%s: %zu units, %zu triangles (%zu in wrapped leaves), %zu entries, stack depth %u, treetop %zu\n", embed ? "embedded" : "separate", b.nodes.size(), b.tris.size(), wrapped, b.entries.size(),
+                b.stack_depth, tt.nodes.size());
+  }
+  std::printf("BVH HOST OK %zu\n", total_nodes);
+  return 0;
+}
