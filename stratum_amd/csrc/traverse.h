@@ -183,18 +183,19 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
   const float U = Cx * By - Cy * Bx;
   const float V = Ax * Cy - Ay * Cx;
   const float W = Bx * Ay - By * Ax;
-  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+  // No early exits: in a wave every lane waits for the slowest one anyway, and each `return` would cost an exec-mask
+  // region (the tests are the same, in the same arithmetic; a zero determinant makes rcp infinite and tt fail its range
+  // test, or NaN, which fails it too — det != 0 is tested all the same).
+  const bool edges_disagree = ((U < 0.0f) | (V < 0.0f) | (W < 0.0f)) & ((U > 0.0f) | (V > 0.0f) | (W > 0.0f));
   const float det = U + V + W;
-  if (det == 0.0f) return false;
   const float Az = s.Sz * Akz, Bz = s.Sz * Bkz, Cz = s.Sz * Ckz;
   const float T = fmaf(W, Cz, fmaf(V, Bz, U * Az));
   const float rcp = 1.0f / det;
   const float tt = T * rcp;
-  if (!(tt > tmin && tt < tmax)) return false;
   t = tt;
   b1 = V * rcp;
   b2 = W * rcp;
-  return true;
+  return !edges_disagree & (det != 0.0f) & (tt > tmin) & (tt < tmax);
 }
 
 // stack sentinels (both carry the leaf bits, so the inner-node loop hands them to the leaf handler)
@@ -300,7 +301,7 @@ struct Traversal {
       // stack has one spare level for it), and selects pick what applies — no exec-mask regions in the loop.
       const bool h0 = tn0 <= tf0;
       const bool h1 = tn1 <= tf1;
-      const bool first1 = h1 && (!h0 || tn1 < tn0);  // descend into child 1 first
+      const bool first1 = h1 & (!h0 | (tn1 < tn0));  // descend into child 1 first (bitwise: a short-circuit here compiles to an exec-mask region)
       stack[top] = first1 ? cr.x : cr.y;
       ref = (h0 || h1) ? (first1 ? cr.y : cr.x) : popped;
       const uint32_t next_top = (h0 && h1) ? top + STRIDE : ((h0 || h1) ? top : top - STRIDE);
@@ -411,12 +412,11 @@ struct Traversal {
           return;
         }
         const uint32_t ip = __float_as_uint(v0.w) | id_bits;
-        if (t < hit.t || (t == hit.t && hit.ip != 0xFFFFFFFFu && hit_key(ip) < hit_key(hit.ip))) {
-          hit.t = t;
-          hit.b1 = b1;
-          hit.b2 = b2;
-          hit.ip = ip;
-        }
+        const bool closer = (t < hit.t) | ((t == hit.t) & (hit.ip != 0xFFFFFFFFu) & (hit_key(ip) < hit_key(hit.ip)));
+        hit.t = closer ? t : hit.t;
+        hit.b1 = closer ? b1 : hit.b1;
+        hit.b2 = closer ? b2 : hit.b2;
+        hit.ip = closer ? ip : hit.ip;
       }
     }
     pop(stack);
