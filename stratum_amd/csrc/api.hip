@@ -560,6 +560,8 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (!sthip::build_scene_bvh(*s, built, err, ctx->bvh_builder, device_build ? &target : nullptr, ctx->embed_leaves && STHIP_NODE_STRIDE == 48))
     return fail(ctx, err.find("only triangle") != std::string::npos ? STHIP_ERR_UNSUPPORTED : STHIP_ERR_INVALID_ARGUMENT, "scene: " + err);
 
+  if (((size_t)built.dev_nodes + built.nodes.size() + 2 * built.entries.size() + 2) * sizeof(BvhNodeSlot) > 0xFFFFFFFFull || ((size_t)built.dev_tris + built.tris.size()) * sizeof(BvhTri) > 0xFFFFFFFFull)
+    return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: the acceleration structure exceeds 4 GiB (the traversal addresses nodes and triangles with 32-bit byte offsets)");
   if (built.stack_depth > STHIP_MAX_STACK_DEPTH) return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: the acceleration structure is too deep for the traversal stack (use the SAH builder)");
   ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
   ctx->stats.bvh_build_gpu_ms = built.gpu_build_ms;

@@ -268,12 +268,12 @@ struct Traversal {
       if (!(ref & BVH_LEAF_BIT)) {
       float4 n0, n1, nz;
       if (TOP && (ref & BVH_TOP_BIT)) {  // a treetop node: three LDS reads instead of three divergent vector loads
-        const LdsFloat4* n = top_lds + (ref & ~BVH_TOP_BIT) * 3u;
+        const LdsFloat4* n = top_lds + (uint32_t)((ref & ~BVH_TOP_BIT) * 3u);
         n0 = lds_load4(n);
         n1 = lds_load4(n + 1);
         nz = lds_load4(n + 2);
       } else {
-        const float4* n = reinterpret_cast<const float4*>(base + (size_t)ref * BVH_NODE_BYTES);
+        const float4* n = reinterpret_cast<const float4*>(base + (uint32_t)(ref * BVH_NODE_BYTES));  // 32-bit offset (the upload checks the array stays below 4 GiB): scalar base + vector offset addressing, no 64-bit multiply
         n0 = n[0];
         n1 = n[1];
         nz = n[2];
