@@ -262,6 +262,7 @@ struct Traversal {
   // wave are still walking (the others would only wait for them).
   DEV void inner_loop(const DeviceBvh& bvh, uint32_t* stack, uint32_t min_lanes, TraverseCounters& cnt) {
     const char* base = reinterpret_cast<const char*>(bvh.nodes);
+    const float tbest = hit.t;  // does not change while inner nodes are walked (an occlusion lane stops at its first hit, so for it hit.t stays tmax)
     // Every lane that holds an inner node takes at least one step per call (progress), then the wave goes on while
     // at least `min_lanes` lanes (>= 1) still hold an inner node: one wave-uniform test per step.
     for (;;) {
@@ -273,18 +274,28 @@ struct Traversal {
         n1 = lds_load4(n + 1);
         nz = lds_load4(n + 2);
       } else {
-        const float4* n = reinterpret_cast<const float4*>(base + (uint32_t)(ref * BVH_NODE_BYTES));  // 32-bit offset (the upload checks the array stays below 4 GiB): scalar base + vector offset addressing, no 64-bit multiply
+        // 32-bit byte offset (the upload checks the array stays below 4 GiB): scalar base + vector offset addressing, no
+        // 64-bit multiply; 48 = 32 + 16 as shifts and an add (a 32-bit v_mul_lo is a quarter-rate instruction)
+        uint32_t offset;
+        if (BVH_NODE_BYTES == 48u) {
+          uint32_t r32;  // (written as ref * 48 or as two shifts the compiler emits v_mul_lo_u32; the asm keeps the shift)
+          asm("v_lshlrev_b32 %0, 5, %1" : "=v"(r32) : "v"(ref));
+          offset = r32 + (ref << 4);
+        } else {
+          offset = ref * BVH_NODE_BYTES;
+        }
+        const float4* n = reinterpret_cast<const float4*>(base + offset);
         n0 = n[0];
         n1 = n[1];
         nz = n[2];
       }
       const uint2 cr = make_uint2(packed_ref(n0), packed_ref(n1));
-      const uint32_t popped = stack[top - STRIDE];
+      uint32_t* slot = stack + (top - STRIDE);  // the pop slot; the push slot is one level above it (one address, two offsets)
+      const uint32_t popped = slot[0];
       if (COUNT) {
         cnt.nodes++;
         if (first_active_lane()) cnt.inner_slots += 64;
       }
-      const float tbest = hit.t;  // an occlusion lane stops at its first hit, so for it hit.t stays tmax
       const float a0x = fmaf(n0.x, sp.idir.x, sp.noodL.x), b0x = fmaf(n0.y, sp.idir.x, sp.noodH.x);
       const float a0y = fmaf(n0.z, sp.idir.y, sp.noodL.y), b0y = fmaf(n0.w, sp.idir.y, sp.noodH.y);
       const float a0z = fmaf(nz.x, sp.idir.z, sp.noodL.z), b0z = fmaf(nz.y, sp.idir.z, sp.noodH.z);
@@ -292,17 +303,19 @@ struct Traversal {
       const float a1y = fmaf(n1.z, sp.idir.y, sp.noodL.y), b1y = fmaf(n1.w, sp.idir.y, sp.noodH.y);
       const float a1z = fmaf(nz.z, sp.idir.z, sp.noodL.z), b1z = fmaf(nz.w, sp.idir.z, sp.noodH.z);
       const float tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), tmin));
-      const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), tbest));
+      const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fmaxf(a0z, b0z));
       const float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), tmin));
-      const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), tbest));
+      const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fmaxf(a1z, b1z));
       // (every node has two valid children: a single-leaf tree is wrapped with the leaf in both slots, bvh_build.cpp)
       // Branch-free step: the pop is read speculatively (the slot below `top` always exists: the DONE sentinel sits
       // at the bottom) next to the node loads, the push is written speculatively (the slot at `top` is free; the LDS
       // stack has one spare level for it), and selects pick what applies — no exec-mask regions in the loop.
-      const bool h0 = tn0 <= tf0;
-      const bool h1 = tn1 <= tf1;
+      // the far bound tbest as a compare of its own (tn <= min(tf, tbest) is tn <= tf and tn <= tbest): a register that comes
+      // from outside the loop would have to be quieted (v_max x, x) before it may enter a min, in every step
+      const bool h0 = (tn0 <= tf0) & (tn0 <= tbest);
+      const bool h1 = (tn1 <= tf1) & (tn1 <= tbest);
       const bool first1 = h1 & (!h0 | (tn1 < tn0));  // descend into child 1 first (bitwise: a short-circuit here compiles to an exec-mask region)
-      stack[top] = first1 ? cr.x : cr.y;
+      slot[STRIDE] = first1 ? cr.x : cr.y;
       ref = (h0 || h1) ? (first1 ? cr.y : cr.x) : popped;
       const uint32_t next_top = (h0 && h1) ? top + STRIDE : ((h0 || h1) ? top : top - STRIDE);
       top = BOUNDED ? min(next_top, limit) : next_top;
