@@ -399,6 +399,10 @@ struct Traversal {
     const uint32_t first = (ref & 0x3FFFFFFFu) >> 2;
     const uint32_t count = (ref & 3u) + 1u;
     const char* tbase = reinterpret_cast<const char*>(bvh.tris);
+    // No exec-mask regions in the triangle loop (each costs more than the arithmetic it would skip: the lanes of a wave wait
+    // for one another anyway): every lane runs the whole test, a candidate is folded in with selects, and an occlusion
+    // lane's verdict is collected in `occluded` and applied behind the loop.
+    bool occluded = false;
     for (uint32_t i = 0; i < count; i++) {
       const float4* tv = reinterpret_cast<const float4*>(tbase + (size_t)((first + i) * 48u));
       const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
@@ -407,32 +411,34 @@ struct Traversal {
         if (first_active_lane()) cnt.tri_slots += 64;
       }
       float t, b1, b2;
-      if (tri_test(sp, xyz(v0), xyz(v1), xyz(v2), tmin, tmax, t, b1, b2)) {
+      bool candidate = tri_test(sp, xyz(v0), xyz(v1), xyz(v2), tmin, tmax, t, b1, b2);
+      if (ALPHA && candidate) {
         // gAlphaTest: the candidate must pass the mask of its instance's material (instances that share a mesh may
         // have different materials, so the mask comes from the instance, the uvs from the leaf triangle)
-        const uint32_t mask = (ALPHA && bvh.alpha_test) ? bvh.inst_alpha[(__float_as_uint(v0.w) | id_bits) & 0xFFFFu] : BVH_NO_ALPHA;
+        const uint32_t mask = bvh.alpha_test ? bvh.inst_alpha[(__float_as_uint(v0.w) | id_bits) & 0xFFFFu] : BVH_NO_ALPHA;
         if (mask != BVH_NO_ALPHA) {
           const float2* q = bvh.tri_uv + (size_t)(first + i) * 3u;
           const float2 u0 = q[0], u1 = q[1], u2 = q[2];
           const float u = u0.x + (u1.x - u0.x) * b1 + (u2.x - u0.x) * b2;  // shading_data.hlsli:2-6
           float v = u0.y + (u1.y - u0.y) * b1 + (u2.y - u0.y) * b2;
           if (bvh.flip_uvs) v = 1 - v;
-          if (!(sample_image1(bvh, mask, u, v) >= 0.75f)) continue;
+          candidate = sample_image1(bvh, mask, u, v) >= 0.75f;
         }
-        if (is_any()) {
-          hit.ip = 0;
-          ref = TRAV_DONE;
-          return;
-        }
-        const uint32_t ip = __float_as_uint(v0.w) | id_bits;
-        const bool closer = (t < hit.t) | ((t == hit.t) & (hit.ip != 0xFFFFFFFFu) & (hit_key(ip) < hit_key(hit.ip)));
-        hit.t = closer ? t : hit.t;
-        hit.b1 = closer ? b1 : hit.b1;
-        hit.b2 = closer ? b2 : hit.b2;
-        hit.ip = closer ? ip : hit.ip;
       }
+      const bool any_lane = is_any();
+      occluded |= candidate & any_lane;
+      const uint32_t ip = __float_as_uint(v0.w) | id_bits;
+      const bool closer = candidate & !any_lane & ((t < hit.t) | ((t == hit.t) & (hit.ip != 0xFFFFFFFFu) & (hit_key(ip) < hit_key(hit.ip))));
+      hit.t = closer ? t : hit.t;
+      hit.b1 = closer ? b1 : hit.b1;
+      hit.b2 = closer ? b2 : hit.b2;
+      hit.ip = closer ? ip : hit.ip;
     }
-    pop(stack);
+    // pop — or, for an occlusion lane that found its hit, the end of the ray (hit.ip = 0 says "occluded")
+    const uint32_t popped = stack[top - STRIDE];
+    hit.ip = occluded ? 0u : hit.ip;
+    ref = occluded ? TRAV_DONE : popped;
+    top = occluded ? top : top - STRIDE;
   }
 
   // one wave-synchronous round: inner nodes until (almost) every lane holds a leaf, then the leaves
