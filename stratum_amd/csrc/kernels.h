@@ -561,12 +561,12 @@ __global__ void __launch_bounds__(STHIP_BLOCK, PRIMARY_BLOCKS) k_trace_primary(F
         const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), tbest));
         const float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), 0.0f));
         const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), tbest));
-        const bool h0 = live && (tn0 <= tf0);
-        const bool h1 = live && (tn1 <= tf1);
+        const bool h0 = live & (tn0 <= tf0);
+        const bool h1 = live & (tn1 <= tf1);
         const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
         if (m0 | m1) {
           // nearer child first by vote: lanes that hit child 1 and see it nearer (or do not hit child 0 at all)
-          const unsigned long long prefer1 = __ballot(h1 && (!h0 || tn1 < tn0));
+          const unsigned long long prefer1 = __ballot(h1 & (!h0 | (tn1 < tn0)));
           const bool first1 = m1 && (!m0 || __popcll(prefer1) * 2 > __popcll(m0 | m1));
           ref = first1 ? cr.y : cr.x;
           if (m0 && m1) {
@@ -628,24 +628,25 @@ __global__ void __launch_bounds__(STHIP_BLOCK, PRIMARY_BLOCKS) k_trace_primary(F
           cnt.tri_slots += 64;
         }
         float t, b1, b2;
-        if (live && tri_test(sp, xyz(v0), xyz(v1), xyz(v2), 0.0f, __builtin_inff(), t, b1, b2)) {
-          const uint32_t mask = (ALPHA && p.bvh.alpha_test) ? p.bvh.inst_alpha[(__float_as_uint(v0.w) | id_bits) & 0xFFFFu] : BVH_NO_ALPHA;
+        // (no exec-mask regions: see Traversal::leaf_step)
+        bool candidate = live & tri_test(sp, xyz(v0), xyz(v1), xyz(v2), 0.0f, __builtin_inff(), t, b1, b2);
+        if (ALPHA && candidate) {
+          const uint32_t mask = p.bvh.alpha_test ? p.bvh.inst_alpha[(__float_as_uint(v0.w) | id_bits) & 0xFFFFu] : BVH_NO_ALPHA;
           if (mask != BVH_NO_ALPHA) {
             const float2* q = p.bvh.tri_uv + (size_t)(first + i) * 3u;
             const float2 u0 = q[0], u1 = q[1], u2 = q[2];
             const float u = u0.x + (u1.x - u0.x) * b1 + (u2.x - u0.x) * b2;
             float v = u0.y + (u1.y - u0.y) * b1 + (u2.y - u0.y) * b2;
             if (p.bvh.flip_uvs) v = 1 - v;
-            if (!(sample_image1(p.bvh, mask, u, v) >= 0.75f)) continue;
-          }
-          const uint32_t ip = __float_as_uint(v0.w) | id_bits;
-          if (t < hit.t || (t == hit.t && hit.ip != 0xFFFFFFFFu && hit_key(ip) < hit_key(hit.ip))) {
-            hit.t = t;
-            hit.b1 = b1;
-            hit.b2 = b2;
-            hit.ip = ip;
+            candidate = sample_image1(p.bvh, mask, u, v) >= 0.75f;
           }
         }
+        const uint32_t ip = __float_as_uint(v0.w) | id_bits;
+        const bool closer = candidate & ((t < hit.t) | ((t == hit.t) & (hit.ip != 0xFFFFFFFFu) & (hit_key(ip) < hit_key(hit.ip))));
+        hit.t = closer ? t : hit.t;
+        hit.b1 = closer ? b1 : hit.b1;
+        hit.b2 = closer ? b2 : hit.b2;
+        hit.ip = closer ? ip : hit.ip;
       }
       ref = top ? stack[--top] : TRAV_DONE;
     }
