@@ -209,6 +209,21 @@ def run_rays(cases=40, seed=1, n=20000):
                 w = np.nonzero(ra != rb)[0]
                 print("  (the oracle's own BVH any-hit differs from its brute force on %d rays, styles %s, closest-hit says %s, tmin %s tmax %s)" % (w.size, style[w], ref["instance_primitive_index"][w] != wire.MISS, rays["tmin"][w], rays["tmax"][w]))
             if not (same and same_any):
+                # A known hole of the CONTRACT, not of a traversal: from an origin hundreds of scene sizes away the sheared
+                # vertices of a triangle collapse in single precision, edge functions come out as exact zeros, and the test
+                # accepts a "hit" whose point o + t d lies nowhere near the triangle (Woop et al. recompute such cases in
+                # double; the contract has no such fallback: DESIGN.md 9). No acceleration structure finds these, the oracle's
+                # own BVH included. They are reported, and not counted, when (1) the HIP path agrees with the oracle's BVH
+                # traversal and (2) every brute-force-only hit point lies outside the scene's bounds by more than its size.
+                rbvh, _ = orc.trace(rays, alpha_test=alpha)
+                agree_bvh = all(np.array_equal(got[f].view(np.uint32), rbvh[f].view(np.uint32)) for f in ("instance_primitive_index", "t", "b1", "b2")) and np.array_equal(ga, rb)
+                w = np.nonzero((got["instance_primitive_index"] != ref["instance_primitive_index"]) | (ga != ra))[0]
+                hp = rays["origin"][w].astype(np.float64) + ref["t"][w].astype(np.float64)[:, None] * rays["direction"][w].astype(np.float64)
+                wlo, whi = lo - 3 * (hi - lo) - 20.0, hi + 3 * (hi - lo) + 20.0  # generous: instances are placed around the meshes
+                outside = ((hp < wlo) | (hp > whi)).any(axis=1) | ~np.isfinite(hp).all(axis=1)
+                if agree_bvh and outside.all():
+                    print("  (%d spurious contract hit(s) from far origins, styles %s: brute force only; HIP == the oracle's BVH traversal)" % (w.size, style[w]))
+                    continue
                 bad += 1
                 diff = np.nonzero(got["instance_primitive_index"] != ref["instance_primitive_index"])[0]
                 w = np.nonzero(ga != ra)[0]
