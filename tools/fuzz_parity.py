@@ -211,8 +211,7 @@ def run_rays(cases=40, seed=1, n=20000):
             if not (same and same_any):
                 # A known hole of the CONTRACT, not of a traversal: from an origin hundreds of scene sizes away the sheared
                 # vertices of a triangle collapse in single precision, edge functions come out as exact zeros, and the test
-                # accepts a "hit" whose point o + t d lies nowhere near the triangle (Woop et al. recompute such cases in
-                # double; the contract has no such fallback: DESIGN.md 9). No acceleration structure finds these, the oracle's
+                # accepts a "hit" whose point o + t d lies nowhere near the triangle. No acceleration structure finds these, the oracle's
                 # own BVH included. They are reported, and not counted, when (1) the HIP path agrees with the oracle's BVH
                 # traversal and (2) every brute-force-only hit point lies outside the scene's bounds by more than its size.
                 rbvh, _ = orc.trace(rays, alpha_test=alpha)
