@@ -409,7 +409,7 @@ def main():
                     "algorithmic_bytes_per_vertex": 244 + 208,
                     "achieved_gbs": round((244 + 208) * float(rays_closest + rays_pr) / max(ms_shade * 1e-3, 1e-12) / 1e9, 1),
                     "peak_gbs": HBM_PEAK_GBS,
-                    "note": "per path vertex 244 B of gathers (3 vertices, indices, instance, transform, material; SURVEY 8d) + 104 B of path state read and written; bound: HBM",
+                    "note": "per path vertex 244 B of gathers (3 vertices, indices, instance, transform, material; SURVEY 8d) + 208 B of path state read and written (algorithmic); the committed PMC profile shows 1.94 GB of HBM-side traffic per step (3.2 TB/s) and ~2300 VALU instructions per vertex: bound by VALU issue under the arithmetic contract (correctly rounded divisions, pcg4d, software transcendentals) at 3 waves/SIMD, not by HBM (DESIGN.md 4)",
                 },
             },
             "note": "k_trace = closest-hit rays of bounce >= 1 and all shadow rays (the first bounce runs as wave packets in k_trace_primary: other_kernels). "
