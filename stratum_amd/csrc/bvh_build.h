@@ -10,9 +10,9 @@
 #include "bvh.h"
 
 #if defined(__HIPCC__)
-#define STHIP_HD __host__ __device__
+#define STHIP_BVH_HD __host__ __device__
 #else
-#define STHIP_HD
+#define STHIP_BVH_HD
 #endif
 
 namespace sthip {
@@ -120,7 +120,7 @@ void build_treetop(const BvhNode* nodes, size_t node_count, const std::vector<Tl
 // one for every b, an upper plane >= it:
 //   lower, v >= 0: M = (m - 255) & ~255 (for m < 255: -0 with M = 0, i.e. values in [-255 ulp, -0]);  lower, v < 0: M = (m + 255) & ~255
 //   upper: mirrored.  Infinite / NaN planes (empty children) are clamped to +-3.4e38 first so that no byte makes a NaN.
-STHIP_HD inline uint32_t pack_plane(float v, bool upper, uint32_t byte) {
+STHIP_BVH_HD inline uint32_t pack_plane(float v, bool upper, uint32_t byte) {
   if (!(v > -3.0e38f)) v = -3.0e38f;  // also NaN
   if (v > 3.0e38f) v = 3.0e38f;
   uint32_t u;
@@ -141,7 +141,7 @@ STHIP_HD inline uint32_t pack_plane(float v, bool upper, uint32_t byte) {
   }
   return sign | M | (byte & 0xFFu);
 }
-STHIP_HD inline BvhNodePacked pack_node(const BvhNode& n) {
+STHIP_BVH_HD inline BvhNodePacked pack_node(const BvhNode& n) {
   BvhNodePacked q;
   uint32_t w[8];
   for (int k = 0; k < 4; k++) {
