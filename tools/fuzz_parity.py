@@ -81,6 +81,7 @@ def run(cases=60, seed=1):
             if rng.integers(4) == 0: opts["treetop"] = 0
             if "bvh_builder" in opts: opts["lbvh_algorithm"] = int(rng.integers(2))
             if rng.integers(4) == 0: opts["lds_stack_levels"] = int(rng.integers(4, 14))  # bounded LDS stacks + k_trace_deep
+            if rng.integers(4) == 0 and "bvh_builder" not in opts: opts["embed_leaves"] = 1  # leaf triangles inside the node array
             for k, v in opts.items():
                 r.set_option(k, v)
             shard_n = 1 if reuse else int(rng.choice([1, 1, 2, 3]))  # a hash grid is a whole-frame structure: rejected on a shard
