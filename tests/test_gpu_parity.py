@@ -569,6 +569,45 @@ def test_embedded_leaves_give_the_same_frames(atrium_scene):
                 assert np.array_equal(a[k][f].view(np.uint32), b[k][f].view(np.uint32)), f
 
 
+@pytest.mark.parametrize("algorithm", [0, 1])
+def test_gpu_lbvh_edge_sizes(algorithm):
+    """The device builder at the sizes where it hands over to the host builder (fewer than 64 triangles per mesh), at its
+    smallest own sizes (64, 65 triangles: a PLOC run of two rounds' worth), with an odd byte stride mix (16- and 32-bit
+    indices) and an identity mesh next to transformed ones: ray batches equal the SAH build's."""
+    from stratum_amd.bdpt import BDPT
+    from stratum_amd.scene import SceneBuilder, rotate_y, scale, translate
+
+    def soup(sizes, seed):
+        rng = np.random.RandomState(seed)
+        b = SceneBuilder("edge")
+        m = b.add_material((0.5, 0.5, 0.5))
+        e = b.add_emitter((5.0, 5.0, 5.0))
+        for k, tris in enumerate(sizes):
+            c = rng.uniform(-1, 1, (tris, 1, 3))
+            pts = (c + rng.normal(scale=0.2, size=(tris, 3, 3))).reshape(-1, 3)
+            mesh = b.add_mesh(pts, None, None, np.arange(tris * 3).reshape(-1, 3), index_stride=2 if k % 2 else 4)
+            b.add_instance(mesh, e if k == 0 else m, None if k < 2 else translate(rng.uniform(-1, 1, 3)) @ rotate_y(rng.uniform(0, 6)) @ scale(rng.uniform(0.5, 1.5, 3)))
+        return b.build()
+
+    rays = random_rays(30000, 21, -2.5, 2.5)
+    for sizes in ([1], [63], [64], [65], [2, 63, 64, 200, 7], [64, 64, 64]):
+        sc = soup(sizes, 5 + len(sizes))
+        out = {}
+        for kind in (0, 1):
+            r = BDPT(device=0)
+            try:
+                r.set_option("bvh_builder", kind)
+                r.set_option("lbvh_algorithm", algorithm)
+                r.update(sc)
+                out[kind] = (r.trace(rays), r.trace(rays, any_hit=True))
+            finally:
+                r.close()
+        for k in (0, 1):
+            for f in ("instance_primitive_index", "t", "b1", "b2"):
+                assert np.array_equal(out[0][k][f].view(np.uint32), out[1][k][f].view(np.uint32)), (sizes, f)
+        assert (out[0][0]["instance_primitive_index"] != wire.MISS).any()
+
+
 def test_gpu_lbvh_device_and_host_regions():
     """A scene whose bottom levels are split between the two builders in device mode: the forest's shared meshes (>= 64
     triangles: built on the GPU in place) next to tiny meshes (< 64 triangles: host SAH, placed behind the device region
