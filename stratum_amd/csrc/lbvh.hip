@@ -362,7 +362,7 @@ __global__ void k_lbvh_result(const LNode* node_boxes, const uint32_t* error, LR
 // Clusters start as the triangles in Morton order. Every round each cluster looks `radius` places to either side for the
 // neighbour with which it makes the smallest box (surface area of the union); two clusters that choose each other merge
 // into a new node that takes the place of the lower one. The result is much closer to a SAH tree than the radix tree of
-// the Morton codes (which only ever splits at the spatial median): 0.94x instead of 0.86x of the SAH tree's trace rate
+// the Morton codes (which only ever splits at the spatial median): 0.93x instead of 0.86x of the SAH tree's trace rate
 // on the bench scene (radius 4; larger radii lower the SAH cost a little but trace no faster). Everything is deterministic: ties prefer the parity partner i ^ 1 (so a run of identical boxes —
 // 60 k copies of one triangle — pairs up completely every round instead of merging one pair per round), then the lower
 // index; new nodes are numbered by a prefix sum over the merging pairs, not by an atomic counter.
