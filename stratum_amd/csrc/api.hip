@@ -167,6 +167,7 @@ struct sthip_ctx {
   bool packet_primary = true;  // the first bounce is traced as wave packets (k_trace_primary)
   bool fuse_trace = true;  // closest-hit rays of a bounce and the shadow rays of the previous one in one launch
   int bvh_builder = 0;  // sthip::BvhBuilderKind
+  uint32_t sah_top_size = 64;  // "sah_top" (measured 32 .. 16384: 64 traces fastest): the GPU builder's subtrees of at most this many triangles get a host-built SAH top (0: off)
   int lbvh_algorithm = 1, ploc_radius = 4;  // of the GPU builder (bvh_build.h: DeviceBuildTarget); radius measured: 4 traces fastest (2 .. 32 tried)
   // levels of the per-lane LDS traversal stack at most; a higher tree runs the BOUNDED instantiations (traverse.h) with the
   // full stack of an overflowing ray in global memory (spill)
@@ -377,6 +378,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->lds_stack_cap = ctx->lds_stack_threshold = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 4), 150);
   } else if (!strcmp(name, "ploc_radius"))
     ctx->ploc_radius = (int)std::min<int64_t>(std::max<int64_t>(value, 1), 32);
+  else if (!strcmp(name, "sah_top"))
+    ctx->sah_top_size = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20);
   else if (!strcmp(name, "max_paths_in_flight"))
     ctx->max_paths_in_flight = (uint64_t)std::max<int64_t>(1, value);
   else if (!strcmp(name, "trace_blocks_per_cu"))
@@ -546,6 +549,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     target.stream = ctx->stream;
     target.algorithm = ctx->lbvh_algorithm;
     target.ploc_radius = ctx->ploc_radius;
+    target.sah_top_size = ctx->lbvh_algorithm == 1 ? ctx->sah_top_size : 0;
     target.user = ctx;
     target.reserve = [](void* user, size_t node_capacity, size_t tri_capacity, sthip::DeviceBuildTarget& self) {
       sthip_ctx* c = (sthip_ctx*)user;

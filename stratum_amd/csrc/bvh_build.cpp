@@ -66,7 +66,8 @@ struct Builder {
   uint32_t depth_cap;
   uint32_t max_depth = 0;
 
-  Builder(const std::vector<Box>& b, uint32_t leaf, uint32_t cap) : boxes(b), leaf_max(leaf), depth_cap(cap) {
+  // parallel_min / task_min: below parallel_min primitives the build stays on the calling thread; a task holds at least task_min
+  Builder(const std::vector<Box>& b, uint32_t leaf, uint32_t cap, size_t parallel_min = 50000, size_t task_min = 4096) : boxes(b), leaf_max(leaf), depth_cap(cap) {
     const size_t n = boxes.size();
     cen.resize(3 * n);
     order.resize(n);
@@ -84,12 +85,12 @@ struct Builder {
     unsigned threads = std::thread::hardware_concurrency();
     if (const char* e = getenv("STHIP_BUILD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
     threads = std::min(threads, 32u);
-    if (n < 50000 || threads <= 1) {
+    if (n < parallel_min || threads <= 1) {
       build(nodes, max_depth, nullptr, 0, (uint32_t)n, 0);
       return;
     }
     std::vector<Task> tasks;
-    task_size = (uint32_t)std::max<size_t>(4096, n / (8 * (size_t)threads));
+    task_size = (uint32_t)std::max<size_t>(task_min, n / (8 * (size_t)threads));
     build(nodes, max_depth, &tasks, 0, (uint32_t)n, 0);
     std::vector<std::vector<TmpNode>> parts(tasks.size());
     std::vector<uint32_t> depths(tasks.size(), 0);
@@ -490,7 +491,8 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
     // upper bounds of what the host adds behind the device region: a mesh of n triangles has at most max(n - 1, 1)
     // nodes, the top level at most 2 per entry; + the headroom a transforms-only update may need
     const size_t entries_upper = (merged.empty() ? 0 : 1) + separate.size() + spheres.size() + volumes.size();
-    if (!device->reserve || !device->reserve(device->user, all_prims + meshes_n + 4 * entries_upper + 8, all_prims + 1, *device)) {
+    // (+ all_prims / 8: the host-built SAH tops over the device-built subtrees, at most ~4 nodes per sah_top_size triangles)
+    if (!device->reserve || !device->reserve(device->user, all_prims + all_prims / 8 + 64 * meshes_n + 4 * entries_upper + 8, all_prims + 1, *device)) {
       err = "lbvh: could not reserve the device arrays";
       return false;
     }
@@ -509,13 +511,39 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       }
       uint32_t root = 0;
       float ms = 0, bb[6];
-      if (!lbvh_build_device(*device, pieces, dev_node_cursor, dev_tri_cursor, root, depth, bb, ms, gpu_err)) return BVH_INVALID_REF;
+      std::vector<FrontierEntry> frontier;
+      if (!lbvh_build_device(*device, pieces, dev_node_cursor, dev_tri_cursor, root, depth, bb, ms, gpu_err, device->sah_top_size ? &frontier : nullptr, device->sah_top_size)) return BVH_INVALID_REF;
       out.gpu_build_ms += ms;
       if (depth <= LBVH_MAX_HEIGHT) {  // (else: the SAH builder below; the reserved stretch of the device region stays unused)
         memcpy(bounds.lo, bb, 12);
         memcpy(bounds.hi, bb + 3, 12);
         dev_node_cursor += (uint32_t)total - 1;
         dev_tri_cursor += (uint32_t)total;
+        if (frontier.size() >= 2) {
+          // A binned-SAH top over the device-built subtrees: host nodes (behind the device region, like the top level) whose
+          // leaves are the subtrees' own references — final already, so they are marked for the offset pass at the end.
+          std::vector<Box> fboxes(frontier.size());
+          uint32_t below = 0;
+          for (size_t k = 0; k < frontier.size(); k++) {
+            memcpy(fboxes[k].lo, frontier[k].lo, 12);
+            memcpy(fboxes[k].hi, frontier[k].hi, 12);
+            below = std::max(below, frontier[k].height);
+          }
+          Builder tb(fboxes, 1, BLAS_DEPTH_CAP, 4000, 512);  // ten thousand boxes or so: worth a few threads, it sits on the rebuild's critical path
+          const size_t first_node = out.nodes.size();
+          const uint32_t TOKEN = BVH_LEAF_BIT | BVH_INST_BIT;  // never a bottom-level reference: stands for "frontier entry i" until the pass below
+          const uint32_t top_root = flatten(tb, 0, out.nodes, [&](uint32_t first, uint32_t) { return TOKEN | tb.order[first]; });
+          out.absolute_ref.resize(2 * out.nodes.size(), 0);
+          for (size_t i = first_node; i < out.nodes.size(); i++)
+            for (int c = 0; c < 2; c++)
+              if ((out.nodes[i].ref[c] & TOKEN) == TOKEN && out.nodes[i].ref[c] != BVH_INVALID_REF) {
+                out.nodes[i].ref[c] = frontier[out.nodes[i].ref[c] & ~TOKEN].ref;
+                out.absolute_ref[2 * i + c] = 1;
+              }
+          depth = tb.max_depth + 1 + below;
+          on_device = false;  // the root is a host node: offset with the other host-built roots
+          return top_root;
+        }
         on_device = true;
         return root;
       }
@@ -832,8 +860,11 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
   }
   if (dev_mode) {  // out.nodes / out.tris start behind the device region: make their references final
     const uint32_t node_off = out.dev_nodes, tri_off = out.dev_tris << 2;
-    for (BvhNode& nd : out.nodes)
+    out.absolute_ref.resize(2 * out.nodes.size(), 0);
+    for (size_t i = 0; i < out.nodes.size(); i++)
       for (int c = 0; c < 2; c++) {
+        BvhNode& nd = out.nodes[i];
+        if (out.absolute_ref[2 * i + c]) continue;  // a reference into the device region (a SAH top's leaf)
         if (!(nd.ref[c] & BVH_LEAF_BIT))
           nd.ref[c] += node_off;
         else if (!(nd.ref[c] & BVH_INST_BIT))

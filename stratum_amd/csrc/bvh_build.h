@@ -48,6 +48,7 @@ struct BuiltBvh {
   // [0, dev_tris) of the final arrays in place; `nodes` / `tris` then hold only what the host built (small meshes, SAH
   // fallbacks, the top level) and belong at [dev_nodes, ...) / [dev_tris, ...): their references are already final.
   uint32_t dev_nodes = 0, dev_tris = 0;
+  std::vector<uint8_t> absolute_ref;  // device builds: [2 * node + child] = 1 for a reference of a host node that is final already (into the device region)
   // Embedded leaves (host builds without a device target): the triangles of a leaf lie in the NODE array, in the 48-byte
   // units right behind the node that refers to them, so the dependent fetch of a leaf visit goes to the cache line(s) the
   // node itself just came from. unit_tri[u] = index into `tris` of the triangle in unit u, or 0xFFFFFFFF for a node;
@@ -79,15 +80,27 @@ struct DeviceBuildTarget {
   void* stream = nullptr;                            // hipStream_t
   int algorithm = 1;                                 // 0: Karras radix tree over the Morton codes; 1: PLOC (better trees, ~2x the build time)
   int ploc_radius = 4;                               // neighbours examined on either side (<= 32)
+  // > 0: the subtrees of at most this many triangles keep their PLOC shape, and the tree ABOVE them is rebuilt on the host
+  // with the binned-SAH builder over their boxes (a few thousand boxes: ~1 ms). PLOC's merges are greedy and local; the
+  // levels a ray spends most visits in are the ones where that costs most.
+  uint32_t sah_top_size = 0;
   // called once the sizes are known, before the first build: makes nodes / raw_nodes / tris at least this large
   bool (*reserve)(void* user, size_t node_capacity, size_t tri_capacity, DeviceBuildTarget& self) = nullptr;
   void* user = nullptr;
+};
+// A subtree of the device-built tree the host may put a better top over (PLOC only): its box, the reference a parent uses for
+// it (a node of the final array, or a leaf), its stack need. See DeviceBuildTarget::sah_top_size.
+struct FrontierEntry {
+  float lo[3];
+  uint32_t ref;
+  float hi[3];
+  uint32_t height;
 };
 // Builds one bottom level over `pieces` on the device: n - 1 nodes at [node_base, ...), n triangles at [tri_base, ...).
 // bounds[6] = lo xyz, hi xyz of the mesh; height = the stack the tree needs. false + err on a HIP error or a vertex index
 // outside gVertices.
 bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece>& pieces, uint32_t node_base, uint32_t tri_base, uint32_t& root_ref, uint32_t& height, float bounds[6],
-                       float& gpu_ms, std::string& err);
+                       float& gpu_ms, std::string& err, std::vector<FrontierEntry>* frontier = nullptr, uint32_t frontier_size = 0);
 
 enum BvhBuilderKind { BVH_BUILDER_SAH_HOST = 0, BVH_BUILDER_LBVH_GPU = 1 };
 

@@ -363,7 +363,8 @@ __global__ void k_lbvh_result(const LNode* node_boxes, const uint32_t* error, LR
 // neighbour with which it makes the smallest box (surface area of the union); two clusters that choose each other merge
 // into a new node that takes the place of the lower one. The result is much closer to a SAH tree than the radix tree of
 // the Morton codes (which only ever splits at the spatial median): 0.93x instead of 0.86x of the SAH tree's trace rate
-// on the bench scene (radius 4; larger radii lower the SAH cost a little but trace no faster). Everything is deterministic: ties prefer the parity partner i ^ 1 (so a run of identical boxes —
+// on the bench scene (radius 4; larger radii lower the SAH cost a little but trace no faster), 0.96x with the host's SAH top
+// over its subtrees (DeviceBuildTarget::sah_top_size). Everything is deterministic: ties prefer the parity partner i ^ 1 (so a run of identical boxes —
 // 60 k copies of one triangle — pairs up completely every round instead of merging one pair per round), then the lower
 // index; new nodes are numbered by a prefix sum over the merging pairs, not by an atomic counter.
 struct PCluster {
@@ -567,6 +568,48 @@ __global__ void k_ploc_result(const LNode* nodes, uint32_t root, const uint32_t*
   out->error = *error;
 }
 
+// ---- the frontier for a host-built SAH top (DeviceBuildTarget::sah_top_size): every child slot (node k, side s) whose
+// parent holds more than `limit` triangles and whose own subtree holds at most `limit`. The slots are flagged, ranked by a
+// prefix sum (deterministic order) and written out with the reference k_ploc_emit gives that child.
+__global__ void __launch_bounds__(LB_BLOCK) k_ploc_frontier_flags(uint32_t n, uint32_t limit, const uint32_t* left, const uint32_t* right, const LNode* nodes, uint32_t* flags) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * (n - 1)) return;
+  const uint32_t k = t >> 1;
+  const uint32_t c = (t & 1u) ? right[k] : left[k];
+  const uint32_t child_count = (c & 0x80000000u) ? 1u : nodes[c].pad;
+  flags[t] = (nodes[k].pad > limit && child_count <= limit) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(LB_BLOCK) k_ploc_frontier_emit(uint32_t n, uint32_t node_base, uint32_t tri_base, const uint32_t* left, const uint32_t* right, const uint32_t* sorted,
+                                                                  const LBox* leaf_boxes, const LNode* nodes, const uint32_t* leaf_pos, const uint32_t* node_start,
+                                                                  const uint32_t* node_index, const uint32_t* flags, const uint32_t* ranks, FrontierEntry* out, uint32_t* total) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * (n - 1)) return;
+  if (t == 2 * (n - 1) - 1) *total = ranks[t] + flags[t];
+  if (!flags[t]) return;
+  const uint32_t k = t >> 1;
+  const uint32_t c = (t & 1u) ? right[k] : left[k];
+  FrontierEntry e;
+  if (c & 0x80000000u) {
+    const uint32_t idx = c & 0x7FFFFFFFu;
+    const LBox b = leaf_boxes[sorted[idx]];
+    for (int a = 0; a < 3; a++) {
+      e.lo[a] = b.lo[a];
+      e.hi[a] = b.hi[a];
+    }
+    e.ref = BVH_LEAF_BIT | ((tri_base + leaf_pos[idx]) << 2);
+    e.height = 0;
+  } else {
+    const LNode nd = nodes[c];
+    for (int a = 0; a < 3; a++) {
+      e.lo[a] = nd.lo[a];
+      e.hi[a] = nd.hi[a];
+    }
+    e.ref = nd.pad <= BVH_MAX_LEAF_TRIS ? (BVH_LEAF_BIT | ((tri_base + node_start[c]) << 2) | (nd.pad - 1u)) : node_base + node_index[c];
+    e.height = nd.height;
+  }
+  out[ranks[t]] = e;
+}
+
 // scratch arena of lbvh_build_gpu, kept for the life of the process (one build at a time: the mutex)
 struct Arena {
   char* base = nullptr;
@@ -705,7 +748,8 @@ done:
 
 
 bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece>& pieces, uint32_t node_base, uint32_t tri_base, uint32_t& root_ref, uint32_t& height, float bounds[6],
-                       float& gpu_ms, std::string& err) {
+                       float& gpu_ms, std::string& err, std::vector<FrontierEntry>* frontier, uint32_t frontier_size) {
+  if (frontier) frontier->clear();
   uint32_t n = 0;
   for (const MeshPiece& pc : pieces) n += pc.prim_count;
   if (n < 2 || pieces.empty()) {
@@ -737,7 +781,12 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
     size_t tmp_need = 0;
     LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_need, d_keys, d_keys_sorted, d_vals, d_sorted, (int)n, 0, 63, st));
     tmp_bytes = tmp_need;
-    if (ploc) LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp_bytes, d_flags, d_ranks, (int)n, st));
+    if (ploc) {
+      LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp_bytes, d_flags, d_ranks, (int)n, st));
+      size_t frontier_scan = 0;  // the frontier's scan runs over 2 (n - 1) 32-bit flags in the same scratch
+      LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, frontier_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(2 * n), st));
+      scan_tmp_bytes = std::max(scan_tmp_bytes, frontier_scan);
+    }
     int dev = 0;
     LB_TRY(hipGetDevice(&dev));
     Arena& A = arena(dev);
@@ -844,6 +893,27 @@ bool lbvh_build_device(const DeviceBuildTarget& tgt, const std::vector<MeshPiece
       hipLaunchKernelGGL(k_ploc_emit, dim3(grid), dim3(LB_BLOCK), 0, st, n, node_base, tri_base, d_left, d_right, d_sorted, d_leaf, d_node, d_leaf_pos, d_node_start, d_node_index, tgt.raw_nodes, tgt.nodes);
       hipLaunchKernelGGL(k_ploc_gather, dim3(grid), dim3(LB_BLOCK), 0, st, d_in, d_sorted, d_leaf_pos, n, tgt.tris + tri_base);
       hipLaunchKernelGGL(k_ploc_result, dim3(1), dim3(1), 0, st, d_node, root_node, d_err, d_res);
+      if (frontier && frontier_size >= BVH_MAX_LEAF_TRIS && n > 2 * frontier_size) {
+        // the child slots under which the host rebuilds the top (the cluster buffers are free by now: flags and ranks take
+        // the scan arrays' place — 2 (n - 1) words fit their n * 8 bytes — and the entries go where the clusters were)
+        uint32_t* f_flags = reinterpret_cast<uint32_t*>(d_flags);
+        uint32_t* f_ranks = reinterpret_cast<uint32_t*>(d_ranks);
+        FrontierEntry* f_out = reinterpret_cast<FrontierEntry*>(d_cl[0]);  // n * 32 bytes: room for n entries; there are at most 2 n / frontier_size
+        const uint32_t slots = 2 * (n - 1);
+        const uint32_t fg = (slots + LB_BLOCK - 1) / LB_BLOCK;
+        hipLaunchKernelGGL(k_ploc_frontier_flags, dim3(fg), dim3(LB_BLOCK), 0, st, n, frontier_size, d_left, d_right, d_node, f_flags);
+        size_t tb = scan_tmp_bytes;
+        LB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, tb, f_flags, f_ranks, (int)slots, st));
+        hipLaunchKernelGGL(k_ploc_frontier_emit, dim3(fg), dim3(LB_BLOCK), 0, st, n, node_base, tri_base, d_left, d_right, d_sorted, d_leaf, d_node, d_leaf_pos, d_node_start, d_node_index, f_flags,
+                           f_ranks, f_out, reinterpret_cast<uint32_t*>(d_totals));
+        uint32_t count = 0;
+        LB_TRY(hipMemcpyAsync(&count, d_totals, 4, hipMemcpyDeviceToHost, st));
+        LB_TRY(hipStreamSynchronize(st));
+        if (count >= 2 && count <= n) {
+          frontier->resize(count);
+          LB_TRY(hipMemcpyAsync(frontier->data(), f_out, (size_t)count * sizeof(FrontierEntry), hipMemcpyDeviceToHost, st));
+        }
+      }
     }
     LB_TRY(hipEventRecord(e1, st));
     LResult res;
