@@ -18,7 +18,7 @@ bool lbvh_build_gpu(const std::vector<BvhTri>&, std::vector<BvhNode>&, std::vect
   err = "no device in this harness";
   return false;
 }
-bool lbvh_build_device(const DeviceBuildTarget&, const std::vector<MeshPiece>&, uint32_t, uint32_t, uint32_t&, uint32_t&, float*, float&, std::string& err) {
+bool lbvh_build_device(const DeviceBuildTarget&, const std::vector<MeshPiece>&, uint32_t, uint32_t, uint32_t&, uint32_t&, float*, float&, std::string& err, std::vector<FrontierEntry>*, uint32_t) {
   err = "no device in this harness";
   return false;
 }
