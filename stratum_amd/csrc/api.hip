@@ -379,7 +379,7 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
   } else if (!strcmp(name, "ploc_radius"))
     ctx->ploc_radius = (int)std::min<int64_t>(std::max<int64_t>(value, 1), 32);
   else if (!strcmp(name, "sah_top"))
-    ctx->sah_top_size = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20);
+    ctx->sah_top_size = value <= 0 ? 0u : (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 16), 1 << 20);  // (the reserved host-node room covers frontiers down to 16)
   else if (!strcmp(name, "max_paths_in_flight"))
     ctx->max_paths_in_flight = (uint64_t)std::max<int64_t>(1, value);
   else if (!strcmp(name, "trace_blocks_per_cu"))

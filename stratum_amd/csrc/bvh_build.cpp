@@ -491,8 +491,9 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
     // upper bounds of what the host adds behind the device region: a mesh of n triangles has at most max(n - 1, 1)
     // nodes, the top level at most 2 per entry; + the headroom a transforms-only update may need
     const size_t entries_upper = (merged.empty() ? 0 : 1) + separate.size() + spheres.size() + volumes.size();
-    // (+ all_prims / 8: the host-built SAH tops over the device-built subtrees, at most ~4 nodes per sah_top_size triangles)
-    if (!device->reserve || !device->reserve(device->user, all_prims + all_prims / 8 + 64 * meshes_n + 4 * entries_upper + 8, all_prims + 1, *device)) {
+    // (+ all_prims / 4: the host-built SAH tops over the device-built subtrees: at most one node per frontier entry, and a
+    // frontier of size s has about 2 n / s entries; s >= 16)
+    if (!device->reserve || !device->reserve(device->user, all_prims + all_prims / 4 + 64 * meshes_n + 4 * entries_upper + 8, all_prims + 1, *device)) {
       err = "lbvh: could not reserve the device arrays";
       return false;
     }
