@@ -79,7 +79,9 @@ def run(cases=60, seed=1):
             if rng.integers(4) == 0: opts["packet_primary"] = 0
             if rng.integers(4) == 0 and kind in ("cornell", "textured", "atrium", "forest"): opts["bvh_builder"] = 1
             if rng.integers(4) == 0: opts["treetop"] = 0
-            if "bvh_builder" in opts: opts["lbvh_algorithm"] = int(rng.integers(2))
+            if "bvh_builder" in opts:
+                opts["lbvh_algorithm"] = int(rng.integers(2))
+                opts["sah_top"] = int(rng.choice([0, 16, 64, 300]))  # the host-built SAH top over the GPU builder's subtrees
             if rng.integers(4) == 0: opts["lds_stack_levels"] = int(rng.integers(4, 14))  # bounded LDS stacks + k_trace_deep
             if rng.integers(4) == 0 and "bvh_builder" not in opts: opts["embed_leaves"] = 1  # leaf triangles inside the node array
             for k, v in opts.items():
