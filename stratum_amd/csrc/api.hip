@@ -120,7 +120,7 @@ struct sthip_ctx {
   DevBuf<BvhNode> raw_nodes;  // device-resident build only: the unpacked nodes before their one copy to nodes_host
   DevBuf<BvhNodePacked> top_nodes;
   DevBuf<TlasEntry> top_entries;
-  bool use_treetop = true;
+  bool use_treetop = false;  // "treetop": measured +1.5 % before k_trace's loop lost its other exec-mask regions, -0.5 % after
   // host builds: leaf triangles in the node array behind their parent (bvh_build.h: BuiltBvh::embedded). Measured on the
   // bench scene: k_trace 2.30 ms either way (the leaf fetch is not what a step waits for), so off: two arrays are simpler
   bool embed_leaves = false;
@@ -190,6 +190,16 @@ struct sthip_ctx {
 // again with a global-memory stack of the tree's full height — bounded here so that the spill buffer stays small
 #define STHIP_MAX_STACK_DEPTH 512u
 
+// k_trace's instantiations by (count_traversal, alpha / volumes, bounded stack, treetop)
+static const void* trace_kernel(bool count, bool alpha, bool bounded, bool top) {
+  static const void* const table[16] = {
+      (const void*)&k_trace<false, false, false, false>, (const void*)&k_trace<true, false, false, false>, (const void*)&k_trace<false, true, false, false>, (const void*)&k_trace<true, true, false, false>,
+      (const void*)&k_trace<false, false, true, false>,  (const void*)&k_trace<true, false, true, false>,  (const void*)&k_trace<false, true, true, false>,  (const void*)&k_trace<true, true, true, false>,
+      (const void*)&k_trace<false, false, false, true>,  (const void*)&k_trace<true, false, false, true>,  (const void*)&k_trace<false, true, false, true>,  (const void*)&k_trace<true, true, false, true>,
+      (const void*)&k_trace<false, false, true, true>,   (const void*)&k_trace<true, false, true, true>,   (const void*)&k_trace<false, true, true, true>,   (const void*)&k_trace<true, true, true, true>};
+  return table[(count ? 1 : 0) | (alpha ? 2 : 0) | (bounded ? 4 : 0) | (top ? 8 : 0)];
+}
+
 #define HIP_TRY(ctx, expr)                                                                            \
   do {                                                                                                \
     hipError_t _e = (expr);                                                                           \
@@ -256,14 +266,7 @@ int sthip_create(int device, sthip_ctx** out_ctx) {
   (void)hipEventCreate(&ctx->ev[1]);
   {  // dynamic LDS beyond the 64 KB default for the kernels that carry the traversal stack
     const int lds_max = 160 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    for (int k = 0; k < 16; k++) (void)hipFuncSetAttribute(trace_kernel((k & 1) != 0, (k & 2) != 0, (k & 4) != 0, (k & 8) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -771,10 +774,7 @@ static uint32_t grid_for(const sthip_ctx* ctx, size_t n) {
 static int trace_occupancy(const sthip_ctx* ctx, size_t lds_bytes) {  // resident k_trace blocks per CU with that much dynamic LDS
   int per_cu = 0;
   hipError_t e;
-  if (ctx->bvh.spill)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false, true>, STHIP_BLOCK, lds_bytes);
-  else
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false>, STHIP_BLOCK, lds_bytes);
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel(false, false, ctx->bvh.spill != nullptr, ctx->use_treetop), STHIP_BLOCK, lds_bytes);
   return e == hipSuccess ? per_cu : 0;
 }
 static uint32_t trace_grid(sthip_ctx* ctx, size_t lds_bytes) {
@@ -1450,33 +1450,21 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       launches_trace++;
       return timed(ms_trace, [&]() {
         const bool alpha = p.bvh.alpha_test || ctx->has_volumes;  // alpha masks under eAlphaTest, volume instances: the instantiation that carries them
-        if (p.bvh.spill) {  // a tree higher than the LDS stack: the bounded instantiations, then the rays that overflowed
-          (void)hipMemsetAsync(p.deep_count, 0, 4, st);
+        void* kargs[3] = {(void*)&p, (void*)&dc, (void*)&ds};
+        if (p.bvh.spill) (void)hipMemsetAsync(p.deep_count, 0, 4, st);
+        (void)hipLaunchKernel(trace_kernel(ctx->count_traversal, alpha, p.bvh.spill != nullptr, p.bvh.top_count != 0), dim3(tgrid), dim3(STHIP_BLOCK), kargs, lds, st);
+        if (p.bvh.spill) {  // a tree higher than the LDS stack ran the bounded instantiation: now the rays that overflowed
           const uint32_t dgrid = (uint32_t)ctx->cu_count * 8u;  // one spill column per thread (configure_stack)
           if (alpha) {
-            if (ctx->count_traversal) {
-              hipLaunchKernelGGL((k_trace<true, true, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
+            if (ctx->count_traversal)
               hipLaunchKernelGGL((k_trace_deep<true, true>), dim3(dgrid), dim3(STHIP_BLOCK), 0, st, p);
-            } else {
-              hipLaunchKernelGGL((k_trace<false, true, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
+            else
               hipLaunchKernelGGL((k_trace_deep<false, true>), dim3(dgrid), dim3(STHIP_BLOCK), 0, st, p);
-            }
-          } else if (ctx->count_traversal) {
-            hipLaunchKernelGGL((k_trace<true, false, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
+          } else if (ctx->count_traversal)
             hipLaunchKernelGGL((k_trace_deep<true, false>), dim3(dgrid), dim3(STHIP_BLOCK), 0, st, p);
-          } else {
-            hipLaunchKernelGGL((k_trace<false, false, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
-            hipLaunchKernelGGL((k_trace_deep<false, false>), dim3(dgrid), dim3(STHIP_BLOCK), 0, st, p);
-          }
-        } else if (alpha) {
-          if (ctx->count_traversal)
-            hipLaunchKernelGGL((k_trace<true, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
           else
-            hipLaunchKernelGGL((k_trace<false, true>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
-        } else if (ctx->count_traversal)
-          hipLaunchKernelGGL((k_trace<true, false>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
-        else
-          hipLaunchKernelGGL((k_trace<false, false>), dim3(tgrid), dim3(STHIP_BLOCK), lds, st, p, dc, ds);
+            hipLaunchKernelGGL((k_trace_deep<false, false>), dim3(dgrid), dim3(STHIP_BLOCK), 0, st, p);
+        }
       });
     };
     // the first bounce as wave packets (k_trace_primary): one 8x8 pixel block per wave

@@ -344,17 +344,21 @@ DEV void finish_ray(const FrameParams& p, float4* target, uint32_t slot, bool sh
 // BOUNDED: the LDS stack has p.bvh.lds_levels < p.bvh.stack_depth levels (a tree too high for the LDS at full occupancy); a
 // ray that overflows it is handed to k_trace_deep, which traces it again with a full stack in global memory (p.bvh.spill) —
 // hits do not depend on the traversal order, so the result is the same as with an LDS stack of full height.
-template <bool COUNT, bool ALPHA, bool BOUNDED = false>
+// TOP: the treetop (DeviceBvh::top_nodes) is held in LDS and followed ("treetop" = 1). Off by default since the loop lost
+// its other exec-mask regions: the LDS-or-global branch it needs in every step now costs more than the LDS reads save.
+template <bool COUNT, bool ALPHA, bool BOUNDED = false, bool TOP = false>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t depth_closest, uint32_t depth_shadow) {
   extern __shared__ uint32_t lds_stack[];
   // the treetop behind the stacks: copied once per (persistent) block
   float4* top_lds = reinterpret_cast<float4*>(lds_stack + (size_t)p.bvh.lds_levels * STHIP_BLOCK);
-  for (uint32_t i = threadIdx.x; i < p.bvh.top_count * 3u; i += STHIP_BLOCK) top_lds[i] = p.bvh.top_nodes[i];
-  __syncthreads();
-  DeviceBvh bvh = p.bvh;  // k_trace's view: the entry table whose roots point into the treetop, and the treetop's root
-  if (p.bvh.top_count) {
-    bvh.entries = p.bvh.top_entries;
-    bvh.root_ref = p.bvh.top_root_ref;
+  DeviceBvh bvh = p.bvh;  // k_trace's view: with TOP the entry table whose roots point into the treetop, and the treetop's root
+  if (TOP) {
+    for (uint32_t i = threadIdx.x; i < p.bvh.top_count * 3u; i += STHIP_BLOCK) top_lds[i] = p.bvh.top_nodes[i];
+    __syncthreads();
+    if (p.bvh.top_count) {
+      bvh.entries = p.bvh.top_entries;
+      bvh.root_ref = p.bvh.top_root_ref;
+    }
   }
   const bool first = depth_closest == 0;        // first bounce: every slot, no queue
   const uint32_t* queue = p.queue[depth_closest & 1u];
@@ -366,7 +370,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
   cnt[0].clear();
   cnt[1].clear();
   uint32_t round_slots[2] = {0, 0}, busy_rounds[2] = {0, 0};
-  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, true, BOUNDED> tr;
+  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, TOP, BOUNDED> tr;
   tr.top_lds = (const LdsFloat4*)top_lds;
   if (BOUNDED) tr.limit = (p.bvh.lds_levels - 1u) * STHIP_BLOCK;
   tr.reset();

@@ -78,7 +78,7 @@ def run(cases=60, seed=1):
             if rng.integers(4) == 0: opts["fuse_trace"] = 0
             if rng.integers(4) == 0: opts["packet_primary"] = 0
             if rng.integers(4) == 0 and kind in ("cornell", "textured", "atrium", "forest"): opts["bvh_builder"] = 1
-            if rng.integers(4) == 0: opts["treetop"] = 0
+            if rng.integers(4) == 0: opts["treetop"] = 1  # the LDS treetop (off by default)
             if "bvh_builder" in opts:
                 opts["lbvh_algorithm"] = int(rng.integers(2))
                 opts["sah_top"] = int(rng.choice([0, 16, 64, 300]))  # the host-built SAH top over the GPU builder's subtrees
