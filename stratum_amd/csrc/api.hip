@@ -743,10 +743,14 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->bvh_tris = tris_total;
   ctx->top = std::move(built.top);
   // the host's copy of the unpacked nodes, with room for a rebuilt top level
-  HIP_TRY(ctx, ctx->nodes_host.ensure(std::max<size_t>(nodes_total, ctx->nodes.n)));
-  if (built.dev_nodes) HIP_TRY(ctx, hipMemcpy(ctx->nodes_host.p, ctx->raw_nodes.p, (size_t)built.dev_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
-  if (!built.nodes.empty()) memcpy(ctx->nodes_host.p + built.dev_nodes, built.nodes.data(), built.nodes.size() * sizeof(BvhNode));
-  ctx->nodes_host.n = nodes_total;
+  // (only the treetop selection reads it: without the treetop a device-resident build copies no node to the host at all)
+  ctx->nodes_host.n = 0;
+  if (ctx->use_treetop) {
+    HIP_TRY(ctx, ctx->nodes_host.ensure(std::max<size_t>(nodes_total, ctx->nodes.n)));
+    if (built.dev_nodes) HIP_TRY(ctx, hipMemcpy(ctx->nodes_host.p, ctx->raw_nodes.p, (size_t)built.dev_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
+    if (!built.nodes.empty()) memcpy(ctx->nodes_host.p + built.dev_nodes, built.nodes.data(), built.nodes.size() * sizeof(BvhNode));
+    ctx->nodes_host.n = nodes_total;
+  }
   {
     const int rc = configure_stack(ctx);
     if (rc != STHIP_OK) return rc;
@@ -929,7 +933,7 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
   ctx->bvh.scene_cz = center[2];
   ctx->bvh.scene_radius = radius;
   ctx->bvh_nodes = next.blas_nodes + tlas.size();
-  if (ctx->nodes_host.cap >= (size_t)next.blas_nodes + tlas.size()) {
+  if (ctx->nodes_host.n && ctx->nodes_host.cap >= (size_t)next.blas_nodes + tlas.size()) {
     if (!tlas.empty()) memcpy(ctx->nodes_host.p + next.blas_nodes, tlas.data(), tlas.size() * sizeof(BvhNode));
     ctx->nodes_host.n = std::max(ctx->nodes_host.n, (size_t)next.blas_nodes + tlas.size());
   }
