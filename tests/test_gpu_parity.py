@@ -1,4 +1,6 @@
 """Parity of the HIP path against the CPU oracle, through the C ABI (needs an MI355X)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -384,6 +386,38 @@ def test_golden_fixtures(renderer, cornell):
     hits = renderer.trace(gr["rays"])
     for f in ("instance_primitive_index", "t", "b1", "b2"):
         assert np.array_equal(hits[f].view(np.uint32), gr["hits"][f].view(np.uint32)), f
+
+
+def test_estimator_golden_fixture_on_the_gpu():
+    """The defined-order estimators against committed frames (tests/golden/estimators.npz), without the oracle in the loop:
+    light vertex cache, reservoir reuse through both hash grids, coherent roulette, coherent sampling."""
+    import importlib.util
+
+    from stratum_amd.bdpt import BDPT
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_estimator_golden", os.path.join(here, "make_estimator_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    # (only its CASES table is used: the module imports the oracle binding, which this test never calls)
+    spec.loader.exec_module(mk)
+    g = np.load(os.path.join(here, "estimators.npz"))
+    sc, cam = scenes.cornell_box()
+    frame = camera.Frame(mk.W, mk.H, cam["fovy"], cam["eye"], cam["target"])
+    key = {"gLightPathCount": "lightPathCount", "gMaxDiffuseVertices": "maxDiffuseVertices", "gReservoirM": "reservoirM", "gHashGridBucketCount": "hashGridBucketCount",
+           "gMinPathVertices": "minPathVertices", "gMaxPathVertices": "maxPathVertices", "gLightPresampleTileSize": "lightPresampleTileSize", "gLightPresampleTileCount": "lightPresampleTileCount"}
+    for name, (names, overrides) in mk.CASES.items():
+        from stratum_amd.bdpt import _flag_key
+
+        flags = [("~" + _flag_key(n[1:])) if n.startswith("~") else _flag_key(n) for n in names]
+        r = BDPT(device=0, args=dict({key[k]: v for k, v in overrides.items()}, bdptFlag=flags))
+        try:
+            assert r.mSamplingFlags == mk.flags_of(names), name
+            r.update(sc)
+            got = r.render(frame, 3, mk.SEEDS)
+        finally:
+            r.close()
+        assert np.array_equal(got["radiance"].view(np.uint32), g[name + "_radiance"].view(np.uint32)), name
+        assert np.array_equal(got["ray_count"], g[name + "_ray_count"]), name
 
 
 def test_errors_are_reported_not_ignored(renderer, cornell):

@@ -421,6 +421,26 @@ def test_cornell_golden_fixture():
     assert np.array_equal(out["ray_count"], g["ray_count"])
 
 
+def test_estimator_golden_fixture():
+    """tests/golden/estimators.npz (make_estimator_golden.py): the estimators whose upstream result depends on scheduling,
+    under the orders DESIGN.md 7 defines, frozen as committed frames — the oracle must keep reproducing them bit for bit."""
+    import importlib.util
+    import os
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_estimator_golden", os.path.join(here, "make_estimator_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    g = np.load(os.path.join(here, "estimators.npz"))
+    sc, cam = scenes.cornell_box()
+    o = orc.OracleScene(sc)
+    fr = camera.Frame(mk.W, mk.H, cam["fovy"], cam["eye"], cam["target"])
+    for name, (names, overrides) in mk.CASES.items():
+        out = o.render(fr, mk.push_constants(sc, overrides), mk.flags_of(names), 3, mk.SEEDS)
+        assert np.array_equal(out["radiance"].view(np.uint32), g[name + "_radiance"].view(np.uint32)), name
+        assert np.array_equal(out["ray_count"], g[name + "_ray_count"]), name
+
+
 # ---------------------------------------------------------------------------------------------
 # N2: software texture sampler (repeat + trilinear over a box-filtered mip chain), ray cones, normal maps
 # ---------------------------------------------------------------------------------------------
