@@ -219,7 +219,7 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
 // for every ray that lost a push (and for the few that merely filled the stack to the brim). Such a traversal still
 // terminates (every reference on the stack is one this ray wrote), but its result is void: the caller traces the ray again
 // with a full-height stack.
-template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false, bool BOUNDED = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
+template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false, bool BOUNDED = false, bool SAVE_WORLD = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
 struct Traversal {
   const LdsFloat4* top_lds;  // TOP only
   uint32_t limit;            // BOUNDED only: (levels - 1) * STRIDE
@@ -229,6 +229,13 @@ struct Traversal {
   f3 o, d;  // world-space ray
   float tmin, tmax;
   RaySpace sp;  // the space currently being traversed (world, or the object space of an instance)
+  // The world-space constants, kept while an instance is traversed (SAVE_WORLD): leaving an instance then copies 13
+  // registers instead of running setup_space again (6 correctly rounded divisions, ~130 instructions) — the values are
+  // the ones start() computed, so nothing changes but the cost. Only where registers allow (the persistent kernel has 23
+  // to spare below its occupancy step).
+  f3 w_idir, w_noodL, w_noodH;
+  float w_Sx, w_Sy, w_Sz;
+  int w_k;
   RayHit hit;
   uint32_t ref;
   uint32_t top;  // stack height in entries * STRIDE (an LDS word offset)
@@ -251,6 +258,15 @@ struct Traversal {
     id_bits = 0;
     ref = bvh.root_ref;  // BVH_INVALID_REF == TRAV_DONE for an empty scene
     setup_space(sp, ro, rd, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
+    if (SAVE_WORLD) {
+      w_idir = sp.idir;
+      w_noodL = sp.noodL;
+      w_noodH = sp.noodH;
+      w_Sx = sp.Sx;
+      w_Sy = sp.Sy;
+      w_Sz = sp.Sz;
+      w_k = sp.k;
+    }
   }
 
   DEV void pop(const uint32_t* stack) {
@@ -328,7 +344,18 @@ struct Traversal {
   DEV void leaf_step(const DeviceBvh& bvh, uint32_t* stack, TraverseCounters& cnt) {
     if (ref >= TRAV_EXIT_INSTANCE) {
       if (ref == TRAV_EXIT_INSTANCE) {  // everything pushed inside the instance is consumed: back to world space
-        setup_space(sp, o, d, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
+        if (SAVE_WORLD) {
+          sp.o = o;
+          sp.idir = w_idir;
+          sp.noodL = w_noodL;
+          sp.noodH = w_noodH;
+          sp.Sx = w_Sx;
+          sp.Sy = w_Sy;
+          sp.Sz = w_Sz;
+          sp.k = w_k;
+        } else {
+          setup_space(sp, o, d, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
+        }
         id_bits = 0;
         pop(stack);
       }
