@@ -1477,7 +1477,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       rays_primary += (uint64_t)primary_rays * in_flight;
       const uint32_t packets = (p.path_count + 63) / 64;
       const unsigned pgrid = std::max(1u, std::min((packets + 3) / 4, (uint32_t)ctx->cu_count * 64u));
-      const size_t plds = (size_t)ctx->bvh.stack_depth * (STHIP_BLOCK / 64) * sizeof(uint32_t);
+      const size_t plds = ((size_t)ctx->bvh.stack_depth * (STHIP_BLOCK / 64) + 13 * STHIP_BLOCK) * sizeof(uint32_t);  // the per-wave stacks + every lane's saved world-space ray constants
       return timed(ms_primary, [&]() {
         if (p.bvh.alpha_test) {
           if (ctx->count_traversal)

@@ -514,6 +514,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK, PRIMARY_BLOCKS) k_trace_primary(F
   extern __shared__ uint32_t lds_stack[];
   const uint32_t wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   uint32_t* stack = lds_stack + wave_in_block * p.bvh.stack_depth;  // one stack per wave
+  // behind the stacks: every lane's world-space ray constants (13 words, [word][thread]), kept while the packet is inside an
+  // instance — leaving it reads them back instead of running setup_space again (this kernel has no registers to spare)
+  float* world_save = reinterpret_cast<float*>(lds_stack + (STHIP_BLOCK / 64) * p.bvh.stack_depth) + threadIdx.x;
   const uint32_t packets = (p.path_count + 63u) >> 6;
   TraverseCounters cnt;
   cnt.clear();
@@ -535,6 +538,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK, PRIMARY_BLOCKS) k_trace_primary(F
     }
     RaySpace sp;
     setup_space(sp, o, d, p.bvh.scene_cx, p.bvh.scene_cy, p.bvh.scene_cz, p.bvh.scene_radius);
+    {
+      const float w[13] = {sp.idir.x, sp.idir.y, sp.idir.z, sp.noodL.x, sp.noodL.y, sp.noodL.z, sp.noodH.x, sp.noodH.y, sp.noodH.z, sp.Sx, sp.Sy, sp.Sz, __int_as_float(sp.k)};
+      for (int k = 0; k < 13; k++) world_save[k * STHIP_BLOCK] = w[k];
+    }
     uint32_t id_bits = 0;
     uint32_t top = 0;
     uint32_t ref = p.bvh.root_ref;  // wave-uniform throughout
@@ -584,7 +591,14 @@ __global__ void __launch_bounds__(STHIP_BLOCK, PRIMARY_BLOCKS) k_trace_primary(F
       }
       // leaf bit: exit sentinel, instance entry, or triangles
       if (ref == TRAV_EXIT_INSTANCE) {
-        setup_space(sp, o, d, p.bvh.scene_cx, p.bvh.scene_cy, p.bvh.scene_cz, p.bvh.scene_radius);
+        sp.o = o;
+        sp.idir = F3(world_save[0], world_save[STHIP_BLOCK], world_save[2 * STHIP_BLOCK]);
+        sp.noodL = F3(world_save[3 * STHIP_BLOCK], world_save[4 * STHIP_BLOCK], world_save[5 * STHIP_BLOCK]);
+        sp.noodH = F3(world_save[6 * STHIP_BLOCK], world_save[7 * STHIP_BLOCK], world_save[8 * STHIP_BLOCK]);
+        sp.Sx = world_save[9 * STHIP_BLOCK];
+        sp.Sy = world_save[10 * STHIP_BLOCK];
+        sp.Sz = world_save[11 * STHIP_BLOCK];
+        sp.k = __float_as_int(world_save[12 * STHIP_BLOCK]);
         id_bits = 0;
         ref = top ? stack[--top] : TRAV_DONE;
         continue;
