@@ -219,7 +219,10 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
 // for every ray that lost a push (and for the few that merely filled the stack to the brim). Such a traversal still
 // terminates (every reference on the stack is one this ray wrote), but its result is void: the caller traces the ray again
 // with a full-height stack.
-template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false, bool BOUNDED = false, bool SAVE_WORLD = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
+#ifndef STHIP_ENTRY_BATCH
+#define STHIP_ENTRY_BATCH 12u
+#endif
+template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false, bool BOUNDED = false, bool SAVE_WORLD = false, uint32_t ENTRY_BATCH = 1>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
 struct Traversal {
   const LdsFloat4* top_lds;  // TOP only
   uint32_t limit;            // BOUNDED only: (levels - 1) * STRIDE
@@ -342,6 +345,8 @@ struct Traversal {
 
   // ref has the leaf bit: a sentinel, an instance, or up to 4 triangles
   DEV void leaf_step(const DeviceBvh& bvh, uint32_t* stack, TraverseCounters& cnt) {
+    // (lanes here hold a leaf reference; "triangles" = a leaf that is neither a sentinel nor an instance entry)
+    const bool entries_due = ENTRY_BATCH > 1 ? !__any(ref < TRAV_EXIT_INSTANCE && !(ref & BVH_INST_BIT)) : true;
     if (ref >= TRAV_EXIT_INSTANCE) {
       if (ref == TRAV_EXIT_INSTANCE) {  // everything pushed inside the instance is consumed: back to world space
         if (SAVE_WORLD) {
@@ -362,6 +367,14 @@ struct Traversal {
       return;  // TRAV_DONE stays
     }
     if (ref & BVH_INST_BIT) {
+      // ENTRY_BATCH (the persistent kernel): entering an instance is ~250 instructions and a dependent load, run by the few
+      // lanes that hold an entry while the rest of the wave waits (9 lanes on average on the bench scene: 8 % of the
+      // kernel's instructions). An entry is therefore put off — the lane keeps its reference and comes back next round —
+      // until at least ENTRY_BATCH lanes hold one or no lane of this round has triangles left to test.
+      if (ENTRY_BATCH > 1) {
+        const uint32_t entering = (uint32_t)__popcll(__ballot(true));  // (the lanes in this branch)
+        if (entering < ENTRY_BATCH && !entries_due) return;
+      }
       const TlasEntry* e = bvh.entries + (ref & 0xFFFFu);
       const float4* ev = reinterpret_cast<const float4*>(e);
       const uint4 info = *reinterpret_cast<const uint4*>(ev + 3);
