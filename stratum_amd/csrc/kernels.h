@@ -385,8 +385,26 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
   bool busy = false;  // this lane holds a ray whose result is not stored yet
   bool shadow_lane = false;  // ... and it came from the shadow queue
   for (;;) {
-    const unsigned long long idle = __ballot(!busy);
+    // A lane whose ray has finished counts as idle, but its result is stored only here, when the wave stops to refill: the
+    // stores (and, for an unoccluded shadow ray, a read-modify-write of the pixel's sum with its load latency) then run for
+    // all the lanes that finished since the last stop at once, instead of for two or three lanes in almost every round.
+    const unsigned long long idle = __ballot(!busy || !tr.active());
     if ((uint32_t)__popcll(idle) >= p.refill_idle || idle == ~0ull) {
+      if (busy && !tr.active()) {
+        if (BOUNDED && tr.overflowed(stack)) {
+          // the LDS stack was too short for this ray: its result is void. k_trace_deep traces it again with a stack as high as
+          // the tree (global memory) and does what would have been done here; hits do not depend on the traversal order
+          const uint32_t e = atomicAdd(p.deep_count, 1u);
+          float4* rec = p.deep_rays + 4 * (size_t)e;
+          rec[0] = make_float4(tr.o.x, tr.o.y, tr.o.z, tr.tmin);
+          rec[1] = make_float4(tr.d.x, tr.d.y, tr.d.z, tr.tmax);
+          rec[2] = make_float4(contribution.x, contribution.y, contribution.z, __uint_as_float(slot));
+          rec[3] = make_float4(__uint_as_float((shadow_lane ? 1u : 0u) | (tr.any ? 2u : 0u)), 0.0f, 0.0f, 0.0f);
+        } else {
+          finish_ray<ALPHA>(p, target, slot, shadow_lane, tr.any, tr.hit, contribution);
+        }
+        busy = false;
+      }
       if (!work_c.exhausted) {
         const uint32_t idx = work_c.take(!busy, ctl_c, first ? 0u : p.seg_stride, p.path_count);
         if (idx != 0xFFFFFFFFu) {
@@ -427,9 +445,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
     }
     if (COUNT) {
       // a round belongs to the kind most of the wave is working on (the kinds only mix while the path queue drains)
-      const uint32_t k = work_c.exhausted && (uint32_t)__popcll(__ballot(busy && tr.any)) * 2u >= (uint32_t)__popcll(__ballot(busy)) ? 1u : 0u;
+      const uint32_t k = work_c.exhausted && (uint32_t)__popcll(__ballot(busy && tr.active() && tr.any)) * 2u >= (uint32_t)__popcll(__ballot(busy && tr.active())) ? 1u : 0u;
       if ((threadIdx.x & 63u) == 0) round_slots[k] += 64;
-      if (busy) busy_rounds[k]++;
+      if (busy && tr.active()) busy_rounds[k]++;
       const uint32_t n0 = cnt[k].inner_slots, t0 = cnt[k].tri_slots;
       TraverseCounters c;
       c.clear();
@@ -440,21 +458,6 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
       cnt[k].tri_slots = t0 + c.tri_slots;
     } else {
       tr.round(bvh, stack, p.inner_min_lanes, cnt[0]);
-    }
-    if (busy && !tr.active()) {
-      if (BOUNDED && tr.overflowed(stack)) {
-        // the LDS stack was too short for this ray: its result is void. k_trace_deep traces it again with a stack as high as
-        // the tree (global memory) and does what would have been done here; hits do not depend on the traversal order
-        const uint32_t e = atomicAdd(p.deep_count, 1u);
-        float4* rec = p.deep_rays + 4 * (size_t)e;
-        rec[0] = make_float4(tr.o.x, tr.o.y, tr.o.z, tr.tmin);
-        rec[1] = make_float4(tr.d.x, tr.d.y, tr.d.z, tr.tmax);
-        rec[2] = make_float4(contribution.x, contribution.y, contribution.z, __uint_as_float(slot));
-        rec[3] = make_float4(__uint_as_float((shadow_lane ? 1u : 0u) | (tr.any ? 2u : 0u)), 0.0f, 0.0f, 0.0f);
-      } else {
-        finish_ray<ALPHA>(p, target, slot, shadow_lane, tr.any, tr.hit, contribution);
-      }
-      busy = false;
     }
   }
   if (COUNT) {
