@@ -1,7 +1,7 @@
 """What a wider node would cost the vector-memory path (GPU box, with a library variant whose ceiling kernel takes the node
 size and the number of 16-byte loads per node from STHIP_CEIL_NODE_BYTES / STHIP_CEIL_LOADS): independent random node
 fetches, as sthip_measure_ceiling does them, for several node shapes; G nodes/s is what a traversal step costs.
-usage: STHIP_LIB=_variants/ceil.so python tools/gather_shape_experiment.py"""
+usage: tools/build_variant.sh ceil tools/variant_patches/ceiling_shapes.py && STHIP_LIB=$PWD/_variants/ceil.so python tools/gather_shape_experiment.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stratum_amd import scenes
