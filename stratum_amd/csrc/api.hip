@@ -113,6 +113,8 @@ struct sthip_ctx {
   DevBuf<BvhNodeSlot> nodes;
   DevBuf<BvhTri> tris;
   DevBuf<TlasEntry> entries;
+  DevBuf<WideNode> wide_nodes;
+  DevBuf<TlasEntry> wide_entries;
   DeviceBvh bvh{};
   uint64_t bvh_nodes = 0, bvh_tris = 0;
   // treetop (bvh_build.h): rebuilt whenever the top level changes; needs the nodes on the host
@@ -124,6 +126,7 @@ struct sthip_ctx {
   // host builds: leaf triangles in the node array behind their parent (bvh_build.h: BuiltBvh::embedded). Measured on the
   // bench scene: k_trace 2.30 ms either way (the leaf fetch is not what a step waits for), so off: two arrays are simpler
   bool embed_leaves = false;
+  bool use_wide = false;  // "wide_bvh": k_trace walks the 4-wide form of a host-built tree (takes effect at the next sthip_scene_upload)
   bool lds_materials = true;  // k_shade stages gMaterialData in LDS when it fits 32 KB
   // frame
   DevBuf<uint8_t> views;  // gViews | gViewTransforms | gPrevViews | gPrevInverseViewTransforms
@@ -199,6 +202,13 @@ static const void* trace_kernel(bool count, bool alpha, bool bounded, bool top) 
       (const void*)&k_trace<false, false, true, true>,   (const void*)&k_trace<true, false, true, true>,   (const void*)&k_trace<false, true, true, true>,   (const void*)&k_trace<true, true, true, true>};
   return table[(count ? 1 : 0) | (alpha ? 2 : 0) | (bounded ? 4 : 0) | (top ? 8 : 0)];
 }
+// ... and over the 4-wide tree ("wide_bvh"; never with the treetop)
+static const void* trace_kernel_wide(bool count, bool alpha, bool bounded) {
+  static const void* const table[8] = {
+      (const void*)&k_trace<false, false, false, false, true>, (const void*)&k_trace<true, false, false, false, true>, (const void*)&k_trace<false, true, false, false, true>, (const void*)&k_trace<true, true, false, false, true>,
+      (const void*)&k_trace<false, false, true, false, true>,  (const void*)&k_trace<true, false, true, false, true>,  (const void*)&k_trace<false, true, true, false, true>,  (const void*)&k_trace<true, true, true, false, true>};
+  return table[(count ? 1 : 0) | (alpha ? 2 : 0) | (bounded ? 4 : 0)];
+}
 
 #define HIP_TRY(ctx, expr)                                                                            \
   do {                                                                                                \
@@ -267,6 +277,7 @@ int sthip_create(int device, sthip_ctx** out_ctx) {
   {  // dynamic LDS beyond the 64 KB default for the kernels that carry the traversal stack
     const int lds_max = 160 * 1024;
     for (int k = 0; k < 16; k++) (void)hipFuncSetAttribute(trace_kernel((k & 1) != 0, (k & 2) != 0, (k & 4) != 0, (k & 8) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    for (int k = 0; k < 8; k++) (void)hipFuncSetAttribute(trace_kernel_wide((k & 1) != 0, (k & 2) != 0, (k & 4) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -375,6 +386,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->lds_materials = value != 0;
   else if (!strcmp(name, "embed_leaves"))  // takes effect at the next sthip_scene_upload
     ctx->embed_leaves = value != 0;
+  else if (!strcmp(name, "wide_bvh"))  // takes effect at the next sthip_scene_upload (host-built trees only)
+    ctx->use_wide = value != 0;
   else if (!strcmp(name, "lbvh_algorithm"))  // 0: Karras radix tree, 1: PLOC (default)
     ctx->lbvh_algorithm = value == 0 ? 0 : 1;
   else if (!strcmp(name, "lds_stack_levels")) {  // takes effect at the next sthip_scene_upload / sthip_scene_update_transforms
@@ -677,6 +690,23 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     if (!built.tris.empty()) HIP_TRY(ctx, hipMemcpy(ctx->tris.p + built.dev_tris, built.tris.data(), built.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
   }
   if (!built.entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->entries.p, built.entries.data(), built.entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
+  ctx->bvh.wide_nodes = nullptr;
+  ctx->bvh.wide_entries = nullptr;
+  ctx->bvh.wide_root_ref = BVH_INVALID_REF;
+  ctx->bvh.wide_stack_depth = 0;
+  if (ctx->use_wide && !ctx->use_treetop && built.dev_nodes == 0) {
+    sthip::build_wide_bvh(built);
+    if (!built.wide_nodes.empty() && built.wide_nodes.size() * sizeof(WideNode) <= 0xFFFFFFFFull) {
+      HIP_TRY(ctx, ctx->wide_nodes.ensure(built.wide_nodes.size()));
+      HIP_TRY(ctx, ctx->wide_entries.ensure(std::max<size_t>(1, built.wide_entries.size())));
+      HIP_TRY(ctx, hipMemcpy(ctx->wide_nodes.p, built.wide_nodes.data(), built.wide_nodes.size() * sizeof(WideNode), hipMemcpyHostToDevice));
+      if (!built.wide_entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->wide_entries.p, built.wide_entries.data(), built.wide_entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
+      ctx->bvh.wide_nodes = reinterpret_cast<const uint4*>(ctx->wide_nodes.p);
+      ctx->bvh.wide_entries = ctx->wide_entries.p;
+      ctx->bvh.wide_root_ref = built.wide_root_ref;
+      ctx->bvh.wide_stack_depth = built.wide_stack_depth;
+    }
+  }
   {  // alpha masks: one-channel images and the per-triangle uvs the traversal interpolates
     std::vector<DeviceImage1> table(s->image1_count);
     std::vector<float> texels;
@@ -778,7 +808,7 @@ static uint32_t grid_for(const sthip_ctx* ctx, size_t n) {
 static int trace_occupancy(const sthip_ctx* ctx, size_t lds_bytes) {  // resident k_trace blocks per CU with that much dynamic LDS
   int per_cu = 0;
   hipError_t e;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel(false, false, ctx->bvh.spill != nullptr, ctx->use_treetop), STHIP_BLOCK, lds_bytes);
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ctx->bvh.wide_nodes ? trace_kernel_wide(false, false, ctx->bvh.spill != nullptr) : trace_kernel(false, false, ctx->bvh.spill != nullptr, ctx->use_treetop), STHIP_BLOCK, lds_bytes);
   return e == hipSuccess ? per_cu : 0;
 }
 static uint32_t trace_grid(sthip_ctx* ctx, size_t lds_bytes) {
@@ -795,8 +825,10 @@ static size_t trace_lds_bytes(const sthip_ctx* ctx) { return stack_bytes(ctx) + 
 // Decides how the traversal stack of the current tree is held: all of it in LDS, or lds_stack_cap levels there and the
 // full height in global memory for the rays that overflow. Then the treetop takes the LDS that is left.
 static int configure_stack(sthip_ctx* ctx) {
-  const bool bounded = ctx->bvh.stack_depth > ctx->lds_stack_threshold;
-  ctx->bvh.lds_levels = bounded ? ctx->lds_stack_cap : ctx->bvh.stack_depth;
+  // (the wide walk pushes up to three children per level and keeps one more level for the pushes of children it missed)
+  const uint32_t need = ctx->bvh.wide_nodes ? ctx->bvh.wide_stack_depth + 1u : ctx->bvh.stack_depth;
+  const bool bounded = need > ctx->lds_stack_threshold;
+  ctx->bvh.lds_levels = bounded ? ctx->lds_stack_cap : need;
   ctx->bvh.spill = nullptr;
   if (bounded) {
     // one column per lane of the largest grid a trace launch can have (persistent: resident blocks; ray batches use it too)
@@ -938,6 +970,8 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
     ctx->nodes_host.n = std::max(ctx->nodes_host.n, (size_t)next.blas_nodes + tlas.size());
   }
   ctx->top = std::move(next);
+  ctx->bvh.wide_nodes = nullptr;  // the wide form was made from the old top level: back to the binary walk until the next upload
+  ctx->bvh.wide_entries = nullptr;
   return configure_stack(ctx);
 }
 
@@ -1456,7 +1490,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
         const bool alpha = p.bvh.alpha_test || ctx->has_volumes;  // alpha masks under eAlphaTest, volume instances: the instantiation that carries them
         void* kargs[3] = {(void*)&p, (void*)&dc, (void*)&ds};
         if (p.bvh.spill) (void)hipMemsetAsync(p.deep_count, 0, 4, st);
-        (void)hipLaunchKernel(trace_kernel(ctx->count_traversal, alpha, p.bvh.spill != nullptr, p.bvh.top_count != 0), dim3(tgrid), dim3(STHIP_BLOCK), kargs, lds, st);
+        (void)hipLaunchKernel(p.bvh.wide_nodes ? trace_kernel_wide(ctx->count_traversal, alpha, p.bvh.spill != nullptr) : trace_kernel(ctx->count_traversal, alpha, p.bvh.spill != nullptr, p.bvh.top_count != 0), dim3(tgrid), dim3(STHIP_BLOCK), kargs, lds, st);
         if (p.bvh.spill) {  // a tree higher than the LDS stack ran the bounded instantiation: now the rays that overflowed
           const uint32_t dgrid = (uint32_t)ctx->cu_count * 8u;  // one spill column per thread (configure_stack)
           if (alpha) {

@@ -62,6 +62,19 @@ struct BvhNodeSlot {
   uint32_t pad[(STHIP_NODE_STRIDE - 48) / 4];
 #endif
 };
+// The 4-wide node k_trace can walk instead ("wide_bvh"; bvh_build.h: build_wide_bvh collapses the binary tree into it): 64
+// aligned bytes = four 16-byte loads per lane. The boxes of up to four children as 8-bit planes on a per-node grid:
+// plane = origin[axis] + q * 2^(exp[axis] - 127), lower planes rounded down and upper planes up on that grid (exactly: the
+// builder checks them in double), so a decoded box contains the child's box. An unused child slot has reference
+// BVH_INVALID_REF (the walk skips it by that; its planes are lo 255, hi 0). References are the binary tree's, except that an inner
+// reference indexes THIS array.
+struct WideNode {
+  float origin[3];
+  uint8_t exp[4];    // biased exponents of the x, y, z plane step; [3] = number of children (not read by the kernel)
+  uint8_t q[6][4];   // [lo.x, hi.x, lo.y, hi.y, lo.z, hi.z][child]
+  uint32_t pad[2];
+  uint32_t ref[4];
+};
 #define BVH_NO_ALPHA 0xFFFFFFFFu  // DeviceBvh::inst_alpha entry of an instance whose material has no alpha mask
 // uv of the three vertices of a leaf triangle, in leaf order next to BvhTri; only built for scenes with alpha masks
 struct BvhTriUv {
@@ -101,5 +114,6 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode");
 static_assert(sizeof(BvhNodePacked) == 48, "BvhNodePacked");
 static_assert(sizeof(BvhNodeSlot) == BVH_NODE_BYTES, "BvhNodeSlot");
 static_assert(sizeof(BvhTri) == 48, "BvhTri");
+static_assert(sizeof(WideNode) == 64, "WideNode");
 static_assert(sizeof(TlasEntry) == 80, "TlasEntry");
 #endif

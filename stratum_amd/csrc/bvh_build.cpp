@@ -892,6 +892,149 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
   return true;
 }
 
+namespace {
+struct WideChild {
+  Box box;
+  uint32_t ref;
+};
+inline Box child_box(const BvhNode& n, int c) {
+  Box b;
+  const float* xy = c == 0 ? n.n0xy : n.n1xy;
+  b.lo[0] = xy[0];
+  b.hi[0] = xy[1];
+  b.lo[1] = xy[2];
+  b.hi[1] = xy[3];
+  b.lo[2] = n.nz[2 * c];
+  b.hi[2] = n.nz[2 * c + 1];
+  return b;
+}
+struct WideBuilder {
+  const std::vector<BvhNode>& nodes;
+  std::vector<WideNode>& out;
+  std::vector<uint32_t> wide_of;   // binary inner node -> wide node made from it, or 0xFFFFFFFF
+  std::vector<uint32_t> height_of; // of a wide node: levels of wide nodes below and including it
+  WideBuilder(const std::vector<BvhNode>& n, std::vector<WideNode>& o) : nodes(n), out(o), wide_of(n.size(), 0xFFFFFFFFu) {}
+
+  // the wide node that stands for binary inner node `i` (meshes shared by several entries are converted once)
+  uint32_t convert(uint32_t i) {
+    if (wide_of[i] != 0xFFFFFFFFu) return wide_of[i];
+    WideChild ch[4];
+    int n = 0;
+    for (int c = 0; c < 2; c++) {
+      const uint32_t r = nodes[i].ref[c];
+      if (r == BVH_INVALID_REF) continue;
+      if (n == 1 && r == ch[0].ref && (r & BVH_LEAF_BIT)) continue;  // a wrapped lone leaf fills both slots: once is enough here
+      ch[n].box = child_box(nodes[i], c);
+      ch[n].ref = r;
+      n++;
+    }
+    while (n < 4) {  // open the inner child with the largest box until there are four (or only leaves)
+      int pick = -1;
+      float area = -1.0f;
+      for (int k = 0; k < n; k++)
+        if (!(ch[k].ref & BVH_LEAF_BIT) && ch[k].box.half_area() > area) {
+          area = ch[k].box.half_area();
+          pick = k;
+        }
+      if (pick < 0) break;
+      const BvhNode& b = nodes[ch[pick].ref];
+      WideChild a0{child_box(b, 0), b.ref[0]}, a1{child_box(b, 1), b.ref[1]};
+      if (a0.ref == a1.ref && (a0.ref & BVH_LEAF_BIT)) {  // (a wrapped lone leaf)
+        ch[pick] = a0;
+        continue;
+      }
+      ch[pick] = a0;
+      ch[n++] = a1;
+    }
+    const uint32_t w = (uint32_t)out.size();
+    out.push_back(WideNode());
+    wide_of[i] = w;
+    height_of.push_back(1);
+    uint32_t below = 0;
+    uint32_t refs[4];
+    for (int k = 0; k < n; k++) {
+      refs[k] = ch[k].ref;
+      if (!(ch[k].ref & BVH_LEAF_BIT)) {
+        refs[k] = convert(ch[k].ref);
+        below = std::max(below, height_of[refs[k]]);
+      }
+    }
+    height_of[w] = 1 + below;
+    WideNode wn;
+    memset(&wn, 0, sizeof(wn));
+    Box all;
+    all.reset();
+    for (int k = 0; k < n; k++) all.grow(ch[k].box);
+    for (int a = 0; a < 3; a++) {
+      wn.origin[a] = all.lo[a];
+      const double ext = (double)all.hi[a] - (double)all.lo[a];
+      int e = 1;  // biased; the step is 2^(e - 127)
+      if (ext > 0) {
+        int x;
+        frexp(ext / 255.0, &x);  // ext / 255 = m * 2^x, m in [0.5, 1): 2^x >= ext / 255
+        e = std::min(254, std::max(1, x + 127));
+      }
+      for (;;) {
+        const double step = ldexp(1.0, e - 127);
+        bool fits = true;
+        for (int k = 0; k < n && fits; k++) {
+          double lo = floor(((double)ch[k].box.lo[a] - (double)wn.origin[a]) / step), hi = ceil(((double)ch[k].box.hi[a] - (double)wn.origin[a]) / step);
+          while (lo > 0 && (double)wn.origin[a] + lo * step > (double)ch[k].box.lo[a]) lo -= 1;
+          while ((double)wn.origin[a] + hi * step < (double)ch[k].box.hi[a]) hi += 1;
+          if (lo < 0) lo = 0;
+          if (hi > 255 || !(hi >= 0)) {
+            fits = false;
+            break;
+          }
+          wn.q[2 * a][k] = (uint8_t)lo;
+          wn.q[2 * a + 1][k] = (uint8_t)hi;
+        }
+        if (fits || e >= 254) break;
+        e++;
+      }
+      wn.exp[a] = (uint8_t)e;
+    }
+    wn.exp[3] = (uint8_t)n;
+    for (int k = 0; k < 4; k++) {
+      if (k < n) {
+        wn.ref[k] = refs[k];
+      } else {
+        wn.ref[k] = BVH_INVALID_REF;
+        for (int a = 0; a < 3; a++) {
+          wn.q[2 * a][k] = 255;
+          wn.q[2 * a + 1][k] = 0;
+        }
+      }
+    }
+    out[w] = wn;
+    return w;
+  }
+};
+}  // namespace
+
+void build_wide_bvh(BuiltBvh& out) {
+  out.wide_nodes.clear();
+  out.wide_entries = out.entries;
+  out.wide_root_ref = out.root_ref;
+  out.wide_stack_depth = 0;
+  if (out.dev_nodes || out.root_ref == BVH_INVALID_REF || out.nodes.empty()) return;
+  out.wide_nodes.reserve(out.nodes.size() / 2 + 16);
+  WideBuilder wb(out.nodes, out.wide_nodes);
+  uint32_t blas_height = 0, top_height = 0;
+  for (TlasEntry& e : out.wide_entries)
+    if (e.identity == TLAS_ENTRY_IDENTITY || e.identity == TLAS_ENTRY_TRANSFORMED) {
+      e.root = wb.convert(e.root);
+      blas_height = std::max(blas_height, wb.height_of[e.root]);
+    }
+  if (out.top_is_world_blas) {
+    out.wide_root_ref = out.wide_entries[0].root;
+  } else if (!(out.root_ref & BVH_LEAF_BIT)) {
+    out.wide_root_ref = wb.convert(out.root_ref);
+    top_height = wb.height_of[out.wide_root_ref];
+  }
+  out.wide_stack_depth = 3 * (top_height + blas_height) + 4;  // three pushes per level at most, the sentinels, a spare level
+}
+
 bool rebuild_top_level(TopLevelState& st, const sthip_TransformData* xf, const sthip_TransformData* inv, uint32_t instance_count, std::vector<BvhNode>& tlas_nodes, uint32_t& root_ref,
                        uint32_t& top_is_world_blas, uint32_t& stack_depth, float scene_center[3], float& scene_radius, std::string& err) {
   const uint32_t TLAS_DEPTH_CAP = 18;

@@ -56,6 +56,13 @@ struct BuiltBvh {
   bool embedded = false;
   std::vector<uint32_t> unit_tri;
   TopLevelState top;
+  // The 4-wide form of the same tree for k_trace (build_wide_bvh; empty unless asked for): its nodes, a copy of `entries`
+  // whose roots index wide_nodes, the reference traversal starts at, and the bound of the stack it needs (up to three
+  // pushes per level).
+  std::vector<WideNode> wide_nodes;
+  std::vector<TlasEntry> wide_entries;
+  uint32_t wide_root_ref = BVH_INVALID_REF;
+  uint32_t wide_stack_depth = 0;
 };
 
 // One run of triangles of a bottom level, as the scene arrays describe it (scene.h:139-161)
@@ -108,6 +115,10 @@ enum BvhBuilderKind { BVH_BUILDER_SAH_HOST = 0, BVH_BUILDER_LBVH_GPU = 1 };
 // `builder`: binned SAH on the host (default; best traversal) or LBVH on the GPU (fastest build; lbvh.hip).
 // With a DeviceBuildTarget (and the LBVH builder) bottom levels of >= 64 triangles are built in place on the device.
 bool build_scene_bvh(const sthip_scene_desc& scene, BuiltBvh& out, std::string& err, int builder = BVH_BUILDER_SAH_HOST, DeviceBuildTarget* device = nullptr, bool embed_leaves = false);
+// Collapses the finished binary tree of a host build (out.dev_nodes == 0) into 4-wide nodes with quantised child boxes
+// (bvh.h: WideNode): out.wide_*. Every leaf reference, and with it every triangle and entry, stays what it is, and every
+// decoded box contains the box it stands for: a traversal of the wide tree finds the hits the binary one finds.
+void build_wide_bvh(BuiltBvh& out);
 
 // Transforms-only update: new entry matrices and world boxes, a new top level. `tlas_nodes` come out with their child
 // references already offset by st.blas_nodes (they go to nodes[st.blas_nodes ...]). Fails (false) when an instance of the

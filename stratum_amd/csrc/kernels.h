@@ -346,7 +346,9 @@ DEV void finish_ray(const FrameParams& p, float4* target, uint32_t slot, bool sh
 // hits do not depend on the traversal order, so the result is the same as with an LDS stack of full height.
 // TOP: the treetop (DeviceBvh::top_nodes) is held in LDS and followed ("treetop" = 1). Off by default since the loop lost
 // its other exec-mask regions: the LDS-or-global branch it needs in every step now costs more than the LDS reads save.
-template <bool COUNT, bool ALPHA, bool BOUNDED = false, bool TOP = false>
+// WIDE: the walk goes over the 4-wide form of the tree (DeviceBvh::wide_nodes, "wide_bvh" = 1): fewer, fatter dependent
+// steps. Its stack has two levels above the last usable one: the canary's (BOUNDED) and the spare level misses are pushed to.
+template <bool COUNT, bool ALPHA, bool BOUNDED = false, bool TOP = false, bool WIDE = false>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t depth_closest, uint32_t depth_shadow) {
   extern __shared__ uint32_t lds_stack[];
   // the treetop behind the stacks: copied once per (persistent) block
@@ -370,9 +372,14 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
   cnt[0].clear();
   cnt[1].clear();
   uint32_t round_slots[2] = {0, 0}, busy_rounds[2] = {0, 0};
-  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, TOP, BOUNDED, true, STHIP_ENTRY_BATCH> tr;  // SAVE_WORLD: 13 more registers, no occupancy step crossed (118 of 128; the ALPHA instantiations sit between 128 and 168 either way)
+  if (WIDE) {
+    bvh.entries = p.bvh.wide_entries;
+    bvh.root_ref = p.bvh.wide_root_ref;
+  }
+  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, TOP, BOUNDED, true, STHIP_ENTRY_BATCH, WIDE> tr;  // SAVE_WORLD: 13 more registers, no occupancy step crossed (118 of 128; the ALPHA instantiations sit between 128 and 168 either way)
   tr.top_lds = (const LdsFloat4*)top_lds;
-  if (BOUNDED) tr.limit = (p.bvh.lds_levels - 1u) * STHIP_BLOCK;
+  if (BOUNDED) tr.limit = (p.bvh.lds_levels - (WIDE ? 2u : 1u)) * STHIP_BLOCK;
+  if (WIDE) tr.dump = (p.bvh.lds_levels - 1u) * STHIP_BLOCK;
   tr.reset();
   tr.any = false;
   WaveWork work_c, work_s;

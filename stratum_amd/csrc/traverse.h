@@ -48,6 +48,12 @@ struct DeviceBvh {
   // words in global memory (`spill`: one column per resident lane of the persistent grid). nullptr: unbounded.
   uint32_t lds_levels;
   uint32_t* spill;
+  // The 4-wide form of the tree (bvh.h: WideNode; "wide_bvh"), walked by k_trace only: nullptr when not built. Inner
+  // references of wide_entries' roots, of wide_root_ref and of the wide nodes index wide_nodes; leaves are the binary tree's.
+  const uint4* wide_nodes;
+  const TlasEntry* wide_entries;
+  uint32_t wide_root_ref;
+  uint32_t wide_stack_depth;
 };
 struct DeviceImage1 {
   uint32_t offset, w, h, pad;
@@ -222,8 +228,9 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
 #ifndef STHIP_ENTRY_BATCH
 #define STHIP_ENTRY_BATCH 12u
 #endif
-template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false, bool BOUNDED = false, bool SAVE_WORLD = false, uint32_t ENTRY_BATCH = 1>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
+template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false, bool BOUNDED = false, bool SAVE_WORLD = false, uint32_t ENTRY_BATCH = 1, bool WIDE = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
 struct Traversal {
+  uint32_t dump;             // WIDE only: the word offset of a spare stack level that takes the pushes of children that were not hit
   const LdsFloat4* top_lds;  // TOP only
   uint32_t limit;            // BOUNDED only: (levels - 1) * STRIDE
   DEV bool overflowed(const uint32_t* stack) const { return BOUNDED && stack[limit] != TRAV_CANARY; }
@@ -244,6 +251,19 @@ struct Traversal {
   uint32_t top;  // stack height in entries * STRIDE (an LDS word offset)
   uint32_t id_bits;
 
+  // WIDE: the wide walk picks the entry and the exit plane of each axis by the sign of the direction; the origin terms are
+  // stored to match — noodL with the entry planes, noodH with the exit planes — right after every setup_space.
+  DEV void orient_space() {
+    if (!WIDE) return;
+    const float lx = sp.noodL.x, ly = sp.noodL.y, lz = sp.noodL.z;
+    const bool nx = sp.idir.x < 0.0f, ny = sp.idir.y < 0.0f, nz = sp.idir.z < 0.0f;
+    sp.noodL.x = nx ? sp.noodH.x : lx;
+    sp.noodH.x = nx ? lx : sp.noodH.x;
+    sp.noodL.y = ny ? sp.noodH.y : ly;
+    sp.noodH.y = ny ? ly : sp.noodH.y;
+    sp.noodL.z = nz ? sp.noodH.z : lz;
+    sp.noodH.z = nz ? lz : sp.noodH.z;
+  }
   DEV bool active() const { return ref != TRAV_DONE; }
   DEV void reset() { ref = TRAV_DONE; }
 
@@ -261,6 +281,7 @@ struct Traversal {
     id_bits = 0;
     ref = bvh.root_ref;  // BVH_INVALID_REF == TRAV_DONE for an empty scene
     setup_space(sp, ro, rd, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
+    orient_space();
     if (SAVE_WORLD) {
       w_idir = sp.idir;
       w_noodL = sp.noodL;
@@ -284,6 +305,10 @@ struct Traversal {
     const float tbest = hit.t;  // does not change while inner nodes are walked (an occlusion lane stops at its first hit, so for it hit.t stays tmax)
     // Every lane that holds an inner node takes at least one step per call (progress), then the wave goes on while
     // at least `min_lanes` lanes (>= 1) still hold an inner node: one wave-uniform test per step.
+    if (WIDE) {
+      wide_loop(bvh, stack, min_lanes, cnt);
+      return;
+    }
     for (;;) {
       if (!(ref & BVH_LEAF_BIT)) {
       float4 n0, n1, nz;
@@ -343,6 +368,87 @@ struct Traversal {
     }
   }
 
+  // The same walk over 4-wide nodes (bvh.h: WideNode): one 64-byte node = four 16-byte loads, the boxes of up to four children
+  // decoded from 8-bit planes — plane = origin + q * 2^e, so t = q * (2^e * idir) + (origin * idir + nood): the product with
+  // the power of two is exact, the two fmas round once each, well inside the padding of the ray's origin (setup_space) —
+  // the hit children ordered by entry distance with a five-comparator network on (distance bits, child), the nearest
+  // followed and the others pushed nearest on top. Branch-free like the binary step: the pop is read speculatively, the
+  // three pushes are always written, those of children that were not hit to the spare level `dump`.
+  DEV void wide_loop(const DeviceBvh& bvh, uint32_t* stack, uint32_t min_lanes, TraverseCounters& cnt) {
+    const char* base = reinterpret_cast<const char*>(bvh.wide_nodes);
+    const float tbest = hit.t;
+    // The entry plane of an axis is the lower one where the ray runs up and the upper one where it runs down: picked once per
+    // node for all four children (their plane bytes share a word), together with the padded origin term that goes with it
+    // (noodL belongs to lower planes, noodH to upper ones, both pad outward whatever the direction: setup_space). Same
+    // boxes as min / max over both planes, twelve instructions instead of twenty-four.
+    // (orient_space has put the entry planes' term into noodL and the exit planes' into noodH already)
+    const bool nx = sp.idir.x < 0.0f, ny = sp.idir.y < 0.0f, nz = sp.idir.z < 0.0f;
+    const float cnx = sp.noodL.x, cfx = sp.noodH.x, cny = sp.noodL.y, cfy = sp.noodH.y, cnz = sp.noodL.z, cfz = sp.noodH.z;
+    for (;;) {
+      if (!(ref & BVH_LEAF_BIT)) {
+        const uint4* n = reinterpret_cast<const uint4*>(base + (ref << 6));
+        const uint4 q0 = n[0], q1 = n[1], q2 = n[2];
+        uint4 q3 = n[3];
+        const uint32_t popped = stack[top - STRIDE];
+        // all four loads in flight before anything is computed: left alone the scheduler sinks the references' load behind the
+        // box tests — a second memory latency in every step
+        asm volatile("" : "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
+        if (COUNT) {
+          cnt.nodes++;
+          if (first_active_lane()) cnt.inner_slots += 64;
+        }
+        const float ax = __uint_as_float((q0.w & 0xFFu) << 23) * sp.idir.x;
+        const float ay = __uint_as_float(((q0.w >> 8) & 0xFFu) << 23) * sp.idir.y;
+        const float az = __uint_as_float(((q0.w >> 16) & 0xFFu) << 23) * sp.idir.z;
+        const float ox = __uint_as_float(q0.x), oy = __uint_as_float(q0.y), oz = __uint_as_float(q0.z);
+        const float enx = fmaf(ox, sp.idir.x, cnx), efx = fmaf(ox, sp.idir.x, cfx);
+        const float eny = fmaf(oy, sp.idir.y, cny), efy = fmaf(oy, sp.idir.y, cfy);
+        const float enz = fmaf(oz, sp.idir.z, cnz), efz = fmaf(oz, sp.idir.z, cfz);
+        const uint32_t qnx = nx ? q1.y : q1.x, qfx = nx ? q1.x : q1.y;
+        const uint32_t qny = ny ? q1.w : q1.z, qfy = ny ? q1.z : q1.w;
+        const uint32_t qnz = nz ? q2.y : q2.x, qfz = nz ? q2.x : q2.y;
+        uint32_t key[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const float tnx = fmaf((float)((qnx >> (8 * c)) & 0xFFu), ax, enx), tfx = fmaf((float)((qfx >> (8 * c)) & 0xFFu), ax, efx);
+          const float tny = fmaf((float)((qny >> (8 * c)) & 0xFFu), ay, eny), tfy = fmaf((float)((qfy >> (8 * c)) & 0xFFu), ay, efy);
+          const float tnz = fmaf((float)((qnz >> (8 * c)) & 0xFFu), az, enz), tfz = fmaf((float)((qfz >> (8 * c)) & 0xFFu), az, efz);
+          const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+          const float tf = fminf(fminf(tfx, tfy), tfz);
+          const uint32_t rc = c == 0 ? q3.x : (c == 1 ? q3.y : (c == 2 ? q3.z : q3.w));
+          const bool h = (tn <= tf) & (tn <= tbest) & (rc != BVH_INVALID_REF);  // (an unused slot's planes are not a miss by themselves)
+          key[c] = h ? ((__float_as_uint(tn) & 0x7FFFFFFCu) | (uint32_t)c) : 0xFFFFFFFFu;
+        }
+        // ascending: (0,1) (2,3) (0,2) (1,3) (1,2)
+        uint32_t k0 = min(key[0], key[1]), k1 = max(key[0], key[1]), k2 = min(key[2], key[3]), k3 = max(key[2], key[3]);
+        uint32_t t0 = min(k0, k2), t2 = max(k0, k2), t1 = min(k1, k3), t3 = max(k1, k3);
+        k0 = t0;
+        k1 = min(t1, t2);
+        k2 = max(t1, t2);
+        k3 = t3;
+        const uint32_t hits = (k0 != 0xFFFFFFFFu ? 1u : 0u) + (k1 != 0xFFFFFFFFu ? 1u : 0u) + (k2 != 0xFFFFFFFFu ? 1u : 0u) + (k3 != 0xFFFFFFFFu ? 1u : 0u);
+        auto child_ref = [&](uint32_t k) {  // reference number (k & 3): two bit masks and three bit selects
+          const uint32_t m0 = (uint32_t)((int32_t)(k << 31) >> 31), m1 = (uint32_t)((int32_t)(k << 30) >> 31);
+          const uint32_t lo = (q3.y & m0) | (q3.x & ~m0), hi = (q3.w & m0) | (q3.z & ~m0);
+          return (hi & m1) | (lo & ~m1);
+        };
+        const uint32_t r0 = child_ref(k0), r1 = child_ref(k1), r2 = child_ref(k2), r3 = child_ref(k3);
+        // the pushes: with h hits the h - 1 farther ones go to top .. top + h - 2, the farthest lowest
+        const uint32_t lim = BOUNDED ? limit : 0xFFFFFFFFu;
+        const uint32_t p1 = hits > 1u ? min(top + (hits - 2u) * STRIDE, lim) : dump;
+        const uint32_t p2 = hits > 2u ? min(top + (hits - 3u) * STRIDE, lim) : dump;
+        const uint32_t p3 = hits > 3u ? min(top, lim) : dump;
+        stack[p3] = r3;
+        stack[p2] = r2;
+        stack[p1] = r1;
+        ref = hits ? r0 : popped;
+        const uint32_t next_top = hits ? top + (hits - 1u) * STRIDE : top - STRIDE;
+        top = BOUNDED ? min(next_top, limit) : next_top;
+      }
+      if ((uint32_t)__popcll(__ballot(!(ref & BVH_LEAF_BIT))) < min_lanes) break;
+    }
+  }
+
   // ref has the leaf bit: a sentinel, an instance, or up to 4 triangles
   DEV void leaf_step(const DeviceBvh& bvh, uint32_t* stack, TraverseCounters& cnt) {
     // (lanes here hold a leaf reference; "triangles" = a leaf that is neither a sentinel nor an instance entry)
@@ -360,6 +466,7 @@ struct Traversal {
           sp.k = w_k;
         } else {
           setup_space(sp, o, d, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
+          orient_space();
         }
         id_bits = 0;
         pop(stack);
@@ -427,6 +534,7 @@ struct Traversal {
           return;
         }
         setup_space(sp, obj_point(m, o), obj_vector(m, d), sph.x, sph.y, sph.z, sph.w);
+        orient_space();
         id_bits = info.y;
         stack[top] = TRAV_EXIT_INSTANCE;
         top = BOUNDED ? min(top + STRIDE, limit) : top + STRIDE;
