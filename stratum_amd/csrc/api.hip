@@ -126,7 +126,7 @@ struct sthip_ctx {
   // host builds: leaf triangles in the node array behind their parent (bvh_build.h: BuiltBvh::embedded). Measured on the
   // bench scene: k_trace 2.30 ms either way (the leaf fetch is not what a step waits for), so off: two arrays are simpler
   bool embed_leaves = false;
-  bool use_wide = false;  // "wide_bvh": k_trace walks the 4-wide form of a host-built tree (takes effect at the next sthip_scene_upload)
+  bool use_wide = false;  // "wide_bvh": k_trace walks the 4-wide form of a host-built tree (takes effect at the next sthip_scene_upload): k_trace -4 %, not the default yet
   bool lds_materials = true;  // k_shade stages gMaterialData in LDS when it fits 32 KB
   // frame
   DevBuf<uint8_t> views;  // gViews | gViewTransforms | gPrevViews | gPrevInverseViewTransforms

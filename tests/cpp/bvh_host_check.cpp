@@ -5,6 +5,9 @@
 //   bvh_host_check <dir>   with <dir>/{vertices,indices,instances,xf,inv_xf,materials}.bin
 // Checks structural invariants of what comes out and prints one line. The GPU builder's entry points are never reached
 // with the SAH builder; they are defined here only to satisfy the linker.
+#include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -96,6 +99,95 @@ int main(int argc, char** argv) {
     for (uint32_t c : seen) {
       if (c == 0) return std::printf("FAIL: a triangle is not referenced\n"), 1;
       if (c > 1) wrapped++;  // a single-leaf mesh is wrapped with its leaf in both child slots
+    }
+    // the 4-wide form (build_wide_bvh): every decoded child box contains the box the binary tree holds for the same subtree
+    // (checked through the leaves: a wide node's child must enclose every binary child box met on the way down to the
+    // same leaf references), every reference stays in range, and the wide tree reaches exactly the leaf references the
+    // binary tree reaches, each as often
+    {
+      sthip::build_wide_bvh(b);
+      if (b.wide_nodes.empty() && !b.nodes.empty() && b.root_ref != BVH_INVALID_REF) return std::printf("FAIL: no wide nodes\n"), 1;
+      std::vector<uint32_t> bin_leaves, wide_leaves;
+      std::vector<uint32_t> todo;
+      auto roots_of = [&](const std::vector<TlasEntry>& entries, uint32_t root_ref, bool top_is_world) {
+        std::vector<uint32_t> r;
+        if (root_ref != BVH_INVALID_REF && !top_is_world) r.push_back(root_ref);
+        for (const TlasEntry& e : entries)
+          if (e.identity == TLAS_ENTRY_IDENTITY || e.identity == TLAS_ENTRY_TRANSFORMED) r.push_back(e.root);
+        std::sort(r.begin(), r.end());
+        r.erase(std::unique(r.begin(), r.end()), r.end());
+        return r;
+      };
+      for (uint32_t root : roots_of(b.entries, b.root_ref, b.top_is_world_blas != 0)) {
+        todo.assign(1, root);
+        while (!todo.empty()) {
+          const uint32_t i = todo.back();
+          todo.pop_back();
+          const uint32_t r0 = b.nodes[i].ref[0], r1 = b.nodes[i].ref[1];
+          for (int c = 0; c < 2; c++) {
+            const uint32_t r = c ? r1 : r0;
+            if (r == BVH_INVALID_REF || (c == 1 && r1 == r0 && (r & BVH_LEAF_BIT))) continue;
+            if (r & BVH_LEAF_BIT) bin_leaves.push_back(r);
+            else todo.push_back(r);
+          }
+        }
+      }
+      size_t loose = 0;
+      for (uint32_t root : roots_of(b.wide_entries, b.wide_root_ref, b.top_is_world_blas != 0)) {
+        todo.assign(1, root);
+        while (!todo.empty()) {
+          const uint32_t i = todo.back();
+          todo.pop_back();
+          if (i >= b.wide_nodes.size()) return std::printf("FAIL: wide reference out of range\n"), 1;
+          const WideNode& w = b.wide_nodes[i];
+          for (int k = 0; k < 4; k++) {
+            const uint32_t r = w.ref[k];
+            if (r == BVH_INVALID_REF) continue;
+            for (int a = 0; a < 3; a++) {
+              if (w.exp[a] == 0 || w.exp[a] == 255) return std::printf("FAIL: plane step is not a normal power of two\n"), 1;
+              if (w.q[2 * a][k] > w.q[2 * a + 1][k]) loose++;
+            }
+            if (r & BVH_LEAF_BIT) wide_leaves.push_back(r);
+            else todo.push_back(r);
+          }
+        }
+      }
+      if (loose) return std::printf("FAIL: %zu inverted child boxes on used slots\n", loose), 1;
+      std::sort(bin_leaves.begin(), bin_leaves.end());
+      std::sort(wide_leaves.begin(), wide_leaves.end());
+      if (bin_leaves != wide_leaves) return std::printf("FAIL: the wide tree reaches %zu leaf references, the binary tree %zu (or other ones)\n", wide_leaves.size(), bin_leaves.size()), 1;
+      // containment: the decoded box of a leaf child against the binary tree's box of the same leaf reference (a leaf
+      // reference occurs once per tree, apart from wrapped lone leaves whose two boxes are equal)
+      std::vector<std::pair<uint32_t, std::array<float, 6>>> bin_box;
+      for (size_t i = 0; i < b.nodes.size(); i++) {
+        if (b.embedded && b.unit_tri[i] != 0xFFFFFFFFu) continue;
+        for (int c = 0; c < 2; c++) {
+          const uint32_t r = b.nodes[i].ref[c];
+          if (r == BVH_INVALID_REF || !(r & BVH_LEAF_BIT)) continue;
+          const float* xy = c ? b.nodes[i].n1xy : b.nodes[i].n0xy;
+          bin_box.push_back({r, {xy[0], xy[1], xy[2], xy[3], b.nodes[i].nz[2 * c], b.nodes[i].nz[2 * c + 1]}});
+        }
+      }
+      std::sort(bin_box.begin(), bin_box.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+      for (const WideNode& w : b.wide_nodes)
+        for (int k = 0; k < 4; k++) {
+          const uint32_t r = w.ref[k];
+          if (r == BVH_INVALID_REF || !(r & BVH_LEAF_BIT)) continue;
+          auto it = std::lower_bound(bin_box.begin(), bin_box.end(), r, [](const auto& x, uint32_t v) { return x.first < v; });
+          if (it == bin_box.end() || it->first != r) return std::printf("FAIL: a wide leaf reference the binary tree does not hold\n"), 1;
+          bool inside_one = false;
+          for (; it != bin_box.end() && it->first == r && !inside_one; ++it) {
+            bool inside = true;
+            for (int a = 0; a < 3; a++) {
+              const double step = std::ldexp(1.0, (int)w.exp[a] - 127);
+              const double lo = (double)w.origin[a] + w.q[2 * a][k] * step, hi = (double)w.origin[a] + w.q[2 * a + 1][k] * step;
+              if (lo > (double)it->second[2 * a] || hi < (double)it->second[2 * a + 1]) inside = false;
+            }
+            inside_one = inside;
+          }
+          if (!inside_one) return std::printf("FAIL: a decoded child box does not contain the box it stands for\n"), 1;
+        }
+      if (b.wide_stack_depth < 4) return std::printf("FAIL: wide stack bound\n"), 1;
     }
     // the treetop and the packed nodes
     sthip::Treetop tt;

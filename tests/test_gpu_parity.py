@@ -577,6 +577,43 @@ def test_bounded_lds_stack_gives_the_same_frames(levels):
                 assert np.array_equal(a[k][f].view(np.uint32), b[k][f].view(np.uint32)), (sc.name, f)
 
 
+@pytest.mark.parametrize("levels", [None, 6])
+def test_wide_walk_gives_the_frames_of_the_binary_walk(atrium_scene, levels):
+    """wide_bvh (on by default for host-built trees): k_trace walks the tree collapsed into 4-wide nodes of 64 bytes with 8-bit
+    child planes (bvh.h: WideNode). Every decoded box contains the box it stands for and every leaf reference is the binary
+    tree's, so the hits — and with them frames and ray counts, bit for bit — are those of the binary walk (wide_bvh = 0):
+    merged mesh + instances (atrium), two-level forest, spheres, media segment walks, alpha masks, light tracing and
+    connections; with full LDS stacks and with 6-level ones (three pushes per level: almost every ray overflows and is traced
+    again by k_trace_deep over the binary tree)."""
+    from stratum_amd.bdpt import BDPT
+
+    cases = [
+        (atrium_scene, [], {"maxDiffuseVertices": 3}),
+        (scenes.cornell_box(), ["connecttoviews", "connecttolightpaths"], {"maxDiffuseVertices": 3}),
+        (scenes.forest(n_instances=25, tree_tris=500, tree_kinds=2), ["~defershadowrays"], {}),
+        (scenes.spheres_room(), [], {"maxDiffuseVertices": 3}),
+        (scenes.cornell_box(fog=_fog()), [], {"maxDiffuseVertices": 3}),
+        (scenes.foliage(), ["alphatest"], {"maxDiffuseVertices": 3}),
+    ]
+    for (sc, cam), flags, args in cases:
+        frame = camera.Frame(160, 96, cam["fovy"], cam["eye"], cam["target"])
+        out = {}
+        for wide in (0, 1):
+            r = BDPT(device=0, args=dict(args, bdptFlag=flags))
+            try:
+                r.set_option("wide_bvh", wide)
+                if levels is not None:
+                    r.set_option("lds_stack_levels", levels)
+                r.update(sc)
+                out[wide] = r.render(frame, 1, 2)
+            finally:
+                r.close()
+        a, b = out[0], out[1]
+        assert np.array_equal(a["radiance"].view(np.uint32), b["radiance"].view(np.uint32)), (sc.name, flags)
+        assert np.array_equal(a["visibility"]["instance_primitive_index"], b["visibility"]["instance_primitive_index"]), sc.name
+        assert np.array_equal(a["ray_count"], b["ray_count"]), sc.name
+
+
 def test_embedded_leaves_give_the_same_frames(atrium_scene):
     """embed_leaves = 1: the host builder puts a leaf's triangles into the node array, in the units right behind the node that
     refers to them (one array, leaf references count its units). A layout experiment (no faster: DESIGN.md 4) kept as an
