@@ -1,10 +1,10 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["STHIP_VERBOSE"] = "1"
 import torch
 from stratum_amd import camera, scenes
 from stratum_amd.bdpt import BDPT
-sc, cam = scenes.SCENES["atrium"]()
+sc, cam = scenes.SCENES[sys.argv[1] if len(sys.argv) > 1 else "atrium"]()
 fr = camera.Frame(1920, 1080, cam["fovy"], cam["eye"], cam["target"])
 buf = torch.zeros((1080, 1920, 4), device="cuda")
 out = {"radiance": buf.data_ptr()}
