@@ -266,8 +266,9 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s);
  * sthip_scene_upload; a failed upload with it leaves the context without a scene), with "lbvh_algorithm" 1 = PLOC
  * (default) or 0 = Karras radix tree, "ploc_radius" (1..32, default 4) and "sah_top" (default 64: subtrees of at most that
  * many triangles keep their PLOC shape under a host-built SAH top; 0 = plain PLOC);
- * "wide_bvh" (default 0: 1 = the persistent trace kernel walks the host-built tree collapsed into 4-wide nodes of 64 bytes with
- * 8-bit child planes; not with "treetop" or the GPU builder, and a transforms-only update goes back to the binary walk),
+ * "wide_bvh" (the persistent trace kernel walks the host-built tree collapsed into 4-wide nodes of 64 bytes with 8-bit child
+ * planes: 0 = never, 1 = always, 2 = default: when the binary nodes exceed 4 MiB, one XCD's L2; not with "treetop" or the GPU
+ * builder, and a transforms-only update goes back to the binary walk),
  * "treetop" (default 0), "embed_leaves" (default 0), "lds_materials" (default 1), "lds_stack_levels" (4..150: LDS levels of the traversal stack; a higher
  * tree runs the bounded kernels, default: bounded at 32 levels beyond a height of 40): layout / scheduling options that
  * never change results, read at the next sthip_scene_upload / sthip_scene_update_transforms */

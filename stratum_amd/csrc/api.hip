@@ -126,7 +126,11 @@ struct sthip_ctx {
   // host builds: leaf triangles in the node array behind their parent (bvh_build.h: BuiltBvh::embedded). Measured on the
   // bench scene: k_trace 2.30 ms either way (the leaf fetch is not what a step waits for), so off: two arrays are simpler
   bool embed_leaves = false;
-  bool use_wide = false;  // "wide_bvh": k_trace walks the 4-wide form of a host-built tree (takes effect at the next sthip_scene_upload): k_trace -4 %, not the default yet
+  // "wide_bvh": k_trace walks the 4-wide form of a host-built tree (takes effect at the next sthip_scene_upload). 0 = never,
+  // 1 = always, 2 (default) = when the binary nodes do not fit one XCD's L2 (4 MiB): the wide step is worth its arithmetic
+  // where a node fetch is slow (bench scene: k_trace -10 %) and is not where the tree sits in L2 (instanced forest: +2 %)
+  int use_wide = 2;
+  size_t wide_node_count = 0;
   bool lds_materials = true;  // k_shade stages gMaterialData in LDS when it fits 32 KB
   // frame
   DevBuf<uint8_t> views;  // gViews | gViewTransforms | gPrevViews | gPrevInverseViewTransforms
@@ -387,7 +391,7 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
   else if (!strcmp(name, "embed_leaves"))  // takes effect at the next sthip_scene_upload
     ctx->embed_leaves = value != 0;
   else if (!strcmp(name, "wide_bvh"))  // takes effect at the next sthip_scene_upload (host-built trees only)
-    ctx->use_wide = value != 0;
+    ctx->use_wide = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
   else if (!strcmp(name, "lbvh_algorithm"))  // 0: Karras radix tree, 1: PLOC (default)
     ctx->lbvh_algorithm = value == 0 ? 0 : 1;
   else if (!strcmp(name, "lds_stack_levels")) {  // takes effect at the next sthip_scene_upload / sthip_scene_update_transforms
@@ -420,7 +424,7 @@ int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out) {
     ctx->stats_pending = false;
   }
   *out = ctx->stats;
-  out->bvh_node_bytes = sizeof(BvhNodePacked);
+  out->bvh_node_bytes = ctx->bvh.wide_nodes ? (uint32_t)sizeof(WideNode) : (uint32_t)sizeof(BvhNodePacked);  // of the nodes k_trace walks (its visits are what the counters count)
   out->bvh_tri_bytes = sizeof(BvhTri);
   out->bvh_nodes = ctx->bvh_nodes;
   out->bvh_tris = ctx->bvh_tris;
@@ -694,7 +698,8 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->bvh.wide_entries = nullptr;
   ctx->bvh.wide_root_ref = BVH_INVALID_REF;
   ctx->bvh.wide_stack_depth = 0;
-  if (ctx->use_wide && !ctx->use_treetop && built.dev_nodes == 0) {
+  ctx->wide_node_count = 0;
+  if ((ctx->use_wide == 1 || (ctx->use_wide == 2 && built.nodes.size() * sizeof(BvhNodePacked) > ((size_t)4 << 20))) && !ctx->use_treetop && built.dev_nodes == 0) {
     sthip::build_wide_bvh(built);
     if (!built.wide_nodes.empty() && built.wide_nodes.size() * sizeof(WideNode) <= 0xFFFFFFFFull) {
       HIP_TRY(ctx, ctx->wide_nodes.ensure(built.wide_nodes.size()));
@@ -705,6 +710,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
       ctx->bvh.wide_entries = ctx->wide_entries.p;
       ctx->bvh.wide_root_ref = built.wide_root_ref;
       ctx->bvh.wide_stack_depth = built.wide_stack_depth;
+      ctx->wide_node_count = built.wide_nodes.size();
     }
   }
   {  // alpha masks: one-channel images and the per-triangle uvs the traversal interpolates
@@ -1955,16 +1961,22 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s) {
     }
   } else if (kind == STHIP_CEILING_NODE_GATHER_TABLE || kind == STHIP_CEILING_NODE_GATHER_L2 || kind == STHIP_CEILING_NODE_GATHER_L1) {
     if (!ctx->has_scene || !ctx->bvh_nodes) return fail(ctx, STHIP_ERR_NO_SCENE, "sthip_measure_ceiling: the node-gather ceilings read the resident acceleration structure: upload a scene first");
-    uint32_t count = (uint32_t)std::min<uint64_t>(ctx->bvh_nodes, 0xFFFFFFFFull);
-    if (kind == STHIP_CEILING_NODE_GATHER_L2) count = std::min<uint32_t>(count, (2u << 20) / BVH_NODE_BYTES);
-    if (kind == STHIP_CEILING_NODE_GATHER_L1) count = std::min<uint32_t>(count, (16u << 10) / BVH_NODE_BYTES);
+    // the nodes k_trace walks: the 48-byte binary ones (3 loads) or, with the wide walk on, the 64-byte 4-wide ones (4 loads)
+    const bool wide = ctx->bvh.wide_nodes != nullptr;
+    const uint32_t nb = wide ? (uint32_t)sizeof(WideNode) : BVH_NODE_BYTES;
+    uint32_t count = (uint32_t)std::min<uint64_t>(wide ? ctx->wide_node_count : ctx->bvh_nodes, 0xFFFFFFFFull);
+    if (kind == STHIP_CEILING_NODE_GATHER_L2) count = std::min<uint32_t>(count, (2u << 20) / nb);
+    if (kind == STHIP_CEILING_NODE_GATHER_L1) count = std::min<uint32_t>(count, (16u << 10) / nb);
     const uint32_t iterations = 64;
     DevBuf<float> sink;
     HIP_TRY(ctx, sink.ensure((size_t)blocks * 256));
-    bytes = (double)sizeof(BvhNodePacked) * (double)blocks * 256.0 * iterations * CEIL_UNROLL;
+    bytes = (double)(wide ? sizeof(WideNode) : sizeof(BvhNodePacked)) * (double)blocks * 256.0 * iterations * CEIL_UNROLL;
     for (int rep = 0; rep < 4; rep++) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-      hipLaunchKernelGGL(k_ceiling_node_gather, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->nodes.p), count, BVH_NODE_BYTES, iterations, sink.p);
+      if (wide)
+        hipLaunchKernelGGL(k_ceiling_node_gather<4>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->wide_nodes.p), count, nb, iterations, sink.p);
+      else
+        hipLaunchKernelGGL(k_ceiling_node_gather<3>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->nodes.p), count, nb, iterations, sink.p);
       HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
       HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
       float ms = 0;

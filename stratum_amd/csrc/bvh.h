@@ -65,8 +65,10 @@ struct BvhNodeSlot {
 // The 4-wide node k_trace can walk instead ("wide_bvh"; bvh_build.h: build_wide_bvh collapses the binary tree into it): 64
 // aligned bytes = four 16-byte loads per lane. The boxes of up to four children as 8-bit planes on a per-node grid:
 // plane = origin[axis] + q * 2^(exp[axis] - 127), lower planes rounded down and upper planes up on that grid (exactly: the
-// builder checks them in double), so a decoded box contains the child's box. An unused child slot has reference
-// BVH_INVALID_REF (the walk skips it by that; its planes are lo 255, hi 0). References are the binary tree's, except that an inner
+// builder checks them in double), so a decoded box contains the child's box. An unused child slot (index >= exp[3])
+// has its lower planes at 255 and its upper planes at 0 — the entry plane lies behind the exit plane on every axis, a miss
+// unless the node is point-sized — and a copy of the first child's reference, so that even then nothing but a repeated
+// visit can happen. References are the binary tree's, except that an inner
 // reference indexes THIS array.
 struct WideNode {
   float origin[3];

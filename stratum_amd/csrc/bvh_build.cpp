@@ -999,7 +999,7 @@ struct WideBuilder {
       if (k < n) {
         wn.ref[k] = refs[k];
       } else {
-        wn.ref[k] = BVH_INVALID_REF;
+        wn.ref[k] = refs[0];  // never followed unless the node is point-sized (the walk has no test for unused slots); then the first child twice, which changes no hit
         for (int a = 0; a < 3; a++) {
           wn.q[2 * a][k] = 255;
           wn.q[2 * a + 1][k] = 0;

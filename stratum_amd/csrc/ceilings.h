@@ -5,7 +5,7 @@
 // divergent traversal is the rate at which the vector-memory path delivers nodes to 64 lanes that each ask for a
 // different one. That rate is a property of the chip and of where the table is served from, and it can be measured:
 // the kernels below issue the traversal's own node fetch (3 x global_load_dwordx4 per lane from one 48-byte packed
-// node, bvh.h) at pseudo-random node indices with NO dependence between fetches (8 in flight per lane, full
+// node, or 4 from one 64-byte wide node when k_trace walks those: bvh.h) at pseudo-random node indices with NO dependence between fetches (8 in flight per lane, full
 // occupancy), i.e. the same bytes through the same units with the latency chain and the arithmetic taken away.
 //   * over the whole resident node array        -> what L2 / Infinity Cache deliver to random node fetches
 //   * over a 2 MB prefix of it (fits one XCD L2) -> the L2-hit rate of the same access
@@ -26,6 +26,8 @@ __device__ __forceinline__ uint32_t ceil_pcg(uint32_t v) {  // Jarzynski & Olano
 }
 
 // nodes: the BVH node array (node_bytes-byte records); node_count: how many of them to spread the fetches over
+// LOADS: 16-byte loads per node — 3 for the 48-byte binary node, 4 for the 64-byte wide node (whichever k_trace walks)
+template <int LOADS>
 __global__ void __launch_bounds__(256) k_ceiling_node_gather(const float4* __restrict__ nodes, uint32_t node_count, uint32_t node_bytes, uint32_t iterations, float* sink) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t state = ceil_pcg(tid * 2654435761u + 12345u);
@@ -39,18 +41,20 @@ __global__ void __launch_bounds__(256) k_ceiling_node_gather(const float4* __res
       state = ceil_pcg(state + (uint32_t)u);
       idx[u] = (uint32_t)(((uint64_t)state * node_count) >> 32);
     }
-    float4 a[CEIL_UNROLL], b[CEIL_UNROLL], c[CEIL_UNROLL];
+    float4 a[CEIL_UNROLL][LOADS];
 #pragma unroll
     for (int u = 0; u < CEIL_UNROLL; u++) {
       const float4* n = reinterpret_cast<const float4*>(base + (size_t)idx[u] * node_bytes);
-      a[u] = n[0];
-      b[u] = n[1];
-      c[u] = n[2];
+#pragma unroll
+      for (int l = 0; l < LOADS; l++) a[u][l] = n[l];
     }
 #pragma unroll
     for (int u = 0; u < CEIL_UNROLL; u++) {
-      acc += a[u].x + a[u].w + b[u].y + b[u].z + c[u].x + c[u].w;
-      acc_u ^= __float_as_uint(a[u].y) + __float_as_uint(b[u].x);
+#pragma unroll
+      for (int l = 0; l < LOADS; l++) {
+        acc += a[u][l].x + a[u][l].w;
+        acc_u ^= __float_as_uint(a[u][l].y) + __float_as_uint(a[u][l].z);
+      }
     }
   }
   if (acc == 123.456f && acc_u == 0x12345u) sink[tid] = acc;  // keeps the loads alive; practically never true

@@ -415,8 +415,7 @@ struct Traversal {
           const float tnz = fmaf((float)((qnz >> (8 * c)) & 0xFFu), az, enz), tfz = fmaf((float)((qfz >> (8 * c)) & 0xFFu), az, efz);
           const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
           const float tf = fminf(fminf(tfx, tfy), tfz);
-          const uint32_t rc = c == 0 ? q3.x : (c == 1 ? q3.y : (c == 2 ? q3.z : q3.w));
-          const bool h = (tn <= tf) & (tn <= tbest) & (rc != BVH_INVALID_REF);  // (an unused slot's planes are not a miss by themselves)
+          const bool h = (tn <= tf) & (tn <= tbest);  // (an unused slot: entry planes behind exit planes, and a copy of the first child's reference should a point-sized node let it through)
           key[c] = h ? ((__float_as_uint(tn) & 0x7FFFFFFCu) | (uint32_t)c) : 0xFFFFFFFFu;
         }
         // ascending: (0,1) (2,3) (0,2) (1,3) (1,2)
@@ -427,10 +426,14 @@ struct Traversal {
         k2 = max(t1, t2);
         k3 = t3;
         const uint32_t hits = (k0 != 0xFFFFFFFFu ? 1u : 0u) + (k1 != 0xFFFFFFFFu ? 1u : 0u) + (k2 != 0xFFFFFFFFu ? 1u : 0u) + (k3 != 0xFFFFFFFFu ? 1u : 0u);
-        auto child_ref = [&](uint32_t k) {  // reference number (k & 3): two bit masks and three bit selects
-          const uint32_t m0 = (uint32_t)((int32_t)(k << 31) >> 31), m1 = (uint32_t)((int32_t)(k << 30) >> 31);
-          const uint32_t lo = (q3.y & m0) | (q3.x & ~m0), hi = (q3.w & m0) | (q3.z & ~m0);
-          return (hi & m1) | (lo & ~m1);
+        auto child_ref = [&](uint32_t k) {  // reference number (k & 3): two bit masks and three bit selects, written as the
+          // instructions (the compiler makes and / not / or triples of the C form) and as one block (it pads every asm
+          // statement with wait states of its own)
+          uint32_t m0, m1, r;
+          asm("v_bfe_i32 %0, %3, 0, 1\n\tv_bfe_i32 %1, %3, 1, 1\n\tv_bfi_b32 %2, %0, %5, %4\n\tv_bfi_b32 %0, %0, %7, %6\n\tv_bfi_b32 %2, %1, %0, %2"
+              : "=&v"(m0), "=&v"(m1), "=&v"(r)
+              : "v"(k), "v"(q3.x), "v"(q3.y), "v"(q3.z), "v"(q3.w));
+          return r;
         };
         const uint32_t r0 = child_ref(k0), r1 = child_ref(k1), r2 = child_ref(k2), r3 = child_ref(k3);
         // the pushes: with h hits the h - 1 farther ones go to top .. top + h - 2, the farthest lowest

@@ -140,9 +140,8 @@ int main(int argc, char** argv) {
           todo.pop_back();
           if (i >= b.wide_nodes.size()) return std::printf("FAIL: wide reference out of range\n"), 1;
           const WideNode& w = b.wide_nodes[i];
-          for (int k = 0; k < 4; k++) {
+          for (int k = 0; k < (int)w.exp[3]; k++) {
             const uint32_t r = w.ref[k];
-            if (r == BVH_INVALID_REF) continue;
             for (int a = 0; a < 3; a++) {
               if (w.exp[a] == 0 || w.exp[a] == 255) return std::printf("FAIL: plane step is not a normal power of two\n"), 1;
               if (w.q[2 * a][k] > w.q[2 * a + 1][k]) loose++;
@@ -169,10 +168,14 @@ int main(int argc, char** argv) {
         }
       }
       std::sort(bin_box.begin(), bin_box.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
-      for (const WideNode& w : b.wide_nodes)
-        for (int k = 0; k < 4; k++) {
+      for (const WideNode& w : b.wide_nodes) {
+        if (w.exp[3] < 1 || w.exp[3] > 4) return std::printf("FAIL: child count\n"), 1;
+        for (int k = (int)w.exp[3]; k < 4; k++)
+          for (int a = 0; a < 3; a++)
+            if (w.q[2 * a][k] != 255 || w.q[2 * a + 1][k] != 0 || w.ref[k] != w.ref[0]) return std::printf("FAIL: unused slot\n"), 1;
+        for (int k = 0; k < (int)w.exp[3]; k++) {
           const uint32_t r = w.ref[k];
-          if (r == BVH_INVALID_REF || !(r & BVH_LEAF_BIT)) continue;
+          if (!(r & BVH_LEAF_BIT)) continue;
           auto it = std::lower_bound(bin_box.begin(), bin_box.end(), r, [](const auto& x, uint32_t v) { return x.first < v; });
           if (it == bin_box.end() || it->first != r) return std::printf("FAIL: a wide leaf reference the binary tree does not hold\n"), 1;
           bool inside_one = false;
@@ -187,6 +190,7 @@ int main(int argc, char** argv) {
           }
           if (!inside_one) return std::printf("FAIL: a decoded child box does not contain the box it stands for\n"), 1;
         }
+      }
       if (b.wide_stack_depth < 4) return std::printf("FAIL: wide stack bound\n"), 1;
     }
     // the treetop and the packed nodes

@@ -11,6 +11,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -
 grep '"metric"' gpurun_out/prof_${tag}.log > gpurun_out/prof_${tag}_bench_line.json
 cp gpurun_out/prof_${tag}/*/*_kernel_stats.csv gpurun_out/prof_${tag}_kernel_stats.csv
 tools/pmc.sh ${tag}
-python3 tools/traffic.py gpurun_out/pmc_${tag}_fetch/*/*_counter_collection.csv gpurun_out/pmc_${tag}_write/*/*_counter_collection.csv "k_trace<false, false, false, false, false>" gpurun_out/pmc_${tag}_traffic.json
-python3 tools/counters.py gpurun_out/pmc_${tag}_sq/*/*_counter_collection.csv gpurun_out/pmc_${tag}_tcc/*/*_counter_collection.csv "k_trace<false, false, false, false, false>" gpurun_out/pmc_${tag}_counters.json
+python3 tools/traffic.py gpurun_out/pmc_${tag}_fetch/*/*_counter_collection.csv gpurun_out/pmc_${tag}_write/*/*_counter_collection.csv "k_trace<false, false, true, false, true>" gpurun_out/pmc_${tag}_traffic.json
+python3 tools/counters.py gpurun_out/pmc_${tag}_sq/*/*_counter_collection.csv gpurun_out/pmc_${tag}_tcc/*/*_counter_collection.csv "k_trace<false, false, true, false, true>" gpurun_out/pmc_${tag}_counters.json
 echo done
