@@ -382,6 +382,7 @@ def main():
             "launch_ms": round(ms_trace / max(launches, 1), 4),
             "launches_per_step": round(launches / args.steps, 2),
             "nodes_per_ray": round((nodes + nodes_sh) / max(rays, 1), 2),
+            "node_bytes": int(node_bytes),  # of the nodes k_trace walks: 48 = binary, 64 = the 4-wide form (wide_bvh)
             "tris_per_ray": round((tris + tris_sh) / max(rays, 1), 2),
             "bytes_per_ray": round(alg_bytes / max(rays, 1), 1),
             "kernel_ms_per_step": {

@@ -1,3 +1,5 @@
+# applies to stratum_amd/csrc as of commit bc88c5a (before the ceiling kernel learnt the wide node's shape itself): check that
+# commit out to repeat tools/gather_shape_experiment.py
 import re
 p='ceilings.h'
 s=open(p).read()
