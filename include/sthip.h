@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STHIP_ABI_VERSION 7
+#define STHIP_ABI_VERSION 8
 
 typedef struct sthip_ctx sthip_ctx;
 
@@ -245,6 +245,11 @@ typedef struct sthip_stats {
   uint64_t tris_tested_primary;
   float ms_trace_primary;
   uint32_t launches_primary;
+  /* where the lanes of the persistent trace kernel are (with "count_traversal"; the 4-wide walk): summed over the wave-level
+   * iterations of the node loop, the lanes [0] taking a node step, [1] waiting with a triangle leaf, [2] waiting with a
+   * sentinel or an instance entry, [3] without a ray; [4] 64 per leaf phase, the lanes that [5] test a triangle and
+   * [6] handle a sentinel or an entry in it; [7] 64 per refill stop of a wave */
+  uint64_t lane_states[8];
 } sthip_stats;
 int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out);
 

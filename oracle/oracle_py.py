@@ -17,9 +17,8 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("stratum_oracle.cpp", "post_oracle.cpp")]
-    if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(_LIB_PATH) < os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    # make decides: the Makefile lists every dependency (both sources and the three shared headers under include/)
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 
 

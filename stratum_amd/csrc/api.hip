@@ -237,6 +237,7 @@ static void fill_counter_stats(sthip_ctx* ctx, const unsigned long long* c) {
     ctx->stats.round_slots[k] = c[CNT_ROUND_SLOTS + k];
     ctx->stats.busy_rounds[k] = c[CNT_BUSY_ROUNDS + k];
   }
+  for (int k = 0; k < 8; k++) ctx->stats.lane_states[k] = c[CNT_LANE_STATES + k];
   ctx->stats.nodes_visited_primary = c[CNT_NODES_PRIMARY];
   ctx->stats.tris_tested_primary = c[CNT_TRIS_PRIMARY];
 }

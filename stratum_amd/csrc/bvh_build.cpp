@@ -913,7 +913,19 @@ struct WideBuilder {
   std::vector<WideNode>& out;
   std::vector<uint32_t> wide_of;   // binary inner node -> wide node made from it, or 0xFFFFFFFF
   std::vector<uint32_t> height_of; // of a wide node: levels of wide nodes below and including it
+  const std::vector<TlasEntry>* entries = nullptr;  // set: a top-level leaf of the merged world-space mesh is replaced by that mesh's root
   WideBuilder(const std::vector<BvhNode>& n, std::vector<WideNode>& o) : nodes(n), out(o), wide_of(n.size(), 0xFFFFFFFFu) {}
+
+  // The entry of the merged world-space mesh needs no change of space and no id bits (TLAS_ENTRY_IDENTITY: traverse.h), so in
+  // the wide tree its top-level leaf IS the mesh's root: an inner reference the collapse may open like any other. A ray then
+  // walks from the top level into the mesh without the stop at a leaf phase an instance entry costs.
+  uint32_t resolve(uint32_t r) const {
+    if (entries && (r & (BVH_LEAF_BIT | BVH_INST_BIT)) == (BVH_LEAF_BIT | BVH_INST_BIT) && r < 0xFFFFFFFEu) {
+      const TlasEntry& e = (*entries)[r & 0xFFFFu];
+      if (e.identity == TLAS_ENTRY_IDENTITY && !(e.root & BVH_LEAF_BIT)) return e.root;
+    }
+    return r;
+  }
 
   // the wide node that stands for binary inner node `i` (meshes shared by several entries are converted once)
   uint32_t convert(uint32_t i) {
@@ -921,9 +933,9 @@ struct WideBuilder {
     WideChild ch[4];
     int n = 0;
     for (int c = 0; c < 2; c++) {
-      const uint32_t r = nodes[i].ref[c];
-      if (r == BVH_INVALID_REF) continue;
-      if (n == 1 && r == ch[0].ref && (r & BVH_LEAF_BIT)) continue;  // a wrapped lone leaf fills both slots: once is enough here
+      if (nodes[i].ref[c] == BVH_INVALID_REF) continue;
+      const uint32_t r = resolve(nodes[i].ref[c]);
+      if (n == 1 && r == ch[0].ref) continue;  // a wrapped lone leaf fills both slots: once is enough here
       ch[n].box = child_box(nodes[i], c);
       ch[n].ref = r;
       n++;
@@ -938,8 +950,8 @@ struct WideBuilder {
         }
       if (pick < 0) break;
       const BvhNode& b = nodes[ch[pick].ref];
-      WideChild a0{child_box(b, 0), b.ref[0]}, a1{child_box(b, 1), b.ref[1]};
-      if (a0.ref == a1.ref && (a0.ref & BVH_LEAF_BIT)) {  // (a wrapped lone leaf)
+      WideChild a0{child_box(b, 0), resolve(b.ref[0])}, a1{child_box(b, 1), resolve(b.ref[1])};
+      if (a0.ref == a1.ref) {  // (a wrapped lone leaf)
         ch[pick] = a0;
         continue;
       }
@@ -1029,8 +1041,9 @@ void build_wide_bvh(BuiltBvh& out) {
   if (out.top_is_world_blas) {
     out.wide_root_ref = out.wide_entries[0].root;
   } else if (!(out.root_ref & BVH_LEAF_BIT)) {
+    wb.entries = &out.entries;  // (the binary tree's: their roots index out.nodes)
     out.wide_root_ref = wb.convert(out.root_ref);
-    top_height = wb.height_of[out.wide_root_ref];
+    top_height = wb.height_of[out.wide_root_ref];  // (with the merged mesh's levels where it is spliced in: an upper bound)
   }
   out.wide_stack_depth = 3 * (top_height + blas_height) + 4;  // three pushes per level at most, the sentinels, a spare level
 }

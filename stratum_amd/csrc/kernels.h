@@ -33,7 +33,8 @@ enum {
   CNT_NODES_PRIMARY = 14,  // the share of CNT_NODES / CNT_TRIS that k_trace_primary (first bounce as wave packets) counted
   CNT_TRIS_PRIMARY = 15,
   CNT_CROSSINGS = 16,  // media: closest-hit queries that only carried a path across a volume boundary (no new trace() call)
-  CNT_TOTAL = 20
+  CNT_LANE_STATES = 20,  // 8 slots: TraverseCounters::st
+  CNT_TOTAL = 28
 };
 
 struct FrameParams {
@@ -281,6 +282,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
 
 
 #define TRACE_NONE 0xFFFFFFFFu
+#ifndef STHIP_POSTPONE
+#define STHIP_POSTPONE 0  // 1: the wide walk postpones a lane's first triangle leaf (traverse.h: POSTPONE; measured neutral, EXPERIMENTS.md)
+#endif
 #ifndef SHADE_BLOCKS
 #define SHADE_BLOCKS 3
 #endif
@@ -376,7 +380,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
     bvh.entries = p.bvh.wide_entries;
     bvh.root_ref = p.bvh.wide_root_ref;
   }
-  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, TOP, BOUNDED, true, STHIP_ENTRY_BATCH, WIDE> tr;  // SAVE_WORLD: 13 more registers, no occupancy step crossed (118 of 128; the ALPHA instantiations sit between 128 and 168 either way)
+  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, TOP, BOUNDED, true, STHIP_ENTRY_BATCH, WIDE, WIDE && STHIP_POSTPONE> tr;  // SAVE_WORLD: 13 more registers, no occupancy step crossed (118 of 128; the ALPHA instantiations sit between 128 and 168 either way)
   tr.top_lds = (const LdsFloat4*)top_lds;
   if (BOUNDED) tr.limit = (p.bvh.lds_levels - (WIDE ? 2u : 1u)) * STHIP_BLOCK;
   if (WIDE) tr.dump = (p.bvh.lds_levels - 1u) * STHIP_BLOCK;
@@ -397,6 +401,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
     // all the lanes that finished since the last stop at once, instead of for two or three lanes in almost every round.
     const unsigned long long idle = __ballot(!busy || !tr.active());
     if ((uint32_t)__popcll(idle) >= p.refill_idle || idle == ~0ull) {
+      if (COUNT && (threadIdx.x & 63u) == 0) cnt[0].st[7] += 64;
       if (busy && !tr.active()) {
         if (BOUNDED && tr.overflowed(stack)) {
           // the LDS stack was too short for this ray: its result is void. k_trace_deep traces it again with a stack as high as
@@ -463,6 +468,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
       cnt[tr.any ? 1 : 0].tris += c.tris;
       cnt[k].inner_slots = n0 + c.inner_slots;
       cnt[k].tri_slots = t0 + c.tri_slots;
+      for (int i = 0; i < 8; i++) cnt[0].st[i] += c.st[i];
     } else {
       tr.round(bvh, stack, p.inner_min_lanes, cnt[0]);
     }
@@ -476,6 +482,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
       wave_add(&p.counters[CNT_ROUND_SLOTS + k], round_slots[k]);
       wave_add(&p.counters[CNT_BUSY_ROUNDS + k], busy_rounds[k]);
     }
+    for (int i = 0; i < 8; i++) wave_add(&p.counters[CNT_LANE_STATES + i], cnt[0].st[i]);
   }
 }
 

@@ -96,7 +96,11 @@ struct RayHit {
 struct TraverseCounters {
   uint32_t nodes, tris;
   uint32_t inner_slots, tri_slots;
-  DEV void clear() { nodes = tris = inner_slots = tri_slots = 0; }
+  uint32_t st[8];  // sthip_stats::lane_states (lane 0 of a wave counts for the wave)
+  DEV void clear() {
+    nodes = tris = inner_slots = tri_slots = 0;
+    for (int i = 0; i < 8; i++) st[i] = 0;
+  }
 };
 DEV bool first_active_lane() { return (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1); }
 
@@ -228,8 +232,15 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
 #ifndef STHIP_ENTRY_BATCH
 #define STHIP_ENTRY_BATCH 12u
 #endif
-template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false, bool BOUNDED = false, bool SAVE_WORLD = false, uint32_t ENTRY_BATCH = 1, bool WIDE = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
+// POSTPONE (with WIDE): a lane that reaches a triangle leaf does not wait for the wave's next leaf phase with it: the leaf goes
+// into `pend` and the lane walks on with what comes next (the nearest other hit child, or the top of its stack); it only
+// waits when it holds a second leaf. A leaf phase tests ONE triangle per lane — the next one of `pend` — so its trips are
+// as full as the wave's supply of pending triangles allows and never wait for a lane's second triangle. Hits do not depend
+// on the traversal order (the contract is a minimum over all triangles), only the far bound used for culling lags by the
+// postponed leaf.
+template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false, bool BOUNDED = false, bool SAVE_WORLD = false, uint32_t ENTRY_BATCH = 1, bool WIDE = false, bool POSTPONE = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
 struct Traversal {
+  uint32_t pend;             // POSTPONE only: the postponed triangle leaf (first triangle << 2 | count - 1, leaf bit set), TRAV_DONE if none
   uint32_t dump;             // WIDE only: the word offset of a spare stack level that takes the pushes of children that were not hit
   const LdsFloat4* top_lds;  // TOP only
   uint32_t limit;            // BOUNDED only: (levels - 1) * STRIDE
@@ -264,8 +275,13 @@ struct Traversal {
     sp.noodL.z = nz ? sp.noodH.z : lz;
     sp.noodH.z = nz ? lz : sp.noodH.z;
   }
-  DEV bool active() const { return ref != TRAV_DONE; }
-  DEV void reset() { ref = TRAV_DONE; }
+  DEV bool active() const { return POSTPONE ? (ref & pend) != TRAV_DONE : ref != TRAV_DONE; }
+  DEV void reset() {
+    ref = TRAV_DONE;
+    if (POSTPONE) pend = TRAV_DONE;
+  }
+  // a triangle leaf (not a sentinel, not an instance entry)
+  static DEV bool is_tri_leaf(uint32_t r) { return (r & (BVH_LEAF_BIT | BVH_INST_BIT)) == BVH_LEAF_BIT; }
 
   DEV void start(const DeviceBvh& bvh, uint32_t* stack, f3 ro, f3 rd, float t0, float t1) {
     o = ro;
@@ -280,6 +296,7 @@ struct Traversal {
     if (BOUNDED) stack[limit] = TRAV_CANARY;
     id_bits = 0;
     ref = bvh.root_ref;  // BVH_INVALID_REF == TRAV_DONE for an empty scene
+    if (POSTPONE) pend = TRAV_DONE;
     setup_space(sp, ro, rd, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
     orient_space();
     if (SAVE_WORLD) {
@@ -385,6 +402,15 @@ struct Traversal {
     const bool nx = sp.idir.x < 0.0f, ny = sp.idir.y < 0.0f, nz = sp.idir.z < 0.0f;
     const float cnx = sp.noodL.x, cfx = sp.noodH.x, cny = sp.noodL.y, cfy = sp.noodH.y, cnz = sp.noodL.z, cfz = sp.noodH.z;
     for (;;) {
+      if (COUNT) {  // where the lanes are (the lanes without a ray are not in this loop)
+        const unsigned long long here = __ballot(true), walking = __ballot(!(ref & BVH_LEAF_BIT)), leaf = __ballot(is_tri_leaf(ref));
+        if (first_active_lane()) {
+          cnt.st[0] += (uint32_t)__popcll(walking);
+          cnt.st[1] += (uint32_t)__popcll(leaf);
+          cnt.st[2] += (uint32_t)__popcll(here & ~walking & ~leaf);
+          cnt.st[3] += 64u - (uint32_t)__popcll(here);
+        }
+      }
       if (!(ref & BVH_LEAF_BIT)) {
         const uint4* n = reinterpret_cast<const uint4*>(base + (ref << 6));
         const uint4 q0 = n[0], q1 = n[1], q2 = n[2];
@@ -435,17 +461,29 @@ struct Traversal {
               : "v"(k), "v"(q3.x), "v"(q3.y), "v"(q3.z), "v"(q3.w));
           return r;
         };
-        const uint32_t r0 = child_ref(k0), r1 = child_ref(k1), r2 = child_ref(k2), r3 = child_ref(k3);
+        uint32_t r0 = child_ref(k0), r1 = child_ref(k1), r2 = child_ref(k2);
+        const uint32_t r3 = child_ref(k3);
+        uint32_t eh = hits;
+        if (POSTPONE) {
+          // the nearest hit child is a triangle leaf and nothing is postponed yet: it goes into `pend`, and the step goes on as
+          // if the node had been hit in the other children only
+          const bool post = (pend == TRAV_DONE) & is_tri_leaf(r0) & (hits != 0u);
+          pend = post ? r0 : pend;
+          r0 = post ? r1 : r0;
+          r1 = post ? r2 : r1;
+          r2 = post ? r3 : r2;
+          eh = hits - (post ? 1u : 0u);
+        }
         // the pushes: with h hits the h - 1 farther ones go to top .. top + h - 2, the farthest lowest
         const uint32_t lim = BOUNDED ? limit : 0xFFFFFFFFu;
-        const uint32_t p1 = hits > 1u ? min(top + (hits - 2u) * STRIDE, lim) : dump;
-        const uint32_t p2 = hits > 2u ? min(top + (hits - 3u) * STRIDE, lim) : dump;
-        const uint32_t p3 = hits > 3u ? min(top, lim) : dump;
+        const uint32_t p1 = eh > 1u ? min(top + (eh - 2u) * STRIDE, lim) : dump;
+        const uint32_t p2 = eh > 2u ? min(top + (eh - 3u) * STRIDE, lim) : dump;
+        const uint32_t p3 = eh > 3u ? min(top, lim) : dump;
         stack[p3] = r3;
         stack[p2] = r2;
         stack[p1] = r1;
-        ref = hits ? r0 : popped;
-        const uint32_t next_top = hits ? top + (hits - 1u) * STRIDE : top - STRIDE;
+        ref = eh ? r0 : popped;
+        const uint32_t next_top = eh ? top + (eh - 1u) * STRIDE : top - STRIDE;
         top = BOUNDED ? min(next_top, limit) : next_top;
       }
       if ((uint32_t)__popcll(__ballot(!(ref & BVH_LEAF_BIT))) < min_lanes) break;
@@ -454,8 +492,26 @@ struct Traversal {
 
   // ref has the leaf bit: a sentinel, an instance, or up to 4 triangles
   DEV void leaf_step(const DeviceBvh& bvh, uint32_t* stack, TraverseCounters& cnt) {
+    if (POSTPONE) {
+      leaf_step_postponed(bvh, stack, cnt);
+      return;
+    }
     // (lanes here hold a leaf reference; "triangles" = a leaf that is neither a sentinel nor an instance entry)
     const bool entries_due = ENTRY_BATCH > 1 ? !__any(ref < TRAV_EXIT_INSTANCE && !(ref & BVH_INST_BIT)) : true;
+    if (COUNT) {
+      const unsigned long long tri = __ballot(is_tri_leaf(ref));
+      if (first_active_lane()) {
+        cnt.st[4] += 64;
+        cnt.st[5] += (uint32_t)__popcll(tri);
+        cnt.st[6] += (uint32_t)__popcll(__ballot(true) & ~tri);
+      }
+    }
+    if (special_step(bvh, stack, cnt, entries_due)) return;
+    triangles_step(bvh, stack, cnt);
+  }
+
+  // ref is a sentinel or an instance entry: handled here (returns true); a triangle leaf: returns false
+  DEV bool special_step(const DeviceBvh& bvh, uint32_t* stack, TraverseCounters& cnt, bool entries_due) {
     if (ref >= TRAV_EXIT_INSTANCE) {
       if (ref == TRAV_EXIT_INSTANCE) {  // everything pushed inside the instance is consumed: back to world space
         if (SAVE_WORLD) {
@@ -474,7 +530,7 @@ struct Traversal {
         id_bits = 0;
         pop(stack);
       }
-      return;  // TRAV_DONE stays
+      return true;  // TRAV_DONE stays
     }
     if (ref & BVH_INST_BIT) {
       // ENTRY_BATCH (the persistent kernel): entering an instance is ~250 instructions and a dependent load, run by the few
@@ -483,7 +539,7 @@ struct Traversal {
       // until at least ENTRY_BATCH lanes hold one or no lane of this round has triangles left to test.
       if (ENTRY_BATCH > 1) {
         const uint32_t entering = (uint32_t)__popcll(__ballot(true));  // (the lanes in this branch)
-        if (entering < ENTRY_BATCH && !entries_due) return;
+        if (entering < ENTRY_BATCH && !entries_due) return true;
       }
       const TlasEntry* e = bvh.entries + (ref & 0xFFFFu);
       const float4* ev = reinterpret_cast<const float4*>(e);
@@ -502,7 +558,7 @@ struct Traversal {
             if (is_any()) {
               hit.ip = 0;
               ref = TRAV_DONE;
-              return;
+              return true;
             }
             const uint32_t ip = info.y | 0xFFFF0000u;  // instance | INVALID_PRIMITIVE << 16
             if (t < hit.t || (t == hit.t && hit.ip != 0xFFFFFFFFu && hit_key(ip) < hit_key(hit.ip))) {
@@ -512,7 +568,7 @@ struct Traversal {
             }
           }
           pop(stack);
-          return;
+          return true;
         }
         if (ALPHA && info.z == TLAS_ENTRY_VOLUME) {  // a volume instance: the slabs of its grid's bounding box (intersection.hlsli:93-113)
           if (COUNT) {
@@ -524,7 +580,7 @@ struct Traversal {
             if (is_any()) {
               hit.ip = 0;
               ref = TRAV_DONE;
-              return;
+              return true;
             }
             const uint32_t ip = info.y | 0xFFFF0000u;
             if (t < hit.t || (t == hit.t && hit.ip != 0xFFFFFFFFu && hit_key(ip) < hit_key(hit.ip))) {
@@ -534,7 +590,7 @@ struct Traversal {
             }
           }
           pop(stack);
-          return;
+          return true;
         }
         setup_space(sp, obj_point(m, o), obj_vector(m, d), sph.x, sph.y, sph.z, sph.w);
         orient_space();
@@ -545,46 +601,53 @@ struct Traversal {
       // identity entry (the merged world-space mesh): same ray, same (larger, still conservative) padding,
       // id_bits stays 0 because its triangles carry their instance index themselves
       ref = info.x;
-      return;
+      return true;
     }
+    return false;
+  }
+
+  // One triangle of a leaf against this lane's ray, folded into the hit record with selects: no exec-mask regions (each costs
+  // more than the arithmetic it would skip: the lanes of a wave wait for one another anyway). Returns whether an occlusion
+  // lane found its hit.
+  DEV bool one_triangle(const DeviceBvh& bvh, uint32_t index, TraverseCounters& cnt) {
+    const float4* tv = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(bvh.tris) + (size_t)(index * 48u));
+    const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+    if (COUNT) {
+      cnt.tris++;
+      if (first_active_lane()) cnt.tri_slots += 64;
+    }
+    float t, b1, b2;
+    bool candidate = tri_test(sp, xyz(v0), xyz(v1), xyz(v2), tmin, tmax, t, b1, b2);
+    if (ALPHA && candidate) {
+      // gAlphaTest: the candidate must pass the mask of its instance's material (instances that share a mesh may
+      // have different materials, so the mask comes from the instance, the uvs from the leaf triangle)
+      const uint32_t mask = bvh.alpha_test ? bvh.inst_alpha[(__float_as_uint(v0.w) | id_bits) & 0xFFFFu] : BVH_NO_ALPHA;
+      if (mask != BVH_NO_ALPHA) {
+        const float2* q = bvh.tri_uv + (size_t)index * 3u;
+        const float2 u0 = q[0], u1 = q[1], u2 = q[2];
+        const float u = u0.x + (u1.x - u0.x) * b1 + (u2.x - u0.x) * b2;  // shading_data.hlsli:2-6
+        float v = u0.y + (u1.y - u0.y) * b1 + (u2.y - u0.y) * b2;
+        if (bvh.flip_uvs) v = 1 - v;
+        candidate = sample_image1(bvh, mask, u, v) >= 0.75f;
+      }
+    }
+    const bool any_lane = is_any();
+    const uint32_t ip = __float_as_uint(v0.w) | id_bits;
+    const bool closer = candidate & !any_lane & ((t < hit.t) | ((t == hit.t) & (hit.ip != 0xFFFFFFFFu) & (hit_key(ip) < hit_key(hit.ip))));
+    hit.t = closer ? t : hit.t;
+    hit.b1 = closer ? b1 : hit.b1;
+    hit.b2 = closer ? b2 : hit.b2;
+    hit.ip = closer ? ip : hit.ip;
+    return candidate & any_lane;
+  }
+
+  // ref is a triangle leaf: all its triangles, then the pop
+  DEV void triangles_step(const DeviceBvh& bvh, uint32_t* stack, TraverseCounters& cnt) {
     const uint32_t first = (ref & 0x3FFFFFFFu) >> 2;
     const uint32_t count = (ref & 3u) + 1u;
-    const char* tbase = reinterpret_cast<const char*>(bvh.tris);
-    // No exec-mask regions in the triangle loop (each costs more than the arithmetic it would skip: the lanes of a wave wait
-    // for one another anyway): every lane runs the whole test, a candidate is folded in with selects, and an occlusion
-    // lane's verdict is collected in `occluded` and applied behind the loop.
+    // an occlusion lane's verdict is collected in `occluded` and applied behind the loop
     bool occluded = false;
-    for (uint32_t i = 0; i < count; i++) {
-      const float4* tv = reinterpret_cast<const float4*>(tbase + (size_t)((first + i) * 48u));
-      const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
-      if (COUNT) {
-        cnt.tris++;
-        if (first_active_lane()) cnt.tri_slots += 64;
-      }
-      float t, b1, b2;
-      bool candidate = tri_test(sp, xyz(v0), xyz(v1), xyz(v2), tmin, tmax, t, b1, b2);
-      if (ALPHA && candidate) {
-        // gAlphaTest: the candidate must pass the mask of its instance's material (instances that share a mesh may
-        // have different materials, so the mask comes from the instance, the uvs from the leaf triangle)
-        const uint32_t mask = bvh.alpha_test ? bvh.inst_alpha[(__float_as_uint(v0.w) | id_bits) & 0xFFFFu] : BVH_NO_ALPHA;
-        if (mask != BVH_NO_ALPHA) {
-          const float2* q = bvh.tri_uv + (size_t)(first + i) * 3u;
-          const float2 u0 = q[0], u1 = q[1], u2 = q[2];
-          const float u = u0.x + (u1.x - u0.x) * b1 + (u2.x - u0.x) * b2;  // shading_data.hlsli:2-6
-          float v = u0.y + (u1.y - u0.y) * b1 + (u2.y - u0.y) * b2;
-          if (bvh.flip_uvs) v = 1 - v;
-          candidate = sample_image1(bvh, mask, u, v) >= 0.75f;
-        }
-      }
-      const bool any_lane = is_any();
-      occluded |= candidate & any_lane;
-      const uint32_t ip = __float_as_uint(v0.w) | id_bits;
-      const bool closer = candidate & !any_lane & ((t < hit.t) | ((t == hit.t) & (hit.ip != 0xFFFFFFFFu) & (hit_key(ip) < hit_key(hit.ip))));
-      hit.t = closer ? t : hit.t;
-      hit.b1 = closer ? b1 : hit.b1;
-      hit.b2 = closer ? b2 : hit.b2;
-      hit.ip = closer ? ip : hit.ip;
-    }
+    for (uint32_t i = 0; i < count; i++) occluded |= one_triangle(bvh, first + i, cnt);
     // pop — or, for an occlusion lane that found its hit, the end of the ray (hit.ip = 0 says "occluded")
     const uint32_t popped = stack[top - STRIDE];
     hit.ip = occluded ? 0u : hit.ip;
@@ -592,10 +655,46 @@ struct Traversal {
     top = occluded ? top : top - STRIDE;
   }
 
+  // POSTPONE: a lane without a postponed leaf that holds a triangle leaf takes it into `pend` and its next reference off the stack
+  DEV void absorb(const uint32_t* stack) {
+    const bool take = (pend == TRAV_DONE) & is_tri_leaf(ref);
+    const uint32_t popped = stack[top - STRIDE];  // (the slot below `top` always exists: the DONE sentinel sits at the bottom)
+    pend = take ? ref : pend;
+    ref = take ? popped : ref;
+    top = take ? top - STRIDE : top;
+  }
+
+  // The leaf phase of the POSTPONE walk: every lane that has a postponed leaf (or holds one it could not postpone) tests its
+  // triangles; then the lanes that hold a sentinel or an instance entry handle it (these change the space the ray is in, so
+  // they come after the postponed triangles of the old space), and whoever holds a triangle leaf afterwards takes it along.
+  DEV void leaf_step_postponed(const DeviceBvh& bvh, uint32_t* stack, TraverseCounters& cnt) {
+    absorb(stack);
+    const bool have_tri = pend != TRAV_DONE;
+    const bool entries_due = ENTRY_BATCH > 1 ? !__any(have_tri) : true;
+    if (COUNT) {
+      const unsigned long long tri = __ballot(have_tri), special = __ballot((ref & BVH_LEAF_BIT) && !is_tri_leaf(ref) && ref != TRAV_DONE);
+      if (first_active_lane()) {
+        cnt.st[4] += 64;
+        cnt.st[5] += (uint32_t)__popcll(tri);
+        cnt.st[6] += (uint32_t)__popcll(special);
+      }
+    }
+    if (have_tri) {
+      const uint32_t first = (pend & 0x3FFFFFFFu) >> 2, count = (pend & 3u) + 1u;
+      bool occluded = false;
+      for (uint32_t i = 0; i < count; i++) occluded |= one_triangle(bvh, first + i, cnt);
+      pend = TRAV_DONE;
+      hit.ip = occluded ? 0u : hit.ip;  // hit.ip = 0 says "occluded": the end of the ray
+      ref = occluded ? TRAV_DONE : ref;
+    }
+    if ((ref & BVH_LEAF_BIT) && !is_tri_leaf(ref)) (void)special_step(bvh, stack, cnt, entries_due);
+    absorb(stack);
+  }
+
   // one wave-synchronous round: inner nodes until (almost) every lane holds a leaf, then the leaves
   DEV void round(const DeviceBvh& bvh, uint32_t* stack, uint32_t min_lanes, TraverseCounters& cnt) {
     if (active()) inner_loop(bvh, stack, min_lanes, cnt);
-    if (active() && (ref & BVH_LEAF_BIT)) leaf_step(bvh, stack, cnt);
+    if (active() && ((ref & BVH_LEAF_BIT) || (POSTPONE && pend != TRAV_DONE))) leaf_step(bvh, stack, cnt);
   }
 };
 

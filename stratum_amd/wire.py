@@ -223,6 +223,7 @@ class Stats(C.Structure):
         ("tris_tested_primary", C.c_uint64),
         ("ms_trace_primary", C.c_float),
         ("launches_primary", C.c_uint32),
+        ("lane_states", C.c_uint64 * 8),
     ]
 
 

@@ -109,16 +109,18 @@ int main(int argc, char** argv) {
       if (b.wide_nodes.empty() && !b.nodes.empty() && b.root_ref != BVH_INVALID_REF) return std::printf("FAIL: no wide nodes\n"), 1;
       std::vector<uint32_t> bin_leaves, wide_leaves;
       std::vector<uint32_t> todo;
-      auto roots_of = [&](const std::vector<TlasEntry>& entries, uint32_t root_ref, bool top_is_world) {
+      // (in the wide tree the top-level leaf of the merged world-space mesh is that mesh's root — build_wide_bvh splices it in —
+      // so there the mesh is reached from the top level and its entry is not a root of its own, nor a leaf reference)
+      auto roots_of = [&](const std::vector<TlasEntry>& entries, uint32_t root_ref, bool top_is_world, bool spliced) {
         std::vector<uint32_t> r;
         if (root_ref != BVH_INVALID_REF && !top_is_world) r.push_back(root_ref);
         for (const TlasEntry& e : entries)
-          if (e.identity == TLAS_ENTRY_IDENTITY || e.identity == TLAS_ENTRY_TRANSFORMED) r.push_back(e.root);
+          if ((e.identity == TLAS_ENTRY_IDENTITY && !(spliced && !top_is_world)) || e.identity == TLAS_ENTRY_TRANSFORMED) r.push_back(e.root);
         std::sort(r.begin(), r.end());
         r.erase(std::unique(r.begin(), r.end()), r.end());
         return r;
       };
-      for (uint32_t root : roots_of(b.entries, b.root_ref, b.top_is_world_blas != 0)) {
+      for (uint32_t root : roots_of(b.entries, b.root_ref, b.top_is_world_blas != 0, false)) {
         todo.assign(1, root);
         while (!todo.empty()) {
           const uint32_t i = todo.back();
@@ -127,13 +129,15 @@ int main(int argc, char** argv) {
           for (int c = 0; c < 2; c++) {
             const uint32_t r = c ? r1 : r0;
             if (r == BVH_INVALID_REF || (c == 1 && r1 == r0 && (r & BVH_LEAF_BIT))) continue;
+            const bool merged_entry = (r & (BVH_LEAF_BIT | BVH_INST_BIT)) == (BVH_LEAF_BIT | BVH_INST_BIT) && b.entries[r & 0xFFFFu].identity == TLAS_ENTRY_IDENTITY;
+            if (merged_entry) continue;  // spliced in the wide tree: no leaf reference there
             if (r & BVH_LEAF_BIT) bin_leaves.push_back(r);
             else todo.push_back(r);
           }
         }
       }
       size_t loose = 0;
-      for (uint32_t root : roots_of(b.wide_entries, b.wide_root_ref, b.top_is_world_blas != 0)) {
+      for (uint32_t root : roots_of(b.wide_entries, b.wide_root_ref, b.top_is_world_blas != 0, true)) {
         todo.assign(1, root);
         while (!todo.empty()) {
           const uint32_t i = todo.back();

@@ -16,6 +16,12 @@ for label, max_vertices in (("primary rays only", 2), ("default (3 closest + 2 s
     r.render(frame, 0, 1, aovs=False)
     s = r.stats()
     print(label)
+    ls = s["lane_states"]
+    it = max(sum(ls[0:4]), 1)
+    print(
+        "  node-loop iterations: %.0f%% of lanes step, %.0f%% wait with a triangle leaf, %.0f%% wait with a sentinel / instance entry, %.0f%% have no ray | leaf phases: %.2f per 10 iterations, %.0f%% of lanes test a triangle, %.0f%% handle a sentinel / entry | refill stops: %.2f per 10 iterations"
+        % (100 * ls[0] / it, 100 * ls[1] / it, 100 * ls[2] / it, 100 * ls[3] / it, 10 * ls[4] / it, 100 * ls[5] / max(ls[4], 1), 100 * ls[6] / max(ls[4], 1), 10 * ls[7] / it)
+    )
     for k, kind in enumerate(("closest", "shadow")):
         nodes = s["nodes_visited" if k == 0 else "nodes_visited_shadow"]
         tris = s["tris_tested" if k == 0 else "tris_tested_shadow"]
