@@ -832,8 +832,8 @@ static size_t trace_lds_bytes(const sthip_ctx* ctx) { return stack_bytes(ctx) + 
 // Decides how the traversal stack of the current tree is held: all of it in LDS, or lds_stack_cap levels there and the
 // full height in global memory for the rays that overflow. Then the treetop takes the LDS that is left.
 static int configure_stack(sthip_ctx* ctx) {
-  // (the wide walk pushes up to three children per level and keeps one more level for the pushes of children it missed)
-  const uint32_t need = ctx->bvh.wide_nodes ? ctx->bvh.wide_stack_depth + 1u : ctx->bvh.stack_depth;
+  // (the wide walk pushes up to three children per level, and every step writes the three levels from `top` on)
+  const uint32_t need = ctx->bvh.wide_nodes ? ctx->bvh.wide_stack_depth + 3u : ctx->bvh.stack_depth;
   const bool bounded = need > ctx->lds_stack_threshold;
   ctx->bvh.lds_levels = bounded ? ctx->lds_stack_cap : need;
   ctx->bvh.spill = nullptr;

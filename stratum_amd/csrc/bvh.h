@@ -64,7 +64,7 @@ struct BvhNodeSlot {
 };
 // The 4-wide node k_trace can walk instead ("wide_bvh"; bvh_build.h: build_wide_bvh collapses the binary tree into it): 64
 // aligned bytes = four 16-byte loads per lane. The boxes of up to four children as 8-bit planes on a per-node grid:
-// plane = origin[axis] + q * 2^(exp[axis] - 127), lower planes rounded down and upper planes up on that grid (exactly: the
+// plane = origin[axis] + q * 2^exp[axis] (exp a signed byte), lower planes rounded down and upper planes up on that grid (exactly: the
 // builder checks them in double), so a decoded box contains the child's box. An unused child slot (index >= exp[3])
 // has its lower planes at 255 and its upper planes at 0 — the entry plane lies behind the exit plane on every axis, a miss
 // unless the node is point-sized — and a copy of the first child's reference, so that even then nothing but a repeated
@@ -72,7 +72,7 @@ struct BvhNodeSlot {
 // reference indexes THIS array.
 struct WideNode {
   float origin[3];
-  uint8_t exp[4];    // biased exponents of the x, y, z plane step; [3] = number of children (not read by the kernel)
+  uint8_t exp[4];    // exponents of the x, y, z plane step as signed bytes (-126 .. 127); [3] = number of children (not read by the kernel)
   uint8_t q[6][4];   // [lo.x, hi.x, lo.y, hi.y, lo.z, hi.z][child]
   uint32_t pad[2];
   uint32_t ref[4];

@@ -913,6 +913,7 @@ struct WideBuilder {
   std::vector<WideNode>& out;
   std::vector<uint32_t> wide_of;   // binary inner node -> wide node made from it, or 0xFFFFFFFF
   std::vector<uint32_t> height_of; // of a wide node: levels of wide nodes below and including it
+  bool ok = true;                  // false: some node's boxes do not fit the 8-bit grid (non-finite or astronomically large extents)
   const std::vector<TlasEntry>* entries = nullptr;  // set: a top-level leaf of the merged world-space mesh is replaced by that mesh's root
   WideBuilder(const std::vector<BvhNode>& n, std::vector<WideNode>& o) : nodes(n), out(o), wide_of(n.size(), 0xFFFFFFFFu) {}
 
@@ -1001,10 +1002,15 @@ struct WideBuilder {
           wn.q[2 * a][k] = (uint8_t)lo;
           wn.q[2 * a + 1][k] = (uint8_t)hi;
         }
-        if (fits || e >= 254) break;
+        if (fits) break;
+        if (e >= 254) {  // no power of two spans it (or a plane is not finite): the tree is not usable, the binary walk keeps its clamped planes
+          ok = false;
+          break;
+        }
         e++;
       }
-      wn.exp[a] = (uint8_t)e;
+      if (!std::isfinite(wn.origin[a])) ok = false;
+      wn.exp[a] = (uint8_t)(int8_t)(e - 127);  // signed: the kernel sign-extends the byte and scales with v_ldexp_f32
     }
     wn.exp[3] = (uint8_t)n;
     for (int k = 0; k < 4; k++) {
@@ -1046,6 +1052,12 @@ void build_wide_bvh(BuiltBvh& out) {
     top_height = wb.height_of[out.wide_root_ref];  // (with the merged mesh's levels where it is spliced in: an upper bound)
   }
   out.wide_stack_depth = 3 * (top_height + blas_height) + 4;  // three pushes per level at most, the sentinels, a spare level
+  if (!wb.ok) {  // (boxes that do not fit the nodes' grid: no wide tree, the caller walks the binary one)
+    out.wide_nodes.clear();
+    out.wide_entries.clear();
+    out.wide_root_ref = BVH_INVALID_REF;
+    out.wide_stack_depth = 0;
+  }
 }
 
 bool rebuild_top_level(TopLevelState& st, const sthip_TransformData* xf, const sthip_TransformData* inv, uint32_t instance_count, std::vector<BvhNode>& tlas_nodes, uint32_t& root_ref,

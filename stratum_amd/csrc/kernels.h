@@ -282,9 +282,6 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
 
 
 #define TRACE_NONE 0xFFFFFFFFu
-#ifndef STHIP_POSTPONE
-#define STHIP_POSTPONE 0  // 1: the wide walk postpones a lane's first triangle leaf (traverse.h: POSTPONE; measured neutral, EXPERIMENTS.md)
-#endif
 #ifndef SHADE_BLOCKS
 #define SHADE_BLOCKS 3
 #endif
@@ -351,7 +348,7 @@ DEV void finish_ray(const FrameParams& p, float4* target, uint32_t slot, bool sh
 // TOP: the treetop (DeviceBvh::top_nodes) is held in LDS and followed ("treetop" = 1). Off by default since the loop lost
 // its other exec-mask regions: the LDS-or-global branch it needs in every step now costs more than the LDS reads save.
 // WIDE: the walk goes over the 4-wide form of the tree (DeviceBvh::wide_nodes, "wide_bvh" = 1): fewer, fatter dependent
-// steps. Its stack has two levels above the last usable one: the canary's (BOUNDED) and the spare level misses are pushed to.
+// steps. Its stack has three levels from the last usable one on: every step writes top, top + 1 and top + 2.
 template <bool COUNT, bool ALPHA, bool BOUNDED = false, bool TOP = false, bool WIDE = false>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t depth_closest, uint32_t depth_shadow) {
   extern __shared__ uint32_t lds_stack[];
@@ -380,10 +377,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
     bvh.entries = p.bvh.wide_entries;
     bvh.root_ref = p.bvh.wide_root_ref;
   }
-  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, TOP, BOUNDED, true, STHIP_ENTRY_BATCH, WIDE, WIDE && STHIP_POSTPONE> tr;  // SAVE_WORLD: 13 more registers, no occupancy step crossed (118 of 128; the ALPHA instantiations sit between 128 and 168 either way)
+  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, TOP, BOUNDED, true, STHIP_ENTRY_BATCH, WIDE> tr;  // SAVE_WORLD: 13 more registers, no occupancy step crossed (118 of 128; the ALPHA instantiations sit between 128 and 168 either way)
   tr.top_lds = (const LdsFloat4*)top_lds;
-  if (BOUNDED) tr.limit = (p.bvh.lds_levels - (WIDE ? 2u : 1u)) * STHIP_BLOCK;
-  if (WIDE) tr.dump = (p.bvh.lds_levels - 1u) * STHIP_BLOCK;
+  if (BOUNDED) tr.limit = (p.bvh.lds_levels - (WIDE ? 3u : 1u)) * STHIP_BLOCK;  // (the wide step writes three levels from `top` on)
   tr.reset();
   tr.any = false;
   WaveWork work_c, work_s;

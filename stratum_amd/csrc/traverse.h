@@ -113,10 +113,14 @@ struct RaySpace {
   int k;              // kx | ky << 2 | kz << 4: the watertight test's axis permutation in one register
 };
 
+// 1 / d for the slab tests, |d| clamped away from 0. The hardware's reciprocal (1 ulp) instead of the correctly rounded
+// division (one instruction for eleven): box tests are not part of the hit contract, they only have to be conservative, and
+// both terms of a slab distance are multiplied by the SAME value, so its error is that of a ray whose direction differs by
+// 1.2e-7 relative per axis — a sideways shift of 1.2e-7 x distance against the 4e-6 x distance the ray's origin is padded by.
 DEV float safe_rcp_dir(float d) {
   const float eps = 1e-30f;
   const float dd = fabsf(d) < eps ? copysignf(eps, d) : d;
-  return 1.0f / dd;
+  return __builtin_amdgcn_rcpf(dd);
 }
 
 DEV void setup_space(RaySpace& s, f3 o, f3 d, float cx, float cy, float cz, float radius) {
@@ -232,16 +236,8 @@ DEV bool tri_test(const RaySpace& s, f3 p0, f3 p1, f3 p2, float tmin, float tmax
 #ifndef STHIP_ENTRY_BATCH
 #define STHIP_ENTRY_BATCH 12u
 #endif
-// POSTPONE (with WIDE): a lane that reaches a triangle leaf does not wait for the wave's next leaf phase with it: the leaf goes
-// into `pend` and the lane walks on with what comes next (the nearest other hit child, or the top of its stack); it only
-// waits when it holds a second leaf. A leaf phase tests ONE triangle per lane — the next one of `pend` — so its trips are
-// as full as the wave's supply of pending triangles allows and never wait for a lane's second triangle. Hits do not depend
-// on the traversal order (the contract is a minimum over all triangles), only the far bound used for culling lags by the
-// postponed leaf.
-template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false, bool BOUNDED = false, bool SAVE_WORLD = false, uint32_t ENTRY_BATCH = 1, bool WIDE = false, bool POSTPONE = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
+template <int MODE, bool COUNT, uint32_t STRIDE, bool ALPHA = false, bool TOP = false, bool BOUNDED = false, bool SAVE_WORLD = false, uint32_t ENTRY_BATCH = 1, bool WIDE = false>  // ALPHA: gAlphaTest is compiled in (scenes with alpha masks)
 struct Traversal {
-  uint32_t pend;             // POSTPONE only: the postponed triangle leaf (first triangle << 2 | count - 1, leaf bit set), TRAV_DONE if none
-  uint32_t dump;             // WIDE only: the word offset of a spare stack level that takes the pushes of children that were not hit
   const LdsFloat4* top_lds;  // TOP only
   uint32_t limit;            // BOUNDED only: (levels - 1) * STRIDE
   DEV bool overflowed(const uint32_t* stack) const { return BOUNDED && stack[limit] != TRAV_CANARY; }
@@ -275,11 +271,8 @@ struct Traversal {
     sp.noodL.z = nz ? sp.noodH.z : lz;
     sp.noodH.z = nz ? lz : sp.noodH.z;
   }
-  DEV bool active() const { return POSTPONE ? (ref & pend) != TRAV_DONE : ref != TRAV_DONE; }
-  DEV void reset() {
-    ref = TRAV_DONE;
-    if (POSTPONE) pend = TRAV_DONE;
-  }
+  DEV bool active() const { return ref != TRAV_DONE; }
+  DEV void reset() { ref = TRAV_DONE; }
   // a triangle leaf (not a sentinel, not an instance entry)
   static DEV bool is_tri_leaf(uint32_t r) { return (r & (BVH_LEAF_BIT | BVH_INST_BIT)) == BVH_LEAF_BIT; }
 
@@ -296,7 +289,6 @@ struct Traversal {
     if (BOUNDED) stack[limit] = TRAV_CANARY;
     id_bits = 0;
     ref = bvh.root_ref;  // BVH_INVALID_REF == TRAV_DONE for an empty scene
-    if (POSTPONE) pend = TRAV_DONE;
     setup_space(sp, ro, rd, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
     orient_space();
     if (SAVE_WORLD) {
@@ -386,11 +378,11 @@ struct Traversal {
   }
 
   // The same walk over 4-wide nodes (bvh.h: WideNode): one 64-byte node = four 16-byte loads, the boxes of up to four children
-  // decoded from 8-bit planes — plane = origin + q * 2^e, so t = q * (2^e * idir) + (origin * idir + nood): the product with
+  // decoded from 8-bit planes — plane = origin + q * 2^e, so t = q * (2^e * idir) + (origin * idir + nood): the scaling by
   // the power of two is exact, the two fmas round once each, well inside the padding of the ray's origin (setup_space) —
   // the hit children ordered by entry distance with a five-comparator network on (distance bits, child), the nearest
   // followed and the others pushed nearest on top. Branch-free like the binary step: the pop is read speculatively, the
-  // three pushes are always written, those of children that were not hit to the spare level `dump`.
+  // three pushes are always written, at fixed places above `top` (see below).
   DEV void wide_loop(const DeviceBvh& bvh, uint32_t* stack, uint32_t min_lanes, TraverseCounters& cnt) {
     const char* base = reinterpret_cast<const char*>(bvh.wide_nodes);
     const float tbest = hit.t;
@@ -423,9 +415,10 @@ struct Traversal {
           cnt.nodes++;
           if (first_active_lane()) cnt.inner_slots += 64;
         }
-        const float ax = __uint_as_float((q0.w & 0xFFu) << 23) * sp.idir.x;
-        const float ay = __uint_as_float(((q0.w >> 8) & 0xFFu) << 23) * sp.idir.y;
-        const float az = __uint_as_float(((q0.w >> 16) & 0xFFu) << 23) * sp.idir.z;
+        // 2^e * idir: the exponents are signed bytes (v_bfe_i32 sign-extends, v_ldexp_f32 scales exactly)
+        const float ax = __builtin_amdgcn_ldexpf(sp.idir.x, (int)(q0.w << 24) >> 24);
+        const float ay = __builtin_amdgcn_ldexpf(sp.idir.y, (int)(q0.w << 16) >> 24);
+        const float az = __builtin_amdgcn_ldexpf(sp.idir.z, (int)(q0.w << 8) >> 24);
         const float ox = __uint_as_float(q0.x), oy = __uint_as_float(q0.y), oz = __uint_as_float(q0.z);
         const float enx = fmaf(ox, sp.idir.x, cnx), efx = fmaf(ox, sp.idir.x, cfx);
         const float eny = fmaf(oy, sp.idir.y, cny), efy = fmaf(oy, sp.idir.y, cfy);
@@ -442,16 +435,15 @@ struct Traversal {
           const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
           const float tf = fminf(fminf(tfx, tfy), tfz);
           const bool h = (tn <= tf) & (tn <= tbest);  // (an unused slot: entry planes behind exit planes, and a copy of the first child's reference should a point-sized node let it through)
-          key[c] = h ? ((__float_as_uint(tn) & 0x7FFFFFFCu) | (uint32_t)c) : 0xFFFFFFFFu;
+          key[c] = h ? ((__float_as_uint(tn) & 0x7FFFFFF8u) | (4u + (uint32_t)c)) : 0u;  // (tn >= tmin >= 0: its bits order like the number; a hit's key is never 0)
         }
-        // ascending: (0,1) (2,3) (0,2) (1,3) (1,2)
-        uint32_t k0 = min(key[0], key[1]), k1 = max(key[0], key[1]), k2 = min(key[2], key[3]), k3 = max(key[2], key[3]);
-        uint32_t t0 = min(k0, k2), t2 = max(k0, k2), t1 = min(k1, k3), t3 = max(k1, k3);
+        // descending — farthest first, misses (0) last: (0,1) (2,3) (0,2) (1,3) (1,2)
+        uint32_t k0 = max(key[0], key[1]), k1 = min(key[0], key[1]), k2 = max(key[2], key[3]), k3 = min(key[2], key[3]);
+        uint32_t t0 = max(k0, k2), t2 = min(k0, k2), t1 = max(k1, k3), t3 = min(k1, k3);
         k0 = t0;
-        k1 = min(t1, t2);
-        k2 = max(t1, t2);
+        k1 = max(t1, t2);
+        k2 = min(t1, t2);
         k3 = t3;
-        const uint32_t hits = (k0 != 0xFFFFFFFFu ? 1u : 0u) + (k1 != 0xFFFFFFFFu ? 1u : 0u) + (k2 != 0xFFFFFFFFu ? 1u : 0u) + (k3 != 0xFFFFFFFFu ? 1u : 0u);
         auto child_ref = [&](uint32_t k) {  // reference number (k & 3): two bit masks and three bit selects, written as the
           // instructions (the compiler makes and / not / or triples of the C form) and as one block (it pads every asm
           // statement with wait states of its own)
@@ -461,29 +453,18 @@ struct Traversal {
               : "v"(k), "v"(q3.x), "v"(q3.y), "v"(q3.z), "v"(q3.w));
           return r;
         };
-        uint32_t r0 = child_ref(k0), r1 = child_ref(k1), r2 = child_ref(k2);
-        const uint32_t r3 = child_ref(k3);
-        uint32_t eh = hits;
-        if (POSTPONE) {
-          // the nearest hit child is a triangle leaf and nothing is postponed yet: it goes into `pend`, and the step goes on as
-          // if the node had been hit in the other children only
-          const bool post = (pend == TRAV_DONE) & is_tri_leaf(r0) & (hits != 0u);
-          pend = post ? r0 : pend;
-          r0 = post ? r1 : r0;
-          r1 = post ? r2 : r1;
-          r2 = post ? r3 : r2;
-          eh = hits - (post ? 1u : 0u);
-        }
-        // the pushes: with h hits the h - 1 farther ones go to top .. top + h - 2, the farthest lowest
-        const uint32_t lim = BOUNDED ? limit : 0xFFFFFFFFu;
-        const uint32_t p1 = eh > 1u ? min(top + (eh - 2u) * STRIDE, lim) : dump;
-        const uint32_t p2 = eh > 2u ? min(top + (eh - 3u) * STRIDE, lim) : dump;
-        const uint32_t p3 = eh > 3u ? min(top, lim) : dump;
-        stack[p3] = r3;
-        stack[p2] = r2;
-        stack[p1] = r1;
-        ref = eh ? r0 : popped;
-        const uint32_t next_top = eh ? top + (eh - 1u) * STRIDE : top - STRIDE;
+        const uint32_t r0 = child_ref(k0), r1 = child_ref(k1), r2 = child_ref(k2), r3 = child_ref(k3);
+        // The pushes need no addresses of their own: the three farthest candidates go to top, top + 1, top + 2 in this order
+        // whatever was hit. With h hits the nearest one is number h - 1 of the order: it is followed, the new top is
+        // top + h - 1, and what lies at or above it — the followed child, the references of missed slots — is never read (the
+        // stack has two spare levels for it; BOUNDED: the canary sits at `limit`, which a step with top >= limit - 2 writes
+        // over, so overflowed() errs on the safe side).
+        stack[top] = r0;
+        stack[top + STRIDE] = r1;
+        stack[top + 2u * STRIDE] = r2;
+        const bool h1 = k0 != 0u, h2 = k1 != 0u, h3 = k2 != 0u, h4 = k3 != 0u;  // at least 1, 2, 3, 4 children hit
+        ref = h4 ? r3 : (h3 ? r2 : (h2 ? r1 : (h1 ? r0 : popped)));
+        const uint32_t next_top = top - STRIDE + ((h1 ? STRIDE : 0u) + (h2 ? STRIDE : 0u) + (h3 ? STRIDE : 0u) + (h4 ? STRIDE : 0u));
         top = BOUNDED ? min(next_top, limit) : next_top;
       }
       if ((uint32_t)__popcll(__ballot(!(ref & BVH_LEAF_BIT))) < min_lanes) break;
@@ -492,10 +473,6 @@ struct Traversal {
 
   // ref has the leaf bit: a sentinel, an instance, or up to 4 triangles
   DEV void leaf_step(const DeviceBvh& bvh, uint32_t* stack, TraverseCounters& cnt) {
-    if (POSTPONE) {
-      leaf_step_postponed(bvh, stack, cnt);
-      return;
-    }
     // (lanes here hold a leaf reference; "triangles" = a leaf that is neither a sentinel nor an instance entry)
     const bool entries_due = ENTRY_BATCH > 1 ? !__any(ref < TRAV_EXIT_INSTANCE && !(ref & BVH_INST_BIT)) : true;
     if (COUNT) {
@@ -655,46 +632,10 @@ struct Traversal {
     top = occluded ? top : top - STRIDE;
   }
 
-  // POSTPONE: a lane without a postponed leaf that holds a triangle leaf takes it into `pend` and its next reference off the stack
-  DEV void absorb(const uint32_t* stack) {
-    const bool take = (pend == TRAV_DONE) & is_tri_leaf(ref);
-    const uint32_t popped = stack[top - STRIDE];  // (the slot below `top` always exists: the DONE sentinel sits at the bottom)
-    pend = take ? ref : pend;
-    ref = take ? popped : ref;
-    top = take ? top - STRIDE : top;
-  }
-
-  // The leaf phase of the POSTPONE walk: every lane that has a postponed leaf (or holds one it could not postpone) tests its
-  // triangles; then the lanes that hold a sentinel or an instance entry handle it (these change the space the ray is in, so
-  // they come after the postponed triangles of the old space), and whoever holds a triangle leaf afterwards takes it along.
-  DEV void leaf_step_postponed(const DeviceBvh& bvh, uint32_t* stack, TraverseCounters& cnt) {
-    absorb(stack);
-    const bool have_tri = pend != TRAV_DONE;
-    const bool entries_due = ENTRY_BATCH > 1 ? !__any(have_tri) : true;
-    if (COUNT) {
-      const unsigned long long tri = __ballot(have_tri), special = __ballot((ref & BVH_LEAF_BIT) && !is_tri_leaf(ref) && ref != TRAV_DONE);
-      if (first_active_lane()) {
-        cnt.st[4] += 64;
-        cnt.st[5] += (uint32_t)__popcll(tri);
-        cnt.st[6] += (uint32_t)__popcll(special);
-      }
-    }
-    if (have_tri) {
-      const uint32_t first = (pend & 0x3FFFFFFFu) >> 2, count = (pend & 3u) + 1u;
-      bool occluded = false;
-      for (uint32_t i = 0; i < count; i++) occluded |= one_triangle(bvh, first + i, cnt);
-      pend = TRAV_DONE;
-      hit.ip = occluded ? 0u : hit.ip;  // hit.ip = 0 says "occluded": the end of the ray
-      ref = occluded ? TRAV_DONE : ref;
-    }
-    if ((ref & BVH_LEAF_BIT) && !is_tri_leaf(ref)) (void)special_step(bvh, stack, cnt, entries_due);
-    absorb(stack);
-  }
-
   // one wave-synchronous round: inner nodes until (almost) every lane holds a leaf, then the leaves
   DEV void round(const DeviceBvh& bvh, uint32_t* stack, uint32_t min_lanes, TraverseCounters& cnt) {
     if (active()) inner_loop(bvh, stack, min_lanes, cnt);
-    if (active() && ((ref & BVH_LEAF_BIT) || (POSTPONE && pend != TRAV_DONE))) leaf_step(bvh, stack, cnt);
+    if (active() && (ref & BVH_LEAF_BIT)) leaf_step(bvh, stack, cnt);
   }
 };
 

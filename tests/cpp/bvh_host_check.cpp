@@ -147,7 +147,7 @@ int main(int argc, char** argv) {
           for (int k = 0; k < (int)w.exp[3]; k++) {
             const uint32_t r = w.ref[k];
             for (int a = 0; a < 3; a++) {
-              if (w.exp[a] == 0 || w.exp[a] == 255) return std::printf("FAIL: plane step is not a normal power of two\n"), 1;
+              if ((int8_t)w.exp[a] < -126) return std::printf("FAIL: plane step is not a normal power of two\n"), 1;
               if (w.q[2 * a][k] > w.q[2 * a + 1][k]) loose++;
             }
             if (r & BVH_LEAF_BIT) wide_leaves.push_back(r);
@@ -186,7 +186,7 @@ int main(int argc, char** argv) {
           for (; it != bin_box.end() && it->first == r && !inside_one; ++it) {
             bool inside = true;
             for (int a = 0; a < 3; a++) {
-              const double step = std::ldexp(1.0, (int)w.exp[a] - 127);
+              const double step = std::ldexp(1.0, (int)(int8_t)w.exp[a]);
               const double lo = (double)w.origin[a] + w.q[2 * a][k] * step, hi = (double)w.origin[a] + w.q[2 * a + 1][k] * step;
               if (lo > (double)it->second[2 * a] || hi < (double)it->second[2 * a + 1]) inside = false;
             }

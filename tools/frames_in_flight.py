@@ -9,7 +9,7 @@ from stratum_amd.bdpt import BDPT
 sc, cam = scenes.atrium()
 W, H = 1920, 1080
 frame = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
-steps = 40
+steps = int(os.environ.get("STEPS", "40"))
 for n in (1, 2, 3):
     rs, bufs = [], []
     for k in range(n):
