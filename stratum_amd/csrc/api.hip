@@ -1228,7 +1228,10 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   HIP_TRY(ctx, ctx->shadow_rays.ensure(3 * shadow_entries * (media ? 2 : 1)));
   if (ctx->bvh.spill) {  // bounded LDS stacks: room for every ray of a trace launch to overflow (4 x float4 each)
     HIP_TRY(ctx, ctx->deep_rays.ensure(4 * (P + shadow_entries)));
-    HIP_TRY(ctx, ctx->deep_count.ensure(1));
+    if (ctx->deep_count.n < 2) {  // [0] rays in the deep queue, [1] k_trace_deep blocks that are through: both zero between launches (k_trace_deep resets them)
+      HIP_TRY(ctx, ctx->deep_count.ensure(2));
+      HIP_TRY(ctx, hipMemsetAsync(ctx->deep_count.p, 0, 8, ctx->stream));
+    }
   }
   if (media) {
     if (2 * shadow_entries > 0xFFFFFFFFull) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: too many shadow rays in flight");
@@ -1407,13 +1410,6 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       p.out_prev_uv = ctx->out_prev_uv.p;
     }
   }
-  // pixels this shard does not own are zero (sum-reduce over shards assembles the frame)
-  HIP_TRY(ctx, hipMemsetAsync(p.out_radiance, 0, radiance_entries * 16, st));
-  if (p.out_albedo) HIP_TRY(ctx, hipMemsetAsync(p.out_albedo, 0, pixels * 16, st));
-  if (p.out_visibility) HIP_TRY(ctx, hipMemsetAsync(p.out_visibility, 0, pixels * 8, st));
-  if (p.out_depth) HIP_TRY(ctx, hipMemsetAsync(p.out_depth, 0, pixels * 16, st));
-  if (p.out_prev_uv) HIP_TRY(ctx, hipMemsetAsync(p.out_prev_uv, 0, pixels * 8, st));
-
   // primary rays = owned pixels that lie inside the image and inside a view (known without asking the GPU)
   uint32_t primary_rays = 0;
   if (pc->gMaxPathVertices >= 2) {
@@ -1438,6 +1434,17 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       }
     }
   }
+  // Pixels this shard does not own and pixels outside every view are zero (a sum-reduce over shards assembles the frame).
+  // When the shard is the whole frame and every pixel lies in a view, every output entry is written by the pass itself —
+  // the first vertex's G-buffer stores (hit or miss) and k_resolve — so the five fills (131 MB at 1080p) are left out.
+  const bool every_entry_written = p.shard_count == 1 && !p.out_packed && !media && pc->gMaxPathVertices >= 2 && (size_t)primary_rays == pixels;
+  if (!every_entry_written) {
+    HIP_TRY(ctx, hipMemsetAsync(p.out_radiance, 0, radiance_entries * 16, st));
+    if (p.out_albedo) HIP_TRY(ctx, hipMemsetAsync(p.out_albedo, 0, pixels * 16, st));
+    if (p.out_visibility) HIP_TRY(ctx, hipMemsetAsync(p.out_visibility, 0, pixels * 8, st));
+    if (p.out_depth) HIP_TRY(ctx, hipMemsetAsync(p.out_depth, 0, pixels * 16, st));
+    if (p.out_prev_uv) HIP_TRY(ctx, hipMemsetAsync(p.out_prev_uv, 0, pixels * 8, st));
+  }
   const uint32_t grid = shade_grid;
   const size_t lds = trace_lds_bytes(ctx);
   uint32_t tgrid = std::min<uint32_t>(trace_grid(ctx, lds), (uint32_t)((P + STHIP_BLOCK - 1) / STHIP_BLOCK));
@@ -1456,6 +1463,11 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     max_bounce_rounds = std::min<uint64_t>(62 - drain_rounds, (uint64_t)max_bounce_rounds * (1 + 2 * ctx->volume_instances));
   }
   p.rounds = max_bounce_rounds + drain_rounds;
+  // The deepest round whose vertices can queue a visibility ray. Without specular materials the vertex shaded in round d is
+  // diffuse vertex d + 1, and the diffuse budget ends a path before NEE (path.hlsli:964-966 precede :978): rounds beyond
+  // gMaxDiffuseVertices - 1 leave their shadow queue empty, and the launch that would trace it is left out.
+  uint32_t max_shadow_round = 0xFFFFFFFFu;
+  if (!ctx->has_specular && !media && !bdpt) max_shadow_round = pc->gMaxDiffuseVertices ? pc->gMaxDiffuseVertices - 1 : 0u;
   const bool timing = ctx->time_kernels;
   float ms_trace = 0, ms_primary = 0, ms_shade = 0, ms_other = 0;
   uint32_t launches_trace = 0, launches_primary = 0;
@@ -1474,7 +1486,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     return STHIP_OK;
   };
 
-  HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_TOTAL * sizeof(unsigned long long), st));
+  bool counters_cleared = false;  // (the first pass's k_clear takes the counters along with its queue control words)
   const bool nee = (sampling_flags & (1u << STHIP_eNEE)) != 0;
   const bool ext = ctx->has_spheres || has_env || bdpt || (sampling_flags & ((1u << STHIP_eNEEReservoirs) | (1u << STHIP_eShadingNormalShadowFix)));
   for (uint32_t s = 0; s < seed_count; s += batch) {
@@ -1485,9 +1497,12 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     int rc = STHIP_OK;
     // queue sizes and heads are per pass; the ray / traversal counters run over the whole call
     auto reset_queues = [&]() -> int {
-      const size_t per_depth = (size_t)QUEUE_SEGMENTS * QCTL_STRIDE * sizeof(unsigned long long);
-      HIP_TRY(ctx, hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 0, 0), 0, (max_bounce_rounds + drain_rounds + 1) * per_depth, st));  // the last round's shade appends to depth + 1; k_resolve sums p.rounds of them
-      HIP_TRY(ctx, hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 1, 0), 0, (max_bounce_rounds + drain_rounds + 1) * per_depth, st));
+      const uint32_t per_depth = QUEUE_SEGMENTS * QCTL_STRIDE;  // 64-bit words
+      const uint32_t words = (max_bounce_rounds + drain_rounds + 1) * per_depth;  // the last round's shade appends to depth + 1; k_resolve sums p.rounds of them
+      hipLaunchKernelGGL(k_clear, dim3(std::max(1u, std::min(64u, (2 * words + CNT_TOTAL + STHIP_BLOCK - 1) / STHIP_BLOCK))), dim3(STHIP_BLOCK), 0, st, queue_ctl_host(ctx->qctl.p, 0, 0), words,
+                         queue_ctl_host(ctx->qctl.p, 1, 0), words, ctx->counters.p, counters_cleared ? 0u : (uint32_t)CNT_TOTAL);
+      counters_cleared = true;
+      HIP_TRY(ctx, hipGetLastError());
       return STHIP_OK;
     };
     auto trace = [&](uint32_t dc, uint32_t ds) -> int {
@@ -1496,7 +1511,6 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       return timed(ms_trace, [&]() {
         const bool alpha = p.bvh.alpha_test || ctx->has_volumes;  // alpha masks under eAlphaTest, volume instances: the instantiation that carries them
         void* kargs[3] = {(void*)&p, (void*)&dc, (void*)&ds};
-        if (p.bvh.spill) (void)hipMemsetAsync(p.deep_count, 0, 4, st);
         (void)hipLaunchKernel(p.bvh.wide_nodes ? trace_kernel_wide(ctx->count_traversal, alpha, p.bvh.spill != nullptr) : trace_kernel(ctx->count_traversal, alpha, p.bvh.spill != nullptr, p.bvh.top_count != 0), dim3(tgrid), dim3(STHIP_BLOCK), kargs, lds, st);
         if (p.bvh.spill) {  // a tree higher than the LDS stack ran the bounded instantiation: now the rays that overflowed
           const uint32_t dgrid = (uint32_t)ctx->cu_count * 8u;  // one spill column per thread (configure_stack)
@@ -1537,7 +1551,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     auto run_rounds = [&](bool light, bool shadow_rays, auto&& shade) -> int {
       for (uint32_t depth = 0; depth <= max_bounce_rounds; depth++) {
         const uint32_t dc = depth < max_bounce_rounds ? depth : TRACE_NONE;
-        const uint32_t ds = depth >= 1 && shadow_rays ? depth - 1 : TRACE_NONE;
+        const uint32_t ds = depth >= 1 && shadow_rays && depth - 1 <= max_shadow_round ? depth - 1 : TRACE_NONE;
         int r;
         if (!light && depth == 0 && dc == 0 && ctx->packet_primary && !ctx->has_volumes) {
           r = trace_primary();

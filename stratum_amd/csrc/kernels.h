@@ -511,6 +511,13 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_deep(FrameParams p) {
       if (cnt[k].tris) atomicAdd(&p.counters[CNT_TRIS + k], (unsigned long long)cnt[k].tris);
     }
   }
+  // The last block to get here leaves the count at zero for the next k_trace launch (no memset between launches): every
+  // block has read the count before it arrives, and nothing else touches it until this kernel has ended.
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(p.deep_count + 1, 1u) == gridDim.x - 1u) {
+    p.deep_count[0] = 0u;
+    p.deep_count[1] = 0u;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2302,6 +2309,18 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
     }
     p.accum[q] = acc;
     if (last_seed && p.out_radiance) p.out_radiance[p.out_packed ? (size_t)q : (size_t)py * p.pc.gOutputExtent[0] + px] = acc;
+  }
+}
+
+// the zero fills a pass starts with, as one launch: up to three ranges of 64-bit words
+__global__ void __launch_bounds__(STHIP_BLOCK) k_clear(unsigned long long* a, uint32_t na, unsigned long long* b, uint32_t nb, unsigned long long* c, uint32_t nc) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nb + nc; i += gridDim.x * blockDim.x) {
+    if (i < na)
+      a[i] = 0ull;
+    else if (i < na + nb)
+      b[i - na] = 0ull;
+    else
+      c[i - na - nb] = 0ull;
   }
 }
 
