@@ -131,6 +131,8 @@ struct sthip_ctx {
   // where a node fetch is slow (bench scene: k_trace -10 %) and is not where the tree sits in L2 (instanced forest: +2 %)
   int use_wide = 2;
   size_t wide_node_count = 0;
+  sthip::DeviceWideScratch* wide_scratch = nullptr;  // buffers of the device-side collapse (wide.hip), kept between calls
+  bool want_wide = false;                            // the current scene is walked in its 4-wide form (decided at upload)
   bool lds_materials = true;  // k_shade stages gMaterialData in LDS when it fits 32 KB
   // frame
   DevBuf<uint8_t> views;  // gViews | gViewTransforms | gPrevViews | gPrevInverseViewTransforms
@@ -298,6 +300,8 @@ void sthip_destroy(sthip_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
+  sthip::device_wide_scratch_destroy(ctx->wide_scratch);
+  ctx->wide_scratch = nullptr;
   ctx->vertices.release();
   ctx->volume_words.release();
   ctx->volumes.release();
@@ -445,6 +449,36 @@ static hipError_t upload_nodes(sthip_ctx* ctx, size_t first, const BvhNode* node
   memset(slots.data(), 0, count * sizeof(BvhNodeSlot));
   for (size_t i = 0; i < count; i++) slots[i].n = packed[i];
   return hipMemcpy(ctx->nodes.p + first, slots.data(), count * sizeof(BvhNodeSlot), hipMemcpyHostToDevice);
+}
+
+// The 4-wide form of the tree that is resident now (ctx->nodes / ctx->entries / ctx->bvh.root_ref), made on the device
+// (wide.hip): after a GPU build and after a transforms-only update. On failure the binary walk stays (STHIP_OK): a tree whose
+// boxes do not fit the wide nodes' grid is still a tree.
+static int collapse_resident_tree(sthip_ctx* ctx) {
+  ctx->bvh.wide_nodes = nullptr;
+  ctx->bvh.wide_entries = nullptr;
+  ctx->bvh.wide_root_ref = BVH_INVALID_REF;
+  ctx->bvh.wide_stack_depth = 0;
+  ctx->wide_node_count = 0;
+  const size_t count = (size_t)ctx->bvh_nodes;
+  if (count == 0 || ctx->bvh.root_ref == BVH_INVALID_REF || (ctx->bvh.root_ref & BVH_LEAF_BIT) || count * sizeof(WideNode) > 0xFFFFFFFFull) return STHIP_OK;
+  if (!ctx->wide_scratch) ctx->wide_scratch = sthip::device_wide_scratch_create();
+  HIP_TRY(ctx, ctx->wide_nodes.ensure(count));
+  HIP_TRY(ctx, ctx->wide_entries.ensure(std::max<size_t>(1, ctx->top.entries.size())));
+  sthip::DeviceWideResult res;
+  std::string err;
+  if (!sthip::collapse_wide_device(ctx->wide_scratch, reinterpret_cast<const BvhNodeSlot*>(ctx->nodes.p), (uint32_t)count, ctx->entries.p, (uint32_t)ctx->top.entries.size(), ctx->bvh.root_ref,
+                                   ctx->bvh.top_is_world_blas != 0, ctx->bvh.stack_depth, ctx->wide_nodes.p, ctx->wide_entries.p, ctx->stream, res, err)) {
+    if (getenv("STHIP_VERBOSE")) fprintf(stderr, "[sthip] no wide tree: %s\n", err.c_str());
+    return STHIP_OK;
+  }
+  ctx->bvh.wide_nodes = reinterpret_cast<const uint4*>(ctx->wide_nodes.p);
+  ctx->bvh.wide_entries = ctx->wide_entries.p;
+  ctx->bvh.wide_root_ref = res.root_ref;
+  ctx->bvh.wide_stack_depth = res.stack_depth;
+  ctx->wide_node_count = res.node_count;
+  ctx->stats.bvh_build_gpu_ms += res.gpu_ms;
+  return STHIP_OK;
 }
 
 int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
@@ -700,7 +734,8 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->bvh.wide_root_ref = BVH_INVALID_REF;
   ctx->bvh.wide_stack_depth = 0;
   ctx->wide_node_count = 0;
-  if ((ctx->use_wide == 1 || (ctx->use_wide == 2 && built.nodes.size() * sizeof(BvhNodePacked) > ((size_t)4 << 20))) && !ctx->use_treetop && built.dev_nodes == 0) {
+  ctx->want_wide = (ctx->use_wide == 1 || (ctx->use_wide == 2 && nodes_total * sizeof(BvhNodePacked) > ((size_t)4 << 20))) && !ctx->use_treetop && !built.embedded;
+  if (ctx->want_wide && built.dev_nodes == 0) {  // a host-built tree: collapsed on the host from its exact boxes (a device build: below, from the nodes in HBM)
     sthip::build_wide_bvh(built);
     if (!built.wide_nodes.empty() && built.wide_nodes.size() * sizeof(WideNode) <= 0xFFFFFFFFull) {
       HIP_TRY(ctx, ctx->wide_nodes.ensure(built.wide_nodes.size()));
@@ -779,6 +814,10 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->bvh_nodes = nodes_total;
   ctx->bvh_tris = tris_total;
   ctx->top = std::move(built.top);
+  if (ctx->want_wide && built.dev_nodes != 0) {  // the GPU builder's tree: its wide form is made where the nodes are
+    const int rc = collapse_resident_tree(ctx);
+    if (rc != STHIP_OK) return rc;
+  }
   // the host's copy of the unpacked nodes, with room for a rebuilt top level
   // (only the treetop selection reads it: without the treetop a device-resident build copies no node to the host at all)
   ctx->nodes_host.n = 0;
@@ -977,8 +1016,14 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
     ctx->nodes_host.n = std::max(ctx->nodes_host.n, (size_t)next.blas_nodes + tlas.size());
   }
   ctx->top = std::move(next);
-  ctx->bvh.wide_nodes = nullptr;  // the wide form was made from the old top level: back to the binary walk until the next upload
+  // the wide form was made from the old top level: made again from the nodes in HBM (the bottom levels come out as before,
+  // the top level new), so a moved scene keeps the walk it was uploaded with
+  ctx->bvh.wide_nodes = nullptr;
   ctx->bvh.wide_entries = nullptr;
+  if (ctx->want_wide) {
+    const int rc = collapse_resident_tree(ctx);
+    if (rc != STHIP_OK) return rc;
+  }
   return configure_stack(ctx);
 }
 

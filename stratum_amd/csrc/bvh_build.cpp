@@ -974,56 +974,12 @@ struct WideBuilder {
     }
     height_of[w] = 1 + below;
     WideNode wn;
-    memset(&wn, 0, sizeof(wn));
-    Box all;
-    all.reset();
-    for (int k = 0; k < n; k++) all.grow(ch[k].box);
-    for (int a = 0; a < 3; a++) {
-      wn.origin[a] = all.lo[a];
-      const double ext = (double)all.hi[a] - (double)all.lo[a];
-      int e = 1;  // biased; the step is 2^(e - 127)
-      if (ext > 0) {
-        int x;
-        frexp(ext / 255.0, &x);  // ext / 255 = m * 2^x, m in [0.5, 1): 2^x >= ext / 255
-        e = std::min(254, std::max(1, x + 127));
-      }
-      for (;;) {
-        const double step = ldexp(1.0, e - 127);
-        bool fits = true;
-        for (int k = 0; k < n && fits; k++) {
-          double lo = floor(((double)ch[k].box.lo[a] - (double)wn.origin[a]) / step), hi = ceil(((double)ch[k].box.hi[a] - (double)wn.origin[a]) / step);
-          while (lo > 0 && (double)wn.origin[a] + lo * step > (double)ch[k].box.lo[a]) lo -= 1;
-          while ((double)wn.origin[a] + hi * step < (double)ch[k].box.hi[a]) hi += 1;
-          if (lo < 0) lo = 0;
-          if (hi > 255 || !(hi >= 0)) {
-            fits = false;
-            break;
-          }
-          wn.q[2 * a][k] = (uint8_t)lo;
-          wn.q[2 * a + 1][k] = (uint8_t)hi;
-        }
-        if (fits) break;
-        if (e >= 254) {  // no power of two spans it (or a plane is not finite): the tree is not usable, the binary walk keeps its clamped planes
-          ok = false;
-          break;
-        }
-        e++;
-      }
-      if (!std::isfinite(wn.origin[a])) ok = false;
-      wn.exp[a] = (uint8_t)(int8_t)(e - 127);  // signed: the kernel sign-extends the byte and scales with v_ldexp_f32
+    WideChildBox boxes[4];
+    for (int k = 0; k < n; k++) {
+      memcpy(boxes[k].lo, ch[k].box.lo, 12);
+      memcpy(boxes[k].hi, ch[k].box.hi, 12);
     }
-    wn.exp[3] = (uint8_t)n;
-    for (int k = 0; k < 4; k++) {
-      if (k < n) {
-        wn.ref[k] = refs[k];
-      } else {
-        wn.ref[k] = refs[0];  // never followed unless the node is point-sized (the walk has no test for unused slots); then the first child twice, which changes no hit
-        for (int a = 0; a < 3; a++) {
-          wn.q[2 * a][k] = 255;
-          wn.q[2 * a + 1][k] = 0;
-        }
-      }
-    }
+    if (!make_wide_node(boxes, refs, n, wn)) ok = false;  // (non-finite planes: no wide tree, the binary walk keeps its clamped ones)
     out[w] = wn;
     return w;
   }

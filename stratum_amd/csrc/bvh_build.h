@@ -1,5 +1,6 @@
 // bvh_build.h — host-side acceleration-structure build (see bvh.h for the layout)
 #pragma once
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -186,6 +187,90 @@ inline void pack_nodes(const BvhNode* in, size_t count, std::vector<BvhNodePacke
   out.resize(count);
   for (size_t i = 0; i < count; i++) out[i] = pack_node(in[i]);
 }
+
+// ---- the 4-wide node (bvh.h: WideNode), made the same way on the host (build_wide_bvh) and on the device (wide.hip) ----
+struct WideChildBox {
+  float lo[3], hi[3];
+};
+// Quantises the boxes of n <= 4 children onto the node's 8-bit grid — origin = the lower corner of their union, a power-of-two
+// step per axis, lower planes rounded down and upper planes up, checked in double — and fills in the references (an unused
+// slot: entry planes behind exit planes and the first child's reference). false: the boxes do not fit any grid (a plane that
+// is not finite): the node must not be used.
+STHIP_BVH_HD inline bool make_wide_node(const WideChildBox* ch, const uint32_t* refs, int n, WideNode& wn) {
+  bool ok = true;
+  memset(&wn, 0, sizeof(wn));
+  for (int a = 0; a < 3; a++) {
+    float lo = ch[0].lo[a], hi = ch[0].hi[a];
+    for (int k = 1; k < n; k++) {
+      lo = ch[k].lo[a] < lo ? ch[k].lo[a] : lo;
+      hi = ch[k].hi[a] > hi ? ch[k].hi[a] : hi;
+    }
+    wn.origin[a] = lo;
+    const double ext = (double)hi - (double)lo;
+    int e = 1;  // biased; the step is 2^(e - 127)
+    if (ext > 0) {
+      int x;
+      (void)frexp(ext / 255.0, &x);  // ext / 255 = m * 2^x, m in [0.5, 1): 2^x >= ext / 255
+      e = x + 127 < 1 ? 1 : (x + 127 > 254 ? 254 : x + 127);
+    }
+    for (;;) {
+      const double step = ldexp(1.0, e - 127);
+      bool fits = true;
+      for (int k = 0; k < n && fits; k++) {
+        double ql = floor(((double)ch[k].lo[a] - (double)lo) / step), qh = ceil(((double)ch[k].hi[a] - (double)lo) / step);
+        while (ql > 0 && (double)lo + ql * step > (double)ch[k].lo[a]) ql -= 1;
+        while ((double)lo + qh * step < (double)ch[k].hi[a]) qh += 1;
+        if (ql < 0) ql = 0;
+        if (qh > 255 || !(qh >= 0)) {
+          fits = false;
+          break;
+        }
+        wn.q[2 * a][k] = (uint8_t)ql;
+        wn.q[2 * a + 1][k] = (uint8_t)qh;
+      }
+      if (fits) break;
+      if (e >= 254) {  // no power of two spans it (or a plane is not finite)
+        ok = false;
+        break;
+      }
+      e++;
+    }
+    if (!(lo > -3.4e38f && lo < 3.4e38f)) ok = false;
+    wn.exp[a] = (uint8_t)(int8_t)(e - 127);  // signed: the kernel sign-extends the byte and scales with v_ldexp_f32
+  }
+  wn.exp[3] = (uint8_t)n;
+  for (int k = 0; k < 4; k++) {
+    if (k < n) {
+      wn.ref[k] = refs[k];
+    } else {
+      wn.ref[k] = refs[0];  // never followed unless the node is point-sized (the walk has no test for unused slots); then the first child twice, which changes no hit
+      for (int a = 0; a < 3; a++) {
+        wn.q[2 * a][k] = 255;
+        wn.q[2 * a + 1][k] = 0;
+      }
+    }
+  }
+  return ok;
+}
+
+// The 4-wide form made ON THE DEVICE from the packed binary nodes as they lie in HBM (wide.hip): for trees the GPU builder
+// made (no node of theirs ever visits the host) and after a transforms-only update (new top level). Same collapse rule as
+// build_wide_bvh (the inner child with the largest box is opened until there are four), the planes the packed nodes hold
+// (rounded outward by pack_plane: still conservative). Deterministic: a wide node is first written at the index of the binary
+// node it stands for, then the used slots are compacted in index order.
+struct DeviceWideResult {
+  uint32_t node_count = 0;
+  uint32_t root_ref = BVH_INVALID_REF;
+  uint32_t stack_depth = 0;
+  float gpu_ms = 0;
+};
+struct DeviceWideScratch;  // (wide.hip: the buffers a collapse needs, kept between calls)
+DeviceWideScratch* device_wide_scratch_create();
+void device_wide_scratch_destroy(DeviceWideScratch*);
+// nodes: node_count packed nodes (device); entries: entry_count entries (device); wide_nodes / wide_entries: device outputs
+// (wide_nodes must hold node_count entries, wide_entries entry_count). max_levels: a bound of the binary tree's height.
+bool collapse_wide_device(DeviceWideScratch* scratch, const BvhNodeSlot* nodes, uint32_t node_count, const TlasEntry* entries, uint32_t entry_count, uint32_t root_ref, bool top_is_world_blas,
+                          uint32_t max_levels, WideNode* wide_nodes, TlasEntry* wide_entries, void* stream, DeviceWideResult& result, std::string& err);
 
 // GPU LBVH of one mesh (lbvh.hip): appends nodes and leaf-ordered triangles to the outputs.
 bool lbvh_build_gpu(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhTri>& tris_out, uint32_t& root_ref, uint32_t& stack_need, float& gpu_ms,

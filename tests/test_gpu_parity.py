@@ -614,6 +614,69 @@ def test_wide_walk_gives_the_frames_of_the_binary_walk(atrium_scene, levels):
         assert np.array_equal(a["ray_count"], b["ray_count"]), sc.name
 
 
+@pytest.mark.parametrize("levels", [None, 7])
+def test_wide_walk_over_gpu_built_trees_and_moved_instances(atrium_scene, levels):
+    """The wide form is also made on the device (wide.hip), from the packed nodes as they lie in HBM: for the trees of the GPU
+    builder (bvh_builder = 1: PLOC with and without the SAH top, the radix tree) and again after a transforms-only update
+    (the top level is new; host- and GPU-built bottom levels). Frames, visibility and ray counts must be those of the
+    binary walk over the same tree, and a moved scene must give what a fresh upload of it gives; stats say which nodes
+    k_trace walked (64-byte ones)."""
+    from stratum_amd.bdpt import BDPT
+    from stratum_amd.scene import rotate_y, translate
+
+    def same(a, b, what):
+        assert np.array_equal(a["radiance"].view(np.uint32), b["radiance"].view(np.uint32)), what
+        assert np.array_equal(a["visibility"]["instance_primitive_index"], b["visibility"]["instance_primitive_index"]), what
+        assert np.array_equal(a["ray_count"], b["ray_count"]), what
+
+    cases = [
+        (atrium_scene, [], {"maxDiffuseVertices": 3}),
+        (scenes.forest(n_instances=30, tree_tris=700, tree_kinds=2), [], {}),
+        (scenes.spheres_room(), [], {"maxDiffuseVertices": 3}),
+        (scenes.foliage(), ["alphatest"], {}),
+    ]
+    for (sc, cam), flags, args in cases:
+        frame = camera.Frame(160, 96, cam["fovy"], cam["eye"], cam["target"])
+        for builder, algorithm, sah_top in ((1, 1, 64), (1, 1, 0), (1, 0, 0), (0, 1, 64)):
+            if builder == 1 and flags:  # (alpha masks need the SAH builder)
+                continue
+            out = {}
+            for wide in (0, 1):
+                r = BDPT(device=0, args=dict(args, bdptFlag=flags))
+                try:
+                    r.set_option("bvh_builder", builder)
+                    r.set_option("lbvh_algorithm", algorithm)
+                    r.set_option("sah_top", sah_top)
+                    r.set_option("wide_bvh", wide)
+                    if levels is not None:
+                        r.set_option("lds_stack_levels", levels)
+                    r.update(sc)
+                    out[wide] = [r.render(frame, 1, 2)]
+                    assert r.stats()["bvh_node_bytes"] == (64 if wide else 48), (sc.name, builder, wide)
+                    # move every instance that is not part of the merged identity mesh, render, move back
+                    ident = np.array([np.array_equal(m, np.eye(4, dtype=np.float32)[:3]) for m in sc.transforms["m"]])
+                    kinds = sc.instances["packed"][:, 0] & 0xF
+                    movable = [int(i) for i in np.nonzero(~ident)[0][:10] if kinds[i] == wire.INSTANCE_TYPE_TRIANGLES]
+                    if movable:
+                        old = {i: np.vstack([sc.transforms["m"][i], [0, 0, 0, 1]]).astype(np.float64) for i in movable}
+                        for k, i in enumerate(movable):
+                            sc.set_instance_transform(i, translate((0.11 * ((k % 3) - 1), 0.0, -0.07 * (k % 2))) @ old[i] @ rotate_y(0.2 * k))
+                        r.update_transforms(sc)
+                        out[wide].append(r.render(frame, 1, 2))
+                        assert r.stats()["bvh_node_bytes"] == (64 if wide else 48), (sc.name, builder, wide, "after the update")
+                        r.update(sc)
+                        out[wide].append(r.render(frame, 1, 2))
+                        for i in movable:
+                            sc.set_instance_transform(i, old[i])
+                finally:
+                    r.close()
+            for k, (a, b) in enumerate(zip(out[0], out[1])):
+                same(a, b, (sc.name, flags, builder, algorithm, sah_top, k))
+            if len(out[1]) == 3:
+                same(out[1][1], out[1][2], (sc.name, "moved scene against its fresh upload", builder))
+                assert not np.array_equal(out[1][0]["radiance"], out[1][1]["radiance"]), sc.name
+
+
 def test_embedded_leaves_give_the_same_frames(atrium_scene):
     """embed_leaves = 1: the host builder puts a leaf's triangles into the node array, in the units right behind the node that
     refers to them (one array, leaf references count its units). A layout experiment (no faster: DESIGN.md 4) kept as an
