@@ -126,10 +126,11 @@ struct sthip_ctx {
   // host builds: leaf triangles in the node array behind their parent (bvh_build.h: BuiltBvh::embedded). Measured on the
   // bench scene: k_trace 2.30 ms either way (the leaf fetch is not what a step waits for), so off: two arrays are simpler
   bool embed_leaves = false;
-  // "wide_bvh": k_trace walks the 4-wide form of a host-built tree (takes effect at the next sthip_scene_upload). 0 = never,
-  // 1 = always, 2 (default) = when the binary nodes do not fit one XCD's L2 (4 MiB): the wide step is worth its arithmetic
-  // where a node fetch is slow (bench scene: k_trace -10 %) and is not where the tree sits in L2 (instanced forest: +2 %)
-  int use_wide = 2;
+  // "wide_bvh": k_trace walks the 4-wide form of the tree (takes effect at the next sthip_scene_upload). 1 (default) = always:
+  // host-built trees are collapsed on the host, GPU-built ones and the trees of a transforms-only update on the device
+  // (wide.hip). 0 = never (the binary walk every other kernel uses), 2 = only when the binary nodes do not fit one XCD's L2
+  // (4 MiB). Bench scene: k_trace -20 % against the binary walk; instanced forest (a 2.6 MB tree): equal.
+  int use_wide = 1;
   size_t wide_node_count = 0;
   sthip::DeviceWideScratch* wide_scratch = nullptr;  // buffers of the device-side collapse (wide.hip), kept between calls
   bool want_wide = false;                            // the current scene is walked in its 4-wide form (decided at upload)

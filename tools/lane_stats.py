@@ -6,9 +6,13 @@ sys.path.insert(0, ".")
 from stratum_amd import camera, scenes  # noqa: E402
 from stratum_amd.bdpt import BDPT  # noqa: E402
 
-sc, cam = scenes.atrium()
+name = sys.argv[1] if len(sys.argv) > 1 else "atrium"
+sc, cam = scenes.SCENES[name]()
 frame = camera.Frame(1920, 1080, cam["fovy"], cam["eye"], cam["target"])
 r = BDPT(0)
+for a in sys.argv[2:]:
+    k, v = a.split("=")
+    r.set_option(k, int(v))
 r.update(sc)
 r.set_option("count_traversal", 1)
 for label, max_vertices in (("primary rays only", 2), ("default (3 closest + 2 shadow rounds)", 8)):
