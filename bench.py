@@ -99,6 +99,9 @@ def parse_args():
     ap.add_argument("--radiance-only", action="store_true", help="do not write the G-buffer AOVs (not the headline configuration)")
     ap.add_argument("--bdpt-flag", action="append", default=[], help="as the reference's --bdptFlag (e.g. connecttolightpaths, ~nee); not the headline configuration")
     ap.add_argument("--max-diffuse-vertices", type=int, default=None)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): a step renders N seeds of the frame on N GPUs (per-GPU work fixed); strong: a step renders --strong-seeds seeds whatever N (total work fixed)")
+    ap.add_argument("--strong-seeds", type=int, default=8, help="seeds per step in --scaling strong (BASELINE.md row 3b's 8 by default)")
     return ap.parse_args()
 
 
@@ -210,7 +213,9 @@ def main():
         }
     aov_ptrs = {k: v.data_ptr() for k, v in aov.items()}
     dev_out = dict(aov_ptrs, radiance=radiance.data_ptr())
-    seeds_per_step = world  # weak scaling: every rank renders one frame's worth of paths per step
+    # weak scaling (the default, what the driver's 1 -> 8 curve is): every rank renders one frame's worth of paths per step.
+    # strong: the same --strong-seeds seeds per step at every N, each rank its tiles of them.
+    seeds_per_step = world if args.scaling == "weak" else max(1, args.strong_seeds)
 
     if world == 1:
 
@@ -288,8 +293,25 @@ def main():
     for i in range(args.steps):
         r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
         rays_local += r.stats()["rays_total"]
+    # the exchange alone (untimed region): the gather of one step's packed tiles and their assembly, between syncs, so that
+    # a scaling record can be split into render time and exchange time
+    exchange_ms = 0.0
+    if dist is not None:
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            k = i & 1
+            if host_staged:
+                g_cpu = torch.zeros((world, stride, 4)) if rank == 0 else None
+                shard.gather_tiles(packed[k].cpu(), g_cpu, dist, dst=0)
+                pending[k] = (None, g_cpu)
+            else:
+                pending[k] = (shard.gather_tiles(packed[k], gathered[k], dist, dst=0, async_op=True), None)
+            finish(k)
+        barrier()
+        exchange_ms = (time.perf_counter() - t0) / args.steps * 1e3
     t = torch.tensor(rep_dt + [float(rays_local)], dtype=torch.float64, device="cuda")
-    devices = [{"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank)}]
+    devices = [{"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank), "median_ms_per_step": round(float(np.median(rep_dt)) / args.steps * 1e3, 3), "rays_per_step": int(rays_local / args.steps)}]
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)  # per repetition: the slowest rank
@@ -515,7 +537,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt_all / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -525,6 +547,8 @@ def main():
                 "rays_per_step": int(rays_all / args.steps),
                 "parallelism": "tile-shard x%d" % world if world > 1 else "single GPU",
                 "exchange": exchange,
+                "exchange_alone_ms_per_step": round(exchange_ms, 4) if world > 1 else None,  # gather + assembly of one step's tiles, not overlapped (in the timed region it runs behind the next step's render)
+                "seeds_per_step": seeds_per_step,
                 "world_size": world_seen,
                 "backend": backend_seen,
                 "devices": devices,

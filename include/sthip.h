@@ -189,6 +189,15 @@ uint32_t sthip_shard_slot_count(uint32_t width, uint32_t height, uint32_t shard_
                                 uint32_t tile_h);
 int sthip_assemble_tiles(sthip_ctx* ctx, const float* packed, uint64_t rank_stride, uint32_t shard_count, uint32_t tile_w,
                          uint32_t tile_h, uint32_t width, uint32_t height, float* frame);
+/* The same for the other outputs of a sharded frame (the G-buffer: albedo 16 B, VisibilityInfo 8 B, DepthInfo 16 B, prev-uv
+ * 8 B per pixel), which sthip_render writes as W x H images that are zero outside the shard's tiles:
+ * sthip_pack_tiles gathers the context's own tiles (its sthip_set_shard) out of such an image into slot order —
+ * sthip_shard_slot_count() entries of entry_bytes each, the padding slots of edge tiles zero — and
+ * sthip_assemble_tiles_bytes scatters the gathered buffers of all ranks (rank r at packed + r * rank_stride entries) into the
+ * image. entry_bytes: a multiple of 4, at most 64. Device pointers; enqueued on the context's stream. */
+int sthip_pack_tiles(sthip_ctx* ctx, const void* image, uint32_t width, uint32_t height, uint32_t entry_bytes, void* packed);
+int sthip_assemble_tiles_bytes(sthip_ctx* ctx, const void* packed, uint64_t rank_stride, uint32_t shard_count, uint32_t tile_w,
+                               uint32_t tile_h, uint32_t width, uint32_t height, uint32_t entry_bytes, void* frame);
 
 /* ---- the traversal contract on its own (T1/T2 of SURVEY.md §8a; intersection.hlsli:65-239) ---- */
 typedef struct sthip_ray {

@@ -30,6 +30,8 @@ EXPORTS = [
     "sthip_set_option",
     "sthip_shard_slot_count",
     "sthip_assemble_tiles",
+    "sthip_assemble_tiles_bytes",
+    "sthip_pack_tiles",
     "sthip_accumulate",
     "sthip_tonemap",
     "sthip_image_compare",
@@ -112,6 +114,10 @@ def lib():
     L.sthip_shard_slot_count.argtypes = [C.c_uint32] * 6
     L.sthip_assemble_tiles.restype = C.c_int
     L.sthip_assemble_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.sthip_assemble_tiles_bytes.restype = C.c_int
+    L.sthip_assemble_tiles_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.sthip_pack_tiles.restype = C.c_int
+    L.sthip_pack_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     L.sthip_accumulate.restype = C.c_int
     L.sthip_accumulate.argtypes = [C.c_void_p, C.POINTER(wire.AccumulateDesc)]
     L.sthip_tonemap.restype = C.c_int

@@ -226,6 +226,16 @@ class BDPT:
         _, n, tw, th = getattr(self, "_shard", (0, 1, 64, 32))
         self._check(self._lib.sthip_assemble_tiles(self._h, packed_ptr, rank_stride, n, tw, th, frame.width, frame.height, frame_ptr), "sthip_assemble_tiles")
 
+    def pack_tiles(self, frame, image_ptr, entry_bytes, packed_ptr):
+        """This shard's tiles of a W x H image of entry_bytes per pixel (a G-buffer output of render) in slot order: what the
+        ranks exchange (device pointers; include/sthip.h: sthip_pack_tiles)."""
+        self._check(self._lib.sthip_pack_tiles(self._h, image_ptr, frame.width, frame.height, entry_bytes, packed_ptr), "sthip_pack_tiles")
+
+    def assemble_tiles_bytes(self, frame, packed_ptr, rank_stride, frame_ptr, entry_bytes):
+        """assemble_tiles for entries of entry_bytes (albedo / depth 16, visibility / prev-uv 8)."""
+        n, tw, th = self._shard[1], self._shard[2], self._shard[3]
+        self._check(self._lib.sthip_assemble_tiles_bytes(self._h, packed_ptr, rank_stride, n, tw, th, frame.width, frame.height, entry_bytes, frame_ptr), "sthip_assemble_tiles_bytes")
+
     def prev_result(self):  # BDPT.hpp:18
         return self._prev_result
 

@@ -1810,17 +1810,34 @@ uint32_t sthip_shard_slot_count(uint32_t width, uint32_t height, uint32_t shard_
   return owned * tile_w * tile_h;
 }
 
-int sthip_assemble_tiles(sthip_ctx* ctx, const float* packed, uint64_t rank_stride, uint32_t shard_count, uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height,
-                         float* frame) {
+int sthip_assemble_tiles_bytes(sthip_ctx* ctx, const void* packed, uint64_t rank_stride, uint32_t shard_count, uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height,
+                               uint32_t entry_bytes, void* frame) {
   if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
   if (!packed || !frame || !shard_count || !width || !height) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_assemble_tiles: a required argument is NULL/zero");
   if (tile_w == 0 || tile_h == 0 || (tile_w & 7) || (tile_h & 7)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_assemble_tiles: tile size must be a multiple of 8");
+  if (entry_bytes == 0 || entry_bytes > 64 || (entry_bytes & 3)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_assemble_tiles: entry size must be a multiple of 4 bytes, at most 64");
   const uint32_t slots = sthip_shard_slot_count(width, height, 0, shard_count, tile_w, tile_h);  // rank 0 owns the most tiles
   if (rank_stride < slots) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_assemble_tiles: rank_stride is smaller than a shard's slot count");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t n = (size_t)shard_count * slots;
-  hipLaunchKernelGGL(k_assemble_tiles, dim3((unsigned)((n + STHIP_BLOCK - 1) / STHIP_BLOCK)), dim3(STHIP_BLOCK), 0, ctx->stream, reinterpret_cast<const float4*>(packed), (size_t)rank_stride, shard_count,
-                     slots, tile_w, tile_h, width, height, reinterpret_cast<float4*>(frame));
+  hipLaunchKernelGGL(k_assemble_tiles, dim3((unsigned)((n + STHIP_BLOCK - 1) / STHIP_BLOCK)), dim3(STHIP_BLOCK), 0, ctx->stream, reinterpret_cast<const uint32_t*>(packed), (size_t)rank_stride, shard_count,
+                     slots, tile_w, tile_h, width, height, entry_bytes / 4, reinterpret_cast<uint32_t*>(frame));
+  HIP_TRY(ctx, hipGetLastError());
+  return STHIP_OK;
+}
+int sthip_assemble_tiles(sthip_ctx* ctx, const float* packed, uint64_t rank_stride, uint32_t shard_count, uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height,
+                         float* frame) {
+  return sthip_assemble_tiles_bytes(ctx, packed, rank_stride, shard_count, tile_w, tile_h, width, height, 16, frame);
+}
+int sthip_pack_tiles(sthip_ctx* ctx, const void* image, uint32_t width, uint32_t height, uint32_t entry_bytes, void* packed) {
+  if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
+  if (!image || !packed || !width || !height) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_pack_tiles: a required argument is NULL/zero");
+  if (entry_bytes == 0 || entry_bytes > 64 || (entry_bytes & 3)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_pack_tiles: entry size must be a multiple of 4 bytes, at most 64");
+  const uint32_t slots = sthip_shard_slot_count(width, height, ctx->shard_rank, ctx->shard_count, ctx->tile_w, ctx->tile_h);
+  if (slots == 0) return STHIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)((slots + STHIP_BLOCK - 1) / STHIP_BLOCK)), dim3(STHIP_BLOCK), 0, ctx->stream, reinterpret_cast<const uint32_t*>(image), ctx->shard_rank, ctx->shard_count,
+                     slots, ctx->tile_w, ctx->tile_h, width, height, entry_bytes / 4, reinterpret_cast<uint32_t*>(packed));
   HIP_TRY(ctx, hipGetLastError());
   return STHIP_OK;
 }

@@ -2424,13 +2424,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_batch(DeviceBvh bvh, cons
 }
 
 
-// Assembles the frame from the packed tiles of every shard (sthip_assemble_tiles): entry (rank, slot) of `packed`
-// is the pixel slot_to_pixel() gives for that shard; one thread per packed entry, disjoint pixels.
-__global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const float4* packed, size_t rank_stride, uint32_t shard_count, uint32_t slots, uint32_t tile_w, uint32_t tile_h, uint32_t width,
-                                                                 uint32_t height, float4* frame) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)shard_count * slots) return;
-  const uint32_t rank = (uint32_t)(i / slots), slot = (uint32_t)(i % slots);
+// Assembles the frame from the packed tiles of every shard (sthip_assemble_tiles, sthip_assemble_tiles_bytes): entry
+// (rank, slot) of `packed` is the pixel slot_to_pixel() gives for that shard; one thread per packed entry, disjoint pixels.
+// An entry is `words` 32-bit words (4: RGBA32F radiance / albedo / DepthInfo, 2: VisibilityInfo / prev-uv).
+DEV bool shard_slot_pixel(uint32_t rank, uint32_t slot, uint32_t shard_count, uint32_t slots, uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height, uint32_t& px, uint32_t& py) {
   FrameParams p;  // only the fields slot_to_pixel reads
   p.paths_per_seed = slots;
   p.tile_w = tile_w;
@@ -2441,7 +2438,28 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const float4* pa
   p.tiles_y = (height + tile_h - 1) / tile_h;
   p.pc.gOutputExtent[0] = width;
   p.pc.gOutputExtent[1] = height;
+  return slot_to_pixel(p, slot, px, py);
+}
+__global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const uint32_t* packed, size_t rank_stride, uint32_t shard_count, uint32_t slots, uint32_t tile_w, uint32_t tile_h, uint32_t width,
+                                                                 uint32_t height, uint32_t words, uint32_t* frame) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)shard_count * slots) return;
+  const uint32_t rank = (uint32_t)(i / slots), slot = (uint32_t)(i % slots);
   uint32_t px, py;
-  if (!slot_to_pixel(p, slot, px, py)) return;
-  frame[(size_t)py * width + px] = packed[(size_t)rank * rank_stride + slot];
+  if (!shard_slot_pixel(rank, slot, shard_count, slots, tile_w, tile_h, width, height, px, py)) return;
+  const uint32_t* src = packed + ((size_t)rank * rank_stride + slot) * words;
+  uint32_t* dst = frame + ((size_t)py * width + px) * words;
+  for (uint32_t k = 0; k < words; k++) dst[k] = src[k];
+}
+// The other direction (sthip_pack_tiles): a W x H image on one rank -> that rank's tiles in slot order (slots outside the
+// image: zero). What the ranks exchange of the G-buffer outputs, which sthip_render writes as images.
+__global__ void __launch_bounds__(STHIP_BLOCK) k_pack_tiles(const uint32_t* image, uint32_t rank, uint32_t shard_count, uint32_t slots, uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height,
+                                                             uint32_t words, uint32_t* packed) {
+  const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= slots) return;
+  uint32_t px, py;
+  const bool inside = shard_slot_pixel(rank, (uint32_t)slot, shard_count, slots, tile_w, tile_h, width, height, px, py);
+  uint32_t* dst = packed + slot * words;
+  const uint32_t* src = image + ((size_t)py * width + px) * words;
+  for (uint32_t k = 0; k < words; k++) dst[k] = inside ? src[k] : 0u;
 }

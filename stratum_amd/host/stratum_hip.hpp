@@ -1034,12 +1034,17 @@ class BDPT {
  protected:
   uint32_t frame_number() const { return mFrameNumber; }
   uint32_t sampling_flags() const { return mSamplingFlags; }
+  // the bookkeeping of a frame that has been handed to the device(s): the next frame's seed and its "previous views"
+  // (BDPT.cpp:480,563). finish_frame does it itself unless told that the frame was noted when it was submitted (frames in flight).
+  void note_submitted(const FrameSetup& fs, uint32_t seed_count) {
+    mFrameNumber += seed_count;
+    mPrevViews = fs.v;
+    mPrevInverseViewTransforms = fs.ti;
+  }
   // what follows the path in BDPT::render: the tone map block and the frame bookkeeping
-  void finish_frame(Frame fr, const FrameSetup& fs, uint32_t seed_count) {
+  void finish_frame(Frame fr, const FrameSetup& fs, uint32_t seed_count, bool noted_at_submit = false) {
     const uint32_t width = fr.width, height = fr.height;
     const size_t n = (size_t)width * height;
-    const std::vector<ViewData>& v = fs.v;
-    const std::vector<TransformData>& ti = fs.ti;
     if (fr.mAlbedo.size() != 4 * n) fr.mAlbedo.assign(4 * n, 0.f);
     // tone map (BDPT.cpp:783-815); without a denoiser gModulateAlbedo stays off (:779-780 only run when one exists)
     fr.mTonemapResult.assign(4 * n, 0.f);
@@ -1057,9 +1062,7 @@ class BDPT {
     tm.gOutput = fr.mTonemapResult.data();
     tm.out_max = fr.mTonemapMax;
     if (sthip_tonemap(mCtx, &tm) != STHIP_OK) throw std::runtime_error(std::string("sthip_tonemap: ") + sthip_last_error(mCtx));
-    mFrameNumber += seed_count;
-    mPrevViews = v;
-    mPrevInverseViewTransforms = ti;
+    if (!noted_at_submit) note_submitted(fs, seed_count);
     mPrevFrame = std::move(fr);
   }
 

@@ -1,6 +1,7 @@
-// stratum_hip_multi.hpp — the multi-GPU driver of the C++ host side: one process, one sthip context per GPU, one host
-// thread per context, the frame cut into pixel tiles (sthip_set_shard), and ONE exchange per render call: an RCCL gather
-// of the ranks' packed tiles to the first device over xGMI, scattered into the image there (sthip_assemble_tiles).
+// stratum_hip_multi.hpp — the multi-GPU driver of the C++ host side: one process, one sthip context per GPU, one
+// persistent host thread per context, the frame cut into pixel tiles (sthip_set_shard), and ONE exchange per render call:
+// an RCCL gather of the ranks' packed tiles to the first device over xGMI, scattered into the images there
+// (sthip_assemble_tiles*).
 //
 // The reference has nothing to compare with: it creates one vk::Device with one queue per family and renders on it
 // (src/Core/Device.cpp:125-131). This is the component BASELINE.json's north star adds ("frames shard by pixel-tile
@@ -9,13 +10,24 @@
 // (x, y, seed, counter) (rng.hlsli:35-47) and a pixel owns its outputs, so the ranks only meet to assemble the frame.
 //
 // stm::MultiDeviceBDPT is a stm::BDPT (same component, same update()/render() the Application drives, BDPT.hpp:23-24):
-// its base context renders rank 0, the extra contexts the other ranks. Needs <rccl/rccl.h> and the HIP runtime
-// (link -lrccl -lamdhip64); stratum_hip.hpp itself stays free of both.
+// its base context renders rank 0, the extra contexts the other ranks. A frame is made in two phases:
+//   1. every rank renders its tiles on its own stream (worker threads, in parallel). If ANY rank fails, the call throws here:
+//      not a single collective has been issued, so nothing is left waiting for a peer that will never come;
+//   2. every rank posts its part of the exchange — ncclSend of its packed tiles, rank 0 the matching ncclRecvs, one group —
+//      on its communication stream, behind the render (an event, no host wait). The radiance always travels; the G-buffer
+//      outputs the reference's render always produces (albedo, VisibilityInfo, DepthInfo, prev-uv: bdpt.hlsl:222-296, what
+//      the denoiser consumes, Denoiser.cpp:186-213) travel the same way when gather_aovs(true) (the default).
+// With pipelined(true) the exchange and assembly of frame i run while frame i + 1 renders (two sets of buffers): render()
+// then returns once frame i - 1 is complete, prev_result() lags one call behind, and flush() completes the last frame.
+// Needs <rccl/rccl.h> and the HIP runtime (link -lrccl -lamdhip64); stratum_hip.hpp itself stays free of both.
 #pragma once
 
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #include "stratum_hip.hpp"
@@ -39,15 +51,83 @@ struct ShardLayout {
     py = ty * tile_h + ((b / blocks_x) << 3) + (lane >> 3);
     return px < width && py < height && tile < tiles_x() * tiles_y();
   }
-  // what sthip_assemble_tiles does on the device, on the host: packed[r] = rank r's buffer (slot_count(r) float4 entries)
-  void assemble(const std::vector<const float*>& packed, float* frame) const {
-    std::memset(frame, 0, (size_t)width * height * 16);
+  // what sthip_assemble_tiles does on the device, on the host: packed[r] = rank r's buffer (slot_count(r) entries of
+  // entry_bytes each)
+  void assemble(const std::vector<const void*>& packed, void* frame, size_t entry_bytes = 16) const {
+    std::memset(frame, 0, (size_t)width * height * entry_bytes);
     for (uint32_t r = 0; r < world; r++)
       for (uint32_t s = 0, n = slot_count(r); s < n; s++) {
         uint32_t x, y;
-        if (slot_pixel(r, s, x, y)) std::memcpy(frame + 4 * ((size_t)y * width + x), packed[r] + 4 * (size_t)s, 16);
+        if (slot_pixel(r, s, x, y)) std::memcpy((char*)frame + entry_bytes * ((size_t)y * width + x), (const char*)packed[r] + entry_bytes * (size_t)s, entry_bytes);
       }
   }
+};
+
+// One host thread per rank for the life of the driver (a context is single-threaded, different contexts may run
+// concurrently: sthip.h). run(fn) hands fn(rank) to the threads of ranks [first, world) and returns when all are through;
+// the first exception (by rank) is rethrown, after every thread has finished its job.
+class RankThreads {
+ public:
+  explicit RankThreads(size_t world) : mJobs(world), mErrors(world) {
+    for (size_t r = 0; r < world; r++) mThreads.emplace_back([this, r]() { loop(r); });
+  }
+  ~RankThreads() {
+    {
+      std::lock_guard<std::mutex> lk(mMutex);
+      mStop = true;
+    }
+    mWake.notify_all();
+    for (auto& t : mThreads) t.join();
+  }
+  void run(size_t first, const std::function<void(size_t)>& fn) {
+    {
+      std::lock_guard<std::mutex> lk(mMutex);
+      for (size_t r = first; r < mJobs.size(); r++) {
+        mJobs[r] = fn;
+        mErrors[r].clear();
+        mPending++;
+      }
+    }
+    mWake.notify_all();
+    std::unique_lock<std::mutex> lk(mMutex);
+    mDone.wait(lk, [this]() { return mPending == 0; });
+    for (size_t r = first; r < mJobs.size(); r++)
+      if (!mErrors[r].empty()) throw std::runtime_error(mErrors[r]);
+  }
+
+ private:
+  void loop(size_t r) {
+    for (;;) {
+      std::function<void(size_t)> job;
+      {
+        std::unique_lock<std::mutex> lk(mMutex);
+        mWake.wait(lk, [this, r]() { return mStop || (bool)mJobs[r]; });
+        if (mStop) return;
+        job.swap(mJobs[r]);
+      }
+      std::string error;
+      try {
+        job(r);
+      } catch (const std::exception& e) {
+        error = e.what()[0] ? e.what() : "error";
+      } catch (...) {
+        error = "unknown error";
+      }
+      {
+        std::lock_guard<std::mutex> lk(mMutex);
+        mErrors[r] = error;
+        mPending--;
+      }
+      mDone.notify_all();
+    }
+  }
+  std::vector<std::thread> mThreads;
+  std::vector<std::function<void(size_t)>> mJobs;
+  std::vector<std::string> mErrors;
+  std::mutex mMutex;
+  std::condition_variable mWake, mDone;
+  size_t mPending = 0;
+  bool mStop = false;
 };
 
 class MultiDeviceBDPT : public BDPT {
@@ -66,97 +146,172 @@ class MultiDeviceBDPT : public BDPT {
       mRanks[r].comm = comms[r];
       check_hip(hipSetDevice(devices[r]), "hipSetDevice");
       check_hip(hipStreamCreateWithFlags(&mRanks[r].stream, hipStreamNonBlocking), "hipStreamCreate");
+      check_hip(hipStreamCreateWithFlags(&mRanks[r].comm_stream, hipStreamNonBlocking), "hipStreamCreate");
+      for (int k = 0; k < 2; k++) {
+        check_hip(hipEventCreateWithFlags(&mRanks[r].rendered[k], hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&mRanks[r].exchanged[k], hipEventDisableTiming), "hipEventCreate");
+      }
       (void)sthip_set_stream(mRanks[r].ctx, mRanks[r].stream);
     }
+    mThreads.reset(new RankThreads(devices.size()));
   }
   ~MultiDeviceBDPT() override {
+    mThreads.reset();
     for (size_t r = 0; r < mRanks.size(); r++) {
       (void)hipSetDevice(mDevices[r]);
       (void)hipStreamSynchronize(mRanks[r].stream);
+      (void)hipStreamSynchronize(mRanks[r].comm_stream);
       if (mRanks[r].comm) (void)ncclCommDestroy(mRanks[r].comm);
-      if (mRanks[r].packed) (void)hipFree(mRanks[r].packed);
-      if (mRanks[r].counters) (void)hipFree(mRanks[r].counters);
+      for (int k = 0; k < 2; k++) {
+        for (void* p : mRanks[r].buf[k].all()) (void)hipFree(p);
+        if (mRanks[r].rendered[k]) (void)hipEventDestroy(mRanks[r].rendered[k]);
+        if (mRanks[r].exchanged[k]) (void)hipEventDestroy(mRanks[r].exchanged[k]);
+      }
       if (r > 0 && mRanks[r].ctx) sthip_destroy(mRanks[r].ctx);  // rank 0's context is the base class's
       if (mRanks[r].stream) (void)hipStreamDestroy(mRanks[r].stream);
+      if (mRanks[r].comm_stream) (void)hipStreamDestroy(mRanks[r].comm_stream);
     }
     (void)hipSetDevice(mDevices[0]);
-    if (mGathered) (void)hipFree(mGathered);
-    if (mFrameDev) (void)hipFree(mFrameDev);
+    for (int k = 0; k < 2; k++)
+      for (void* p : mGathered[k].all()) (void)hipFree(p);
+    for (void* p : mFrameDev.all()) (void)hipFree(p);
   }
   size_t world() const { return mRanks.size(); }
+  void gather_aovs(bool on) { mGatherAOVs = on; }  // also exchange albedo / visibility / depth / prev-uv (default on)
+  void pipelined(bool on) {
+    flush();
+    mPipelined = on;
+  }
 
-  // the scene goes to every GPU (replicated: a 1M-triangle scene is < 200 MB of 288 GB), in parallel
+  // the scene goes to every GPU (replicated: a 1M-triangle scene is < 200 MB of 288 GB), in parallel. Every rank takes the
+  // SAME path — a transforms-only update everywhere or a full upload everywhere — so all of them walk the same tree form.
   void update(CommandBuffer& cb, float dt) override {
     auto scene = mNode.find_in_ancestor<Scene>();
     if (!scene) scene = mNode.root().find_in_descendants<Scene>();
     if (!scene || !scene->data() || scene->data().get() == mBound) return;
+    flush();
     BDPT::update(cb, dt);  // rank 0, and the bookkeeping (mBound, light count, environment)
     (void)sthip_set_stream(mCtx, mRanks[0].stream);
     const sthip_scene_desc d = scene->data()->desc();
     const bool transforms_only = last_update_was_transforms_only();
-    for_each_rank(1, [&](size_t r) {
-      int rc = STHIP_ERR_UNSUPPORTED;
-      if (transforms_only) rc = sthip_scene_update_transforms(mRanks[r].ctx, d.gInstanceTransforms, d.gInstanceInverseTransforms, d.gInstanceMotionTransforms, d.instance_count);
-      if (rc != STHIP_OK && sthip_scene_upload(mRanks[r].ctx, &d) != STHIP_OK) throw std::runtime_error(std::string("sthip_scene_upload (rank ") + std::to_string(r) + "): " + sthip_last_error(mRanks[r].ctx));
+    std::vector<int> took_update(mRanks.size(), 0);
+    mThreads->run(1, [&](size_t r) {
+      if (transforms_only && sthip_scene_update_transforms(mRanks[r].ctx, d.gInstanceTransforms, d.gInstanceInverseTransforms, d.gInstanceMotionTransforms, d.instance_count) == STHIP_OK) {
+        took_update[r] = 1;
+        return;
+      }
+      if (sthip_scene_upload(mRanks[r].ctx, &d) != STHIP_OK) throw std::runtime_error(std::string("sthip_scene_upload (rank ") + std::to_string(r) + "): " + sthip_last_error(mRanks[r].ctx));
     });
+    if (transforms_only)  // a rank that had to fall back to the full upload (cannot happen with identical histories) makes everyone do so
+      for (size_t r = 1; r < mRanks.size(); r++)
+        if (!took_update[r]) {
+          mThreads->run(0, [&](size_t q) {
+            if (sthip_scene_upload(mRanks[q].ctx, &d) != STHIP_OK) throw std::runtime_error(std::string("sthip_scene_upload (rank ") + std::to_string(q) + "): " + sthip_last_error(mRanks[q].ctx));
+          });
+          break;
+        }
   }
 
-  // One frame over all GPUs: every rank renders its tiles for all the seeds of the call (packed, 1 / world of the frame),
-  // the tiles are gathered on rank 0 (one message per rank straight over its xGMI link: ncclSend / ncclRecv in a group,
-  // no ring) and scattered into the image there. mPrevFrame holds the radiance and the ray counts; the G-buffer AOVs of a
-  // sharded frame stay with the rank that owns the pixel and are not exchanged (render on one device when they are needed).
+  // One frame over all GPUs (see the header of this file). mPrevFrame holds the assembled outputs and the ray counts.
   void render(CommandBuffer&, uint32_t width, uint32_t height, const std::vector<std::pair<ViewData, TransformData>>& views, uint32_t seed_count = 1) override {
     FrameSetup fs;
     prepare_frame(width, height, views, fs);
     const ShardLayout layout{width, height, (uint32_t)mRanks.size(), mTileW, mTileH};
     const size_t stride = layout.slot_count(0);  // rank 0 owns the most tiles: equal-size messages
-    ensure_buffers(stride, (size_t)width * height);
+    const size_t pixels = (size_t)width * height;
+    ensure_buffers(stride, pixels);
     const uint32_t seed_begin = frame_number();
-    for_each_rank(0, [&](size_t r) {
+    const int k = mPipelined ? (int)(mSubmitted & 1u) : 0;
+    if (mInFlight[k].valid) finish(k);  // (cannot be: the frame that used these buffers was completed at the end of the call before last)
+    // ---- phase 1: every rank renders; no collective has been issued when this returns or throws ----
+    mThreads->run(0, [&](size_t r) {
       Rank& rk = mRanks[r];
+      Buffers& b = rk.buf[k];
       check_hip(hipSetDevice(mDevices[r]), "hipSetDevice");
       if (sthip_set_shard(rk.ctx, (uint32_t)r, (uint32_t)mRanks.size(), mTileW, mTileH) != STHIP_OK) throw std::runtime_error(sthip_last_error(rk.ctx));
       sthip_outputs o{};
       o.device_ptrs = 1;
       o.radiance_layout = STHIP_LAYOUT_SHARD_TILES;
-      o.gRadiance = rk.packed;
-      o.gRayCount = rk.counters;
+      o.gRadiance = (float*)b.radiance;
+      o.gRayCount = (uint64_t*)b.counters;
+      if (mGatherAOVs) {
+        o.gAlbedo = (float*)b.img_albedo;
+        o.gVisibility = (VisibilityInfo*)b.img_visibility;
+        o.gDepth = (DepthInfo*)b.img_depth;
+        o.gPrevUVs = (float*)b.img_prev_uv;
+      }
       if (sthip_render(rk.ctx, &fs.pc, sampling_flags(), fs.scene_flags, &fs.f, seed_begin, seed_count, &o) != STHIP_OK)
         throw std::runtime_error(std::string("sthip_render (rank ") + std::to_string(r) + "): " + sthip_last_error(rk.ctx));
-      // the exchange: behind the render on the rank's stream, so nothing on the host waits in between
-      check_nccl(ncclGroupStart(), "ncclGroupStart");
-      check_nccl(ncclSend(rk.packed, stride * 4, ncclFloat, 0, rk.comm, rk.stream), "ncclSend");
-      if (r == 0)
-        for (size_t q = 0; q < mRanks.size(); q++) check_nccl(ncclRecv(mGathered + q * stride * 4, stride * 4, ncclFloat, (int)q, rk.comm, rk.stream), "ncclRecv");
-      check_nccl(ncclGroupEnd(), "ncclGroupEnd");
-      check_hip(hipMemcpyAsync(rk.ray_count, rk.counters, 16, hipMemcpyDeviceToHost, rk.stream), "hipMemcpyAsync");
-      if (r == 0) {
-        if (sthip_assemble_tiles(rk.ctx, mGathered, stride, (uint32_t)mRanks.size(), mTileW, mTileH, width, height, mFrameDev) != STHIP_OK) throw std::runtime_error(sthip_last_error(rk.ctx));
+      if (mGatherAOVs) {  // the G-buffer images -> this rank's tiles in slot order, like the radiance
+        const void* img[4] = {b.img_albedo, b.img_visibility, b.img_depth, b.img_prev_uv};
+        void* pk[4] = {b.albedo, b.visibility, b.depth, b.prev_uv};
+        for (int a = 0; a < 4; a++)
+          if (sthip_pack_tiles(rk.ctx, img[a], width, height, kEntryBytes[a + 1], pk[a]) != STHIP_OK) throw std::runtime_error(std::string("sthip_pack_tiles: ") + sthip_last_error(rk.ctx));
       }
-      check_hip(hipStreamSynchronize(rk.stream), "hipStreamSynchronize");
+      check_hip(hipMemcpyAsync(rk.ray_count[k], b.counters, 16, hipMemcpyDeviceToHost, rk.stream), "hipMemcpyAsync");
+      check_hip(hipEventRecord(rk.rendered[k], rk.stream), "hipEventRecord");
     });
-    Frame fr;
-    fr.width = width;
-    fr.height = height;
-    fr.mRadiance.assign(4 * (size_t)width * height, 0.f);
-    check_hip(hipSetDevice(mDevices[0]), "hipSetDevice");
-    check_hip(hipMemcpy(fr.mRadiance.data(), mFrameDev, fr.mRadiance.size() * 4, hipMemcpyDeviceToHost), "hipMemcpy");
-    for (const Rank& rk : mRanks) {
-      fr.mRayCount[0] += rk.ray_count[0];
-      fr.mRayCount[1] += rk.ray_count[1];
-    }
-    finish_frame(std::move(fr), fs, seed_count);
+    // ---- phase 2: the exchange, on the communication streams, behind the renders ----
+    mThreads->run(0, [&](size_t r) {
+      Rank& rk = mRanks[r];
+      Buffers& b = rk.buf[k];
+      check_hip(hipSetDevice(mDevices[r]), "hipSetDevice");
+      check_hip(hipStreamWaitEvent(rk.comm_stream, rk.rendered[k], 0), "hipStreamWaitEvent");
+      const void* src[5] = {b.radiance, b.albedo, b.visibility, b.depth, b.prev_uv};
+      void* dst[5] = {mGathered[k].radiance, mGathered[k].albedo, mGathered[k].visibility, mGathered[k].depth, mGathered[k].prev_uv};
+      const int parts = mGatherAOVs ? 5 : 1;
+      check_nccl(ncclGroupStart(), "ncclGroupStart");
+      for (int a = 0; a < parts; a++) {
+        const size_t bytes = stride * kEntryBytes[a];
+        check_nccl(ncclSend(src[a], bytes, ncclChar, 0, rk.comm, rk.comm_stream), "ncclSend");
+        if (r == 0)
+          for (size_t q = 0; q < mRanks.size(); q++) check_nccl(ncclRecv((char*)dst[a] + q * bytes, bytes, ncclChar, (int)q, rk.comm, rk.comm_stream), "ncclRecv");
+      }
+      check_nccl(ncclGroupEnd(), "ncclGroupEnd");
+      check_hip(hipEventRecord(rk.exchanged[k], rk.comm_stream), "hipEventRecord");
+    });
+    mInFlight[k].valid = true;
+    mInFlight[k].width = width;
+    mInFlight[k].height = height;
+    mInFlight[k].seed_count = seed_count;
+    mInFlight[k].fs = fs;
+    mInFlight[k].fs.f = sthip_frame_desc{};  // (its pointers lead into `fs`, which ends with this call; finish() needs the vectors only)
+    mSubmitted++;
+    note_submitted(fs, seed_count);
+    if (!mPipelined)
+      finish(k);
+    else if (mInFlight[k ^ 1].valid)
+      finish(k ^ 1);  // the frame before this one: its exchange, assembly and read-back run while this one renders
   }
-  const float* device_frame() const { return mFrameDev; }  // RGBA32F W x H on devices[0], valid until the next render
+  // completes the frames still in flight (pipelined mode): prev_result() is then the last frame submitted
+  void flush() {
+    for (int n = 0; n < 2; n++) {
+      const int k = (int)((mSubmitted + n) & 1u);  // oldest first
+      if (mInFlight[k].valid) finish(k);
+    }
+  }
+  const float* device_frame() const { return (const float*)mFrameDev.radiance; }  // RGBA32F W x H on devices[0], valid until the next frame is finished
 
  private:
+  static constexpr size_t kEntryBytes[5] = {16, 16, 8, 16, 8};  // radiance, albedo, VisibilityInfo, DepthInfo, prev-uv
+  struct Buffers {  // one set per frame in flight, per rank: packed tiles (what travels) and the G-buffer images sthip_render writes
+    void *radiance = nullptr, *albedo = nullptr, *visibility = nullptr, *depth = nullptr, *prev_uv = nullptr;
+    void *img_albedo = nullptr, *img_visibility = nullptr, *img_depth = nullptr, *img_prev_uv = nullptr;
+    void* counters = nullptr;
+    std::vector<void*> all() const { return {radiance, albedo, visibility, depth, prev_uv, img_albedo, img_visibility, img_depth, img_prev_uv, counters}; }
+  };
   struct Rank {
     sthip_ctx* ctx = nullptr;
     ncclComm_t comm = nullptr;
-    hipStream_t stream = nullptr;
-    float* packed = nullptr;  // this rank's tiles in slot order
-    uint64_t* counters = nullptr;
-    uint64_t ray_count[2] = {0, 0};
+    hipStream_t stream = nullptr, comm_stream = nullptr;
+    hipEvent_t rendered[2] = {nullptr, nullptr}, exchanged[2] = {nullptr, nullptr};
+    Buffers buf[2];
+    uint64_t ray_count[2][2] = {{0, 0}, {0, 0}};
+  };
+  struct InFlight {
+    bool valid = false;
+    uint32_t width = 0, height = 0, seed_count = 1;
+    FrameSetup fs;
   };
   static void check_hip(hipError_t e, const char* what) {
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -164,48 +319,101 @@ class MultiDeviceBDPT : public BDPT {
   static void check_nccl(ncclResult_t e, const char* what) {
     if (e != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(e));
   }
-  // fn(rank) on one host thread per rank (a context is single-threaded, different contexts may run concurrently: sthip.h)
-  template <typename F>
-  void for_each_rank(size_t first, F&& fn) {
-    std::vector<std::thread> pool;
-    std::vector<std::string> errors(mRanks.size());
-    for (size_t r = first; r < mRanks.size(); r++)
-      pool.emplace_back([&, r]() {
-        try {
-          fn(r);
-        } catch (const std::exception& e) {
-          errors[r] = e.what();
-        }
-      });
-    for (auto& t : pool) t.join();
-    for (const std::string& e : errors)
-      if (!e.empty()) throw std::runtime_error(e);
+  // frame k has been rendered and exchanged (or will have been when the events say so): assemble it on rank 0, read it back
+  void finish(int k) {
+    InFlight& f = mInFlight[k];
+    f.valid = false;
+    const uint32_t width = f.width, height = f.height;
+    const size_t pixels = (size_t)width * height;
+    const ShardLayout layout{width, height, (uint32_t)mRanks.size(), mTileW, mTileH};
+    const size_t stride = layout.slot_count(0);
+    Rank& r0 = mRanks[0];
+    check_hip(hipSetDevice(mDevices[0]), "hipSetDevice");
+    check_hip(hipStreamWaitEvent(r0.stream, r0.exchanged[k], 0), "hipStreamWaitEvent");  // the assembly runs on rank 0's render stream (its context's)
+    const void* src[5] = {mGathered[k].radiance, mGathered[k].albedo, mGathered[k].visibility, mGathered[k].depth, mGathered[k].prev_uv};
+    void* dst[5] = {mFrameDev.radiance, mFrameDev.albedo, mFrameDev.visibility, mFrameDev.depth, mFrameDev.prev_uv};
+    const int parts = mGatherAOVs ? 5 : 1;
+    for (int a = 0; a < parts; a++)
+      if (sthip_assemble_tiles_bytes(r0.ctx, src[a], stride, (uint32_t)mRanks.size(), mTileW, mTileH, width, height, (uint32_t)kEntryBytes[a], dst[a]) != STHIP_OK)
+        throw std::runtime_error(sthip_last_error(r0.ctx));
+    Frame fr;
+    fr.width = width;
+    fr.height = height;
+    fr.mRadiance.assign(4 * pixels, 0.f);
+    check_hip(hipMemcpyAsync(fr.mRadiance.data(), mFrameDev.radiance, pixels * 16, hipMemcpyDeviceToHost, r0.stream), "hipMemcpyAsync");
+    if (mGatherAOVs) {
+      fr.mAlbedo.assign(4 * pixels, 0.f);
+      fr.mVisibility.assign(pixels, VisibilityInfo{});
+      fr.mDepth.assign(pixels, DepthInfo{});
+      fr.mPrevUVs.assign(2 * pixels, 0.f);
+      check_hip(hipMemcpyAsync(fr.mAlbedo.data(), mFrameDev.albedo, pixels * 16, hipMemcpyDeviceToHost, r0.stream), "hipMemcpyAsync");
+      check_hip(hipMemcpyAsync(fr.mVisibility.data(), mFrameDev.visibility, pixels * 8, hipMemcpyDeviceToHost, r0.stream), "hipMemcpyAsync");
+      check_hip(hipMemcpyAsync(fr.mDepth.data(), mFrameDev.depth, pixels * 16, hipMemcpyDeviceToHost, r0.stream), "hipMemcpyAsync");
+      check_hip(hipMemcpyAsync(fr.mPrevUVs.data(), mFrameDev.prev_uv, pixels * 8, hipMemcpyDeviceToHost, r0.stream), "hipMemcpyAsync");
+    }
+    check_hip(hipStreamSynchronize(r0.stream), "hipStreamSynchronize");
+    for (size_t r = 0; r < mRanks.size(); r++) {  // the ray counts: every rank's render stream has passed its copy when its `rendered` event has
+      check_hip(hipSetDevice(mDevices[r]), "hipSetDevice");
+      check_hip(hipEventSynchronize(mRanks[r].rendered[k]), "hipEventSynchronize");
+      fr.mRayCount[0] += mRanks[r].ray_count[k][0];
+      fr.mRayCount[1] += mRanks[r].ray_count[k][1];
+    }
+    check_hip(hipSetDevice(mDevices[0]), "hipSetDevice");
+    finish_frame(std::move(fr), f.fs, f.seed_count, true);  // (frame number and previous views moved on when the frame was submitted)
   }
   void ensure_buffers(size_t stride, size_t pixels) {
-    if (stride > mStride) {
+    if (stride > mStride || pixels > mPixels) {
+      flush();
+      const size_t s = std::max(stride, mStride), px = std::max(pixels, mPixels);
+      auto renew = [&](void*& p, size_t bytes) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        check_hip(hipMalloc(&p, std::max<size_t>(bytes, 16)), "hipMalloc");
+        check_hip(hipMemset(p, 0, std::max<size_t>(bytes, 16)), "hipMemset");
+      };
       for (size_t r = 0; r < mRanks.size(); r++) {
         check_hip(hipSetDevice(mDevices[r]), "hipSetDevice");
-        if (mRanks[r].packed) (void)hipFree(mRanks[r].packed);
-        check_hip(hipMalloc((void**)&mRanks[r].packed, stride * 16), "hipMalloc");
-        if (!mRanks[r].counters) check_hip(hipMalloc((void**)&mRanks[r].counters, 16), "hipMalloc");
+        for (int k = 0; k < 2; k++) {
+          Buffers& b = mRanks[r].buf[k];
+          renew(b.radiance, s * 16);
+          renew(b.albedo, s * 16);
+          renew(b.visibility, s * 8);
+          renew(b.depth, s * 16);
+          renew(b.prev_uv, s * 8);
+          renew(b.img_albedo, px * 16);
+          renew(b.img_visibility, px * 8);
+          renew(b.img_depth, px * 16);
+          renew(b.img_prev_uv, px * 8);
+          renew(b.counters, 16);
+        }
       }
       check_hip(hipSetDevice(mDevices[0]), "hipSetDevice");
-      if (mGathered) (void)hipFree(mGathered);
-      check_hip(hipMalloc((void**)&mGathered, mRanks.size() * stride * 16), "hipMalloc");
-      mStride = stride;
-    }
-    if (pixels > mPixels) {
-      check_hip(hipSetDevice(mDevices[0]), "hipSetDevice");
-      if (mFrameDev) (void)hipFree(mFrameDev);
-      check_hip(hipMalloc((void**)&mFrameDev, pixels * 16), "hipMalloc");
-      mPixels = pixels;
+      const size_t w = mRanks.size();
+      for (int k = 0; k < 2; k++) {
+        renew(mGathered[k].radiance, w * s * 16);
+        renew(mGathered[k].albedo, w * s * 16);
+        renew(mGathered[k].visibility, w * s * 8);
+        renew(mGathered[k].depth, w * s * 16);
+        renew(mGathered[k].prev_uv, w * s * 8);
+      }
+      renew(mFrameDev.radiance, px * 16);
+      renew(mFrameDev.albedo, px * 16);
+      renew(mFrameDev.visibility, px * 8);
+      renew(mFrameDev.depth, px * 16);
+      renew(mFrameDev.prev_uv, px * 8);
+      mStride = s;
+      mPixels = px;
     }
   }
   std::vector<int> mDevices;
   std::vector<Rank> mRanks;
+  std::unique_ptr<RankThreads> mThreads;
   uint32_t mTileW, mTileH;
-  float* mGathered = nullptr;
-  float* mFrameDev = nullptr;
+  Buffers mGathered[2];  // on devices[0]: rank r's tiles at r * stride entries (only the packed members are used)
+  Buffers mFrameDev;     // on devices[0]: the assembled W x H images (radiance, albedo, visibility, depth, prev_uv)
+  InFlight mInFlight[2];
+  uint64_t mSubmitted = 0;
+  bool mGatherAOVs = true, mPipelined = false;
   size_t mStride = 0, mPixels = 0;
 };
 

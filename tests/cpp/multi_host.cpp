@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
       std::vector<float> frame((size_t)L.width * L.height * 4), back(frame.size());
       for (size_t i = 0; i < frame.size(); i++) frame[i] = (float)((i * 2654435761ull) % 1000003ull) + 1.0f;
       std::vector<std::vector<float>> packed(L.world);
-      std::vector<const float*> ptrs;
+      std::vector<const void*> ptrs;
       for (uint32_t r = 0; r < L.world; r++) {
         const uint32_t n = L.slot_count(r);
         packed[r].assign((size_t)n * 4, 0.f);
