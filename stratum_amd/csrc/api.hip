@@ -23,6 +23,9 @@
 namespace sthip {
 hipError_t lvc_compact(const float4* staging, uint32_t slots_per_seed, uint32_t seeds, uint32_t vertices_per_seed, float4* cache, uint32_t* counts, uint32_t* flags, uint32_t* offsets,
                        void* tmp, size_t& tmp_bytes, hipStream_t stream, uint32_t rec = 4, uint32_t flag_at = 2);  // lvc.hip
+hipError_t hashgrid_build_device(const uint2* keys, const uint32_t* count, uint32_t slots, uint32_t buckets, uint32_t* checksums, uint32_t* counters, uint32_t* indices, uint32_t* dest, uint32_t* owner,
+                                 uint32_t* bucket_of, uint32_t* append_index, uint32_t* sorted_bucket, uint32_t* sorted_append, unsigned long long* key64, unsigned long long* sorted_key64, void* tmp,
+                                 size_t& tmp_bytes, hipStream_t stream, bool force_serial = false);  // hashgrid.hip
 }
 
 namespace {
@@ -152,6 +155,8 @@ struct sthip_ctx {
   // eNEEReservoirReuse: the append stage and its compaction, the keys / destinations of the host-side probing, the grid
   DevBuf<float4> hg_appends, hg_compact, hg_data;
   DevBuf<uint32_t> hg_count, hg_flags, hg_offsets, hg_dest, hg_checksums, hg_counters, hg_indices;
+  DevBuf<uint32_t> hg_owner, hg_bucket_of, hg_append, hg_sorted_bucket, hg_sorted_append;  // scratch of the device-side grid build (hashgrid.hip)
+  DevBuf<unsigned long long> hg_key64, hg_sorted_key64;
   DevBuf<uint2> hg_keys;
   DevBuf<uint8_t> hg_tmp;
   DevBuf<float4> lg_appends, lg_compact, lg_data;  // eLVCReservoirReuse: the same for gLVCHashGrid (keys / flags / tmp are shared)
@@ -172,6 +177,7 @@ struct sthip_ctx {
   uint32_t shard_rank = 0, shard_count = 1, tile_w = 64, tile_h = 32;
   // options / stats
   bool count_traversal = false, time_kernels = false;
+  bool hashgrid_serial = false;  // "hashgrid_serial": build the reuse grids with the one-thread probe sequence (hashgrid.hip's rare-case path; tests)
   uint32_t refill_idle = 16, inner_min_lanes = 24, trace_blocks_per_cu = 0;
   uint64_t max_paths_in_flight = 1ull << 22;
   bool packet_primary = true;  // the first bounce is traced as wave packets (k_trace_primary)
@@ -412,6 +418,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->trace_blocks_per_cu = (uint32_t)std::min<int64_t>(16, std::max<int64_t>(0, value));
   else if (!strcmp(name, "treetop"))  // takes effect at the next sthip_scene_upload / sthip_scene_update_transforms
     ctx->use_treetop = value != 0;
+  else if (!strcmp(name, "hashgrid_serial"))
+    ctx->hashgrid_serial = value != 0;
   else if (!strcmp(name, "inner_min_lanes"))
     ctx->inner_min_lanes = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
   else
@@ -1028,9 +1036,10 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
   return configure_stack(ctx);
 }
 
-// One hash grid from one seed's staged appends (hashgrid.h): compact the stage in (path, vertex) order, hash the keys on
-// the device, probe them on the host in that order exactly as find_or_insert does (hashgrid.hlsli:43-58 run serially),
-// prefix the bucket counters (compute_indices, :72-79) and scatter the records into their bucket ranges (swizzle, :81-88).
+// One hash grid from one seed's staged appends (hashgrid.h): compact the stage in (path, vertex) order, hash the keys, build
+// the table the serial probe sequence of find_or_insert would build (hashgrid.hlsli:43-58; in parallel: hashgrid.hip), prefix
+// the bucket counters (compute_indices, :72-79) and scatter the records into their bucket ranges (swizzle, :81-88) — all of it
+// enqueued on the stream, nothing visits the host.
 static int build_hash_grid(sthip_ctx* ctx, hipStream_t st, const float4* appends, float4* compact, float4* data, size_t slots, uint32_t rec, uint32_t flag_at, bool lvc_records,
                            uint32_t bucket_count, DevBuf<uint32_t>& d_checksums, DevBuf<uint32_t>& d_counters, DevBuf<uint32_t>& d_indices) {
   const uint32_t buckets = bucket_count + 32u;  // probing does not wrap
@@ -1041,43 +1050,15 @@ static int build_hash_grid(sthip_ctx* ctx, hipStream_t st, const float4* appends
     hipLaunchKernelGGL(k_hg_keys_lvc, dim3(kgrid), dim3(STHIP_BLOCK), 0, st, compact, ctx->hg_count.p, bucket_count, ctx->hg_keys.p);
   else
     hipLaunchKernelGGL(k_hg_keys, dim3(kgrid), dim3(STHIP_BLOCK), 0, st, compact, ctx->hg_count.p, bucket_count, ctx->hg_keys.p);
-  uint32_t n_app = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&n_app, ctx->hg_count.p, 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
-  std::vector<uint2> keys(n_app);
-  if (n_app) HIP_TRY(ctx, hipMemcpy(keys.data(), ctx->hg_keys.p, (size_t)n_app * 8, hipMemcpyDeviceToHost));
-  std::vector<uint32_t> checksums(buckets, 0u), counters(buckets, 0u), indices(buckets, 0u), dest(std::max<size_t>(1, n_app), 0xFFFFFFFFu), bucket_of(n_app), rank_of(n_app);
-  for (uint32_t k = 0; k < n_app; k++) {
-    uint32_t b = keys[k].x, found = 0xFFFFFFFFu;
-    for (uint32_t i = 0; i < 32; i++, b++) {
-      if (checksums[b] == 0) checksums[b] = keys[k].y;
-      if (checksums[b] == keys[k].y) {
-        found = b;
-        break;
-      }
-    }
-    bucket_of[k] = found;
-    if (found != 0xFFFFFFFFu) rank_of[k] = counters[found]++;
-  }
-  uint32_t running = 0;
-  for (uint32_t b = 0; b < buckets; b++) {
-    indices[b] = running;
-    running += counters[b];
-  }
-  for (uint32_t k = 0; k < n_app; k++)
-    if (bucket_of[k] != 0xFFFFFFFFu) dest[k] = indices[bucket_of[k]] + rank_of[k];
-  HIP_TRY(ctx, hipMemcpyAsync(d_checksums.p, checksums.data(), (size_t)buckets * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(d_counters.p, counters.data(), (size_t)buckets * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(d_indices.p, indices.data(), (size_t)buckets * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->hg_dest.p, dest.data(), dest.size() * 4, hipMemcpyHostToDevice, st));
-  if (n_app) {
-    const unsigned sgrid = (n_app + STHIP_BLOCK - 1) / STHIP_BLOCK;
-    if (lvc_records)
-      hipLaunchKernelGGL(k_hg_scatter_lvc, dim3(sgrid), dim3(STHIP_BLOCK), 0, st, compact, n_app, ctx->hg_dest.p, data);
-    else
-      hipLaunchKernelGGL(k_hg_scatter, dim3(sgrid), dim3(STHIP_BLOCK), 0, st, compact, n_app, ctx->hg_dest.p, data);
-  }
-  HIP_TRY(ctx, hipStreamSynchronize(st));  // the host vectors above are the source of the copies
+  // the probe sequence, the bucket ranges and every record's place, on the device (hashgrid.hip): no host hop
+  size_t build_bytes = ctx->hg_tmp.n;
+  HIP_TRY(ctx, sthip::hashgrid_build_device(ctx->hg_keys.p, ctx->hg_count.p, (uint32_t)slots, buckets, d_checksums.p, d_counters.p, d_indices.p, ctx->hg_dest.p, ctx->hg_owner.p, ctx->hg_bucket_of.p,
+                                            ctx->hg_append.p, ctx->hg_sorted_bucket.p, ctx->hg_sorted_append.p, ctx->hg_key64.p, ctx->hg_sorted_key64.p, ctx->hg_tmp.p, build_bytes, st, ctx->hashgrid_serial));
+  if (lvc_records)
+    hipLaunchKernelGGL(k_hg_scatter_lvc, dim3(kgrid), dim3(STHIP_BLOCK), 0, st, compact, ctx->hg_count.p, ctx->hg_dest.p, data);
+  else
+    hipLaunchKernelGGL(k_hg_scatter, dim3(kgrid), dim3(STHIP_BLOCK), 0, st, compact, ctx->hg_count.p, ctx->hg_dest.p, data);
+  HIP_TRY(ctx, hipGetLastError());
   return STHIP_OK;
 }
 
@@ -1248,9 +1229,18 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     HIP_TRY(ctx, ctx->hg_checksums.ensure(hg_buckets));
     HIP_TRY(ctx, ctx->hg_counters.ensure(hg_buckets));
     HIP_TRY(ctx, ctx->hg_indices.ensure(hg_buckets));
-    size_t tmp_bytes = 0;
+    HIP_TRY(ctx, ctx->hg_owner.ensure(hg_buckets + 2 + 1024));  // (+ hashgrid.hip's control words and special-cell list)
+    HIP_TRY(ctx, ctx->hg_key64.ensure(hg_slots));
+    HIP_TRY(ctx, ctx->hg_sorted_key64.ensure(hg_slots));
+    HIP_TRY(ctx, ctx->hg_bucket_of.ensure(hg_slots));
+    HIP_TRY(ctx, ctx->hg_append.ensure(hg_slots));
+    HIP_TRY(ctx, ctx->hg_sorted_bucket.ensure(hg_slots));
+    HIP_TRY(ctx, ctx->hg_sorted_append.ensure(hg_slots));
+    size_t tmp_bytes = 0, build_bytes = 0;
     HIP_TRY(ctx, sthip::lvc_compact(nullptr, (uint32_t)hg_slots, 1, 0, nullptr, nullptr, ctx->hg_flags.p, ctx->hg_offsets.p, nullptr, tmp_bytes, ctx->stream));
-    HIP_TRY(ctx, ctx->hg_tmp.ensure(std::max<size_t>(16, tmp_bytes)));
+    HIP_TRY(ctx, sthip::hashgrid_build_device(nullptr, nullptr, (uint32_t)hg_slots, hg_buckets, nullptr, ctx->hg_counters.p, ctx->hg_indices.p, nullptr, nullptr, ctx->hg_bucket_of.p, ctx->hg_append.p,
+                                              ctx->hg_sorted_bucket.p, ctx->hg_sorted_append.p, ctx->hg_key64.p, ctx->hg_sorted_key64.p, nullptr, build_bytes, ctx->stream));
+    HIP_TRY(ctx, ctx->hg_tmp.ensure(std::max<size_t>(16, std::max(tmp_bytes, build_bytes))));
   }
 
   HIP_TRY(ctx, ctx->ray_o.ensure(P));

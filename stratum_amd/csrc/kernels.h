@@ -2364,9 +2364,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys(const float4* appends, 
   keys[i] = make_uint2(home, checksum);
 }
 // dest[i] = index into gNEEHashGrid.mData of append i, or 0xFFFFFFFF when its 32 probes found no slot (dropped, hashgrid.hlsli:56-58)
-__global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter(const float4* appends, uint32_t n, const uint32_t* dest, float4* data) {
+__global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter(const float4* appends, const uint32_t* count, const uint32_t* dest, float4* data) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= *count) return;
   const uint32_t d = dest[i];
   if (d == 0xFFFFFFFFu) return;
   const float4 a0 = appends[4 * (size_t)i], a1 = appends[4 * (size_t)i + 1], a2 = appends[4 * (size_t)i + 2], a3 = appends[4 * (size_t)i + 3];
@@ -2383,9 +2383,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys_lvc(const float4* appen
   const uint32_t home = hashgrid_bucket_index(xyz(a0), a0.w, bucket_count, checksum);
   keys[i] = make_uint2(home, checksum);
 }
-__global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter_lvc(const float4* appends, uint32_t n, const uint32_t* dest, float4* data) {
+__global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter_lvc(const float4* appends, const uint32_t* count, const uint32_t* dest, float4* data) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= *count) return;
   const uint32_t d = dest[i];
   if (d == 0xFFFFFFFFu) return;
   for (int q = 0; q < 5; q++) data[5 * (size_t)d + q] = appends[6 * (size_t)i + 1 + q];

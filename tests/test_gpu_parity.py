@@ -1086,6 +1086,32 @@ def test_nee_reservoir_reuse(flags, args):
     _compare_frame(sc, cam, flags, w=100, h=76, seeds=4, args=args)
 
 
+def test_hash_grid_build_paths_agree():
+    """The reuse grids are built on the device (hashgrid.hip): in parallel by priority insertion, or — in the rare frame where
+    two cells share a 32-bit checksum — by one thread running the serial probe sequence. Both must give the grid the defined
+    order gives: the same frames with the serial path forced, with a table so small that cells compete and records drop."""
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = scenes.cornell_box()
+    frame = camera.Frame(100, 76, cam["fovy"], cam["eye"], cam["target"])
+    for flags, args in (
+        (["neereservoirs", "neereservoirreuse"], {"reservoirM": 2, "hashGridBucketCount": 40}),
+        (["neereservoirs", "neereservoirreuse"], {"reservoirM": 4}),
+        (["connecttolightpaths", "lvc", "lvcreservoirs", "lvcreservoirreuse"], {"lightPathCount": 3000, "hashGridBucketCount": 500}),
+    ):
+        out = []
+        for serial in (0, 1):
+            r = BDPT(device=0, args=dict(args, bdptFlag=flags))
+            try:
+                r.set_option("hashgrid_serial", serial)
+                r.update(sc)
+                out.append(r.render(frame, 0, 4))
+            finally:
+                r.close()
+        assert np.array_equal(out[0]["radiance"].view(np.uint32), out[1]["radiance"].view(np.uint32)), (flags, args)
+        assert np.array_equal(out[0]["ray_count"], out[1]["ray_count"]), (flags, args)
+
+
 def test_two_views_in_one_frame(renderer, cornell):
     """gViewCount = 2 (one ViewData per eye with its own image rectangle, scene.h:132-137): every output of both halves
     equals the oracle's; pixels outside every view (odd width: the last column) stay untouched."""

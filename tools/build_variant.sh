@@ -10,5 +10,5 @@ d=$base/pkg/csrc
 rm -rf $base; mkdir -p $base/pkg; cp -r $root/stratum_amd/csrc $d; cp -r $root/include $base/include
 if [ -n "$patch" ]; then (cd $d && python3 $patch); fi
 mkdir -p $root/_variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math $EXTRA_FLAGS -o $root/_variants/$name.so $d/api.hip $d/lbvh.hip $d/lvc.hip $d/wide.hip $d/bvh_build.cpp $d/hdr_writer.cpp
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math $EXTRA_FLAGS -o $root/_variants/$name.so $d/api.hip $d/lbvh.hip $d/lvc.hip $d/hashgrid.hip $d/wide.hip $d/bvh_build.cpp $d/hdr_writer.cpp
 echo built _variants/$name.so
