@@ -853,3 +853,45 @@ def test_oracle_bvh_never_loses_a_hit_on_awkward_rays():
         ha = o.trace(rays, any_hit=True, brute=True)[0]["instance_primitive_index"] != wire.MISS
         hb = o.trace(rays, any_hit=True)[0]["instance_primitive_index"] != wire.MISS
         assert np.array_equal(ha, hb), sc.name
+
+
+def test_far_origin_hits_of_the_contract_are_pinned():
+    """A known hole of the hit CONTRACT ("spurious contract hits from far origins"), pinned as it is: the contract's
+    triangle test is Woop, Benthin and Wald's in single precision; from an origin hundreds of scene sizes away the
+    translated and sheared vertices collapse, edge functions come out as exact zeros, and the test admits a "hit" whose
+    point o + t d lies nowhere near the triangle. No acceleration structure can find such a hit (its boxes are nowhere near
+    the ray), so brute force and every traversal — the oracle's own BVH and the HIP kernels, which agree with each other
+    bit for bit (tools/fuzz_parity.py rays) — differ there. What this test fixes: (1) for origins within ten scene sizes
+    brute force and the BVH traversal agree on every ray; (2) from farther away every disagreement is of that one kind —
+    brute force reports a hit the traversal does not, and its hit point lies outside the scene's bounds by more than
+    the scene's size. A guard in the contract (hit point against the triangle's padded bounds) would remove the hole; it
+    changes both sides and every golden frame, and is not made."""
+    sc, _ = scenes.forest(n_instances=12, tree_tris=400, tree_kinds=2)
+    o = orc.OracleScene(sc)
+    lo, hi = np.array([-12.0, -1.0, -12.0]), np.array([12.0, 9.0, 12.0])  # (generous bounds of the instanced scene)
+    size = float((hi - lo).max())
+    rng = np.random.default_rng(9)
+    for scale, must_agree in ((1.0, True), (10.0, True), (300.0, False), (3000.0, False)):
+        n = 12000
+        origin = rng.uniform(lo, hi, (n, 3)) * scale
+        target = rng.uniform(lo, hi, (n, 3))
+        rays = np.zeros(n, wire.Ray)
+        rays["origin"] = origin.astype(np.float32)
+        rays["direction"] = (target - origin).astype(np.float32)  # unnormalised, aimed at the scene
+        rays["tmin"], rays["tmax"] = 0.0, np.inf
+        brute, _ = o.trace(rays, brute=True)
+        bvh, _ = o.trace(rays)
+        differ = np.nonzero(brute["instance_primitive_index"] != bvh["instance_primitive_index"])[0]
+        same_where_equal = np.ones(n, bool)
+        same_where_equal[differ] = False
+        for f in ("t", "b1", "b2"):
+            assert np.array_equal(brute[f][same_where_equal].view(np.uint32), bvh[f][same_where_equal].view(np.uint32)), (scale, f)
+        if must_agree:
+            assert differ.size == 0, (scale, differ.size)
+            continue
+        assert differ.size < n // 200, (scale, differ.size)  # rare
+        if differ.size:
+            assert (bvh["instance_primitive_index"][differ] == wire.MISS).all() or (brute["t"][differ] < bvh["t"][differ]).all(), scale
+            hp = rays["origin"][differ].astype(np.float64) + brute["t"][differ].astype(np.float64)[:, None] * rays["direction"][differ].astype(np.float64)
+            outside = ((hp < lo - size) | (hp > hi + size)).any(axis=1) | ~np.isfinite(hp).all(axis=1)
+            assert outside.all(), (scale, hp[~outside])
