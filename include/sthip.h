@@ -280,9 +280,11 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s);
  * sthip_scene_upload; a failed upload with it leaves the context without a scene), with "lbvh_algorithm" 1 = PLOC
  * (default) or 0 = Karras radix tree, "ploc_radius" (1..32, default 4) and "sah_top" (default 64: subtrees of at most that
  * many triangles keep their PLOC shape under a host-built SAH top; 0 = plain PLOC);
- * "wide_bvh" (the persistent trace kernel walks the host-built tree collapsed into 4-wide nodes of 64 bytes with 8-bit child
- * planes: 0 = never, 1 = always, 2 = default: when the binary nodes exceed 4 MiB, one XCD's L2; not with "treetop" or the GPU
- * builder, and a transforms-only update goes back to the binary walk),
+ * "wide_bvh" (the persistent trace kernel walks the tree collapsed into 4-wide nodes of 64 bytes with 8-bit child planes:
+ * 1 = always (default) — host-built trees are collapsed on the host, the GPU builder's trees and the tree of a
+ * transforms-only update on the device; 0 = never; 2 = only when the binary nodes exceed 4 MiB, one XCD's L2; not with
+ * "treetop" or "embed_leaves"), "hashgrid_serial" (0/1: build the reservoir-reuse hash grids with the one-thread serial probe
+ * sequence instead of the parallel device build: the same grids, for tests),
  * "treetop" (default 0), "embed_leaves" (default 0), "lds_materials" (default 1), "lds_stack_levels" (4..150: LDS levels of the traversal stack; a higher
  * tree runs the bounded kernels, default: bounded at 32 levels beyond a height of 40): layout / scheduling options that
  * never change results, read at the next sthip_scene_upload / sthip_scene_update_transforms */
@@ -295,7 +297,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value);
  * frame's accumulated colour and luminance moments are fetched at gPrevUVs with a bilinear footprint whose taps must
  * pass the instance / normal / depth tests (:74-97), without it the same pixel is used (:102-109); then the new sample
  * is blended in with alpha = n_new / n, n clamped by history_limit (gHistoryLimit, 0 = unlimited). The binding names
- * are the shader's (denoiser.h). gViews is always a host pointer; the images are host pointers unless device_ptrs.
+ * are the shader's (denoiser.h). gViews is always a host pointer; the images are host pointers unless device_ptrs
+ * (then, with up to 4 views, the call only enqueues its kernel on the context's stream: nothing is allocated or waited for).
  * (sthip_render's own N-seed mean is the same-pixel branch of this kernel applied seed by seed.) */
 typedef struct sthip_accumulate_desc {
   uint32_t width, height;

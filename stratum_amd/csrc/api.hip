@@ -1868,7 +1868,10 @@ int sthip_accumulate(sthip_ctx* ctx, const sthip_accumulate_desc* d) {
   p.demodulate_albedo = d->demodulate_albedo;
   p.history_limit = d->history_limit;
   p.instance_count = d->instance_count;
-  {  // gViews is a host array in either mode
+  if (d->view_count <= ACCUMULATE_INLINE_VIEWS) {  // gViews is a host array in either mode: a few views ride in the kernel's arguments
+    p.views = nullptr;
+    memcpy(p.inline_views, d->gViews, (size_t)d->view_count * sizeof(sthip_ViewData));
+  } else {
     void* q = nullptr;
     if (hipMalloc(&q, (size_t)d->view_count * sizeof(sthip_ViewData)) != hipSuccess ||
         hipMemcpyAsync(q, d->gViews, (size_t)d->view_count * sizeof(sthip_ViewData), hipMemcpyHostToDevice, st) != hipSuccess)
@@ -1912,8 +1915,8 @@ int sthip_accumulate(sthip_ctx* ctx, const sthip_accumulate_desc* d) {
     e = hipMemcpyAsync(d->gAccumColor, out_c, n * 16, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d->gAccumMoments, out_m, n * 8, hipMemcpyDeviceToHost, st);
   }
-  // the staged copies (gViews at least) must outlive the kernel
-  const hipError_t es = hipStreamSynchronize(st);
+  // staged copies must outlive the kernel; with device pointers and inline views nothing is staged: the call is only enqueued
+  const hipError_t es = staged.empty() ? hipSuccess : hipStreamSynchronize(st);
   release();
   if (e != hipSuccess || es != hipSuccess) return fail(ctx, STHIP_ERR_HIP, std::string("sthip_accumulate: ") + hipGetErrorString(e != hipSuccess ? e : es));
   return STHIP_OK;

@@ -197,11 +197,13 @@ __global__ void __launch_bounds__(64) k_image_compare(const float4* image1, cons
 // new sample in with alpha = n_new / n. Both specialisations (gReprojection on / off) and gDemodulateAlbedo.
 // As upstream: the normal test compares against cos(degrees(2)) (degrees, not radians: 114.59 rad).
 // ---------------------------------------------------------------------------------------------------------------
+#define ACCUMULATE_INLINE_VIEWS 4u
 struct AccumulateParams {
   uint32_t width, height, view_count, reprojection, demodulate_albedo;
   float history_limit;
   uint32_t instance_count;
-  const sthip_ViewData* views;
+  const sthip_ViewData* views;  // device array, or null: the views travel in `inline_views` (up to ACCUMULATE_INLINE_VIEWS: no staging, no wait)
+  sthip_ViewData inline_views[4];
   const float4* radiance;
   const float4* albedo;
   const sthip_VisibilityInfo* visibility;
@@ -221,15 +223,16 @@ __global__ void __launch_bounds__(256) k_accumulate(AccumulateParams p) {
   if (i >= p.width * p.height) return;
   const uint32_t x = i % p.width, y = i / p.width;
   int view_index = -1;
+  const sthip_ViewData* views = p.views ? p.views : p.inline_views;
   for (uint32_t v = 0; v < p.view_count; v++) {
-    const sthip_ViewData& vw = p.views[v];
+    const sthip_ViewData& vw = views[v];
     if ((int)x >= vw.image_min[0] && (int)y >= vw.image_min[1] && (int)x < vw.image_max[0] && (int)y < vw.image_max[1]) {
       view_index = (int)v;
       break;
     }
   }
   if (view_index < 0) return;
-  const sthip_ViewData& view = p.views[view_index];
+  const sthip_ViewData& view = views[view_index];
   float4 color_prev = make_float4(0, 0, 0, 0);
   float2 moments_prev = make_float2(0, 0);
   float sum_w = 0;
