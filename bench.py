@@ -427,7 +427,7 @@ def main():
             "launch_ms": round(launch_ms, 4),
             "launches_per_step": round(launches / args.steps, 2),
             "nodes_per_ray": round((nodes + nodes_sh) / max(rays, 1), 2),
-            "node_bytes": int(node_bytes),  # of the nodes k_trace walks: 48 = binary, 64 = the 4-wide form (wide_bvh, DESIGN.md 9)
+            "node_bytes": int(node_bytes),  # of the nodes k_trace walks: 48 = binary, 64 = the 4-wide form (wide_bvh, DESIGN.md 3)
             "counts_from": "the kernel's own visit counters on its own tree (count_traversal pass of the same steps); the oracle's counts on its tree are in cpu_baseline",
             "tris_per_ray": round((tris + tris_sh) / max(rays, 1), 2),
             "bytes_per_ray": round(alg_bytes / max(rays, 1), 1),

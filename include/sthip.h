@@ -160,12 +160,12 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* gIn
  * eRayCones, eFlip*, eShadingNormalShadowFix, eUniformSphereSampling, eSampleEnvironmentMapDirectly, ePresampleLights,
  * eNEEReservoirs, eConnectToViews (sample_photons + add_light_trace), eConnectToLightPaths, and BDPT_FLAG_HAS_MEDIA
  * (volume instances over gVolumes). The flags whose upstream result depends on the order threads run in are built
- * with ONE defined order each ("Defined orders"): eLVC / eLVCReservoirs (cache filled in light-path
+ * with ONE defined order each: eLVC / eLVCReservoirs (cache filled in light-path
  * index order), eNEEReservoirReuse / eLVCReservoirReuse (hash-grid appends in (path, vertex) order; the seeds of a call
  * are then traced one at a time, seed s reading the grid of seed s - 1; not on a pixel-tile shard), eCoherentRR and
  * eCoherentSampling (the wave = the 8x4 pixel group, its first lane = the lowest lane that executes the statement).
  * Rejected with STHIP_ERR_UNSUPPORTED, never ignored: eSampleLightPower (reads an uninitialised table upstream) and the
- * combinations DESIGN.md section 7 lists (media need eDeferShadowRays and exclude light subpaths / reservoirs /
+ * combinations DESIGN.md section 5 lists (media need eDeferShadowRays and exclude light subpaths / reservoirs /
  * eCoherentSampling; light subpaths and reuse exclude environments).
  * ePerformanceCounters does not change results here; eRemapThreads only through the path index
  * (map_pixel_coord, bdpt_util.hlsli:76-83) that ePresampleLights and the light subpaths key on. */

@@ -679,7 +679,7 @@ def test_wide_walk_over_gpu_built_trees_and_moved_instances(atrium_scene, levels
 
 def test_embedded_leaves_give_the_same_frames(atrium_scene):
     """embed_leaves = 1: the host builder puts a leaf's triangles into the node array, in the units right behind the node that
-    refers to them (one array, leaf references count its units). A layout experiment (no faster: DESIGN.md 4) kept as an
+    refers to them (one array, leaf references count its units). A layout experiment (no faster: EXPERIMENTS.md) kept as an
     option; frames, alpha-masked frames and ray batches must not change."""
     from stratum_amd.bdpt import BDPT
 

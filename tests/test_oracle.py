@@ -423,7 +423,7 @@ def test_cornell_golden_fixture():
 
 def test_estimator_golden_fixture():
     """tests/golden/estimators.npz (make_estimator_golden.py): the estimators whose upstream result depends on scheduling,
-    under the orders DESIGN.md 7 defines, frozen as committed frames — the oracle must keep reproducing them bit for bit."""
+    under the orders DESIGN.md 5 defines, frozen as committed frames — the oracle must keep reproducing them bit for bit."""
     import importlib.util
     import os
 

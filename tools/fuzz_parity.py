@@ -45,7 +45,7 @@ def run(cases=60, seed=1):
         args = {"bdptFlag": flags, "maxDiffuseVertices": int(rng.integers(1, 5)), "maxPathVertices": int(rng.integers(2, 9)), "minPathVertices": int(rng.integers(2, 6))}
         W, H = int(rng.integers(3, 20)) * 8, int(rng.integers(3, 16)) * 4
         if rng.integers(3) == 0: W, H = W + int(rng.integers(1, 8)), H + int(rng.integers(1, 4))
-        # the estimators with a defined order (DESIGN.md 7): light vertex cache, the two hash grids, coherent roulette
+        # the estimators with a defined order (DESIGN.md 5): light vertex cache, the two hash grids, coherent roulette
         bundle = int(rng.integers(8))
         if bundle == 0:
             flags += ["connecttolightpaths", "lightvertexcache"] + (["lvcreservoirs"] if rng.integers(2) else []) + (["lvcreservoirs", "lvcreservoirreuse"] if rng.integers(3) == 0 else [])
@@ -215,7 +215,7 @@ def run_rays(cases=40, seed=1, n=20000):
             if not (same and same_any):
                 # A known hole of the CONTRACT, not of a traversal: from an origin hundreds of scene sizes away the sheared
                 # vertices of a triangle collapse in single precision, edge functions come out as exact zeros, and the test
-                # accepts a "hit" whose point o + t d lies nowhere near the triangle (DESIGN.md 9). No acceleration structure finds these, the oracle's
+                # accepts a "hit" whose point o + t d lies nowhere near the triangle (DESIGN.md 6). No acceleration structure finds these, the oracle's
                 # own BVH included. They are reported, and not counted, when (1) the HIP path agrees with the oracle's BVH
                 # traversal and (2) every brute-force-only hit point lies outside the scene's bounds by more than its size.
                 rbvh, _ = orc.trace(rays, alpha_test=alpha)
