@@ -213,6 +213,33 @@ int main(int argc, char** argv) {
     std::printf("%s: %zu units, %zu triangles (%zu in wrapped leaves), %zu entries, stack depth %u, treetop %zu\n", embed ? "embedded" : "separate", b.nodes.size(), b.tris.size(), wrapped, b.entries.size(),
                 b.stack_depth, tt.nodes.size());
   }
+  // vertices no 8-bit grid can hold (an infinite one, and a pair 6e38 apart): the build either refuses the scene or keeps a
+  // binary tree, and build_wide_bvh then reports "no wide tree" by leaving EVERY wide output empty (api.hip walks the binary
+  // tree for such a scene) — never a half-filled one
+  for (int kind = 0; kind < 2 && !vertices.empty(); kind++) {
+    std::vector<sthip_PackedVertexData> bad = vertices;
+    const size_t at = bad.size() / 2;
+    if (kind == 0) bad[at].position[1] = INFINITY;
+    else bad[at].position[0] = 3.0e38f, bad[(at + 1) % bad.size()].position[0] = -3.0e38f;
+    sthip_scene_desc sb = s;
+    sb.gVertices = bad.data();
+    sthip::BuiltBvh b;
+    std::string err;
+    if (!sthip::build_scene_bvh(sb, b, err, sthip::BVH_BUILDER_SAH_HOST, nullptr, false)) {
+      std::printf("non-finite case %d: refused (%s)\n", kind, err.c_str());
+      continue;
+    }
+    sthip::build_wide_bvh(b);
+    if (b.wide_nodes.empty()) {
+      if (!b.wide_entries.empty() || b.wide_root_ref != BVH_INVALID_REF || b.wide_stack_depth != 0) return std::printf("FAIL: a failed wide build left outputs behind\n"), 1;
+      std::printf("non-finite case %d: no wide tree\n", kind);
+    } else {
+      for (const WideNode& w : b.wide_nodes)
+        for (int a = 0; a < 3; a++)
+          if (!std::isfinite(w.origin[a]) || (int8_t)w.exp[a] < -126) return std::printf("FAIL: a wide node with a non-finite grid\n"), 1;
+      std::printf("non-finite case %d: wide tree kept (%zu nodes)\n", kind, b.wide_nodes.size());
+    }
+  }
   std::printf("BVH HOST OK %zu\n", total_nodes);
   return 0;
 }
