@@ -29,7 +29,8 @@ The JSON line also carries
                 (sthip_measure_ceiling: stream triad; the traversal's own 64-byte node fetch at random
                 nodes without dependence, served from the whole BVH / from L2 / from L1), each with
                 its own fraction. `frac` is SURVEY 8d's: algorithmic GB/s / 8000; `valu_issue` is the share of
-                the chip's vector-issue cycles the kernel's instructions take (what binds it);
+                the chip's vector-issue cycles the kernel's instructions take, `occupancy` what the committed
+                profile says binds it (the dependent round trip per step at 4 waves / SIMD);
   cpu_baseline  the CPU oracle (a port of the reference shaders; the reference has no CPU path), built
                 -O3 -march=native on this box, timed on the host cores on a bounded sample of the same
                 workload (median of 5 runs) and on one thread, plus the rel-L2 between the GPU and the
@@ -73,7 +74,7 @@ def committed_profile():
     import glob
 
     out = {}
-    for name in ("traffic.json", "counters.json"):
+    for name in ("traffic.json", "counters.json", "occupancy.json"):
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", name)))
         if files:
             try:
@@ -389,7 +390,7 @@ def main():
         for c in ceilings.values():
             c["exceeded"] = bool(c["frac"] is not None and c["frac"] > 1.0)
         prof = committed_profile()
-        # What binds the kernel according to the committed PMC profile: vector-instruction issue. A wave64 VALU
+        # The kernel's share of vector-instruction issue according to the committed PMC profile. A wave64 VALU
         # instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md), 1024 SIMDs at 2.4 GHz:
         #   valu_issue.frac = SQ_INSTS_VALU per launch * 2 / (1024 * 2.4e9 * launch time)
         # The instruction count is the committed profile's (PMC counters need rocprofv3), the launch time is this run's.
@@ -409,7 +410,10 @@ def main():
             }
         roofline = {
             "bound": "hbm",  # SURVEY 8d's roofline: divergent gathers, no MFMA on this path
-            "bound_observed": "valu_issue" if valu else None,  # what the counters say binds it
+            # what the counters say binds it (profiles/r03): neither HBM nor vector issue (0.44) nor the L1 front end, but
+            # the dependent fetch -> test -> fetch round trip of a step at the 4 waves / SIMD its registers and LDS stacks allow
+            "bound_observed": "latency_at_occupancy" if prof.get("occupancy") else ("valu_issue" if valu else None),
+            "occupancy": prof.get("occupancy"),
             "kernel": "k_trace",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
@@ -449,19 +453,19 @@ def main():
                     "nodes_per_packet": round(nodes_pr / max(rays_pr / 64.0, 1), 1),
                     "tris_per_packet": round(tris_pr / max(rays_pr / 64.0, 1), 1),
                     "mray_per_s": round(rays_pr / max(ms_primary, 1e-9) / 1e3, 1),
-                    "note": "first bounce as 8x8-pixel wave packets: one wave-uniform (scalar) node fetch serves 64 rays, so the bound is the dependent scalar-load latency per packet step, not bytes",
+                    "note": "first bounce as 8x8-pixel wave packets: one wave-uniform (scalar) node fetch serves 64 rays; ~50 % of the vector-issue cycles at 6 waves / SIMD (profiles/r03/pmc_sq.txt) — the 64 slab / triangle tests per step, not bytes and not the scalar-load chain (EXPERIMENTS.md)",
                 },
                 "k_shade": {
                     "ms_per_step": round(ms_shade / args.steps, 4),
                     "algorithmic_bytes_per_vertex": 244 + 208,
                     "achieved_gbs": round((244 + 208) * float(rays_closest + rays_pr) / max(ms_shade * 1e-3, 1e-12) / 1e9, 1),
                     "peak_gbs": HBM_PEAK_GBS,
-                    "note": "per path vertex 244 B of gathers (3 vertices, indices, instance, transform, material; SURVEY 8d) + 208 B of path state read and written (algorithmic); the committed PMC profile shows 1.94 GB of HBM-side traffic per step (3.2 TB/s) and ~2300 VALU instructions per vertex: bound by VALU issue under the arithmetic contract (correctly rounded divisions, pcg4d, software transcendentals) at 3 waves/SIMD, not by HBM (DESIGN.md 4)",
+                    "note": "per path vertex 244 B of gathers (3 vertices, indices, instance, transform, material; SURVEY 8d) + 208 B of path state read and written (algorithmic); the committed PMC profile shows 1.94 GB of HBM-side traffic per step (3.2 TB/s) and ~2300 VALU instructions per vertex (correctly rounded divisions, pcg4d, software transcendentals: the arithmetic contract): 31 % of the vector-issue cycles, waves parked on dependent gathers (hit -> instance -> indices -> vertices -> material) 55 % of theirs at the 3 waves / SIMD its 168 registers allow; not HBM (DESIGN.md 4)",
                 },
             },
             "note": "k_trace = closest-hit rays of bounce >= 1 and all shadow rays (the first bounce runs as wave packets in k_trace_primary: other_kernels). "
             "algorithmic_gbs counts 48 B/ray + node and triangle bytes per visit (SURVEY 8d); the BVH lives in L2 / Infinity Cache, so that figure can exceed the HBM peak "
-            "HBM-side traffic (`traffic`, committed PMC profile) is about half of it: HBM does not bind this kernel, vector-instruction issue does (valu_issue). "
+            "HBM-side traffic (`traffic`, committed PMC profile) is about half of it: HBM does not bind this kernel; vector-instruction issue stands at valu_issue.frac, and `occupancy` (committed profile) shows what does: the dependent round trip of a step at 4 waves / SIMD. "
             "frac = algorithmic_gbs / 8000 (SURVEY 8d); ceilings lists every measured ceiling with its own fraction, `exceeded` where the kernel runs above it.",
         }
 

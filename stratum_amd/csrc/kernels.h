@@ -512,7 +512,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace_deep(FrameParams p) {
     }
   }
   // The last block to get here leaves the count at zero for the next k_trace launch (no memset between launches): every
-  // block has read the count before it arrives, and nothing else touches it until this kernel has ended.
+  // block has read the count before it arrives, and nothing else touches it until this kernel has ended. With no ray in
+  // the queue (nearly every launch) there is nothing to reset, and the 2048 blocks do not line up on one atomic (~11 ns each).
+  if (count == 0) return;
   __syncthreads();
   if (threadIdx.x == 0 && atomicAdd(p.deep_count + 1, 1u) == gridDim.x - 1u) {
     p.deep_count[0] = 0u;

@@ -43,8 +43,8 @@ def main():
     names = subprocess.run([DEMANGLE], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.split("\n")
     print("%-72s %5s %5s %5s %8s %7s %6s %6s" % ("kernel", "vgpr", "sgpr", "agpr", "scratch", "lds", "vspill", "sspill"))
     for r, n in sorted(zip(rows, names), key=lambda x: x[1]):
-        n = re.sub(r"\(.*", "", n)
-        if filt in n:
+        n = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", ""))
+        if filt in n and "rocprim" not in n and "hipcub" not in n:  # (the library's sort / scan kernels are not ours to tune)
             print("%-72s %5s %5s %5s %8s %7s %6s %6s" % ((n[:72],) + r[1:]))
 
 
