@@ -159,6 +159,16 @@ class OracleScene:
             "is_environment": out[:, 15] != 0,
         }
 
+    def delta_track(self, medium_address, keys, origin, direction, t_max, beta=1.0, can_scatter=True, max_null_collisions=64):
+        """Medium::delta_track (medium.hlsli:74-127), one call per row -> dict of arrays"""
+        keys = np.ascontiguousarray(keys, np.uint32).reshape(-1, 4)
+        n = keys.shape[0]
+        q = np.zeros((n, 8), np.float32)
+        q[:, 0:3], q[:, 3:6], q[:, 6], q[:, 7] = origin, direction, t_max, beta
+        out = np.zeros((n, 16), np.float32)
+        self._L.orc_delta_track(C.c_void_p(self.h), C.c_uint32(medium_address), wire.ptr(keys), wire.ptr(q), C.c_uint32(1 if can_scatter else 0), C.c_uint32(max_null_collisions), wire.ptr(out), C.c_uint32(n))
+        return {"beta": out[:, 0:3], "dir_pdf": out[:, 3:6], "nee_pdf": out[:, 6:9], "position": out[:, 9:12], "scattered": out[:, 12] != 0, "draws": out[:, 13].astype(np.int64)}
+
     def sample_image(self, index, uv_size, ray_cones=True):
         q = np.ascontiguousarray(uv_size, np.float32).reshape(-1, 3)
         out = np.zeros((q.shape[0], 4), np.float32)

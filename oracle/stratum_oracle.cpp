@@ -3989,6 +3989,29 @@ void orc_sample_light(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
     o[15] = ls.is_environment ? 1.0f : 0.0f;
   }
 }
+// One delta_track call per sample (medium.hlsli:74-127) for the medium whose record lies at `medium_address` of the scene's
+// material bytes: in8 = origin, direction (object space of the volume instance), t_max, beta (same for all channels);
+// keys = the rng state (x, y, seed, counter) before the call; out16 = beta, dir_pdf, nee_pdf, scatter position, scattered,
+// counter after (as a float), -, -.
+void orc_delta_track(orc_scene* sc, uint32_t medium_address, const uint32_t* keys, const float* in8, uint32_t can_scatter, uint32_t max_null_collisions, float* out16, uint32_t n) {
+  Medium m;
+  m.load(*sc, medium_address);
+  for (uint32_t i = 0; i < n; i++) {
+    Rng rng;
+    memcpy(rng.v, keys + 4 * (size_t)i, 16);
+    const float* q = in8 + 8 * (size_t)i;
+    v3 beta = V3(q[7]), dir_pdf = V3(1.0f), nee_pdf = V3(1.0f), p = V3(0.0f);
+    const bool scattered = m.delta_track(*sc, rng, V3(q[0], q[1], q[2]), V3(q[3], q[4], q[5]), q[6], beta, dir_pdf, nee_pdf, can_scatter != 0, max_null_collisions, p);
+    float* o = out16 + 16 * (size_t)i;
+    o[0] = beta.x, o[1] = beta.y, o[2] = beta.z;
+    o[3] = dir_pdf.x, o[4] = dir_pdf.y, o[5] = dir_pdf.z;
+    o[6] = nee_pdf.x, o[7] = nee_pdf.y, o[8] = nee_pdf.z;
+    o[9] = p.x, o[10] = p.y, o[11] = p.z;
+    o[12] = scattered ? 1.0f : 0.0f;
+    o[13] = (float)(rng.v[3] - keys[4 * (size_t)i + 3]);
+    o[14] = o[15] = 0.0f;
+  }
+}
 // the NanoVDB reader on its own: header[8] = bbox min, bbox max, grid ok, -; header_f[1] = root maximum; values at coords;
 // maps[m][4][3] = world_to_indexf, world_to_index_dirf of points[m], index_to_worldf of the first, index_to_world_dirf of the second
 int orc_nvdb_probe(const void* grid, uint64_t bytes, const int32_t* coords, uint32_t n, float* values, int32_t* header, float* root_max, const float* points, uint32_t m, float* maps) {

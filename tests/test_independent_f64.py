@@ -10,7 +10,9 @@ oracle and the kernel passes every GPU-vs-oracle test; it does not pass these.
     1 / (2 pi^2 sin theta) Jacobian (environment.h:62-77), against the tables build_distributions makes;
   * sphere lights: cone sampling with its small-angle branch, and uniform-area sampling (light.hlsli:58-121);
   * triangle shading data: the uv Jacobian, dP/du, dP/dv, uv_screen_size and the mean curvature (shading_data.hlsli:2-61);
-  * the integer hash under every random number: pcg4d (rng.hlsli:16-33; Jarzynski and Olano 2020) in Python integers."""
+  * the integer hash under every random number: pcg4d (rng.hlsli:16-33; Jarzynski and Olano 2020) in Python integers;
+  * one delta-tracking segment through a NanoVDB medium (materials/medium.hlsli:74-127): channel choice, free-flight
+    distance, real / null collision, the three throughputs."""
 import numpy as np
 import pytest
 
@@ -328,3 +330,125 @@ def test_pcg4d_in_python_integers():
     assert np.array_equal(got, want)
     # the structure of the hash, from the published listing: the zero vector maps to the LCG increment pushed through the mix
     assert pcg4d([0, 0, 0, 0]) == [int(x) for x in got[500]]
+
+
+# ---------------------------------------------------------------------------------------------
+# one delta-tracking segment through a NanoVDB medium
+# ---------------------------------------------------------------------------------------------
+def test_delta_tracking_segment_against_a_float64_statement():
+    """Medium::delta_track (materials/medium.hlsli:74-127), from the formulas, in float64 with Python-integer random numbers:
+    majorant = density_scale * the grid's root maximum; one colour channel drawn with rng % 3; a free-flight distance
+    t = unit * -log(1 - r0) / majorant[channel]; if it ends inside the segment, the local density decides between a real
+    collision (r1 < sigma_t / majorant of that channel: beta *= tr * sigma_s, the position comes back in world space) and a
+    null collision, which ENDS the walk upstream (beta *= tr * (majorant - sigma_t), tr = exp(-majorant t) / max(majorant));
+    otherwise the segment is crossed (all three throughputs *= exp(-majorant t_max)). The grid itself (values, root maximum,
+    the index / world maps) is read by the NanoVDB reader that tests/test_oracle.py pins against the reference's own PNanoVDB.h."""
+    import os
+
+    M = 1 << 32
+
+    def pcg4d(v):
+        v = [(x * 1664525 + 1013904223) % M for x in v]
+        for _ in range(2):
+            v[0] = (v[0] + v[1] * v[3]) % M
+            v[1] = (v[1] + v[2] * v[0]) % M
+            v[2] = (v[2] + v[0] * v[1]) % M
+            v[3] = (v[3] + v[1] * v[2]) % M
+            if _ == 0:
+                v = [x ^ (x >> 16) for x in v]
+        return v
+
+    def draws(key, n):
+        out = []
+        for k in range(n):
+            out.append(pcg4d([int(key[0]), int(key[1]), int(key[2]), (int(key[3]) + 1 + k) % M])[0])
+        return out
+
+    to_float = lambda u: float(np.array([0x3F800000 | (u >> 9)], np.uint32).view(np.float32)[0]) - 1.0  # rng_next_float, rng.hlsli:35-37
+
+    grid = np.load(os.path.join(os.path.dirname(__file__), "golden", "fog_sphere.npz"))["grid"]
+    density_scale, albedo_scale, unit = np.array([3.0, 2.0, 1.5]), np.array([0.9, 0.6, 0.3]), 0.7
+    sc0, _ = scenes.furnace_box(albedo=0.5, emission=1.0)
+    b = sc0.builder
+    b.add_medium(b.add_volume(grid), density_scale=tuple(density_scale), albedo_scale=tuple(albedo_scale), anisotropy=0.3, attenuation_unit=unit)
+    sc = b.build()
+    o = orc.OracleScene(sc)
+    address = int(sc.instances["packed"][-1][0]) >> 4
+    bmin, bmax, root_max, _, _ = orc.nvdb_probe(grid, np.zeros((1, 3), np.int32), np.zeros((1, 3), np.float32))
+    assert root_max > 0
+
+    n = 3000
+    rs = np.random.RandomState(11)
+    keys = rs.randint(0, 1 << 31, (n, 4)).astype(np.uint32)
+    # rays through the grid's world-space box (the sphere of fog sits in its middle), some segments short, some long
+    # (the grid's map is affine: world_to_index(p) = B p + c, read off the pinned reader at the origin and the unit points)
+    _, _, _, _, unit_maps = orc.nvdb_probe(grid, np.zeros((1, 3), np.int32), np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32))
+    c0 = unit_maps[0, 0].astype(np.float64)
+    B = np.stack([unit_maps[1 + i, 0].astype(np.float64) - c0 for i in range(3)], 1)
+    corners = np.linalg.solve(B, (np.stack([bmin, bmax]).astype(np.float64) - c0).T).T  # index_to_world of the index box
+    wlo, whi = corners.min(0), corners.max(0)
+    origin = rs.uniform(wlo, whi, (n, 3)).astype(np.float32)
+    direction = rs.normal(size=(n, 3))
+    direction = (direction / np.linalg.norm(direction, axis=1, keepdims=True)).astype(np.float32)
+    t_max = rs.choice([0.02, 0.1, 0.5, 3.0], n).astype(np.float32) * float(np.linalg.norm(whi - wlo))
+    for can_scatter in (True, False):
+        got = o.delta_track(address, keys, origin, direction, t_max, beta=1.0, can_scatter=can_scatter)
+        _, _, _, _, maps = orc.nvdb_probe(grid, np.zeros((1, 3), np.int32), np.stack([origin, direction], 1).reshape(-1, 3))
+        # (maps[m] = world_to_index of point m, world_to_index_dir of point m, ...: rows 2 k and 2 k + 1 are sample k's origin and direction)
+        o_idx, d_idx = maps[0::2, 0].astype(np.float64), maps[1::2, 1].astype(np.float64)
+        majorant = density_scale * float(root_max)
+        checked = {"real": 0, "null": 0, "crossed": 0}
+        lookups, where = [], []
+        plan = []
+        for k in range(n):
+            u = draws(keys[k], 3)
+            c = u[0] % 3
+            r0, r1 = to_float(u[1]), to_float(u[2])
+            t = unit * -np.log(1.0 - r0) / majorant[c]
+            tm = float(t_max[k])
+            if abs(t - tm) < 1e-4 * tm:
+                plan.append(None)  # the two precisions may disagree about which side of the segment's end t falls
+                continue
+            plan.append((c, r1, t, tm))
+            if t < tm:
+                pos = o_idx[k] + d_idx[k] * t
+                if np.abs(pos - np.round(pos)).min() < 1e-3:
+                    plan[-1] = None  # too close to a voxel face for the two precisions to pick the same voxel
+                    continue
+                lookups.append(np.floor(pos).astype(np.int32))
+                where.append(k)
+        _, _, _, dens, _ = orc.nvdb_probe(grid, np.array(lookups, np.int32), np.zeros((1, 3), np.float32))
+        density_at = dict(zip(where, dens.astype(np.float64)))
+        for k in range(n):
+            if plan[k] is None:
+                continue
+            c, r1, t, tm = plan[k]
+            assert got["draws"][k] == 3  # the channel and one pair of numbers: the walk ends at its first event
+            if t < tm:
+                local = density_scale * density_at[k]
+                sigma_s, sigma_t = local * albedo_scale, local * albedo_scale + local * (1 - albedo_scale)
+                real_prob = sigma_t / majorant
+                tr = np.exp(-majorant * t) / majorant.max()
+                if abs(r1 - real_prob[c]) < 1e-5:
+                    continue
+                if can_scatter and r1 < real_prob[c]:
+                    assert got["scattered"][k]
+                    assert np.allclose(got["beta"][k], tr * sigma_s, rtol=2e-5, atol=1e-9)
+                    assert np.allclose(got["dir_pdf"][k], tr * majorant * real_prob, rtol=2e-5, atol=1e-9)
+                    assert np.allclose(got["nee_pdf"][k], 1.0)
+                    # the position comes back in world space; the map is affine, so that is the point t along the world-space ray
+                    assert np.allclose(got["position"][k], origin[k].astype(np.float64) + direction[k].astype(np.float64) * t, rtol=1e-4, atol=1e-4 * float(np.linalg.norm(whi - wlo)))
+                    checked["real"] += 1
+                else:
+                    assert not got["scattered"][k]
+                    assert np.allclose(got["beta"][k], tr * (majorant - sigma_t), rtol=2e-5, atol=1e-9)
+                    assert np.allclose(got["dir_pdf"][k], tr * majorant * (1 - real_prob), rtol=2e-5, atol=1e-9)
+                    assert np.allclose(got["nee_pdf"][k], tr * majorant, rtol=2e-5, atol=1e-9)
+                    checked["null"] += 1
+            else:
+                tr = np.exp(-majorant * tm)
+                assert not got["scattered"][k]
+                for name in ("beta", "dir_pdf", "nee_pdf"):
+                    assert np.allclose(got[name][k], tr, rtol=2e-5, atol=1e-12)
+                checked["crossed"] += 1
+        assert checked["null"] > 100 and checked["crossed"] > 100 and (checked["real"] > 100) == can_scatter, checked
