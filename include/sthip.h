@@ -284,7 +284,8 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s);
  * 1 = always (default) — host-built trees are collapsed on the host, the GPU builder's trees and the tree of a
  * transforms-only update on the device; 0 = never; 2 = only when the binary nodes exceed 4 MiB, one XCD's L2; not with
  * "treetop" or "embed_leaves"), "hashgrid_serial" (0/1: build the reservoir-reuse hash grids with the one-thread serial probe
- * sequence instead of the parallel device build: the same grids, for tests),
+ * sequence instead of the parallel device build: the same grids, for tests), "cull_terminal" (default 1: in a round where the
+ * path or diffuse budget can end, only the paths that still have something to do reach the shading kernel),
  * "treetop" (default 0), "embed_leaves" (default 0), "lds_materials" (default 1), "lds_stack_levels" (4..150: LDS levels of the traversal stack; a higher
  * tree runs the bounded kernels, default: bounded at 32 levels beyond a height of 40): layout / scheduling options that
  * never change results, read at the next sthip_scene_upload / sthip_scene_update_transforms */

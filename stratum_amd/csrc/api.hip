@@ -142,7 +142,10 @@ struct sthip_ctx {
   DevBuf<uint8_t> views;  // gViews | gViewTransforms | gPrevViews | gPrevInverseViewTransforms
   DevBuf<float4> ray_o, ray_d, hit, beta, radiance, shadow_sum, accum, shadow_rays, light_vertices, conn, media_state, shadow_hit, shadow_ext, shadow_result;
   DevBuf<uint32_t> view_medium;
-  DevBuf<uint32_t> meta, queue0, queue1;
+  DevBuf<uint32_t> meta, queue0, queue1, queue_kept;
+  // "cull_terminal": 1 (default) = in a round where paths can reach their last vertex, k_cull_terminal hands k_shade only the
+  // paths that still have something to do (kernels.h); 0 = k_shade sees the whole queue. Same frames either way.
+  int cull_terminal = 1;
   DevBuf<unsigned long long> counters;
   DevBuf<float> distributions;  // gDistributions
   DevBuf<float4> presampled;    // gPresampledLights
@@ -394,6 +397,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->fuse_trace = value != 0;
   else if (!strcmp(name, "packet_primary"))
     ctx->packet_primary = value != 0;
+  else if (!strcmp(name, "cull_terminal"))
+    ctx->cull_terminal = value != 0;
   else if (!strcmp(name, "refill_idle"))
     ctx->refill_idle = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
   else if (!strcmp(name, "bvh_builder"))
@@ -1280,6 +1285,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   HIP_TRY(ctx, ctx->meta.ensure(P));
   HIP_TRY(ctx, ctx->queue0.ensure(seg_stride * QUEUE_SEGMENTS));
   HIP_TRY(ctx, ctx->queue1.ensure(seg_stride * QUEUE_SEGMENTS));
+  HIP_TRY(ctx, ctx->queue_kept.ensure(seg_stride * QUEUE_SEGMENTS));
   HIP_TRY(ctx, ctx->counters.ensure(CNT_TOTAL));
   HIP_TRY(ctx, ctx->qctl.ensure((size_t)2 * 64 * QUEUE_SEGMENTS * QCTL_STRIDE));
   // ePresampleLights (BDPT.cpp:644-651): gLightPresampleTileSize x TileCount light points per seed in flight
@@ -1413,6 +1419,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   }
   p.count_traversal = ctx->count_traversal ? 1u : 0u;
   p.refill_idle = ctx->refill_idle;
+  p.culled = 0;
   p.inner_min_lanes = ctx->inner_min_lanes;
 
   // outputs: device pointers are written in place, host pointers go through staging buffers
@@ -1740,7 +1747,14 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
         hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
       else if (ext)
         hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
-      else
+      else if (ctx->cull_terminal && depth >= 1 && !p.rr && !p.cs_nee && !p.cs_lvc && (depth + 2 >= pc->gMaxPathVertices || depth + 1 > pc->gMaxDiffuseVertices)) {
+        // the path or diffuse budget can end at this round's vertex: only the paths that still have something to do reach k_shade
+        hipLaunchKernelGGL(k_cull_terminal, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth, ctx->queue_kept.p);
+        FrameParams pk = p;
+        pk.queue[depth & 1u] = ctx->queue_kept.p;
+        pk.culled = 1;
+        hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, pk, depth);
+      } else
         hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
     });
     if (rc) return rc;

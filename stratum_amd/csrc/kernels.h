@@ -147,6 +147,7 @@ struct FrameParams {
   uint32_t count_traversal;
   uint32_t refill_idle;      // persistent trace kernels: refill when this many lanes of a wave are idle
   uint32_t inner_min_lanes;  // leave the inner-node loop when fewer lanes than this are still walking
+  uint32_t culled;           // k_shade: queue[depth & 1] is what k_cull_terminal kept of the round's queue (sizes in QCTL_KEPT)
 };
 
 DEV bool flag(const FrameParams& p, int bit) { return (p.sampling_flags >> bit) & 1u; }
@@ -1172,7 +1173,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
     slot0 = seg * per;
     n = slot0 < p.path_count ? (slot0 + per < p.path_count ? per : p.path_count - slot0) : 0u;
   } else {
-    n = (uint32_t)queue_ctl(p.qctl, 0, depth, seg)[QCTL_SIZE];
+    n = (uint32_t)queue_ctl(p.qctl, 0, depth, seg)[p.culled ? QCTL_KEPT : QCTL_SIZE];
   }
   const uint32_t first = (blockIdx.x / QUEUE_SEGMENTS) * blockDim.x + threadIdx.x;
   const uint32_t step = ((gridDim.x - seg + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) * blockDim.x;
@@ -2155,6 +2156,50 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
       }
       const uint32_t k = (uint32_t)atomicAdd(queue_size, 1ull);
       queue_out[k] = slot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cull_terminal: in front of k_shade in a round where paths can reach their last vertex (the path or diffuse budget ends
+// there, path.hlsli:964-966,1061): such a vertex can only still ADD the emission of what was hit (eval_emission,
+// path.hlsli:847-894), so a path that ends on a surface without emission — nearly all of them — has nothing left to do:
+// k_shade would fetch indices, vertices and transform, build the shading data, find Le = 0 and stop, writing back the
+// radiance it read. This pass reads hit -> instance -> material only and keeps the paths that have something to do, packed
+// (ballot ranks, one atomic per wave), so that k_shade's waves are full of them. Plain instantiation only (no textures —
+// Le would need the uv —, no spheres / environment, no light subpaths, no media), which is the headline path.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(STHIP_BLOCK) k_cull_terminal(FrameParams p, uint32_t depth, uint32_t* kept) {
+  const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
+  const uint32_t seg_base = seg * p.seg_stride;
+  unsigned long long* line = queue_ctl(p.qctl, 0, depth, seg);
+  const uint32_t n = (uint32_t)line[QCTL_SIZE];
+  const uint32_t first = (blockIdx.x / QUEUE_SEGMENTS) * blockDim.x + threadIdx.x;
+  const uint32_t step = ((gridDim.x - seg + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) * blockDim.x;
+  const uint32_t* queue_in = p.queue[depth & 1u] + seg_base;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t i = first; __any(i < n); i += step) {  // (a wave's lanes hold consecutive i: they leave the loop together)
+    bool keep = false;
+    uint32_t slot = 0;
+    if (i < n) {
+      slot = queue_in[i];
+      const uint32_t meta = p.meta[slot];
+      const uint32_t ip = __float_as_uint(p.hit[slot].w);
+      if (meta < 0xFFFFFFFEu && ip != 0xFFFFFFFFu) {  // (a miss without an environment adds nothing: path.hlsli:1049-1058)
+        const uint32_t path_length = (meta & 0xFFu) + 1u, diffuse_vertices = (meta >> 8) & 0xFFu;
+        const Inst in = load_inst(p.scene, ip & 0xFFFFu);
+        DisneyMaterial m;
+        m.load(p.scene, in.material_address());
+        const bool last = !m.can_eval() || path_length >= p.pc.gMaxPathVertices || (!m.is_specular() && diffuse_vertices + 1u > p.pc.gMaxDiffuseVertices);
+        keep = !(last && all_le0(m.Le()));
+      }
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (mask) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(&line[QCTL_KEPT], (unsigned long long)__popcll(mask));
+      const uint32_t b32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+      if (keep) kept[seg_base + b32 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
     }
   }
 }

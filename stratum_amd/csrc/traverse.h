@@ -660,6 +660,7 @@ DEV bool traverse(const DeviceBvh& bvh, f3 o, f3 d, float tmin, float tmax, uint
 #define QCTL_STRIDE 32u  // 64-bit words per segment: two 128-byte lines, so that reading the size (constant while a
                          // consumer runs) never touches the line its dequeue atomics keep busy
 #define QCTL_SIZE 0u     // word: entries produced
+#define QCTL_KEPT 1u     // word: entries k_cull_terminal kept for k_shade (kernels.h)
 #define QCTL_HEAD 16u    // word: dequeue head of the consuming trace kernel
 // control line of (kind: 0 = path queue entering bounce `depth`, 1 = shadow rays of bounce `depth`; depth < 64; segment)
 DEV unsigned long long* queue_ctl(unsigned long long* qctl, uint32_t kind, uint32_t depth, uint32_t seg) {

@@ -1544,3 +1544,63 @@ def test_treetop_and_packed_nodes_do_not_change_results(atrium_scene):
         assert np.array_equal(a["radiance"].view(np.uint32), b["radiance"].view(np.uint32))
         assert np.array_equal(a["visibility"]["instance_primitive_index"], b["visibility"]["instance_primitive_index"])
         assert np.array_equal(a["ray_count"], b["ray_count"])
+
+
+def _cornell_with_a_mirror_and_glass():
+    """The Cornell box plus a mirror on the back wall and a pane of glass in front of the blocks (triangles only, no textures:
+    the plain k_shade instantiation): specular vertices do not count against the diffuse budget."""
+    from stratum_amd.scene import translate
+
+    sc0, cam = scenes.cornell_box()
+    b = sc0.builder
+    mirror = b.add_material((0.95, 0.95, 0.95), metallic=1.0, roughness=0.0)
+    glass = b.add_material((1.0, 1.0, 1.0), transmission=1.0, roughness=0.0, eta=1.5)
+    pos, nrm, uv, tri = scenes._quad((-0.7, -0.6, -0.99), (0.7, -0.6, -0.99), (0.7, 0.7, -0.99), (-0.7, 0.7, -0.99), (0, 0, 1))
+    b.add_instance(b.add_mesh(pos, nrm, uv, tri), mirror)
+    pos, nrm, uv, tri = scenes._quad((-0.8, -0.9, 0.0), (0.8, -0.9, 0.0), (0.8, 0.2, 0.0), (-0.8, 0.2, 0.0), (0, 0, 1))
+    b.add_instance(b.add_mesh(pos, nrm, uv, tri), glass, translate((0.0, 0.0, 0.85)))
+    return b.build(), cam
+
+
+def test_culling_finished_paths_in_front_of_k_shade_does_not_change_results(atrium_scene):
+    """k_cull_terminal (kernels.h, option "cull_terminal"): in a round where the path or diffuse budget can end, only the
+    paths that still have something to do — an emitter was hit, or a specular vertex lets the path go on — are handed to
+    k_shade. Frames and ray counts with and without it are bit-identical, for budgets that end paths by their length, by
+    their diffuse vertices, or (mirrors / glass in the scene) leave some of them running; one of them against the oracle."""
+    from oracle import oracle_py as orc
+    from stratum_amd.bdpt import BDPT
+
+    cases = (
+        (lambda: atrium_scene, {}, (320, 192)),
+        (lambda: atrium_scene, {"maxDiffuseVertices": 3, "maxPathVertices": 4}, (256, 160)),
+        (lambda: atrium_scene, {"maxDiffuseVertices": 4, "maxPathVertices": 9, "minPathVertices": 3}, (256, 160)),
+        (scenes.cornell_box, {"maxDiffuseVertices": 1, "maxPathVertices": 6}, (200, 200)),
+        (scenes.cornell_box, {"maxDiffuseVertices": 5, "maxPathVertices": 3}, (200, 200)),
+        (_cornell_with_a_mirror_and_glass, {"maxDiffuseVertices": 2, "maxPathVertices": 8}, (240, 160)),
+    )
+    for make, args, (W, H) in cases:
+        sc, cam = make()
+        frame = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+        frames = []
+        for cull in (1, 0):
+            r = BDPT(device=0, args=args)
+            try:
+                r.set_option("cull_terminal", cull)
+                r.update(sc)
+                frames.append(r.render(frame, 3, 2))
+            finally:
+                r.close()
+        a, b = frames
+        assert np.array_equal(a["radiance"].view(np.uint32), b["radiance"].view(np.uint32)), args
+        assert np.array_equal(a["ray_count"], b["ray_count"]), args
+        assert a["radiance"][..., :3].max() > 0
+    # ... and the culled frame is the oracle's (the last case: mirrors and glass keep some paths alive past the diffuse budget)
+    o = orc.OracleScene(sc)
+    r = BDPT(device=0, args=args)
+    try:
+        r.update(sc)
+        pc = r.push_constants(frame)
+        ref = o.render(frame, pc, r.mSamplingFlags, 3, 2)
+    finally:
+        r.close()
+    assert np.array_equal(a["radiance"].view(np.uint32), ref["radiance"].view(np.uint32))
