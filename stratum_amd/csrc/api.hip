@@ -169,6 +169,7 @@ struct sthip_ctx {
   DevBuf<float> image1_texels;
   DevBuf<BvhTriUv> tri_uvs;
   DevBuf<uint32_t> inst_alpha;
+  DevBuf<uint8_t> inst_flags;  // per instance: INST_FLAG_* of its (untextured) material, for k_cull_terminal
   DevBuf<unsigned long long> qctl;  // queue control lines (queue_ctl)
   DevBuf<uint32_t> post_scratch;  // maxima / metric accumulator of post.h
   DevBuf<sthip_ray> ray_staging;  // sthip_trace_rays with host pointers
@@ -356,6 +357,7 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->image1_texels.release();
   ctx->tri_uvs.release();
   ctx->inst_alpha.release();
+  ctx->inst_flags.release();
   ctx->qctl.release();
   ctx->post_scratch.release();
   ctx->out_radiance.release();
@@ -557,6 +559,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     if (lo != lo || hi != hi) lo = -__builtin_inff(), hi = __builtin_inff();
   };
   // materials: constant values or image values over gImages (image_value.h:183-207)
+  std::vector<uint8_t> inst_flags(std::max<uint32_t>(1, s->instance_count), (uint8_t)INST_FLAG_KEEP);  // k_cull_terminal's table (kernels.h)
   for (uint32_t i = 0; i < s->instance_count; i++) {
     const uint32_t addr = s->gInstances[i].packed[0] >> 4;
     if ((s->gInstances[i].packed[0] & 0xF) == STHIP_INSTANCE_TYPE_VOLUME) {  // a Medium record (Material.hpp:80-87), 40 bytes
@@ -592,7 +595,20 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     value_range(rec, 1, 1, roughness_lo, lo);
     value_range(rec, 2, 2, lo, transmission_hi);
     if ((metallic_hi > 0.999f || transmission_hi > 0.999f) && roughness_lo <= 1e-2f) any_specular = true;
+    if ((s->gInstances[i].packed[0] & 0xF) == STHIP_INSTANCE_TYPE_TRIANGLES) {
+      // what DisneyMaterial::load reads of an untextured record (shading.h), with the device's arithmetic: Le = base_color *
+      // emission, can_eval, is_specular (only the plain k_shade instantiation, i.e. a scene without images, consults this)
+      float f[14];
+      memcpy(f, (const uint8_t*)s->gMaterialData + addr, sizeof(f));
+      const float le[3] = {f[0] * f[3], f[1] * f[3], f[2] * f[3]};
+      const bool emits = le[0] > 0 || le[1] > 0 || le[2] > 0;
+      const bool can_eval = f[3] <= 0 && (f[0] > 0 || f[1] > 0 || f[2] > 0);
+      const bool specular = (f[5] > 0.999f || f[12] > 0.999f) && f[6] <= 1e-2f;
+      inst_flags[i] = (uint8_t)((emits ? INST_FLAG_EMITS : 0) | (can_eval ? INST_FLAG_CAN_EVAL : 0) | (specular ? INST_FLAG_SPECULAR : 0));
+    }
   }
+  HIP_TRY(ctx, ctx->inst_flags.ensure(inst_flags.size()));
+  HIP_TRY(ctx, hipMemcpy(ctx->inst_flags.p, inst_flags.data(), inst_flags.size(), hipMemcpyHostToDevice));
   ctx->has_specular = any_specular;
   ctx->textured = any_image;
   if (s->image_count && !s->gImages) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "scene: image_count > 0 but gImages is NULL");
@@ -1420,6 +1436,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.count_traversal = ctx->count_traversal ? 1u : 0u;
   p.refill_idle = ctx->refill_idle;
   p.culled = 0;
+  p.inst_flags = ctx->inst_flags.p;
   p.inner_min_lanes = ctx->inner_min_lanes;
 
   // outputs: device pointers are written in place, host pointers go through staging buffers

@@ -148,7 +148,14 @@ struct FrameParams {
   uint32_t refill_idle;      // persistent trace kernels: refill when this many lanes of a wave are idle
   uint32_t inner_min_lanes;  // leave the inner-node loop when fewer lanes than this are still walking
   uint32_t culled;           // k_shade: queue[depth & 1] is what k_cull_terminal kept of the round's queue (sizes in QCTL_KEPT)
+  const uint8_t* inst_flags; // per instance: INST_FLAG_* of its material (scenes without images), for k_cull_terminal
 };
+// DisneyMaterial::Le() > 0 somewhere / can_eval() / is_specular() of an instance's untextured material, evaluated on the host with
+// the device's arithmetic at upload (api.hip); KEEP: not a triangle instance, no statement made
+#define INST_FLAG_EMITS 1u
+#define INST_FLAG_CAN_EVAL 2u
+#define INST_FLAG_SPECULAR 4u
+#define INST_FLAG_KEEP 0x80u
 
 DEV bool flag(const FrameParams& p, int bit) { return (p.sampling_flags >> bit) & 1u; }
 
@@ -2165,7 +2172,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
 // there, path.hlsli:964-966,1061): such a vertex can only still ADD the emission of what was hit (eval_emission,
 // path.hlsli:847-894), so a path that ends on a surface without emission — nearly all of them — has nothing left to do:
 // k_shade would fetch indices, vertices and transform, build the shading data, find Le = 0 and stop, writing back the
-// radiance it read. This pass reads hit -> instance -> material only and keeps the paths that have something to do, packed
+// radiance it read. This pass reads the hit and one byte about the instance's material only and keeps the paths that have something to do, packed
 // (ballot ranks, one atomic per wave), so that k_shade's waves are full of them. Plain instantiation only (no textures —
 // Le would need the uv —, no spheres / environment, no light subpaths, no media), which is the headline path.
 // ---------------------------------------------------------------------------------------------
@@ -2187,11 +2194,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_cull_terminal(FrameParams p, ui
       const uint32_t ip = __float_as_uint(p.hit[slot].w);
       if (meta < 0xFFFFFFFEu && ip != 0xFFFFFFFFu) {  // (a miss without an environment adds nothing: path.hlsli:1049-1058)
         const uint32_t path_length = (meta & 0xFFu) + 1u, diffuse_vertices = (meta >> 8) & 0xFFu;
-        const Inst in = load_inst(p.scene, ip & 0xFFFFu);
-        DisneyMaterial m;
-        m.load(p.scene, in.material_address());
-        const bool last = !m.can_eval() || path_length >= p.pc.gMaxPathVertices || (!m.is_specular() && diffuse_vertices + 1u > p.pc.gMaxDiffuseVertices);
-        keep = !(last && all_le0(m.Le()));
+        const uint32_t f = p.inst_flags[ip & 0xFFFFu];
+        const bool last = !(f & INST_FLAG_CAN_EVAL) || path_length >= p.pc.gMaxPathVertices || (!(f & INST_FLAG_SPECULAR) && diffuse_vertices + 1u > p.pc.gMaxDiffuseVertices);
+        keep = (f & (INST_FLAG_KEEP | INST_FLAG_EMITS)) || !last;
       }
     }
     const unsigned long long mask = __ballot(keep);
