@@ -97,6 +97,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ceilings", action="store_true", help="skip the measured ceilings (profiling runs)")
+    ap.add_argument("--no-last-ray-filter", action="store_true", help="skip the extra timed pass with answer_last_rays = 1 (profiling runs: one configuration per trace)")
     ap.add_argument("--radiance-only", action="store_true", help="do not write the G-buffer AOVs (not the headline configuration)")
     ap.add_argument("--bdpt-flag", action="append", default=[], help="as the reference's --bdptFlag (e.g. connecttolightpaths, ~nee); not the headline configuration")
     ap.add_argument("--max-diffuse-vertices", type=int, default=None)
@@ -200,6 +201,10 @@ def main():
         bargs["maxDiffuseVertices"] = args.max_diffuse_vertices
     r = BDPT(device=local_rank, args=bargs)
     r.update(sc)
+    # The headline traces EVERY ray. The library's default answers the last ray of a path from the emitters' bounds when it cannot
+    # reach one (sthip.h "answer_last_rays": same frames, same gRayCount, 1/5 of the rays of this workload never walk the tree);
+    # that configuration is timed separately below and reported as `last_ray_filter`, never as `value`.
+    r.set_option("answer_last_rays", 0)
     r.set_shard(rank, world, 64, 32)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     radiance = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
@@ -290,10 +295,12 @@ def main():
         rep_dt.append(time.perf_counter() - t0)
     # rays of the timed region: the same steps again with the counters read back (untimed; every repetition traces
     # the same seeds, hence the same rays)
-    rays_local = 0
+    rays_local = answered_local = 0
     for i in range(args.steps):
         r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
-        rays_local += r.stats()["rays_total"]
+        st = r.stats()
+        rays_local += st["rays_total"]
+        answered_local += st["rays_answered"]  # of them: last rays of paths answered from the emitters' bounds, no traversal (sthip.h)
     # the exchange alone (untimed region): the gather of one step's packed tiles and their assembly, between syncs, so that
     # a scaling record can be split into render time and exchange time
     exchange_ms = 0.0
@@ -311,19 +318,19 @@ def main():
             finish(k)
         barrier()
         exchange_ms = (time.perf_counter() - t0) / args.steps * 1e3
-    t = torch.tensor(rep_dt + [float(rays_local)], dtype=torch.float64, device="cuda")
+    t = torch.tensor(rep_dt + [float(answered_local), float(rays_local)], dtype=torch.float64, device="cuda")
     devices = [{"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank), "median_ms_per_step": round(float(np.median(rep_dt)) / args.steps * 1e3, 3), "rays_per_step": int(rays_local / args.steps)}]
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)  # per repetition: the slowest rank
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        rep_all, rays_all = [float(x) for x in tmax[:-1]], float(t[-1])
+        rep_all, rays_all, answered_all = [float(x) for x in tmax[:-2]], float(t[-1]), float(t[-2])
         gathered_devices = [None] * world
         dist.all_gather_object(gathered_devices, devices[0])
         devices = gathered_devices
         world_seen, backend_seen = dist.get_world_size(), dist.get_backend()
     else:
-        rep_all, rays_all = [float(x) for x in t[:-1]], float(t[-1])
+        rep_all, rays_all, answered_all = [float(x) for x in t[:-2]], float(t[-1]), float(t[-2])
         world_seen, backend_seen = 1, "none"
     dt_all = float(np.median(rep_all))
 
@@ -357,7 +364,7 @@ def main():
             rays_closest -= s["rays_primary_packets"]
             nodes_sh += s["nodes_visited_shadow"]
             tris_sh += s["tris_tested_shadow"]
-            rays_closest += s["rays_path"]
+            rays_closest += s["rays_path"] - s["rays_answered"]  # (answered last rays never reach k_trace)
             rays_shadow += s["rays_shadow"]
             lanes["inner"][0] += s["nodes_visited"] - s["nodes_visited_primary"] + s["nodes_visited_shadow"]
             lanes["inner"][1] += s["inner_slots"][0] + s["inner_slots"][1]
@@ -469,6 +476,40 @@ def main():
             "frac = algorithmic_gbs / 8000 (SURVEY 8d); ceilings lists every measured ceiling with its own fraction, `exceeded` where the kernel runs above it.",
         }
 
+        # ---- the library's default: last rays answered from the emitters' bounds (identical frames and ray counts). Timed the same
+        # way as the headline, reported beside it: rays = the reference's trace_ray calls (gRayCount), of which `answered` walk no tree.
+        last_ray_filter = None
+        if world == 1 and not args.no_last_ray_filter:
+            r.set_option("answer_last_rays", 1)
+            for i in range(2):
+                step(i)
+            reps_f = []
+            for _ in range(3):
+                barrier()
+                tf0 = time.perf_counter()
+                for i in range(args.steps):
+                    step(args.warmup + i)
+                barrier()
+                reps_f.append(time.perf_counter() - tf0)
+            frays = fans = 0
+            for i in range(args.steps):
+                r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
+                st = r.stats()
+                frays += st["rays_total"]
+                fans += st["rays_answered"]
+            r.set_option("answer_last_rays", 0)
+            dtf = float(np.median(reps_f))
+            last_ray_filter = {
+                "option": "answer_last_rays = 1 (the library's default; `value` above is measured with 0: every ray traced)",
+                "value": round(frays / dtf / 1e6, 2),
+                "unit": "Mray/s (gRayCount semantics: the reference's trace_ray calls of the identical frame)",
+                "ms_per_step": round(dtf / args.steps * 1e3, 3),
+                "rays_per_step": int(frays / args.steps),
+                "rays_answered_without_traversal_per_step": int(fans / args.steps),
+                "value_traversed_rays_only": round((frays - fans) / dtf / 1e6, 2),
+                "what": "a path's last ray (the path / diffuse budget ends at its far end: it can only still find an emitter) is queued only if it can reach the bounds of an emissive instance; frames and ray counts are bit-identical (tests/test_gpu_parity.py)",
+            }
+
         # ---- the same steps through HOST output pointers (what a caller without device buffers pays): the frame comes
         # back over PCIe inside the call. Reported next to `value`, never as `value`.
         host_rate = None
@@ -549,6 +590,7 @@ def main():
                 "workload": "procedural %s, %d triangles, %dx%d, %d sample(s)/pixel/step, %s, %s, pixel-tile shard 64x32 over %d GPU(s)"
                 % (args.scene, sc.triangle_count, W, H, seeds_per_step, flags_text, "radiance only" if args.radiance_only else "radiance + albedo/visibility/depth/prev-uv AOVs written", world),
                 "rays_per_step": int(rays_all / args.steps),
+                "rays_answered_without_traversal_per_step": int(answered_all / args.steps),  # 0: the headline traces every ray (last_ray_filter below is the other configuration)
                 "parallelism": "tile-shard x%d" % world if world > 1 else "single GPU",
                 "exchange": exchange,
                 "exchange_alone_ms_per_step": round(exchange_ms, 4) if world > 1 else None,  # gather + assembly of one step's tiles, not overlapped (in the timed region it runs behind the next step's render)
@@ -558,6 +600,7 @@ def main():
                 "devices": devices,
             },
             "repetitions": {"n": len(rep_all), "ms_per_step": [round(x / args.steps * 1e3, 3) for x in rep_all], "value_is": "median"},
+            "last_ray_filter": last_ray_filter,
             "host_output_value": host_rate,  # Mray/s with the radiance image copied to host memory inside every call
             "roofline": roofline,
             "cpu_baseline": cpu,

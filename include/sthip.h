@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STHIP_ABI_VERSION 8
+#define STHIP_ABI_VERSION 9
 
 typedef struct sthip_ctx sthip_ctx;
 
@@ -259,6 +259,11 @@ typedef struct sthip_stats {
    * sentinel or an instance entry, [3] without a ray; [4] 64 per leaf phase, the lanes that [5] test a triangle and
    * [6] handle a sentinel or an entry in it; [7] 64 per refill stop of a wave */
   uint64_t lane_states[8];
+  /* of rays_total / rays_path: last rays of paths — the path or diffuse budget ends at their far end, so they could only
+   * still find an emitter — that missed the bounds of every emissive instance and were answered without a traversal
+   * ("answer_last_rays" = 1, the default; scenes without images, spheres, environment or media). They are trace_ray calls of
+   * the reference and are counted as such; nodes_visited etc. hold no visits for them */
+  uint64_t rays_answered;
 } sthip_stats;
 int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out);
 
@@ -285,7 +290,8 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s);
  * transforms-only update on the device; 0 = never; 2 = only when the binary nodes exceed 4 MiB, one XCD's L2; not with
  * "treetop" or "embed_leaves"), "hashgrid_serial" (0/1: build the reservoir-reuse hash grids with the one-thread serial probe
  * sequence instead of the parallel device build: the same grids, for tests), "cull_terminal" (default 1: in a round where the
- * path or diffuse budget can end, only the paths that still have something to do reach the shading kernel),
+ * path or diffuse budget can end, only the paths that still have something to do reach the shading kernel), "answer_last_rays"
+ * (default 1: a path's last ray is traced only if it can reach the bounds of an emissive instance; sthip_stats::rays_answered),
  * "treetop" (default 0), "embed_leaves" (default 0), "lds_materials" (default 1), "lds_stack_levels" (4..150: LDS levels of the traversal stack; a higher
  * tree runs the bounded kernels, default: bounded at 32 levels beyond a height of 40): layout / scheduling options that
  * never change results, read at the next sthip_scene_upload / sthip_scene_update_transforms */

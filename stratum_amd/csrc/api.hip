@@ -170,6 +170,12 @@ struct sthip_ctx {
   DevBuf<BvhTriUv> tri_uvs;
   DevBuf<uint32_t> inst_alpha;
   DevBuf<uint8_t> inst_flags;  // per instance: INST_FLAG_* of its (untextured) material, for k_cull_terminal
+  std::vector<uint8_t> inst_flags_host;
+  // "answer_last_rays": 1 (default) = the last ray of a path is only queued if it can reach the bounds of an emissive instance
+  // (kernels.h: aims_at_emitter); 0 = every ray is queued and traced. Same frames and ray counts either way.
+  int answer_last_rays = 1;
+  DevBuf<EmitterBounds> emitters;
+  uint32_t emitter_count = 0;  // 0: not applicable to this scene (no or too many emissive triangle instances)
   DevBuf<unsigned long long> qctl;  // queue control lines (queue_ctl)
   DevBuf<uint32_t> post_scratch;  // maxima / metric accumulator of post.h
   DevBuf<sthip_ray> ray_staging;  // sthip_trace_rays with host pointers
@@ -251,6 +257,7 @@ static void fill_counter_stats(sthip_ctx* ctx, const unsigned long long* c) {
     ctx->stats.busy_rounds[k] = c[CNT_BUSY_ROUNDS + k];
   }
   for (int k = 0; k < 8; k++) ctx->stats.lane_states[k] = c[CNT_LANE_STATES + k];
+  ctx->stats.rays_answered = c[CNT_RAYS_ANSWERED];
   ctx->stats.nodes_visited_primary = c[CNT_NODES_PRIMARY];
   ctx->stats.tris_tested_primary = c[CNT_TRIS_PRIMARY];
 }
@@ -399,6 +406,8 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->fuse_trace = value != 0;
   else if (!strcmp(name, "packet_primary"))
     ctx->packet_primary = value != 0;
+  else if (!strcmp(name, "answer_last_rays"))
+    ctx->answer_last_rays = value != 0;
   else if (!strcmp(name, "cull_terminal"))
     ctx->cull_terminal = value != 0;
   else if (!strcmp(name, "refill_idle"))
@@ -607,6 +616,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
       inst_flags[i] = (uint8_t)((emits ? INST_FLAG_EMITS : 0) | (can_eval ? INST_FLAG_CAN_EVAL : 0) | (specular ? INST_FLAG_SPECULAR : 0));
     }
   }
+  ctx->inst_flags_host = inst_flags;
   HIP_TRY(ctx, ctx->inst_flags.ensure(inst_flags.size()));
   HIP_TRY(ctx, hipMemcpy(ctx->inst_flags.p, inst_flags.data(), inst_flags.size(), hipMemcpyHostToDevice));
   ctx->has_specular = any_specular;
@@ -654,6 +664,61 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   if (built.stack_depth > STHIP_MAX_STACK_DEPTH) return fail(ctx, STHIP_ERR_UNSUPPORTED, "scene: the acceleration structure is too deep for the traversal stack (use the SAH builder)");
   ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
   ctx->stats.bvh_build_gpu_ms = built.gpu_build_ms;
+  {
+    // The bounds of the emissive triangle instances (kernels.h: EmitterBounds), from the validated scene arrays: the box of the
+    // vertices an instance's triangles refer to, widened by 2^-15 of its coordinates' magnitude as the packed nodes of the
+    // tree are, in world space for an instance with identity transforms (that is where its triangles are tested, whether the
+    // builder merged it or not: the identity's fmaf chain returns the world-space ray) and in object space otherwise.
+    std::vector<EmitterBounds> bounds;
+    bool usable = true;
+    for (uint32_t i = 0; i < s->instance_count && usable; i++) {
+      if ((s->gInstances[i].packed[0] & 0xF) != STHIP_INSTANCE_TYPE_TRIANGLES || !(ctx->inst_flags_host[i] & INST_FLAG_EMITS)) continue;
+      if (bounds.size() == STHIP_MAX_EMITTER_BOUNDS) {
+        usable = false;
+        break;
+      }
+      const uint32_t prims = (s->gInstances[i].packed[1] >> 12) & 0xFFFFu, stride = s->gInstances[i].packed[1] >> 28;
+      const uint32_t first_vertex = s->gInstances[i].packed[2];
+      const uint8_t* ib = (const uint8_t*)s->gIndices + s->gInstances[i].packed[3];
+      EmitterBounds b{};
+      for (int a = 0; a < 3; a++) b.lo[a] = __builtin_inff(), b.hi[a] = -__builtin_inff();
+      for (uint32_t k = 0; k < 3 * prims; k++) {
+        uint32_t index;
+        if (stride == 2) {
+          uint16_t w;
+          memcpy(&w, ib + 2 * (size_t)k, 2);
+          index = w;
+        } else {
+          memcpy(&index, ib + 4 * (size_t)k, 4);
+        }
+        const float* pos = s->gVertices[first_vertex + index].position;
+        for (int a = 0; a < 3; a++) {
+          b.lo[a] = std::min(b.lo[a], pos[a]);
+          b.hi[a] = std::max(b.hi[a], pos[a]);
+        }
+      }
+      if (!prims || !(b.lo[0] <= b.hi[0])) continue;  // (no triangle: nothing to hit)
+      double diag = 0;
+      for (int a = 0; a < 3; a++) {
+        const float mag = std::max(fabsf(b.lo[a]), fabsf(b.hi[a])) * (1.0f / 32768.0f) + 1e-30f;
+        b.lo[a] -= mag;
+        b.hi[a] += mag;
+        b.sphere[a] = 0.5f * b.lo[a] + 0.5f * b.hi[a];
+        diag += ((double)b.hi[a] - b.lo[a]) * ((double)b.hi[a] - b.lo[a]);
+      }
+      b.sphere[3] = (float)sqrt(diag);  // (twice the box's own radius: the padding only has to be large enough)
+      if (!std::isfinite(b.sphere[3])) usable = false;
+      b.instance = i;
+      static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+      b.identity = (!memcmp(&s->gInstanceTransforms[i], ident, 48) && !memcmp(&s->gInstanceInverseTransforms[i], ident, 48)) ? 1u : 0u;
+      bounds.push_back(b);
+    }
+    ctx->emitter_count = usable ? (uint32_t)bounds.size() : 0u;
+    if (ctx->emitter_count) {
+      HIP_TRY(ctx, ctx->emitters.ensure(bounds.size()));
+      HIP_TRY(ctx, hipMemcpy(ctx->emitters.p, bounds.data(), bounds.size() * sizeof(EmitterBounds), hipMemcpyHostToDevice));
+    }
+  }
   if (!device_build) {
     HIP_TRY(ctx, ctx->vertices.ensure(std::max(1u, s->vertex_count)));
     HIP_TRY(ctx, ctx->indices.ensure((size_t)s->indices_bytes + 8));
@@ -1437,6 +1502,9 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   p.refill_idle = ctx->refill_idle;
   p.culled = 0;
   p.inst_flags = ctx->inst_flags.p;
+  p.emitters = ctx->emitters.p;
+  p.emitter_count = 0;  // (set where the view pass starts: only the plain pipeline answers last rays)
+  p.no_specular = ctx->has_specular ? 0u : 1u;
   p.inner_min_lanes = ctx->inner_min_lanes;
 
   // outputs: device pointers are written in place, host pointers go through staging buffers
@@ -1701,6 +1769,7 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       });
       if (rc) return rc;
     }
+    p.emitter_count = ctx->answer_last_rays ? ctx->emitter_count : 0u;  // (only the plain k_shade instantiation looks at it)
     rc = run_rounds(false, nee || connect_paths, [&](uint32_t depth) {
       // eCoherentRR: a vertex shaded in round `depth` has path_length depth + 2; the roulette runs for
       // gMinPathVertices <= path_length < gMaxPathVertices at a non-specular vertex that is within the diffuse budget —

@@ -33,6 +33,7 @@ enum {
   CNT_NODES_PRIMARY = 14,  // the share of CNT_NODES / CNT_TRIS that k_trace_primary (first bounce as wave packets) counted
   CNT_TRIS_PRIMARY = 15,
   CNT_CROSSINGS = 16,  // media: closest-hit queries that only carried a path across a volume boundary (no new trace() call)
+  CNT_RAYS_ANSWERED = 17,  // of CNT_RAYS_CLOSEST: last rays of paths that k_shade answered from the emitters' bounds (never queued)
   CNT_LANE_STATES = 20,  // 8 slots: TraverseCounters::st
   CNT_TOTAL = 28
 };
@@ -149,7 +150,21 @@ struct FrameParams {
   uint32_t inner_min_lanes;  // leave the inner-node loop when fewer lanes than this are still walking
   uint32_t culled;           // k_shade: queue[depth & 1] is what k_cull_terminal kept of the round's queue (sizes in QCTL_KEPT)
   const uint8_t* inst_flags; // per instance: INST_FLAG_* of its material (scenes without images), for k_cull_terminal
+  const struct EmitterBounds* emitters;  // the emissive triangle instances' bounds (aims_at_emitter), emitter_count of them;
+  uint32_t emitter_count;                // 0: the last-ray filter of k_shade is off
+  uint32_t no_specular;                  // no material of the scene is specular: the diffuse budget ends every path that reaches it
 };
+// One emissive triangle instance: the box of its vertices in the space the traversal tests its triangles in (world space for an
+// instance with identity transforms, the instance's object space otherwise) and a sphere around it that sizes the per-ray
+// padding of the slab test exactly as the traversal's own boxes are padded (setup_space).
+struct EmitterBounds {
+  float lo[3];
+  uint32_t instance;
+  float hi[3];
+  uint32_t identity;
+  float sphere[4];
+};
+#define STHIP_MAX_EMITTER_BOUNDS 16u
 // DisneyMaterial::Le() > 0 somewhere / can_eval() / is_specular() of an instance's untextured material, evaluated on the host with
 // the device's arithmetic at upload (api.hip); KEEP: not a triangle instance, no statement made
 #define INST_FLAG_EMITS 1u
@@ -710,6 +725,41 @@ __global__ void __launch_bounds__(STHIP_BLOCK, PRIMARY_BLOCKS) k_trace_primary(F
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The last ray of a path. A vertex at which the path or diffuse budget ends can only add the emission of what the ray hits
+// (next_vertex, path.hlsli:955-966 in front of :975; eval_emission :847-894), so when k_shade sends a path into its last
+// vertex the ray matters only if its closest hit lies on an emissive triangle — and it cannot if the ray misses the bounds
+// of every emissive instance. Such a ray is answered on the spot: counted as the trace_ray call it stands for, never
+// queued, and the path ends with what it has. The test is the traversal's own box test (setup_space's padded slab
+// arithmetic, in the space the instance's triangles are tested in) on a box that holds all triangles of the instance, i.e.
+// exactly what the walk itself asks of every ancestor of a triangle it finds: a ray whose closest hit the contract puts on
+// an emitter passes it. Frames and ray counts are those of the unfiltered pipeline bit for bit ("answer_last_rays" = 0).
+// ---------------------------------------------------------------------------------------------
+DEV bool aims_at_emitter(const FrameParams& p, f3 o, f3 d) {
+  // the table and the transforms are read at wave-uniform addresses (scalar loads); no early exit: every lane tests every box
+  RaySpace world;
+  setup_space(world, o, d, p.bvh.scene_cx, p.bvh.scene_cy, p.bvh.scene_cz, p.bvh.scene_radius);
+  bool aims = false;
+  for (uint32_t e = 0; e < p.emitter_count; e++) {
+    const size_t at = (size_t)e * sizeof(EmitterBounds);
+    const float4 b0 = uniform_load4(p.emitters, at), b1 = uniform_load4(p.emitters, at + 16), b2 = uniform_load4(p.emitters, at + 32);  // lo | instance, hi | identity, sphere
+    RaySpace sp = world;
+    if (__float_as_uint(b1.w) == 0u) {  // (wave-uniform) an instance with a transform: its triangles are tested in object space
+      const size_t xat = (size_t)__float_as_uint(b0.w) * sizeof(sthip_TransformData);
+      const float4 r0 = uniform_load4(p.scene.inv_xf, xat), r1 = uniform_load4(p.scene.inv_xf, xat + 16), r2 = uniform_load4(p.scene.inv_xf, xat + 32);
+      const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+      setup_space(sp, obj_point(m, o), obj_vector(m, d), b2.x, b2.y, b2.z, b2.w);
+    }
+    const float ax = fmaf(b0.x, sp.idir.x, sp.noodL.x), bx = fmaf(b1.x, sp.idir.x, sp.noodH.x);
+    const float ay = fmaf(b0.y, sp.idir.y, sp.noodL.y), by = fmaf(b1.y, sp.idir.y, sp.noodH.y);
+    const float az = fmaf(b0.z, sp.idir.z, sp.noodL.z), bz = fmaf(b1.z, sp.idir.z, sp.noodH.z);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    aims = aims | (tn <= tf);
+  }
+  return aims;
+}
+
 // sample_point_on_light, light.hlsli:37-152 (uniform light choice), as one function for connect_light and presample_lights
 struct LightSample {
   f3 Le, to_light, normal, position;
@@ -901,13 +951,15 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate_light(FrameParams p) {
 
 // ray counts of a finished pass: every queued path / shadow record was traced exactly once
 __global__ void k_count_rays(FrameParams p) {
-  unsigned long long closest = 0, shadow = 0;
+  unsigned long long closest = 0, shadow = 0, answered = 0;
   for (uint32_t d = 0; d < p.rounds; d++)
     for (uint32_t s = 0; s < QUEUE_SEGMENTS; s++) {
       if (d) closest += queue_ctl(p.qctl, 0, d, s)[QCTL_SIZE];
+      if (d) answered += queue_ctl(p.qctl, 0, d, s)[QCTL_ANSWERED];
       shadow += queue_ctl(p.qctl, 1, d, s)[QCTL_SIZE];
     }
-  p.counters[CNT_RAYS_CLOSEST] += closest;
+  p.counters[CNT_RAYS_CLOSEST] += closest + answered;
+  p.counters[CNT_RAYS_ANSWERED] += answered;
   p.counters[CNT_RAYS_SHADOW] += shadow;
 }
 
@@ -2150,6 +2202,16 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
     if (PROBE) continue;
 
     p.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    if (!TEXTURED && !EXT && !LT && !MEDIA && p.emitter_count) {
+      // the path's next vertex is its last one and its ray cannot reach an emitter: answered here (aims_at_emitter)
+      const bool last_next = alive && (path_length + 1u >= p.pc.gMaxPathVertices || (p.no_specular && diffuse_vertices + 1u > p.pc.gMaxDiffuseVertices));
+      bool answered = false;
+      if (__any(last_next)) answered = last_next && !aims_at_emitter(p, new_origin, new_direction);
+      if (answered) {  // counted where the queue's own size is (one of eight lines; a single counter would serialise the waves)
+        alive = false;
+        atomicAdd(queue_size + (QCTL_ANSWERED - QCTL_SIZE), 1ull);
+      }
+    }
     if (alive) {
       p.ray_o[slot] = make_float4(new_origin.x, new_origin.y, new_origin.z, bsdf_pdf);
       p.ray_d[slot] = make_float4(new_direction.x, new_direction.y, new_direction.z, eta_scale);
@@ -2298,13 +2360,16 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_shadow_media(FrameParams p, uin
 __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t first_seed, uint32_t last_seed, uint32_t primary_rays) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // every queued path / shadow record was traced exactly once: ray counts are the queue sizes
-    unsigned long long closest = primary_rays, shadow = 0;
+    // (a last ray answered by k_shade is a trace_ray call too: QCTL_ANSWERED of the bounce it belongs to)
+    unsigned long long closest = primary_rays, shadow = 0, answered = 0;
     for (uint32_t d = 0; d < p.rounds; d++)
       for (uint32_t s = 0; s < QUEUE_SEGMENTS; s++) {
         if (d) closest += queue_ctl(p.qctl, 0, d, s)[QCTL_SIZE];
+        if (d) answered += queue_ctl(p.qctl, 0, d, s)[QCTL_ANSWERED];
         shadow += queue_ctl(p.qctl, 1, d, s)[QCTL_SIZE];
       }
-    p.counters[CNT_RAYS_CLOSEST] += closest;
+    p.counters[CNT_RAYS_CLOSEST] += closest + answered;
+    p.counters[CNT_RAYS_ANSWERED] += answered;
     p.counters[CNT_RAYS_SHADOW] += shadow;
   }
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < p.paths_per_seed; q += gridDim.x * blockDim.x) {

@@ -661,6 +661,7 @@ DEV bool traverse(const DeviceBvh& bvh, f3 o, f3 d, float tmin, float tmax, uint
                          // consumer runs) never touches the line its dequeue atomics keep busy
 #define QCTL_SIZE 0u     // word: entries produced
 #define QCTL_KEPT 1u     // word: entries k_cull_terminal kept for k_shade (kernels.h)
+#define QCTL_ANSWERED 2u // word: rays of this bounce that k_shade answered instead of queueing them (aims_at_emitter, kernels.h)
 #define QCTL_HEAD 16u    // word: dequeue head of the consuming trace kernel
 // control line of (kind: 0 = path queue entering bounce `depth`, 1 = shadow rays of bounce `depth`; depth < 64; segment)
 DEV unsigned long long* queue_ctl(unsigned long long* qctl, uint32_t kind, uint32_t depth, uint32_t seg) {

@@ -224,6 +224,7 @@ class Stats(C.Structure):
         ("ms_trace_primary", C.c_float),
         ("launches_primary", C.c_uint32),
         ("lane_states", C.c_uint64 * 8),
+        ("rays_answered", C.c_uint64),
     ]
 
 

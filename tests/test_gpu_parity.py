@@ -1565,7 +1565,8 @@ def _cornell_with_a_mirror_and_glass():
 def test_culling_finished_paths_in_front_of_k_shade_does_not_change_results(atrium_scene):
     """k_cull_terminal (kernels.h, option "cull_terminal"): in a round where the path or diffuse budget can end, only the
     paths that still have something to do — an emitter was hit, or a specular vertex lets the path go on — are handed to
-    k_shade. Frames and ray counts with and without it are bit-identical, for budgets that end paths by their length, by
+    k_shade. "answer_last_rays": the ray into a path's last vertex is traced only if it can reach the bounds of an emissive
+    instance (aims_at_emitter), and counted either way. Frames and ray counts with and without them are bit-identical, for budgets that end paths by their length, by
     their diffuse vertices, or (mirrors / glass in the scene) leave some of them running; one of them against the oracle."""
     from oracle import oracle_py as orc
     from stratum_amd.bdpt import BDPT
@@ -1581,19 +1582,28 @@ def test_culling_finished_paths_in_front_of_k_shade_does_not_change_results(atri
     for make, args, (W, H) in cases:
         sc, cam = make()
         frame = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
-        frames = []
-        for cull in (1, 0):
+        frames, answered = [], []
+        for cull, answer in ((1, 1), (0, 0), (1, 0), (0, 1)):
             r = BDPT(device=0, args=args)
             try:
                 r.set_option("cull_terminal", cull)
+                r.set_option("answer_last_rays", answer)
                 r.update(sc)
                 frames.append(r.render(frame, 3, 2))
+                answered.append(r.stats()["rays_answered"])
             finally:
                 r.close()
-        a, b = frames
-        assert np.array_equal(a["radiance"].view(np.uint32), b["radiance"].view(np.uint32)), args
-        assert np.array_equal(a["ray_count"], b["ray_count"]), args
+        a = frames[0]
+        for b in frames[1:]:
+            assert np.array_equal(a["radiance"].view(np.uint32), b["radiance"].view(np.uint32)), args
+            assert np.array_equal(a["ray_count"], b["ray_count"]), args
+            assert np.array_equal(a["visibility"]["instance_primitive_index"], b["visibility"]["instance_primitive_index"])
         assert a["radiance"][..., :3].max() > 0
+        # last rays that cannot reach an emitter's bounds are answered without a traversal (and only with the option on):
+        # most of them where every path ends by its budget, none where the budget never ends a path in these rounds
+        assert answered[1] == 0 and answered[2] == 0 and answered[0] == answered[3], answered
+        if make is not _cornell_with_a_mirror_and_glass:  # (with specular materials only the path-length budget ends a path for sure)
+            assert answered[0] > 0, (args, answered)
     # ... and the culled frame is the oracle's (the last case: mirrors and glass keep some paths alive past the diffuse budget)
     o = orc.OracleScene(sc)
     r = BDPT(device=0, args=args)
@@ -1604,3 +1614,45 @@ def test_culling_finished_paths_in_front_of_k_shade_does_not_change_results(atri
     finally:
         r.close()
     assert np.array_equal(a["radiance"].view(np.uint32), ref["radiance"].view(np.uint32))
+
+
+def test_last_rays_answered_from_the_bounds_of_moving_emitters():
+    """aims_at_emitter (kernels.h) with emitters that are instances with a transform — the slab test then runs in the
+    instance's object space, as the walk's own tests of its triangles do — next to the ceiling light of the merged mesh; the
+    emitters then move (sthip_scene_update_transforms: the bounds are the object-space box and the current inverse transform).
+    Frames, AOVs and ray counts are the oracle's bit for bit before and after the move, and the filter answers rays."""
+    from oracle import oracle_py
+    from stratum_amd.bdpt import BDPT
+    from stratum_amd.scene import rotate_y, scale, translate
+
+    sc0, cam = scenes.cornell_box()
+    b = sc0.builder
+    glow = b.add_emitter((3.0, 6.0, 9.0))
+    pos, nrm, uv, tri = scenes._quad((-0.5, 0.0, 0.5), (0.5, 0.0, 0.5), (0.5, 0.0, -0.5), (-0.5, 0.0, -0.5), (0, 1, 0))
+    panel = b.add_mesh(pos, nrm, uv, tri)
+    first = b.add_instance(panel, glow, translate((0.55, -0.2, 0.1)) @ rotate_y(0.7) @ scale((0.3, 1.0, 0.5)))
+    second = b.add_instance(panel, glow, translate((-0.6, 0.4, -0.5)) @ rotate_y(-1.1) @ scale((0.25, 1.0, 0.25)))
+    sc = b.build()
+    frame = camera.Frame(160, 120, cam["fovy"], cam["eye"], cam["target"])
+    for args in ({}, {"maxDiffuseVertices": 3, "maxPathVertices": 5}):
+        r = BDPT(device=0, args=args)
+        try:
+            r.update(sc)
+            for moved in (False, True):
+                if moved:
+                    sc.set_instance_transform(sc.instances.shape[0] - 2, translate((0.2, 0.3, 0.4)) @ rotate_y(-0.3) @ scale((0.5, 1.0, 0.3)))
+                    sc.set_instance_transform(sc.instances.shape[0] - 1, translate((-0.3, -0.5, 0.2)) @ rotate_y(2.0) @ scale((0.3, 1.0, 0.6)))
+                    r.update_transforms(sc)
+                got = r.render(frame, 1, 2)
+                assert r.stats()["rays_answered"] > 0
+                ref = oracle_py.OracleScene(sc).render(frame, r.push_constants(frame), r.mSamplingFlags, 1, 2)
+                for k in ("radiance", "albedo"):
+                    assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (args, moved, k)
+                assert np.array_equal(got["ray_count"], ref["ray_count"]), (args, moved)
+                r.set_option("answer_last_rays", 0)
+                plain = r.render(frame, 1, 2)
+                assert r.stats()["rays_answered"] == 0
+                r.set_option("answer_last_rays", 1)
+                assert np.array_equal(got["radiance"].view(np.uint32), plain["radiance"].view(np.uint32)) and np.array_equal(got["ray_count"], plain["ray_count"])
+        finally:
+            r.close()

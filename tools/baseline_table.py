@@ -1,7 +1,7 @@
 """one row per configuration x backend, measured on the box this runs on (one MI355X + its host
 cores). GPU: median of 5 timed sthip_render calls with device outputs after a warm-up; CPU: the oracle built -O3
 -march=native on this box, on a BOUNDED window / seed count of the same frame (the whole frames of configs 2-5 would take
-hours), median of 3. usage (GPU box): python tools/baseline_table.py [--no-cpu] > gpurun_out/baseline_table.md"""
+hours), median of 3. usage (GPU box): python tools/baseline_table.py [--no-cpu] [--answer-last-rays] > gpurun_out/baseline_table.md"""
 import os, sys, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +13,7 @@ from stratum_amd import camera, scenes, shard
 from stratum_amd.bdpt import BDPT
 
 NO_CPU = "--no-cpu" in sys.argv
+ANSWER = 1 if "--answer-last-rays" in sys.argv else 0  # the table traces every ray; with the flag: the library's default (sthip.h "answer_last_rays"), rays in gRayCount semantics
 if not NO_CPU:
     from oracle import oracle_py
 
@@ -25,6 +26,7 @@ def gpu_leg(sc, cam, W, H, seeds, args, shard_of=None):
         if shard_of:
             r.set_shard(0, shard_of, 64, 32)
         r.update(sc)
+        r.set_option("answer_last_rays", ANSWER)
         fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
         packed = shard_of is not None
         rad = torch.zeros((r.shard_slot_count(fr), 4) if packed else (H, W, 4), device="cuda")

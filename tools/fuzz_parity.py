@@ -85,6 +85,7 @@ def run(cases=60, seed=1):
             if rng.integers(4) == 0: opts["lds_stack_levels"] = int(rng.integers(4, 14))  # bounded LDS stacks + k_trace_deep
             if rng.integers(4) == 0 and "bvh_builder" not in opts: opts["embed_leaves"] = 1  # leaf triangles inside the node array
             opts["cull_terminal"] = seed0 & 1  # k_cull_terminal in front of k_shade (without drawing: the cases of a seed stay the same)
+            opts["answer_last_rays"] = (seed0 >> 1) & 1  # last rays answered from the emitters' bounds
             if os.environ.get("STHIP_FUZZ_WIDE") is not None: opts["wide_bvh"] = int(os.environ["STHIP_FUZZ_WIDE"])  # the 4-wide walk forced on / off (without drawing: the cases of a seed stay the same)
             for k, v in opts.items():
                 r.set_option(k, v)

@@ -11,6 +11,6 @@ for group in "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" "TA_ADDR_STALLED_BY_TC
   "TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_TOTAL_ACCESSES_sum"; do
   n=$((n + 1))
   d=gpurun_out/pmc_${tag}_l1_$n
-  rocprofv3 --pmc $group --output-format csv -d $d -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ceilings --reps 1 > $d.log 2>&1 || { echo "pass $n failed"; tail -3 $d.log; continue; }
+  rocprofv3 --pmc $group --output-format csv -d $d -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-last-ray-filter --no-ceilings --reps 1 > $d.log 2>&1 || { echo "pass $n failed"; tail -3 $d.log; continue; }
   python3 tools/pmc_summary.py $d/*/*_counter_collection.csv > $d.txt
 done

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # the oracle (bench.py's checker) is built BEFORE the profiler starts anything: a profiled, GPU-initialised process must
 # not spawn make / g++; the profiled command itself carries no CPU leg (it would mix seconds of host time into the trace)
 python3 -c "import __graft_entry__ as g; g.build_product(); g.build_oracle()"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python3 bench.py --steps 10 --warmup 2 --reps 1 --no-cpu-baseline > gpurun_out/prof_${tag}.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python3 bench.py --steps 10 --warmup 2 --reps 1 --no-cpu-baseline --no-last-ray-filter > gpurun_out/prof_${tag}.log 2>&1
 grep '"metric"' gpurun_out/prof_${tag}.log > gpurun_out/prof_${tag}_bench_line.json
 cp gpurun_out/prof_${tag}/*/*_kernel_stats.csv gpurun_out/prof_${tag}_kernel_stats.csv
 tools/pmc.sh ${tag}
