@@ -1835,7 +1835,13 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
         hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
       else if (ctx->cull_terminal && depth >= 1 && !p.rr && !p.cs_nee && !p.cs_lvc && (depth + 2 >= pc->gMaxPathVertices || depth + 1 > pc->gMaxDiffuseVertices)) {
         // the path or diffuse budget can end at this round's vertex: only the paths that still have something to do reach k_shade
-        hipLaunchKernelGGL(k_cull_terminal, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth, ctx->queue_kept.p);
+        // a block keeps what it meets in LDS: as many blocks per segment as it takes for a segment's share to fit (16 KB at 1080p)
+        uint32_t per_segment = CULL_BLOCKS_PER_SEGMENT, per_block;
+        for (;; per_segment *= 2) {
+          per_block = (uint32_t)((((size_t)p.seg_stride + (size_t)per_segment * STHIP_BLOCK - 1) / ((size_t)per_segment * STHIP_BLOCK)) * STHIP_BLOCK);  // entries a block can meet
+          if ((size_t)(per_block + 2) * 4 <= 48 * 1024) break;
+        }
+        hipLaunchKernelGGL(k_cull_terminal, dim3(QUEUE_SEGMENTS * per_segment), dim3(STHIP_BLOCK), (size_t)(per_block + 2) * 4, st, p, depth, ctx->queue_kept.p, per_block);
         FrameParams pk = p;
         pk.queue[depth & 1u] = ctx->queue_kept.p;
         pk.culled = 1;

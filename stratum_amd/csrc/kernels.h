@@ -2235,10 +2235,13 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
 // path.hlsli:847-894), so a path that ends on a surface without emission — nearly all of them — has nothing left to do:
 // k_shade would fetch indices, vertices and transform, build the shading data, find Le = 0 and stop, writing back the
 // radiance it read. This pass reads the hit and one byte about the instance's material only and keeps the paths that have something to do, packed
-// (ballot ranks, one atomic per wave), so that k_shade's waves are full of them. Plain instantiation only (no textures —
+// (gathered per block in LDS, one atomic per block), so that k_shade's waves are full of them. Plain instantiation only (no textures —
 // Le would need the uv —, no spheres / environment, no light subpaths, no media), which is the headline path.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(STHIP_BLOCK) k_cull_terminal(FrameParams p, uint32_t depth, uint32_t* kept) {
+#define CULL_BLOCKS_PER_SEGMENT 64u  // a block gathers what it keeps in LDS and appends it with ONE atomic (a wave-level append would
+                                     // put ~25 000 atomics on the eight control lines: 11 ns each, longer than the pass itself)
+__global__ void __launch_bounds__(STHIP_BLOCK) k_cull_terminal(FrameParams p, uint32_t depth, uint32_t* kept, uint32_t capacity) {
+  extern __shared__ uint32_t cull_lds[];  // [0] count, [1] base, [2 ..] up to `capacity` kept slots
   const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
   const uint32_t seg_base = seg * p.seg_stride;
   unsigned long long* line = queue_ctl(p.qctl, 0, depth, seg);
@@ -2246,29 +2249,27 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_cull_terminal(FrameParams p, ui
   const uint32_t first = (blockIdx.x / QUEUE_SEGMENTS) * blockDim.x + threadIdx.x;
   const uint32_t step = ((gridDim.x - seg + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) * blockDim.x;
   const uint32_t* queue_in = p.queue[depth & 1u] + seg_base;
-  const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t i = first; __any(i < n); i += step) {  // (a wave's lanes hold consecutive i: they leave the loop together)
-    bool keep = false;
-    uint32_t slot = 0;
-    if (i < n) {
-      slot = queue_in[i];
-      const uint32_t meta = p.meta[slot];
-      const uint32_t ip = __float_as_uint(p.hit[slot].w);
-      if (meta < 0xFFFFFFFEu && ip != 0xFFFFFFFFu) {  // (a miss without an environment adds nothing: path.hlsli:1049-1058)
-        const uint32_t path_length = (meta & 0xFFu) + 1u, diffuse_vertices = (meta >> 8) & 0xFFu;
-        const uint32_t f = p.inst_flags[ip & 0xFFFFu];
-        const bool last = !(f & INST_FLAG_CAN_EVAL) || path_length >= p.pc.gMaxPathVertices || (!(f & INST_FLAG_SPECULAR) && diffuse_vertices + 1u > p.pc.gMaxDiffuseVertices);
-        keep = (f & (INST_FLAG_KEEP | INST_FLAG_EMITS)) || !last;
-      }
-    }
-    const unsigned long long mask = __ballot(keep);
-    if (mask) {
-      unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(&line[QCTL_KEPT], (unsigned long long)__popcll(mask));
-      const uint32_t b32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-      if (keep) kept[seg_base + b32 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+  if (threadIdx.x == 0) cull_lds[0] = 0;
+  __syncthreads();
+  for (uint32_t i = first; i < n; i += step) {
+    const uint32_t slot = queue_in[i];
+    const uint32_t meta = p.meta[slot];
+    const uint32_t ip = __float_as_uint(p.hit[slot].w);
+    if (meta >= 0xFFFFFFFEu || ip == 0xFFFFFFFFu) continue;  // (a miss without an environment adds nothing: path.hlsli:1049-1058)
+    const uint32_t path_length = (meta & 0xFFu) + 1u, diffuse_vertices = (meta >> 8) & 0xFFu;
+    const uint32_t f = p.inst_flags[ip & 0xFFFFu];
+    const bool last = !(f & INST_FLAG_CAN_EVAL) || path_length >= p.pc.gMaxPathVertices || (!(f & INST_FLAG_SPECULAR) && diffuse_vertices + 1u > p.pc.gMaxDiffuseVertices);
+    if ((f & (INST_FLAG_KEEP | INST_FLAG_EMITS)) || !last) {
+      const uint32_t k = atomicAdd(&cull_lds[0], 1u);
+      if (k < capacity) cull_lds[2 + k] = slot;  // (capacity = the most entries a block can meet: always true)
     }
   }
+  __syncthreads();
+  const uint32_t count = min(cull_lds[0], capacity);
+  if (threadIdx.x == 0 && count) cull_lds[1] = (uint32_t)atomicAdd(&line[QCTL_KEPT], (unsigned long long)count);
+  __syncthreads();
+  const uint32_t base = cull_lds[1];
+  for (uint32_t k = threadIdx.x; k < count; k += blockDim.x) kept[seg_base + base + k] = cull_lds[2 + k];
 }
 
 // ---------------------------------------------------------------------------------------------
