@@ -691,6 +691,10 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
         } else {
           memcpy(&index, ib + 4 * (size_t)k, 4);
         }
+        if ((size_t)first_vertex + index >= s->vertex_count) {  // (the builders have refused such a scene already)
+          usable = false;
+          break;
+        }
         const float* pos = s->gVertices[first_vertex + index].position;
         for (int a = 0; a < 3; a++) {
           b.lo[a] = std::min(b.lo[a], pos[a]);
