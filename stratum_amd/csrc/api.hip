@@ -189,7 +189,8 @@ struct sthip_ctx {
   bool count_traversal = false, time_kernels = false;
   bool hashgrid_serial = false;  // "hashgrid_serial": build the reuse grids with the one-thread probe sequence (hashgrid.hip's rare-case path; tests)
   uint32_t refill_idle = 16, inner_min_lanes = 24, trace_blocks_per_cu = 0;
-  uint64_t max_paths_in_flight = 1ull << 22;
+  uint64_t max_paths_in_flight = 1ull << 25;  // ~11 GB of path state, queues and shadow records at the default flags: launches large enough
+                                              // that their tails stop mattering (atrium x 8 seeds +7 %, forest at 4K +23 % over 2^22; tools/in_flight_sweep.py)
   bool packet_primary = true;  // the first bounce is traced as wave packets (k_trace_primary)
   bool fuse_trace = true;  // closest-hit rays of a bounce and the shadow rays of the previous one in one launch
   int bvh_builder = 0;  // sthip::BvhBuilderKind
