@@ -280,7 +280,8 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s);
 
 /* named integer options: "count_traversal" (0/1), "time_kernels" (0/1); scheduler tuning of the persistent
  * trace kernels: "refill_idle" (1..64, default 16), "inner_min_lanes" (1..64, default 24),
- * "max_paths_in_flight" (default 33554432: how many seeds of the owned pixels are traced together; ~330 B of device memory per path);
+ * "max_paths_in_flight" (how many seeds of the owned pixels are traced together; ~330 B of device memory per path at the default
+ * flags; default: the largest power of two that leaves 4 KB of device memory per path, 2^26 on a 288 GB MI355X);
  * "bvh_builder": 0 = binned SAH on the host (default), 1 = the device-resident GPU builder (set before
  * sthip_scene_upload; a failed upload with it leaves the context without a scene), with "lbvh_algorithm" 1 = PLOC
  * (default) or 0 = Karras radix tree, "ploc_radius" (1..32, default 4) and "sah_top" (default 64: subtrees of at most that

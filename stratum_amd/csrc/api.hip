@@ -189,8 +189,8 @@ struct sthip_ctx {
   bool count_traversal = false, time_kernels = false;
   bool hashgrid_serial = false;  // "hashgrid_serial": build the reuse grids with the one-thread probe sequence (hashgrid.hip's rare-case path; tests)
   uint32_t refill_idle = 16, inner_min_lanes = 24, trace_blocks_per_cu = 0;
-  uint64_t max_paths_in_flight = 1ull << 25;  // ~11 GB of path state, queues and shadow records at the default flags: launches large enough
-                                              // that their tails stop mattering (atrium x 8 seeds +7 %, forest at 4K +23 % over 2^22; tools/in_flight_sweep.py)
+  uint64_t max_paths_in_flight = 1ull << 22;  // (sthip_create sizes it to the device: 2^26 on a 288 GB MI355X — launches large enough that their
+                                              // tails stop mattering: atrium x 8 seeds +7 %, forest at 4K x 16 +38 % over 2^22; tools/in_flight_sweep.py)
   bool packet_primary = true;  // the first bounce is traced as wave packets (k_trace_primary)
   bool fuse_trace = true;  // closest-hit rays of a bounce and the shadow rays of the previous one in one launch
   int bvh_builder = 0;  // sthip::BvhBuilderKind
@@ -297,7 +297,14 @@ int sthip_create(int device, sthip_ctx** out_ctx) {
   sthip_ctx* ctx = new sthip_ctx();
   ctx->device = device;
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    ctx->cu_count = prop.multiProcessorCount;
+    // paths in flight by default: the largest power of two that leaves 4 KB of device memory per path (a path costs ~330 B of
+    // state, queues and shadow records at the default flags, more with light subpaths): 2^26 on a 288 GB MI355X
+    uint64_t paths = 1ull << 22;
+    while (paths * 2 * 4096 <= (uint64_t)prop.totalGlobalMem && paths < (1ull << 27)) paths *= 2;
+    ctx->max_paths_in_flight = paths;
+  }
   (void)hipEventCreate(&ctx->ev[0]);
   (void)hipEventCreate(&ctx->ev[1]);
   {  // dynamic LDS beyond the 64 KB default for the kernels that carry the traversal stack

@@ -19,7 +19,7 @@ for name, make, W, H, seeds, args in (
     rc = torch.zeros(2, dtype=torch.int64, device="cuda")
     out = {"radiance": rad.data_ptr(), "ray_count": rc.data_ptr()}
     ref = None
-    for shift in (22, 23, 24, 25, 26):
+    for shift in (22, 23, 24, 25, 26, 27):
         r = BDPT(0, args=args)
         r.set_option("answer_last_rays", 0)
         r.set_option("max_paths_in_flight", 1 << shift)
