@@ -257,8 +257,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
     uint32_t px, py;
     const bool inside = slot_to_pixel(p, slot, px, py);
     const int view_index = inside ? get_view_index(p, px, py) : -1;
-    p.radiance[slot] = make_float4(0, 0, 0, 0);
     p.shadow_sum[slot] = make_float4(0, 0, 0, 0);
+    // (the radiance sum of a live path is first written by k_shade's first round; with media that round reads it)
+    if (p.media || view_index < 0 || p.pc.gMaxPathVertices < 2) p.radiance[slot] = make_float4(0, 0, 0, 0);
     if (view_index < 0 || p.pc.gMaxPathVertices < 2) {
       // not traced: a ray that cannot hit anything and a dead path
       p.ray_o[slot] = make_float4(0, 0, 0, 1);
@@ -1333,6 +1334,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
       }
     }
     f3 radiance = (!MEDIA && depth == 0) ? F3s(0.0f) : xyz(p.radiance[slot]);
+    bool radiance_dirty = !MEDIA && depth == 0;  // the first round writes the sum (k_generate leaves it unwritten), later ones only a changed one
     const bool connect_paths = LT && flag(p, STHIP_eConnectToLightPaths);
     if (connect_paths && depth > 0 && !PROBE) {
       // connect_light_subpath's accumulate_contribution calls of the previous vertex (path.hlsli:802-822), whose
@@ -1342,6 +1344,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
         const float4 c = cn[k];
         if (c.x != 0 || c.y != 0 || c.z != 0) {
           radiance = radiance + xyz(c);
+          radiance_dirty = true;
           cn[k] = make_float4(0, 0, 0, 0);
         }
       }
@@ -1520,6 +1523,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             float weight = 1;
             if (path_length > 2 && use_nee) weight = flag(p, STHIP_eNEEReservoirs) ? 0.5f : mis2(use_mis, bsdf_pdf, light_pdf);
             radiance = radiance + (beta * eLe) * weight;
+            radiance_dirty = true;
           }
         }
         break;
@@ -1614,6 +1618,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             weight = (EXT && flag(p, STHIP_eNEEReservoirs)) ? 0.5f : mis2(use_mis, bsdf_pdf * G, light_pdfA);  // path.hlsli:881-886
         }
         radiance = radiance + contrib * weight;
+        radiance_dirty = true;
       };
 
       if (primary) {
@@ -1940,6 +1945,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
                 target[slot] = make_float4(acc.x + c.x, acc.y + c.y, acc.z + c.z, 0.0f);
               } else {
                 radiance = radiance + c;
+                radiance_dirty = true;
               }
               break;
             }
@@ -2201,7 +2207,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
     } while (0);
     if (PROBE) continue;
 
-    p.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    if (radiance_dirty) p.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
     if (!TEXTURED && !EXT && !LT && !MEDIA && p.emitter_count) {
       // the path's next vertex is its last one and its ray cannot reach an emitter: answered here (aims_at_emitter)
       const bool last_next = alive && (path_length + 1u >= p.pc.gMaxPathVertices || (p.no_specular && diffuse_vertices + 1u > p.pc.gMaxDiffuseVertices));
