@@ -612,9 +612,9 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     value_range(rec, 1, 1, roughness_lo, lo);
     value_range(rec, 2, 2, lo, transmission_hi);
     if ((metallic_hi > 0.999f || transmission_hi > 0.999f) && roughness_lo <= 1e-2f) any_specular = true;
-    if ((s->gInstances[i].packed[0] & 0xF) == STHIP_INSTANCE_TYPE_TRIANGLES) {
+    if ((s->gInstances[i].packed[0] & 0xF) == STHIP_INSTANCE_TYPE_TRIANGLES || (s->gInstances[i].packed[0] & 0xF) == STHIP_INSTANCE_TYPE_SPHERE) {
       // what DisneyMaterial::load reads of an untextured record (shading.h), with the device's arithmetic: Le = base_color *
-      // emission, can_eval, is_specular (only the plain k_shade instantiation, i.e. a scene without images, consults this)
+      // emission, can_eval, is_specular (only the untextured k_shade instantiations, i.e. a scene without images, consult this)
       float f[14];
       memcpy(f, (const uint8_t*)s->gMaterialData + addr, sizeof(f));
       const float le[3] = {f[0] * f[3], f[1] * f[3], f[2] * f[3]};
@@ -680,6 +680,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     std::vector<EmitterBounds> bounds;
     bool usable = true;
     for (uint32_t i = 0; i < s->instance_count && usable; i++) {
+      // (sphere lights, environments: scenes of the extended k_shade instantiation, which does not answer last rays)
       if ((s->gInstances[i].packed[0] & 0xF) != STHIP_INSTANCE_TYPE_TRIANGLES || !(ctx->inst_flags_host[i] & INST_FLAG_EMITS)) continue;
       if (bounds.size() == STHIP_MAX_EMITTER_BOUNDS) {
         usable = false;
@@ -1843,23 +1844,26 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
         hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
       else if (ctx->textured)
         hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
-      else if (ext)
-        hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
-      else if (ctx->cull_terminal && depth >= 1 && !p.rr && !p.cs_nee && !p.cs_lvc && (depth + 2 >= pc->gMaxPathVertices || depth + 1 > pc->gMaxDiffuseVertices)) {
-        // the path or diffuse budget can end at this round's vertex: only the paths that still have something to do reach k_shade
-        // a block keeps what it meets in LDS: as many blocks per segment as it takes for a segment's share to fit (16 KB at 1080p)
-        uint32_t per_segment = CULL_BLOCKS_PER_SEGMENT, per_block;
-        for (;; per_segment *= 2) {
-          per_block = (uint32_t)((((size_t)p.seg_stride + (size_t)per_segment * STHIP_BLOCK - 1) / ((size_t)per_segment * STHIP_BLOCK)) * STHIP_BLOCK);  // entries a block can meet
-          if ((size_t)(per_block + 2) * 4 <= 48 * 1024) break;
-        }
-        hipLaunchKernelGGL(k_cull_terminal, dim3(QUEUE_SEGMENTS * per_segment), dim3(STHIP_BLOCK), (size_t)(per_block + 2) * 4, st, p, depth, ctx->queue_kept.p, per_block);
+      else {
+        // untextured scenes, no light subpaths, no media. Where the path or diffuse budget can end at this round's vertex, only
+        // the paths that still have something to do reach k_shade (k_cull_terminal).
         FrameParams pk = p;
-        pk.queue[depth & 1u] = ctx->queue_kept.p;
-        pk.culled = 1;
-        hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, pk, depth);
-      } else
-        hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
+        if (ctx->cull_terminal && depth >= 1 && !p.rr && !p.cs_nee && !p.cs_lvc && (depth + 2 >= pc->gMaxPathVertices || depth + 1 > pc->gMaxDiffuseVertices)) {
+          // a block keeps what it meets in LDS: as many blocks per segment as it takes for a segment's share to fit (16 KB at 1080p)
+          uint32_t per_segment = CULL_BLOCKS_PER_SEGMENT, per_block;
+          for (;; per_segment *= 2) {
+            per_block = (uint32_t)((((size_t)p.seg_stride + (size_t)per_segment * STHIP_BLOCK - 1) / ((size_t)per_segment * STHIP_BLOCK)) * STHIP_BLOCK);  // entries a block can meet
+            if ((size_t)(per_block + 2) * 4 <= 48 * 1024) break;
+          }
+          hipLaunchKernelGGL(k_cull_terminal, dim3(QUEUE_SEGMENTS * per_segment), dim3(STHIP_BLOCK), (size_t)(per_block + 2) * 4, st, p, depth, ctx->queue_kept.p, per_block);
+          pk.queue[depth & 1u] = ctx->queue_kept.p;
+          pk.culled = 1;
+        }
+        if (ext)
+          hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, pk, depth);
+        else
+          hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, pk, depth);
+      }
     });
     if (rc) return rc;
     rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + in_flight == seed_count ? 1u : 0u, primary_rays * in_flight); });

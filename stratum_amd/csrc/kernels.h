@@ -2208,7 +2208,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
     if (PROBE) continue;
 
     if (radiance_dirty) p.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-    if (!TEXTURED && !EXT && !LT && !MEDIA && p.emitter_count) {
+    if (!TEXTURED && !EXT && !LT && !MEDIA && p.emitter_count) {  // (the plain instantiation only: in the extended one this code cost 10 % of k_shade in spills)
       // the path's next vertex is its last one and its ray cannot reach an emitter: answered here (aims_at_emitter)
       const bool last_next = alive && (path_length + 1u >= p.pc.gMaxPathVertices || (p.no_specular && diffuse_vertices + 1u > p.pc.gMaxDiffuseVertices));
       bool answered = false;
@@ -2241,8 +2241,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
 // path.hlsli:847-894), so a path that ends on a surface without emission — nearly all of them — has nothing left to do:
 // k_shade would fetch indices, vertices and transform, build the shading data, find Le = 0 and stop, writing back the
 // radiance it read. This pass reads the hit and one byte about the instance's material only and keeps the paths that have something to do, packed
-// (gathered per block in LDS, one atomic per block), so that k_shade's waves are full of them. Plain instantiation only (no textures —
-// Le would need the uv —, no spheres / environment, no light subpaths, no media), which is the headline path.
+// (gathered per block in LDS, one atomic per block), so that k_shade's waves are full of them. Scenes without images only (Le would
+// need the uv), no light subpaths, no media; with an environment a miss is kept (it adds the background).
 // ---------------------------------------------------------------------------------------------
 #define CULL_BLOCKS_PER_SEGMENT 64u  // a block gathers what it keeps in LDS and appends it with ONE atomic (a wave-level append would
                                      // put ~25 000 atomics on the eight control lines: 11 ns each, longer than the pass itself)
@@ -2261,11 +2261,17 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_cull_terminal(FrameParams p, ui
     const uint32_t slot = queue_in[i];
     const uint32_t meta = p.meta[slot];
     const uint32_t ip = __float_as_uint(p.hit[slot].w);
-    if (meta >= 0xFFFFFFFEu || ip == 0xFFFFFFFFu) continue;  // (a miss without an environment adds nothing: path.hlsli:1049-1058)
-    const uint32_t path_length = (meta & 0xFFu) + 1u, diffuse_vertices = (meta >> 8) & 0xFFu;
-    const uint32_t f = p.inst_flags[ip & 0xFFFFu];
-    const bool last = !(f & INST_FLAG_CAN_EVAL) || path_length >= p.pc.gMaxPathVertices || (!(f & INST_FLAG_SPECULAR) && diffuse_vertices + 1u > p.pc.gMaxDiffuseVertices);
-    if ((f & (INST_FLAG_KEEP | INST_FLAG_EMITS)) || !last) {
+    if (meta >= 0xFFFFFFFEu) continue;
+    bool keep = false;
+    if (ip == 0xFFFFFFFFu) {
+      keep = (p.scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT) != 0;  // (a miss without an environment adds nothing: path.hlsli:1049-1058)
+    } else {
+      const uint32_t path_length = (meta & 0xFFu) + 1u, diffuse_vertices = (meta >> 8) & 0xFFu;
+      const uint32_t f = p.inst_flags[ip & 0xFFFFu];
+      const bool last = !(f & INST_FLAG_CAN_EVAL) || path_length >= p.pc.gMaxPathVertices || (!(f & INST_FLAG_SPECULAR) && diffuse_vertices + 1u > p.pc.gMaxDiffuseVertices);
+      keep = (f & (INST_FLAG_KEEP | INST_FLAG_EMITS)) || !last;
+    }
+    if (keep) {
       const uint32_t k = atomicAdd(&cull_lds[0], 1u);
       if (k < capacity) cull_lds[2 + k] = slot;  // (capacity = the most entries a block can meet: always true)
     }

@@ -1656,3 +1656,44 @@ def test_last_rays_answered_from_the_bounds_of_moving_emitters():
                 assert np.array_equal(got["radiance"].view(np.uint32), plain["radiance"].view(np.uint32)) and np.array_equal(got["ray_count"], plain["ray_count"])
         finally:
             r.close()
+
+
+def test_culling_finished_paths_with_spheres_reservoirs_and_an_environment():
+    """k_cull_terminal in front of the extended k_shade instantiation (scenes without images: sphere instances and lights, an
+    environment, NEE reservoirs): a hit on a sphere is judged by its instance's material like any other, a miss is kept where
+    an environment adds the background, NEE reservoirs change what a vertex does but not what a last vertex can add. Last rays
+    are not answered there (the filter lives in the plain instantiation). Frames and ray counts are the oracle's and do not
+    depend on the options."""
+    from oracle import oracle_py
+    from stratum_amd.bdpt import BDPT
+
+    cases = (
+        (scenes.spheres_room, {}, [], False),
+        (scenes.spheres_room, {"maxDiffuseVertices": 3, "maxPathVertices": 5}, ["uniformspheresampling"], False),
+        (scenes.cornell_box, {}, ["neereservoirs"], False),
+        (lambda: scenes.environment_scene(image=True, emitter=True), {}, [], False),
+        (lambda: scenes.environment_scene(image=False, emitter=False), {"maxDiffuseVertices": 1}, [], False),
+    )
+    for make, args, flags, answers in cases:
+        sc, cam = make()
+        frame = camera.Frame(128, 96, cam["fovy"], cam["eye"], cam["target"])
+        frames, answered = [], []
+        for cull, answer in ((1, 1), (0, 0)):
+            r = BDPT(device=0, args=dict(args, bdptFlag=flags))
+            try:
+                r.set_option("cull_terminal", cull)
+                r.set_option("answer_last_rays", answer)
+                r.update(sc)
+                frames.append(r.render(frame, 5, 2))
+                answered.append(r.stats()["rays_answered"])
+                if cull:
+                    ref = oracle_py.OracleScene(sc).render(frame, r.push_constants(frame), r.mSamplingFlags, 5, 2)
+            finally:
+                r.close()
+        a, b = frames
+        for k in ("radiance", "albedo"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (sc.name, flags, k)
+        assert np.array_equal(a["ray_count"], b["ray_count"])
+        assert np.array_equal(a["radiance"].view(np.uint32), ref["radiance"].view(np.uint32)), (sc.name, flags)
+        assert np.array_equal(a["ray_count"], ref["ray_count"])
+        assert answered[1] == 0 and (answered[0] > 0) == answers, (sc.name, flags, answered)

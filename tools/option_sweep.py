@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: one sthip option swept on the bench frame — per-kernel ms of a step (time_kernels) and the frame's bytes against the first value.
-usage: tools/option_sweep.py <scene> <option> <value> [value ...] [-- other=value ...]"""
+usage: [STHIP_SWEEP_FLAGS=flag,flag] tools/option_sweep.py <scene> <option> <value> [value ...] [-- other=value ...]"""
+import os
 import sys
 
 import numpy as np
@@ -17,7 +18,7 @@ if "--" in args:
 name, option, values = args[0], args[1], [int(v, 0) for v in args[2:]]
 sc, cam = scenes.SCENES[name]()
 frame = camera.Frame(1920, 1080, cam["fovy"], cam["eye"], cam["target"])
-r = BDPT(0)
+r = BDPT(0, args={"bdptFlag": os.environ["STHIP_SWEEP_FLAGS"].split(",")} if os.environ.get("STHIP_SWEEP_FLAGS") else None)  # e.g. STHIP_SWEEP_FLAGS=neereservoirs
 for a in fixed:
     k, v = a.split("=")
     r.set_option(k, int(v, 0))
