@@ -118,6 +118,11 @@ struct sthip_ctx {
   DevBuf<TlasEntry> entries;
   DevBuf<WideNode> wide_nodes;
   DevBuf<TlasEntry> wide_entries;
+  DevBuf<Wide8Node> wide8_nodes;
+  DevBuf<TlasEntry> wide8_entries;
+  std::vector<Wide8Node> wide8_host;  // the 8-wide nodes as uploaded: a transforms-only update makes the top level's again behind the bottom levels'
+  size_t wide8_node_count = 0;
+  uint32_t tri_min_lanes = 1;  // "tri_min_lanes" (DeviceBvh::wide8_tri_min)
   DeviceBvh bvh{};
   uint64_t bvh_nodes = 0, bvh_tris = 0;
   // treetop (bvh_build.h): rebuilt whenever the top level changes; needs the nodes on the host
@@ -133,6 +138,8 @@ struct sthip_ctx {
   // host-built trees are collapsed on the host, GPU-built ones and the trees of a transforms-only update on the device
   // (wide.hip). 0 = never (the binary walk every other kernel uses), 2 = only when the binary nodes do not fit one XCD's L2
   // (4 MiB). Bench scene: k_trace -20 % against the binary walk; instanced forest (a 2.6 MB tree): equal.
+  // 3 = the 8-wide compressed form (bvh.h: Wide8Node) for host-built trees (collapsed on the host, at upload and at every
+  // transforms-only update); trees it cannot take (GPU-built ones, embedded leaves) get the 4-wide form as with 1.
   int use_wide = 1;
   size_t wide_node_count = 0;
   sthip::DeviceWideScratch* wide_scratch = nullptr;  // buffers of the device-side collapse (wide.hip), kept between calls
@@ -226,11 +233,18 @@ static const void* trace_kernel(bool count, bool alpha, bool bounded, bool top) 
       (const void*)&k_trace<false, false, true, true>,   (const void*)&k_trace<true, false, true, true>,   (const void*)&k_trace<false, true, true, true>,   (const void*)&k_trace<true, true, true, true>};
   return table[(count ? 1 : 0) | (alpha ? 2 : 0) | (bounded ? 4 : 0) | (top ? 8 : 0)];
 }
+// ... over the 8-wide compressed tree ("wide_bvh" = 3)
+static const void* trace_kernel_wide8(bool count, bool alpha, bool bounded) {
+  static const void* const table[8] = {
+      (const void*)&k_trace<false, false, false, false, 2>, (const void*)&k_trace<true, false, false, false, 2>, (const void*)&k_trace<false, true, false, false, 2>, (const void*)&k_trace<true, true, false, false, 2>,
+      (const void*)&k_trace<false, false, true, false, 2>,  (const void*)&k_trace<true, false, true, false, 2>,  (const void*)&k_trace<false, true, true, false, 2>,  (const void*)&k_trace<true, true, true, false, 2>};
+  return table[(count ? 1 : 0) | (alpha ? 2 : 0) | (bounded ? 4 : 0)];
+}
 // ... and over the 4-wide tree ("wide_bvh"; never with the treetop)
 static const void* trace_kernel_wide(bool count, bool alpha, bool bounded) {
   static const void* const table[8] = {
-      (const void*)&k_trace<false, false, false, false, true>, (const void*)&k_trace<true, false, false, false, true>, (const void*)&k_trace<false, true, false, false, true>, (const void*)&k_trace<true, true, false, false, true>,
-      (const void*)&k_trace<false, false, true, false, true>,  (const void*)&k_trace<true, false, true, false, true>,  (const void*)&k_trace<false, true, true, false, true>,  (const void*)&k_trace<true, true, true, false, true>};
+      (const void*)&k_trace<false, false, false, false, 1>, (const void*)&k_trace<true, false, false, false, 1>, (const void*)&k_trace<false, true, false, false, 1>, (const void*)&k_trace<true, true, false, false, 1>,
+      (const void*)&k_trace<false, false, true, false, 1>,  (const void*)&k_trace<true, false, true, false, 1>,  (const void*)&k_trace<false, true, true, false, 1>,  (const void*)&k_trace<true, true, true, false, 1>};
   return table[(count ? 1 : 0) | (alpha ? 2 : 0) | (bounded ? 4 : 0)];
 }
 
@@ -311,6 +325,7 @@ int sthip_create(int device, sthip_ctx** out_ctx) {
     const int lds_max = 160 * 1024;
     for (int k = 0; k < 16; k++) (void)hipFuncSetAttribute(trace_kernel((k & 1) != 0, (k & 2) != 0, (k & 4) != 0, (k & 8) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     for (int k = 0; k < 8; k++) (void)hipFuncSetAttribute(trace_kernel_wide((k & 1) != 0, (k & 2) != 0, (k & 4) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    for (int k = 0; k < 8; k++) (void)hipFuncSetAttribute(trace_kernel_wide8((k & 1) != 0, (k & 2) != 0, (k & 4) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_batch<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -427,7 +442,9 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
   else if (!strcmp(name, "embed_leaves"))  // takes effect at the next sthip_scene_upload
     ctx->embed_leaves = value != 0;
   else if (!strcmp(name, "wide_bvh"))  // takes effect at the next sthip_scene_upload (host-built trees only)
-    ctx->use_wide = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
+    ctx->use_wide = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 3);
+  else if (!strcmp(name, "tri_min_lanes"))  // the 8-wide walk's leaf phase goes on while at least this many lanes hold a triangle
+    ctx->tri_min_lanes = ctx->bvh.wide8_tri_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 64);
   else if (!strcmp(name, "lbvh_algorithm"))  // 0: Karras radix tree, 1: PLOC (default)
     ctx->lbvh_algorithm = value == 0 ? 0 : 1;
   else if (!strcmp(name, "lds_stack_levels")) {  // takes effect at the next sthip_scene_upload / sthip_scene_update_transforms
@@ -462,7 +479,7 @@ int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out) {
     ctx->stats_pending = false;
   }
   *out = ctx->stats;
-  out->bvh_node_bytes = ctx->bvh.wide_nodes ? (uint32_t)sizeof(WideNode) : (uint32_t)sizeof(BvhNodePacked);  // of the nodes k_trace walks (its visits are what the counters count)
+  out->bvh_node_bytes = ctx->bvh.wide8_nodes ? (uint32_t)sizeof(Wide8Node) : ctx->bvh.wide_nodes ? (uint32_t)sizeof(WideNode) : (uint32_t)sizeof(BvhNodePacked);  // of the nodes k_trace walks (its visits are what the counters count)
   out->bvh_tri_bytes = sizeof(BvhTri);
   out->bvh_nodes = ctx->bvh_nodes;
   out->bvh_tris = ctx->bvh_tris;
@@ -815,6 +832,8 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     ctx->image_count = s->image_count;
   }
 
+  // the 8-wide form permutes the leaf triangles (bvh_build.h): made before anything of the tree is uploaded
+  if (ctx->use_wide == 3 && !ctx->use_treetop && !built.embedded && built.dev_nodes == 0) sthip::build_wide8_bvh(built);
   // headroom: a transforms-only update may build a top level with more inner nodes than this one (at most 2 per entry)
   const size_t nodes_total = (size_t)built.dev_nodes + built.nodes.size(), tris_total = (size_t)built.dev_tris + built.tris.size();
   const size_t nodes_needed = std::max<size_t>(1, built.top.blas_nodes + 2 * built.entries.size() + 2);
@@ -842,7 +861,27 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   ctx->bvh.wide_root_ref = BVH_INVALID_REF;
   ctx->bvh.wide_stack_depth = 0;
   ctx->wide_node_count = 0;
-  ctx->want_wide = (ctx->use_wide == 1 || (ctx->use_wide == 2 && nodes_total * sizeof(BvhNodePacked) > ((size_t)4 << 20))) && !ctx->use_treetop && !built.embedded;
+  ctx->bvh.wide8_nodes = nullptr;
+  ctx->bvh.wide8_entries = nullptr;
+  ctx->bvh.wide8_root = BVH_INVALID_REF;
+  ctx->bvh.wide8_stack_depth = 0;
+  ctx->bvh.wide8_tri_min = ctx->tri_min_lanes;
+  ctx->wide8_node_count = 0;
+  ctx->wide8_host.clear();
+  if (!built.wide8_nodes.empty()) {
+    // (room for a rebuilt top level: at most one node per entry and per two entries above them, and a copy of the merged mesh's root)
+    HIP_TRY(ctx, ctx->wide8_nodes.ensure(built.top.wide8_blas_nodes + 2 * built.entries.size() + 4));
+    HIP_TRY(ctx, ctx->wide8_entries.ensure(std::max<size_t>(1, built.entries.size())));
+    HIP_TRY(ctx, hipMemcpy(ctx->wide8_nodes.p, built.wide8_nodes.data(), built.wide8_nodes.size() * sizeof(Wide8Node), hipMemcpyHostToDevice));
+    if (!built.wide8_entries.empty()) HIP_TRY(ctx, hipMemcpy(ctx->wide8_entries.p, built.wide8_entries.data(), built.wide8_entries.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
+    ctx->bvh.wide8_nodes = reinterpret_cast<const uint4*>(ctx->wide8_nodes.p);
+    ctx->bvh.wide8_entries = ctx->wide8_entries.p;
+    ctx->bvh.wide8_root = built.wide8_root;
+    ctx->bvh.wide8_stack_depth = built.wide8_stack_depth;
+    ctx->wide8_node_count = built.wide8_nodes.size();
+    ctx->wide8_host = std::move(built.wide8_nodes);
+  }
+  ctx->want_wide = (ctx->use_wide == 1 || (ctx->use_wide == 3 && !ctx->bvh.wide8_nodes) || (ctx->use_wide == 2 && nodes_total * sizeof(BvhNodePacked) > ((size_t)4 << 20))) && !ctx->use_treetop && !built.embedded;
   if (ctx->want_wide && built.dev_nodes == 0) {  // a host-built tree: collapsed on the host from its exact boxes (a device build: below, from the nodes in HBM)
     sthip::build_wide_bvh(built);
     if (!built.wide_nodes.empty() && built.wide_nodes.size() * sizeof(WideNode) <= 0xFFFFFFFFull) {
@@ -962,7 +1001,11 @@ static uint32_t grid_for(const sthip_ctx* ctx, size_t n) {
 static int trace_occupancy(const sthip_ctx* ctx, size_t lds_bytes) {  // resident k_trace blocks per CU with that much dynamic LDS
   int per_cu = 0;
   hipError_t e;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ctx->bvh.wide_nodes ? trace_kernel_wide(false, false, ctx->bvh.spill != nullptr) : trace_kernel(false, false, ctx->bvh.spill != nullptr, ctx->use_treetop), STHIP_BLOCK, lds_bytes);
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu,
+                                                   ctx->bvh.wide8_nodes  ? trace_kernel_wide8(false, false, ctx->bvh.spill != nullptr)
+                                                   : ctx->bvh.wide_nodes ? trace_kernel_wide(false, false, ctx->bvh.spill != nullptr)
+                                                                         : trace_kernel(false, false, ctx->bvh.spill != nullptr, ctx->use_treetop),
+                                                   STHIP_BLOCK, lds_bytes);
   return e == hipSuccess ? per_cu : 0;
 }
 static uint32_t trace_grid(sthip_ctx* ctx, size_t lds_bytes) {
@@ -971,7 +1014,7 @@ static uint32_t trace_grid(sthip_ctx* ctx, size_t lds_bytes) {
   if (ctx->trace_blocks_per_cu) per_cu = (int)ctx->trace_blocks_per_cu;
   return (uint32_t)(ctx->cu_count * per_cu);
 }
-static size_t stack_bytes(const sthip_ctx* ctx) { return (size_t)ctx->bvh.lds_levels * STHIP_BLOCK * sizeof(uint32_t); }
+static size_t stack_bytes(const sthip_ctx* ctx) { return (size_t)ctx->bvh.lds_levels * STHIP_BLOCK * (ctx->bvh.wide8_nodes ? sizeof(uint2) : sizeof(uint32_t)); }  // (the 8-wide walk's entries are 64-bit groups)
 
 // LDS of one k_trace block: the per-lane stacks and, behind them, the treetop
 static size_t trace_lds_bytes(const sthip_ctx* ctx) { return stack_bytes(ctx) + (size_t)ctx->bvh.top_count * sizeof(BvhNodePacked); }
@@ -980,9 +1023,10 @@ static size_t trace_lds_bytes(const sthip_ctx* ctx) { return stack_bytes(ctx) + 
 // full height in global memory for the rays that overflow. Then the treetop takes the LDS that is left.
 static int configure_stack(sthip_ctx* ctx) {
   // (the wide walk pushes up to three children per level, and every step writes the three levels from `top` on)
-  const uint32_t need = ctx->bvh.wide_nodes ? ctx->bvh.wide_stack_depth + 3u : ctx->bvh.stack_depth;
-  const bool bounded = need > ctx->lds_stack_threshold;
-  ctx->bvh.lds_levels = bounded ? ctx->lds_stack_cap : need;
+  const uint32_t need = ctx->bvh.wide8_nodes ? ctx->bvh.wide8_stack_depth : ctx->bvh.wide_nodes ? ctx->bvh.wide_stack_depth + 3u : ctx->bvh.stack_depth;
+  // (a 64-bit entry counts as two levels of the limits, which are about LDS bytes)
+  const bool bounded = ctx->bvh.wide8_nodes ? 2u * need > ctx->lds_stack_threshold : need > ctx->lds_stack_threshold;
+  ctx->bvh.lds_levels = bounded ? (ctx->bvh.wide8_nodes ? std::max(4u, ctx->lds_stack_cap / 2u) : ctx->lds_stack_cap) : need;
   ctx->bvh.spill = nullptr;
   if (bounded) {
     // one column per lane of the largest grid a trace launch can have (persistent: resident blocks; ray batches use it too)
@@ -1128,7 +1172,26 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
   // the top level new), so a moved scene keeps the walk it was uploaded with
   ctx->bvh.wide_nodes = nullptr;
   ctx->bvh.wide_entries = nullptr;
-  if (ctx->want_wide) {
+  if (ctx->bvh.wide8_nodes) {  // the 8-wide form: its top level again, on the host (a node per few entries), behind the bottom levels' nodes
+    std::vector<TlasEntry> entries8;
+    uint32_t root8 = BVH_INVALID_REF, depth8 = 0;
+    ctx->bvh.wide8_nodes = nullptr;
+    if (sthip::build_wide8_top(ctx->top, tlas.data(), ctx->top.blas_nodes, root_ref, top_is_world != 0, ctx->wide8_host, entries8, root8, depth8) && ctx->wide8_host.size() <= ctx->wide8_nodes.n &&
+        entries8.size() <= ctx->wide8_entries.n) {
+      const size_t first = ctx->top.wide8_blas_nodes;
+      if (ctx->wide8_host.size() > first)
+        HIP_TRY(ctx, hipMemcpy(ctx->wide8_nodes.p + first, ctx->wide8_host.data() + first, (ctx->wide8_host.size() - first) * sizeof(Wide8Node), hipMemcpyHostToDevice));
+      if (!entries8.empty()) HIP_TRY(ctx, hipMemcpy(ctx->wide8_entries.p, entries8.data(), entries8.size() * sizeof(TlasEntry), hipMemcpyHostToDevice));
+      ctx->bvh.wide8_nodes = reinterpret_cast<const uint4*>(ctx->wide8_nodes.p);
+      ctx->bvh.wide8_entries = ctx->wide8_entries.p;
+      ctx->bvh.wide8_root = root8;
+      ctx->bvh.wide8_stack_depth = depth8;
+      ctx->wide8_node_count = ctx->wide8_host.size();
+    } else {  // (a top level that cannot take the form: the 4-wide one from here on)
+      ctx->want_wide = !ctx->use_treetop;
+    }
+  }
+  if (ctx->want_wide && !ctx->bvh.wide8_nodes) {
     const int rc = collapse_resident_tree(ctx);
     if (rc != STHIP_OK) return rc;
   }
@@ -1652,7 +1715,10 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
       return timed(ms_trace, [&]() {
         const bool alpha = p.bvh.alpha_test || ctx->has_volumes;  // alpha masks under eAlphaTest, volume instances: the instantiation that carries them
         void* kargs[3] = {(void*)&p, (void*)&dc, (void*)&ds};
-        (void)hipLaunchKernel(p.bvh.wide_nodes ? trace_kernel_wide(ctx->count_traversal, alpha, p.bvh.spill != nullptr) : trace_kernel(ctx->count_traversal, alpha, p.bvh.spill != nullptr, p.bvh.top_count != 0), dim3(tgrid), dim3(STHIP_BLOCK), kargs, lds, st);
+        (void)hipLaunchKernel(p.bvh.wide8_nodes  ? trace_kernel_wide8(ctx->count_traversal, alpha, p.bvh.spill != nullptr)
+                              : p.bvh.wide_nodes ? trace_kernel_wide(ctx->count_traversal, alpha, p.bvh.spill != nullptr)
+                                                 : trace_kernel(ctx->count_traversal, alpha, p.bvh.spill != nullptr, p.bvh.top_count != 0),
+                              dim3(tgrid), dim3(STHIP_BLOCK), kargs, lds, st);
         if (p.bvh.spill) {  // a tree higher than the LDS stack ran the bounded instantiation: now the rays that overflowed
           const uint32_t dgrid = (uint32_t)ctx->cu_count * 8u;  // one spill column per thread (configure_stack)
           if (alpha) {

@@ -77,6 +77,29 @@ struct WideNode {
   uint32_t pad[2];
   uint32_t ref[4];
 };
+// The 8-wide compressed node ("wide_bvh" = 3; bvh_build.h: build_wide8_bvh): 80 bytes = five 16-byte loads per lane, after
+// Ylitie, Karras, Laine, "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs" (HPG 2017). The boxes of
+// up to eight children as 8-bit planes on the node's grid (as WideNode). No child references: the INNER children of a node
+// are consecutive nodes of this array from child_base on, in slot order (child of slot s = child_base + popcount(imask &
+// ((1 << s) - 1))); its LEAF children's items (triangles; top-level entries in a node of the top level) are consecutive
+// from leaf_base on. So what a walk keeps of a visited node is a GROUP — a base and a bit mask — and its stack holds groups.
+//   meta[s]: 0 = unused slot; inner child: 0x20 | (24 + s); leaf child: (unary item count: 1, 3 or 7) << 5 | first item
+//   (relative to leaf_base, < 24). A hit child contributes (meta >> 5) << (meta & 31) to the 32-bit hit mask of the node:
+//   items in bits 0..23, inner children in bits 24..31 — the latter at 24 + (s ^ octinv), octinv = 7 ^ (sign bits of the
+//   ray direction), so that the highest set bit is the child to visit first: the builder puts the child lying toward the
+//   (+x, +y, +z) corner of the node into slot 7, toward (-x, -y, -z) into slot 0, and so on.
+// Slots are filled sparsely (by position); an unused slot also has entry planes behind its exit planes.
+struct Wide8Node {
+  float origin[3];
+  uint8_t exp[3];       // signed exponents of the x, y, z plane step
+  uint8_t imask;        // slots that hold inner children
+  uint32_t child_base;  // index of the first inner child in this array
+  uint32_t leaf_base;   // first item of the leaf children: a triangle index, or WIDE8_ENTRY_BIT | index into the entry table
+  uint8_t meta[8];
+  uint8_t q[6][8];      // [lo.x, hi.x, lo.y, hi.y, lo.z, hi.z][slot]
+};
+#define WIDE8_ENTRY_BIT 0x80000000u
+#define WIDE8_MAX_ITEMS 24
 #define BVH_NO_ALPHA 0xFFFFFFFFu  // DeviceBvh::inst_alpha entry of an instance whose material has no alpha mask
 // uv of the three vertices of a leaf triangle, in leaf order next to BvhTri; only built for scenes with alpha masks
 struct BvhTriUv {
@@ -117,5 +140,6 @@ static_assert(sizeof(BvhNodePacked) == 48, "BvhNodePacked");
 static_assert(sizeof(BvhNodeSlot) == BVH_NODE_BYTES, "BvhNodeSlot");
 static_assert(sizeof(BvhTri) == 48, "BvhTri");
 static_assert(sizeof(WideNode) == 64, "WideNode");
+static_assert(sizeof(Wide8Node) == 80, "Wide8Node");
 static_assert(sizeof(TlasEntry) == 80, "TlasEntry");
 #endif

@@ -1016,6 +1016,311 @@ void build_wide_bvh(BuiltBvh& out) {
   }
 }
 
+// ---- the 8-wide compressed form (bvh.h: Wide8Node) ----
+namespace {
+struct Wide8Child {
+  Box box;
+  uint32_t ref;     // binary reference; for a spliced bottom level: the wide8 node to copy
+  uint8_t kind;     // 0 = inner (binary node to collapse), 1 = leaf (triangles / an entry), 2 = a bottom level's root spliced in
+};
+// Which child goes to which slot: the child lying toward corner (sx, sy, sz) of the node belongs in the slot with those bits,
+// so that a ray meets the slots in the order of (slot ^ its octant) — greedy over cost(child, slot) = <centroid offset, corner
+// direction>, largest first (Ylitie et al. 2017, section 4.2, with the greedy assignment instead of the auction).
+void assign_slots(const Wide8Child* ch, int n, uint8_t* slot) {
+  Box all;
+  all.reset();
+  for (int k = 0; k < n; k++) all.grow(ch[k].box);
+  float cost[8][8];
+  for (int k = 0; k < n; k++)
+    for (int s = 0; s < 8; s++) {
+      float c = 0;
+      for (int a = 0; a < 3; a++) {
+        const float d = 0.5f * (ch[k].box.lo[a] + ch[k].box.hi[a]) - 0.5f * (all.lo[a] + all.hi[a]);
+        c += ((s >> a) & 1) ? d : -d;
+      }
+      cost[k][s] = c;
+    }
+  bool child_done[8] = {false, false, false, false, false, false, false, false}, slot_taken[8] = {false, false, false, false, false, false, false, false};
+  for (int round = 0; round < n; round++) {
+    int bk = -1, bs = -1;
+    float best = -INFINITY;
+    for (int k = 0; k < n; k++) {
+      if (child_done[k]) continue;
+      for (int s = 0; s < 8; s++)
+        if (!slot_taken[s] && (bk < 0 || cost[k][s] > best)) {
+          best = cost[k][s];
+          bk = k;
+          bs = s;
+        }
+    }
+    child_done[bk] = true;
+    slot_taken[bs] = true;
+    slot[bk] = (uint8_t)bs;
+  }
+}
+
+struct Wide8Builder {
+  std::vector<Wide8Node>& out;
+  bool ok = true;
+  // bottom levels: the binary nodes and the triangle permutation
+  const std::vector<BvhNode>* nodes = nullptr;
+  const std::vector<BvhTri>* tris_in = nullptr;
+  std::vector<BvhTri> tris_out;
+  std::vector<uint32_t> new_index;  // old triangle index -> new
+  // top level
+  const TopLevelState* st = nullptr;
+  const BvhNode* tlas = nullptr;
+  uint32_t tlas_base = 0;
+  std::vector<TlasEntry>* entries_out = nullptr;
+
+  explicit Wide8Builder(std::vector<Wide8Node>& o) : out(o) {}
+
+  const BvhNode& bin(uint32_t r, bool top) const { return top ? tlas[r - tlas_base] : (*nodes)[r]; }
+
+  // the child a binary reference stands for (top level: the merged mesh's entry is its bottom level's root, spliced in)
+  Wide8Child make_child(const Box& box, uint32_t r, bool top) const {
+    Wide8Child c;
+    c.box = box;
+    c.ref = r;
+    c.kind = (r & BVH_LEAF_BIT) ? 1 : 0;
+    if (top && !(r & BVH_LEAF_BIT) && r < tlas_base) c.kind = 3;  // (never: top-level nodes only refer to top-level nodes and entries; fill() gives up)
+    if (top && (r & (BVH_LEAF_BIT | BVH_INST_BIT)) == (BVH_LEAF_BIT | BVH_INST_BIT) && r < 0xFFFFFFFEu) {
+      const uint32_t k = r & 0xFFFFu;
+      if (st->entries[k].identity == TLAS_ENTRY_IDENTITY && st->wide8_root[k] != BVH_INVALID_REF) {
+        c.kind = 2;
+        c.ref = st->wide8_root[k];
+      }
+    }
+    return c;
+  }
+
+  // up to eight children of binary inner node i: the inner child with the largest box is opened until there are eight
+  int gather(uint32_t i, bool top, Wide8Child* ch) const {
+    int n = 0;
+    const BvhNode& root = bin(i, top);
+    for (int c = 0; c < 2; c++) {
+      if (root.ref[c] == BVH_INVALID_REF) continue;
+      if (n == 1 && root.ref[c] == root.ref[0]) continue;  // a wrapped lone leaf fills both slots
+      ch[n++] = make_child(child_box(root, c), root.ref[c], top);
+    }
+    while (n < 8) {
+      int pick = -1;
+      float area = -1.0f;
+      for (int k = 0; k < n; k++)
+        if (ch[k].kind == 0 && ch[k].box.half_area() > area) {
+          area = ch[k].box.half_area();
+          pick = k;
+        }
+      if (pick < 0) break;
+      const BvhNode& b = bin(ch[pick].ref, top);
+      if (b.ref[0] == b.ref[1] || b.ref[1] == BVH_INVALID_REF) {
+        ch[pick] = make_child(child_box(b, 0), b.ref[0], top);
+        continue;
+      }
+      if (b.ref[0] == BVH_INVALID_REF) {
+        ch[pick] = make_child(child_box(b, 1), b.ref[1], top);
+        continue;
+      }
+      const Wide8Child a1 = make_child(child_box(b, 1), b.ref[1], top);
+      ch[pick] = make_child(child_box(b, 0), b.ref[0], top);
+      ch[n++] = a1;
+    }
+    return n;
+  }
+
+  // makes wide8 node w from binary inner node i; returns the height of the subtree (levels of wide8 nodes, a spliced bottom
+  // level counted with blas_height)
+  uint32_t fill(uint32_t w, uint32_t i, bool top, uint32_t blas_height) {
+    Wide8Child ch[8];
+    const int n = gather(i, top, ch);
+    uint8_t slot[8];
+    assign_slots(ch, n, slot);
+    int at[8];  // slot -> child or -1
+    for (int s = 0; s < 8; s++) at[s] = -1;
+    for (int k = 0; k < n; k++) at[slot[k]] = k;
+    Wide8Node wn;
+    memset(&wn, 0, sizeof(wn));
+    WideChildBox boxes[8];
+    for (int k = 0; k < n; k++) {
+      memcpy(boxes[k].lo, ch[k].box.lo, 12);
+      memcpy(boxes[k].hi, ch[k].box.hi, 12);
+    }
+    if (n == 0 || !wide8_quantise(boxes, slot, n, wn)) ok = false;
+    for (int k = 0; k < n; k++)
+      if (ch[k].kind == 3) {
+        ok = false;
+        ch[k].kind = 1;
+        ch[k].ref = BVH_LEAF_BIT | BVH_INST_BIT;
+      }
+    if (!ok) {  // (the caller drops the whole form)
+      out[w] = wn;
+      return 1;
+    }
+    uint32_t inner = 0;
+    for (int k = 0; k < n; k++) inner += ch[k].kind != 1 ? 1u : 0u;
+    wn.child_base = (uint32_t)out.size();
+    out.resize(out.size() + inner);
+    uint32_t items = 0;
+    if (top)
+      wn.leaf_base = WIDE8_ENTRY_BIT | (uint32_t)entries_out->size();
+    else
+      wn.leaf_base = (uint32_t)tris_out.size();
+    for (int s = 0; s < 8; s++) {
+      if (at[s] < 0) continue;
+      const Wide8Child& c = ch[at[s]];
+      if (c.kind != 1) {
+        wn.imask |= (uint8_t)(1u << s);
+        wn.meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
+        continue;
+      }
+      uint32_t count = 1;
+      if (top) {  // a top-level entry: its bottom level starts at a wide8 node
+        const uint32_t k = c.ref & 0xFFFFu;
+        TlasEntry e = st->entries[k];
+        if (e.identity == TLAS_ENTRY_IDENTITY || e.identity == TLAS_ENTRY_TRANSFORMED) {
+          e.root = st->wide8_root[k];
+          if (e.root == BVH_INVALID_REF) ok = false;
+        }
+        entries_out->push_back(e);
+      } else {
+        const uint32_t first = (c.ref & 0x3FFFFFFFu) >> 2;
+        count = (c.ref & 3u) + 1u;
+        if (count > 3u || first + count > tris_in->size() || new_index[first] != 0xFFFFFFFFu) {
+          ok = false;
+          count = 1;
+        } else {
+          for (uint32_t t = 0; t < count; t++) {
+            new_index[first + t] = (uint32_t)tris_out.size();
+            tris_out.push_back((*tris_in)[first + t]);
+          }
+        }
+      }
+      if (items + count > WIDE8_MAX_ITEMS) ok = false;
+      wn.meta[s] = (uint8_t)((((1u << count) - 1u) << 5) | (items & 31u));
+      items += count;
+    }
+    out[w] = wn;
+    uint32_t below = 0, rank = 0;
+    for (int s = 0; s < 8; s++) {
+      if (at[s] < 0 || ch[at[s]].kind == 1) continue;
+      const Wide8Child& c = ch[at[s]];
+      const uint32_t cw = wn.child_base + rank++;
+      if (c.kind == 2) {  // the merged mesh's root, copied: its own children and items stay where they are
+        out[cw] = out[c.ref];
+        below = std::max(below, blas_height);
+      } else {
+        below = std::max(below, fill(cw, c.ref, top, blas_height));
+      }
+    }
+    return 1 + below;
+  }
+};
+}  // namespace
+
+void build_wide8_bvh(BuiltBvh& out) {
+  out.wide8_nodes.clear();
+  out.wide8_entries.clear();
+  out.wide8_root = BVH_INVALID_REF;
+  out.wide8_stack_depth = 0;
+  out.top.wide8_root.assign(out.entries.size(), BVH_INVALID_REF);
+  out.top.wide8_blas_nodes = 0;
+  out.top.wide8_blas_height = 0;
+  if (out.dev_nodes || out.embedded || out.root_ref == BVH_INVALID_REF || out.nodes.empty()) return;
+  std::vector<Wide8Node> nodes;
+  nodes.reserve(out.nodes.size() / 3 + 16);
+  Wide8Builder wb(nodes);
+  wb.nodes = &out.nodes;
+  wb.tris_in = &out.tris;
+  wb.tris_out.reserve(out.tris.size());
+  wb.new_index.assign(out.tris.size(), 0xFFFFFFFFu);
+  // bottom levels: one per binary root (instances of a shared mesh share theirs)
+  std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> of_root;  // binary root -> (wide8 root, height)
+  uint32_t blas_height = 0;
+  for (size_t k = 0; k < out.entries.size(); k++) {
+    const TlasEntry& e = out.entries[k];
+    if (e.identity != TLAS_ENTRY_IDENTITY && e.identity != TLAS_ENTRY_TRANSFORMED) continue;
+    if (e.root == BVH_INVALID_REF || (e.root & BVH_LEAF_BIT) || e.root >= out.nodes.size()) return;
+    auto it = of_root.find(e.root);
+    if (it == of_root.end()) {
+      const uint32_t w = (uint32_t)nodes.size();
+      nodes.push_back(Wide8Node());
+      const uint32_t h = wb.fill(w, e.root, false, 0);
+      it = of_root.emplace(e.root, std::make_pair(w, h)).first;
+    }
+    out.top.wide8_root[k] = it->second.first;
+    blas_height = std::max(blas_height, it->second.second);
+  }
+  if (!wb.ok || nodes.size() >= (1u << 24)) return;
+  out.top.wide8_blas_nodes = (uint32_t)nodes.size();
+  out.top.wide8_blas_height = blas_height;
+  // the permutation is complete only if every triangle was reached (it is: every triangle lies in a leaf of some bottom
+  // level); anything else keeps its place behind the others
+  for (size_t t = 0; t < out.tris.size(); t++)
+    if (wb.new_index[t] == 0xFFFFFFFFu) {
+      wb.new_index[t] = (uint32_t)wb.tris_out.size();
+      wb.tris_out.push_back(out.tris[t]);
+    }
+  std::vector<TlasEntry> entries;
+  uint32_t root = BVH_INVALID_REF, depth = 0;
+  // (the top level's binary nodes are the ones behind the bottom levels': out.nodes itself serves as `tlas` with base 0 —
+  // every reference of a top-level node to another one is >= out.top.blas_nodes, which build_wide8_top takes as its base)
+  if (!build_wide8_top(out.top, out.nodes.data() + out.top.blas_nodes, out.top.blas_nodes, out.root_ref, out.top_is_world_blas != 0, nodes, entries, root, depth)) {
+    out.top.wide8_root.assign(out.entries.size(), BVH_INVALID_REF);
+    out.top.wide8_blas_nodes = 0;
+    return;
+  }
+  // commit: the triangles in their new order, the binary leaves pointing at them
+  for (BvhNode& nd : out.nodes)
+    for (int c = 0; c < 2; c++) {
+      const uint32_t r = nd.ref[c];
+      if ((r & (BVH_LEAF_BIT | BVH_INST_BIT)) != BVH_LEAF_BIT) continue;
+      nd.ref[c] = BVH_LEAF_BIT | (wb.new_index[(r & 0x3FFFFFFFu) >> 2] << 2) | (r & 3u);
+    }
+  if (!out.tri_uvs.empty()) {
+    std::vector<BvhTriUv> uv(out.tri_uvs.size());
+    for (size_t t = 0; t < out.tris.size() && t < out.tri_uvs.size(); t++) uv[wb.new_index[t]] = out.tri_uvs[t];
+    out.tri_uvs.swap(uv);
+  }
+  out.tris.swap(wb.tris_out);
+  out.wide8_nodes.swap(nodes);
+  out.wide8_entries.swap(entries);
+  out.wide8_root = root;
+  out.wide8_stack_depth = depth;
+}
+
+bool build_wide8_top(const TopLevelState& st, const BvhNode* tlas, uint32_t tlas_base, uint32_t root_ref, bool top_is_world_blas, std::vector<Wide8Node>& nodes, std::vector<TlasEntry>& entries,
+                     uint32_t& wide8_root, uint32_t& wide8_stack_depth) {
+  entries.clear();
+  nodes.resize(st.wide8_blas_nodes);
+  wide8_root = BVH_INVALID_REF;
+  wide8_stack_depth = 0;
+  if (st.wide8_root.size() != st.entries.size() || root_ref == BVH_INVALID_REF) return false;
+  if (top_is_world_blas) {  // no top level: the walk starts at the merged mesh's root
+    if (st.entries.empty() || st.wide8_root[0] == BVH_INVALID_REF) return false;
+    entries = st.entries;
+    for (size_t k = 0; k < entries.size(); k++)
+      if (st.wide8_root[k] != BVH_INVALID_REF) entries[k].root = st.wide8_root[k];
+    wide8_root = st.wide8_root[0];
+    wide8_stack_depth = st.wide8_blas_height + 2;  // a group per level at most, the sentinel at the bottom, the spare slot of the speculative push
+    return true;
+  }
+  if ((root_ref & BVH_LEAF_BIT) || root_ref < tlas_base) return false;
+  Wide8Builder wb(nodes);
+  wb.st = &st;
+  wb.tlas = tlas;
+  wb.tlas_base = tlas_base;
+  wb.entries_out = &entries;
+  const uint32_t w = (uint32_t)nodes.size();
+  nodes.push_back(Wide8Node());
+  const uint32_t top_height = wb.fill(w, root_ref, true, st.wide8_blas_height);
+  if (!wb.ok || nodes.size() >= (1u << 24) || entries.size() >= 0x7FFFFFFFu) return false;
+  wide8_root = w;
+  // per level of the top level one group; entering an instance leaves the rest of the node group, the rest of the entry group
+  // and the exit sentinel; then a group per level of the bottom level; the sentinel at the bottom, the spare slot
+  wide8_stack_depth = top_height + 3 + st.wide8_blas_height + 2;
+  return true;
+}
+
 bool rebuild_top_level(TopLevelState& st, const sthip_TransformData* xf, const sthip_TransformData* inv, uint32_t instance_count, std::vector<BvhNode>& tlas_nodes, uint32_t& root_ref,
                        uint32_t& top_is_world_blas, uint32_t& stack_depth, float scene_center[3], float& scene_radius, std::string& err) {
   const uint32_t TLAS_DEPTH_CAP = 18;

@@ -30,6 +30,11 @@ struct TopLevelState {
   uint32_t blas_depth = 0;
   float merged_box[6] = {0, 0, 0, 0, 0, 0};  // world box of the merged mesh's entry
   bool has_merged = false;
+  // the 8-wide form (build_wide8_bvh): the bottom levels' nodes are [0, wide8_blas_nodes) of the wide8 array and stay; a
+  // transforms-only update makes the top level's nodes again behind them (build_wide8_top)
+  std::vector<uint32_t> wide8_root;  // per entry: the wide8 node its bottom level starts at (BVH_INVALID_REF: none)
+  uint32_t wide8_blas_nodes = 0;
+  uint32_t wide8_blas_height = 0;
 };
 
 struct BuiltBvh {
@@ -64,6 +69,12 @@ struct BuiltBvh {
   std::vector<TlasEntry> wide_entries;
   uint32_t wide_root_ref = BVH_INVALID_REF;
   uint32_t wide_stack_depth = 0;
+  // The 8-wide compressed form (build_wide8_bvh; bvh.h: Wide8Node): nodes, the entry table in the order the top level's
+  // nodes refer to it (roots index wide8_nodes), the node the walk starts at, the number of 64-bit stack entries it needs.
+  std::vector<Wide8Node> wide8_nodes;
+  std::vector<TlasEntry> wide8_entries;
+  uint32_t wide8_root = BVH_INVALID_REF;
+  uint32_t wide8_stack_depth = 0;
 };
 
 // One run of triangles of a bottom level, as the scene arrays describe it (scene.h:139-161)
@@ -120,6 +131,18 @@ bool build_scene_bvh(const sthip_scene_desc& scene, BuiltBvh& out, std::string& 
 // (bvh.h: WideNode): out.wide_*. Every leaf reference, and with it every triangle and entry, stays what it is, and every
 // decoded box contains the box it stands for: a traversal of the wide tree finds the hits the binary one finds.
 void build_wide_bvh(BuiltBvh& out);
+
+// Collapses the finished binary tree of a host build (out.dev_nodes == 0, no embedded leaves) into 8-wide compressed nodes
+// (bvh.h: Wide8Node): out.wide8_*. The items of a node's leaf children must be consecutive, so this PERMUTES out.tris (and
+// out.tri_uvs) — every binary leaf keeps its triangles together and in order — and rewrites the binary nodes' leaf
+// references to match: call it before anything is uploaded. Leaves nothing (wide8_nodes empty) when the tree cannot take
+// the form: a box that fits no grid, a leaf of more than three triangles. out.top.wide8_* keeps what build_wide8_top needs.
+void build_wide8_bvh(BuiltBvh& out);
+// The top level of the 8-wide form over `tlas` (binary top-level nodes whose inner references count from tlas_base =
+// st.blas_nodes, as rebuild_top_level returns them) and st.entries: appends to `nodes` (which holds the bottom levels'
+// st.wide8_blas_nodes nodes), makes `entries`. root_ref: the binary tree's root (rebuild_top_level). false: no 8-wide form.
+bool build_wide8_top(const TopLevelState& st, const BvhNode* tlas, uint32_t tlas_base, uint32_t root_ref, bool top_is_world_blas, std::vector<Wide8Node>& nodes, std::vector<TlasEntry>& entries,
+                     uint32_t& wide8_root, uint32_t& wide8_stack_depth);
 
 // Transforms-only update: new entry matrices and world boxes, a new top level. `tlas_nodes` come out with their child
 // references already offset by st.blas_nodes (they go to nodes[st.blas_nodes ...]). Fails (false) when an instance of the
@@ -249,6 +272,58 @@ STHIP_BVH_HD inline bool make_wide_node(const WideChildBox* ch, const uint32_t* 
         wn.q[2 * a + 1][k] = 0;
       }
     }
+  }
+  return ok;
+}
+
+// ---- the 8-wide compressed node (bvh.h: Wide8Node) ----
+// Quantises the boxes of n <= 8 children, child k in slot slot[k], onto the node's 8-bit grid exactly as make_wide_node does
+// (origin = the lower corner of their union, a power-of-two step per axis, lower planes rounded down and upper planes up,
+// checked in double); unused slots get entry planes behind exit planes. Fills origin, exp and q only. false: no grid fits.
+STHIP_BVH_HD inline bool wide8_quantise(const WideChildBox* ch, const uint8_t* slot, int n, Wide8Node& wn) {
+  bool ok = true;
+  for (int a = 0; a < 3; a++) {
+    for (int s = 0; s < 8; s++) {
+      wn.q[2 * a][s] = 255;
+      wn.q[2 * a + 1][s] = 0;
+    }
+    float lo = ch[0].lo[a], hi = ch[0].hi[a];
+    for (int k = 1; k < n; k++) {
+      lo = ch[k].lo[a] < lo ? ch[k].lo[a] : lo;
+      hi = ch[k].hi[a] > hi ? ch[k].hi[a] : hi;
+    }
+    wn.origin[a] = lo;
+    const double ext = (double)hi - (double)lo;
+    int e = 1;  // biased; the step is 2^(e - 127)
+    if (ext > 0) {
+      int x;
+      (void)frexp(ext / 255.0, &x);
+      e = x + 127 < 1 ? 1 : (x + 127 > 254 ? 254 : x + 127);
+    }
+    for (;;) {
+      const double step = ldexp(1.0, e - 127);
+      bool fits = true;
+      for (int k = 0; k < n && fits; k++) {
+        double ql = floor(((double)ch[k].lo[a] - (double)lo) / step), qh = ceil(((double)ch[k].hi[a] - (double)lo) / step);
+        while (ql > 0 && (double)lo + ql * step > (double)ch[k].lo[a]) ql -= 1;
+        while ((double)lo + qh * step < (double)ch[k].hi[a]) qh += 1;
+        if (ql < 0) ql = 0;
+        if (qh > 255 || !(qh >= 0)) {
+          fits = false;
+          break;
+        }
+        wn.q[2 * a][slot[k]] = (uint8_t)ql;
+        wn.q[2 * a + 1][slot[k]] = (uint8_t)qh;
+      }
+      if (fits) break;
+      if (e >= 254) {
+        ok = false;
+        break;
+      }
+      e++;
+    }
+    if (!(lo > -3.4e38f && lo < 3.4e38f)) ok = false;
+    wn.exp[a] = (uint8_t)(int8_t)(e - 127);
   }
   return ok;
 }

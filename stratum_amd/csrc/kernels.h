@@ -17,6 +17,7 @@
 #include "hashgrid.h"
 #include "medium.h"
 #include "traverse.h"
+#include <type_traits>
 
 #define STHIP_BLOCK 256
 
@@ -373,7 +374,9 @@ DEV void finish_ray(const FrameParams& p, float4* target, uint32_t slot, bool sh
 // its other exec-mask regions: the LDS-or-global branch it needs in every step now costs more than the LDS reads save.
 // WIDE: the walk goes over the 4-wide form of the tree (DeviceBvh::wide_nodes, "wide_bvh" = 1): fewer, fatter dependent
 // steps. Its stack has three levels from the last usable one on: every step writes top, top + 1 and top + 2.
-template <bool COUNT, bool ALPHA, bool BOUNDED = false, bool TOP = false, bool WIDE = false>
+// WIDE = 2: the walk goes over the 8-wide compressed form (DeviceBvh::wide8_nodes, "wide_bvh" = 3; traverse.h: Traversal8):
+// the stack holds 64-bit groups, one push per step at most.
+template <bool COUNT, bool ALPHA, bool BOUNDED = false, bool TOP = false, int WIDE = 0>
 __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t depth_closest, uint32_t depth_shadow) {
   extern __shared__ uint32_t lds_stack[];
   // the treetop behind the stacks: copied once per (persistent) block
@@ -391,19 +394,29 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t d
   const uint32_t* queue = p.queue[depth_closest & 1u];
   unsigned long long* ctl_c = queue_ctl(p.qctl, 0, depth_closest == TRACE_NONE ? 0u : depth_closest, 0);
   unsigned long long* ctl_s = queue_ctl(p.qctl, 1, depth_shadow == TRACE_NONE ? 0u : depth_shadow, 0);
-  uint32_t* stack = lds_stack + threadIdx.x;
+  uint32_t* stack = lds_stack + (WIDE == 2 ? 2u * threadIdx.x : threadIdx.x);  // (8-wide: this lane's column of 64-bit entries)
   float4* target = flag(p, STHIP_eDeferShadowRays) ? p.shadow_sum : p.radiance;
   TraverseCounters cnt[2];
   cnt[0].clear();
   cnt[1].clear();
   uint32_t round_slots[2] = {0, 0}, busy_rounds[2] = {0, 0};
-  if (WIDE) {
+  if (WIDE == 1) {
     bvh.entries = p.bvh.wide_entries;
     bvh.root_ref = p.bvh.wide_root_ref;
   }
-  Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, TOP, BOUNDED, true, STHIP_ENTRY_BATCH, WIDE> tr;  // SAVE_WORLD: 13 more registers, no occupancy step crossed (118 of 128; the ALPHA instantiations sit between 128 and 168 either way)
-  tr.top_lds = (const LdsFloat4*)top_lds;
-  if (BOUNDED) tr.limit = (p.bvh.lds_levels - (WIDE ? 3u : 1u)) * STHIP_BLOCK;  // (the wide step writes three levels from `top` on)
+  if (WIDE == 2) {
+    bvh.entries = p.bvh.wide8_entries;
+    bvh.root_ref = p.bvh.wide8_root;
+  }
+  typename std::conditional<WIDE == 2, Traversal8<COUNT, STHIP_BLOCK, ALPHA, BOUNDED, STHIP_ENTRY_BATCH>,
+                            Traversal<TRAV_MIXED, COUNT, STHIP_BLOCK, ALPHA, TOP, BOUNDED, true, STHIP_ENTRY_BATCH, WIDE == 1>>::type tr;  // SAVE_WORLD: 13 more registers, no occupancy step crossed (118 of 128; the ALPHA instantiations sit between 128 and 168 either way)
+  if constexpr (WIDE == 2) {
+    tr.tri_min = p.bvh.wide8_tri_min;
+    if (BOUNDED) tr.limit = (p.bvh.lds_levels - 1u) * STHIP_BLOCK;
+  } else {
+    tr.top_lds = (const LdsFloat4*)top_lds;
+    if (BOUNDED) tr.limit = (p.bvh.lds_levels - (WIDE ? 3u : 1u)) * STHIP_BLOCK;  // (the wide step writes three levels from `top` on)
+  }
   tr.reset();
   tr.any = false;
   WaveWork work_c, work_s;

@@ -54,6 +54,13 @@ struct DeviceBvh {
   const TlasEntry* wide_entries;
   uint32_t wide_root_ref;
   uint32_t wide_stack_depth;
+  // The 8-wide compressed form (bvh.h: Wide8Node; "wide_bvh" = 3), walked by k_trace only: nullptr when not built. Its entry
+  // table is in the order its top-level nodes refer to (roots index wide8_nodes); its stack entries are 64-bit groups.
+  const uint4* wide8_nodes;
+  const TlasEntry* wide8_entries;
+  uint32_t wide8_root;
+  uint32_t wide8_stack_depth;
+  uint32_t wide8_tri_min;  // the leaf phase of the 8-wide walk goes on while at least this many lanes of the wave hold a triangle ("tri_min_lanes")
 };
 struct DeviceImage1 {
   uint32_t offset, w, h, pad;
@@ -636,6 +643,337 @@ struct Traversal {
   DEV void round(const DeviceBvh& bvh, uint32_t* stack, uint32_t min_lanes, TraverseCounters& cnt) {
     if (active()) inner_loop(bvh, stack, min_lanes, cnt);
     if (active() && (ref & BVH_LEAF_BIT)) leaf_step(bvh, stack, cnt);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The walk over the 8-wide compressed tree (bvh.h: Wide8Node), k_trace's "wide_bvh" = 3. What a lane holds of the tree is
+// not a reference but two GROUPS: the node group G = (base index of a node's inner children, their hit bits in 31..24 in
+// visiting order | the node's imask in 7..0) and the item group T = (first item of the node's leaf children, the items
+// still to test in bits 23..0) — after Ylitie, Karras, Laine (HPG 2017). The stack holds groups (64-bit entries, LDS
+// [level][lane]): a node step pushes at most ONE entry — the rest of the group it took its node from — whatever the
+// number of children hit, needs no sort (the hit bits come out in the ray's octant order) and no child references (an
+// inner child's index is base + popcount(imask below its slot)). States of a lane:
+//   walking   gy > 0x00FFFFFF and ty == 0: it visits the node of the highest inner bit
+//   items     ty != 0: it waits for the leaf phase, which tests one item per lane and iteration (a triangle; or, for a
+//             top-level node's group, tx has WIDE8_ENTRY_BIT: enters / tests one top-level entry)
+//   sentinel  neither: the last pop brought W8_EXIT (back to world space, pop again) or W8_DONE (finished) in gx
+// Whenever a lane has nothing pending (no inner bits, no items) it pops at once; a popped entry with no inner bits is an
+// item group (pushed when an instance is entered) or a sentinel (y == 0). Hits do not depend on the order of any of
+// this (the contract), so frames are the ones the binary walk gives, bit for bit.
+#define W8_DONE 0xFFFFFFFFu
+#define W8_EXIT 0xFFFFFFFEu
+#define W8_CANARY 0xFFFFFFFDu
+#ifndef STHIP_WIDE8_STRIDE
+#define STHIP_WIDE8_STRIDE 80u  // bytes from node to node in HBM
+#endif
+template <bool COUNT, uint32_t STRIDE, bool ALPHA, bool BOUNDED, uint32_t ENTRY_BATCH>
+struct Traversal8 {
+  uint32_t limit;  // BOUNDED only: (levels - 1) * STRIDE
+  bool any;
+  DEV bool is_any() const { return any; }
+  f3 o, d;
+  float tmin, tmax;
+  RaySpace sp;
+  f3 w_idir, w_noodL, w_noodH;  // the world-space constants while an instance is walked (as Traversal's SAVE_WORLD)
+  float w_Sx, w_Sy, w_Sz;
+  int w_k;
+  RayHit hit;
+  uint32_t gx, gy, tx, ty;
+  uint32_t top;  // stack height in entries * STRIDE
+  uint32_t id_bits;
+  uint32_t tri_min;
+
+  static DEV uint2* column(uint32_t* stack) { return reinterpret_cast<uint2*>(stack); }
+  DEV bool overflowed(const uint32_t* stack) const { return BOUNDED && reinterpret_cast<const uint2*>(stack)[limit].x != W8_CANARY; }
+  DEV bool walking() const { return (gy > 0x00FFFFFFu) & (ty == 0u); }
+  DEV bool active() const { return (ty != 0u) | (gy > 0x00FFFFFFu) | (gx != W8_DONE); }
+  DEV void reset() {
+    gx = W8_DONE;
+    gy = ty = tx = 0u;
+  }
+  // entry planes' origin term into noodL, exit planes' into noodH (as Traversal::orient_space for the wide walk)
+  DEV void orient_space() {
+    const float lx = sp.noodL.x, ly = sp.noodL.y, lz = sp.noodL.z;
+    const bool nx = sp.idir.x < 0.0f, ny = sp.idir.y < 0.0f, nz = sp.idir.z < 0.0f;
+    sp.noodL.x = nx ? sp.noodH.x : lx;
+    sp.noodH.x = nx ? lx : sp.noodH.x;
+    sp.noodL.y = ny ? sp.noodH.y : ly;
+    sp.noodH.y = ny ? ly : sp.noodH.y;
+    sp.noodL.z = nz ? sp.noodH.z : lz;
+    sp.noodH.z = nz ? lz : sp.noodH.z;
+  }
+  DEV void start(const DeviceBvh& bvh, uint32_t* stack, f3 ro, f3 rd, float t0, float t1) {
+    o = ro;
+    d = rd;
+    tmin = t0;
+    tmax = t1;
+    hit.t = t1;
+    hit.b1 = hit.b2 = 0.0f;
+    hit.ip = 0xFFFFFFFFu;
+    uint2* st = column(stack);
+    st[0] = make_uint2(W8_DONE, 0u);
+    top = STRIDE;
+    if (BOUNDED) st[limit] = make_uint2(W8_CANARY, 0u);
+    id_bits = 0;
+    gx = bvh.root_ref;  // (an empty scene: BVH_INVALID_REF == W8_DONE)
+    gy = bvh.root_ref == BVH_INVALID_REF ? 0u : 0x80000000u;  // a group of one: the root, whatever the octant (imask 0: index = base)
+    tx = ty = 0u;
+    setup_space(sp, ro, rd, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
+    orient_space();
+    w_idir = sp.idir;
+    w_noodL = sp.noodL;
+    w_noodH = sp.noodH;
+    w_Sx = sp.Sx;
+    w_Sy = sp.Sy;
+    w_Sz = sp.Sz;
+    w_k = sp.k;
+  }
+  DEV void push(uint2* st, uint32_t x, uint32_t y, bool keep) {
+    st[top] = make_uint2(x, y);
+    const uint32_t next = keep ? top + STRIDE : top;
+    top = BOUNDED ? min(next, limit) : next;
+  }
+  // the popped entry becomes the lane's state: a node group, or (no inner bits) an item group / a sentinel
+  DEV void take(uint2 P) {
+    gx = P.x;
+    gy = P.y;
+    tx = P.x;
+    ty = P.y <= 0x00FFFFFFu ? P.y : 0u;
+  }
+  DEV void finish_occluded() {
+    hit.ip = 0u;
+    gx = W8_DONE;
+    gy = ty = 0u;
+  }
+
+  DEV void node_loop(const DeviceBvh& bvh, uint32_t* stack, uint32_t min_lanes, TraverseCounters& cnt) {
+    const char* base = reinterpret_cast<const char*>(bvh.wide8_nodes);
+    uint2* st = column(stack);
+    const float tbest = hit.t;
+    const bool nx = sp.idir.x < 0.0f, ny = sp.idir.y < 0.0f, nz = sp.idir.z < 0.0f;
+    const uint32_t octinv = (nx ? 0u : 1u) | (ny ? 0u : 2u) | (nz ? 0u : 4u);
+    const uint32_t oct4 = octinv * 0x01010101u;
+    const float cnx = sp.noodL.x, cfx = sp.noodH.x, cny = sp.noodL.y, cfy = sp.noodH.y, cnz = sp.noodL.z, cfz = sp.noodH.z;
+    for (;;) {
+      if (COUNT) {
+        const unsigned long long here = __ballot(true), walk = __ballot(walking()), leaf = __ballot(ty != 0u && !(tx & WIDE8_ENTRY_BIT));
+        if (first_active_lane()) {
+          cnt.st[0] += (uint32_t)__popcll(walk);
+          cnt.st[1] += (uint32_t)__popcll(leaf);
+          cnt.st[2] += (uint32_t)__popcll(here & ~walk & ~leaf);
+          cnt.st[3] += 64u - (uint32_t)__popcll(here);
+        }
+      }
+      if (walking()) {
+        const uint32_t bit = 31u - (uint32_t)__clz((int)gy);
+        const uint32_t rest = gy & ~(1u << bit);
+        const uint32_t slot = (bit - 24u) ^ octinv;
+        const uint32_t index = gx + (uint32_t)__popc(gy & ((1u << slot) - 1u));  // (slot <= 7: only imask bits are counted)
+        st[top] = make_uint2(gx, rest);  // the rest of this group: kept if it still has inner bits
+        uint32_t ntop = rest > 0x00FFFFFFu ? top + STRIDE : top;
+        if (BOUNDED) ntop = min(ntop, limit);
+        const uint4* n = reinterpret_cast<const uint4*>(base + __umul24(index, STHIP_WIDE8_STRIDE));
+        const uint4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+        uint4 n4 = n[4];
+        const uint2 P = st[ntop - STRIDE];  // what a node without hits falls back to (the DONE sentinel at the very bottom)
+        asm volatile("" : "+v"(n4.x), "+v"(n4.y), "+v"(n4.z), "+v"(n4.w));  // all five loads in flight before anything is computed
+        if (COUNT) {
+          cnt.nodes++;
+          if (first_active_lane()) cnt.inner_slots += 64;
+        }
+        const float ax = __builtin_amdgcn_ldexpf(sp.idir.x, (int)(n0.w << 24) >> 24);
+        const float ay = __builtin_amdgcn_ldexpf(sp.idir.y, (int)(n0.w << 16) >> 24);
+        const float az = __builtin_amdgcn_ldexpf(sp.idir.z, (int)(n0.w << 8) >> 24);
+        const float ox = __uint_as_float(n0.x), oy = __uint_as_float(n0.y), oz = __uint_as_float(n0.z);
+        const float enx = fmaf(ox, sp.idir.x, cnx), efx = fmaf(ox, sp.idir.x, cfx);
+        const float eny = fmaf(oy, sp.idir.y, cny), efy = fmaf(oy, sp.idir.y, cfy);
+        const float enz = fmaf(oz, sp.idir.z, cnz), efz = fmaf(oz, sp.idir.z, cfz);
+        // entry / exit plane words of each axis (slots 0-3, slots 4-7), picked by the sign of the direction
+        const uint32_t qnx[2] = {nx ? n2.z : n2.x, nx ? n2.w : n2.y}, qfx[2] = {nx ? n2.x : n2.z, nx ? n2.y : n2.w};
+        const uint32_t qny[2] = {ny ? n3.z : n3.x, ny ? n3.w : n3.y}, qfy[2] = {ny ? n3.x : n3.z, ny ? n3.y : n3.w};
+        const uint32_t qnz[2] = {nz ? n4.z : n4.x, nz ? n4.w : n4.y}, qfz[2] = {nz ? n4.x : n4.z, nz ? n4.y : n4.w};
+        // per slot (byte-parallel over four): what a hit adds to the mask (meta >> 5) and where (meta & 31, inner children
+        // moved to the ray's visiting order: ^ octinv)
+        uint32_t bits4[2], at4[2];
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+          const uint32_t m = w ? n1.w : n1.z;
+          const uint32_t is_inner = (m & (m << 1)) & 0x10101010u;      // both of bits 3 and 4: a position of 24 or more
+          const uint32_t low3 = (is_inner - (is_inner >> 3)) >> 1;     // 0x07 in the bytes of inner children
+          at4[w] = (m ^ (oct4 & low3)) & 0x1F1F1F1Fu;
+          bits4[w] = (m >> 5) & 0x07070707u;
+        }
+        uint32_t hitmask = 0u;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const int w = c >> 2, b = 8 * (c & 3);
+          const float tnx = fmaf((float)((qnx[w] >> b) & 0xFFu), ax, enx), tfx = fmaf((float)((qfx[w] >> b) & 0xFFu), ax, efx);
+          const float tny = fmaf((float)((qny[w] >> b) & 0xFFu), ay, eny), tfy = fmaf((float)((qfy[w] >> b) & 0xFFu), ay, efy);
+          const float tnz = fmaf((float)((qnz[w] >> b) & 0xFFu), az, enz), tfz = fmaf((float)((qfz[w] >> b) & 0xFFu), az, efz);
+          const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+          const float tf = fminf(fminf(tfx, tfy), tfz);
+          const bool h = (tn <= tf) & (tn <= tbest);
+          const uint32_t add = ((bits4[w] >> b) & 0xFFu) << ((at4[w] >> b) & 0xFFu);
+          hitmask |= h ? add : 0u;
+        }
+        const bool nohit = hitmask == 0u;
+        gx = nohit ? P.x : n1.x;
+        gy = nohit ? P.y : ((hitmask & 0xFF000000u) | (n0.w >> 24));
+        tx = nohit ? P.x : n1.y;
+        ty = nohit ? (P.y <= 0x00FFFFFFu ? P.y : 0u) : (hitmask & 0x00FFFFFFu);
+        top = nohit ? ntop - STRIDE : ntop;
+      }
+      if ((uint32_t)__popcll(__ballot(walking())) < min_lanes) break;
+    }
+  }
+
+  // One triangle against this lane's ray (as Traversal::one_triangle)
+  DEV bool one_triangle(const DeviceBvh& bvh, uint32_t index, TraverseCounters& cnt) {
+    const float4* tv = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(bvh.tris) + (size_t)(index * 48u));
+    const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+    if (COUNT) {
+      cnt.tris++;
+      if (first_active_lane()) cnt.tri_slots += 64;
+    }
+    float t, b1, b2;
+    bool candidate = tri_test(sp, xyz(v0), xyz(v1), xyz(v2), tmin, tmax, t, b1, b2);
+    if (ALPHA && candidate) {
+      const uint32_t mask = bvh.alpha_test ? bvh.inst_alpha[(__float_as_uint(v0.w) | id_bits) & 0xFFFFu] : BVH_NO_ALPHA;
+      if (mask != BVH_NO_ALPHA) {
+        const float2* q = bvh.tri_uv + (size_t)index * 3u;
+        const float2 u0 = q[0], u1 = q[1], u2 = q[2];
+        const float u = u0.x + (u1.x - u0.x) * b1 + (u2.x - u0.x) * b2;  // shading_data.hlsli:2-6
+        float v = u0.y + (u1.y - u0.y) * b1 + (u2.y - u0.y) * b2;
+        if (bvh.flip_uvs) v = 1 - v;
+        candidate = sample_image1(bvh, mask, u, v) >= 0.75f;
+      }
+    }
+    const uint32_t ip = __float_as_uint(v0.w) | id_bits;
+    const bool closer = candidate & !any & ((t < hit.t) | ((t == hit.t) & (hit.ip != 0xFFFFFFFFu) & (hit_key(ip) < hit_key(hit.ip))));
+    hit.t = closer ? t : hit.t;
+    hit.b1 = closer ? b1 : hit.b1;
+    hit.b2 = closer ? b2 : hit.b2;
+    hit.ip = closer ? ip : hit.ip;
+    return candidate & any;
+  }
+  // a sphere or volume entry's verdict folded into the hit record; true: an occlusion lane found its hit
+  DEV bool fold_entry_hit(bool found, float t, uint32_t instance) {
+    if (!found) return false;
+    if (any) return true;
+    const uint32_t ip = instance | 0xFFFF0000u;  // instance | INVALID_PRIMITIVE << 16
+    if (t < hit.t || (t == hit.t && hit.ip != 0xFFFFFFFFu && hit_key(ip) < hit_key(hit.ip))) {
+      hit.t = t;
+      hit.b1 = hit.b2 = 0.0f;
+      hit.ip = ip;
+    }
+    return false;
+  }
+
+  // the lanes that are not walking: sentinels, one top-level entry per lane, then triangles
+  DEV void leaf_step(const DeviceBvh& bvh, uint32_t* stack, TraverseCounters& cnt) {
+    uint2* st = column(stack);
+    if (COUNT) {
+      const unsigned long long tri = __ballot(ty != 0u && !(tx & WIDE8_ENTRY_BIT));
+      if (first_active_lane()) {
+        cnt.st[4] += 64;
+        cnt.st[5] += (uint32_t)__popcll(tri);
+        cnt.st[6] += (uint32_t)__popcll(__ballot(true) & ~tri);
+      }
+    }
+    if (ty == 0u && gx == W8_EXIT) {  // (not walking and no items: a sentinel) everything pushed inside the instance is consumed
+      sp.o = o;
+      sp.idir = w_idir;
+      sp.noodL = w_noodL;
+      sp.noodH = w_noodH;
+      sp.Sx = w_Sx;
+      sp.Sy = w_Sy;
+      sp.Sz = w_Sz;
+      sp.k = w_k;
+      id_bits = 0;
+      top -= STRIDE;
+      take(st[top]);
+    }
+    const bool has_entry = ty != 0u && (tx & WIDE8_ENTRY_BIT);
+    // entering an instance is ~250 instructions and a dependent load run by the few lanes that hold an entry: put off until
+    // ENTRY_BATCH lanes hold one or no lane of this round has triangles to test (as Traversal::special_step)
+    const bool entries_due = ENTRY_BATCH > 1 ? !__any(ty != 0u && !(tx & WIDE8_ENTRY_BIT)) : true;
+    if (has_entry && (entries_due || (uint32_t)__popcll(__ballot(true)) >= ENTRY_BATCH)) {
+      const uint32_t bit = (uint32_t)__ffs((int)ty) - 1u;
+      ty &= ty - 1u;
+      const TlasEntry* e = bvh.entries + ((tx & ~WIDE8_ENTRY_BIT) + bit);
+      const float4* ev = reinterpret_cast<const float4*>(e);
+      const uint4 info = *reinterpret_cast<const uint4*>(ev + 3);
+      bool in_place = false, occluded = false;
+      if (info.z != TLAS_ENTRY_IDENTITY) {
+        const float4 r0 = ev[0], r1 = ev[1], r2 = ev[2];
+        const float4 sph = ev[4];
+        const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+        if (info.z == TLAS_ENTRY_SPHERE) {  // tested right here (intersection.hlsli:79-89)
+          if (COUNT) {
+            cnt.tris++;
+            if (first_active_lane()) cnt.tri_slots += 64;
+          }
+          float t = 0.0f;
+          const bool found = sphere_test(obj_point(m, o), obj_vector(m, d), sph.w, tmin, tmax, t);
+          occluded = fold_entry_hit(found, t, info.y);
+          in_place = true;
+        } else if (ALPHA && info.z == TLAS_ENTRY_VOLUME) {  // the slabs of its grid's bounding box (intersection.hlsli:93-113)
+          if (COUNT) {
+            cnt.tris++;
+            if (first_active_lane()) cnt.tri_slots += 64;
+          }
+          float t = 0.0f;
+          const bool found = volume_test(bvh.volumes[info.x], obj_point(m, o), obj_vector(m, d), tmin, tmax, t);
+          occluded = fold_entry_hit(found, t, info.y);
+          in_place = true;
+        } else {
+          // what is pending at this level waits on the stack: the rest of the node group, the rest of the entry group
+          push(st, gx, gy, gy > 0x00FFFFFFu);
+          push(st, tx, ty, ty != 0u);
+          push(st, W8_EXIT, 0u, true);
+          setup_space(sp, obj_point(m, o), obj_vector(m, d), sph.x, sph.y, sph.z, sph.w);
+          orient_space();
+          id_bits = info.y;
+        }
+      } else {  // (the merged mesh is spliced into the top level; an entry of it all the same: same space, no id bits)
+        push(st, gx, gy, gy > 0x00FFFFFFu);
+        push(st, tx, ty, ty != 0u);
+      }
+      if (!in_place) {
+        gx = info.x;
+        gy = 0x80000000u;
+        ty = 0u;
+      } else if (occluded) {
+        finish_occluded();
+      } else if (ty == 0u && gy <= 0x00FFFFFFu) {
+        top -= STRIDE;
+        take(st[top]);
+      }
+    }
+    // triangles: one per lane and iteration, while enough lanes hold one (at least once)
+    for (;;) {
+      const bool has = ty != 0u && !(tx & WIDE8_ENTRY_BIT);
+      if (has) {
+        const uint32_t bit = (uint32_t)__ffs((int)ty) - 1u;
+        ty &= ty - 1u;
+        const uint2 P = st[top - STRIDE];
+        const bool occluded = one_triangle(bvh, tx + bit, cnt);
+        const bool pop = !occluded & (ty == 0u) & (gy <= 0x00FFFFFFu);
+        hit.ip = occluded ? 0u : hit.ip;
+        gx = occluded ? W8_DONE : (pop ? P.x : gx);
+        gy = occluded ? 0u : (pop ? P.y : gy);
+        tx = pop ? P.x : tx;
+        ty = occluded ? 0u : (pop ? (P.y <= 0x00FFFFFFu ? P.y : 0u) : ty);
+        top = pop ? top - STRIDE : top;
+      }
+      if ((uint32_t)__popcll(__ballot(ty != 0u && !(tx & WIDE8_ENTRY_BIT))) < tri_min) break;
+    }
+  }
+
+  DEV void round(const DeviceBvh& bvh, uint32_t* stack, uint32_t min_lanes, TraverseCounters& cnt) {
+    if (active()) node_loop(bvh, stack, min_lanes, cnt);
+    if (active() && !walking()) leaf_step(bvh, stack, cnt);
   }
 };
 

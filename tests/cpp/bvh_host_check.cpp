@@ -41,6 +41,236 @@ static std::vector<T> slurp(const std::string& path) {
   return v;
 }
 
+
+// ---- the 8-wide compressed form (build_wide8_bvh): a CPU walk with the kernel's group logic (traverse.h: Traversal8) against
+// a walk of the binary tree, both with exact-in-double conservative box tests and the same triangle test, so the closest
+// hits must agree whatever the trees look like ----
+namespace w8 {
+struct Ray {
+  double o[3], d[3];
+};
+struct Hit {
+  double t = 1e300;
+  uint32_t tri = 0xFFFFFFFFu, inst = 0xFFFFFFFFu;
+  bool operator==(const Hit& h) const { return t == h.t && tri == h.tri && inst == h.inst; }
+};
+static bool slab(const double lo[3], const double hi[3], const Ray& r, double tbest) {
+  double tn = 0, tf = tbest;
+  for (int a = 0; a < 3; a++) {
+    const double inv = 1.0 / (std::fabs(r.d[a]) < 1e-300 ? 1e-300 : r.d[a]);
+    double t0 = (lo[a] - 1e-9 - r.o[a]) * inv, t1 = (hi[a] + 1e-9 - r.o[a]) * inv;
+    if (t0 > t1) std::swap(t0, t1);
+    tn = std::max(tn, t0);
+    tf = std::min(tf, t1);
+  }
+  return tn <= tf;
+}
+static void tri_hit(const BvhTri& t, uint32_t index, uint32_t inst, const Ray& r, Hit& h) {  // Moeller-Trumbore in double
+  const double e1[3] = {(double)t.v1[0] - t.v0[0], (double)t.v1[1] - t.v0[1], (double)t.v1[2] - t.v0[2]}, e2[3] = {(double)t.v2[0] - t.v0[0], (double)t.v2[1] - t.v0[1], (double)t.v2[2] - t.v0[2]};
+  const double p[3] = {r.d[1] * e2[2] - r.d[2] * e2[1], r.d[2] * e2[0] - r.d[0] * e2[2], r.d[0] * e2[1] - r.d[1] * e2[0]};
+  const double det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
+  if (det == 0) return;
+  const double s[3] = {r.o[0] - t.v0[0], r.o[1] - t.v0[1], r.o[2] - t.v0[2]};
+  const double u = (s[0] * p[0] + s[1] * p[1] + s[2] * p[2]) / det;
+  const double q[3] = {s[1] * e1[2] - s[2] * e1[1], s[2] * e1[0] - s[0] * e1[2], s[0] * e1[1] - s[1] * e1[0]};
+  const double v = (r.d[0] * q[0] + r.d[1] * q[1] + r.d[2] * q[2]) / det;
+  const double tt = (e2[0] * q[0] + e2[1] * q[1] + e2[2] * q[2]) / det;
+  if (u < 0 || v < 0 || u + v > 1 || !(tt > 0)) return;
+  if (tt < h.t || (tt == h.t && (inst < h.inst || (inst == h.inst && index < h.tri)))) {
+    h.t = tt;
+    h.tri = index;
+    h.inst = inst;
+  }
+}
+static Ray to_object(const TlasEntry& e, const Ray& r) {
+  Ray q;
+  for (int a = 0; a < 3; a++) {
+    q.o[a] = e.inv[4 * a] * r.o[0] + e.inv[4 * a + 1] * r.o[1] + e.inv[4 * a + 2] * r.o[2] + e.inv[4 * a + 3];
+    q.d[a] = e.inv[4 * a] * r.d[0] + e.inv[4 * a + 1] * r.d[1] + e.inv[4 * a + 2] * r.d[2];
+  }
+  return q;
+}
+// the binary tree (triangle ids: the triangle's own id word, so that the permutation of the array does not matter)
+static void walk2(const sthip::BuiltBvh& b, uint32_t root, const Ray& r, uint32_t inst, Hit& h, size_t& visits) {
+  std::vector<uint32_t> todo(1, root);
+  while (!todo.empty()) {
+    const uint32_t i = todo.back();
+    todo.pop_back();
+    visits++;
+    const BvhNode& n = b.nodes[i];
+    for (int c = 0; c < 2; c++) {
+      const uint32_t ref = n.ref[c];
+      if (ref == BVH_INVALID_REF || (c == 1 && ref == n.ref[0] && (ref & BVH_LEAF_BIT))) continue;
+      const float* xy = c ? n.n1xy : n.n0xy;
+      const double lo[3] = {xy[0], xy[2], n.nz[2 * c]}, hi[3] = {xy[1], xy[3], n.nz[2 * c + 1]};
+      if (!slab(lo, hi, r, h.t)) continue;
+      if (!(ref & BVH_LEAF_BIT)) {
+        todo.push_back(ref);
+      } else if (ref & BVH_INST_BIT) {
+        const TlasEntry& e = b.entries[ref & 0xFFFFu];
+        if (e.identity == TLAS_ENTRY_IDENTITY) walk2(b, e.root, r, inst, h, visits);
+        else if (e.identity == TLAS_ENTRY_TRANSFORMED) walk2(b, e.root, to_object(e, r), e.id_bits, h, visits);
+      } else {
+        const uint32_t first = (ref & 0x3FFFFFFFu) >> 2, count = (ref & 3u) + 1;
+        for (uint32_t k = 0; k < count; k++) tri_hit(b.tris[first + k], b.tris[first + k].id, inst, r, h);
+      }
+    }
+  }
+}
+// the 8-wide form, with the kernel's states and stack discipline; returns false on a malformed tree
+static bool walk8(const sthip::BuiltBvh& b, const Ray& world, Hit& h, size_t& visits, size_t& max_stack) {
+  struct Group {
+    uint32_t x, y;
+  };
+  const uint32_t DONE = 0xFFFFFFFFu, EXIT = 0xFFFFFFFEu;
+  std::vector<Group> st;
+  st.push_back({DONE, 0});
+  Ray r = world;
+  uint32_t inst = 0xFFFFFFFFu;
+  uint32_t gx = b.wide8_root, gy = 0x80000000u, tx = 0, ty = 0;
+  auto take = [&](Group P) {
+    gx = P.x;
+    gy = P.y;
+    tx = P.x;
+    ty = P.y <= 0x00FFFFFFu ? P.y : 0u;
+  };
+  for (size_t guard = 0; guard < 10000000; guard++) {
+    max_stack = std::max(max_stack, st.size());
+    if (gy > 0x00FFFFFFu && ty == 0) {  // walking
+      const uint32_t octinv = (r.d[0] < 0 ? 0u : 1u) | (r.d[1] < 0 ? 0u : 2u) | (r.d[2] < 0 ? 0u : 4u);
+      const uint32_t bit = 31u - (uint32_t)__builtin_clz(gy);
+      const uint32_t rest = gy & ~(1u << bit);
+      const uint32_t slot = (bit - 24u) ^ octinv;
+      const uint32_t index = gx + (uint32_t)__builtin_popcount(gy & ((1u << slot) - 1u));
+      if (rest > 0x00FFFFFFu) st.push_back({gx, rest});
+      if (index >= b.wide8_nodes.size()) return std::printf("FAIL: wide8 node index out of range\n"), false;
+      const Wide8Node& n = b.wide8_nodes[index];
+      visits++;
+      uint32_t hitmask = 0;
+      for (int s = 0; s < 8; s++) {
+        const uint32_t m = n.meta[s];
+        if (!m) continue;
+        double lo[3], hi[3];
+        for (int a = 0; a < 3; a++) {
+          const double step = std::ldexp(1.0, (int)(int8_t)n.exp[a]);
+          lo[a] = (double)n.origin[a] + n.q[2 * a][s] * step;
+          hi[a] = (double)n.origin[a] + n.q[2 * a + 1][s] * step;
+        }
+        if (!slab(lo, hi, r, h.t)) continue;
+        const bool inner = (m & 0x18u) == 0x18u;
+        const uint32_t at = inner ? ((m ^ octinv) & 31u) : (m & 31u);
+        hitmask |= (m >> 5) << at;
+      }
+      if (hitmask == 0) {
+        take(st.back());
+        st.pop_back();
+      } else {
+        gx = n.child_base;
+        gy = (hitmask & 0xFF000000u) | n.imask;
+        tx = n.leaf_base;
+        ty = hitmask & 0x00FFFFFFu;
+      }
+    } else if (ty != 0) {
+      const uint32_t bit = (uint32_t)__builtin_ctz(ty);
+      ty &= ty - 1;
+      if (tx & WIDE8_ENTRY_BIT) {
+        const uint32_t k = (tx & ~WIDE8_ENTRY_BIT) + bit;
+        if (k >= b.wide8_entries.size()) return std::printf("FAIL: wide8 entry index out of range\n"), false;
+        const TlasEntry& e = b.wide8_entries[k];
+        if (e.identity == TLAS_ENTRY_TRANSFORMED || e.identity == TLAS_ENTRY_IDENTITY) {
+          if (gy > 0x00FFFFFFu) st.push_back({gx, gy});
+          if (ty) st.push_back({tx, ty});
+          if (e.identity == TLAS_ENTRY_TRANSFORMED) {
+            st.push_back({EXIT, 0});
+            r = to_object(e, world);
+            inst = e.id_bits;
+          }
+          gx = e.root;
+          gy = 0x80000000u;
+          ty = 0;
+          continue;
+        }
+        // (spheres / volumes: not part of this comparison)
+      } else {
+        const uint32_t k = tx + bit;
+        if (k >= b.tris.size()) return std::printf("FAIL: wide8 triangle index out of range\n"), false;
+        tri_hit(b.tris[k], b.tris[k].id, inst, r, h);
+      }
+      if (ty == 0 && gy <= 0x00FFFFFFu) {
+        take(st.back());
+        st.pop_back();
+      }
+    } else if (gx == EXIT) {
+      r = world;
+      inst = 0xFFFFFFFFu;
+      take(st.back());
+      st.pop_back();
+    } else if (gx == DONE) {
+      return st.empty() ? true : (std::printf("FAIL: wide8 walk ended with %zu stack entries\n", st.size()), false);
+    } else {
+      return std::printf("FAIL: wide8 walk in an undefined state\n"), false;
+    }
+  }
+  return std::printf("FAIL: wide8 walk does not end\n"), false;
+}
+static uint32_t rnd_state = 12345u;
+static double rnd() {
+  rnd_state = rnd_state * 1664525u + 1013904223u;
+  return (rnd_state >> 8) * (1.0 / 16777216.0);
+}
+// structure: indices in range, every triangle an item of exactly one node, items and inner children consistent with meta / imask
+static bool check_structure(const sthip::BuiltBvh& b) {
+  std::vector<uint32_t> seen(b.tris.size(), 0);
+  std::vector<uint8_t> is_top(b.wide8_nodes.size(), 0);
+  for (size_t i = b.top.wide8_blas_nodes; i < b.wide8_nodes.size(); i++) is_top[i] = 1;
+  for (size_t i = 0; i < b.wide8_nodes.size(); i++) {
+    const Wide8Node& n = b.wide8_nodes[i];
+    uint32_t inner = 0, items = 0;
+    for (int s = 0; s < 8; s++) {
+      const uint32_t m = n.meta[s];
+      const bool in = (n.imask >> s) & 1;
+      if (in != ((m & 0x18u) == 0x18u && m != 0)) return std::printf("FAIL: wide8 imask / meta disagree\n"), false;
+      if (!m) {
+        for (int a = 0; a < 3; a++)
+          if (n.q[2 * a][s] != 255 || n.q[2 * a + 1][s] != 0) return std::printf("FAIL: wide8 unused slot has a box\n"), false;
+        continue;
+      }
+      for (int a = 0; a < 3; a++)
+        if (n.q[2 * a][s] > n.q[2 * a + 1][s]) return std::printf("FAIL: wide8 inverted box on a used slot\n"), false;
+      if (in) {
+        if (m != (0x20u | (24u + (uint32_t)s))) return std::printf("FAIL: wide8 inner meta\n"), false;
+        inner++;
+        continue;
+      }
+      const uint32_t unary = m >> 5, first = m & 31u, count = unary == 1 ? 1 : unary == 3 ? 2 : unary == 7 ? 3 : 0;
+      if (!count || first != items) return std::printf("FAIL: wide8 leaf meta (items not consecutive)\n"), false;
+      items += count;
+      if (items > WIDE8_MAX_ITEMS) return std::printf("FAIL: wide8 too many items\n"), false;
+      if (n.leaf_base & WIDE8_ENTRY_BIT) {
+        if (!is_top[i] || count != 1 || (n.leaf_base & ~WIDE8_ENTRY_BIT) + first >= b.wide8_entries.size()) return std::printf("FAIL: wide8 entry item\n"), false;
+      } else {
+        for (uint32_t k = 0; k < count; k++) {
+          if (n.leaf_base + first + k >= b.tris.size()) return std::printf("FAIL: wide8 triangle item out of range\n"), false;
+          if (!is_top[i]) seen[n.leaf_base + first + k]++;  // (a copy of the merged mesh's root in the top level repeats that root's items)
+          // the decoded box holds the triangle
+          const BvhTri& t = b.tris[n.leaf_base + first + k];
+          for (int a = 0; a < 3; a++) {
+            const double step = std::ldexp(1.0, (int)(int8_t)n.exp[a]);
+            const double lo = (double)n.origin[a] + n.q[2 * a][s] * step, hi = (double)n.origin[a] + n.q[2 * a + 1][s] * step;
+            for (const float* v : {t.v0, t.v1, t.v2})
+              if ((double)v[a] < lo || (double)v[a] > hi) return std::printf("FAIL: a wide8 leaf box does not hold its triangle\n"), false;
+          }
+        }
+      }
+    }
+    if (inner && (size_t)n.child_base + inner > b.wide8_nodes.size()) return std::printf("FAIL: wide8 children out of range\n"), false;
+  }
+  for (uint32_t c : seen)
+    if (c != 1) return std::printf("FAIL: a triangle is an item of %u wide8 nodes\n", c), false;
+  return true;
+}
+}  // namespace w8
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   const std::string d = argv[1];
@@ -196,6 +426,83 @@ int main(int argc, char** argv) {
         }
       }
       if (b.wide_stack_depth < 4) return std::printf("FAIL: wide stack bound\n"), 1;
+    }
+    // the 8-wide compressed form: made from a build of its own (it permutes the triangles), walked on the CPU against the
+    // binary tree of the same build: same closest hits for rays through the scene
+    if (!embed) {
+      sthip::BuiltBvh b8;
+      if (!sthip::build_scene_bvh(s, b8, err, sthip::BVH_BUILDER_SAH_HOST, nullptr, false)) return std::printf("BUILD FAILED: %s\n", err.c_str()), 1;
+      sthip::build_wide8_bvh(b8);
+      bool has_tri_entry = false;
+      for (const TlasEntry& e : b8.entries) has_tri_entry |= e.identity == TLAS_ENTRY_IDENTITY || e.identity == TLAS_ENTRY_TRANSFORMED;
+      if (b8.wide8_nodes.empty() && has_tri_entry) return std::printf("FAIL: no wide8 nodes\n"), 1;
+      if (!b8.wide8_nodes.empty()) {
+        if (b8.tris.size() != b.tris.size()) return std::printf("FAIL: wide8 changed the triangle count\n"), 1;
+        if (!w8::check_structure(b8)) return 1;
+        // the binary leaves still name every triangle once
+        std::vector<uint32_t> seen8(b8.tris.size(), 0);
+        for (const BvhNode& nd : b8.nodes)
+          for (int c = 0; c < 2; c++) {
+            const uint32_t r = nd.ref[c];
+            if ((r & (BVH_LEAF_BIT | BVH_INST_BIT)) != BVH_LEAF_BIT || (c == 1 && r == nd.ref[0])) continue;
+            for (uint32_t k = 0; k <= (r & 3u); k++) {
+              if (((r & 0x3FFFFFFFu) >> 2) + k >= b8.tris.size()) return std::printf("FAIL: remapped leaf out of range\n"), 1;
+              seen8[((r & 0x3FFFFFFFu) >> 2) + k]++;
+            }
+          }
+        for (uint32_t c : seen8)
+          if (c != 1) return std::printf("FAIL: after the wide8 permutation a triangle is in %u binary leaves\n", c), 1;
+        size_t v2 = 0, v8 = 0, max_stack = 0, hits = 0;
+        const int RAYS = 3000;
+        for (int k = 0; k < RAYS; k++) {
+          w8::Ray r;
+          for (int a = 0; a < 3; a++) {
+            r.o[a] = b8.scene_center[a] + (w8::rnd() * 2 - 1) * 0.6 * b8.scene_radius;
+            r.d[a] = w8::rnd() * 2 - 1;
+          }
+          w8::Hit h2, h8;
+          if (b8.top_is_world_blas) w8::walk2(b8, b8.root_ref, r, 0xFFFFFFFFu, h2, v2);
+          else w8::walk2(b8, b8.root_ref, r, 0xFFFFFFFFu, h2, v2);
+          if (!w8::walk8(b8, r, h8, v8, max_stack)) return 1;
+          if (!(h2 == h8)) return std::printf("FAIL: ray %d: binary walk t=%.9g tri=%u inst=%u, wide8 walk t=%.9g tri=%u inst=%u\n", k, h2.t, h2.tri, h2.inst, h8.t, h8.tri, h8.inst), 1;
+          hits += h2.tri != 0xFFFFFFFFu;
+        }
+        if (max_stack > b8.wide8_stack_depth) return std::printf("FAIL: the wide8 walk needed %zu stack entries, the bound says %u\n", max_stack, b8.wide8_stack_depth), 1;
+        // a transforms-only rebuild with the same transforms gives a top level that walks the same
+        {
+          std::vector<BvhNode> tlas8;
+          uint32_t root8 = 0, world8 = 0, depth8 = 0;
+          float c8[3], r8 = 0;
+          sthip::TopLevelState st8 = b8.top;
+          if (!sthip::rebuild_top_level(st8, xf.data(), inv.data(), s.instance_count, tlas8, root8, world8, depth8, c8, r8, err)) return std::printf("REBUILD FAILED: %s\n", err.c_str()), 1;
+          std::vector<Wide8Node> nodes8 = b8.wide8_nodes;
+          std::vector<TlasEntry> entries8;
+          uint32_t wroot = 0, wdepth = 0;
+          if (!sthip::build_wide8_top(st8, tlas8.data(), st8.blas_nodes, root8, world8 != 0, nodes8, entries8, wroot, wdepth)) return std::printf("FAIL: build_wide8_top\n"), 1;
+          sthip::BuiltBvh moved = b8;
+          moved.wide8_nodes = nodes8;
+          moved.wide8_entries = entries8;
+          moved.wide8_root = wroot;
+          moved.wide8_stack_depth = wdepth;
+          moved.top = st8;
+          if (!w8::check_structure(moved)) return 1;
+          size_t dummy = 0, ms = 0;
+          for (int k = 0; k < 300; k++) {
+            w8::Ray r;
+            for (int a = 0; a < 3; a++) {
+              r.o[a] = b8.scene_center[a] + (w8::rnd() * 2 - 1) * 0.6 * b8.scene_radius;
+              r.d[a] = w8::rnd() * 2 - 1;
+            }
+            w8::Hit h2, h8;
+            w8::walk2(b8, b8.root_ref, r, 0xFFFFFFFFu, h2, dummy);
+            if (!w8::walk8(moved, r, h8, dummy, ms)) return 1;
+            if (!(h2 == h8)) return std::printf("FAIL: rebuilt wide8 top level: ray %d differs\n", k), 1;
+          }
+          if (ms > wdepth) return std::printf("FAIL: rebuilt wide8 stack bound\n"), 1;
+        }
+        std::printf("wide8: %zu nodes (%u bottom-level), %zu entries, stack %u (walks used %zu); %d rays, %zu hit: %.2f binary / %.2f wide8 node visits per ray\n", b8.wide8_nodes.size(),
+                    b8.top.wide8_blas_nodes, b8.wide8_entries.size(), b8.wide8_stack_depth, max_stack, RAYS, hits, (double)v2 / RAYS, (double)v8 / RAYS);
+      }
     }
     // the treetop and the packed nodes
     sthip::Treetop tt;

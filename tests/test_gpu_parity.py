@@ -580,8 +580,9 @@ def test_bounded_lds_stack_gives_the_same_frames(levels):
 @pytest.mark.parametrize("levels", [None, 6])
 def test_wide_walk_gives_the_frames_of_the_binary_walk(atrium_scene, levels):
     """wide_bvh (on by default for host-built trees): k_trace walks the tree collapsed into 4-wide nodes of 64 bytes with 8-bit
-    child planes (bvh.h: WideNode). Every decoded box contains the box it stands for and every leaf reference is the binary
-    tree's, so the hits — and with them frames and ray counts, bit for bit — are those of the binary walk (wide_bvh = 0):
+    child planes (bvh.h: WideNode), or (wide_bvh = 3) into 8-wide compressed nodes of 80 bytes whose children are addressed
+    by a base and a mask (bvh.h: Wide8Node; the stack then holds 64-bit groups). Every decoded box contains the box it stands
+    for and every leaf holds the binary tree's triangles, so the hits — and with them frames and ray counts, bit for bit — are those of the binary walk (wide_bvh = 0):
     merged mesh + instances (atrium), two-level forest, spheres, media segment walks, alpha masks, light tracing and
     connections; with full LDS stacks and with 6-level ones (three pushes per level: almost every ray overflows and is traced
     again by k_trace_deep over the binary tree)."""
@@ -598,7 +599,7 @@ def test_wide_walk_gives_the_frames_of_the_binary_walk(atrium_scene, levels):
     for (sc, cam), flags, args in cases:
         frame = camera.Frame(160, 96, cam["fovy"], cam["eye"], cam["target"])
         out = {}
-        for wide in (0, 1):
+        for wide in (0, 1, 3):
             r = BDPT(device=0, args=dict(args, bdptFlag=flags))
             try:
                 r.set_option("wide_bvh", wide)
@@ -606,12 +607,14 @@ def test_wide_walk_gives_the_frames_of_the_binary_walk(atrium_scene, levels):
                     r.set_option("lds_stack_levels", levels)
                 r.update(sc)
                 out[wide] = r.render(frame, 1, 2)
+                assert r.stats()["bvh_node_bytes"] == {0: 48, 1: 64, 3: 80}[wide], (sc.name, wide)
             finally:
                 r.close()
-        a, b = out[0], out[1]
-        assert np.array_equal(a["radiance"].view(np.uint32), b["radiance"].view(np.uint32)), (sc.name, flags)
-        assert np.array_equal(a["visibility"]["instance_primitive_index"], b["visibility"]["instance_primitive_index"]), sc.name
-        assert np.array_equal(a["ray_count"], b["ray_count"]), sc.name
+        for wide in (1, 3):
+            a, b = out[0], out[wide]
+            assert np.array_equal(a["radiance"].view(np.uint32), b["radiance"].view(np.uint32)), (sc.name, flags, wide)
+            assert np.array_equal(a["visibility"]["instance_primitive_index"], b["visibility"]["instance_primitive_index"]), (sc.name, wide)
+            assert np.array_equal(a["ray_count"], b["ray_count"]), (sc.name, wide)
 
 
 @pytest.mark.parametrize("levels", [None, 7])
@@ -641,7 +644,8 @@ def test_wide_walk_over_gpu_built_trees_and_moved_instances(atrium_scene, levels
             if builder == 1 and flags:  # (alpha masks need the SAH builder)
                 continue
             out = {}
-            for wide in (0, 1):
+            for wide in (0, 1, 3):
+                node_bytes = {0: 48, 1: 64, 3: 80 if builder == 0 else 64}[wide]  # (GPU-built trees get the 4-wide form where the 8-wide one is asked for)
                 r = BDPT(device=0, args=dict(args, bdptFlag=flags))
                 try:
                     r.set_option("bvh_builder", builder)
@@ -652,7 +656,7 @@ def test_wide_walk_over_gpu_built_trees_and_moved_instances(atrium_scene, levels
                         r.set_option("lds_stack_levels", levels)
                     r.update(sc)
                     out[wide] = [r.render(frame, 1, 2)]
-                    assert r.stats()["bvh_node_bytes"] == (64 if wide else 48), (sc.name, builder, wide)
+                    assert r.stats()["bvh_node_bytes"] == node_bytes, (sc.name, builder, wide)
                     # move every instance that is not part of the merged identity mesh, render, move back
                     ident = np.array([np.array_equal(m, np.eye(4, dtype=np.float32)[:3]) for m in sc.transforms["m"]])
                     kinds = sc.instances["packed"][:, 0] & 0xF
@@ -663,18 +667,19 @@ def test_wide_walk_over_gpu_built_trees_and_moved_instances(atrium_scene, levels
                             sc.set_instance_transform(i, translate((0.11 * ((k % 3) - 1), 0.0, -0.07 * (k % 2))) @ old[i] @ rotate_y(0.2 * k))
                         r.update_transforms(sc)
                         out[wide].append(r.render(frame, 1, 2))
-                        assert r.stats()["bvh_node_bytes"] == (64 if wide else 48), (sc.name, builder, wide, "after the update")
+                        assert r.stats()["bvh_node_bytes"] == node_bytes, (sc.name, builder, wide, "after the update")
                         r.update(sc)
                         out[wide].append(r.render(frame, 1, 2))
                         for i in movable:
                             sc.set_instance_transform(i, old[i])
                 finally:
                     r.close()
-            for k, (a, b) in enumerate(zip(out[0], out[1])):
-                same(a, b, (sc.name, flags, builder, algorithm, sah_top, k))
-            if len(out[1]) == 3:
-                same(out[1][1], out[1][2], (sc.name, "moved scene against its fresh upload", builder))
-                assert not np.array_equal(out[1][0]["radiance"], out[1][1]["radiance"]), sc.name
+            for wide in (1, 3):
+                for k, (a, b) in enumerate(zip(out[0], out[wide])):
+                    same(a, b, (sc.name, flags, builder, algorithm, sah_top, wide, k))
+                if len(out[wide]) == 3:
+                    same(out[wide][1], out[wide][2], (sc.name, "moved scene against its fresh upload", builder, wide))
+                    assert not np.array_equal(out[wide][0]["radiance"], out[wide][1]["radiance"]), sc.name
 
 
 def test_embedded_leaves_give_the_same_frames(atrium_scene):
