@@ -1094,8 +1094,125 @@ struct Wide8Builder {
     return c;
   }
 
+  // ---- bottom levels: the collapse that minimises the surface-area cost of the wide tree over all ways of cutting this binary
+  // tree into 8-wide nodes (Ylitie et al. 2017, section 3.1): c(n, i) = the least cost of representing the subtree of n as at
+  // most i children of a wide node; a subtree of at most three triangles may become ONE leaf child (its binary leaves' triangles
+  // follow one another in the new order); cost of a wide node = its area, of a leaf child = its area x triangles x W8_CPRIM.
+  std::vector<float> cost;        // [7 * node + (i - 1)], i = 1..7
+  std::vector<uint8_t> split;     // [8 * node + (j - 1)], j = 2..8: how many of j slots the left child gets (c_distribute)
+  std::vector<uint8_t> as_leaf;   // [node]: with one slot the subtree is a leaf child
+  std::vector<uint8_t> tri_count; // [node]: triangles below, saturating at 255
+  float cprim = 0.4f;
+  static float child_area(const BvhNode& n, int c) {
+    const Box b = child_box(n, c);
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.0f;
+  }
+  static float own_area(const BvhNode& n) {  // of the union of the child boxes
+    Box b;
+    b.reset();
+    for (int c = 0; c < 2; c++)
+      if (n.ref[c] != BVH_INVALID_REF) b.grow(child_box(n, c));
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.0f;
+  }
+  float ref_cost(uint32_t r, float area, int i) const {  // c(child, i) of the child a reference stands for
+    if (r & BVH_LEAF_BIT) return area * (float)((r & 3u) + 1u) * cprim;
+    return cost[7 * (size_t)r + (size_t)(i - 1)];
+  }
+  uint32_t ref_tris(uint32_t r) const { return (r & BVH_LEAF_BIT) ? (r & 3u) + 1u : tri_count[r]; }
+  void plan(uint32_t root) {  // fills cost / split / as_leaf for the subtree of binary inner node `root`
+    std::vector<uint32_t> order, todo(1, root);
+    while (!todo.empty()) {
+      const uint32_t i = todo.back();
+      todo.pop_back();
+      order.push_back(i);
+      const BvhNode& n = (*nodes)[i];
+      for (int c = 0; c < 2; c++)
+        if (n.ref[c] != BVH_INVALID_REF && !(n.ref[c] & BVH_LEAF_BIT) && !(c == 1 && n.ref[1] == n.ref[0])) todo.push_back(n.ref[c]);
+    }
+    for (size_t k = order.size(); k-- > 0;) {  // children before parents
+      const uint32_t i = order[k];
+      const BvhNode& n = (*nodes)[i];
+      const bool lone = n.ref[1] == n.ref[0] || n.ref[1] == BVH_INVALID_REF;  // a wrapped lone leaf (or a single child)
+      const uint32_t rl = n.ref[0] == BVH_INVALID_REF ? n.ref[1] : n.ref[0], rr = n.ref[1];
+      const float al = child_area(n, n.ref[0] == BVH_INVALID_REF ? 1 : 0), ar = child_area(n, 1), area = own_area(n);
+      float* c = &cost[7 * (size_t)i];
+      if (lone) {
+        tri_count[i] = (uint8_t)std::min(255u, ref_tris(rl));
+        for (int j = 1; j <= 7; j++) c[j - 1] = ref_cost(rl, al, j);  // nothing to distribute: the node stands for its child
+        as_leaf[i] = (rl & BVH_LEAF_BIT) ? 1 : as_leaf[rl];
+        for (int j = 2; j <= 8; j++) split[8 * (size_t)i + (size_t)(j - 1)] = 0;  // 0: "pass through to the only child"
+        continue;
+      }
+      const uint32_t tris = std::min(255u, ref_tris(rl) + ref_tris(rr));
+      tri_count[i] = (uint8_t)tris;
+      float dist[9];  // c_distribute(n, j), j = 2..8
+      for (int j = 2; j <= 8; j++) {
+        float best = INFINITY;
+        int bk = 1;
+        for (int kk = 1; kk < j; kk++) {
+          const float v = ref_cost(rl, al, std::min(kk, 7)) + ref_cost(rr, ar, std::min(j - kk, 7));
+          if (v < best) {
+            best = v;
+            bk = kk;
+          }
+        }
+        dist[j] = best;
+        split[8 * (size_t)i + (size_t)(j - 1)] = (uint8_t)bk;
+      }
+      const float c_leaf = tris <= 3 ? area * (float)tris * cprim : INFINITY;
+      const float c_int = dist[8] + area;
+      as_leaf[i] = c_leaf <= c_int ? 1 : 0;
+      c[0] = std::min(c_leaf, c_int);
+      for (int j = 2; j <= 7; j++) c[j - 1] = std::min(dist[j], c[j - 2]);
+    }
+  }
+  // the children the plan gives binary inner node i when it gets j slots (appended to ch)
+  void distribute(uint32_t i, int j, Wide8Child* ch, int& n) const {
+    const BvhNode& nd = (*nodes)[i];
+    const uint8_t k = split[8 * (size_t)i + (size_t)(j - 1)];
+    if (k == 0) {  // a lone child
+      const int c = nd.ref[0] == BVH_INVALID_REF ? 1 : 0;
+      place(child_box(nd, c), nd.ref[c], j, ch, n);
+      return;
+    }
+    place(child_box(nd, 0), nd.ref[0], k, ch, n);
+    place(child_box(nd, 1), nd.ref[1], j - k, ch, n);
+  }
+  void place(const Box& box, uint32_t r, int slots, Wide8Child* ch, int& n) const {
+    if (r & BVH_LEAF_BIT) {
+      ch[n++] = Wide8Child{box, r, 1};
+      return;
+    }
+    slots = std::min(slots, 7);
+    while (slots > 1 && cost[7 * (size_t)r + (size_t)(slots - 1)] == cost[7 * (size_t)r + (size_t)(slots - 2)]) slots--;  // c(n, i) = c(n, i - 1): the extra slot buys nothing
+    if (slots == 1) {
+      ch[n++] = Wide8Child{box, r, (uint8_t)(as_leaf[r] ? 4 : 0)};  // 4: a subtree that becomes one leaf child
+      return;
+    }
+    distribute(r, slots, ch, n);
+  }
+  // the triangles below a binary reference, in leaf order
+  void subtree_triangles(uint32_t r, std::vector<uint32_t>& firsts_counts) const {
+    if (r & BVH_LEAF_BIT) {
+      firsts_counts.push_back(r);
+      return;
+    }
+    const BvhNode& nd = (*nodes)[r];
+    for (int c = 0; c < 2; c++) {
+      if (nd.ref[c] == BVH_INVALID_REF || (c == 1 && nd.ref[1] == nd.ref[0])) continue;
+      subtree_triangles(nd.ref[c], firsts_counts);
+    }
+  }
+
   // up to eight children of binary inner node i: the inner child with the largest box is opened until there are eight
   int gather(uint32_t i, bool top, Wide8Child* ch) const {
+    if (!top && !cost.empty()) {
+      int n = 0;
+      distribute(i, 8, ch, n);
+      return n;
+    }
     int n = 0;
     const BvhNode& root = bin(i, top);
     for (int c = 0; c < 2; c++) {
@@ -1156,8 +1273,9 @@ struct Wide8Builder {
       out[w] = wn;
       return 1;
     }
+    auto is_leaf = [](const Wide8Child& c) { return c.kind == 1 || c.kind == 4; };
     uint32_t inner = 0;
-    for (int k = 0; k < n; k++) inner += ch[k].kind != 1 ? 1u : 0u;
+    for (int k = 0; k < n; k++) inner += is_leaf(ch[k]) ? 0u : 1u;
     wn.child_base = (uint32_t)out.size();
     out.resize(out.size() + inner);
     uint32_t items = 0;
@@ -1168,7 +1286,7 @@ struct Wide8Builder {
     for (int s = 0; s < 8; s++) {
       if (at[s] < 0) continue;
       const Wide8Child& c = ch[at[s]];
-      if (c.kind != 1) {
+      if (!is_leaf(c)) {
         wn.imask |= (uint8_t)(1u << s);
         wn.meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
         continue;
@@ -1183,15 +1301,24 @@ struct Wide8Builder {
         }
         entries_out->push_back(e);
       } else {
-        const uint32_t first = (c.ref & 0x3FFFFFFFu) >> 2;
-        count = (c.ref & 3u) + 1u;
-        if (count > 3u || first + count > tris_in->size() || new_index[first] != 0xFFFFFFFFu) {
+        std::vector<uint32_t> leaves;  // the binary leaves this leaf child holds (one; several for a merged subtree)
+        subtree_triangles(c.ref, leaves);
+        count = 0;
+        for (uint32_t r : leaves) count += (r & 3u) + 1u;
+        if (count > 3u) {
           ok = false;
           count = 1;
         } else {
-          for (uint32_t t = 0; t < count; t++) {
-            new_index[first + t] = (uint32_t)tris_out.size();
-            tris_out.push_back((*tris_in)[first + t]);
+          for (uint32_t r : leaves) {
+            const uint32_t first = (r & 0x3FFFFFFFu) >> 2, cnt = (r & 3u) + 1u;
+            if (first + cnt > tris_in->size() || new_index[first] != 0xFFFFFFFFu) {
+              ok = false;
+              break;
+            }
+            for (uint32_t t = 0; t < cnt; t++) {
+              new_index[first + t] = (uint32_t)tris_out.size();
+              tris_out.push_back((*tris_in)[first + t]);
+            }
           }
         }
       }
@@ -1202,7 +1329,7 @@ struct Wide8Builder {
     out[w] = wn;
     uint32_t below = 0, rank = 0;
     for (int s = 0; s < 8; s++) {
-      if (at[s] < 0 || ch[at[s]].kind == 1) continue;
+      if (at[s] < 0 || is_leaf(ch[at[s]])) continue;
       const Wide8Child& c = ch[at[s]];
       const uint32_t cw = wn.child_base + rank++;
       if (c.kind == 2) {  // the merged mesh's root, copied: its own children and items stay where they are
@@ -1233,6 +1360,14 @@ void build_wide8_bvh(BuiltBvh& out) {
   wb.tris_in = &out.tris;
   wb.tris_out.reserve(out.tris.size());
   wb.new_index.assign(out.tris.size(), 0xFFFFFFFFu);
+  const bool greedy = getenv("STHIP_W8_GREEDY") != nullptr;  // (experiments: the largest-box-first collapse instead of the planned one)
+  if (const char* e = getenv("STHIP_W8_CPRIM")) wb.cprim = (float)atof(e);
+  if (!greedy) {
+    wb.cost.assign(7 * out.nodes.size(), INFINITY);
+    wb.split.assign(8 * out.nodes.size(), 0);
+    wb.as_leaf.assign(out.nodes.size(), 0);
+    wb.tri_count.assign(out.nodes.size(), 0);
+  }
   // bottom levels: one per binary root (instances of a shared mesh share theirs)
   std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> of_root;  // binary root -> (wide8 root, height)
   uint32_t blas_height = 0;
@@ -1244,6 +1379,7 @@ void build_wide8_bvh(BuiltBvh& out) {
     if (it == of_root.end()) {
       const uint32_t w = (uint32_t)nodes.size();
       nodes.push_back(Wide8Node());
+      if (!greedy) wb.plan(e.root);
       const uint32_t h = wb.fill(w, e.root, false, 0);
       it = of_root.emplace(e.root, std::make_pair(w, h)).first;
     }

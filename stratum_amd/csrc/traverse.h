@@ -667,7 +667,9 @@ struct Traversal {
 #ifndef STHIP_WIDE8_STRIDE
 #define STHIP_WIDE8_STRIDE 80u  // bytes from node to node in HBM
 #endif
-template <bool COUNT, uint32_t STRIDE, bool ALPHA, bool BOUNDED, uint32_t ENTRY_BATCH>
+// SAVE_WORLD: the world-space constants are kept while an instance is walked (13 registers: 143 instead of 125, a wave per
+// SIMD less) instead of being made again when it is left (~130 instructions per instance a ray enters)
+template <bool COUNT, uint32_t STRIDE, bool ALPHA, bool BOUNDED, uint32_t ENTRY_BATCH, bool SAVE_WORLD = false>
 struct Traversal8 {
   uint32_t limit;  // BOUNDED only: (levels - 1) * STRIDE
   bool any;
@@ -721,13 +723,15 @@ struct Traversal8 {
     tx = ty = 0u;
     setup_space(sp, ro, rd, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
     orient_space();
-    w_idir = sp.idir;
-    w_noodL = sp.noodL;
-    w_noodH = sp.noodH;
-    w_Sx = sp.Sx;
-    w_Sy = sp.Sy;
-    w_Sz = sp.Sz;
-    w_k = sp.k;
+    if (SAVE_WORLD) {
+      w_idir = sp.idir;
+      w_noodL = sp.noodL;
+      w_noodH = sp.noodH;
+      w_Sx = sp.Sx;
+      w_Sy = sp.Sy;
+      w_Sz = sp.Sz;
+      w_k = sp.k;
+    }
   }
   DEV void push(uint2* st, uint32_t x, uint32_t y, bool keep) {
     st[top] = make_uint2(x, y);
@@ -882,14 +886,19 @@ struct Traversal8 {
       }
     }
     if (ty == 0u && gx == W8_EXIT) {  // (not walking and no items: a sentinel) everything pushed inside the instance is consumed
-      sp.o = o;
-      sp.idir = w_idir;
-      sp.noodL = w_noodL;
-      sp.noodH = w_noodH;
-      sp.Sx = w_Sx;
-      sp.Sy = w_Sy;
-      sp.Sz = w_Sz;
-      sp.k = w_k;
+      if (SAVE_WORLD) {
+        sp.o = o;
+        sp.idir = w_idir;
+        sp.noodL = w_noodL;
+        sp.noodH = w_noodH;
+        sp.Sx = w_Sx;
+        sp.Sy = w_Sy;
+        sp.Sz = w_Sz;
+        sp.k = w_k;
+      } else {
+        setup_space(sp, o, d, bvh.scene_cx, bvh.scene_cy, bvh.scene_cz, bvh.scene_radius);
+        orient_space();
+      }
       id_bits = 0;
       top -= STRIDE;
       take(st[top]);
