@@ -104,6 +104,9 @@ def parse_args():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): a step renders N seeds of the frame on N GPUs (per-GPU work fixed); strong: a step renders --strong-seeds seeds whatever N (total work fixed)")
     ap.add_argument("--strong-seeds", type=int, default=8, help="seeds per step in --scaling strong (BASELINE.md row 3b's 8 by default)")
+    ap.add_argument("--sustained-seconds", type=float, default=3.0, help="after the timed repetitions: one pass of back-to-back steps (the same seeds cycling) at least this long, reported as `sustained` beside `value` (0: skip)")
+    ap.add_argument("--dump-frame", default=None, help="rank 0 saves the outputs of one more step (seed block 0) as <path>.npz after the measurements: what tests compare between N = 1 and N > 1")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the config-5 forest sub-record (other_workloads.forest; N = 1 only)")
     return ap.parse_args()
 
 
@@ -146,6 +149,66 @@ def spawn_ranks(n):
     if code != 0:
         sys.stderr.write("bench: a rank exited with code %d\n" % code)
     return code if code >= 0 else 1
+
+
+def forest_record(device):
+    """Config 5 of BASELINE.json on one GPU: timed like tools/baseline_table.py's row 5 (median of 3 calls of 16 seeds after a
+    warm-up call, device outputs, every ray traced), the G-buffer written as in the headline."""
+    import torch
+
+    from stratum_amd import camera, scenes
+    from stratum_amd.bdpt import BDPT
+
+    W, H, seeds = 3840, 2160, 16
+    t0 = time.perf_counter()
+    sc, cam = scenes.forest()
+    t_scene = time.perf_counter() - t0
+    r = BDPT(device=device, args={"maxDiffuseVertices": 8, "maxPathVertices": 10, "minPathVertices": 4, "bdptFlag": ["~coherentrr"]})
+    try:
+        t0 = time.perf_counter()
+        r.update(sc)
+        t_upload = time.perf_counter() - t0
+        r.set_option("answer_last_rays", 0)
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
+        fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+        out = {
+            "radiance": torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"),
+            "albedo": torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"),
+            "visibility": torch.zeros((H, W, 2), dtype=torch.int32, device="cuda"),
+            "depth": torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"),
+            "prev_uv": torch.zeros((H, W, 2), dtype=torch.float32, device="cuda"),
+            "ray_count": torch.zeros(2, dtype=torch.int64, device="cuda"),
+        }
+        ptrs = {k: v.data_ptr() for k, v in out.items()}
+        r.render(fr, 0, 2, device_outputs=ptrs)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter()
+            r.render(fr, 0, seeds, device_outputs=ptrs)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t)
+        rays = int(out["ray_count"][0].item())
+        st = r.stats()
+        dt = float(np.median(ts))
+        in_flight = int(min(seeds, max(1, (1 << 26) // (W * H))))  # (max_paths_in_flight as sthip_create sizes it on a 288 GB device; include/sthip.h)
+        return {
+            "workload": "BASELINE.json configs[4] on ONE GPU: procedural forest, %d triangles in %d instances, %dx%d, %d samples/pixel in one call, maxDiffuseVertices 8, maxPathVertices 10, minPathVertices 4, ~coherentrr, radiance + AOVs written, every ray traced"
+            % (sc.triangle_count, len(sc.instances), W, H, seeds),
+            "value": round(rays / dt / 1e6, 2),
+            "unit": "Mray/s",
+            "ms_per_call": round(dt * 1e3, 2),
+            "calls_ms": [round(x * 1e3, 2) for x in ts],
+            "rays_per_call": rays,
+            "seeds_per_call": seeds,
+            "seeds_in_flight": in_flight,
+            "bvh_node_bytes": int(st["bvh_node_bytes"]),
+            "bvh_build_ms": round(float(st.get("bvh_build_ms", 0.0)), 1),
+            "scene_generation_s": round(t_scene, 2),
+            "upload_s": round(t_upload, 2),
+        }
+    finally:
+        r.close()
 
 
 def main():
@@ -232,14 +295,29 @@ def main():
             pass
 
         exchange = "none"
+        exchange_bytes_per_step = 0
     else:
         # Sharded frame: every rank renders only its tiles (packed, 1 / world of the frame) and the one exchange of the
         # path is a gather of those to rank 0, which scatters them into the image (sthip_assemble_tiles). The gather of
         # step i runs on RCCL's stream while step i + 1 renders into the other buffer. A failure of the exchange is a
         # failure of the run: nothing here falls back to another form.
         stride = shard.slot_count(W, H, 0, world)  # rank 0 owns the most tiles: equal-size messages
-        packed = [torch.zeros((stride, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
-        gathered = [torch.zeros((world, stride, 4), dtype=torch.float32, device="cuda") if rank == 0 else None for _ in range(2)]
+        # One message per rank and step: its tiles of EVERY output of the frame, in slot order — the radiance (16 B per slot,
+        # written packed by the render) and, as the reference's pass always yields them (bdpt.hlsl:222-296), the G-buffer:
+        # albedo 16 B, DepthInfo 16 B, VisibilityInfo 8 B, previous-frame uv 8 B (sthip_pack_tiles of the rank's own images):
+        # 64 B per slot, so an N-GPU step delivers what the one-GPU step delivers.
+        segments = {"radiance": (0, 16)}  # output -> (first float of its segment in a rank's message, bytes per slot)
+        entry_floats = 4
+        for name, nbytes in (("albedo", 16), ("depth", 16), ("visibility", 8), ("prev_uv", 8)):
+            if name in aov:
+                segments[name] = (entry_floats * stride, nbytes)
+                entry_floats += nbytes // 4
+        packed = [torch.zeros(stride * entry_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+        gathered = [torch.zeros((world, stride * entry_floats), dtype=torch.float32, device="cuda") if rank == 0 else None for _ in range(2)]
+        # what the rank renders its own G-buffer tiles into (W x H images, zero elsewhere); `aov` holds the assembled frame's on rank 0
+        aov_local = {k: torch.zeros_like(v) for k, v in aov.items()}
+        aov_local_ptrs = {k: v.data_ptr() for k, v in aov_local.items()}
+        exchange_bytes_per_step = world * stride * entry_floats * 4
         host_staged = backend != "nccl"  # gloo rehearsal: collectives on CPU tensors
         pending = [None, None]
 
@@ -252,16 +330,23 @@ def main():
             if rank == 0:
                 if g_cpu is not None:
                     gathered[k].copy_(g_cpu)
-                r.assemble_tiles(frame, gathered[k].data_ptr(), stride, radiance.data_ptr())
+                base = gathered[k].data_ptr()
+                r.assemble_tiles(frame, base, stride * entry_floats // 4, radiance.data_ptr())
+                for name, t in aov.items():
+                    first, nbytes = segments[name]
+                    r.assemble_tiles_bytes(frame, base + 4 * first, stride * entry_floats * 4 // nbytes, t.data_ptr(), nbytes)
             pending[k] = None
 
         def step(i):
             k = i & 1
             finish(k)  # buffer k is free again once its gather has been consumed
-            r.render(frame, seed_begin=i * seeds_per_step, seed_count=seeds_per_step, device_outputs=dict(aov_ptrs, radiance=packed[k].data_ptr()), packed_tiles=True)
+            r.render(frame, seed_begin=i * seeds_per_step, seed_count=seeds_per_step, device_outputs=dict(aov_local_ptrs, radiance=packed[k].data_ptr()), packed_tiles=True)
+            for name, t in aov_local.items():
+                first, nbytes = segments[name]
+                r.pack_tiles(frame, t.data_ptr(), nbytes, packed[k].data_ptr() + 4 * first)
             if host_staged:
                 src = packed[k].cpu()
-                g_cpu = torch.zeros((world, stride, 4)) if rank == 0 else None
+                g_cpu = torch.zeros((world, stride * entry_floats)) if rank == 0 else None
                 shard.gather_tiles(src, g_cpu, dist, dst=0)
                 pending[k] = (None, g_cpu)
             else:
@@ -272,7 +357,7 @@ def main():
             finish(0)
             finish(1)
 
-        exchange = "gather of packed tiles to rank 0 (%s), pipelined behind the next step" % ("RCCL" if backend == "nccl" else backend)
+        exchange = "gather of packed tiles (%s; %d B per slot) to rank 0 (%s), pipelined behind the next step" % (" + ".join(segments), entry_floats * 4, "RCCL" if backend == "nccl" else backend)
 
     def barrier():
         if dist is not None:
@@ -310,7 +395,7 @@ def main():
         for i in range(args.steps):
             k = i & 1
             if host_staged:
-                g_cpu = torch.zeros((world, stride, 4)) if rank == 0 else None
+                g_cpu = torch.zeros((world, stride * entry_floats)) if rank == 0 else None
                 shard.gather_tiles(packed[k].cpu(), g_cpu, dist, dst=0)
                 pending[k] = (None, g_cpu)
             else:
@@ -333,6 +418,32 @@ def main():
         rep_all, rays_all, answered_all = [float(x) for x in t[:-2]], float(t[-1]), float(t[-2])
         world_seen, backend_seen = 1, "none"
     dt_all = float(np.median(rep_all))
+    # ---- steady state: ONE pass of back-to-back steps at least --sustained-seconds long (the same K seeds cycling, so the rays
+    # of a cycle are the counted ones), between the same barriers. Reported beside `value`, never instead of it: `value` is the
+    # median of short bursts; this shows what survives the clocks and power the chip settles at.
+    sustained = None
+    if args.sustained_seconds > 0:
+        cycles = max(1, int(np.ceil(args.sustained_seconds / max(dt_all, 1e-6))))  # (dt_all is the same on every rank: all-reduced)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(cycles):
+            for i in range(args.steps):
+                step(args.warmup + i)
+        drain()
+        barrier()
+        sdt = time.perf_counter() - t0
+        if dist is not None:
+            ts = torch.tensor([sdt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            sdt = float(ts[0])
+        sustained = {
+            "value": round(rays_all * cycles / sdt / 1e6, 2),
+            "unit": "Mray/s",
+            "ms_per_step": round(sdt / (cycles * args.steps) * 1e3, 3),
+            "seconds": round(sdt, 3),
+            "steps": cycles * args.steps,
+            "what": "one uninterrupted pass of the timed region's steps (the same %d seeds cycling), barrier + synchronize on both sides, max over ranks" % args.steps,
+        }
 
     result = None
     if rank == 0:
@@ -572,6 +683,11 @@ def main():
                 "gpu_tris_per_ray": round(gtris / max(gs["rays_total"], 1), 2),
                 "gpu_over_oracle_node_visits": round(gnodes / max(float(ref["stats"][2]), 1.0), 3),
             }
+        # ---- BASELINE.json configs[4] on this one GPU, as a clearly labelled second record (never `value`): the 10M-triangle
+        # instanced forest, 3840x2160, 16 seeds in one call, 8 diffuse / 10 path vertices, ~coherentrr, every output written
+        other_workloads = None
+        if world == 1 and not args.no_other_workloads and args.scene == "atrium":
+            other_workloads = {"forest": forest_record(local_rank)}
         flags_text = "default BDPT flags" if not (args.bdpt_flag or args.max_diffuse_vertices) else "flags %s maxDiffuseVertices %s" % (args.bdpt_flag, args.max_diffuse_vertices)
         result = {
             "metric": "Mray/s at 1920x1080x1spp (1M-tri scene)",
@@ -593,6 +709,7 @@ def main():
                 "rays_answered_without_traversal_per_step": int(answered_all / args.steps),  # 0: the headline traces every ray (last_ray_filter below is the other configuration)
                 "parallelism": "tile-shard x%d" % world if world > 1 else "single GPU",
                 "exchange": exchange,
+                "exchange_bytes_per_step": exchange_bytes_per_step,  # what reaches rank 0 per step: every rank's tiles of every output
                 "exchange_alone_ms_per_step": round(exchange_ms, 4) if world > 1 else None,  # gather + assembly of one step's tiles, not overlapped (in the timed region it runs behind the next step's render)
                 "seeds_per_step": seeds_per_step,
                 "world_size": world_seen,
@@ -600,11 +717,19 @@ def main():
                 "devices": devices,
             },
             "repetitions": {"n": len(rep_all), "ms_per_step": [round(x / args.steps * 1e3, 3) for x in rep_all], "value_is": "median"},
+            "sustained": sustained,
+            "other_workloads": other_workloads,
             "last_ray_filter": last_ray_filter,
             "host_output_value": host_rate,  # Mray/s with the radiance image copied to host memory inside every call
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+    if args.dump_frame:
+        step(0)
+        drain()
+        barrier()
+        if rank == 0:
+            np.savez(args.dump_frame, radiance=radiance.cpu().numpy(), **{k: v.cpu().numpy() for k, v in aov.items()})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
