@@ -423,19 +423,23 @@ def main():
     # median of short bursts; this shows what survives the clocks and power the chip settles at.
     sustained = None
     if args.sustained_seconds > 0:
-        cycles = max(1, int(np.ceil(args.sustained_seconds / max(dt_all, 1e-6))))  # (dt_all is the same on every rank: all-reduced)
+        cycles = 0
         barrier()
         t0 = time.perf_counter()
-        for _ in range(cycles):
-            for i in range(args.steps):
-                step(args.warmup + i)
-        drain()
-        barrier()
-        sdt = time.perf_counter() - t0
-        if dist is not None:
-            ts = torch.tensor([sdt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-            sdt = float(ts[0])
+        sdt = 0.0
+        while sdt < args.sustained_seconds:  # (normally once: the estimate comes from the timed region; every rank sees the same all-reduced times)
+            batch = max(1, int(np.ceil(1.05 * (args.sustained_seconds - sdt) / max(dt_all, 1e-6))))
+            for _ in range(batch):
+                for i in range(args.steps):
+                    step(args.warmup + i)
+            drain()
+            barrier()
+            cycles += batch
+            sdt = time.perf_counter() - t0
+            if dist is not None:
+                ts = torch.tensor([sdt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+                sdt = float(ts[0])
         sustained = {
             "value": round(rays_all * cycles / sdt / 1e6, 2),
             "unit": "Mray/s",

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STHIP_ABI_VERSION 9
+#define STHIP_ABI_VERSION 10
 
 typedef struct sthip_ctx sthip_ctx;
 
@@ -264,6 +264,14 @@ typedef struct sthip_stats {
    * ("answer_last_rays" = 1, the default; scenes without images, spheres, environment or media). They are trace_ray calls of
    * the reference and are counted as such; nodes_visited etc. hold no visits for them */
   uint64_t rays_answered;
+  /* the batch of the last render: paths of one seed on this shard, seeds traced together, the cap in force ("max_paths_in_flight":
+   * sized at sthip_create from the device's FREE memory) and how often sthip_render has halved it because the device could not
+   * hold a batch's state (a render retries with half the batch instead of failing with out-of-memory) */
+  uint32_t paths_per_seed;
+  uint32_t seeds_in_flight;
+  uint64_t max_paths_in_flight;
+  uint32_t batch_halvings;
+  uint32_t reserved0;
 } sthip_stats;
 int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out);
 

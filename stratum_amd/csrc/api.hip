@@ -212,6 +212,8 @@ struct sthip_ctx {
   DevBuf<float4> deep_rays;  // rays that overflowed a bounded LDS stack (k_trace_deep), and their count
   DevBuf<uint32_t> deep_count;
   sthip_stats stats{};
+  hipError_t last_hip_error = hipSuccess;  // of the last failed HIP_TRY (sthip_render halves its batch after an out-of-memory)
+  bool render_launched = false;            // the render call in progress has enqueued work (no second attempt from here on)
   bool stats_pending = false;  // ray / traversal counters of the last render still live on the device
   hipEvent_t ev[2] = {nullptr, nullptr};
 };
@@ -253,6 +255,7 @@ static const void* trace_kernel_wide(bool count, bool alpha, bool bounded) {
     hipError_t _e = (expr);                                                                           \
     if (_e != hipSuccess) {                                                                           \
       (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(_e);                               \
+      (ctx)->last_hip_error = _e;                                                                     \
       return STHIP_ERR_HIP;                                                                           \
     }                                                                                                 \
   } while (0)
@@ -315,8 +318,12 @@ int sthip_create(int device, sthip_ctx** out_ctx) {
     ctx->cu_count = prop.multiProcessorCount;
     // paths in flight by default: the largest power of two that leaves 4 KB of device memory per path (a path costs ~330 B of
     // state, queues and shadow records at the default flags, more with light subpaths): 2^26 on a 288 GB MI355X
-    uint64_t paths = 1ull << 22;
-    while (paths * 2 * 4096 <= (uint64_t)prop.totalGlobalMem && paths < (1ull << 27)) paths *= 2;
+    // — of the memory that is FREE now: a host application (or other contexts on the device) may hold most of it; should the
+    // batch still not fit when a render allocates it, sthip_render halves it and tries again
+    size_t free_bytes = 0, total_bytes = 0;
+    if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) free_bytes = prop.totalGlobalMem;
+    uint64_t paths = 1ull << 18;
+    while (paths * 2 * 4096 <= (uint64_t)free_bytes && paths < (1ull << 27)) paths *= 2;
     ctx->max_paths_in_flight = paths;
   }
   (void)hipEventCreate(&ctx->ev[0]);
@@ -443,7 +450,14 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->embed_leaves = value != 0;
   else if (!strcmp(name, "wide_bvh"))  // takes effect at the next sthip_scene_upload (host-built trees only)
     ctx->use_wide = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 3);
-  else if (!strcmp(name, "tri_min_lanes"))  // the 8-wide walk's leaf phase goes on while at least this many lanes hold a triangle
+  else if (!strcmp(name, "poison_deep_queue")) {  // tests: leaves the deep queue's control words as a call cut short between k_trace and k_trace_deep would (the next render must not care)
+    if (value && ctx->deep_count.p) {
+      const uint32_t junk[2] = {5u, 3u};
+      (void)hipSetDevice(ctx->device);
+      (void)hipStreamSynchronize(ctx->stream);
+      if (hipMemcpy(ctx->deep_count.p, junk, 8, hipMemcpyHostToDevice) != hipSuccess) return fail(ctx, STHIP_ERR_HIP, "poison_deep_queue: copy failed");
+    }
+  } else if (!strcmp(name, "tri_min_lanes"))  // the 8-wide walk's leaf phase goes on while at least this many lanes hold a triangle
     ctx->tri_min_lanes = ctx->bvh.wide8_tri_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 64);
   else if (!strcmp(name, "lbvh_algorithm"))  // 0: Karras radix tree, 1: PLOC (default)
     ctx->lbvh_algorithm = value == 0 ? 0 : 1;
@@ -1193,7 +1207,12 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
   }
   if (ctx->want_wide && !ctx->bvh.wide8_nodes) {
     const int rc = collapse_resident_tree(ctx);
-    if (rc != STHIP_OK) return rc;
+    if (rc != STHIP_OK) {  // (an allocation of the collapse failed: the new binary tree is resident and walked; its stack must be configured for it)
+      const std::string why = ctx->error;
+      (void)configure_stack(ctx);
+      ctx->error = why;
+      return rc;
+    }
   }
   return configure_stack(ctx);
 }
@@ -1224,9 +1243,69 @@ static int build_hash_grid(sthip_ctx* ctx, hipStream_t st, const float4* appends
   return STHIP_OK;
 }
 
+// The buffers sthip_render sizes by the number of paths in flight (released before a second attempt with half the batch)
+static void release_path_state(sthip_ctx* ctx) {
+  (void)hipStreamSynchronize(ctx->stream);  // an earlier call's kernels may still read them
+  ctx->ray_o.release();
+  ctx->ray_d.release();
+  ctx->hit.release();
+  ctx->beta.release();
+  ctx->radiance.release();
+  ctx->shadow_sum.release();
+  ctx->shadow_rays.release();
+  ctx->light_vertices.release();
+  ctx->conn.release();
+  ctx->media_state.release();
+  ctx->shadow_hit.release();
+  ctx->shadow_ext.release();
+  ctx->shadow_result.release();
+  ctx->cone.release();
+  ctx->meta.release();
+  ctx->queue0.release();
+  ctx->queue1.release();
+  ctx->queue_kept.release();
+  ctx->bdpt.release();
+  ctx->rr.release();
+  ctx->cs_nee.release();
+  ctx->cs_lvc.release();
+  ctx->lvc_staging.release();
+  ctx->lvc_flags.release();
+  ctx->lvc_offsets.release();
+  ctx->lvc_tmp.release();
+  ctx->path_contrib.release();
+  ctx->light_trace.release();
+  ctx->presampled.release();
+  ctx->deep_rays.release();
+}
+
+static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin, uint32_t seed_count,
+                       const sthip_outputs* out);
+
+// A render allocates its path state (~330 B per path in flight at the default flags) before it enqueues anything. Should the
+// device not have that much left — a host application that holds memory of its own, several contexts on one device — the
+// batch is halved (fewer seeds traced together: the same frame, a little slower) and the call tried again, down to one seed;
+// the smaller batch stays for the calls that follow (stats: max_paths_in_flight, batch_halvings).
 int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin,
                  uint32_t seed_count, const sthip_outputs* out) {
   if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
+  for (;;) {
+    ctx->last_hip_error = hipSuccess;
+    ctx->render_launched = false;
+    const int rc = render_once(ctx, pc, sampling_flags, scene_flags, frame, seed_begin, seed_count, out);
+    ctx->stats.max_paths_in_flight = ctx->max_paths_in_flight;
+    if (rc != STHIP_ERR_HIP || ctx->last_hip_error != hipErrorOutOfMemory || ctx->render_launched) return rc;
+    (void)hipGetLastError();  // (the allocation's error is not sticky, but it is the "last error" until read)
+    const uint64_t per_seed = std::max<uint64_t>(1, ctx->stats.paths_per_seed);
+    if (ctx->max_paths_in_flight <= per_seed || ctx->max_paths_in_flight <= 1) return rc;  // one seed in flight already: it does not fit
+    release_path_state(ctx);
+    ctx->max_paths_in_flight = std::max<uint64_t>(per_seed, ctx->max_paths_in_flight / 2);
+    ctx->stats.batch_halvings++;
+    if (getenv("STHIP_VERBOSE")) fprintf(stderr, "[sthip] out of device memory (%s): max_paths_in_flight -> %llu\n", ctx->error.c_str(), (unsigned long long)ctx->max_paths_in_flight);
+  }
+}
+
+static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sampling_flags, uint32_t scene_flags, const sthip_frame_desc* frame, uint32_t seed_begin, uint32_t seed_count,
+                       const sthip_outputs* out) {
   if (!pc || !frame || !out || !out->gRadiance || !frame->gViews || !frame->gViewTransforms || frame->view_count == 0 || seed_count == 0)
     return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: a required argument is NULL/zero");
   if (!ctx->has_scene) return fail(ctx, STHIP_ERR_NO_SCENE, "no scene uploaded");
@@ -1313,6 +1392,8 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
   const bool lvc_reuse = (sampling_flags & (1u << STHIP_eLVCReservoirReuse)) != 0;
   const uint32_t batch = (nee_reuse || lvc_reuse) ? 1u : std::min(seed_count, max_in_flight);
   p.path_count = batch * p.paths_per_seed;
+  ctx->stats.paths_per_seed = p.paths_per_seed;
+  ctx->stats.seeds_in_flight = batch;
   // light tracing (eConnectToViews, BDPT.cpp:653-667): sample_photons' padded dispatch, dispatch_over(W, ceil(gLightPathCount / W))
   const bool connect_views = (sampling_flags & (1u << STHIP_eConnectToViews)) != 0;
   const bool connect_paths = (sampling_flags & (1u << STHIP_eConnectToLightPaths)) != 0;  // light-subpath connections, no light vertex cache
@@ -1690,6 +1771,10 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t sam
     return STHIP_OK;
   };
 
+  ctx->render_launched = true;  // everything the call needs is allocated: from here on work is enqueued
+  // the deep queue's control words: k_trace_deep leaves them at zero, but a call that was cut short between k_trace and
+  // k_trace_deep (a failed launch, an error return) would not have: one 8-byte fill per call keeps every call self-contained
+  if (ctx->bvh.spill && ctx->deep_count.p) HIP_TRY(ctx, hipMemsetAsync(ctx->deep_count.p, 0, 8, st));
   bool counters_cleared = false;  // (the first pass's k_clear takes the counters along with its queue control words)
   const bool nee = (sampling_flags & (1u << STHIP_eNEE)) != 0;
   const bool ext = ctx->has_spheres || has_env || bdpt || (sampling_flags & ((1u << STHIP_eNEEReservoirs) | (1u << STHIP_eShadingNormalShadowFix)));

@@ -225,6 +225,11 @@ class Stats(C.Structure):
         ("launches_primary", C.c_uint32),
         ("lane_states", C.c_uint64 * 8),
         ("rays_answered", C.c_uint64),
+        ("paths_per_seed", C.c_uint32),
+        ("seeds_in_flight", C.c_uint32),
+        ("max_paths_in_flight", C.c_uint64),
+        ("batch_halvings", C.c_uint32),
+        ("reserved0", C.c_uint32),
     ]
 
 

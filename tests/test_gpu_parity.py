@@ -1705,3 +1705,75 @@ def test_culling_finished_paths_with_spheres_reservoirs_and_an_environment():
         assert np.array_equal(a["radiance"].view(np.uint32), ref["radiance"].view(np.uint32)), (sc.name, flags)
         assert np.array_equal(a["ray_count"], ref["ray_count"])
         assert answered[1] == 0 and (answered[0] > 0) == answers, (sc.name, flags, answered)
+
+
+def test_a_render_does_not_depend_on_what_a_failed_one_left_in_the_deep_queue(atrium_scene):
+    """k_trace_deep leaves the deep queue's control words at zero for the next launch; a call that ended between k_trace and
+    k_trace_deep (a failed launch, an early error return) would leave them dirty. sthip_render fills them once per call, so
+    every call is self-contained: the frame after such a failure (simulated: option poison_deep_queue) is the frame."""
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = atrium_scene
+    frame = camera.Frame(160, 96, cam["fovy"], cam["eye"], cam["target"])
+    r = BDPT(device=0, args={"maxDiffuseVertices": 3})
+    try:
+        r.set_option("lds_stack_levels", 6)  # bounded stacks: nearly every ray goes through the deep queue
+        r.update(sc)
+        ref = r.render(frame, 1, 2)
+        r.set_option("poison_deep_queue", 1)
+        got = r.render(frame, 1, 2)
+        again = r.render(frame, 1, 2)
+    finally:
+        r.close()
+    for x in (got, again):
+        assert np.array_equal(ref["radiance"].view(np.uint32), x["radiance"].view(np.uint32))
+        assert np.array_equal(ref["ray_count"], x["ray_count"])
+
+
+def test_render_halves_its_batch_when_the_device_is_nearly_full():
+    """max_paths_in_flight is sized from the device's FREE memory at sthip_create, and a render whose path state does not fit
+    beside what else lives on the device retries with half the batch instead of failing (stats: batch_halvings): the frame
+    does not depend on how many seeds are traced together. Here another owner (a torch tensor) takes all but ~3 GB after the
+    context was sized for an empty device."""
+    import torch
+
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = scenes.cornell_box()
+    frame = camera.Frame(1920, 1080, cam["fovy"], cam["eye"], cam["target"])
+    seeds = 16
+    r = BDPT(device=0)
+    try:
+        r.update(sc)
+        ref = r.render(frame, 0, seeds, aovs=False)
+        st = r.stats()
+        assert st["seeds_in_flight"] == seeds and st["batch_halvings"] == 0 and st["paths_per_seed"] >= 1920 * 1080
+    finally:
+        r.close()
+    r = BDPT(device=0)  # sized now, while the device is empty
+    hog = None
+    try:
+        r.update(sc)
+        torch.cuda.synchronize()
+        free, _ = torch.cuda.mem_get_info()
+        hog = torch.empty(max(0, free - (3 << 30)), dtype=torch.uint8, device="cuda")
+        got = r.render(frame, 0, seeds, aovs=False)
+        st = r.stats()
+        assert st["batch_halvings"] >= 1 and 1 <= st["seeds_in_flight"] < seeds, st
+        again = r.render(frame, 0, seeds, aovs=False)  # the smaller batch stays: no second round of failures
+        assert r.stats()["batch_halvings"] == st["batch_halvings"]
+        late = BDPT(device=0)  # a context created on the full device starts small
+        try:
+            late.update(sc)
+            small = late.render(frame, 0, 4, aovs=False)
+            assert late.stats()["max_paths_in_flight"] < st["max_paths_in_flight"] * 4 and late.stats()["batch_halvings"] == 0
+        finally:
+            late.close()
+    finally:
+        r.close()
+        del hog
+        torch.cuda.empty_cache()
+    assert np.array_equal(ref["radiance"].view(np.uint32), got["radiance"].view(np.uint32))
+    assert np.array_equal(ref["radiance"].view(np.uint32), again["radiance"].view(np.uint32))
+    assert np.array_equal(ref["ray_count"], got["ray_count"])
+    assert small["radiance"].shape == (1080, 1920, 4)
