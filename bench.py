@@ -104,6 +104,9 @@ def parse_args():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): a step renders N seeds of the frame on N GPUs (per-GPU work fixed); strong: a step renders --strong-seeds seeds whatever N (total work fixed)")
     ap.add_argument("--strong-seeds", type=int, default=8, help="seeds per step in --scaling strong (BASELINE.md row 3b's 8 by default)")
+    ap.add_argument("--shard", choices=("tiles", "seeds"), default="tiles",
+                    help="N > 1: tiles (default): every rank renders its 64x32 tiles of every seed, one gather of the packed tiles; seeds: every rank renders the WHOLE frame for its "
+                    "part of the step's seeds and one sum-reduce of the accumulation buffer adds them (SURVEY 8e 'replicas + sum-reduce': what the whole-frame estimators need)")
     ap.add_argument("--sustained-seconds", type=float, default=3.0, help="after the timed repetitions: one pass of back-to-back steps (the same seeds cycling) at least this long, reported as `sustained` beside `value` (0: skip)")
     ap.add_argument("--dump-frame", default=None, help="rank 0 saves the outputs of one more step (seed block 0) as <path>.npz after the measurements: what tests compare between N = 1 and N > 1")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the config-5 forest sub-record (other_workloads.forest; N = 1 only)")
@@ -268,7 +271,11 @@ def main():
     # reach one (sthip.h "answer_last_rays": same frames, same gRayCount, 1/5 of the rays of this workload never walk the tree);
     # that configuration is timed separately below and reported as `last_ray_filter`, never as `value`.
     r.set_option("answer_last_rays", 0)
-    r.set_shard(rank, world, 64, 32)
+    seed_split = world > 1 and args.shard == "seeds"
+    if seed_split:
+        r.set_shard(0, 1, 64, 32)  # the whole frame on every rank; the ranks differ in the seeds they render
+    else:
+        r.set_shard(rank, world, 64, 32)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     radiance = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     # the G-buffer the reference's sample_visibility always writes (bdpt.hlsl:222-296); every rank writes its own pixels
@@ -296,6 +303,48 @@ def main():
 
         exchange = "none"
         exchange_bytes_per_step = 0
+    elif seed_split:
+        # Replicas: rank r renders the whole frame for its share of the step's seeds into its own accumulation buffer, turns
+        # (mean, count) into (sum, count) and ONE sum-reduce adds the buffers on rank 0 (RCCL reduce over xGMI, behind the next
+        # step's render), which divides by the count. The G-buffer does not depend on the seed: rank 0's is the frame's.
+        first, count = shard.seed_range(rank, world, seeds_per_step)
+        sums = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        exchange_bytes_per_step = world * W * H * 16
+        host_staged = backend != "nccl"
+        pending = [None, None]
+
+        def finish(k):
+            if pending[k] is None:
+                return
+            work, cpu = pending[k]
+            if work is not None:
+                work.wait()
+            if rank == 0:
+                radiance.copy_(cpu if cpu is not None else sums[k])
+                r.radiance_to_sums(radiance.data_ptr(), W * H, back=True)
+            pending[k] = None
+
+        def step(i):
+            k = i & 1
+            finish(k)
+            if count:
+                r.render(frame, seed_begin=i * seeds_per_step + first, seed_count=count, device_outputs=dict(aov_ptrs, radiance=sums[k].data_ptr()))
+                r.radiance_to_sums(sums[k].data_ptr(), W * H)
+            else:
+                sums[k].zero_()
+            if host_staged:
+                cpu = sums[k].cpu()
+                shard.reduce_seed_sums(cpu, dist, dst=0)
+                pending[k] = (None, cpu)
+            else:
+                pending[k] = (shard.reduce_seed_sums(sums[k], dist, dst=0, async_op=True), None)
+            finish(k ^ 1)
+
+        def drain():
+            finish(0)
+            finish(1)
+
+        exchange = "sum-reduce of the whole-frame accumulation buffers to rank 0 (%s), pipelined behind the next step" % ("RCCL" if backend == "nccl" else backend)
     else:
         # Sharded frame: every rank renders only its tiles (packed, 1 / world of the frame) and the one exchange of the
         # path is a gather of those to rank 0, which scatters them into the image (sthip_assemble_tiles). The gather of
@@ -382,7 +431,13 @@ def main():
     # the same seeds, hence the same rays)
     rays_local = answered_local = 0
     for i in range(args.steps):
-        r.render(frame, seed_begin=(args.warmup + i) * seeds_per_step, seed_count=seeds_per_step, device_outputs=dev_out)
+        sb, sn = (args.warmup + i) * seeds_per_step, seeds_per_step
+        if seed_split:  # this rank's share of the step's seeds, the whole frame
+            f0, sn = shard.seed_range(rank, world, seeds_per_step)
+            sb += f0
+        if sn == 0:
+            continue
+        r.render(frame, seed_begin=sb, seed_count=sn, device_outputs=dev_out)
         st = r.stats()
         rays_local += st["rays_total"]
         answered_local += st["rays_answered"]  # of them: last rays of paths answered from the emitters' bounds, no traversal (sthip.h)
@@ -394,7 +449,14 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             k = i & 1
-            if host_staged:
+            if seed_split:
+                if host_staged:
+                    cpu = sums[k].cpu()
+                    shard.reduce_seed_sums(cpu, dist, dst=0)
+                    pending[k] = (None, cpu)
+                else:
+                    pending[k] = (shard.reduce_seed_sums(sums[k], dist, dst=0, async_op=True), None)
+            elif host_staged:
                 g_cpu = torch.zeros((world, stride * entry_floats)) if rank == 0 else None
                 shard.gather_tiles(packed[k].cpu(), g_cpu, dist, dst=0)
                 pending[k] = (None, g_cpu)
@@ -708,10 +770,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "procedural %s, %d triangles, %dx%d, %d sample(s)/pixel/step, %s, %s, pixel-tile shard 64x32 over %d GPU(s)"
-                % (args.scene, sc.triangle_count, W, H, seeds_per_step, flags_text, "radiance only" if args.radiance_only else "radiance + albedo/visibility/depth/prev-uv AOVs written", world),
+                % (args.scene, sc.triangle_count, W, H, seeds_per_step, flags_text, "radiance only" if args.radiance_only else "radiance + albedo/visibility/depth/prev-uv AOVs written", world)
+                + (" (--shard seeds: whole frames over disjoint seed ranges, one sum-reduce)" if seed_split else ""),
                 "rays_per_step": int(rays_all / args.steps),
                 "rays_answered_without_traversal_per_step": int(answered_all / args.steps),  # 0: the headline traces every ray (last_ray_filter below is the other configuration)
-                "parallelism": "tile-shard x%d" % world if world > 1 else "single GPU",
+                "parallelism": ("seed-split replicas x%d" % world if seed_split else "tile-shard x%d" % world) if world > 1 else "single GPU",
                 "exchange": exchange,
                 "exchange_bytes_per_step": exchange_bytes_per_step,  # what reaches rank 0 per step: every rank's tiles of every output
                 "exchange_alone_ms_per_step": round(exchange_ms, 4) if world > 1 else None,  # gather + assembly of one step's tiles, not overlapped (in the timed region it runs behind the next step's render)

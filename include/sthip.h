@@ -199,6 +199,15 @@ int sthip_pack_tiles(sthip_ctx* ctx, const void* image, uint32_t width, uint32_t
 int sthip_assemble_tiles_bytes(sthip_ctx* ctx, const void* packed, uint64_t rank_stride, uint32_t shard_count, uint32_t tile_w,
                                uint32_t tile_h, uint32_t width, uint32_t height, uint32_t entry_bytes, void* frame);
 
+/* The other way to spread a render call over GPUs: every GPU renders the WHOLE frame for its own part of the
+ * seed range (sthip_set_shard(ctx, 0, 1, ..)), and the images are added up — one ncclReduce(sum) of the accumulation buffer.
+ * It serves the estimators that build whole-frame structures (light tracing's splats, the reservoir-reuse hash grids), which
+ * a tile shard cannot; the mean of N seeds then depends on the order of a floating-point sum (~1e-7 relative against the
+ * one-GPU frame, where a tile shard is bit-identical). A call's radiance output is (mean over its seeds, their number):
+ * sthip_radiance_to_sums turns `entries` RGBA32F entries in place into (sum over the seeds, their number), which a
+ * sum-reduce can add; with back != 0 it turns such sums back into (mean, number). Device pointer; enqueued on the stream. */
+int sthip_radiance_to_sums(sthip_ctx* ctx, float* image, uint64_t entries, uint32_t back);
+
 /* ---- the traversal contract on its own (T1/T2 of SURVEY.md §8a; intersection.hlsli:65-239) ---- */
 typedef struct sthip_ray {
   float origin[3];

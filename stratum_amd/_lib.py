@@ -32,6 +32,7 @@ EXPORTS = [
     "sthip_assemble_tiles",
     "sthip_assemble_tiles_bytes",
     "sthip_pack_tiles",
+    "sthip_radiance_to_sums",
     "sthip_accumulate",
     "sthip_tonemap",
     "sthip_image_compare",
@@ -116,6 +117,8 @@ def lib():
     L.sthip_assemble_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     L.sthip_assemble_tiles_bytes.restype = C.c_int
     L.sthip_assemble_tiles_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.sthip_radiance_to_sums.restype = C.c_int
+    L.sthip_radiance_to_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
     L.sthip_pack_tiles.restype = C.c_int
     L.sthip_pack_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     L.sthip_accumulate.restype = C.c_int

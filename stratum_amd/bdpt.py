@@ -226,6 +226,11 @@ class BDPT:
         _, n, tw, th = getattr(self, "_shard", (0, 1, 64, 32))
         self._check(self._lib.sthip_assemble_tiles(self._h, packed_ptr, rank_stride, n, tw, th, frame.width, frame.height, frame_ptr), "sthip_assemble_tiles")
 
+    def radiance_to_sums(self, image_ptr, entries, back=False):
+        """(mean over the seeds, their number) -> (sum, number) in place, or back: what the seed-split replica mode reduces
+        (device pointer; include/sthip.h: sthip_radiance_to_sums)."""
+        self._check(self._lib.sthip_radiance_to_sums(self._h, image_ptr, entries, 1 if back else 0), "sthip_radiance_to_sums")
+
     def pack_tiles(self, frame, image_ptr, entry_bytes, packed_ptr):
         """This shard's tiles of a W x H image of entry_bytes per pixel (a G-buffer output of render) in slot order: what the
         ranks exchange (device pointers; include/sthip.h: sthip_pack_tiles)."""

@@ -2092,6 +2092,16 @@ int sthip_assemble_tiles(sthip_ctx* ctx, const float* packed, uint64_t rank_stri
                          float* frame) {
   return sthip_assemble_tiles_bytes(ctx, packed, rank_stride, shard_count, tile_w, tile_h, width, height, 16, frame);
 }
+int sthip_radiance_to_sums(sthip_ctx* ctx, float* image, uint64_t entries, uint32_t back) {
+  if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
+  if (!image) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_radiance_to_sums: image is NULL");
+  if (entries == 0) return STHIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_radiance_sums, dim3(grid_for(ctx, (size_t)entries)), dim3(STHIP_BLOCK), 0, ctx->stream, reinterpret_cast<float4*>(image), (size_t)entries, back ? 0u : 1u);
+  HIP_TRY(ctx, hipGetLastError());
+  return STHIP_OK;
+}
+
 int sthip_pack_tiles(sthip_ctx* ctx, const void* image, uint32_t width, uint32_t height, uint32_t entry_bytes, void* packed) {
   if (!ctx) return STHIP_ERR_INVALID_ARGUMENT;
   if (!image || !packed || !width || !height) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "sthip_pack_tiles: a required argument is NULL/zero");

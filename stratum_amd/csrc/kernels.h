@@ -2596,6 +2596,24 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const uint32_t* 
 }
 // The other direction (sthip_pack_tiles): a W x H image on one rank -> that rank's tiles in slot order (slots outside the
 // image: zero). What the ranks exchange of the G-buffer outputs, which sthip_render writes as images.
+// The seed-split replica mode (sthip.h: sthip_radiance_to_sums): a call's output is (mean over its seeds, their number); what a
+// sum-reduce over replicas can add up is (sum over its seeds, their number). Back: mean = sum / number, correctly rounded.
+__global__ void __launch_bounds__(STHIP_BLOCK) k_radiance_sums(float4* image, size_t n, uint32_t to_sums) {
+  for (size_t i = blockIdx.x * (size_t)STHIP_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * STHIP_BLOCK) {
+    float4 v = image[i];
+    if (to_sums) {
+      v.x = v.x * v.w;
+      v.y = v.y * v.w;
+      v.z = v.z * v.w;
+    } else if (v.w > 0.0f) {
+      v.x = v.x / v.w;
+      v.y = v.y / v.w;
+      v.z = v.z / v.w;
+    }
+    image[i] = v;
+  }
+}
+
 __global__ void __launch_bounds__(STHIP_BLOCK) k_pack_tiles(const uint32_t* image, uint32_t rank, uint32_t shard_count, uint32_t slots, uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height,
                                                              uint32_t words, uint32_t* packed) {
   const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -17,14 +17,28 @@
 //      on its communication stream, behind the render (an event, no host wait). The radiance always travels; the G-buffer
 //      outputs the reference's render always produces (albedo, VisibilityInfo, DepthInfo, prev-uv: bdpt.hlsl:222-296, what
 //      the denoiser consumes, Denoiser.cpp:186-213) travel the same way when gather_aovs(true) (the default).
-// With pipelined(true) the exchange and assembly of frame i run while frame i + 1 renders (two sets of buffers): render()
-// then returns once frame i - 1 is complete, prev_result() lags one call behind, and flush() completes the last frame.
+// With pipelined(true) the exchange, the assembly and the read-back of frame i run while frame i + 1 renders (two sets of
+// buffers; the assembly and the copies go to rank 0's COMMUNICATION stream, so they do not queue behind that render):
+// render() then returns once frame i - 1 is complete, prev_result() lags one call behind, flush() completes the last frame.
+//
+// split_seeds(true) is the other way to spread a call ("replicas + sum-reduce"): every GPU renders the WHOLE
+// frame for its own part of the call's seed range, the images become sums (sthip_radiance_to_sums) and ONE
+// ncclReduce(sum) of the accumulation buffer adds them on rank 0. It is what the whole-frame estimators need (light tracing,
+// reservoir reuse: a tile shard is refused for them); reservoir reuse then restarts its chain of grids at the first seed of
+// every rank's range. The G-buffer is the same on every rank: rank 0's is used.
+//
+// A failure inside the exchange (phase 2) cannot leave peers waiting: the thread that fails aborts EVERY communicator
+// (ncclCommAbort), which ends the calls its peers are blocked in; the call throws, the communicators are made again at the
+// next render. finish() polls ncclCommGetAsyncError while it waits for an exchange to complete, with the same outcome.
+// read_back(false) leaves the assembled frame on devices[0] (device_frame() and friends): no device-to-host copies at all.
 // Needs <rccl/rccl.h> and the HIP runtime (link -lrccl -lamdhip64); stratum_hip.hpp itself stays free of both.
 #pragma once
 
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -137,13 +151,12 @@ class MultiDeviceBDPT : public BDPT {
       : BDPT(node, devices.empty() ? 0 : devices[0]), mDevices(devices), mTileW(tile_w), mTileH(tile_h) {
     if (devices.empty()) throw std::invalid_argument("MultiDeviceBDPT: no devices");
     mRanks.resize(devices.size());
+    mCommMutex = std::vector<std::mutex>(devices.size());
     mRanks[0].ctx = mCtx;
     for (size_t r = 1; r < devices.size(); r++)
       if (sthip_create(devices[r], &mRanks[r].ctx) != STHIP_OK) throw std::runtime_error(std::string("sthip_create: ") + sthip_last_error(nullptr));
-    std::vector<ncclComm_t> comms(devices.size());
-    check_nccl(ncclCommInitAll(comms.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
+    init_comms();
     for (size_t r = 0; r < devices.size(); r++) {
-      mRanks[r].comm = comms[r];
       check_hip(hipSetDevice(devices[r]), "hipSetDevice");
       check_hip(hipStreamCreateWithFlags(&mRanks[r].stream, hipStreamNonBlocking), "hipStreamCreate");
       check_hip(hipStreamCreateWithFlags(&mRanks[r].comm_stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -178,6 +191,11 @@ class MultiDeviceBDPT : public BDPT {
   }
   size_t world() const { return mRanks.size(); }
   void gather_aovs(bool on) { mGatherAOVs = on; }  // also exchange albedo / visibility / depth / prev-uv (default on)
+  void split_seeds(bool on) {                       // replicas of the whole frame over disjoint seed ranges + one sum-reduce, instead of tiles + a gather
+    flush();
+    mSplitSeeds = on;
+  }
+  void read_back(bool on) { mReadBack = on; }       // false: prev_result() carries the ray counts only, the images stay on devices[0]
   void pipelined(bool on) {
     flush();
     mPipelined = on;
@@ -223,54 +241,99 @@ class MultiDeviceBDPT : public BDPT {
     const uint32_t seed_begin = frame_number();
     const int k = mPipelined ? (int)(mSubmitted & 1u) : 0;
     if (mInFlight[k].valid) finish(k);  // (cannot be: the frame that used these buffers was completed at the end of the call before last)
+    if (mCommsAborted.load()) init_comms();    // an earlier exchange failed and took the communicators with it
+    const bool seeds_mode = mSplitSeeds;
+    const uint32_t world_n = (uint32_t)mRanks.size();
+    // seeds mode: rank r takes seeds [first_of(r), first_of(r + 1)) of the call (the first seed_count % world ranks one more)
+    auto first_of = [&](uint32_t r) { return (seed_count / world_n) * r + std::min(r, seed_count % world_n); };
     // ---- phase 1: every rank renders; no collective has been issued when this returns or throws ----
     mThreads->run(0, [&](size_t r) {
       Rank& rk = mRanks[r];
       Buffers& b = rk.buf[k];
       check_hip(hipSetDevice(mDevices[r]), "hipSetDevice");
-      if (sthip_set_shard(rk.ctx, (uint32_t)r, (uint32_t)mRanks.size(), mTileW, mTileH) != STHIP_OK) throw std::runtime_error(sthip_last_error(rk.ctx));
+      if (sthip_set_shard(rk.ctx, seeds_mode ? 0u : (uint32_t)r, seeds_mode ? 1u : world_n, mTileW, mTileH) != STHIP_OK) throw std::runtime_error(sthip_last_error(rk.ctx));
       sthip_outputs o{};
       o.device_ptrs = 1;
-      o.radiance_layout = STHIP_LAYOUT_SHARD_TILES;
-      o.gRadiance = (float*)b.radiance;
       o.gRayCount = (uint64_t*)b.counters;
-      if (mGatherAOVs) {
-        o.gAlbedo = (float*)b.img_albedo;
-        o.gVisibility = (VisibilityInfo*)b.img_visibility;
-        o.gDepth = (DepthInfo*)b.img_depth;
-        o.gPrevUVs = (float*)b.img_prev_uv;
-      }
-      if (sthip_render(rk.ctx, &fs.pc, sampling_flags(), fs.scene_flags, &fs.f, seed_begin, seed_count, &o) != STHIP_OK)
-        throw std::runtime_error(std::string("sthip_render (rank ") + std::to_string(r) + "): " + sthip_last_error(rk.ctx));
-      if (mGatherAOVs) {  // the G-buffer images -> this rank's tiles in slot order, like the radiance
-        const void* img[4] = {b.img_albedo, b.img_visibility, b.img_depth, b.img_prev_uv};
-        void* pk[4] = {b.albedo, b.visibility, b.depth, b.prev_uv};
-        for (int a = 0; a < 4; a++)
-          if (sthip_pack_tiles(rk.ctx, img[a], width, height, kEntryBytes[a + 1], pk[a]) != STHIP_OK) throw std::runtime_error(std::string("sthip_pack_tiles: ") + sthip_last_error(rk.ctx));
+      if (seeds_mode) {
+        const uint32_t s0 = first_of((uint32_t)r), n = first_of((uint32_t)r + 1) - s0;
+        o.radiance_layout = STHIP_LAYOUT_IMAGE;
+        o.gRadiance = (float*)b.full;
+        if (r == 0 && mGatherAOVs) {  // the G-buffer does not depend on the seed: rank 0's is the frame's
+          o.gAlbedo = (float*)b.img_albedo;
+          o.gVisibility = (VisibilityInfo*)b.img_visibility;
+          o.gDepth = (DepthInfo*)b.img_depth;
+          o.gPrevUVs = (float*)b.img_prev_uv;
+        }
+        if (n == 0) {  // more ranks than seeds: this one adds nothing
+          check_hip(hipMemsetAsync(b.full, 0, pixels * 16, rk.stream), "hipMemsetAsync");
+          check_hip(hipMemsetAsync(b.counters, 0, 16, rk.stream), "hipMemsetAsync");
+        } else {
+          if (sthip_render(rk.ctx, &fs.pc, sampling_flags(), fs.scene_flags, &fs.f, seed_begin + s0, n, &o) != STHIP_OK)
+            throw std::runtime_error(std::string("sthip_render (rank ") + std::to_string(r) + "): " + sthip_last_error(rk.ctx));
+          if (sthip_radiance_to_sums(rk.ctx, (float*)b.full, pixels, 0) != STHIP_OK) throw std::runtime_error(std::string("sthip_radiance_to_sums: ") + sthip_last_error(rk.ctx));
+        }
+      } else {
+        o.radiance_layout = STHIP_LAYOUT_SHARD_TILES;
+        o.gRadiance = (float*)b.radiance;
+        if (mGatherAOVs) {
+          o.gAlbedo = (float*)b.img_albedo;
+          o.gVisibility = (VisibilityInfo*)b.img_visibility;
+          o.gDepth = (DepthInfo*)b.img_depth;
+          o.gPrevUVs = (float*)b.img_prev_uv;
+        }
+        if (sthip_render(rk.ctx, &fs.pc, sampling_flags(), fs.scene_flags, &fs.f, seed_begin, seed_count, &o) != STHIP_OK)
+          throw std::runtime_error(std::string("sthip_render (rank ") + std::to_string(r) + "): " + sthip_last_error(rk.ctx));
+        if (mGatherAOVs) {  // the G-buffer images -> this rank's tiles in slot order, like the radiance
+          const void* img[4] = {b.img_albedo, b.img_visibility, b.img_depth, b.img_prev_uv};
+          void* pk[4] = {b.albedo, b.visibility, b.depth, b.prev_uv};
+          for (int a = 0; a < 4; a++)
+            if (sthip_pack_tiles(rk.ctx, img[a], width, height, kEntryBytes[a + 1], pk[a]) != STHIP_OK) throw std::runtime_error(std::string("sthip_pack_tiles: ") + sthip_last_error(rk.ctx));
+        }
       }
       check_hip(hipMemcpyAsync(rk.ray_count[k], b.counters, 16, hipMemcpyDeviceToHost, rk.stream), "hipMemcpyAsync");
       check_hip(hipEventRecord(rk.rendered[k], rk.stream), "hipEventRecord");
     });
-    // ---- phase 2: the exchange, on the communication streams, behind the renders ----
-    mThreads->run(0, [&](size_t r) {
-      Rank& rk = mRanks[r];
-      Buffers& b = rk.buf[k];
-      check_hip(hipSetDevice(mDevices[r]), "hipSetDevice");
-      check_hip(hipStreamWaitEvent(rk.comm_stream, rk.rendered[k], 0), "hipStreamWaitEvent");
-      const void* src[5] = {b.radiance, b.albedo, b.visibility, b.depth, b.prev_uv};
-      void* dst[5] = {mGathered[k].radiance, mGathered[k].albedo, mGathered[k].visibility, mGathered[k].depth, mGathered[k].prev_uv};
-      const int parts = mGatherAOVs ? 5 : 1;
-      check_nccl(ncclGroupStart(), "ncclGroupStart");
-      for (int a = 0; a < parts; a++) {
-        const size_t bytes = stride * kEntryBytes[a];
-        check_nccl(ncclSend(src[a], bytes, ncclChar, 0, rk.comm, rk.comm_stream), "ncclSend");
-        if (r == 0)
-          for (size_t q = 0; q < mRanks.size(); q++) check_nccl(ncclRecv((char*)dst[a] + q * bytes, bytes, ncclChar, (int)q, rk.comm, rk.comm_stream), "ncclRecv");
-      }
-      check_nccl(ncclGroupEnd(), "ncclGroupEnd");
-      check_hip(hipEventRecord(rk.exchanged[k], rk.comm_stream), "hipEventRecord");
-    });
+    // ---- phase 2: the exchange, on the communication streams, behind the renders. A rank that fails in here takes every
+    // communicator down with it (abort_comms), which ends the calls its peers are blocked in: nobody waits for ever ----
+    try {
+      mThreads->run(0, [&](size_t r) {
+        try {
+          Rank& rk = mRanks[r];
+          Buffers& b = rk.buf[k];
+          check_hip(hipSetDevice(mDevices[r]), "hipSetDevice");
+          check_hip(hipStreamWaitEvent(rk.comm_stream, rk.rendered[k], 0), "hipStreamWaitEvent");
+          CommUse use(*this, r);  // (throws if a peer has aborted the communicators already; an abort that comes later ends the calls below)
+          if (seeds_mode) {
+            // (into this frame's own buffer on rank 0 — the gather's, large enough: world x stride >= pixels — so that a frame in
+            // flight never writes what the one before it is still being read from)
+            check_nccl(ncclReduce(b.full, mGathered[k].radiance, 4 * pixels, ncclFloat, ncclSum, 0, use.comm, rk.comm_stream), "ncclReduce");
+          } else {
+            const void* src[5] = {b.radiance, b.albedo, b.visibility, b.depth, b.prev_uv};
+            void* dst[5] = {mGathered[k].radiance, mGathered[k].albedo, mGathered[k].visibility, mGathered[k].depth, mGathered[k].prev_uv};
+            const int parts = mGatherAOVs ? 5 : 1;
+            check_nccl(ncclGroupStart(), "ncclGroupStart");
+            for (int a = 0; a < parts; a++) {
+              const size_t bytes = stride * kEntryBytes[a];
+              check_nccl(ncclSend(src[a], bytes, ncclChar, 0, use.comm, rk.comm_stream), "ncclSend");
+              if (r == 0)
+                for (size_t q = 0; q < mRanks.size(); q++) check_nccl(ncclRecv((char*)dst[a] + q * bytes, bytes, ncclChar, (int)q, use.comm, rk.comm_stream), "ncclRecv");
+            }
+            check_nccl(ncclGroupEnd(), "ncclGroupEnd");
+          }
+          check_hip(hipEventRecord(rk.exchanged[k], rk.comm_stream), "hipEventRecord");
+        } catch (...) {
+          abort_comms();
+          throw;
+        }
+      });
+    } catch (...) {
+      abort_comms();
+      throw;
+    }
+    mInFlight[k].seeds_mode = seeds_mode;
     mInFlight[k].valid = true;
+    mInFlight[k].aovs = mGatherAOVs;
     mInFlight[k].width = width;
     mInFlight[k].height = height;
     mInFlight[k].seed_count = seed_count;
@@ -290,15 +353,21 @@ class MultiDeviceBDPT : public BDPT {
       if (mInFlight[k].valid) finish(k);
     }
   }
-  const float* device_frame() const { return (const float*)mFrameDev.radiance; }  // RGBA32F W x H on devices[0], valid until the next frame is finished
+  // the assembled frame on devices[0], valid until the next frame is finished: RGBA32F W x H, and the G-buffer
+  const float* device_frame() const { return (const float*)mFrameDev.radiance; }
+  const float* device_albedo() const { return (const float*)mFrameDev.albedo; }
+  const VisibilityInfo* device_visibility() const { return (const VisibilityInfo*)mFrameDev.visibility; }
+  const DepthInfo* device_depth() const { return (const DepthInfo*)mFrameDev.depth; }
+  const float* device_prev_uv() const { return (const float*)mFrameDev.prev_uv; }
 
  private:
   static constexpr size_t kEntryBytes[5] = {16, 16, 8, 16, 8};  // radiance, albedo, VisibilityInfo, DepthInfo, prev-uv
   struct Buffers {  // one set per frame in flight, per rank: packed tiles (what travels) and the G-buffer images sthip_render writes
     void *radiance = nullptr, *albedo = nullptr, *visibility = nullptr, *depth = nullptr, *prev_uv = nullptr;
     void *img_albedo = nullptr, *img_visibility = nullptr, *img_depth = nullptr, *img_prev_uv = nullptr;
+    void* full = nullptr;  // split_seeds: this rank's whole-frame radiance (sums over its seeds), what the reduce adds up
     void* counters = nullptr;
-    std::vector<void*> all() const { return {radiance, albedo, visibility, depth, prev_uv, img_albedo, img_visibility, img_depth, img_prev_uv, counters}; }
+    std::vector<void*> all() const { return {radiance, albedo, visibility, depth, prev_uv, img_albedo, img_visibility, img_depth, img_prev_uv, full, counters}; }
   };
   struct Rank {
     sthip_ctx* ctx = nullptr;
@@ -309,7 +378,7 @@ class MultiDeviceBDPT : public BDPT {
     uint64_t ray_count[2][2] = {{0, 0}, {0, 0}};
   };
   struct InFlight {
-    bool valid = false;
+    bool valid = false, seeds_mode = false, aovs = true;
     uint32_t width = 0, height = 0, seed_count = 1;
     FrameSetup fs;
   };
@@ -318,6 +387,56 @@ class MultiDeviceBDPT : public BDPT {
   }
   static void check_nccl(ncclResult_t e, const char* what) {
     if (e != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(e));
+  }
+  void init_comms() {
+    std::vector<ncclComm_t> comms(mDevices.size());
+    check_nccl(ncclCommInitAll(comms.data(), (int)mDevices.size(), mDevices.data()), "ncclCommInitAll");
+    for (size_t r = 0; r < mDevices.size(); r++) mRanks[r].comm = comms[r];
+    mCommsAborted.store(false);
+  }
+  // Ends every collective in flight and every call a rank is blocked in; callable from any rank thread, once per failure
+  // (the communicators are gone afterwards and made again by the next render()). A rank thread takes its communicator
+  // through CommUse: under the rank's mutex it either sees the abort and throws, or is marked as inside its calls — so a
+  // communicator is never aborted (freed) between a thread's look at it and that thread's next call on it.
+  void abort_comms() {
+    std::lock_guard<std::mutex> lk(mAbortMutex);
+    if (mCommsAborted.exchange(true)) return;
+    for (size_t r = 0; r < mRanks.size(); r++) {
+      std::lock_guard<std::mutex> lr(mCommMutex[r]);
+      if (mRanks[r].comm) {
+        (void)ncclCommAbort(mRanks[r].comm);
+        mRanks[r].comm = nullptr;
+      }
+    }
+  }
+  struct CommUse {
+    MultiDeviceBDPT& d;
+    size_t r;
+    ncclComm_t comm;
+    CommUse(MultiDeviceBDPT& driver, size_t rank) : d(driver), r(rank), comm(nullptr) {
+      std::lock_guard<std::mutex> lk(d.mCommMutex[r]);
+      if (d.mCommsAborted.load() || !d.mRanks[r].comm) throw std::runtime_error("the exchange was aborted (a peer failed in it)");
+      comm = d.mRanks[r].comm;
+    }
+  };
+  // the exchange of frame k has completed on rank 0 — or a communicator reports an asynchronous error (a peer died, a link
+  // went down), in which case everything is aborted and the call throws instead of waiting for an event that never comes
+  void wait_for_exchange(int k) {
+    Rank& r0 = mRanks[0];
+    for (;;) {
+      const hipError_t q = hipEventQuery(r0.exchanged[k]);
+      if (q == hipSuccess) return;
+      if (q != hipErrorNotReady) check_hip(q, "hipEventQuery");
+      for (size_t r = 0; r < mRanks.size(); r++) {
+        ncclResult_t async = ncclSuccess;
+        if (mRanks[r].comm && ncclCommGetAsyncError(mRanks[r].comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+          abort_comms();
+          mInFlight[0].valid = mInFlight[1].valid = false;
+          throw std::runtime_error(std::string("RCCL reports an asynchronous error on rank ") + std::to_string(r) + ": " + ncclGetErrorString(async));
+        }
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
   }
   // frame k has been rendered and exchanged (or will have been when the events say so): assemble it on rank 0, read it back
   void finish(int k) {
@@ -329,29 +448,52 @@ class MultiDeviceBDPT : public BDPT {
     const size_t stride = layout.slot_count(0);
     Rank& r0 = mRanks[0];
     check_hip(hipSetDevice(mDevices[0]), "hipSetDevice");
-    check_hip(hipStreamWaitEvent(r0.stream, r0.exchanged[k], 0), "hipStreamWaitEvent");  // the assembly runs on rank 0's render stream (its context's)
-    const void* src[5] = {mGathered[k].radiance, mGathered[k].albedo, mGathered[k].visibility, mGathered[k].depth, mGathered[k].prev_uv};
-    void* dst[5] = {mFrameDev.radiance, mFrameDev.albedo, mFrameDev.visibility, mFrameDev.depth, mFrameDev.prev_uv};
-    const int parts = mGatherAOVs ? 5 : 1;
-    for (int a = 0; a < parts; a++)
-      if (sthip_assemble_tiles_bytes(r0.ctx, src[a], stride, (uint32_t)mRanks.size(), mTileW, mTileH, width, height, (uint32_t)kEntryBytes[a], dst[a]) != STHIP_OK)
-        throw std::runtime_error(sthip_last_error(r0.ctx));
+    wait_for_exchange(k);
+    // the assembly and the read-back run on rank 0's communication stream, behind the exchange: in pipelined mode rank 0's render
+    // stream already holds the next frame, and nothing here should wait for it
+    (void)sthip_set_stream(r0.ctx, r0.comm_stream);
+    struct Restore {
+      sthip_ctx* c;
+      void* s;
+      ~Restore() { (void)sthip_set_stream(c, s); }
+    } restore{r0.ctx, r0.stream};
+    const bool aovs = f.aovs;
+    if (f.seeds_mode) {
+      check_hip(hipMemcpyAsync(mFrameDev.radiance, mGathered[k].radiance, pixels * 16, hipMemcpyDeviceToDevice, r0.comm_stream), "hipMemcpyAsync");
+      if (sthip_radiance_to_sums(r0.ctx, (float*)mFrameDev.radiance, pixels, 1) != STHIP_OK) throw std::runtime_error(sthip_last_error(r0.ctx));
+      if (aovs) {  // rank 0's render wrote the G-buffer (its comm stream is behind that render: phase 2 made it wait)
+        const Buffers& b0 = r0.buf[k];
+        check_hip(hipMemcpyAsync(mFrameDev.albedo, b0.img_albedo, pixels * 16, hipMemcpyDeviceToDevice, r0.comm_stream), "hipMemcpyAsync");
+        check_hip(hipMemcpyAsync(mFrameDev.visibility, b0.img_visibility, pixels * 8, hipMemcpyDeviceToDevice, r0.comm_stream), "hipMemcpyAsync");
+        check_hip(hipMemcpyAsync(mFrameDev.depth, b0.img_depth, pixels * 16, hipMemcpyDeviceToDevice, r0.comm_stream), "hipMemcpyAsync");
+        check_hip(hipMemcpyAsync(mFrameDev.prev_uv, b0.img_prev_uv, pixels * 8, hipMemcpyDeviceToDevice, r0.comm_stream), "hipMemcpyAsync");
+      }
+    } else {
+      const void* src[5] = {mGathered[k].radiance, mGathered[k].albedo, mGathered[k].visibility, mGathered[k].depth, mGathered[k].prev_uv};
+      void* dst[5] = {mFrameDev.radiance, mFrameDev.albedo, mFrameDev.visibility, mFrameDev.depth, mFrameDev.prev_uv};
+      const int parts = aovs ? 5 : 1;
+      for (int a = 0; a < parts; a++)
+        if (sthip_assemble_tiles_bytes(r0.ctx, src[a], stride, (uint32_t)mRanks.size(), mTileW, mTileH, width, height, (uint32_t)kEntryBytes[a], dst[a]) != STHIP_OK)
+          throw std::runtime_error(sthip_last_error(r0.ctx));
+    }
     Frame fr;
     fr.width = width;
     fr.height = height;
-    fr.mRadiance.assign(4 * pixels, 0.f);
-    check_hip(hipMemcpyAsync(fr.mRadiance.data(), mFrameDev.radiance, pixels * 16, hipMemcpyDeviceToHost, r0.stream), "hipMemcpyAsync");
-    if (mGatherAOVs) {
-      fr.mAlbedo.assign(4 * pixels, 0.f);
-      fr.mVisibility.assign(pixels, VisibilityInfo{});
-      fr.mDepth.assign(pixels, DepthInfo{});
-      fr.mPrevUVs.assign(2 * pixels, 0.f);
-      check_hip(hipMemcpyAsync(fr.mAlbedo.data(), mFrameDev.albedo, pixels * 16, hipMemcpyDeviceToHost, r0.stream), "hipMemcpyAsync");
-      check_hip(hipMemcpyAsync(fr.mVisibility.data(), mFrameDev.visibility, pixels * 8, hipMemcpyDeviceToHost, r0.stream), "hipMemcpyAsync");
-      check_hip(hipMemcpyAsync(fr.mDepth.data(), mFrameDev.depth, pixels * 16, hipMemcpyDeviceToHost, r0.stream), "hipMemcpyAsync");
-      check_hip(hipMemcpyAsync(fr.mPrevUVs.data(), mFrameDev.prev_uv, pixels * 8, hipMemcpyDeviceToHost, r0.stream), "hipMemcpyAsync");
+    if (mReadBack) {
+      fr.mRadiance.assign(4 * pixels, 0.f);
+      check_hip(hipMemcpyAsync(fr.mRadiance.data(), mFrameDev.radiance, pixels * 16, hipMemcpyDeviceToHost, r0.comm_stream), "hipMemcpyAsync");
+      if (aovs) {
+        fr.mAlbedo.assign(4 * pixels, 0.f);
+        fr.mVisibility.assign(pixels, VisibilityInfo{});
+        fr.mDepth.assign(pixels, DepthInfo{});
+        fr.mPrevUVs.assign(2 * pixels, 0.f);
+        check_hip(hipMemcpyAsync(fr.mAlbedo.data(), mFrameDev.albedo, pixels * 16, hipMemcpyDeviceToHost, r0.comm_stream), "hipMemcpyAsync");
+        check_hip(hipMemcpyAsync(fr.mVisibility.data(), mFrameDev.visibility, pixels * 8, hipMemcpyDeviceToHost, r0.comm_stream), "hipMemcpyAsync");
+        check_hip(hipMemcpyAsync(fr.mDepth.data(), mFrameDev.depth, pixels * 16, hipMemcpyDeviceToHost, r0.comm_stream), "hipMemcpyAsync");
+        check_hip(hipMemcpyAsync(fr.mPrevUVs.data(), mFrameDev.prev_uv, pixels * 8, hipMemcpyDeviceToHost, r0.comm_stream), "hipMemcpyAsync");
+      }
     }
-    check_hip(hipStreamSynchronize(r0.stream), "hipStreamSynchronize");
+    check_hip(hipStreamSynchronize(r0.comm_stream), "hipStreamSynchronize");
     for (size_t r = 0; r < mRanks.size(); r++) {  // the ray counts: every rank's render stream has passed its copy when its `rendered` event has
       check_hip(hipSetDevice(mDevices[r]), "hipSetDevice");
       check_hip(hipEventSynchronize(mRanks[r].rendered[k]), "hipEventSynchronize");
@@ -384,6 +526,7 @@ class MultiDeviceBDPT : public BDPT {
           renew(b.img_visibility, px * 8);
           renew(b.img_depth, px * 16);
           renew(b.img_prev_uv, px * 8);
+          renew(b.full, px * 16);
           renew(b.counters, 16);
         }
       }
@@ -413,7 +556,10 @@ class MultiDeviceBDPT : public BDPT {
   Buffers mFrameDev;     // on devices[0]: the assembled W x H images (radiance, albedo, visibility, depth, prev_uv)
   InFlight mInFlight[2];
   uint64_t mSubmitted = 0;
-  bool mGatherAOVs = true, mPipelined = false;
+  bool mGatherAOVs = true, mPipelined = false, mSplitSeeds = false, mReadBack = true;
+  std::atomic<bool> mCommsAborted{false};
+  std::mutex mAbortMutex;
+  std::vector<std::mutex> mCommMutex;  // per rank: its communicator pointer (CommUse / abort_comms)
   size_t mStride = 0, mPixels = 0;
 };
 

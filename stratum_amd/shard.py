@@ -77,3 +77,31 @@ def gather_tiles(packed, gathered, dist, dst=0, async_op=False):
     lst = [gathered[i] for i in range(gathered.shape[0])] if gathered is not None else None
     return dist.gather(packed, gather_list=lst, dst=dst, async_op=async_op)
 
+
+
+# ---- the other split (SURVEY.md 8e "replicas + sum-reduce"): whole frames over disjoint seed ranges ----
+def seed_range(rank, world, seed_count):
+    """(first, count) of the seeds of a call that rank `rank` renders: the first seed_count % world ranks take one more
+    (the rule of MultiDeviceBDPT::split_seeds, stratum_hip_multi.hpp); count may be 0 when there are more ranks than seeds."""
+    base, extra = divmod(seed_count, world)
+    first = base * rank + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def to_sums(image):
+    """(mean over the seeds, their number) -> (sum, number) per pixel: what a sum-reduce can add (sthip_radiance_to_sums).
+    Works on numpy arrays and torch tensors of shape (..., 4), in place."""
+    image[..., :3] *= image[..., 3:4]
+    return image
+
+
+def from_sums(image):
+    """(sum, number) -> (mean, number), pixels without samples stay zero."""
+    n = image[..., 3:4]
+    image[..., :3] /= n.clip(1) if hasattr(n, "clip") and not hasattr(n, "clamp") else n.clamp(min=1)
+    return image
+
+
+def reduce_seed_sums(tensor, dist, dst=0, async_op=False):
+    """One sum-reduce of the accumulation buffer (the rank's whole-frame sums) to `dst`: north_star's collective."""
+    return dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM, async_op=async_op)

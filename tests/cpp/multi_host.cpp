@@ -62,7 +62,11 @@ int main(int argc, char** argv) {
       for (int a = 6; a < argc; a++) {  // instance arguments as --key=value (BDPT.cpp:78-127)
         const std::string kv = argv[a];
         const size_t eq = kv.find('=');
-        if (kv.rfind("--", 0) == 0 && eq != std::string::npos) renderer->set_argument(kv.substr(2, eq - 2), kv.substr(eq + 1));
+        if (kv.rfind("--", 0) != 0 || eq == std::string::npos) continue;
+        if (kv.substr(2, eq - 2) == "splitSeeds")  // the seed-split replica mode: whole frames over disjoint seed ranges + one ncclReduce(sum)
+          renderer->split_seeds(kv.substr(eq + 1) != "0");
+        else
+          renderer->set_argument(kv.substr(2, eq - 2), kv.substr(eq + 1));
       }
       const uint32_t seeds = (uint32_t)atoi(argv[4]);
       app->OnRenderWindow.add_listener(renderer.node(), [&](CommandBuffer& c) { renderer->render(c, L.W, L.H, {{L.view, L.view_xf}}, seeds); });

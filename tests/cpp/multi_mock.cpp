@@ -4,7 +4,10 @@
 // threads through mailboxes and block like the real ones when a peer never posts). What runs unmodified is the driver: its
 // persistent rank threads, the two phases of a frame, the packing and assembly through ShardLayout, the frames in flight of
 // the pipelined mode, the scene update taking the same path on every rank, and — the reason this test exists — what happens
-// when one rank fails: the call must throw before a single collective has been posted, and the driver must stay usable.
+// when one rank fails: the call must throw before a single collective has been posted, and the driver must stay usable; a
+// failure INSIDE the exchange (an ncclSend that errors on one rank, an asynchronous error while rank 0 waits) must abort every
+// communicator so that no peer is left waiting, throw, and leave a driver that renders the next frame. Also the seed-split
+// replica mode (whole frames over disjoint seed ranges + one ncclReduce(sum)) and read_back(false).
 //   multi_mock <scene.bin> <world> [tile_w tile_h]
 #include <unistd.h>
 
@@ -31,6 +34,14 @@ struct Ctx {
 std::atomic<int> fail_render_rank{-1};   // sthip_render fails on this rank
 std::atomic<int> fail_update_rank{-1};   // sthip_scene_update_transforms fails on this rank
 std::atomic<int> nccl_calls{0};          // ncclSend + ncclRecv calls so far
+std::atomic<int> fail_send_rank{-1};     // ncclSend / ncclReduce fails on this rank (phase 2)
+std::atomic<int> async_error_rank{-1};   // ncclCommGetAsyncError reports an error on this rank's communicator
+std::atomic<bool> stall_events{false};   // hipEventQuery says "not ready" (an exchange that never completes)
+std::atomic<int> aborts{0};              // ncclCommAbort calls so far
+std::atomic<int> comm_inits{0};
+std::atomic<int> d2h_copies{0};          // device-to-host copies of more than 16 bytes (frames; the ray counts are 16)
+bool aborted = false;                    // (under mail_mutex) the communicators of this generation were aborted
+int reduce_world = 0;                    // ranks of the communicators (ncclCommInitAll)
 std::mutex mail_mutex;
 std::condition_variable mail_cv;
 std::map<std::pair<int, int>, std::deque<std::vector<char>>> mail;  // (from, to) -> messages in order
@@ -78,7 +89,17 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData*, co
   c->updates++;
   return STHIP_OK;
 }
-int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t, uint32_t, const sthip_frame_desc*, uint32_t seed_begin, uint32_t, const sthip_outputs* o) {
+int sthip_radiance_to_sums(sthip_ctx*, float* image, uint64_t entries, uint32_t back) {
+  for (uint64_t i = 0; i < entries; i++) {
+    float* v = image + 4 * i;
+    for (int c = 0; c < 3; c++) {
+      if (!back) v[c] = v[c] * v[3];
+      else if (v[3] > 0.0f) v[c] = v[c] / v[3];
+    }
+  }
+  return STHIP_OK;
+}
+int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t, uint32_t, const sthip_frame_desc*, uint32_t seed_begin, uint32_t seed_count, const sthip_outputs* o) {
   auto* c = reinterpret_cast<mock::Ctx*>(ctx);
   if (mock::fail_render_rank.load() == (int)c->rank) {
     c->error = "stand-in: this rank fails";
@@ -93,10 +114,23 @@ int sthip_render(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32_t, ui
   if (o->gVisibility) std::memset(o->gVisibility, 0, (size_t)W * H * 8);
   if (o->gDepth) std::memset(o->gDepth, 0, (size_t)W * H * 16);
   if (o->gPrevUVs) std::memset(o->gPrevUVs, 0, (size_t)W * H * 8);
+  const bool image = o->radiance_layout == STHIP_LAYOUT_IMAGE;  // (the whole frame: the seed-split mode; rgb = mean over the call's seeds, a = their number)
   for (uint32_t s = 0; s < n; s++) {
     uint32_t x, y;
     const bool inside = L.slot_pixel(c->rank, s, x, y);
-    for (int k = 0; k < 4; k++) rad[4 * (size_t)s + k] = inside ? mock::radiance_of(x, y, seed_begin, k) : 0.f;
+    if (image) {
+      if (inside) {
+        float* v = rad + 4 * ((size_t)y * W + x);
+        for (int k = 0; k < 3; k++) {
+          float sum = 0.f;
+          for (uint32_t q = 0; q < seed_count; q++) sum += mock::radiance_of(x, y, seed_begin + q, k);
+          v[k] = sum / (float)seed_count;
+        }
+        v[3] = (float)seed_count;
+      }
+    } else {
+      for (int k = 0; k < 4; k++) rad[4 * (size_t)s + k] = inside ? mock::radiance_of(x, y, seed_begin, k) : 0.f;
+    }
     if (!inside) continue;
     owned++;
     const size_t px = (size_t)y * W + x;
@@ -151,10 +185,16 @@ hipError_t hipMemset(void* p, int v, size_t n) {
   std::memset(p, v, n);
   return hipSuccess;
 }
-hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind kind, hipStream_t) {
+  if (kind == hipMemcpyDeviceToHost && n > 16) mock::d2h_copies++;
   std::memcpy(d, s, n);
   return hipSuccess;
 }
+hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+  std::memset(p, v, n);
+  return hipSuccess;
+}
+hipError_t hipEventQuery(hipEvent_t) { return mock::stall_events.load() ? hipErrorNotReady : hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
   *s = reinterpret_cast<hipStream_t>(new int(0));
   return hipSuccess;
@@ -183,6 +223,27 @@ struct MockComm {
 };
 ncclResult_t ncclCommInitAll(ncclComm_t* comms, int n, const int*) {
   for (int r = 0; r < n; r++) comms[r] = reinterpret_cast<ncclComm_t>(new MockComm{r});
+  std::lock_guard<std::mutex> lk(mock::mail_mutex);
+  mock::mail.clear();  // a new generation: what the aborted one left in flight is gone
+  mock::reduce_world = n;
+  mock::aborted = false;
+  mock::comm_inits++;
+  return ncclSuccess;
+}
+// ends what its peers are blocked in (the stand-in keeps the object until the process ends: a peer may still be inside a call on it)
+static std::vector<std::unique_ptr<MockComm>> graveyard;
+ncclResult_t ncclCommAbort(ncclComm_t c) {
+  mock::aborts++;
+  {
+    std::lock_guard<std::mutex> lk(mock::mail_mutex);
+    mock::aborted = true;
+    graveyard.emplace_back(reinterpret_cast<MockComm*>(c));
+  }
+  mock::mail_cv.notify_all();
+  return ncclSuccess;
+}
+ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* e) {
+  *e = mock::async_error_rank.load() == reinterpret_cast<MockComm*>(comm)->rank ? ncclSystemError : ncclSuccess;
   return ncclSuccess;
 }
 ncclResult_t ncclCommDestroy(ncclComm_t c) {
@@ -195,11 +256,43 @@ ncclResult_t ncclGroupEnd() { return ncclSuccess; }
 ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t, int peer, ncclComm_t comm, hipStream_t) {
   mock::nccl_calls++;
   const int me = reinterpret_cast<MockComm*>(comm)->rank;
+  if (mock::fail_send_rank.load() == me) return ncclSystemError;
   {
     std::lock_guard<std::mutex> lk(mock::mail_mutex);
+    if (mock::aborted) return ncclInternalError;
     mock::mail[{me, peer}].emplace_back((const char*)buf, (const char*)buf + count);
   }
   mock::mail_cv.notify_all();
+  return ncclSuccess;
+}
+// sum-reduce of floats to `root`: the others send, the root adds in rank order (a fixed order: the check below repeats it)
+ncclResult_t ncclReduce(const void* send, void* recv, size_t count, ncclDataType_t, ncclRedOp_t, int root, ncclComm_t comm, hipStream_t) {
+  mock::nccl_calls++;
+  const int me = reinterpret_cast<MockComm*>(comm)->rank;
+  if (mock::fail_send_rank.load() == me) return ncclSystemError;
+  if (me != root) {
+    {
+      std::lock_guard<std::mutex> lk(mock::mail_mutex);
+      if (mock::aborted) return ncclInternalError;
+      mock::mail[{me, root}].emplace_back((const char*)send, (const char*)send + 4 * count);
+    }
+    mock::mail_cv.notify_all();
+    return ncclSuccess;
+  }
+  std::vector<float> acc((const float*)send, (const float*)send + count);
+  int world = 0;
+  for (;; world++) {  // (the stand-in learns the world size from who has a mailbox towards the root: every rank > 0 posts one)
+    if (world == me) continue;
+    std::unique_lock<std::mutex> lk(mock::mail_mutex);
+    if (world >= mock::reduce_world) break;
+    auto& q = mock::mail[{world, me}];
+    mock::mail_cv.wait(lk, [&]() { return !q.empty() || mock::aborted; });
+    if (mock::aborted) return ncclInternalError;
+    const float* v = (const float*)q.front().data();
+    for (size_t i = 0; i < count; i++) acc[i] += v[i];
+    q.pop_front();
+  }
+  std::memcpy(recv, acc.data(), 4 * count);
   return ncclSuccess;
 }
 ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t, int peer, ncclComm_t comm, hipStream_t) {
@@ -207,7 +300,8 @@ ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t, int peer, ncclCom
   const int me = reinterpret_cast<MockComm*>(comm)->rank;
   std::unique_lock<std::mutex> lk(mock::mail_mutex);
   auto& q = mock::mail[{peer, me}];
-  mock::mail_cv.wait(lk, [&]() { return !q.empty(); });  // (a peer that never sends: main()'s alarm ends the test)
+  mock::mail_cv.wait(lk, [&]() { return !q.empty() || mock::aborted; });  // (a peer that never sends and nobody aborts: main()'s alarm ends the test)
+  if (mock::aborted) return ncclInternalError;
   if (q.front().size() != count) return ncclInvalidArgument;
   std::memcpy(buf, q.front().data(), count);
   q.pop_front();
@@ -293,6 +387,114 @@ int main(int argc, char** argv) {
     seeds = 1;
     app->run_frame(cb);
     if (check_frame(renderer->prev_result(), L.W, L.H, base + 6, true, "after three seeds")) return 1;
+    // 6. a failure INSIDE the exchange: ncclSend errors on one rank while rank 0 already waits in its receives. The failing
+    // thread aborts every communicator, the call throws (it must not hang: the alarm would end the test), the next call
+    // makes new communicators and renders
+    uint32_t next_seed = base + 7;
+    for (int bad : {world - 1, world > 3 ? 3 : 0}) {
+      const int aborts_before = mock::aborts.load(), inits_before = mock::comm_inits.load();
+      mock::fail_send_rank = bad;
+      bool threw = false;
+      try {
+        app->run_frame(cb);
+      } catch (const std::exception& e) {
+        threw = true;
+      }
+      mock::fail_send_rank = -1;
+      if (!threw) return std::printf("FAIL: a failing ncclSend on rank %d did not surface as an exception\n", bad), 1;
+      if (mock::aborts.load() < aborts_before + world) return std::printf("FAIL: %d of %d communicators were aborted after rank %d failed in the exchange\n", mock::aborts.load() - aborts_before, world, bad), 1;
+      app->run_frame(cb);
+      if (mock::comm_inits.load() != inits_before + 1) return std::printf("FAIL: the communicators were not made again after an abort\n"), 1;
+      // (the failed call consumed no seed: the frame number moves on with completed submissions only)
+      if (check_frame(renderer->prev_result(), L.W, L.H, next_seed++, true, "after a failed exchange")) return 1;
+    }
+    // 7. an asynchronous error while rank 0 waits for an exchange that never completes: finish() polls, aborts, throws
+    {
+      const int aborts_before = mock::aborts.load();
+      mock::stall_events = true;
+      mock::async_error_rank = world - 1;
+      bool threw = false;
+      try {
+        app->run_frame(cb);
+      } catch (const std::exception& e) {
+        threw = std::string(e.what()).find("asynchronous error") != std::string::npos;
+      }
+      mock::stall_events = false;
+      mock::async_error_rank = -1;
+      if (!threw) return std::printf("FAIL: an asynchronous RCCL error did not end the wait for the exchange\n"), 1;
+      if (mock::aborts.load() < aborts_before + world) return std::printf("FAIL: communicators not aborted after an asynchronous error\n"), 1;
+      next_seed++;  // (that frame had been submitted — rendered and its exchange posted — when the wait for it failed: its seed is spent)
+      app->run_frame(cb);
+      if (check_frame(renderer->prev_result(), L.W, L.H, next_seed++, true, "after an asynchronous error")) return 1;
+    }
+    // 8. read_back(false): the frame stays on rank 0's device, no image crosses to the host
+    {
+      renderer->read_back(false);
+      const int copies = mock::d2h_copies.load();
+      app->run_frame(cb);
+      if (mock::d2h_copies.load() != copies) return std::printf("FAIL: read_back(false) still copied %d images to the host\n", mock::d2h_copies.load() - copies), 1;
+      const BDPT::Frame& fr = renderer->prev_result();
+      if (!fr.mRadiance.empty() || fr.mRayCount[0] != 5ull * L.W * L.H) return std::printf("FAIL: read_back(false): host frame / ray counts\n"), 1;
+      const float* dev = renderer->device_frame();  // ("device" memory is host memory here)
+      for (uint32_t y = 0; y < L.H; y += 7)
+        for (uint32_t x = 0; x < L.W; x += 5)
+          for (int k = 0; k < 4; k++)
+            if (dev[4 * ((size_t)y * L.W + x) + k] != mock::radiance_of(x, y, next_seed, k)) return std::printf("FAIL: read_back(false): device frame at %u,%u\n", x, y), 1;
+      const uint32_t* alb = (const uint32_t*)renderer->device_albedo();
+      if (alb[4 * 3 + 1] != mock::aov_word(3, 0, 0, 1)) return std::printf("FAIL: read_back(false): device albedo\n"), 1;
+      next_seed++;
+      renderer->read_back(true);
+    }
+    // 9. the seed-split replica mode: whole frames over disjoint seed ranges, one sum-reduce; more ranks than seeds; pipelined
+    {
+      renderer->split_seeds(true);
+      auto expect = [&](uint32_t first, uint32_t count, const char* what) {
+        const BDPT::Frame& fr = renderer->prev_result();
+        if (fr.width != L.W || fr.mRadiance.size() != 4 * (size_t)L.W * L.H) return std::printf("FAIL (%s): frame size\n", what), 1;
+        for (uint32_t y = 0; y < L.H; y++)
+          for (uint32_t x = 0; x < L.W; x++) {
+            float want[4] = {0, 0, 0, 0};
+            for (int r = 0; r < world; r++) {  // what each rank renders, turns into sums, and the reduce adds in rank order
+              const uint32_t s0 = (count / world) * r + std::min<uint32_t>(r, count % world), s1 = (count / world) * (r + 1) + std::min<uint32_t>(r + 1, count % world);
+              if (s1 == s0) continue;
+              for (int k = 0; k < 3; k++) {
+                float sum = 0.f;
+                for (uint32_t q = s0; q < s1; q++) sum += mock::radiance_of(x, y, first + q, k);
+                want[k] += (sum / (float)(s1 - s0)) * (float)(s1 - s0);
+              }
+              want[3] += (float)(s1 - s0);
+            }
+            for (int k = 0; k < 3; k++) want[k] = want[k] / want[3];
+            for (int k = 0; k < 4; k++)
+              if (fr.mRadiance[4 * ((size_t)y * L.W + x) + k] != want[k]) return std::printf("FAIL (%s): radiance at %u,%u channel %d is %g, expected %g\n", what, x, y, k, fr.mRadiance[4 * ((size_t)y * L.W + x) + k], want[k]), 1;
+            const uint32_t* a = (const uint32_t*)fr.mAlbedo.data();
+            if (a[4 * ((size_t)y * L.W + x) + 2] != mock::aov_word(x, y, 0, 2)) return std::printf("FAIL (%s): albedo\n", what), 1;
+          }
+        if (fr.mRayCount[0] != 5ull * L.W * L.H * std::min<uint32_t>(count, world)) return std::printf("FAIL (%s): ray counts %llu\n", what, (unsigned long long)fr.mRayCount[0]), 1;
+        return 0;
+      };
+      seeds = 2 * (uint32_t)world + 1;  // uneven ranges
+      app->run_frame(cb);
+      if (expect(next_seed, seeds, "seed split, uneven")) return 1;
+      next_seed += seeds;
+      seeds = 1;  // more ranks than seeds: the others add zeros
+      app->run_frame(cb);
+      if (expect(next_seed, 1, "seed split, one seed")) return 1;
+      next_seed += 1;
+      seeds = (uint32_t)world;
+      renderer->pipelined(true);
+      app->run_frame(cb);
+      app->run_frame(cb);
+      if (expect(next_seed, seeds, "seed split, pipelined")) return 1;
+      renderer->flush();
+      if (expect(next_seed + seeds, seeds, "seed split, flushed")) return 1;
+      next_seed += 2 * seeds;
+      renderer->pipelined(false);
+      renderer->split_seeds(false);
+      seeds = 1;
+      app->run_frame(cb);
+      if (check_frame(renderer->prev_result(), L.W, L.H, next_seed++, true, "tiles again")) return 1;
+    }
     std::printf("MULTI MOCK OK world %d frame %ux%u tiles %ux%u collectives %d\n", world, L.W, L.H, tw, th, mock::nccl_calls.load());
     return 0;
   } catch (const std::exception& e) {

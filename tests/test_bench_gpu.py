@@ -39,3 +39,17 @@ def test_two_rank_rehearsal_delivers_the_one_rank_frame(tmp_path):
         s = line["sustained"]
         assert s["seconds"] >= 0.2 and s["steps"] >= 2 and s["value"] > 0
         assert line["value"] > 0 and line["scaling"] == "strong"
+
+
+@pytest.mark.gpu
+def test_two_rank_seed_split_rehearsal(tmp_path):
+    """--shard seeds: every rank the whole frame for its share of the step's seeds, one sum-reduce of the accumulation buffers
+    (SURVEY 8e 'replicas + sum-reduce'): the one-rank frame up to the order of the floating-point sum, the same rays."""
+    one, f1 = _run(tmp_path, 1, extra=["--sustained-seconds", "0"])
+    two, f2 = _run(tmp_path, 2, {"STHIP_BENCH_ONE_DEVICE": "1", "STHIP_BENCH_BACKEND": "gloo"}, extra=["--sustained-seconds", "0", "--shard", "seeds"])
+    assert np.array_equal(f1["radiance"][..., 3], f2["radiance"][..., 3]) and f1["radiance"][..., 3].max() == 2
+    np.testing.assert_allclose(f2["radiance"][..., :3], f1["radiance"][..., :3], rtol=1e-6, atol=1e-7)
+    for k in ("albedo", "visibility", "depth", "prev_uv"):
+        assert np.array_equal(f1[k].view(np.uint32), f2[k].view(np.uint32)), k
+    assert one["config"]["rays_per_step"] == two["config"]["rays_per_step"]
+    assert two["config"]["exchange_bytes_per_step"] == 2 * 256 * 128 * 16 and "seed-split" in two["config"]["parallelism"] and one["sustained"] is None

@@ -244,6 +244,35 @@ def test_cpp_multi_device_driver_under_thread_sanitizer(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cpp_multi_device_driver_seed_split_on_one_gpu(built, tmp_path):
+    """MultiDeviceBDPT::split_seeds with the one GPU of this box: the whole frame rendered for the call's seeds, turned into
+    sums (sthip_radiance_to_sums), reduced with the real ncclReduce(sum) and turned back: the single-device frame up to the
+    rounding of (mean * n) / n; light tracing's splats — refused on a tile shard of more than one rank — go through it."""
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = scenes.cornell_box()
+    W, H, seeds = 192, 96, 3
+    fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+    desc, outp = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    dump_description(desc, sc, fr)
+    for extra, args in (([], {}), (["--bdptFlag=connecttoviews"], {"bdptFlag": ["connecttoviews"]})):
+        out = subprocess.run([_multi_host(built), "render", desc, outp, str(seeds), "0", "--splitSeeds=1"] + extra, capture_output=True, text=True)
+        assert out.returncode == 0 and "RENDER OK world 1" in out.stdout, out.stdout + out.stderr
+        raw = np.fromfile(outp, dtype=np.uint8)
+        rad = raw[: W * H * 16].view(np.float32).reshape(H, W, 4)
+        rays = raw[W * H * 16 : W * H * 16 + 16].view(np.uint64)
+        r = BDPT(device=0, args=args)
+        try:
+            r.update(sc)
+            ref = r.render(fr, 0, seeds)
+        finally:
+            r.close()
+        assert np.array_equal(rad[..., 3], ref["radiance"][..., 3])
+        np.testing.assert_allclose(rad[..., :3], ref["radiance"][..., :3], rtol=3e-7, atol=0)
+        assert np.array_equal(rays, ref["ray_count"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("make", [scenes.cornell_box, shared_mesh_scene])
 def test_cpp_multi_device_driver_on_one_gpu(built, tmp_path, make):
     """MultiDeviceBDPT with the one GPU of this box: its whole path runs (one thread per rank, packed tiles, the RCCL

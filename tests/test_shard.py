@@ -73,6 +73,14 @@ def _worker(rank, world, port, tmp):
     packed[: xy.shape[0]][ok] = full[xy[ok, 1], xy[ok, 0]]
     gathered = torch.zeros((world, stride, 4)) if rank == 0 else None
     shard.gather_tiles(torch.from_numpy(packed), gathered, dist, dst=0)
+    # the seed-split replica mode: every rank the whole frame for its own seeds, one sum-reduce of the accumulation buffer
+    first, count = shard.seed_range(rank, world, 2 * world + 1)
+    part = orc.OracleScene(sc).render(fr, pc, seed_begin=first, seed_count=count, threads=2, aovs=False)["radiance"]
+    sums = torch.from_numpy(shard.to_sums(part.copy()))
+    shard.reduce_seed_sums(sums, dist, dst=0)
+    if rank == 0:
+        np.save(os.path.join(tmp, "seed_split.npy"), shard.from_sums(sums.numpy()))
+        np.save(os.path.join(tmp, "seed_split_ref.npy"), orc.OracleScene(sc).render(fr, pc, seed_begin=0, seed_count=2 * world + 1, threads=2, aovs=False)["radiance"])
     if rank == 0:
         np.save(os.path.join(tmp, "assembled.npy"), t.numpy())
         np.save(os.path.join(tmp, "gathered.npy"), shard.assemble_tiles([g.numpy() for g in gathered], W, H, 16, 8))
@@ -91,3 +99,8 @@ def test_gloo_world2_assembles_the_frame(tmp_path):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     g = np.load(tmp_path / "gathered.npy")
     assert np.array_equal(g.view(np.uint32), b.view(np.uint32))
+    # seed split: the same mean up to the order of a floating-point sum (~1e-7 relative), the sample counts exact
+    s, sref = np.load(tmp_path / "seed_split.npy"), np.load(tmp_path / "seed_split_ref.npy")
+    assert np.array_equal(s[..., 3], sref[..., 3]) and s[..., 3].max() == 5
+    np.testing.assert_allclose(s[..., :3], sref[..., :3], rtol=2e-6, atol=1e-7)
+    assert [shard.seed_range(r, 3, 7) for r in range(3)] == [(0, 3), (3, 2), (5, 2)] and shard.seed_range(2, 3, 1) == (1, 0)
