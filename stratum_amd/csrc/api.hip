@@ -175,6 +175,8 @@ struct sthip_ctx {
   DevBuf<DeviceImage1> images1;  // gImage1s (alpha masks)
   DevBuf<float> image1_texels;
   DevBuf<BvhTriUv> tri_uvs;
+  DevBuf<BvhTriShade> tri_shade;  // beside the leaf triangles: their vertices' normals and uvs (k_fill_tri_shade)
+  DevBuf<uint32_t> hit_leaf;      // per path: the leaf triangle of its hit
   DevBuf<uint32_t> inst_alpha;
   DevBuf<uint8_t> inst_flags;  // per instance: INST_FLAG_* of its (untextured) material, for k_cull_terminal
   std::vector<uint8_t> inst_flags_host;
@@ -280,6 +282,11 @@ static void fill_counter_stats(sthip_ctx* ctx, const unsigned long long* c) {
   ctx->stats.tris_tested_primary = c[CNT_TRIS_PRIMARY];
 }
 
+static uint32_t grid_for_early(const sthip_ctx* ctx, size_t n) {  // (grid_for, for code above its definition)
+  const size_t blocks = (n + STHIP_BLOCK - 1) / STHIP_BLOCK;
+  return (uint32_t)std::max<size_t>(1, std::min(blocks, (size_t)ctx->cu_count * 32));
+}
+
 static int fail(sthip_ctx* ctx, int code, const std::string& msg) {
   ctx->error = msg;
   return code;
@@ -370,6 +377,7 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->ray_o.release();
   ctx->ray_d.release();
   ctx->hit.release();
+  ctx->hit_leaf.release();
   ctx->beta.release();
   ctx->radiance.release();
   ctx->shadow_sum.release();
@@ -393,6 +401,8 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->images1.release();
   ctx->image1_texels.release();
   ctx->tri_uvs.release();
+  ctx->tri_shade.release();
+  ctx->hit_leaf.release();
   ctx->inst_alpha.release();
   ctx->inst_flags.release();
   ctx->qctl.release();
@@ -988,6 +998,23 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     if (!built.nodes.empty()) memcpy(ctx->nodes_host.p + built.dev_nodes, built.nodes.data(), built.nodes.size() * sizeof(BvhNode));
     ctx->nodes_host.n = nodes_total;
   }
+  {  // the shading records beside the leaf triangles (bvh.h: BvhTriShade), from the triangles as they lie in HBM now
+    const size_t units = built.embedded ? nodes_total : tris_total;  // (embedded leaves: a triangle is a unit of the node array; the units that are nodes get a record nobody reads)
+    HIP_TRY(ctx, ctx->tri_shade.ensure(std::max<size_t>(1, units)));
+    if (units && s->vertex_count) {
+      DevBuf<uint8_t> is_tri;  // embedded leaves: which units are triangles
+      if (built.embedded) {
+        std::vector<uint8_t> flags(units, 0);
+        for (size_t u = 0; u < built.unit_tri.size() && u < units; u++) flags[u] = built.unit_tri[u] != 0xFFFFFFFFu;
+        HIP_TRY(ctx, is_tri.ensure(units));
+        HIP_TRY(ctx, hipMemcpy(is_tri.p, flags.data(), units, hipMemcpyHostToDevice));
+      }
+      hipLaunchKernelGGL(k_fill_tri_shade, dim3(grid_for_early(ctx, units)), dim3(STHIP_BLOCK), 0, ctx->stream, reinterpret_cast<const BvhTri*>(ctx->bvh.tris), (uint32_t)units, is_tri.p, ctx->vertices.p, s->vertex_count,
+                         ctx->indices.p, (uint64_t)s->indices_bytes, ctx->tri_shade.p);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (`is_tri` goes out of scope)
+    }
+  }
   {
     const int rc = configure_stack(ctx);
     if (rc != STHIP_OK) return rc;
@@ -1489,6 +1516,7 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   HIP_TRY(ctx, ctx->ray_o.ensure(P));
   HIP_TRY(ctx, ctx->ray_d.ensure(P));
   HIP_TRY(ctx, ctx->hit.ensure(P));
+  HIP_TRY(ctx, ctx->hit_leaf.ensure(P));
   HIP_TRY(ctx, ctx->beta.ensure(P));
   HIP_TRY(ctx, ctx->radiance.ensure(P));
   HIP_TRY(ctx, ctx->shadow_sum.ensure(P));
@@ -1617,9 +1645,12 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   p.scene.volume_words = ctx->volume_words.p;
   p.scene.volumes = ctx->volumes.p;
   p.scene.volume_count = ctx->volume_count;
+  p.scene.leaf_tris = ctx->bvh.tris;
+  p.scene.leaf_shade = reinterpret_cast<const float4*>(ctx->tri_shade.p);
   p.ray_o = ctx->ray_o.p;
   p.ray_d = ctx->ray_d.p;
   p.hit = ctx->hit.p;
+  p.hit_leaf = ctx->hit_leaf.p;
   p.beta = ctx->beta.p;
   p.meta = ctx->meta.p;
   p.radiance = ctx->radiance.p;

@@ -34,9 +34,18 @@ struct BvhTri {
   float v0[3];
   uint32_t id;
   float v1[3];
-  uint32_t pad1;
+  uint32_t src_indices;  // where the triangle came from: byte offset of its index triple in gIndices
   float v2[3];
-  uint32_t pad2;
+  uint32_t src_vertex;   // ... first_vertex of its mesh, bit31 = 32-bit indices (k_fill_tri_shade reads the vertices again through these)
+};
+// Beside every leaf triangle, in the same order: what shading needs of its three vertices apart from the positions BvhTri
+// holds — normal and v of each, the three u (sthip_PackedVertexData: position.xyz u | normal.xyz v). Filled on the device
+// once the tree is resident (api.hip: k_fill_tri_shade), whoever built it.
+struct BvhTriShade {
+  float n0[3], v0;
+  float n1[3], v1;
+  float n2[3], v2;
+  float u[3], pad;
 };
 // The node as it lies in HBM (and in the LDS treetop): 48 bytes = three float4, so a lane fetches it with THREE 16-byte
 // loads. The traversal kernel is bound by the rate at which the vector-memory front end takes divergent lane loads
@@ -139,6 +148,7 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode");
 static_assert(sizeof(BvhNodePacked) == 48, "BvhNodePacked");
 static_assert(sizeof(BvhNodeSlot) == BVH_NODE_BYTES, "BvhNodeSlot");
 static_assert(sizeof(BvhTri) == 48, "BvhTri");
+static_assert(sizeof(BvhTriShade) == 64, "BvhTriShade");
 static_assert(sizeof(WideNode) == 64, "WideNode");
 static_assert(sizeof(Wide8Node) == 80, "Wide8Node");
 static_assert(sizeof(TlasEntry) == 80, "TlasEntry");

@@ -334,6 +334,11 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
   // embedded leaves need every bottom level in one array the host lays out: not with the device builder, not through lbvh_build_gpu
   out.embedded = embed_leaves && builder == BVH_BUILDER_SAH_HOST;
   const uint32_t BLAS_DEPTH_CAP = 22, TLAS_DEPTH_CAP = 18, LBVH_MAX_HEIGHT = 120;
+  // (a leaf triangle remembers where its index triple lies and its mesh's first vertex in 32 and 31 bits: bvh.h: BvhTri)
+  if (s.indices_bytes > 0xFFFFFFFFull || s.vertex_count >= 0x80000000u) {
+    err = "gIndices beyond 4 GiB or more than 2^31 vertices";
+    return false;
+  }
   // ---- validate + classify ----
   std::vector<uint32_t> merged, separate, spheres, volumes;
   // gVolumes: NanoVDB float grids, format 32.x (PNanoVDB.h:761-777,904-916,964-968, FLOAT row of the type constants)
@@ -578,7 +583,8 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
         memcpy(t.v1, s.gVertices[tri[1]].position, 12);
         memcpy(t.v2, s.gVertices[tri[2]].position, 12);
         t.id = (prims[k].second << 16) | (with_instance_bits ? prims[k].first : 0u);
-        t.pad1 = t.pad2 = 0;
+        t.src_indices = in.indices_byte_offset + prims[k].second * 3u * in.stride;
+        t.src_vertex = in.first_vertex | (in.stride == 4u ? 0x80000000u : 0u);
         bounds.grow(t.v0);
         bounds.grow(t.v1);
         bounds.grow(t.v2);
@@ -621,7 +627,8 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       memcpy(t.v1, s.gVertices[tri[1]].position, 12);
       memcpy(t.v2, s.gVertices[tri[2]].position, 12);
       t.id = (pr.second << 16) | (with_instance_bits ? pr.first : 0u);
-      t.pad1 = t.pad2 = 0;
+      t.src_indices = in.indices_byte_offset + pr.second * 3u * in.stride;
+      t.src_vertex = in.first_vertex | (in.stride == 4u ? 0x80000000u : 0u);
       if (any_alpha) {
         BvhTriUv uv;
         for (int v = 0; v < 3; v++) {
@@ -928,11 +935,97 @@ struct WideBuilder {
     return r;
   }
 
+  // Bottom levels: which subtrees become the (up to four) children of a wide node is planned for the whole tree at once — the
+  // cut that minimises the summed surface area of the wide nodes (Ylitie et al. 2017, section 3.1, for width 4): c(n, i) = the
+  // least cost of the subtree of n as at most i children. (The largest-box-first rule below serves the top level and
+  // STHIP_WIDE_GREEDY.)
+  std::vector<float> cost;     // [3 * node + (i - 1)], i = 1..3
+  std::vector<uint8_t> split;  // [4 * node + (j - 1)], j = 2..4: slots of the left child; 0 = a lone child
+  static float area_of(const Box& b) {
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.0f;
+  }
+  float ref_cost(uint32_t r, int i) const { return (r & BVH_LEAF_BIT) ? 0.0f : cost[3 * (size_t)r + (size_t)(i - 1)]; }  // (a leaf costs the same wherever it hangs)
+  void plan(uint32_t root) {
+    if (cost.empty()) {
+      cost.assign(3 * nodes.size(), INFINITY);
+      split.assign(4 * nodes.size(), 0);
+    }
+    std::vector<uint32_t> order, todo(1, root);
+    while (!todo.empty()) {
+      const uint32_t i = todo.back();
+      todo.pop_back();
+      order.push_back(i);
+      for (int c = 0; c < 2; c++) {
+        const uint32_t r = nodes[i].ref[c];
+        if (r != BVH_INVALID_REF && !(r & BVH_LEAF_BIT) && !(c == 1 && r == nodes[i].ref[0])) todo.push_back(r);
+      }
+    }
+    for (size_t k = order.size(); k-- > 0;) {
+      const uint32_t i = order[k];
+      const BvhNode& n = nodes[i];
+      float* c = &cost[3 * (size_t)i];
+      const bool lone = n.ref[1] == n.ref[0] || n.ref[1] == BVH_INVALID_REF || n.ref[0] == BVH_INVALID_REF;
+      if (lone) {
+        const uint32_t r = n.ref[0] == BVH_INVALID_REF ? n.ref[1] : n.ref[0];
+        for (int j = 1; j <= 3; j++) c[j - 1] = ref_cost(r, j);
+        continue;  // (split stays 0)
+      }
+      Box own = child_box(n, 0);
+      own.grow(child_box(n, 1));
+      float dist[5];
+      for (int j = 2; j <= 4; j++) {
+        float best = INFINITY;
+        int bk = 1;
+        for (int kk = 1; kk < j; kk++) {
+          const float v = ref_cost(n.ref[0], std::min(kk, 3)) + ref_cost(n.ref[1], std::min(j - kk, 3));
+          if (v < best) {
+            best = v;
+            bk = kk;
+          }
+        }
+        dist[j] = best;
+        split[4 * (size_t)i + (size_t)(j - 1)] = (uint8_t)bk;
+      }
+      c[0] = dist[4] + area_of(own);
+      c[1] = std::min(dist[2], c[0]);
+      c[2] = std::min(dist[3], c[1]);
+    }
+  }
+  void place(const Box& box, uint32_t r, int slots, WideChild* ch, int& n) const {
+    if (r & BVH_LEAF_BIT) {
+      ch[n++] = WideChild{box, r};
+      return;
+    }
+    slots = std::min(slots, 3);
+    while (slots > 1 && cost[3 * (size_t)r + (size_t)(slots - 1)] == cost[3 * (size_t)r + (size_t)(slots - 2)]) slots--;
+    if (slots == 1) {
+      ch[n++] = WideChild{box, r};
+      return;
+    }
+    distribute(r, slots, ch, n);
+  }
+  void distribute(uint32_t i, int j, WideChild* ch, int& n) const {
+    const BvhNode& nd = nodes[i];
+    const uint8_t k = split[4 * (size_t)i + (size_t)(j - 1)];
+    if (k == 0) {
+      const int c = nd.ref[0] == BVH_INVALID_REF ? 1 : 0;
+      place(child_box(nd, c), nd.ref[c], j, ch, n);
+      return;
+    }
+    place(child_box(nd, 0), nd.ref[0], k, ch, n);
+    place(child_box(nd, 1), nd.ref[1], j - k, ch, n);
+  }
+
   // the wide node that stands for binary inner node `i` (meshes shared by several entries are converted once)
   uint32_t convert(uint32_t i) {
     if (wide_of[i] != 0xFFFFFFFFu) return wide_of[i];
     WideChild ch[4];
     int n = 0;
+    if (!entries && !cost.empty() && std::isfinite(cost[3 * (size_t)i])) {  // a planned bottom level
+      distribute(i, 4, ch, n);
+      return emit(i, ch, n);
+    }
     for (int c = 0; c < 2; c++) {
       if (nodes[i].ref[c] == BVH_INVALID_REF) continue;
       const uint32_t r = resolve(nodes[i].ref[c]);
@@ -959,6 +1052,9 @@ struct WideBuilder {
       ch[pick] = a0;
       ch[n++] = a1;
     }
+    return emit(i, ch, n);
+  }
+  uint32_t emit(uint32_t i, const WideChild* ch, int n) {
     const uint32_t w = (uint32_t)out.size();
     out.push_back(WideNode());
     wide_of[i] = w;
@@ -995,8 +1091,10 @@ void build_wide_bvh(BuiltBvh& out) {
   out.wide_nodes.reserve(out.nodes.size() / 2 + 16);
   WideBuilder wb(out.nodes, out.wide_nodes);
   uint32_t blas_height = 0, top_height = 0;
+  const bool greedy = getenv("STHIP_WIDE_GREEDY") != nullptr;  // (experiments: the largest-box-first collapse everywhere)
   for (TlasEntry& e : out.wide_entries)
     if (e.identity == TLAS_ENTRY_IDENTITY || e.identity == TLAS_ENTRY_TRANSFORMED) {
+      if (!greedy && !(e.root & BVH_LEAF_BIT) && e.root < out.nodes.size() && wb.wide_of[e.root] == 0xFFFFFFFFu) wb.plan(e.root);
       e.root = wb.convert(e.root);
       blas_height = std::max(blas_height, wb.height_of[e.root]);
     }

@@ -60,6 +60,7 @@ struct FrameParams {
   float4* ray_o;       // xyz origin, w = bsdf_pdf
   float4* ray_d;       // xyz direction, w = eta_scale
   float4* hit;         // t, b1, b2, bits(instance_primitive_index)
+  uint32_t* hit_leaf;  // the hit triangle's index in the leaf-triangle array (RayHit::leaf): where k_shade reads its vertices
   float4* beta;        // xyz beta, w = bits(rng counter)
   uint32_t* meta;      // path_length | diffuse_vertices << 8
   float4* radiance;    // gRadiance[px].rgb of the seed in flight
@@ -339,6 +340,7 @@ DEV void finish_ray(const FrameParams& p, float4* target, uint32_t slot, bool sh
     p.shadow_hit[slot] = make_float4(hit.t, hit.b1, hit.b2, __uint_as_float(hit.ip));
   } else if (!any) {
     p.hit[slot] = make_float4(hit.t, hit.b1, hit.b2, __uint_as_float(hit.ip));
+    p.hit_leaf[slot] = hit.leaf;
   } else if (hit.ip == 0xFFFFFFFFu) {  // unoccluded
     if (slot & 0x80000000u) {
       // a light-path vertex seen by the camera: accumulate_light_contribution, path.hlsli:47-60 — quantised
@@ -591,6 +593,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, PRIMARY_BLOCKS) k_trace_primary(F
     hit.t = __builtin_inff();
     hit.b1 = hit.b2 = 0.0f;
     hit.ip = 0xFFFFFFFFu;
+    hit.leaf = 0xFFFFFFFFu;
     if (!__any(live)) {
       if (slot < p.path_count) p.hit[slot] = make_float4(hit.t, 0, 0, __uint_as_float(hit.ip));
       continue;
@@ -724,10 +727,14 @@ __global__ void __launch_bounds__(STHIP_BLOCK, PRIMARY_BLOCKS) k_trace_primary(F
         hit.b1 = closer ? b1 : hit.b1;
         hit.b2 = closer ? b2 : hit.b2;
         hit.ip = closer ? ip : hit.ip;
+        hit.leaf = closer ? first + i : hit.leaf;
       }
       ref = top ? stack[--top] : TRAV_DONE;
     }
-    if (slot < p.path_count) p.hit[slot] = make_float4(hit.t, hit.b1, hit.b2, __uint_as_float(hit.ip));
+    if (slot < p.path_count) {
+      p.hit[slot] = make_float4(hit.t, hit.b1, hit.b2, __uint_as_float(hit.ip));
+      p.hit_leaf[slot] = hit.leaf;
+    }
   }
   if (COUNT) {
     wave_add(&p.counters[CNT_NODES], cnt.nodes);
@@ -1017,6 +1024,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
     uint32_t tx, ty, path_index;
     light_thread(p, slot - seed_index * p.light_threads, tx, ty, path_index);
     const float4 ro = p.ray_o[slot], rd = p.ray_d[slot], hh = p.hit[slot], bb = p.beta[slot], bd = p.bdpt[slot];
+    const uint32_t hit_leaf = p.hit_leaf[slot];
     const f3 origin = xyz(ro), direction = xyz(rd);
     float bsdf_pdf = ro.w, eta_scale = rd.w;
     f3 beta = xyz(bb);
@@ -1037,7 +1045,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
       if (all_le0(beta)) break;  // trace(), path.hlsli:1009-1010
       path_length++;
       if (ip == 0xFFFFFFFFu) break;  // light paths that leave the scene end (no environment with light tracing)
-      const uint32_t inst_index = ip & 0xFFFFu, prim = ip >> 16;
+      const uint32_t inst_index = ip & 0xFFFFu;
       const Inst in = load_inst(p.scene, inst_index);
       ShadingData sd;
       if (EXT && in.type() == STHIP_INSTANCE_TYPE_SPHERE) {
@@ -1045,7 +1053,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
         const float im[12] = {inv.r0.x, inv.r0.y, inv.r0.z, inv.r0.w, inv.r1.x, inv.r1.y, inv.r1.z, inv.r1.w, inv.r2.x, inv.r2.y, inv.r2.z, inv.r2.w};
         make_sphere_shading_data(p.scene, sd, inst_index, in, obj_point(im, origin) + obj_vector(im, direction) * hh.x);
       } else {
-        make_triangle_shading_data(p.scene, sd, inst_index, in, prim, hh.y, hh.z, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
+        make_hit_shading_data(p.scene, sd, inst_index, hit_leaf, hh.y, hh.z, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
       }
       const f3 gn = sd.geometry_normal();
       const float dist2 = len_sqr(sd.position - origin);
@@ -1268,6 +1276,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
     uint32_t px, py;
     slot_to_pixel(p, slot, px, py);
     const float4 ro = p.ray_o[slot], rd = p.ray_d[slot], hh = p.hit[slot], bb = p.beta[slot];
+    const uint32_t hit_leaf = p.hit_leaf[slot];  // (the slots of misses hold stale values: only read behind `ip != miss`)
     const f3 seg_origin = xyz(ro), direction = xyz(rd);  // the ray k_trace traced
     f3 origin = seg_origin;                              // the previous vertex (differs from seg_origin only with MEDIA)
     float bsdf_pdf = ro.w;
@@ -1541,7 +1550,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
         }
         break;
       }
-      const uint32_t inst_index = ip & 0xFFFFu, prim = ip >> 16;
+      const uint32_t inst_index = ip & 0xFFFFu;
       const Inst in = load_inst(p.scene, inst_index);
       ShadingData sd;
       float shape_pdf;
@@ -1562,7 +1571,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
           shape_pdf_area_measure = false;
         }
       } else {
-        make_triangle_shading_data(p.scene, sd, inst_index, in, prim, hh.y, hh.z, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
+        make_hit_shading_data(p.scene, sd, inst_index, hit_leaf, hh.y, hh.z, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
         shape_pdf = 1 / (sd.shape_area * (float)in.prim_count());  // intersection.hlsli:172
       }
       const f3 gn = sd.geometry_normal();
@@ -2596,6 +2605,42 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const uint32_t* 
 }
 // The other direction (sthip_pack_tiles): a W x H image on one rank -> that rank's tiles in slot order (slots outside the
 // image: zero). What the ranks exchange of the G-buffer outputs, which sthip_render writes as images.
+// What shading needs of a leaf triangle's vertices apart from their positions (bvh.h: BvhTriShade), written once per scene
+// upload beside the leaf triangles as they lie in HBM: the triangle says where its index triple is (BvhTri::src_indices /
+// src_vertex), the vertices are read again — so the record holds the floats shading would have gathered (shading_data.hlsli:2-6)
+__global__ void __launch_bounds__(STHIP_BLOCK) k_fill_tri_shade(const BvhTri* tris, uint32_t n, const uint8_t* is_tri, const sthip_PackedVertexData* vertices, uint32_t vertex_count, const uint8_t* indices,
+                                                                uint64_t indices_bytes, BvhTriShade* out) {
+  for (uint32_t i = blockIdx.x * STHIP_BLOCK + threadIdx.x; i < n; i += gridDim.x * STHIP_BLOCK) {
+    BvhTriShade r;
+    memset(&r, 0, sizeof(r));
+    if (!is_tri || is_tri[i]) {
+      const BvhTri t = tris[i];
+      const uint32_t stride = (t.src_vertex >> 31) ? 4u : 2u, first = t.src_vertex & 0x7FFFFFFFu;
+      uint32_t idx[3] = {0, 0, 0};
+      if ((uint64_t)t.src_indices + 3u * stride <= indices_bytes)
+        for (int k = 0; k < 3; k++) {  // byte loads: an index buffer's byte offset need not be aligned to its stride
+          const uint8_t* q = indices + (size_t)t.src_indices + (size_t)k * stride;
+          idx[k] = stride == 2u ? ((uint32_t)q[0] | (uint32_t)q[1] << 8) : ((uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24);
+          idx[k] += first;
+          if (idx[k] >= vertex_count) idx[k] = 0;  // (the builders have refused such scenes already)
+        }
+      const sthip_PackedVertexData a = vertices[idx[0]], b = vertices[idx[1]], c = vertices[idx[2]];
+      for (int k = 0; k < 3; k++) {
+        r.n0[k] = a.normal[k];
+        r.n1[k] = b.normal[k];
+        r.n2[k] = c.normal[k];
+      }
+      r.v0 = a.v;
+      r.v1 = b.v;
+      r.v2 = c.v;
+      r.u[0] = a.u;
+      r.u[1] = b.u;
+      r.u[2] = c.u;
+    }
+    out[i] = r;
+  }
+}
+
 // The seed-split replica mode (sthip.h: sthip_radiance_to_sums): a call's output is (mean over its seeds, their number); what a
 // sum-reduce over replicas can add up is (sum over its seeds, their number). Back: mean = sum / number, correctly rounded.
 __global__ void __launch_bounds__(STHIP_BLOCK) k_radiance_sums(float4* image, size_t n, uint32_t to_sums) {

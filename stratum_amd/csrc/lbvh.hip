@@ -232,7 +232,8 @@ __global__ void __launch_bounds__(LB_BLOCK) k_lbvh_fetch(const MeshPiece* pieces
       t.v2[a] = vertices[idx[2]].position[a];
     }
     t.id = (prim << 16) | pc.id_bits;
-    t.pad1 = t.pad2 = 0;
+    t.src_indices = pc.indices_byte_offset + prim * 3u * pc.stride;
+    t.src_vertex = pc.first_vertex | (pc.stride == 4u ? 0x80000000u : 0u);
     tris[i] = t;
     LBox b;
     for (int a = 0; a < 3; a++) {

@@ -27,6 +27,11 @@ struct DeviceScene {
   const uint32_t* volume_words;  // ByteAddressBuffer gVolumes[]: the NanoVDB grids back to back
   const DeviceVolume* volumes;   // their parsed headers (media.h)
   uint32_t volume_count;
+  // the leaf triangles of the acceleration structure (bvh.h: BvhTri, three float4: the positions) and, in the same order, what
+  // else a hit needs of its three vertices (bvh.h: BvhTriShade, four float4: normals and uvs): a hit carries its leaf index
+  // (RayHit::leaf), so k_shade reads both at once instead of walking hit -> instance -> indices -> vertices
+  const float4* leaf_tris;
+  const float4* leaf_shade;
 };
 
 #define STHIP_MAX_MIPS 16
@@ -187,6 +192,10 @@ DEV Frame3 make_frame(const ShadingData& sd) {
   return f;
 }
 
+// The ShadingData of a point on a triangle from its three vertices (positions, normals, uvs) — shading_data.hlsli:2-73
+DEV void triangle_shading_data(const Xf& xf, ShadingData& r, f3 p0, f3 p1, f3 p2, f3 n0, f3 n1, f3 n2, float u0, float v0, float u1, float v1, float u2, float v2, float b1, float b2, bool flip_uvs);
+
+// ... of triangle `prim` of an instance, through the scene arrays (instance -> indices -> vertices): light sampling
 DEV void make_triangle_shading_data(const DeviceScene& sc, ShadingData& r, uint32_t inst_index, const Inst& in, uint32_t prim, float b1, float b2, bool flip_uvs = false) {
   const Xf xf = load_xf(sc.xf, inst_index);
   uint32_t i0, i1, i2;
@@ -195,9 +204,19 @@ DEV void make_triangle_shading_data(const DeviceScene& sc, ShadingData& r, uint3
   const float4* q1 = reinterpret_cast<const float4*>(sc.vertices + i1);
   const float4* q2 = reinterpret_cast<const float4*>(sc.vertices + i2);
   const float4 a0 = q0[0], a1 = q0[1], c0 = q1[0], c1 = q1[1], e0 = q2[0], e1 = q2[1];
-  const f3 p0 = xyz(a0), p1 = xyz(c0), p2 = xyz(e0);
-  const f3 n0 = xyz(a1), n1 = xyz(c1), n2 = xyz(e1);
-  const float u0 = a0.w, v0 = a1.w, u1 = c0.w, v1 = c1.w, u2 = e0.w, v2 = e1.w;
+  triangle_shading_data(xf, r, xyz(a0), xyz(c0), xyz(e0), xyz(a1), xyz(c1), xyz(e1), a0.w, a1.w, c0.w, c1.w, e0.w, e1.w, b1, b2, flip_uvs);
+}
+// ... of a HIT: the leaf triangle the traversal found (its positions are the vertices' own, object space) and the record
+// beside it (k_fill_tri_shade: the same vertices' normals and uvs) — the same twenty-four floats, two dependent loads earlier
+DEV void make_hit_shading_data(const DeviceScene& sc, ShadingData& r, uint32_t inst_index, uint32_t leaf, float b1, float b2, bool flip_uvs = false) {
+  const Xf xf = load_xf(sc.xf, inst_index);
+  const float4* t = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.leaf_tris) + (size_t)leaf * 48u);
+  const float4* h = sc.leaf_shade + (size_t)leaf * 4u;
+  const float4 a0 = t[0], c0 = t[1], e0 = t[2];
+  const float4 a1 = h[0], c1 = h[1], e1 = h[2], uu = h[3];
+  triangle_shading_data(xf, r, xyz(a0), xyz(c0), xyz(e0), xyz(a1), xyz(c1), xyz(e1), uu.x, a1.w, uu.y, c1.w, uu.z, e1.w, b1, b2, flip_uvs);
+}
+DEV void triangle_shading_data(const Xf& xf, ShadingData& r, f3 p0, f3 p1, f3 p2, f3 n0, f3 n1, f3 n2, float u0, float v0, float u1, float v1, float u2, float v2, float b1, float b2, bool flip_uvs) {
   // :64-73
   const f3 v1v0 = p1 - p0, v2v0 = p2 - p0;
   const f3 local_position = p0 + v1v0 * b1 + v2v0 * b2;

@@ -95,7 +95,8 @@ DEV uint32_t packed_ref(float4 q) {
 
 struct RayHit {
   float t, b1, b2;
-  uint32_t ip;  // instance | primitive << 16; 0xFFFFFFFF = miss
+  uint32_t ip;    // instance | primitive << 16; 0xFFFFFFFF = miss
+  uint32_t leaf;  // index of the hit triangle in the leaf-triangle array (k_shade finds its vertices there: BvhTri / BvhTriShade); unset for a sphere / volume / miss
 };
 
 // Diagnostics of the COUNT instantiations. *_slots count 64 per wave-level iteration (added by the first active
@@ -291,6 +292,7 @@ struct Traversal {
     hit.t = t1;
     hit.b1 = hit.b2 = 0.0f;
     hit.ip = 0xFFFFFFFFu;
+    hit.leaf = 0xFFFFFFFFu;
     stack[0] = TRAV_DONE;
     top = STRIDE;
     if (BOUNDED) stack[limit] = TRAV_CANARY;
@@ -622,6 +624,7 @@ struct Traversal {
     hit.b1 = closer ? b1 : hit.b1;
     hit.b2 = closer ? b2 : hit.b2;
     hit.ip = closer ? ip : hit.ip;
+    hit.leaf = closer ? index : hit.leaf;
     return candidate & any_lane;
   }
 
@@ -713,6 +716,7 @@ struct Traversal8 {
     hit.t = t1;
     hit.b1 = hit.b2 = 0.0f;
     hit.ip = 0xFFFFFFFFu;
+    hit.leaf = 0xFFFFFFFFu;
     uint2* st = column(stack);
     st[0] = make_uint2(W8_DONE, 0u);
     top = STRIDE;
@@ -859,6 +863,7 @@ struct Traversal8 {
     hit.b1 = closer ? b1 : hit.b1;
     hit.b2 = closer ? b2 : hit.b2;
     hit.ip = closer ? ip : hit.ip;
+    hit.leaf = closer ? index : hit.leaf;
     return candidate & any;
   }
   // a sphere or volume entry's verdict folded into the hit record; true: an occlusion lane found its hit
