@@ -1,8 +1,14 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/pmc_l1.sh <tag>
-# The vector-memory front end of the kernels (texture addresser TA, L1 TCP, data return TD: its counters hang the profiler on this pool and are left out), one small --pmc pass per counter group of
+# The vector-memory front end of the kernels (texture addresser TA, L1 TCP), one small --pmc pass per counter group of
 # bench.py --steps 2 (no tracing domains mixed in; a single rank): is k_trace held by address processing / tag lookups rather than
 # by VALU issue or HBM?  Summaries: gpurun_out/pmc_<tag>_l1_<n>.txt
+# The data-return block (TD) is not in the list. Round 3's seventh pass asked for a group of TD counters; what happened (its log,
+# gpurun_out/pmc_r03_l1_7.log) was not a GPU hang: rocprofiler refused the group at the first HIP call of the profiled process —
+# "rocprofiler_create_counter_config ... error code 38: Request exceeds the capabilities of the hardware to collect" (more
+# counters of one block than the block has counter registers) — logged it as fatal, the process got SIGABRT 1.5 s after its
+# start, and rocprofv3's signal handler ("finalizing after signal 6...") never returned: the tool stalled on the host, no kernel
+# had been launched. A TD pass therefore takes ONE counter per pass (append e.g. "TD_TD_BUSY_sum" as a group of its own).
 tag=$1
 export TMPDIR=/tmp
 n=0
