@@ -305,11 +305,15 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s);
  * many triangles keep their PLOC shape under a host-built SAH top; 0 = plain PLOC);
  * "wide_bvh" (the persistent trace kernel walks the tree collapsed into 4-wide nodes of 64 bytes with 8-bit child planes:
  * 1 = always (default) — host-built trees are collapsed on the host, the GPU builder's trees and the tree of a
- * transforms-only update on the device; 0 = never; 2 = only when the binary nodes exceed 4 MiB, one XCD's L2; not with
- * "treetop" or "embed_leaves"), "hashgrid_serial" (0/1: build the reservoir-reuse hash grids with the one-thread serial probe
+ * transforms-only update on the device; 0 = never; 2 = only when the binary nodes exceed 4 MiB, one XCD's L2; 3 = the 8-wide
+ * compressed form (80-byte nodes whose children are addressed by a base and a mask, 64-bit group stack) for host-built
+ * trees, the 4-wide form for the others; not with "treetop" or "embed_leaves"), "tri_min_lanes" (1..64, default 1: the
+ * 8-wide walk's leaf phase goes on while at least this many lanes hold a triangle), "hashgrid_serial" (0/1: build the reservoir-reuse hash grids with the one-thread serial probe
  * sequence instead of the parallel device build: the same grids, for tests), "cull_terminal" (default 1: in a round where the
  * path or diffuse budget can end, only the paths that still have something to do reach the shading kernel), "answer_last_rays"
- * (default 1: a path's last ray is traced only if it can reach the bounds of an emissive instance; sthip_stats::rays_answered),
+ * (default 1: a path's last ray is traced only if it can reach the bounds of an emissive instance; sthip_stats::rays_answered;
+ * identical results for rays that start within a few scene sizes of the scene — as every path ray does — which is also what
+ * the hit contract itself needs),
  * "treetop" (default 0), "embed_leaves" (default 0), "lds_materials" (default 1), "lds_stack_levels" (4..150: LDS levels of the traversal stack; a higher
  * tree runs the bounded kernels, default: bounded at 32 levels beyond a height of 40): layout / scheduling options that
  * never change results, read at the next sthip_scene_upload / sthip_scene_update_transforms */

@@ -751,10 +751,16 @@ __global__ void __launch_bounds__(STHIP_BLOCK, PRIMARY_BLOCKS) k_trace_primary(F
 // (next_vertex, path.hlsli:955-966 in front of :975; eval_emission :847-894), so when k_shade sends a path into its last
 // vertex the ray matters only if its closest hit lies on an emissive triangle — and it cannot if the ray misses the bounds
 // of every emissive instance. Such a ray is answered on the spot: counted as the trace_ray call it stands for, never
-// queued, and the path ends with what it has. The test is the traversal's own box test (setup_space's padded slab
-// arithmetic, in the space the instance's triangles are tested in) on a box that holds all triangles of the instance, i.e.
-// exactly what the walk itself asks of every ancestor of a triangle it finds: a ray whose closest hit the contract puts on
-// an emitter passes it. Frames and ray counts are those of the unfiltered pipeline bit for bit ("answer_last_rays" = 0).
+// queued, and the path ends with what it has. The test is the traversal's slab ARITHMETIC (setup_space's padded form, in the
+// space the instance's triangles are tested in) on the box of the instance's vertices widened by 2^-15 of their magnitude.
+// That box is not one of the walk's: the tree's ancestors of a triangle are looser (outward-rounded planes, 8-bit grids,
+// the top level's boxes), so the filter asks MORE of a ray than the walk does. It drops nothing the walk would find as long
+// as the triangle test only accepts points the padded box holds: the test's own tolerance is ~3e-7 x distance, the padding
+// 4e-6 x (distance to the scene + its radius) + 3e-7 |origin| — true while the ray's origin lies within a few scene sizes of
+// the scene, the same precondition under which any tree finds the contract's hits at all (tests/test_oracle.py pins the far-origin hole of the
+// contract; paths start on surfaces of the scene, so they meet it). Under it frames and ray counts are those of the
+// unfiltered pipeline bit for bit ("answer_last_rays" = 0): tested on degenerate / sliver / tiny emitters and on scenes at
+// large coordinates (tests/test_gpu_parity.py), and by tools/stress_last_ray_filter.py at 50 M rays per scene.
 // ---------------------------------------------------------------------------------------------
 DEV bool aims_at_emitter(const FrameParams& p, f3 o, f3 d) {
   // the table and the transforms are read at wave-uniform addresses (scalar loads); no early exit: every lane tests every box

@@ -1777,3 +1777,54 @@ def test_render_halves_its_batch_when_the_device_is_nearly_full():
     assert np.array_equal(ref["radiance"].view(np.uint32), again["radiance"].view(np.uint32))
     assert np.array_equal(ref["ray_count"], got["ray_count"])
     assert small["radiance"].shape == (1080, 1920, 4)
+
+
+def test_last_ray_filter_on_ill_conditioned_emitters():
+    """answer_last_rays against the plain walk where the filter's box test is least comfortable: emitters with
+    zero-area and sliver triangles (a box that is a segment / a point in one axis), a tiny scaled emitter instance (grazing
+    rays), and the whole scene at large coordinates (every instance and the camera 4096 units away: the padding terms of the
+    slab tests are then dominated by |origin|). The filter holds as long as the origin is within a few scene sizes of the
+    scene (the precondition of the hit contract itself): frames and ray counts are identical with it on and off."""
+    from stratum_amd.bdpt import BDPT
+    from stratum_amd.scene import rotate_y, scale, translate
+
+    def degenerate():
+        sc0, cam = scenes.cornell_box()
+        b = sc0.builder
+        glow = b.add_emitter((5.0, 4.0, 3.0))
+        pos = np.array([(-0.3, 0.0, -0.3), (0.3, 0.0, -0.3), (0.3, 0.0, 0.3), (-0.3, 0.0, 0.3),   # a quad ...
+                        (0.0, 0.0, 0.0), (0.1, 0.0, 0.0), (0.2, 0.0, 0.0),                           # ... a zero-area triangle (three points on a line) ...
+                        (0.5, 0.0, 0.5), (0.5, 0.0, 0.5), (0.5, 0.0, 0.5),                           # ... a point ...
+                        (-0.5, 0.0, 0.4), (0.5, 0.0, 0.4), (0.5, 0.0, 0.400001)], np.float32)         # ... and a sliver
+        nrm = np.tile(np.array([(0, -1, 0)], np.float32), (pos.shape[0], 1))
+        uv = np.zeros((pos.shape[0], 2), np.float32)
+        tri = np.array([(0, 2, 1), (0, 3, 2), (4, 5, 6), (7, 8, 9), (10, 11, 12)], np.uint32)
+        mesh = b.add_mesh(pos, nrm, uv, tri)
+        b.add_instance(mesh, glow, translate((0.1, 0.55, -0.2)) @ rotate_y(0.4))
+        b.add_instance(mesh, glow, translate((-0.4, -0.3, 0.3)) @ rotate_y(1.9) @ scale((0.004, 1.0, 0.004)))  # 2 mm across
+        return b.build(), cam
+
+    def far_away():
+        sc, cam = degenerate()
+        T = np.array((4096.0, -2048.0, 1024.0))
+        for i in range(sc.instances.shape[0]):
+            m = np.vstack([sc.transforms["m"][i], [0, 0, 0, 1]]).astype(np.float64)
+            sc.set_instance_transform(i, translate(tuple(T)) @ m)
+        return sc, dict(cam, eye=tuple(np.array(cam["eye"]) + T), target=tuple(np.array(cam["target"]) + T))
+
+    for make, args in ((degenerate, {}), (degenerate, {"maxDiffuseVertices": 3, "maxPathVertices": 5}), (far_away, {})):
+        sc, cam = make()
+        frame = camera.Frame(160, 120, cam["fovy"], cam["eye"], cam["target"])
+        out = {}
+        for opt in (1, 0):
+            r = BDPT(device=0, args=args)
+            try:
+                r.set_option("answer_last_rays", opt)
+                r.update(sc)
+                out[opt] = r.render(frame, 0, 6, aovs=False)
+                out[opt]["answered"] = r.stats()["rays_answered"]
+            finally:
+                r.close()
+        assert out[1]["answered"] > 0 and out[0]["answered"] == 0, make.__name__
+        assert np.array_equal(out[0]["radiance"].view(np.uint32), out[1]["radiance"].view(np.uint32)), (make.__name__, args)
+        assert np.array_equal(out[0]["ray_count"], out[1]["ray_count"]), (make.__name__, args)
