@@ -145,8 +145,10 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* scene);
  * rebuilt): new gInstanceTransforms / gInstanceInverseTransforms / gInstanceMotionTransforms (may be NULL: identity) for
  * the instance_count instances of the last sthip_scene_upload. The bottom levels stay in HBM, the top level is rebuilt
  * over the new world boxes. Instances whose transform was the identity at upload are part of one merged world-space
- * mesh and must stay at the identity: if one of them moved the call returns STHIP_ERR_UNSUPPORTED and changes nothing —
- * upload the scene again. */
+ * mesh: when one of THEM moves the resident tree cannot follow and the call builds the scene again, from the copy of the
+ * arrays the context keeps since the upload ("keep_scene" = 1, the default) and the new transforms, with the configured
+ * builder ("bvh_builder" = 1: ~10 ms per million triangles on the device) — sthip_stats::full_rebuilds counts these.
+ * With "keep_scene" = 0 nothing is kept and such a call returns STHIP_ERR_UNSUPPORTED and changes nothing. */
 int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* gInstanceTransforms, const sthip_TransformData* gInstanceInverseTransforms,
                                   const sthip_TransformData* gInstanceMotionTransforms, uint32_t instance_count);
 
@@ -280,7 +282,7 @@ typedef struct sthip_stats {
   uint32_t seeds_in_flight;
   uint64_t max_paths_in_flight;
   uint32_t batch_halvings;
-  uint32_t reserved0;
+  uint32_t full_rebuilds; /* sthip_scene_update_transforms calls that had to build the scene again (an instance of the merged mesh moved) */
 } sthip_stats;
 int sthip_get_stats(sthip_ctx* ctx, sthip_stats* out);
 
@@ -314,7 +316,7 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s);
  * (default 1: a path's last ray is traced only if it can reach the bounds of an emissive instance; sthip_stats::rays_answered;
  * identical results for rays that start within a few scene sizes of the scene — as every path ray does — which is also what
  * the hit contract itself needs),
- * "treetop" (default 0), "embed_leaves" (default 0), "lds_materials" (default 1), "lds_stack_levels" (4..150: LDS levels of the traversal stack; a higher
+ * "keep_scene" (default 1: a host copy of the uploaded arrays, see sthip_scene_update_transforms), "treetop" (default 0), "embed_leaves" (default 0), "lds_materials" (default 1), "lds_stack_levels" (4..150: LDS levels of the traversal stack; a higher
  * tree runs the bounded kernels, default: bounded at 32 levels beyond a height of 40): layout / scheduling options that
  * never change results, read at the next sthip_scene_upload / sthip_scene_update_transforms */
 int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value);

@@ -81,6 +81,77 @@ struct PinnedNodes {
 };
 }  // namespace
 
+// The scene as it was uploaded, kept on the host ("keep_scene" = 1, the default): what a change that the resident tree cannot
+// follow — an instance of the merged world-space mesh that moves — is rebuilt from, inside sthip_scene_update_transforms
+// (the reference rebuilds whatever is dirty, Scene.cpp:345,435-459,614-629: it has the scene graph to rebuild from).
+struct KeptScene {
+  std::vector<sthip_PackedVertexData> vertices;
+  std::vector<uint8_t> indices, materials;
+  std::vector<sthip_InstanceData> instances;
+  std::vector<sthip_TransformData> xf, inv, motion;
+  std::vector<uint32_t> lights;
+  std::vector<std::vector<float>> image_pixels, image1_pixels;
+  std::vector<sthip_image_desc> images, images1;
+  std::vector<float> distributions;
+  std::vector<std::vector<uint8_t>> volume_bytes;
+  std::vector<sthip_volume_desc> volumes;
+  bool valid = false;
+  void keep(const sthip_scene_desc& s) {
+    vertices.assign(s.gVertices, s.gVertices + (s.gVertices ? s.vertex_count : 0));
+    indices.assign((const uint8_t*)s.gIndices, (const uint8_t*)s.gIndices + (s.gIndices ? s.indices_bytes : 0));
+    materials.assign((const uint8_t*)s.gMaterialData, (const uint8_t*)s.gMaterialData + (s.gMaterialData ? s.material_bytes : 0));
+    instances.assign(s.gInstances, s.gInstances + s.instance_count);
+    xf.assign(s.gInstanceTransforms, s.gInstanceTransforms + s.instance_count);
+    inv.assign(s.gInstanceInverseTransforms, s.gInstanceInverseTransforms + s.instance_count);
+    motion.clear();
+    if (s.gInstanceMotionTransforms) motion.assign(s.gInstanceMotionTransforms, s.gInstanceMotionTransforms + s.instance_count);
+    lights.assign(s.gLightInstances, s.gLightInstances + (s.gLightInstances ? s.light_count : 0));
+    auto take = [](const sthip_image_desc* in, uint32_t n, size_t channels, std::vector<std::vector<float>>& px, std::vector<sthip_image_desc>& d) {
+      px.assign(n, {});
+      d.assign(n, sthip_image_desc{});
+      for (uint32_t i = 0; i < n; i++) {
+        px[i].assign(in[i].pixels, in[i].pixels + (size_t)in[i].width * in[i].height * channels);
+        d[i] = sthip_image_desc{px[i].data(), in[i].width, in[i].height};
+      }
+    };
+    take(s.gImages, s.gImages ? s.image_count : 0, 4, image_pixels, images);
+    take(s.gImage1s, s.gImage1s ? s.image1_count : 0, 1, image1_pixels, images1);
+    distributions.assign(s.gDistributions, s.gDistributions + (s.gDistributions ? s.distribution_count : 0));
+    volume_bytes.assign(s.gVolumes ? s.volume_count : 0, {});
+    volumes.assign(volume_bytes.size(), sthip_volume_desc{});
+    for (size_t i = 0; i < volume_bytes.size(); i++) {
+      volume_bytes[i].assign((const uint8_t*)s.gVolumes[i].data, (const uint8_t*)s.gVolumes[i].data + s.gVolumes[i].bytes);
+      volumes[i] = sthip_volume_desc{volume_bytes[i].data(), s.gVolumes[i].bytes};
+    }
+    valid = true;
+  }
+  sthip_scene_desc desc() const {
+    sthip_scene_desc d{};
+    d.gVertices = vertices.data();
+    d.vertex_count = (uint32_t)vertices.size();
+    d.gIndices = indices.data();
+    d.indices_bytes = (uint32_t)indices.size();
+    d.gInstances = instances.data();
+    d.instance_count = (uint32_t)instances.size();
+    d.gInstanceTransforms = xf.data();
+    d.gInstanceInverseTransforms = inv.data();
+    d.gInstanceMotionTransforms = motion.empty() ? nullptr : motion.data();
+    d.gMaterialData = materials.data();
+    d.material_bytes = (uint32_t)materials.size();
+    d.gLightInstances = lights.data();
+    d.light_count = (uint32_t)lights.size();
+    d.gImages = images.empty() ? nullptr : images.data();
+    d.image_count = (uint32_t)images.size();
+    d.gDistributions = distributions.empty() ? nullptr : distributions.data();
+    d.distribution_count = (uint32_t)distributions.size();
+    d.gImage1s = images1.empty() ? nullptr : images1.data();
+    d.image1_count = (uint32_t)images1.size();
+    d.gVolumes = volumes.empty() ? nullptr : volumes.data();
+    d.volume_count = (uint32_t)volumes.size();
+    return d;
+  }
+};
+
 struct sthip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -95,6 +166,8 @@ struct sthip_ctx {
   uint32_t volume_count = 0, volume_instances = 0;
   std::vector<uint8_t> instance_is_volume;
   sthip::TopLevelState top;  // what sthip_scene_update_transforms rebuilds the top level from
+  KeptScene kept;            // ... and what it rebuilds everything from when the top level alone cannot follow the change
+  bool keep_scene = true;    // "keep_scene"
   size_t nodes_capacity = 0;
   DevBuf<uint32_t> volume_words;
   DevBuf<DeviceVolume> volumes;
@@ -458,7 +531,10 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->lds_materials = value != 0;
   else if (!strcmp(name, "embed_leaves"))  // takes effect at the next sthip_scene_upload
     ctx->embed_leaves = value != 0;
-  else if (!strcmp(name, "wide_bvh"))  // takes effect at the next sthip_scene_upload (host-built trees only)
+  else if (!strcmp(name, "keep_scene")) {  // takes effect at the next sthip_scene_upload
+    ctx->keep_scene = value != 0;
+    if (!ctx->keep_scene) ctx->kept = KeptScene();
+  } else if (!strcmp(name, "wide_bvh"))  // takes effect at the next sthip_scene_upload (host-built trees only)
     ctx->use_wide = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 3);
   else if (!strcmp(name, "poison_deep_queue")) {  // tests: leaves the deep queue's control words as a call cut short between k_trace and k_trace_deep would (the next render must not care)
     if (value && ctx->deep_count.p) {
@@ -934,14 +1010,13 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     }
     HIP_TRY(ctx, ctx->images1.ensure(std::max<size_t>(1, table.size())));
     HIP_TRY(ctx, ctx->image1_texels.ensure(std::max<size_t>(1, texels.size())));
-    HIP_TRY(ctx, ctx->tri_uvs.ensure(std::max<size_t>(1, built.tri_uvs.size())));
+    HIP_TRY(ctx, ctx->tri_uvs.ensure(1));  // (sized and filled with the shading records further down, once the triangles are resident)
     if (!table.empty()) HIP_TRY(ctx, hipMemcpy(ctx->images1.p, table.data(), table.size() * sizeof(DeviceImage1), hipMemcpyHostToDevice));
     if (!texels.empty()) HIP_TRY(ctx, hipMemcpy(ctx->image1_texels.p, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (!built.tri_uvs.empty()) HIP_TRY(ctx, hipMemcpy(ctx->tri_uvs.p, built.tri_uvs.data(), built.tri_uvs.size() * sizeof(BvhTriUv), hipMemcpyHostToDevice));
     HIP_TRY(ctx, ctx->inst_alpha.ensure(std::max<size_t>(1, built.inst_alpha.size())));
     if (!built.inst_alpha.empty()) HIP_TRY(ctx, hipMemcpy(ctx->inst_alpha.p, built.inst_alpha.data(), built.inst_alpha.size() * 4, hipMemcpyHostToDevice));
     ctx->bvh.inst_alpha = ctx->inst_alpha.p;
-    ctx->has_alpha = any_alpha && !built.tri_uvs.empty();
+    ctx->has_alpha = any_alpha && built.any_alpha;
     ctx->bvh.tri_uv = reinterpret_cast<const float2*>(ctx->tri_uvs.p);
     ctx->bvh.images1 = ctx->images1.p;
     ctx->bvh.image1_texels = ctx->image1_texels.p;
@@ -1001,6 +1076,10 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
   {  // the shading records beside the leaf triangles (bvh.h: BvhTriShade), from the triangles as they lie in HBM now
     const size_t units = built.embedded ? nodes_total : tris_total;  // (embedded leaves: a triangle is a unit of the node array; the units that are nodes get a record nobody reads)
     HIP_TRY(ctx, ctx->tri_shade.ensure(std::max<size_t>(1, units)));
+    if (ctx->has_alpha) {  // the uvs the traversal's alpha test interpolates (gAlphaTest, intersection.hlsli:117-131), in the same order
+      HIP_TRY(ctx, ctx->tri_uvs.ensure(std::max<size_t>(1, units)));
+      ctx->bvh.tri_uv = reinterpret_cast<const float2*>(ctx->tri_uvs.p);
+    }
     if (units && s->vertex_count) {
       DevBuf<uint8_t> is_tri;  // embedded leaves: which units are triangles
       if (built.embedded) {
@@ -1010,7 +1089,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
         HIP_TRY(ctx, hipMemcpy(is_tri.p, flags.data(), units, hipMemcpyHostToDevice));
       }
       hipLaunchKernelGGL(k_fill_tri_shade, dim3(grid_for_early(ctx, units)), dim3(STHIP_BLOCK), 0, ctx->stream, reinterpret_cast<const BvhTri*>(ctx->bvh.tris), (uint32_t)units, is_tri.p, ctx->vertices.p, s->vertex_count,
-                         ctx->indices.p, (uint64_t)s->indices_bytes, ctx->tri_shade.p);
+                         ctx->indices.p, (uint64_t)s->indices_bytes, ctx->tri_shade.p, ctx->has_alpha ? ctx->tri_uvs.p : nullptr);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (`is_tri` goes out of scope)
     }
@@ -1020,6 +1099,11 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     if (rc != STHIP_OK) return rc;
   }
   ctx->has_scene = true;
+  if (ctx->keep_scene) {
+    if (s->gVertices != ctx->kept.vertices.data() || !ctx->kept.valid) ctx->kept.keep(*s);  // (a rebuild from the kept copy itself keeps nothing anew)
+  } else {
+    ctx->kept = KeptScene();
+  }
   if (getenv("STHIP_VERBOSE")) {
     int per_cu = 0;
     per_cu = trace_occupancy(ctx, trace_lds_bytes(ctx));
@@ -1179,7 +1263,23 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* xf,
   uint32_t root_ref = 0, top_is_world = 1, stack_depth = 4;
   float center[3] = {ctx->bvh.scene_cx, ctx->bvh.scene_cy, ctx->bvh.scene_cz}, radius = ctx->bvh.scene_radius;
   std::string err;
-  if (!sthip::rebuild_top_level(next, xf, inv, instance_count, tlas, root_ref, top_is_world, stack_depth, center, radius, err)) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: " + err);
+  if (!sthip::rebuild_top_level(next, xf, inv, instance_count, tlas, root_ref, top_is_world, stack_depth, center, radius, err)) {
+    // An instance of the merged world-space mesh (identity transform at upload) moved: the tree that is resident cannot follow,
+    // the scene is built again from the copy kept at upload, with the new transforms — the configured builder ("bvh_builder" = 1:
+    // ~10 ms per million triangles on the device), everything else as uploaded. Without the copy ("keep_scene" = 0) it is refused.
+    if (ctx->kept.valid && ctx->kept.instances.size() == instance_count) {
+      ctx->kept.xf.assign(xf, xf + instance_count);
+      ctx->kept.inv.assign(inv, inv + instance_count);
+      if (motion)
+        ctx->kept.motion.assign(motion, motion + instance_count);
+      else
+        ctx->kept.motion.clear();
+      const sthip_scene_desc d = ctx->kept.desc();
+      ctx->stats.full_rebuilds++;
+      return sthip_scene_upload(ctx, &d);
+    }
+    return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: " + err);
+  }
   if (stack_depth > STHIP_MAX_STACK_DEPTH) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: the new top level is too deep for the traversal stack");
   if ((size_t)next.blas_nodes + tlas.size() > ctx->nodes.n) return fail(ctx, STHIP_ERR_UNSUPPORTED, "sthip_scene_update_transforms: the new top level does not fit: upload the scene again");
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still read the old top level

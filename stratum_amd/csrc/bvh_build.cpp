@@ -456,10 +456,8 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       any_alpha = true;
     }
   }
-  if (any_alpha && builder == BVH_BUILDER_LBVH_GPU) {
-    err = "only triangle soups without alpha masks go through the GPU LBVH builder (use the SAH builder)";
-    return false;
-  }
+  // (the uvs the alpha test interpolates lie beside the leaf triangles and are filled on the device from the resident
+  // triangles, whoever built the tree: api.hip, k_fill_tri_shade)
 
   std::string gpu_err;
   // ---- device mode: the region the GPU builder fills is sized before anything is built ----
@@ -629,15 +627,6 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       t.id = (pr.second << 16) | (with_instance_bits ? pr.first : 0u);
       t.src_indices = in.indices_byte_offset + pr.second * 3u * in.stride;
       t.src_vertex = in.first_vertex | (in.stride == 4u ? 0x80000000u : 0u);
-      if (any_alpha) {
-        BvhTriUv uv;
-        for (int v = 0; v < 3; v++) {
-          uv.uv[v][0] = s.gVertices[tri[v]].u;
-          uv.uv[v][1] = s.gVertices[tri[v]].v;
-        }
-        if (out.tri_uvs.size() < tri_base + prims.size()) out.tri_uvs.resize(tri_base + prims.size());
-        out.tri_uvs[tri_base + k] = uv;
-      }
     }
     const uint32_t root = flatten(b, 0, out.nodes, [&](uint32_t first, uint32_t count) {
       if (!out.embedded) return BVH_LEAF_BIT | ((tri_base + first) << 2) | (count - 1);
@@ -880,19 +869,12 @@ bool build_scene_bvh(const sthip_scene_desc& s, BuiltBvh& out, std::string& err,
       }
     if (!out.top_is_world_blas && out.root_ref != BVH_INVALID_REF) out.root_ref += node_off;  // the top level is host-built
   }
-  if (any_alpha) out.tri_uvs.resize(out.tris.size());
+  out.any_alpha = any_alpha;
   if (out.embedded) {
     out.unit_tri.resize(out.nodes.size(), 0xFFFFFFFFu);
     if (out.nodes.size() >= (1u << 28)) {
       err = "too many triangles";
       return false;
-    }
-    if (any_alpha) {  // the uv side array follows the leaf references: by unit
-      std::vector<BvhTriUv> by_unit(out.nodes.size());
-      memset(by_unit.data(), 0, by_unit.size() * sizeof(BvhTriUv));
-      for (size_t u = 0; u < out.unit_tri.size(); u++)
-        if (out.unit_tri[u] != 0xFFFFFFFFu) by_unit[u] = out.tri_uvs[out.unit_tri[u]];
-      out.tri_uvs.swap(by_unit);
     }
   }
   out.inst_alpha = inst_alpha;
@@ -1510,11 +1492,6 @@ void build_wide8_bvh(BuiltBvh& out) {
       if ((r & (BVH_LEAF_BIT | BVH_INST_BIT)) != BVH_LEAF_BIT) continue;
       nd.ref[c] = BVH_LEAF_BIT | (wb.new_index[(r & 0x3FFFFFFFu) >> 2] << 2) | (r & 3u);
     }
-  if (!out.tri_uvs.empty()) {
-    std::vector<BvhTriUv> uv(out.tri_uvs.size());
-    for (size_t t = 0; t < out.tris.size() && t < out.tri_uvs.size(); t++) uv[wb.new_index[t]] = out.tri_uvs[t];
-    out.tri_uvs.swap(uv);
-  }
   out.tris.swap(wb.tris_out);
   out.wide8_nodes.swap(nodes);
   out.wide8_entries.swap(entries);

@@ -40,7 +40,7 @@ struct TopLevelState {
 struct BuiltBvh {
   std::vector<BvhNode> nodes;
   std::vector<BvhTri> tris;
-  std::vector<BvhTriUv> tri_uvs;  // parallel to tris when some material has an alpha mask, else empty
+  bool any_alpha = false;  // some material has an alpha mask: the uploader keeps the leaf triangles' uvs beside them (BvhTriUv, filled on the device)
   std::vector<uint32_t> inst_alpha;  // per instance: gImage1s index of its material's alpha mask or BVH_NO_ALPHA
   std::vector<TlasEntry> entries;
   std::vector<DeviceVolume> volumes;  // parsed headers of gVolumes (first_word is filled by the uploader)
@@ -133,8 +133,8 @@ bool build_scene_bvh(const sthip_scene_desc& scene, BuiltBvh& out, std::string& 
 void build_wide_bvh(BuiltBvh& out);
 
 // Collapses the finished binary tree of a host build (out.dev_nodes == 0, no embedded leaves) into 8-wide compressed nodes
-// (bvh.h: Wide8Node): out.wide8_*. The items of a node's leaf children must be consecutive, so this PERMUTES out.tris (and
-// out.tri_uvs) — every binary leaf keeps its triangles together and in order — and rewrites the binary nodes' leaf
+// (bvh.h: Wide8Node): out.wide8_*. The items of a node's leaf children must be consecutive, so this PERMUTES out.tris
+// — every binary leaf keeps its triangles together and in order — and rewrites the binary nodes' leaf
 // references to match: call it before anything is uploaded. Leaves nothing (wide8_nodes empty) when the tree cannot take
 // the form: a box that fits no grid, a leaf of more than three triangles. out.top.wide8_* keeps what build_wide8_top needs.
 void build_wide8_bvh(BuiltBvh& out);

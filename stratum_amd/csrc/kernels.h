@@ -2615,7 +2615,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const uint32_t* 
 // upload beside the leaf triangles as they lie in HBM: the triangle says where its index triple is (BvhTri::src_indices /
 // src_vertex), the vertices are read again — so the record holds the floats shading would have gathered (shading_data.hlsli:2-6)
 __global__ void __launch_bounds__(STHIP_BLOCK) k_fill_tri_shade(const BvhTri* tris, uint32_t n, const uint8_t* is_tri, const sthip_PackedVertexData* vertices, uint32_t vertex_count, const uint8_t* indices,
-                                                                uint64_t indices_bytes, BvhTriShade* out) {
+                                                                uint64_t indices_bytes, BvhTriShade* out, BvhTriUv* out_uv) {
   for (uint32_t i = blockIdx.x * STHIP_BLOCK + threadIdx.x; i < n; i += gridDim.x * STHIP_BLOCK) {
     BvhTriShade r;
     memset(&r, 0, sizeof(r));
@@ -2644,6 +2644,16 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_fill_tri_shade(const BvhTri* tr
       r.u[2] = c.u;
     }
     out[i] = r;
+    if (out_uv) {  // (scenes with alpha masks) what the traversal's alpha test interpolates
+      BvhTriUv q;
+      q.uv[0][0] = r.u[0];
+      q.uv[0][1] = r.v0;
+      q.uv[1][0] = r.u[1];
+      q.uv[1][1] = r.v1;
+      q.uv[2][0] = r.u[2];
+      q.uv[2][1] = r.v2;
+      out_uv[i] = q;
+    }
   }
 }
 

@@ -229,7 +229,7 @@ class Stats(C.Structure):
         ("seeds_in_flight", C.c_uint32),
         ("max_paths_in_flight", C.c_uint64),
         ("batch_halvings", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("full_rebuilds", C.c_uint32),
     ]
 
 

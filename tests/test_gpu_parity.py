@@ -641,8 +641,6 @@ def test_wide_walk_over_gpu_built_trees_and_moved_instances(atrium_scene, levels
     for (sc, cam), flags, args in cases:
         frame = camera.Frame(160, 96, cam["fovy"], cam["eye"], cam["target"])
         for builder, algorithm, sah_top in ((1, 1, 64), (1, 1, 0), (1, 0, 0), (0, 1, 64)):
-            if builder == 1 and flags:  # (alpha masks need the SAH builder)
-                continue
             out = {}
             for wide in (0, 1, 3):
                 node_bytes = {0: 48, 1: 64, 3: 80 if builder == 0 else 64}[wide]  # (GPU-built trees get the 4-wide form where the 8-wide one is asked for)
@@ -1025,18 +1023,32 @@ def test_alpha_masked_foliage(flags):
     _compare_frame(sc, cam, flags, args={"maxDiffuseVertices": 3})
 
 
-def test_alpha_masks_need_the_sah_builder():
-    from stratum_amd import _lib
+def test_alpha_masks_with_the_gpu_builder():
+    """Scenes with alpha masks go through the GPU builder too: the uvs the traversal's alpha test interpolates are
+    filled on the device from the resident leaf triangles (k_fill_tri_shade), whoever built the tree. The frame and the ray
+    batches are those of the host-built tree; without the flag the masks do not apply."""
     from stratum_amd.bdpt import BDPT
 
-    sc, _ = scenes.foliage()
-    r = BDPT(device=0)
-    try:
-        r.set_option("bvh_builder", 1)
-        with pytest.raises(_lib.StratumHipError, match="alpha masks"):
+    sc, cam = scenes.foliage()
+    frame = camera.Frame(160, 96, cam["fovy"], cam["eye"], cam["target"])
+    rays = random_rays(20000, 8, -6.0, 6.0)
+    out = {}
+    for builder in (0, 1):
+        r = BDPT(device=0, args={"bdptFlag": ["alphatest"]})
+        try:
+            r.set_option("bvh_builder", builder)
             r.update(sc)
-    finally:
-        r.close()
+            out[builder] = (r.render(frame, 1, 2), r.trace(rays, alpha_test=True), r.trace(rays, any_hit=True, alpha_test=True), r.trace(rays))
+        finally:
+            r.close()
+    a, b = out[0], out[1]
+    assert np.array_equal(a[0]["radiance"].view(np.uint32), b[0]["radiance"].view(np.uint32))
+    assert np.array_equal(a[0]["visibility"]["instance_primitive_index"], b[0]["visibility"]["instance_primitive_index"])
+    assert np.array_equal(a[0]["ray_count"], b[0]["ray_count"])
+    for k in (1, 2, 3):
+        for f in ("instance_primitive_index", "t", "b1", "b2"):
+            assert np.array_equal(a[k][f].view(np.uint32), b[k][f].view(np.uint32)), (k, f)
+    assert not np.array_equal(b[1]["instance_primitive_index"], b[3]["instance_primitive_index"])  # the masks do cut something
 
 
 @pytest.mark.parametrize("flags", [["presamplelights"], ["presamplelights", "~remapthreads", "~defershadowrays"], ["presamplelights", "~samplebsdfs"]])
@@ -1421,7 +1433,8 @@ def test_randomised_differential():
 
 def test_transforms_only_update(renderer):
     """sthip_scene_update_transforms: instances move, the bottom levels stay in HBM, the top level is rebuilt. Frames equal
-    the oracle's on the moved scene and what a full upload gives; an instance of the merged identity mesh may not move."""
+    the oracle's on the moved scene and what a full upload gives; when an instance of the merged identity mesh moves the call
+    builds the scene again from the copy kept at upload (refused without it: keep_scene = 0)."""
     from oracle import oracle_py
     from stratum_amd import _lib
     from stratum_amd.bdpt import BDPT
@@ -1460,11 +1473,42 @@ def test_transforms_only_update(renderer):
             assert np.array_equal(r.render(frame, 0, 2)["radiance"].view(np.uint32), got["radiance"].view(np.uint32))
         finally:
             r.close()
+    # An instance of the merged world-space mesh that moves: the resident tree cannot follow, the call builds the scene again
+    # from the copy kept at upload (Scene.cpp:345,435-459: the reference rebuilds whatever is dirty) — with either builder, and
+    # the frame is the one a fresh upload of the moved scene gives (and the oracle's). Without the copy it is refused.
+    from oracle import oracle_py
+
+    for builder in (0, 1):
+        sc, cam = scenes.cornell_box()
+        frame = camera.Frame(128, 96, cam["fovy"], cam["eye"], cam["target"])
+        r = BDPT(device=0)
+        try:
+            r.set_option("bvh_builder", builder)
+            r.update(sc)
+            before = r.render(frame, 0, 2)["radiance"].copy()
+            sc.set_instance_transform(0, translate((0.0, 0.1, 0.0)))  # the floor: part of the merged world-space mesh
+            r.update_transforms(sc)
+            assert r.stats()["full_rebuilds"] == 1
+            got = r.render(frame, 0, 2)
+            assert not np.array_equal(before, got["radiance"])
+            ref = oracle_py.OracleScene(sc).render(frame, r.push_constants(frame), r.mSamplingFlags, 0, 2)
+            assert np.array_equal(got["radiance"].view(np.uint32), ref["radiance"].view(np.uint32)), builder
+            assert np.array_equal(got["ray_count"], ref["ray_count"])
+            sc.set_instance_transform(0, translate((0.0, 0.0, 0.0)))  # ... and back: the instance is a transformed one now, the top level follows
+            r.update_transforms(sc)
+            assert np.array_equal(r.render(frame, 0, 2)["radiance"].view(np.uint32), before.view(np.uint32))
+        finally:
+            r.close()
     sc, cam = scenes.cornell_box()
-    renderer.update(sc)
-    sc.set_instance_transform(0, translate((0.0, 0.1, 0.0)))  # the floor: part of the merged world-space mesh
-    with pytest.raises(_lib.StratumHipError, match="upload the scene again"):
-        renderer.update_transforms(sc)
+    r = BDPT(device=0)
+    try:
+        r.set_option("keep_scene", 0)
+        r.update(sc)
+        sc.set_instance_transform(0, translate((0.0, 0.1, 0.0)))
+        with pytest.raises(_lib.StratumHipError, match="upload the scene again"):
+            r.update_transforms(sc)
+    finally:
+        r.close()
 
 
 def test_estimators_converge_to_the_same_image(renderer):
