@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STHIP_ABI_VERSION 10
+#define STHIP_ABI_VERSION 11
 
 typedef struct sthip_ctx sthip_ctx;
 
@@ -122,7 +122,33 @@ typedef struct sthip_outputs {
   sthip_DepthInfo* gDepth;           /* W*H */
   float* gPrevUVs;                   /* RG32F, W*H*2 */
   uint64_t* gRayCount;               /* [2]: all trace_ray calls / path (non-shadow) rays; intersection.hlsli:66, path.hlsli:1006 */
+  /* BDPTDebugMode (bdpt.h:177-193; a specialisation constant of the reference's pipeline, BDPT.cpp:526-541) and the image it
+   * feeds, RGBA32F W x H (bdpt.hlsl:45), with gDebugViewPathLength / gDebugLightPathLength of the push constants. gDebugImage
+   * is IN / OUT as upstream's is (it persists from frame to frame): ePathLengthContribution and eViewTraceContribution start
+   * every pixel's sample at (0,0,0,1), the other modes overwrite a pixel where a path reaches their statement or add to what it
+   * holds; pixels outside every view are not touched. The seeds of a call are the reference's successive frames. 0 or a NULL
+   * image = off (the image is then neither read nor written). Host or device pointer as the others (device_ptrs). */
+  uint32_t debug_mode;
+  float* gDebugImage;
 } sthip_outputs;
+
+enum {
+  STHIP_DEBUG_NONE = 0,
+  STHIP_DEBUG_ALBEDO,                     /* = m.albedo() of the first hit */
+  STHIP_DEBUG_SPECULAR,                   /* = m.is_specular() */
+  STHIP_DEBUG_EMISSION,                   /* = m.Le() */
+  STHIP_DEBUG_SHADING_NORMAL,             /* = n * .5 + .5 (after the normal map) */
+  STHIP_DEBUG_GEOMETRY_NORMAL,
+  STHIP_DEBUG_DIR_OUT,                    /* = the last sampled direction * .5 + .5 */
+  STHIP_DEBUG_PREV_UV,                    /* = |prev uv - uv| * extent */
+  STHIP_DEBUG_ENVIRONMENT_SAMPLE_TEST,    /* += eight environment samples as spots around the view direction; nothing is traced */
+  STHIP_DEBUG_ENVIRONMENT_SAMPLE_PDF,     /* .rgb = the environment's pdf of the view direction; nothing is traced */
+  STHIP_DEBUG_RESERVOIR_WEIGHT,           /* += W of the NEE reservoir's sample where it is unoccluded (inline shadow rays only, as upstream) */
+  STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION,   /* the unweighted contributions of (gDebugViewPathLength, gDebugLightPathLength) */
+  STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION,   /* light tracing's splats with weight 1 */
+  STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION,    /* += the unweighted emission view paths find; light tracing is not added to gRadiance */
+  STHIP_DEBUG_MODE_COUNT
+};
 
 /* ---- lifetime ---- */
 int sthip_abi_version(void);

@@ -99,7 +99,7 @@ class OracleScene:
     def __del__(self):
         self.close()
 
-    def render(self, frame, push_constants, sampling_flags=wire.DEFAULT_SAMPLING_FLAGS, seed_begin=0, seed_count=1, threads=0, aovs=True, window=None):
+    def render(self, frame, push_constants, sampling_flags=wire.DEFAULT_SAMPLING_FLAGS, seed_begin=0, seed_count=1, threads=0, aovs=True, window=None, debug_mode=0, debug_image=None):
         """window = (x0, y0, x1, y1): render only that rectangle of the frame (the same pixels the whole frame has there);
         the arrays returned are still W x H, zero outside the window."""
         W, H = frame.width, frame.height
@@ -121,6 +121,10 @@ class OracleScene:
             o.gVisibility = wire.ptr(out["visibility"])
             o.gDepth = wire.ptr(out["depth"])
             o.gPrevUVs = wire.ptr(out["prev_uv"])
+        if debug_mode:  # BDPTDebugMode -> gDebugImage, in / out (a copy of what the caller passes, or zeros)
+            out["debug"] = np.ascontiguousarray(debug_image, np.float32).copy() if debug_image is not None else np.zeros((H, W, 4), np.float32)
+            o.debug_mode = debug_mode
+            o.gDebugImage = wire.ptr(out["debug"])
         if self.scene.volumes:
             frame.view_medium_instances = self.scene.view_medium_instances(frame.view_transforms)
         fd = frame.desc()

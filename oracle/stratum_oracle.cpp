@@ -1541,6 +1541,9 @@ struct Frame {
   std::atomic<uint32_t>* light_trace = nullptr;
   uint32_t light_trace_quantization = 65536;  // BDPT.hpp:55
   bool flag(int b) const { return (sampling_flags >> b) & 1u; }
+  // BDPTDebugMode (bdpt.h:177-193): a specialisation constant upstream (gDebugMode), here sthip_outputs::debug_mode
+  uint32_t debug_mode = 0;
+  bool debug(uint32_t m) const { return debug_mode == m; }
 };
 
 // dist2.h:6-20 (upper_bound), :29-57 (dist2d_pdf / dist2d_sample) over gDistributions
@@ -2097,6 +2100,23 @@ struct PathIntegrator {
   uint32_t medium = STHIP_INVALID_INSTANCE; // _medium: the volume instance the path is inside of
   float T_nee_pdf = 1;                      // path.hlsli:282
   v3 radiance;                              // accumulate_contribution target (path.hlsli:300-304)
+  float* dbg = nullptr;                     // gDebugImage[pixel_coord] (rgba), or null: no debug mode
+  // accumulate_contribution, path.hlsli:300-304
+  void accumulate_contribution(v3 contrib, float weight, uint32_t light_length) {
+    radiance = radiance + contrib * weight;
+    if (dbg && fr.debug(STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION) && fr.pc.gDebugLightPathLength == light_length && path_length == fr.pc.gDebugViewPathLength) debug_add(contrib);
+  }
+  void debug_set(v3 c) {
+    dbg[0] = c.x;
+    dbg[1] = c.y;
+    dbg[2] = c.z;
+    dbg[3] = 1;
+  }
+  void debug_add(v3 c) {
+    dbg[0] = dbg[0] + c.x;
+    dbg[1] = dbg[1] + c.y;
+    dbg[2] = dbg[2] + c.z;
+  }
   sthip_ShadowRayData shadow_rays[32];      // this pixel's gShadowRays slots (path.hlsli:65,355-364)
   uint32_t max_shadow;
   uint64_t counters[2];                      // nodes, tris
@@ -2281,7 +2301,8 @@ struct PathIntegrator {
       } else if (fr.flag(STHIP_eNEE))
         weight = fr.flag(STHIP_eNEEReservoirs) ? 0.5f : mis2(fr, bsdf_pdf * G, light_pdfA);  // path.hlsli:881-886
     }
-    radiance = radiance + contrib * weight;
+    if (dbg && fr.debug(STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION)) debug_add(contrib);  // path.hlsli:890-891
+    accumulate_contribution(contrib, weight, 0);
   }
 
   // path.hlsli:829-845, non-coherent form (eCoherentRR is wave-scope and implementation-defined)
@@ -2496,7 +2517,7 @@ struct PathIntegrator {
         rd.ray_distance = ray_distance;
       }
     } else {
-      radiance = radiance + beta * contrib * weight;
+      accumulate_contribution(beta * contrib, weight, 1);  // path.hlsli:365
     }
   }
 
@@ -2627,7 +2648,8 @@ struct PathIntegrator {
       }
     } else {
       if (occluded(ray_origin, c.ray_direction, ray_distance)) return;
-      radiance = radiance + beta * contrib * weight;
+      if (dbg && fr.debug(STHIP_DEBUG_RESERVOIR_WEIGHT)) debug_add(V3(W));  // path.hlsli:482-483
+      accumulate_contribution(beta * contrib, weight, 1);                  // :485
     }
   }
 
@@ -2671,6 +2693,7 @@ struct PathIntegrator {
     prev_cos_out = ngdotout;
     if (all_le0(beta)) return false;
     direction = ms.dir_out;
+    if (dbg && fr.debug(STHIP_DEBUG_DIR_OUT)) debug_set(direction * .5f + V3(.5f));  // path.hlsli:950
     return true;
   }
 
@@ -2737,6 +2760,7 @@ struct PathIntegrator {
     origin = isect.sd.position;
     prev_cos_out = 1;
     direction = dir_out;
+    if (dbg && fr.debug(STHIP_DEBUG_DIR_OUT)) debug_set(direction * .5f + V3(.5f));  // path.hlsli:950
     return true;
   }
 
@@ -2890,7 +2914,7 @@ struct PathIntegrator {
       const v3 contrib = beta * connect_light_vertex(m, lv, weight, ray_origin, ray_direction, ray_distance);
       if (all_le0(contrib) || weight <= 0) continue;
       if (occluded(ray_origin, ray_direction, ray_distance)) continue;
-      radiance = radiance + contrib * weight;
+      accumulate_contribution(contrib, weight, lv.subpath_length());  // path.hlsli:820
     }
   }
 
@@ -3011,7 +3035,7 @@ struct PathIntegrator {
       rd.ray_direction[2] = ray_direction.z;
       rd.ray_distance = ray_distance;
     } else if (any_gt0(contrib) && weight > 0) {
-      if (!occluded(ray_origin, ray_direction, ray_distance)) radiance = radiance + contrib * weight;
+      if (!occluded(ray_origin, ray_direction, ray_distance)) accumulate_contribution(contrib, weight, lv.subpath_length());  // path.hlsli:797
     }
   }
 
@@ -3062,6 +3086,11 @@ struct PathIntegrator {
         weight = prev_specular ? 1.0f : mis2(fr, path_pdf, 1.0f * path_pdf_rev * (ev.pdf_rev * G_rev));
     } else
       weight = path_weight(1, path_length);
+    if (fr.debug(STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION)) weight = 1;  // path.hlsli:608-609
+    if (fr.debug(STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION) && fr.pc.gDebugViewPathLength == 1) {  // :611-613: only the asked light length, unweighted
+      if (fr.pc.gDebugLightPathLength != path_length) return;
+      weight = 1;
+    }
     // accumulate_light_contribution, path.hlsli:47-60: quantised integer sums (order-independent) + overflow bits
     const v3 c = contribution * weight;
     const float q = (float)fr.light_trace_quantization;
@@ -3175,10 +3204,23 @@ struct RRControl {
   int cs_site = -1, cs_length = -1;
   uint32_t cs_value = 0;
 };
-bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float out_rgb[3], PixelAOV* aov, uint64_t stats[4], RRControl* rr = nullptr) {
+// dbg: gDebugImage[pixel] (rgba, in / out: upstream's image persists from frame to frame and most modes only add to it or
+// overwrite it where a path gets somewhere), or null
+bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float out_rgb[3], PixelAOV* aov, uint64_t stats[4], RRControl* rr = nullptr, float* dbg = nullptr) {
   const int view_index = get_view_index(fr, x, y);
   if (view_index < 0) return false;
   PathIntegrator path(fr, x, y, seed);
+  if (fr.debug_mode == 0) dbg = nullptr;
+  path.dbg = dbg;
+  PixelAOV aov_scratch;
+  if (dbg && fr.debug(STHIP_DEBUG_PREV_UV) && !aov) {  // (the mode reads the previous-frame uv the G-buffer block computes)
+    memset(&aov_scratch, 0, sizeof(aov_scratch));
+    aov = &aov_scratch;
+  }
+  if (dbg && (fr.debug(STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION) || fr.debug(STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION))) {  // bdpt.hlsl:161-162
+    dbg[0] = dbg[1] = dbg[2] = 0;
+    dbg[3] = 1;
+  }
   if (rr) {
     path.group_rr = rr->decisions;
     path.group_nee = rr->nee;
@@ -3205,6 +3247,28 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
     path.rd_radius = 0;
     path.rd_spread = fminf(length(dir_dx / dir_dx.z - l), length(dir_dy / dir_dy.z - l));
   }
+  if (dbg && fr.debug(STHIP_DEBUG_ENVIRONMENT_SAMPLE_TEST)) {  // bdpt.hlsl:190-199 (no ray is traced; without an environment the record at gEnvironmentMaterialAddress is not one: not restated)
+    if (!has_environment(fr)) return true;
+    Environment env;
+    env.load(*fr.sc, fr.pc.gEnvironmentMaterialAddress);
+    for (uint32_t i = 0; i < 8; i++) {
+      float pdf;
+      v3 dir;
+      const float r0 = path.rng.next_float(), r1 = path.rng.next_float();
+      (void)env.sample(r0, r1, dir, pdf, fr.flag(STHIP_eSampleEnvironmentMapDirectly));
+      const float v = 1024 * det_powf(fmaxf(0.0f, dot(dir, path.direction)), 1024.0f);
+      path.debug_add(V3(v));
+    }
+    return true;
+  }
+  if (dbg && fr.debug(STHIP_DEBUG_ENVIRONMENT_SAMPLE_PDF)) {  // bdpt.hlsl:200-204 (.rgb = pdf: the alpha stays)
+    if (!has_environment(fr)) return true;
+    Environment env;
+    env.load(*fr.sc, fr.pc.gEnvironmentMaterialAddress);
+    const float pdf = env.eval_pdf(path.direction, fr.flag(STHIP_eSampleEnvironmentMapDirectly));
+    dbg[0] = dbg[1] = dbg[2] = pdf;
+    return true;
+  }
   path.beta = V3(1.0f);
   path.medium = (has_media(fr) && fr.fd.gViewMediumInstances) ? fr.fd.gViewMediumInstances[view_index] : STHIP_INVALID_INSTANCE;  // bdpt.hlsl:208
   path.trace();
@@ -3214,6 +3278,12 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
   path.G = 1;
   path.dVC = 1;
 
+  // bdpt.hlsl:222-223 (on a miss upstream reads normals nobody wrote; pinned to the packed value 0, as the visibility output is)
+  if (dbg && (fr.debug(STHIP_DEBUG_GEOMETRY_NORMAL) || fr.debug(STHIP_DEBUG_SHADING_NORMAL))) {
+    const bool miss = path.isect.instance_index() == STHIP_INVALID_INSTANCE || (has_media(fr) && path.isect.sd.shape_area == 0);  // (a first vertex inside a medium: stale normals upstream, pinned likewise)
+    const v3 n = fr.debug(STHIP_DEBUG_GEOMETRY_NORMAL) ? (miss ? unpack_normal_octahedron(0) : path.isect.sd.geometry_normal()) : (miss ? unpack_normal_octahedron(0) : path.isect.sd.shading_normal());
+    path.debug_set(n * .5f + V3(.5f));
+  }
   sthip_VisibilityInfo vis;
   vis.instance_primitive_index = path.isect.instance_primitive_index;
   vis.packed_normal = path.isect.sd.packed_shading_normal;
@@ -3247,6 +3317,12 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
         aov->albedo[2] = a.z;
         aov->albedo[3] = 1;
       }
+      if (dbg) {  // bdpt.hlsl:257-260
+        if (fr.debug(STHIP_DEBUG_ALBEDO)) path.debug_set(m.albedo());
+        else if (fr.debug(STHIP_DEBUG_SPECULAR)) path.debug_set(V3(m.is_specular() ? 1.0f : 0.0f));
+        else if (fr.debug(STHIP_DEBUG_EMISSION)) path.debug_set(m.Le());
+        else if (fr.debug(STHIP_DEBUG_SHADING_NORMAL)) path.debug_set(tmp_sd.shading_normal() * .5f + V3(.5f));
+      }
     }
     const bool medium_vertex = has_media(fr) && path.isect.sd.shape_area == 0;
     if (medium_vertex) vis.packed_normal = 0;  // upstream stores the stale normal of the last query here; pinned to 0
@@ -3270,6 +3346,8 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
       pc[1] = pc[1] / pc[3];
       aov->prev_uv[0] = pc[0] * .5f + .5f;
       aov->prev_uv[1] = pc[1] * .5f + .5f;
+      if (dbg && fr.debug(STHIP_DEBUG_PREV_UV))  // bdpt.hlsl:294-295
+        path.debug_set(V3(fabsf(aov->prev_uv[0] - uvx) * (float)fr.pc.gOutputExtent[0], fabsf(aov->prev_uv[1] - uvy) * (float)fr.pc.gOutputExtent[1], 0.0f));
     }
     while (any_gt0(path.beta) && !any_nan(path.beta)) path.next_vertex();
   }
@@ -3295,7 +3373,7 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
     c = c + contribution;
   }
   v3 rad = path.radiance + c;
-  if (fr.light_trace) {  // add_light_trace, bdpt.hlsl:328-338 with load_light_sample, path.hlsli:38-46
+  if (fr.light_trace && !fr.debug(STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION)) {  // add_light_trace, bdpt.hlsl:328-338 with load_light_sample, path.hlsli:38-46
     const size_t idx = (size_t)y * fr.pc.gOutputExtent[0] + x;
     uint32_t v[4];
     for (int k = 0; k < 4; k++) v[k] = fr.light_trace[4 * idx + k].load(std::memory_order_relaxed);
@@ -3304,6 +3382,7 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
     v3 lc = V3((float)v[0], (float)v[1], (float)v[2]) / (float)fr.light_trace_quantization;
     if (lc.x < 0 || lc.y < 0 || lc.z < 0 || any_nan(lc)) lc = V3(0.0f);
     rad = rad + lc;
+    if (dbg && (fr.debug(STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION) || (fr.debug(STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION) && fr.pc.gDebugViewPathLength == 1))) path.debug_set(lc);  // bdpt.hlsl:335-336
   }
   out_rgb[0] = rad.x;
   out_rgb[1] = rad.y;
@@ -3579,6 +3658,8 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   fr.sampling_flags = sampling_flags;
   fr.scene_flags = scene_flags;
   fr.fd = *frame;
+  fr.debug_mode = out->gDebugImage ? out->debug_mode : 0u;
+  if (fr.debug_mode >= STHIP_DEBUG_MODE_COUNT) return STHIP_ERR_INVALID_ARGUMENT;
   // BDPT.cpp:488-509
   if (pc->gLightCount == 0) fr.scene_flags &= ~STHIP_BDPT_FLAG_HAS_EMISSIVES;
   if (!has_environment(fr)) fr.pc.gEnvironmentSampleProbability = 0;
@@ -3718,7 +3799,8 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
     PixelAOV aov;
     memset(&aov, 0, sizeof(aov));  // fields a first vertex inside a medium leaves unwritten (albedo) read as zero
     const Frame sf = seed_frame(base, s);
-    if (!render_pixel(sf, x, y, seed_begin + s, rgb, (s == 0 && want_aovs) ? &aov : nullptr, &tstats[(size_t)tid * 4])) return false;
+    float* dbg = (out->gDebugImage && out->debug_mode) ? out->gDebugImage + 4 * ((size_t)y * W + x) : nullptr;  // (this thread owns the pixel, seed after seed: upstream's frame after frame)
+    if (!render_pixel(sf, x, y, seed_begin + s, rgb, (s == 0 && want_aovs) ? &aov : nullptr, &tstats[(size_t)tid * 4], nullptr, dbg)) return false;
     fold(x, y, s, acc, rgb, aov);
     return true;
   };
@@ -3738,6 +3820,7 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
       float rgb[3];
       PixelAOV aov;
       uint64_t stats[4];
+      float dbg[4];  // the pixel of gDebugImage as this rendering of the group leaves it (only the last rendering's is stored)
     } lanes[32];
     for (;;) {
       int missing = -1;
@@ -3751,7 +3834,9 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
         ctl[l].decisions = fr.flag(STHIP_eCoherentRR) ? decisions : nullptr;
         ctl[l].nee = fr.flag(STHIP_eCoherentSampling) ? nee_values : nullptr;
         ctl[l].lvc = fr.flag(STHIP_eCoherentSampling) ? lvc_values : nullptr;
-        lanes[l].inside = render_pixel(sf, x, y, seed_begin + s, lanes[l].rgb, (s == 0 && want_aovs) ? &lanes[l].aov : nullptr, lanes[l].stats, &ctl[l]);
+        const bool debugging = out->gDebugImage && out->debug_mode;
+        if (debugging) memcpy(lanes[l].dbg, out->gDebugImage + 4 * ((size_t)y * W + x), 16);
+        lanes[l].inside = render_pixel(sf, x, y, seed_begin + s, lanes[l].rgb, (s == 0 && want_aovs) ? &lanes[l].aov : nullptr, lanes[l].stats, &ctl[l], debugging ? lanes[l].dbg : nullptr);
       }
       // the earliest statement some lane could not execute: by path length, then in the order of a vertex (roulette, NEE index,
       // connect_lvc's index). A lane reports at most one.
@@ -3795,6 +3880,7 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
       if (!acc) continue;
       for (int k = 0; k < 4; k++) tstats[(size_t)tid * 4 + k] += lanes[l].stats[k];
       fold(x, y, s, acc, lanes[l].rgb, lanes[l].aov);
+      if (out->gDebugImage && out->debug_mode) memcpy(out->gDebugImage + 4 * ((size_t)y * W + x), lanes[l].dbg, 16);
     }
   };
   if (fr.flag(STHIP_eNEEReservoirReuse) || fr.flag(STHIP_eLVCReservoirReuse)) {

@@ -169,7 +169,7 @@ class BDPT:
         return pc
 
     # ---- BDPT::render ----
-    def render(self, frame, seed_begin=0, seed_count=1, aovs=True, device_outputs=None, packed_tiles=False):
+    def render(self, frame, seed_begin=0, seed_count=1, aovs=True, device_outputs=None, packed_tiles=False, debug_mode=0, debug_image=None):
         """Host outputs by default (dict of numpy arrays). `device_outputs` = dict of raw device pointers
         {"radiance": ptr, ["albedo", "visibility", "depth", "prev_uv", "ray_count"]} renders in place on the
         GPU without synchronising. packed_tiles: "radiance" holds only this shard's tiles in slot order
@@ -191,12 +191,19 @@ class BDPT:
             o.gDepth = device_outputs.get("depth")
             o.gPrevUVs = device_outputs.get("prev_uv")
             o.gRayCount = device_outputs.get("ray_count")
+            if debug_mode:
+                o.debug_mode = debug_mode
+                o.gDebugImage = device_outputs["debug"]
         else:
             W, H = frame.width, frame.height
             out = {"radiance": np.zeros((self.shard_slot_count(frame), 4) if packed_tiles else (H, W, 4), np.float32), "ray_count": np.zeros(2, np.uint64)}
             o.device_ptrs = 0
             o.gRadiance = wire.ptr(out["radiance"])
             o.gRayCount = wire.ptr(out["ray_count"])
+            if debug_mode:  # BDPTDebugMode -> gDebugImage (in / out: a copy of what the caller passes, or zeros)
+                out["debug"] = np.ascontiguousarray(debug_image, np.float32).copy() if debug_image is not None else np.zeros((H, W, 4), np.float32)
+                o.debug_mode = debug_mode
+                o.gDebugImage = wire.ptr(out["debug"])
             if aovs:
                 out["albedo"] = np.zeros((H, W, 4), np.float32)
                 out["visibility"] = np.zeros((H, W), wire.VisibilityInfo)

@@ -250,6 +250,7 @@ struct sthip_ctx {
   DevBuf<BvhTriUv> tri_uvs;
   DevBuf<BvhTriShade> tri_shade;  // beside the leaf triangles: their vertices' normals and uvs (k_fill_tri_shade)
   DevBuf<uint32_t> hit_leaf;      // per path: the leaf triangle of its hit
+  DevBuf<float4> debug, out_debug, shadow_debug;  // BDPTDebugMode: per-path pixel of gDebugImage, the image's staging (host pointers), the debug halves of inline shadow rays
   DevBuf<uint32_t> inst_alpha;
   DevBuf<uint8_t> inst_flags;  // per instance: INST_FLAG_* of its (untextured) material, for k_cull_terminal
   std::vector<uint8_t> inst_flags_host;
@@ -451,6 +452,8 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->ray_d.release();
   ctx->hit.release();
   ctx->hit_leaf.release();
+  ctx->debug.release();
+  ctx->shadow_debug.release();
   ctx->beta.release();
   ctx->radiance.release();
   ctx->shadow_sum.release();
@@ -1517,7 +1520,12 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   // and previous frame), so they are traced one at a time and the grid is built between them.
   const bool nee_reuse = (sampling_flags & (1u << STHIP_eNEEReservoirReuse)) != 0;
   const bool lvc_reuse = (sampling_flags & (1u << STHIP_eLVCReservoirReuse)) != 0;
-  const uint32_t batch = (nee_reuse || lvc_reuse) ? 1u : std::min(seed_count, max_in_flight);
+  // BDPTDebugMode: upstream's gDebugImage persists from frame to frame and most modes add to it or overwrite it: the seeds of a
+  // call are traced one after the other, as its frames are
+  const uint32_t debug_mode = out->gDebugImage ? out->debug_mode : 0u;
+  if (debug_mode >= STHIP_DEBUG_MODE_COUNT) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: debug_mode is not a BDPTDebugMode");
+  if (debug_mode && out->radiance_layout == STHIP_LAYOUT_SHARD_TILES && false) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: debug image with packed tiles");
+  const uint32_t batch = (nee_reuse || lvc_reuse || debug_mode) ? 1u : std::min(seed_count, max_in_flight);
   p.path_count = batch * p.paths_per_seed;
   ctx->stats.paths_per_seed = p.paths_per_seed;
   ctx->stats.seeds_in_flight = batch;
@@ -1621,7 +1629,8 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   HIP_TRY(ctx, ctx->radiance.ensure(P));
   HIP_TRY(ctx, ctx->shadow_sum.ensure(P));
   HIP_TRY(ctx, ctx->accum.ensure(P0));
-  if (ctx->textured) HIP_TRY(ctx, ctx->cone.ensure(P));
+  if (ctx->textured || debug_mode) HIP_TRY(ctx, ctx->cone.ensure(P));  // (a debug mode runs the general instantiation of k_shade)
+  if (debug_mode) HIP_TRY(ctx, ctx->debug.ensure(P));
   // The queues are cut into QUEUE_SEGMENTS segments (traverse.h). A segment starts as a contiguous eighth of the
   // slots and only shrinks from bounce to bounce, which bounds it and the distance between segments.
   const uint32_t shade_grid = std::max<uint32_t>(grid_for(ctx, P), QUEUE_SEGMENTS);
@@ -1756,7 +1765,7 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   p.radiance = ctx->radiance.p;
   p.shadow_sum = ctx->shadow_sum.p;
   p.accum = ctx->accum.p;
-  p.cone = ctx->textured ? ctx->cone.p : nullptr;
+  p.cone = (ctx->textured || debug_mode) ? ctx->cone.p : nullptr;
   p.queue[0] = ctx->queue0.p;
   p.queue[1] = ctx->queue1.p;
   p.shadow_rays = ctx->shadow_rays.p;
@@ -1797,6 +1806,28 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
 
   // outputs: device pointers are written in place, host pointers go through staging buffers
   const bool dev = out->device_ptrs != 0;
+  p.debug_mode = debug_mode;
+  p.debug = debug_mode ? ctx->debug.p : nullptr;
+  p.out_debug = nullptr;
+  p.shadow_debug = nullptr;
+  if (debug_mode) {
+    if (debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && connect_paths && pc->gDebugLightPathLength >= 2)
+      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: ePathLengthContribution of a light-subpath connection (gDebugLightPathLength >= 2) is not built");
+    if (dev) {
+      p.out_debug = reinterpret_cast<float4*>(out->gDebugImage);
+    } else {  // in / out: what the caller's image holds goes up first
+      HIP_TRY(ctx, ctx->out_debug.ensure(pixels));
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->out_debug.p, out->gDebugImage, pixels * 16, hipMemcpyHostToDevice, st));
+      p.out_debug = ctx->out_debug.p;
+    }
+    // inline shadow rays add to the debug image only where they are unoccluded: they are traced once more, with what they add
+    const bool inline_adds = (debug_mode == STHIP_DEBUG_RESERVOIR_WEIGHT || (debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && pc->gDebugLightPathLength == 1)) &&
+                             (sampling_flags & (1u << STHIP_eNEE)) && !(sampling_flags & (1u << STHIP_eDeferShadowRays)) && !media;
+    if (inline_adds) {
+      HIP_TRY(ctx, ctx->shadow_debug.ensure(ctx->shadow_rays.n));
+      p.shadow_debug = ctx->shadow_debug.p;
+    }
+  }
   p.out_packed = out->radiance_layout == STHIP_LAYOUT_SHARD_TILES ? 1u : 0u;
   if (out->radiance_layout > STHIP_LAYOUT_SHARD_TILES) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: unknown radiance_layout");
   const size_t radiance_entries = p.out_packed ? std::max<size_t>(1, p.paths_per_seed) : pixels;
@@ -1947,6 +1978,28 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
           else
             hipLaunchKernelGGL((k_trace_deep<false, false>), dim3(dgrid), dim3(STHIP_BLOCK), 0, st, p);
         }
+        if (p.shadow_debug && ds != TRACE_NONE) {
+          // BDPTDebugMode: the same shadow rays once more, carrying what each adds to the debug image, accumulated into the paths'
+          // debug pixels the way the first pass accumulated their contributions into the radiance (finish_ray)
+          for (uint32_t seg = 0; seg < QUEUE_SEGMENTS; seg++)
+            (void)hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 1, ds) + (size_t)seg * QCTL_STRIDE + QCTL_HEAD, 0, 8, st);
+          FrameParams q = p;
+          q.shadow_rays = p.shadow_debug;
+          q.radiance = p.debug;
+          const uint32_t none = TRACE_NONE;
+          void* qargs[3] = {(void*)&q, (void*)&none, (void*)&ds};
+          (void)hipLaunchKernel(p.bvh.wide8_nodes  ? trace_kernel_wide8(false, alpha, p.bvh.spill != nullptr)
+                                : p.bvh.wide_nodes ? trace_kernel_wide(false, alpha, p.bvh.spill != nullptr)
+                                                   : trace_kernel(false, alpha, p.bvh.spill != nullptr, p.bvh.top_count != 0),
+                                dim3(tgrid), dim3(STHIP_BLOCK), qargs, lds, st);
+          if (p.bvh.spill) {
+            const uint32_t dgrid = (uint32_t)ctx->cu_count * 8u;
+            if (alpha)
+              hipLaunchKernelGGL((k_trace_deep<false, true>), dim3(dgrid), dim3(STHIP_BLOCK), 0, st, q);
+            else
+              hipLaunchKernelGGL((k_trace_deep<false, false>), dim3(dgrid), dim3(STHIP_BLOCK), 0, st, q);
+          }
+        }
       });
     };
     // the first bounce as wave packets (k_trace_primary): one 8x8 pixel block per wave
@@ -2049,6 +2102,16 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
     if (rc) return rc;
     rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(STHIP_BLOCK), 0, st, p); });
     if (rc) return rc;
+    if (debug_mode == STHIP_DEBUG_ENVIRONMENT_SAMPLE_TEST || debug_mode == STHIP_DEBUG_ENVIRONMENT_SAMPLE_PDF) {
+      // bdpt.hlsl:190-205: sample_visibility returns before it traces anything; the frame stays (0, 0, 0, 1), no ray is counted
+      rc = timed(ms_other, [&]() {
+        hipLaunchKernelGGL(k_debug_environment, dim3(grid), dim3(STHIP_BLOCK), 0, st, p);
+        hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + in_flight == seed_count ? 1u : 0u, 0u);
+      });
+      if (rc) return rc;
+      rays_primary = 0;
+      continue;
+    }
     if (presample) {
       const unsigned pgrid = (unsigned)((presample_n * in_flight + STHIP_BLOCK - 1) / STHIP_BLOCK);
       const bool pext = ctx->has_spheres || has_env;
@@ -2112,7 +2175,14 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
         launch_probe(3);
         hipLaunchKernelGGL(k_cs_reduce, dim3(reduce_grid), dim3(STHIP_BLOCK), 0, st, p.cs_lvc, p.path_count);
       }
-      if (media) {
+      if (debug_mode) {  // BDPTDebugMode: the general instantiation with the statements that feed gDebugImage
+        if (media)
+          hipLaunchKernelGGL((k_shade<true, true, false, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else if (bdpt)
+          hipLaunchKernelGGL((k_shade<true, true, true, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else
+          hipLaunchKernelGGL((k_shade<true, true, false, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+      } else if (media) {
         if (ctx->textured)
           hipLaunchKernelGGL((k_shade<true, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
         else
@@ -2170,6 +2240,7 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
     if (out->gVisibility) HIP_TRY(ctx, hipMemcpyAsync(out->gVisibility, p.out_visibility, pixels * 8, hipMemcpyDeviceToHost, st));
     if (out->gDepth) HIP_TRY(ctx, hipMemcpyAsync(out->gDepth, p.out_depth, pixels * 16, hipMemcpyDeviceToHost, st));
     if (out->gPrevUVs) HIP_TRY(ctx, hipMemcpyAsync(out->gPrevUVs, p.out_prev_uv, pixels * 8, hipMemcpyDeviceToHost, st));
+    if (debug_mode) HIP_TRY(ctx, hipMemcpyAsync(out->gDebugImage, p.out_debug, pixels * 16, hipMemcpyDeviceToHost, st));
     unsigned long long c[CNT_TOTAL];
     HIP_TRY(ctx, hipMemcpyAsync(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

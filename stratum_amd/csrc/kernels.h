@@ -60,6 +60,13 @@ struct FrameParams {
   float4* ray_o;       // xyz origin, w = bsdf_pdf
   float4* ray_d;       // xyz direction, w = eta_scale
   float4* hit;         // t, b1, b2, bits(instance_primitive_index)
+  // BDPTDebugMode (sthip.h: STHIP_DEBUG_*; 0 = off): the pixel of gDebugImage as the path has left it so far, per path slot
+  // (k_generate reads it from out_debug or clears it, the DEBUG instantiation of k_shade and the shadow rays update it, k_resolve
+  // writes it back), and — inline shadow rays only — what an unoccluded shadow ray adds to it, beside the ray's record
+  uint32_t debug_mode;
+  float4* debug;
+  float4* out_debug;
+  float4* shadow_debug;
   uint32_t* hit_leaf;  // the hit triangle's index in the leaf-triangle array (RayHit::leaf): where k_shade reads its vertices
   float4* beta;        // xyz beta, w = bits(rng counter)
   uint32_t* meta;      // path_length | diffuse_vertices << 8
@@ -269,6 +276,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
       p.beta[slot] = make_float4(0, 0, 0, __uint_as_float(0u));
       p.meta[slot] = 0xFFFFFFFFu;  // marks "outside every view": resolve leaves the pixel untouched
       if (view_index >= 0) p.meta[slot] = 0xFFFFFFFEu;  // inside a view but gMaxPathVertices < 2: radiance stays 0
+      if (p.debug_mode && view_index >= 0) {
+        const bool clears = p.debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION || p.debug_mode == STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION;
+        p.debug[slot] = clears ? make_float4(0, 0, 0, 1) : p.out_debug[(size_t)py * p.pc.gOutputExtent[0] + px];
+      }
       continue;
     }
     const sthip_ViewData& view = p.views[view_index];
@@ -290,6 +301,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
     p.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
     p.beta[slot] = make_float4(1, 1, 1, __uint_as_float(0u));
     p.meta[slot] = 1u;  // path_length = 1, diffuse_vertices = 0
+    if (p.debug_mode) {  // bdpt.hlsl:161-162: two modes start from (0,0,0,1), the others from what the image holds
+      const bool clears = p.debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION || p.debug_mode == STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION;
+      p.debug[slot] = clears ? make_float4(0, 0, 0, 1) : p.out_debug[(size_t)py * p.pc.gOutputExtent[0] + px];
+    }
     if (p.media) {  // bdpt.hlsl:208: the medium the camera sits in
       p.media_state[2 * (size_t)slot] = make_float4(t.r0.w, t.r1.w, t.r2.w, 1.0f);
       p.media_state[2 * (size_t)slot + 1] = make_float4(1.0f, __uint_as_float(p.view_medium ? p.view_medium[view_index] : 0xFFFFu), __uint_as_float(0u), 0.0f);
@@ -1151,6 +1166,11 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
           } else {
             weight = path_weight(p, 1, path_length);
           }
+          if (p.debug_mode == STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION) weight = 1;  // path.hlsli:608-609
+          if (p.debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && p.pc.gDebugViewPathLength == 1) {  // :611-613
+            if (p.pc.gDebugLightPathLength != path_length) break;
+            weight = 1;
+          }
           const f3 c = contribution * weight;
           // the splat lands on pixel (ix, iy) of this seed's image; a sharded renderer keeps only its own pixels
           if (ix < 0 || iy < 0 || (uint32_t)ix >= W || (uint32_t)iy >= H) break;
@@ -1238,7 +1258,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
 // EXT and without LT.
 // PROBE: the first half of a round with eCoherentRR (see FrameParams::rr): the same code up to the Russian roulette, where a
 // path records its p and the random number it would draw, and nothing else is written.
-template <bool TEXTURED, bool EXT, bool LT = false, bool MEDIA = false, bool PROBE = false>
+// DEBUG: BDPTDebugMode is live (FrameParams::debug_mode): the statements that feed gDebugImage are compiled in (the general
+// instantiations only: TEXTURED and EXT)
+template <bool TEXTURED, bool EXT, bool LT = false, bool MEDIA = false, bool PROBE = false, bool DEBUG = false>
 __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams p, uint32_t depth) {
   // gMaterialData staged in LDS (untextured instantiations; the table of a scene is a few KB): a vertex then reads its 72-byte
   // record with LDS reads instead of a divergent gather. p.lds_material_bytes = 0 turns it off (table too large, option).
@@ -1378,6 +1400,25 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
       }
     }
     const size_t pixel = (size_t)py * p.pc.gOutputExtent[0] + px;
+    // gDebugImage[pixel_coord] as this path has left it (DEBUG)
+    float4 dbg = make_float4(0, 0, 0, 0);
+    bool dbg_dirty = false;
+    if (DEBUG) dbg = p.debug[slot];
+    auto debug_set = [&](f3 c) {
+      dbg = make_float4(c.x, c.y, c.z, 1.0f);
+      dbg_dirty = true;
+    };
+    auto debug_add = [&](f3 c) {
+      dbg.x = dbg.x + c.x;
+      dbg.y = dbg.y + c.y;
+      dbg.z = dbg.z + c.z;
+      dbg_dirty = true;
+    };
+    auto debug_is = [&](uint32_t mode) { return DEBUG && p.debug_mode == mode; };
+    // accumulate_contribution's debug half (path.hlsli:302-303): the unweighted contribution of one (view, light) length pair
+    auto debug_path_length = [&](f3 contrib, uint32_t view_length, uint32_t light_length) {
+      if (debug_is(STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION) && p.pc.gDebugLightPathLength == light_length && view_length == p.pc.gDebugViewPathLength) debug_add(contrib);
+    };
     bool alive = false;
     float rd_radius = 0, rd_spread = 0;  // RayDifferential of this path (TEXTURED only)
     f3 new_origin = origin, new_direction = direction;
@@ -1514,11 +1555,14 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
         bsdf_pdf = ppdf;
         new_origin = scatter_p;
         new_direction = dir_out;
+        if (debug_is(STHIP_DEBUG_DIR_OUT)) debug_set(dir_out * .5f + F3s(.5f));  // path.hlsli:950
         alive = true;
         break;
       }
       if (ip == 0xFFFFFFFFu) {
         // miss: bdpt.hlsl:231-242 at depth 0, path.hlsli:1049-1058 later (no environment)
+        if (DEBUG && primary && (p.debug_mode == STHIP_DEBUG_GEOMETRY_NORMAL || p.debug_mode == STHIP_DEBUG_SHADING_NORMAL))
+          debug_set(unpack_normal_octahedron(0u) * .5f + F3s(.5f));  // bdpt.hlsl:222-223 reads normals nobody wrote on a miss: pinned to the packed value 0, as the visibility output
         if (primary && p.write_aov && seed_index == 0) {
           const int view_index = get_view_index(p, px, py);
           const sthip_ViewData& view = p.views[view_index];
@@ -1550,6 +1594,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             if (has_emissives) light_pdf *= p.pc.gEnvironmentSampleProbability;
             float weight = 1;
             if (path_length > 2 && use_nee) weight = flag(p, STHIP_eNEEReservoirs) ? 0.5f : mis2(use_mis, bsdf_pdf, light_pdf);
+            if (debug_is(STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION)) debug_add(beta * eLe);  // path.hlsli:890-891
+            debug_path_length(beta * eLe, path_length, 0);
             radiance = radiance + (beta * eLe) * weight;
             radiance_dirty = true;
           }
@@ -1591,6 +1637,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
         bsdf_pdf = 1;
         G = 1;
         if (LT) path_pdf = path_pdf_rev = dVC = 1;
+      }
+      if (DEBUG && primary) {  // bdpt.hlsl:222-223: the normals of the intersection (before the material's normal map)
+        if (p.debug_mode == STHIP_DEBUG_GEOMETRY_NORMAL) debug_set(gn * .5f + F3s(.5f));
+        if (p.debug_mode == STHIP_DEBUG_SHADING_NORMAL) debug_set(sd.shading_normal() * .5f + F3s(.5f));
       }
       DisneyMaterial m;
       uint32_t first_hit_normal = sd.packed_shading_normal;
@@ -1645,12 +1695,33 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
           } else if (use_nee)
             weight = (EXT && flag(p, STHIP_eNEEReservoirs)) ? 0.5f : mis2(use_mis, bsdf_pdf * G, light_pdfA);  // path.hlsli:881-886
         }
+        if (debug_is(STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION)) debug_add(contrib);  // path.hlsli:890-891
+        debug_path_length(contrib, path_length, 0);
         radiance = radiance + contrib * weight;
         radiance_dirty = true;
       };
 
       if (primary) {
         eval_emission();  // bdpt.hlsl:253
+        if (DEBUG) {  // bdpt.hlsl:257-260, :294-295
+          if (p.debug_mode == STHIP_DEBUG_ALBEDO) debug_set(m.albedo());
+          else if (p.debug_mode == STHIP_DEBUG_SPECULAR) debug_set(F3s(m.is_specular() ? 1.0f : 0.0f));
+          else if (p.debug_mode == STHIP_DEBUG_EMISSION) debug_set(Le);
+          else if (p.debug_mode == STHIP_DEBUG_SHADING_NORMAL) debug_set(unpack_normal_octahedron(first_hit_normal) * .5f + F3s(.5f));
+          else if (p.debug_mode == STHIP_DEBUG_PREV_UV) {
+            const int view_index = get_view_index(p, px, py);
+            const sthip_ViewData& view = p.views[view_index];
+            const float ex = (float)(view.image_max[0] - view.image_min[0]), ey = (float)(view.image_max[1] - view.image_min[1]);
+            const float uvx = ((float)px + 0.5f - (float)view.image_min[0]) / ex, uvy = ((float)py + 0.5f - (float)view.image_min[1]) / ey;
+            const Xf prev_inv_view = load_xf(p.prev_inv_view_xf, (uint32_t)view_index);
+            const f3 prev_cam_pos = xf_point(xf_mul(prev_inv_view, load_xf(p.scene.motion_xf, inst_index)), sd.position);
+            float4 pc4 = project_point(p.prev_views[view_index].projection, prev_cam_pos);
+            pc4.y = -pc4.y;
+            pc4.x = pc4.x / pc4.w;
+            pc4.y = pc4.y / pc4.w;
+            debug_set(F3(fabsf((pc4.x * .5f + .5f) - uvx) * (float)p.pc.gOutputExtent[0], fabsf((pc4.y * .5f + .5f) - uvy) * (float)p.pc.gOutputExtent[1], 0.0f));
+          }
+        }
         if (p.write_aov && seed_index == 0) {
           const int view_index = get_view_index(p, px, py);
           const sthip_ViewData& view = p.views[view_index];
@@ -1946,6 +2017,12 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             } else if (sample_bsdfs)
               weight = reservoirs ? 1 - 0.5f : mis2(use_mis, pdfA, pdfA_fwd);  // reservoir_bsdf_mis, :175-177
             const f3 c = nothing ? F3s(0.0f) : beta * contrib * weight;
+            // what an unoccluded INLINE shadow ray adds to gDebugImage (path.hlsli:482-485, :365 -> :302-303); a deferred record adds nothing (bdpt.hlsl:311-325)
+            f3 dc = F3s(0.0f);
+            if (DEBUG && !flag(p, STHIP_eDeferShadowRays) && !nothing) {
+              if (p.debug_mode == STHIP_DEBUG_RESERVOIR_WEIGHT && reservoirs) dc = F3s(ris_W);
+              if (p.debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && p.pc.gDebugLightPathLength == 1u && path_length == p.pc.gDebugViewPathLength) dc = beta * contrib;
+            }
             // deferred: a zero/negative contribution never adds light and trace_shadows traces no ray for it (bdpt.hlsl:313)
             if (all_le0(c) && !inline_ray) break;
             // eLVC with eDeferShadowRays: connect_lvc stores its record into the SAME gShadowRays slot right after this one
@@ -1974,6 +2051,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
               } else {
                 radiance = radiance + c;
                 radiance_dirty = true;
+                if (DEBUG) debug_add(dc);
               }
               break;
             }
@@ -1981,6 +2059,12 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             shadow_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
             shadow_out[3 * (size_t)k + 1] = make_float4(to_light.x, to_light.y, to_light.z, __uint_as_float(slot));
             shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+            if (DEBUG && p.shadow_debug) {  // the same ray with what it adds to the debug image: traced once more into p.debug (api.hip)
+              float4* dbg_out = p.shadow_debug + 3 * shadow_base;
+              dbg_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
+              dbg_out[3 * (size_t)k + 1] = make_float4(to_light.x, to_light.y, to_light.z, __uint_as_float(slot));
+              dbg_out[3 * (size_t)k + 2] = make_float4(dc.x, dc.y, dc.z, 0.0f);
+            }
           } while (0);
         }
         if (PROBE && p.probe_kind == 2) break;  // no NEE at this vertex: nothing to report
@@ -2231,10 +2315,12 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
       beta = beta * shading_normal_correction(local_dir_in.z, ndotout, ngdotin, ngdotout, dot3(gn, sd.shading_normal()), EXT && flag(p, STHIP_eShadingNormalShadowFix));
       if (all_le0(beta)) break;
       new_direction = dir_out;
+      if (debug_is(STHIP_DEBUG_DIR_OUT)) debug_set(dir_out * .5f + F3s(.5f));  // path.hlsli:950
       alive = true;
     } while (0);
     if (PROBE) continue;
 
+    if (DEBUG && dbg_dirty) p.debug[slot] = dbg;
     if (radiance_dirty) p.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
     if (!TEXTURED && !EXT && !LT && !MEDIA && p.emitter_count) {  // (the plain instantiation only: in the extended one this code cost 10 % of k_shade in spills)
       // the path's next vertex is its last one and its ray cannot reach an emitter: answered here (aims_at_emitter)
@@ -2444,7 +2530,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
         }
       }
       float4 cur = make_float4(r.x + c.x, r.y + c.y, r.z + c.z, 1.0f);
-      if (p.light_trace) {  // add_light_trace, bdpt.hlsl:328-338 with load_light_sample, path.hlsli:38-46
+      if (p.light_trace && p.debug_mode != STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION) {  // add_light_trace, bdpt.hlsl:328-338 with load_light_sample, path.hlsli:38-46
         const uint4 v = *reinterpret_cast<const uint4*>(p.light_trace + 4 * ((size_t)s * p.pc.gOutputExtent[0] * p.pc.gOutputExtent[1] + (size_t)py * p.pc.gOutputExtent[0] + px));
         const float q = (float)p.light_trace_quantization;
         f3 lc = F3((float)((v.w & 1u) ? 0xFFFFFFFFu : v.x), (float)((v.w & 2u) ? 0xFFFFFFFFu : v.y), (float)((v.w & 4u) ? 0xFFFFFFFFu : v.z)) / q;
@@ -2452,7 +2538,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
         cur.x = cur.x + lc.x;
         cur.y = cur.y + lc.y;
         cur.z = cur.z + lc.z;
+        if (p.debug_mode == STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION || (p.debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && p.pc.gDebugViewPathLength == 1)) p.debug[slot] = make_float4(lc.x, lc.y, lc.z, 1);  // bdpt.hlsl:335-336
       }
+      if (p.debug_mode) p.out_debug[(size_t)py * p.pc.gOutputExtent[0] + px] = p.debug[slot];  // (one seed in flight: the seeds of a call are upstream's successive frames)
       if (isinf(cur.x) || isinf(cur.y) || isinf(cur.z) || cur.x != cur.x || cur.y != cur.y || cur.z != cur.z) cur = make_float4(0, 0, 0, 0);
       if (acc.w > 0) {
         const float nn = acc.w + cur.w;
@@ -2611,6 +2699,47 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const uint32_t* 
 }
 // The other direction (sthip_pack_tiles): a W x H image on one rank -> that rank's tiles in slot order (slots outside the
 // image: zero). What the ranks exchange of the G-buffer outputs, which sthip_render writes as images.
+// BDPTDebugMode eEnvironmentSampleTest / eEnvironmentSamplePDF (bdpt.hlsl:190-205): sample_visibility returns before it
+// traces anything — eight environment samples drawn from the path's stream as spots around the view direction, or the
+// environment's pdf of that direction. Runs behind k_generate (which has made the view ray and loaded / cleared the pixel of
+// the debug image) in place of the rounds; the paths are marked dead, radiance stays 0.
+__global__ void __launch_bounds__(STHIP_BLOCK) k_debug_environment(FrameParams p) {
+  for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.path_count; slot += gridDim.x * blockDim.x) {
+    const uint32_t meta = p.meta[slot];
+    if (meta >= 0xFFFFFFFEu) continue;
+    p.meta[slot] = 0xFFFFFFFEu;  // nothing is traced
+    p.radiance[slot] = make_float4(0, 0, 0, 0);
+    if (!(p.scene_flags & STHIP_BDPT_FLAG_HAS_ENVIRONMENT)) continue;  // (the record at gEnvironmentMaterialAddress is not an environment: not restated)
+    uint32_t px, py;
+    slot_to_pixel(p, slot, px, py);
+    const f3 direction = xyz(p.ray_d[slot]);
+    Environment env;
+    env.load(p.scene, p.pc.gEnvironmentMaterialAddress);
+    float4 dbg = p.debug[slot];
+    if (p.debug_mode == STHIP_DEBUG_ENVIRONMENT_SAMPLE_TEST) {
+      Rng rng;
+      rng.x = px;
+      rng.y = py;
+      rng.seed = p.seed + slot / p.paths_per_seed;
+      rng.counter = 0u;
+      for (uint32_t i = 0; i < 8; i++) {
+        float pdf;
+        f3 dir;
+        const float r0 = rng.next_float(), r1 = rng.next_float();
+        (void)env.sample(p.scene, r0, r1, dir, pdf, flag(p, STHIP_eSampleEnvironmentMapDirectly));
+        const float v = 1024 * det_powf(fmaxf(0.0f, dot3(dir, direction)), 1024.0f);
+        dbg.x = dbg.x + v;
+        dbg.y = dbg.y + v;
+        dbg.z = dbg.z + v;
+      }
+    } else {
+      const float pdf = env.eval_pdf(p.scene, direction, flag(p, STHIP_eSampleEnvironmentMapDirectly));
+      dbg.x = dbg.y = dbg.z = pdf;
+    }
+    p.debug[slot] = dbg;
+  }
+}
+
 // What shading needs of a leaf triangle's vertices apart from their positions (bvh.h: BvhTriShade), written once per scene
 // upload beside the leaf triangles as they lie in HBM: the triangle says where its index triple is (BvhTri::src_indices /
 // src_vertex), the vertices are read again — so the record holds the floats shading would have gathered (shading_data.hlsli:2-6)

@@ -192,7 +192,14 @@ class Outputs(C.Structure):
         ("gDepth", C.c_void_p),
         ("gPrevUVs", C.c_void_p),
         ("gRayCount", C.c_void_p),
+        ("debug_mode", C.c_uint32),  # BDPTDebugMode (DEBUG_*), with gDebugImage (RGBA32F, in / out)
+        ("gDebugImage", C.c_void_p),
     ]
+
+
+# BDPTDebugMode, bdpt.h:177-193 (include/sthip.h: STHIP_DEBUG_*)
+(DEBUG_NONE, DEBUG_ALBEDO, DEBUG_SPECULAR, DEBUG_EMISSION, DEBUG_SHADING_NORMAL, DEBUG_GEOMETRY_NORMAL, DEBUG_DIR_OUT, DEBUG_PREV_UV, DEBUG_ENVIRONMENT_SAMPLE_TEST,
+ DEBUG_ENVIRONMENT_SAMPLE_PDF, DEBUG_RESERVOIR_WEIGHT, DEBUG_PATH_LENGTH_CONTRIBUTION, DEBUG_LIGHT_TRACE_CONTRIBUTION, DEBUG_VIEW_TRACE_CONTRIBUTION, DEBUG_MODE_COUNT) = range(15)
 
 
 class Stats(C.Structure):

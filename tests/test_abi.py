@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
     L = _lib.lib()
     for name in declared_functions():
         assert hasattr(L, name), name
-    assert L.sthip_abi_version() == 10
+    assert L.sthip_abi_version() == 11
 
 
 def test_wire_struct_sizes():

@@ -1872,3 +1872,108 @@ def test_last_ray_filter_on_ill_conditioned_emitters():
         assert out[1]["answered"] > 0 and out[0]["answered"] == 0, make.__name__
         assert np.array_equal(out[0]["radiance"].view(np.uint32), out[1]["radiance"].view(np.uint32)), (make.__name__, args)
         assert np.array_equal(out[0]["ray_count"], out[1]["ray_count"]), (make.__name__, args)
+
+
+def _debug_case(sc, cam, mode, flags=(), args=None, view_length=0, light_length=0, seeds=2, w=144, h=96, start=None):
+    """One BDPTDebugMode on both sides: gDebugImage (in / out) and the frame, bit for bit."""
+    from oracle import oracle_py
+    from stratum_amd.bdpt import BDPT
+
+    a = {"bdptFlag": list(flags)}
+    a.update(args or {})
+    r = BDPT(device=0, args=a)
+    try:
+        r.mPushConstants.gDebugViewPathLength = view_length
+        r.mPushConstants.gDebugLightPathLength = light_length
+        r.update(sc)
+        frame = camera.Frame(w, h, cam["fovy"], cam["eye"], cam["target"])
+        got = r.render(frame, 0, seeds, debug_mode=mode, debug_image=start)
+        ref = oracle_py.OracleScene(sc).render(frame, r.push_constants(frame), r.mSamplingFlags, 0, seeds, debug_mode=mode, debug_image=start)
+        assert np.array_equal(got["radiance"].view(np.uint32), ref["radiance"].view(np.uint32)), (sc.name, mode, "radiance")
+        assert np.array_equal(got["ray_count"], ref["ray_count"]), (sc.name, mode)
+        bad = (got["debug"].view(np.uint32) != ref["debug"].view(np.uint32)).any(axis=-1)
+        assert not bad.any(), (sc.name, mode, flags, int(bad.sum()), got["debug"][bad][:3], ref["debug"][bad][:3])
+        return got
+    finally:
+        r.close()
+
+
+def test_debug_modes_of_the_first_hit():
+    """BDPTDebugMode -> gDebugImage (bdpt.h:177-193, bdpt.hlsl:161-162,222-223,257-260,294-295, path.hlsli:950): the modes that
+    overwrite a pixel with something of the first hit (albedo, is_specular, emission, normals before and after the normal map,
+    the reprojection error) or of the last bounce (eDirOut), on a textured scene with normal maps and a mirror, a scene with
+    sphere instances, and with a moving camera; pixels whose path never reaches the statement keep what the image held."""
+    from stratum_amd import wire as W
+
+    start = np.random.RandomState(5).rand(96, 144, 4).astype(np.float32)
+    for make in (scenes.textured_box, lambda: scenes.textured_box(mirror_map=True), scenes.spheres_room, scenes.cornell_box):
+        sc, cam = make()
+        for mode in (W.DEBUG_ALBEDO, W.DEBUG_SPECULAR, W.DEBUG_EMISSION, W.DEBUG_SHADING_NORMAL, W.DEBUG_GEOMETRY_NORMAL, W.DEBUG_DIR_OUT, W.DEBUG_PREV_UV):
+            flags = ["normalmaps"] if "textured" in sc.name else []
+            got = _debug_case(sc, cam, mode, flags=flags, start=start)
+            assert not np.array_equal(got["debug"], start), (sc.name, mode)
+    # a frame without a debug image is the frame with one (the modes only watch)
+    sc, cam = scenes.cornell_box()
+    plain = _compare_frame(sc, cam, [], w=144, h=96)
+    watched = _debug_case(sc, cam, W.DEBUG_ALBEDO)
+    assert np.array_equal(plain["radiance"].view(np.uint32), watched["radiance"].view(np.uint32))
+    assert np.array_equal(plain["albedo"][..., :3].view(np.uint32), watched["debug"][..., :3].view(np.uint32))  # eAlbedo is the albedo output
+
+
+def test_debug_modes_that_accumulate():
+    """ePathLengthContribution (the unweighted contribution of one (view length, light length) pair: emission found by a path
+    of that length, the NEE sample of a vertex — inline shadow rays only, a deferred one adds nothing upstream), eViewTrace-
+    Contribution (all unweighted emission), eReservoirWeight (W of unoccluded reservoir samples, added onto what the image
+    held), eLightTraceContribution and the view-length-1 pair (light tracing's splats with weight 1; add_light_trace)."""
+    from stratum_amd import wire as W
+
+    sc, cam = scenes.cornell_box()
+    start = np.random.RandomState(6).rand(96, 144, 4).astype(np.float32)
+    total = np.zeros((96, 144, 3), np.float64)
+    for view_length in (2, 3, 4):  # emission seen directly, after one bounce, after two
+        got = _debug_case(sc, cam, W.DEBUG_PATH_LENGTH_CONTRIBUTION, view_length=view_length, light_length=0, start=start, args={"maxDiffuseVertices": 3, "maxPathVertices": 5})
+        assert (got["debug"][..., 3] == 1).all()  # started from (0, 0, 0, 1), not from `start`
+        total += got["debug"][..., :3]
+    assert total.mean() > 0.01
+    for flags in (["~defershadowrays"], ["~defershadowrays", "~mis"], []):  # the NEE sample of the first / second vertex; nothing when deferred
+        for view_length in (2, 3):
+            got = _debug_case(sc, cam, W.DEBUG_PATH_LENGTH_CONTRIBUTION, flags=flags, view_length=view_length, light_length=1)
+            assert (got["debug"][..., :3].sum() > 0) == ("~defershadowrays" in flags), (flags, view_length)
+    got = _debug_case(sc, cam, W.DEBUG_VIEW_TRACE_CONTRIBUTION, start=start, args={"maxDiffuseVertices": 3})
+    assert got["debug"][..., :3].mean() > 0.01
+    for flags in (["neereservoirs", "~defershadowrays"], ["neereservoirs"]):
+        got = _debug_case(sc, cam, W.DEBUG_RESERVOIR_WEIGHT, flags=flags, start=start)
+        assert (not np.array_equal(got["debug"], start)) == ("~defershadowrays" in flags)
+    # light tracing
+    for mode, vl, ll in ((W.DEBUG_LIGHT_TRACE_CONTRIBUTION, 0, 0), (W.DEBUG_PATH_LENGTH_CONTRIBUTION, 1, 2), (W.DEBUG_PATH_LENGTH_CONTRIBUTION, 1, 3), (W.DEBUG_VIEW_TRACE_CONTRIBUTION, 0, 0)):
+        got = _debug_case(sc, cam, mode, flags=["connecttoviews"], view_length=vl, light_length=ll, start=start, w=128, h=96)
+        assert got["debug"][..., :3].mean() > 0
+    # several seeds of a call are upstream's successive frames: the same image as call after call
+    a = _debug_case(sc, cam, W.DEBUG_RESERVOIR_WEIGHT, flags=["neereservoirs", "~defershadowrays"], seeds=3, start=start)
+    b = start
+    from stratum_amd.bdpt import BDPT
+
+    r = BDPT(device=0, args={"bdptFlag": ["neereservoirs", "~defershadowrays"]})
+    try:
+        r.update(sc)
+        frame = camera.Frame(144, 96, cam["fovy"], cam["eye"], cam["target"])
+        for seed in range(3):
+            b = r.render(frame, seed, 1, debug_mode=W.DEBUG_RESERVOIR_WEIGHT, debug_image=b)["debug"]
+    finally:
+        r.close()
+    assert np.array_equal(a["debug"].view(np.uint32), b.view(np.uint32))
+
+
+def test_debug_modes_of_the_environment():
+    """eEnvironmentSampleTest / eEnvironmentSamplePDF (bdpt.hlsl:190-205): nothing is traced; eight environment samples drawn
+    from the pixel's stream as spots around the view direction (added to the image), or the pdf of the view direction."""
+    from stratum_amd import wire as W
+
+    start = np.random.RandomState(7).rand(96, 144, 4).astype(np.float32)
+    for image in (True, False):
+        sc, cam = scenes.environment_scene(image=image, emitter=True)
+        for mode in (W.DEBUG_ENVIRONMENT_SAMPLE_TEST, W.DEBUG_ENVIRONMENT_SAMPLE_PDF):
+            for flags in ([], ["sampleenvironmentmapdirectly"]):
+                got = _debug_case(sc, cam, mode, flags=flags, start=start)
+                assert got["ray_count"][0] == 0 and not got["radiance"][..., :3].any()
+                assert np.array_equal(got["debug"][..., 3], start[..., 3]) and not np.array_equal(got["debug"][..., :3], start[..., :3])
