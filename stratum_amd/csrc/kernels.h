@@ -1167,10 +1167,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
             weight = path_weight(p, 1, path_length);
           }
           if (p.debug_mode == STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION) weight = 1;  // path.hlsli:608-609
-          if (p.debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && p.pc.gDebugViewPathLength == 1) {  // :611-613
-            if (p.pc.gDebugLightPathLength != path_length) break;
-            weight = 1;
-          }
+          if (p.debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && p.pc.gDebugViewPathLength == 1)  // :611-613: only the asked light length adds, unweighted (its visibility ray has been traced either way, :588)
+            weight = p.pc.gDebugLightPathLength == path_length ? 1.0f : 0.0f;
           const f3 c = contribution * weight;
           // the splat lands on pixel (ix, iy) of this seed's image; a sharded renderer keeps only its own pixels
           if (ix < 0 || iy < 0 || (uint32_t)ix >= W || (uint32_t)iy >= H) break;

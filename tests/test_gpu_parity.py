@@ -1917,7 +1917,8 @@ def test_debug_modes_of_the_first_hit():
     plain = _compare_frame(sc, cam, [], w=144, h=96)
     watched = _debug_case(sc, cam, W.DEBUG_ALBEDO)
     assert np.array_equal(plain["radiance"].view(np.uint32), watched["radiance"].view(np.uint32))
-    assert np.array_equal(plain["albedo"][..., :3].view(np.uint32), watched["debug"][..., :3].view(np.uint32))  # eAlbedo is the albedo output
+    hit = plain["visibility"]["instance_primitive_index"] != wire.MISS  # eAlbedo is the albedo output where something was hit (a miss writes albedo 1 and leaves the debug image alone)
+    assert np.array_equal(plain["albedo"][..., :3][hit].view(np.uint32), watched["debug"][..., :3][hit].view(np.uint32)) and not watched["debug"][~hit].any()
 
 
 def test_debug_modes_that_accumulate():
