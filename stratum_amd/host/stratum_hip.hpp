@@ -821,6 +821,7 @@ class BDPT {
     std::vector<VisibilityInfo> mVisibility;
     std::vector<DepthInfo> mDepth;
     uint64_t mRayCount[2] = {0, 0};
+    std::vector<float> mDebugImage;  // gDebugImage (BDPT.cpp:560): RGBA32F, only with a debug mode
   };
 
   explicit BDPT(Node& node, int device = 0) : mNode(node) {
@@ -1025,11 +1026,24 @@ class BDPT {
     o.gDepth = fr.mDepth.data();
     o.gPrevUVs = fr.mPrevUVs.data();
     o.gRayCount = fr.mRayCount;
+    if (mDebugMode != STHIP_DEBUG_NONE) {  // BDPT.cpp:526-541 (gDebugMode), :560: the image persists from frame to frame
+      if (mDebugImage.size() != 4 * n) mDebugImage.assign(4 * n, 0.f);
+      o.debug_mode = mDebugMode;
+      o.gDebugImage = mDebugImage.data();
+    }
     (void)sthip_set_stream(mCtx, cb.hip_stream);
     if (sthip_render(mCtx, &pc, mSamplingFlags, scene_flags, &f, mFrameNumber, seed_count, &o) != STHIP_OK)
       throw std::runtime_error(std::string("sthip_render: ") + sthip_last_error(mCtx));
+    if (mDebugMode != STHIP_DEBUG_NONE) fr.mDebugImage = mDebugImage;
     finish_frame(std::move(fr), fs, seed_count);
   }
+  // BDPTDebugMode (bdpt.h:177-193; the inspector's "Debug mode", BDPT.cpp:253-262) with mPushConstants.gDebugViewPathLength /
+  // gDebugLightPathLength; the image starts from zero when the mode or the frame size changes
+  void set_debug_mode(uint32_t mode) {
+    if (mode != mDebugMode) mDebugImage.clear();
+    mDebugMode = mode < STHIP_DEBUG_MODE_COUNT ? mode : (uint32_t)STHIP_DEBUG_NONE;
+  }
+  uint32_t debug_mode() const { return mDebugMode; }
 
  protected:
   uint32_t frame_number() const { return mFrameNumber; }
@@ -1057,7 +1071,7 @@ class BDPT {
     tm.exposure = mExposure;
     tm.exposure_alpha = mExposureAlpha;       // gExposureAlpha, BDPT.cpp:51,192,307
     tm.exposure_state = mTonemapState;        // mPrevFrame->mTonemapMax bytes 16..39 -> gPrevMax, BDPT.cpp:810-811
-    tm.gInput = fr.mRadiance.data();
+    tm.gInput = fr.mDebugImage.size() == 4 * n ? fr.mDebugImage.data() : fr.mRadiance.data();  // BDPT.cpp:764: with a debug mode the debug image is what is shown
     tm.gAlbedo = fr.mAlbedo.data();
     tm.gOutput = fr.mTonemapResult.data();
     tm.out_max = fr.mTonemapMax;
@@ -1089,6 +1103,8 @@ class BDPT {
   uint32_t mSamplingFlags = 0;
   BDPTPushConstants mPushConstants;
   uint32_t mFrameNumber = 0;
+  uint32_t mDebugMode = STHIP_DEBUG_NONE;
+  std::vector<float> mDebugImage;
   uint32_t mTonemapMode = STHIP_TONEMAP_RAW;  // BDPT.cpp:48
   float mExposure = 0;
   float mExposureAlpha = 0;
