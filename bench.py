@@ -101,6 +101,7 @@ def parse_args():
     ap.add_argument("--radiance-only", action="store_true", help="do not write the G-buffer AOVs (not the headline configuration)")
     ap.add_argument("--bdpt-flag", action="append", default=[], help="as the reference's --bdptFlag (e.g. connecttolightpaths, ~nee); not the headline configuration")
     ap.add_argument("--max-diffuse-vertices", type=int, default=None)
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="sthip_set_option before the scene upload (e.g. wide_bvh=3: the 8-wide walk); recorded in config.options; not the headline configuration")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): a step renders N seeds of the frame on N GPUs (per-GPU work fixed); strong: a step renders --strong-seeds seeds whatever N (total work fixed)")
     ap.add_argument("--strong-seeds", type=int, default=8, help="seeds per step in --scaling strong (BASELINE.md row 3b's 8 by default)")
@@ -266,6 +267,11 @@ def main():
     if args.max_diffuse_vertices is not None:
         bargs["maxDiffuseVertices"] = args.max_diffuse_vertices
     r = BDPT(device=local_rank, args=bargs)
+    options = {}
+    for kv in args.option:
+        k, v = kv.split("=", 1)
+        options[k] = int(v)
+        r.set_option(k, int(v))
     r.update(sc)
     # The headline traces EVERY ray. The library's default answers the last ray of a path from the emitters' bounds when it cannot
     # reach one (sthip.h "answer_last_rays": same frames, same gRayCount, 1/5 of the rays of this workload never walk the tree);
@@ -779,6 +785,7 @@ def main():
                 "exchange_bytes_per_step": exchange_bytes_per_step,  # what reaches rank 0 per step: every rank's tiles of every output
                 "exchange_alone_ms_per_step": round(exchange_ms, 4) if world > 1 else None,  # gather + assembly of one step's tiles, not overlapped (in the timed region it runs behind the next step's render)
                 "seeds_per_step": seeds_per_step,
+                "options": options or None,  # sthip_set_option overrides of this run (none: the library's defaults, answer_last_rays aside)
                 "world_size": world_seen,
                 "backend": backend_seen,
                 "devices": devices,
