@@ -2517,19 +2517,21 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s) {
     }
   } else if (kind == STHIP_CEILING_NODE_GATHER_TABLE || kind == STHIP_CEILING_NODE_GATHER_L2 || kind == STHIP_CEILING_NODE_GATHER_L1) {
     if (!ctx->has_scene || !ctx->bvh_nodes) return fail(ctx, STHIP_ERR_NO_SCENE, "sthip_measure_ceiling: the node-gather ceilings read the resident acceleration structure: upload a scene first");
-    // the nodes k_trace walks: the 48-byte binary ones (3 loads) or, with the wide walk on, the 64-byte 4-wide ones (4 loads)
-    const bool wide = ctx->bvh.wide_nodes != nullptr;
-    const uint32_t nb = wide ? (uint32_t)sizeof(WideNode) : BVH_NODE_BYTES;
-    uint32_t count = (uint32_t)std::min<uint64_t>(wide ? ctx->wide_node_count : ctx->bvh_nodes, 0xFFFFFFFFull);
+    // the nodes k_trace walks: the 48-byte binary ones (3 loads), the 64-byte 4-wide ones (4 loads) or the 80-byte 8-wide ones (5 loads)
+    const bool wide8 = ctx->bvh.wide8_nodes != nullptr, wide = !wide8 && ctx->bvh.wide_nodes != nullptr;
+    const uint32_t nb = wide8 ? (uint32_t)sizeof(Wide8Node) : wide ? (uint32_t)sizeof(WideNode) : BVH_NODE_BYTES;
+    uint32_t count = (uint32_t)std::min<uint64_t>(wide8 ? ctx->wide8_node_count : wide ? ctx->wide_node_count : ctx->bvh_nodes, 0xFFFFFFFFull);
     if (kind == STHIP_CEILING_NODE_GATHER_L2) count = std::min<uint32_t>(count, (2u << 20) / nb);
     if (kind == STHIP_CEILING_NODE_GATHER_L1) count = std::min<uint32_t>(count, (16u << 10) / nb);
     const uint32_t iterations = 64;
     DevBuf<float> sink;
     HIP_TRY(ctx, sink.ensure((size_t)blocks * 256));
-    bytes = (double)(wide ? sizeof(WideNode) : sizeof(BvhNodePacked)) * (double)blocks * 256.0 * iterations * CEIL_UNROLL;
+    bytes = (double)(wide8 ? sizeof(Wide8Node) : wide ? sizeof(WideNode) : sizeof(BvhNodePacked)) * (double)blocks * 256.0 * iterations * CEIL_UNROLL;
     for (int rep = 0; rep < 4; rep++) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-      if (wide)
+      if (wide8)
+        hipLaunchKernelGGL(k_ceiling_node_gather<5>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->wide8_nodes.p), count, nb, iterations, sink.p);
+      else if (wide)
         hipLaunchKernelGGL(k_ceiling_node_gather<4>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->wide_nodes.p), count, nb, iterations, sink.p);
       else
         hipLaunchKernelGGL(k_ceiling_node_gather<3>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->nodes.p), count, nb, iterations, sink.p);

@@ -1407,14 +1407,26 @@ struct Wide8Builder {
       items += count;
     }
     out[w] = wn;
+    // (stack entries a walk can hold below this node: a group per level; entering an instance leaves the rest of the node
+    // group, the rest of the entry group and the exit sentinel behind, then takes a group per level of its bottom level)
     uint32_t below = 0, rank = 0;
+    if (top)
+      for (int s = 0; s < 8; s++)
+        if (at[s] >= 0 && ch[at[s]].kind == 1) {
+          const uint32_t k = ch[at[s]].ref & 0xFFFFu;
+          const TlasEntry& e = st->entries[k];
+          if (e.identity == TLAS_ENTRY_IDENTITY || e.identity == TLAS_ENTRY_TRANSFORMED) below = std::max(below, 2u + (k < st->wide8_height.size() ? st->wide8_height[k] : blas_height));
+        }
     for (int s = 0; s < 8; s++) {
       if (at[s] < 0 || is_leaf(ch[at[s]])) continue;
       const Wide8Child& c = ch[at[s]];
       const uint32_t cw = wn.child_base + rank++;
       if (c.kind == 2) {  // the merged mesh's root, copied: its own children and items stay where they are
         out[cw] = out[c.ref];
-        below = std::max(below, blas_height);
+        uint32_t h = blas_height;
+        for (size_t k = 0; k < st->wide8_root.size(); k++)
+          if (st->wide8_root[k] == c.ref && k < st->wide8_height.size()) h = st->wide8_height[k];
+        below = std::max(below, h);
       } else {
         below = std::max(below, fill(cw, c.ref, top, blas_height));
       }
@@ -1430,6 +1442,7 @@ void build_wide8_bvh(BuiltBvh& out) {
   out.wide8_root = BVH_INVALID_REF;
   out.wide8_stack_depth = 0;
   out.top.wide8_root.assign(out.entries.size(), BVH_INVALID_REF);
+  out.top.wide8_height.assign(out.entries.size(), 0);
   out.top.wide8_blas_nodes = 0;
   out.top.wide8_blas_height = 0;
   if (out.dev_nodes || out.embedded || out.root_ref == BVH_INVALID_REF || out.nodes.empty()) return;
@@ -1464,6 +1477,7 @@ void build_wide8_bvh(BuiltBvh& out) {
       it = of_root.emplace(e.root, std::make_pair(w, h)).first;
     }
     out.top.wide8_root[k] = it->second.first;
+    out.top.wide8_height[k] = it->second.second;
     blas_height = std::max(blas_height, it->second.second);
   }
   if (!wb.ok || nodes.size() >= (1u << 24)) return;
@@ -1512,7 +1526,7 @@ bool build_wide8_top(const TopLevelState& st, const BvhNode* tlas, uint32_t tlas
     for (size_t k = 0; k < entries.size(); k++)
       if (st.wide8_root[k] != BVH_INVALID_REF) entries[k].root = st.wide8_root[k];
     wide8_root = st.wide8_root[0];
-    wide8_stack_depth = st.wide8_blas_height + 2;  // a group per level at most, the sentinel at the bottom, the spare slot of the speculative push
+    wide8_stack_depth = (st.wide8_height.empty() ? st.wide8_blas_height : st.wide8_height[0]) + 2;  // a group per level at most, the sentinel at the bottom, the spare slot of the speculative push
     return true;
   }
   if ((root_ref & BVH_LEAF_BIT) || root_ref < tlas_base) return false;
@@ -1526,9 +1540,9 @@ bool build_wide8_top(const TopLevelState& st, const BvhNode* tlas, uint32_t tlas
   const uint32_t top_height = wb.fill(w, root_ref, true, st.wide8_blas_height);
   if (!wb.ok || nodes.size() >= (1u << 24) || entries.size() >= 0x7FFFFFFFu) return false;
   wide8_root = w;
-  // per level of the top level one group; entering an instance leaves the rest of the node group, the rest of the entry group
-  // and the exit sentinel; then a group per level of the bottom level; the sentinel at the bottom, the spare slot
-  wide8_stack_depth = top_height + 3 + st.wide8_blas_height + 2;
+  // (fill() has counted what lies below every node, instances and the spliced mesh included) + the sentinel at the bottom and
+  // the spare slot of the speculative push
+  wide8_stack_depth = top_height + 2;
   return true;
 }
 

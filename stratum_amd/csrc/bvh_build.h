@@ -33,6 +33,7 @@ struct TopLevelState {
   // the 8-wide form (build_wide8_bvh): the bottom levels' nodes are [0, wide8_blas_nodes) of the wide8 array and stay; a
   // transforms-only update makes the top level's nodes again behind them (build_wide8_top)
   std::vector<uint32_t> wide8_root;  // per entry: the wide8 node its bottom level starts at (BVH_INVALID_REF: none)
+  std::vector<uint32_t> wide8_height;  // ... and that bottom level's height in wide8 nodes
   uint32_t wide8_blas_nodes = 0;
   uint32_t wide8_blas_height = 0;
 };
