@@ -77,7 +77,7 @@ def run(cases=60, seed=1):
             if rng.integers(3) == 0: opts["max_paths_in_flight"] = int(rng.integers(1, 4)) * W * H
             if rng.integers(4) == 0: opts["fuse_trace"] = 0
             if rng.integers(4) == 0: opts["packet_primary"] = 0
-            if rng.integers(4) == 0 and kind in ("cornell", "textured", "atrium", "forest"): opts["bvh_builder"] = 1
+            if rng.integers(4) == 0 and kind in ("cornell", "textured", "atrium", "forest", "foliage"): opts["bvh_builder"] = 1  # (alpha-masked scenes too: the uvs of the alpha test are filled on the device)
             if rng.integers(4) == 0: opts["treetop"] = 1  # the LDS treetop (off by default)
             if "bvh_builder" in opts:
                 opts["lbvh_algorithm"] = int(rng.integers(2))
@@ -87,6 +87,11 @@ def run(cases=60, seed=1):
             opts["cull_terminal"] = seed0 & 1  # k_cull_terminal in front of k_shade (without drawing: the cases of a seed stay the same)
             opts["answer_last_rays"] = (seed0 >> 1) & 1  # last rays answered from the emitters' bounds
             if os.environ.get("STHIP_FUZZ_WIDE") is not None: opts["wide_bvh"] = int(os.environ["STHIP_FUZZ_WIDE"])  # the 4-wide walk forced on / off (without drawing: the cases of a seed stay the same)
+            elif (seed0 >> 2) & 1: opts["wide_bvh"] = 3  # the 8-wide compressed walk (host-built trees; the others fall back to the 4-wide one)
+            if (seed0 >> 3) & 1: opts["tri_min_lanes"] = 1 + (seed0 >> 5) % 24
+            # BDPTDebugMode in about a fifth of the cases: gDebugImage must come out of both sides bit for bit, started from noise
+            dm = (seed0 >> 4) & 63
+            debug_mode = dm if 0 < dm < 14 else 0
             for k, v in opts.items():
                 r.set_option(k, v)
             shard_n = 1 if reuse else int(rng.choice([1, 1, 2, 3]))  # a hash grid is a whole-frame structure: rejected on a shard
@@ -112,11 +117,16 @@ def run(cases=60, seed=1):
                 fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"], prev=prev)
             else:
                 fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+            debug_start = None
+            if debug_mode:
+                r.mPushConstants.gDebugViewPathLength = 1 + (seed0 >> 10) % 3
+                r.mPushConstants.gDebugLightPathLength = (seed0 >> 12) & 1
+                debug_start = np.random.default_rng(seed0).random((fr.height, fr.width, 4), dtype=np.float32)
             try:
-                got = r.render(fr, seed0, seeds)
+                got = r.render(fr, seed0, seeds, debug_mode=debug_mode, debug_image=debug_start)
             except StratumHipError as e:
                 try:
-                    oracle_py.OracleScene(sc).render(fr, r.push_constants(fr), r.mSamplingFlags, seed0, seeds)
+                    oracle_py.OracleScene(sc).render(fr, r.push_constants(fr), r.mSamplingFlags, seed0, seeds, debug_mode=debug_mode, debug_image=debug_start)
                 except RuntimeError:
                     rejected += 1
                     continue
@@ -124,7 +134,7 @@ def run(cases=60, seed=1):
                 bad += 1
                 continue
             try:
-                ref = oracle_py.OracleScene(sc).render(fr, r.push_constants(fr), r.mSamplingFlags, seed0, seeds)
+                ref = oracle_py.OracleScene(sc).render(fr, r.push_constants(fr), r.mSamplingFlags, seed0, seeds, debug_mode=debug_mode, debug_image=debug_start)
             except RuntimeError as e:
                 print("MISMATCH (oracle rejects, GPU accepts): %s %s %s: %s" % (kind, flags, args, e))
                 bad += 1
@@ -144,6 +154,10 @@ def run(cases=60, seed=1):
                 for k in ("visibility", "depth"):
                     ref[k] = got[k]
                 ref["radiance"] = got["radiance"]
+                if debug_mode:  # (a shard leaves the pixels of the others as they were; light tracing's splats land on its own pixels only)
+                    ok &= np.array_equal(got["debug"].view(np.uint32)[own], ref["debug"].view(np.uint32)[own]) and np.array_equal(got["debug"][~own], debug_start[~own])
+                    ref["debug"] = got["debug"]
+            if debug_mode: ok &= np.array_equal(got["debug"].view(np.uint32), ref["debug"].view(np.uint32))
             for k in ("radiance", "albedo", "prev_uv"):
                 ok &= np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32))
             ok &= np.array_equal(got["visibility"]["instance_primitive_index"], ref["visibility"]["instance_primitive_index"])
@@ -155,7 +169,7 @@ def run(cases=60, seed=1):
             if not ok:
                 bad += 1
                 nd = int((got["radiance"].view(np.uint32) != ref["radiance"].view(np.uint32)).any(axis=-1).sum())
-                print("MISMATCH %s %s %s opts %s shard %d/%d %dx%d seeds %d+%d mode %d %s: %d radiance pixels differ, rays %s vs %s" % (kind, flags, args, opts, shard_r, shard_n, W, H, seed0, seeds, mode, fog_params if kind == "fog" else "", nd, got["ray_count"], ref["ray_count"]))
+                print("MISMATCH %s %s %s opts %s shard %d/%d %dx%d seeds %d+%d mode %d debug %d %s: %d radiance pixels differ, rays %s vs %s" % (kind, flags, args, opts, shard_r, shard_n, W, H, seed0, seeds, mode, debug_mode, fog_params if kind == "fog" else "", nd, got["ray_count"], ref["ray_count"]))
         finally:
             r.close()
     print("%d cases compared, %d rejected on both sides, %d mismatches, %.0f s" % (done, rejected, bad, time.time() - t0))
