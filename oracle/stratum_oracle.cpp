@@ -3229,6 +3229,58 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
   }
   out_rgb[0] = out_rgb[1] = out_rgb[2] = 0;
   if (fr.pc.gMaxPathVertices < 2) return true;
+  // what follows the path for every pixel inside a view, also one whose sample_visibility returned early: trace_shadows, add_light_trace, the outputs
+  auto finish = [&]() -> bool {
+    // trace_shadows, bdpt.hlsl:302-326
+    v3 c = V3(0.0f);
+    for (uint32_t i = 1; i <= fr.pc.gMaxDiffuseVertices && i <= path.max_shadow; i++) {
+      const sthip_ShadowRayData& rd = path.shadow_rays[i - 1];
+      v3 contribution = V3(rd.contribution[0], rd.contribution[1], rd.contribution[2]);
+      if (all_le0(contribution)) continue;
+      if (has_media(fr)) {
+        Rng r;  // rng_init(pixel_coord, rd.rng_offset), bdpt.hlsl:315
+        r.v[0] = x;
+        r.v[1] = y;
+        r.v[2] = seed;
+        r.v[3] = rd.rng_offset;
+        float nee_pdf = 1;
+        path.trace_visibility_media(r, V3(rd.ray_origin[0], rd.ray_origin[1], rd.ray_origin[2]), V3(rd.ray_direction[0], rd.ray_direction[1], rd.ray_direction[2]), rd.ray_distance, rd.medium,
+                                    contribution, nee_pdf);
+        if (nee_pdf > 0) contribution = contribution / nee_pdf;
+      } else if (path.occluded(V3(rd.ray_origin[0], rd.ray_origin[1], rd.ray_origin[2]), V3(rd.ray_direction[0], rd.ray_direction[1], rd.ray_direction[2]), rd.ray_distance))
+        contribution = V3(0.0f);
+      c = c + contribution;
+    }
+    v3 rad = path.radiance + c;
+    if (fr.light_trace && !fr.debug(STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION)) {  // add_light_trace, bdpt.hlsl:328-338 with load_light_sample, path.hlsli:38-46
+      const size_t idx = (size_t)y * fr.pc.gOutputExtent[0] + x;
+      uint32_t v[4];
+      for (int k = 0; k < 4; k++) v[k] = fr.light_trace[4 * idx + k].load(std::memory_order_relaxed);
+      for (int k = 0; k < 3; k++)
+        if (v[3] & (1u << k)) v[k] = 0xFFFFFFFFu;
+      v3 lc = V3((float)v[0], (float)v[1], (float)v[2]) / (float)fr.light_trace_quantization;
+      if (lc.x < 0 || lc.y < 0 || lc.z < 0 || any_nan(lc)) lc = V3(0.0f);
+      rad = rad + lc;
+      if (dbg && (fr.debug(STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION) || (fr.debug(STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION) && fr.pc.gDebugViewPathLength == 1))) path.debug_set(lc);  // bdpt.hlsl:335-336
+    }
+    out_rgb[0] = rad.x;
+    out_rgb[1] = rad.y;
+    out_rgb[2] = rad.z;
+    stats[0] += path.rays_total;
+    stats[1] += path.rays_path;
+    stats[2] += path.counters[0];
+    stats[3] += path.counters[1];
+    if (rr) {
+      rr->missing_length = path.rr_missing_length;
+      rr->missing_p = path.rr_missing_p;
+      rr->missing_rnd = path.rr_missing_rnd;
+      rr->cs_site = path.cs_missing_site;
+      rr->cs_length = path.cs_missing_length;
+      rr->cs_value = path.cs_missing_value;
+    }
+    return true;
+};
+
   const sthip_ViewData& view = fr.fd.gViews[view_index];
   const sthip_TransformData& t = fr.fd.gViewTransforms[view_index];
   const float ex = (float)(view.image_max[0] - view.image_min[0]), ey = (float)(view.image_max[1] - view.image_min[1]);
@@ -3248,7 +3300,7 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
     path.rd_spread = fminf(length(dir_dx / dir_dx.z - l), length(dir_dy / dir_dy.z - l));
   }
   if (dbg && fr.debug(STHIP_DEBUG_ENVIRONMENT_SAMPLE_TEST)) {  // bdpt.hlsl:190-199 (no ray is traced; without an environment the record at gEnvironmentMaterialAddress is not one: not restated)
-    if (!has_environment(fr)) return true;
+    if (!has_environment(fr)) return finish();
     Environment env;
     env.load(*fr.sc, fr.pc.gEnvironmentMaterialAddress);
     for (uint32_t i = 0; i < 8; i++) {
@@ -3259,15 +3311,15 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
       const float v = 1024 * det_powf(fmaxf(0.0f, dot(dir, path.direction)), 1024.0f);
       path.debug_add(V3(v));
     }
-    return true;
+    return finish();  // (light tracing's image is still added: add_light_trace is a pass of its own)
   }
   if (dbg && fr.debug(STHIP_DEBUG_ENVIRONMENT_SAMPLE_PDF)) {  // bdpt.hlsl:200-204 (.rgb = pdf: the alpha stays)
-    if (!has_environment(fr)) return true;
+    if (!has_environment(fr)) return finish();
     Environment env;
     env.load(*fr.sc, fr.pc.gEnvironmentMaterialAddress);
     const float pdf = env.eval_pdf(path.direction, fr.flag(STHIP_eSampleEnvironmentMapDirectly));
     dbg[0] = dbg[1] = dbg[2] = pdf;
-    return true;
+    return finish();
   }
   path.beta = V3(1.0f);
   path.medium = (has_media(fr) && fr.fd.gViewMediumInstances) ? fr.fd.gViewMediumInstances[view_index] : STHIP_INVALID_INSTANCE;  // bdpt.hlsl:208
@@ -3352,54 +3404,7 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
     while (any_gt0(path.beta) && !any_nan(path.beta)) path.next_vertex();
   }
 
-  // trace_shadows, bdpt.hlsl:302-326
-  v3 c = V3(0.0f);
-  for (uint32_t i = 1; i <= fr.pc.gMaxDiffuseVertices && i <= path.max_shadow; i++) {
-    const sthip_ShadowRayData& rd = path.shadow_rays[i - 1];
-    v3 contribution = V3(rd.contribution[0], rd.contribution[1], rd.contribution[2]);
-    if (all_le0(contribution)) continue;
-    if (has_media(fr)) {
-      Rng r;  // rng_init(pixel_coord, rd.rng_offset), bdpt.hlsl:315
-      r.v[0] = x;
-      r.v[1] = y;
-      r.v[2] = seed;
-      r.v[3] = rd.rng_offset;
-      float nee_pdf = 1;
-      path.trace_visibility_media(r, V3(rd.ray_origin[0], rd.ray_origin[1], rd.ray_origin[2]), V3(rd.ray_direction[0], rd.ray_direction[1], rd.ray_direction[2]), rd.ray_distance, rd.medium,
-                                  contribution, nee_pdf);
-      if (nee_pdf > 0) contribution = contribution / nee_pdf;
-    } else if (path.occluded(V3(rd.ray_origin[0], rd.ray_origin[1], rd.ray_origin[2]), V3(rd.ray_direction[0], rd.ray_direction[1], rd.ray_direction[2]), rd.ray_distance))
-      contribution = V3(0.0f);
-    c = c + contribution;
-  }
-  v3 rad = path.radiance + c;
-  if (fr.light_trace && !fr.debug(STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION)) {  // add_light_trace, bdpt.hlsl:328-338 with load_light_sample, path.hlsli:38-46
-    const size_t idx = (size_t)y * fr.pc.gOutputExtent[0] + x;
-    uint32_t v[4];
-    for (int k = 0; k < 4; k++) v[k] = fr.light_trace[4 * idx + k].load(std::memory_order_relaxed);
-    for (int k = 0; k < 3; k++)
-      if (v[3] & (1u << k)) v[k] = 0xFFFFFFFFu;
-    v3 lc = V3((float)v[0], (float)v[1], (float)v[2]) / (float)fr.light_trace_quantization;
-    if (lc.x < 0 || lc.y < 0 || lc.z < 0 || any_nan(lc)) lc = V3(0.0f);
-    rad = rad + lc;
-    if (dbg && (fr.debug(STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION) || (fr.debug(STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION) && fr.pc.gDebugViewPathLength == 1))) path.debug_set(lc);  // bdpt.hlsl:335-336
-  }
-  out_rgb[0] = rad.x;
-  out_rgb[1] = rad.y;
-  out_rgb[2] = rad.z;
-  stats[0] += path.rays_total;
-  stats[1] += path.rays_path;
-  stats[2] += path.counters[0];
-  stats[3] += path.counters[1];
-  if (rr) {
-    rr->missing_length = path.rr_missing_length;
-    rr->missing_p = path.rr_missing_p;
-    rr->missing_rnd = path.rr_missing_rnd;
-    rr->cs_site = path.cs_missing_site;
-    rr->cs_length = path.cs_missing_length;
-    rr->cs_value = path.cs_missing_value;
-  }
-  return true;
+  return finish();
 }
 
 template <typename F>

@@ -1662,7 +1662,7 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   HIP_TRY(ctx, ctx->queue1.ensure(seg_stride * QUEUE_SEGMENTS));
   HIP_TRY(ctx, ctx->queue_kept.ensure(seg_stride * QUEUE_SEGMENTS));
   HIP_TRY(ctx, ctx->counters.ensure(CNT_TOTAL));
-  HIP_TRY(ctx, ctx->qctl.ensure((size_t)2 * 64 * QUEUE_SEGMENTS * QCTL_STRIDE));
+  HIP_TRY(ctx, ctx->qctl.ensure((size_t)3 * 64 * QUEUE_SEGMENTS * QCTL_STRIDE));  // path queues, shadow queues, and (BDPTDebugMode) the shadow rays' debug halves
   // ePresampleLights (BDPT.cpp:644-651): gLightPresampleTileSize x TileCount light points per seed in flight
   const bool presample = (sampling_flags & (1u << STHIP_ePresampleLights)) && pc->gMaxPathVertices > 2;
   const size_t presample_n = (size_t)pc->gLightPresampleTileSize * pc->gLightPresampleTileCount;
@@ -1953,6 +1953,7 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
       hipLaunchKernelGGL(k_clear, dim3(std::max(1u, std::min(64u, (2 * words + CNT_TOTAL + STHIP_BLOCK - 1) / STHIP_BLOCK))), dim3(STHIP_BLOCK), 0, st, queue_ctl_host(ctx->qctl.p, 0, 0), words,
                          queue_ctl_host(ctx->qctl.p, 1, 0), words, ctx->counters.p, counters_cleared ? 0u : (uint32_t)CNT_TOTAL);
       counters_cleared = true;
+      if (p.shadow_debug) HIP_TRY(ctx, hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 2, 0), 0, (size_t)words * 8, st));  // the debug halves' queues (BDPTDebugMode)
       HIP_TRY(ctx, hipGetLastError());
       return STHIP_OK;
     };
@@ -1981,11 +1982,10 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
         if (p.shadow_debug && ds != TRACE_NONE) {
           // BDPTDebugMode: the same shadow rays once more, carrying what each adds to the debug image, accumulated into the paths'
           // debug pixels the way the first pass accumulated their contributions into the radiance (finish_ray)
-          for (uint32_t seg = 0; seg < QUEUE_SEGMENTS; seg++)
-            (void)hipMemsetAsync(queue_ctl_host(ctx->qctl.p, 1, ds) + (size_t)seg * QCTL_STRIDE + QCTL_HEAD, 0, 8, st);
           FrameParams q = p;
           q.shadow_rays = p.shadow_debug;
           q.radiance = p.debug;
+          q.qctl = p.qctl + (size_t)64 * QUEUE_SEGMENTS * QCTL_STRIDE;  // its "shadow queues" (kind 1) are the debug queues (kind 2) k_shade filled
           const uint32_t none = TRACE_NONE;
           void* qargs[3] = {(void*)&q, (void*)&none, (void*)&ds};
           (void)hipLaunchKernel(p.bvh.wide8_nodes  ? trace_kernel_wide8(false, alpha, p.bvh.spill != nullptr)
@@ -2104,6 +2104,13 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
     if (rc) return rc;
     if (debug_mode == STHIP_DEBUG_ENVIRONMENT_SAMPLE_TEST || debug_mode == STHIP_DEBUG_ENVIRONMENT_SAMPLE_PDF) {
       // bdpt.hlsl:190-205: sample_visibility returns before it traces anything; the frame stays (0, 0, 0, 1), no ray is counted
+      // (the G-buffer outputs are not written upstream either: they are left zero here)
+      if (s == 0) {
+        if (p.out_albedo) HIP_TRY(ctx, hipMemsetAsync(p.out_albedo, 0, pixels * 16, st));
+        if (p.out_visibility) HIP_TRY(ctx, hipMemsetAsync(p.out_visibility, 0, pixels * 8, st));
+        if (p.out_depth) HIP_TRY(ctx, hipMemsetAsync(p.out_depth, 0, pixels * 16, st));
+        if (p.out_prev_uv) HIP_TRY(ctx, hipMemsetAsync(p.out_prev_uv, 0, pixels * 8, st));
+      }
       rc = timed(ms_other, [&]() {
         hipLaunchKernelGGL(k_debug_environment, dim3(grid), dim3(STHIP_BLOCK), 0, st, p);
         hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + in_flight == seed_count ? 1u : 0u, 0u);

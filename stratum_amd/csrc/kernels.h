@@ -2057,11 +2057,14 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             shadow_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
             shadow_out[3 * (size_t)k + 1] = make_float4(to_light.x, to_light.y, to_light.z, __uint_as_float(slot));
             shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
-            if (DEBUG && p.shadow_debug) {  // the same ray with what it adds to the debug image: traced once more into p.debug (api.hip)
+            if (DEBUG && p.shadow_debug && !all_le0(dc)) {
+              // the same ray with what it adds to the debug image, in a queue of its own (control lines of "kind 2"): traced once
+              // more, into p.debug (api.hip), the way the ray above is traced into the radiance
+              const uint32_t k2 = (uint32_t)atomicAdd(&queue_ctl(p.qctl, 2, depth, seg)[QCTL_SIZE], 1ull);
               float4* dbg_out = p.shadow_debug + 3 * shadow_base;
-              dbg_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
-              dbg_out[3 * (size_t)k + 1] = make_float4(to_light.x, to_light.y, to_light.z, __uint_as_float(slot));
-              dbg_out[3 * (size_t)k + 2] = make_float4(dc.x, dc.y, dc.z, 0.0f);
+              dbg_out[3 * (size_t)k2] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
+              dbg_out[3 * (size_t)k2 + 1] = make_float4(to_light.x, to_light.y, to_light.z, __uint_as_float(slot));
+              dbg_out[3 * (size_t)k2 + 2] = make_float4(dc.x, dc.y, dc.z, 0.0f);
             }
           } while (0);
         }
