@@ -47,6 +47,13 @@ struct DevBuf {
     if (count == 0) return hipSuccess;
     hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
     if (e == hipSuccess) n = count;
+    // tests: STHIP_POISON_ALLOC=<byte> fills every new device buffer with that byte, so that a read of something nothing has
+    // written shows in a fresh process too (where new device memory is zero pages) and not only once the heap is recycled
+    static const int poison = [] {
+      const char* v = getenv("STHIP_POISON_ALLOC");
+      return v && *v ? (int)(strtoul(v, nullptr, 0) & 0xFFu) : -1;
+    }();
+    if (e == hipSuccess && poison >= 0) e = hipMemset(p, poison, count * sizeof(T));
     return e;
   }
   void release() {

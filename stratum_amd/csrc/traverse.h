@@ -737,10 +737,19 @@ struct Traversal8 {
       w_k = sp.k;
     }
   }
-  DEV void push(uint2* st, uint32_t x, uint32_t y, bool keep) {
+  // BOUNDED: a write at `limit` (the canary's slot) makes the ray's result void (k_trace hands it to k_trace_deep), and the
+  // walk must END there: a group's hit bits are in the visiting order of the space it was made in, so a walk that has lost
+  // an exit sentinel and reads a world-space group inside an instance would compute child indices the node does not have.
+  // Returns true when that happened.
+  DEV bool push(uint2* st, uint32_t x, uint32_t y, bool keep) {
+    const bool lost = BOUNDED && top == limit;
     st[top] = make_uint2(x, y);
-    const uint32_t next = keep ? top + STRIDE : top;
-    top = BOUNDED ? min(next, limit) : next;
+    top = keep && !lost ? top + STRIDE : top;
+    return lost;
+  }
+  DEV void give_up() {  // (BOUNDED, after a write at `limit`)
+    gx = W8_DONE;
+    gy = ty = 0u;
   }
   // the popped entry becomes the lane's state: a node group, or (no inner bits) an item group / a sentinel
   DEV void take(uint2 P) {
@@ -778,9 +787,9 @@ struct Traversal8 {
         const uint32_t rest = gy & ~(1u << bit);
         const uint32_t slot = (bit - 24u) ^ octinv;
         const uint32_t index = gx + (uint32_t)__popc(gy & ((1u << slot) - 1u));  // (slot <= 7: only imask bits are counted)
+        const bool lost = BOUNDED && top == limit;  // (this write takes the canary: see push())
         st[top] = make_uint2(gx, rest);  // the rest of this group: kept if it still has inner bits
-        uint32_t ntop = rest > 0x00FFFFFFu ? top + STRIDE : top;
-        if (BOUNDED) ntop = min(ntop, limit);
+        const uint32_t ntop = rest > 0x00FFFFFFu && !lost ? top + STRIDE : top;
         const uint4* n = reinterpret_cast<const uint4*>(base + __umul24(index, STHIP_WIDE8_STRIDE));
         const uint4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
         uint4 n4 = n[4];
@@ -831,6 +840,7 @@ struct Traversal8 {
         tx = nohit ? P.x : n1.y;
         ty = nohit ? (P.y <= 0x00FFFFFFu ? P.y : 0u) : (hitmask & 0x00FFFFFFu);
         top = nohit ? ntop - STRIDE : ntop;
+        if (lost) give_up();
       }
       if ((uint32_t)__popcll(__ballot(walking())) < min_lanes) break;
     }
@@ -918,7 +928,7 @@ struct Traversal8 {
       const TlasEntry* e = bvh.entries + ((tx & ~WIDE8_ENTRY_BIT) + bit);
       const float4* ev = reinterpret_cast<const float4*>(e);
       const uint4 info = *reinterpret_cast<const uint4*>(ev + 3);
-      bool in_place = false, occluded = false;
+      bool in_place = false, occluded = false, lost = false;
       if (info.z != TLAS_ENTRY_IDENTITY) {
         const float4 r0 = ev[0], r1 = ev[1], r2 = ev[2];
         const float4 sph = ev[4];
@@ -943,18 +953,20 @@ struct Traversal8 {
           in_place = true;
         } else {
           // what is pending at this level waits on the stack: the rest of the node group, the rest of the entry group
-          push(st, gx, gy, gy > 0x00FFFFFFu);
-          push(st, tx, ty, ty != 0u);
-          push(st, W8_EXIT, 0u, true);
+          lost = push(st, gx, gy, gy > 0x00FFFFFFu);
+          lost |= push(st, tx, ty, ty != 0u);
+          lost |= push(st, W8_EXIT, 0u, true);
           setup_space(sp, obj_point(m, o), obj_vector(m, d), sph.x, sph.y, sph.z, sph.w);
           orient_space();
           id_bits = info.y;
         }
       } else {  // (the merged mesh is spliced into the top level; an entry of it all the same: same space, no id bits)
-        push(st, gx, gy, gy > 0x00FFFFFFu);
-        push(st, tx, ty, ty != 0u);
+        lost = push(st, gx, gy, gy > 0x00FFFFFFu);
+        lost |= push(st, tx, ty, ty != 0u);
       }
-      if (!in_place) {
+      if (lost) {
+        give_up();
+      } else if (!in_place) {
         gx = info.x;
         gy = 0x80000000u;
         ty = 0u;

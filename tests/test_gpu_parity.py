@@ -1978,3 +1978,19 @@ def test_debug_modes_of_the_environment():
                 got = _debug_case(sc, cam, mode, flags=flags, start=start)
                 assert got["ray_count"][0] == 0 and not got["radiance"][..., :3].any()
                 assert np.array_equal(got["debug"][..., 3], start[..., 3]) and not np.array_equal(got["debug"][..., :3], start[..., :3])
+
+
+def test_bounded_wide8_walk_with_recycled_device_memory():
+    """A ray that overflows the bounded LDS stack of the 8-wide walk must stop there (k_trace_deep traces it again): walking on
+    with an exit sentinel lost would read world-space groups with an instance's octant — child indices the node does not have,
+    and behind the last node whatever the allocation holds. Fresh device memory is zero (an empty node), so the case only shows
+    with the heap recycled: STHIP_POISON_ALLOC fills every new buffer (read once per process, hence the child process). The
+    case is number 129 of fuzz seed 302: a fog scene with instances, wide_bvh = 3, lds_stack_levels = 6."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STHIP_POISON_ALLOC="0x7F", STHIP_FUZZ_ONLY="129")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "130", "302"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "1 cases compared, 0 rejected on both sides, 0 mismatches" in out.stdout

@@ -10,6 +10,28 @@ from stratum_amd._lib import StratumHipError
 from stratum_amd.bdpt import BDPT
 
 FOG = np.load(os.path.join(ROOT, "tests", "golden", "fog_sphere.npz"))["grid"]
+# STHIP_FUZZ_SET="name=value,name=": execution options forced on / dropped from every case.
+# STHIP_FUZZ_ONLY=a[-b]: only these cases of the run touch the GPU (the others still draw their random numbers, so a case is the
+# one the full run has at that number); STHIP_FUZZ_TRACE=1 prints every case before it runs (to find the one a fault belongs to)
+ONLY = os.environ.get("STHIP_FUZZ_ONLY")
+TRACE = os.environ.get("STHIP_FUZZ_TRACE") == "1"
+
+
+class _Dry:
+    """Stands in for the renderer in the cases STHIP_FUZZ_ONLY leaves out."""
+
+    def __init__(self, device=0, args=None):
+        from stratum_amd import wire
+
+        self.mPushConstants = wire.default_push_constants(0, 0, 0)
+        self.mSamplingFlags = 0
+
+    def set_option(self, *a): pass
+    def set_shard(self, *a): pass
+    def update(self, sc): pass
+    def update_transforms(self, sc): pass
+    def push_constants(self, fr): return self.mPushConstants
+    def close(self): pass
 
 
 def run(cases=60, seed=1):
@@ -69,7 +91,11 @@ def run(cases=60, seed=1):
         if rng.integers(4) == 0:  # objects that moved since the previous frame (gInstanceMotionTransforms feeds prev-uv / prev_z)
             m = sc.motion_transforms["m"]
             m += rng.normal(scale=0.02, size=m.shape).astype(np.float32)
-        r = BDPT(0, args=args)
+        selected = True
+        if ONLY:
+            lo, _, hi = ONLY.partition("-")
+            selected = int(lo) <= case <= int(hi or lo)
+        r = BDPT(0, args=args) if selected else _Dry()
         try:
             # execution options that must not change any result: how many seeds share a pass, the fused / split trace launches,
             # the first-bounce packets, the GPU LBVH builder (triangle soups without alpha masks only), pixel-tile sharding
@@ -89,6 +115,10 @@ def run(cases=60, seed=1):
             if os.environ.get("STHIP_FUZZ_WIDE") is not None: opts["wide_bvh"] = int(os.environ["STHIP_FUZZ_WIDE"])  # the 4-wide walk forced on / off (without drawing: the cases of a seed stay the same)
             elif (seed0 >> 2) & 1: opts["wide_bvh"] = 3  # the 8-wide compressed walk (host-built trees; the others fall back to the 4-wide one)
             if (seed0 >> 3) & 1: opts["tri_min_lanes"] = 1 + (seed0 >> 5) % 24
+            for kv in filter(None, os.environ.get("STHIP_FUZZ_SET", "").split(",")):  # "name=value,name=": options forced / dropped (narrowing a case down)
+                k, _, v = kv.partition("=")
+                if v == "": opts.pop(k, None)
+                else: opts[k] = int(v)
             # BDPTDebugMode in about a fifth of the cases: gDebugImage must come out of both sides bit for bit, started from noise
             dm = (seed0 >> 4) & 63
             debug_mode = dm if 0 < dm < 14 else 0
@@ -117,6 +147,8 @@ def run(cases=60, seed=1):
                 fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"], prev=prev)
             else:
                 fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+            if TRACE and selected: print("CASE %d: %s %s opts %s shard %d/%d %dx%d seeds %d+%d mode %d debug %d" % (case, kind, args, opts, shard_r, shard_n, W, H, seed0, seeds, mode, debug_mode), flush=True)
+            if not selected: continue
             debug_start = None
             if debug_mode:
                 r.mPushConstants.gDebugViewPathLength = 1 + (seed0 >> 10) % 3
