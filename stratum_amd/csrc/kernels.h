@@ -1413,6 +1413,20 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
       dbg_dirty = true;
     };
     auto debug_is = [&](uint32_t mode) { return DEBUG && p.debug_mode == mode; };
+    // bdpt.hlsl:294-295: how far the first vertex moved on the screen since the previous frame, in pixels
+    auto debug_prev_uv = [&](uint32_t instance, f3 position) {
+      const int view_index = get_view_index(p, px, py);
+      const sthip_ViewData& view = p.views[view_index];
+      const float ex = (float)(view.image_max[0] - view.image_min[0]), ey = (float)(view.image_max[1] - view.image_min[1]);
+      const float uvx = ((float)px + 0.5f - (float)view.image_min[0]) / ex, uvy = ((float)py + 0.5f - (float)view.image_min[1]) / ey;
+      const Xf prev_inv_view = load_xf(p.prev_inv_view_xf, (uint32_t)view_index);
+      const f3 prev_cam_pos = xf_point(xf_mul(prev_inv_view, load_xf(p.scene.motion_xf, instance)), position);
+      float4 pc4 = project_point(p.prev_views[view_index].projection, prev_cam_pos);
+      pc4.y = -pc4.y;
+      pc4.x = pc4.x / pc4.w;
+      pc4.y = pc4.y / pc4.w;
+      debug_set(F3(fabsf((pc4.x * .5f + .5f) - uvx) * (float)p.pc.gOutputExtent[0], fabsf((pc4.y * .5f + .5f) - uvy) * (float)p.pc.gOutputExtent[1], 0.0f));
+    };
     // accumulate_contribution's debug half (path.hlsli:302-303): the unweighted contribution of one (view, light) length pair
     auto debug_path_length = [&](f3 contrib, uint32_t view_length, uint32_t light_length) {
       if (debug_is(STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION) && p.pc.gDebugLightPathLength == light_length && view_length == p.pc.gDebugViewPathLength) debug_add(contrib);
@@ -1434,6 +1448,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
         const float dist2 = len_sqr(scatter_p - origin);  // G = 1 / dist2 (no cosine, path.hlsli:1035-1036) only feeds the BDPT quantities
         if (primary) {  // bdpt.hlsl:213-220,245-296: no albedo / emission for a medium vertex; the visibility normal and
           bsdf_pdf = 1;   // the depth derivatives read the stale surface of the last query upstream and are pinned to 0
+          if (DEBUG) {    // (bdpt.hlsl:222-223: the stale normals again, pinned likewise; :294-295)
+            if (p.debug_mode == STHIP_DEBUG_GEOMETRY_NORMAL || p.debug_mode == STHIP_DEBUG_SHADING_NORMAL) debug_set(unpack_normal_octahedron(0u) * .5f + F3s(.5f));
+            else if (p.debug_mode == STHIP_DEBUG_PREV_UV) debug_prev_uv(medium, scatter_p);
+          }
           if (p.write_aov && seed_index == 0) {
             const int view_index = get_view_index(p, px, py);
             if (p.out_visibility) {
@@ -1706,19 +1724,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
           else if (p.debug_mode == STHIP_DEBUG_SPECULAR) debug_set(F3s(m.is_specular() ? 1.0f : 0.0f));
           else if (p.debug_mode == STHIP_DEBUG_EMISSION) debug_set(Le);
           else if (p.debug_mode == STHIP_DEBUG_SHADING_NORMAL) debug_set(unpack_normal_octahedron(first_hit_normal) * .5f + F3s(.5f));
-          else if (p.debug_mode == STHIP_DEBUG_PREV_UV) {
-            const int view_index = get_view_index(p, px, py);
-            const sthip_ViewData& view = p.views[view_index];
-            const float ex = (float)(view.image_max[0] - view.image_min[0]), ey = (float)(view.image_max[1] - view.image_min[1]);
-            const float uvx = ((float)px + 0.5f - (float)view.image_min[0]) / ex, uvy = ((float)py + 0.5f - (float)view.image_min[1]) / ey;
-            const Xf prev_inv_view = load_xf(p.prev_inv_view_xf, (uint32_t)view_index);
-            const f3 prev_cam_pos = xf_point(xf_mul(prev_inv_view, load_xf(p.scene.motion_xf, inst_index)), sd.position);
-            float4 pc4 = project_point(p.prev_views[view_index].projection, prev_cam_pos);
-            pc4.y = -pc4.y;
-            pc4.x = pc4.x / pc4.w;
-            pc4.y = pc4.y / pc4.w;
-            debug_set(F3(fabsf((pc4.x * .5f + .5f) - uvx) * (float)p.pc.gOutputExtent[0], fabsf((pc4.y * .5f + .5f) - uvy) * (float)p.pc.gOutputExtent[1], 0.0f));
-          }
+          else if (p.debug_mode == STHIP_DEBUG_PREV_UV) debug_prev_uv(inst_index, sd.position);
         }
         if (p.write_aov && seed_index == 0) {
           const int view_index = get_view_index(p, px, py);
