@@ -2239,7 +2239,7 @@ struct PathIntegrator {
 
   // trace_visibility_ray with media, intersection.hlsli:192-239: surfaces block, volume boundaries are crossed, the
   // medium in between attenuates (delta tracking that cannot scatter)
-  void trace_visibility_media(Rng& r, v3 o, v3 d, float t_max, uint32_t cur_medium, v3& contribution, float& T_nee) {
+  void trace_visibility_media(Rng& r, v3 o, v3 d, float t_max, uint32_t cur_medium, v3& contribution, float& T_dir, float& T_nee) {
     Medium m;
     if (cur_medium != STHIP_INVALID_INSTANCE) m.load(*fr.sc, fr.sc->instances[cur_medium].material_address());
     while (t_max > 1e-6f) {
@@ -2251,6 +2251,7 @@ struct PathIntegrator {
       const Inst& in = fr.sc->instances[sh.instance_index()];
       if (in.type() != STHIP_INSTANCE_TYPE_VOLUME) {  // a surface
         contribution = V3(0.0f);
+        T_dir = 0;
         T_nee = 0;
         break;
       }
@@ -2258,6 +2259,7 @@ struct PathIntegrator {
         const sthip_TransformData& inv = fr.sc->inv_xf[cur_medium];
         v3 dir_pdf = V3(1.0f), nee_pdf = V3(1.0f), scatter_p;
         m.delta_track(*fr.sc, r, transform_point(inv, o), transform_vector(inv, d), dt, contribution, dir_pdf, nee_pdf, false, fr.pc.gMaxNullCollisions, scatter_p);
+        T_dir *= average3(dir_pdf);
         T_nee *= average3(nee_pdf);
       }
       if (sh.sd.flags & STHIP_SHADING_FLAG_FRONT_FACE) {
@@ -2285,6 +2287,7 @@ struct PathIntegrator {
     bool area_measure;
     float light_pdfA = point_on_light_pdf(fr, isect, direction, area_measure);
     if (!area_measure) light_pdfA = light_pdfA * G;  // pdfWtoA
+    if (!fr.flag(STHIP_eDeferShadowRays)) light_pdfA *= T_nee_pdf;  // path.hlsli:866 (1 without media)
     float weight = 1;
     if (path_length > 2) {
       if (fr.bdpt()) {  // path.hlsli:870-880
@@ -2476,11 +2479,12 @@ struct PathIntegrator {
     if (all_le0(Le) && pdfA < 1e-6f) return;
     MaterialEvalRecord ev;
     m.eval(ev, local_dir_in, local_to_light, false);
-    const float pdfA_fwd = ev.pdf_fwd * cG;
+    float pdfA_fwd = ev.pdf_fwd * cG;
     if (pdfA_fwd < 1e-6f) return;
     const bool defer = fr.flag(STHIP_eDeferShadowRays);
-    if (!defer) {
-      if (occluded(ray_origin, ray_direction, ray_distance)) Le = V3(0.0f);
+    if (!defer) {  // path.hlsli:329-332: with media the walk attenuates Le, scales both pdfs and draws from the path's own stream
+      if (has_media(fr)) trace_visibility_media(rng, ray_origin, ray_direction, ray_distance, medium, Le, pdfA_fwd, pdfA);
+      else if (occluded(ray_origin, ray_direction, ray_distance)) Le = V3(0.0f);
       if (all_le0(Le)) return;
     }
     cG *= shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, dot(geometry_normal, isect.sd.shading_normal()), fr.flag(STHIP_eShadingNormalShadowFix));
@@ -2771,12 +2775,23 @@ struct PathIntegrator {
     const LightCandidate cand = light_candidate(presampled, presampled ? rng.next_uint() : 0u);
     if (all_le0(cand.Le) && cand.pdfA < 1e-6f) return;
     const float f = m.phase(local_dir_in, cand.ray_direction);
-    const float pdfA_fwd = f * cand.G;
+    float pdfA_fwd = f * cand.G;
     if (pdfA_fwd < 1e-6f) return;
-    const v3 contrib = cand.Le * f * cand.G / cand.pdfA;
+    v3 Le = cand.Le;
+    float pdfA = cand.pdfA;
+    const bool defer = fr.flag(STHIP_eDeferShadowRays);
+    if (!defer) {  // path.hlsli:329-332 (a medium vertex: no ray offset, no distance epsilon, :207-212)
+      trace_visibility_media(rng, isect.sd.position, cand.ray_direction, cand.ray_distance, medium, Le, pdfA_fwd, pdfA);
+      if (all_le0(Le)) return;
+    }
+    const v3 contrib = Le * f * cand.G / pdfA;
     if (all_le0(contrib)) return;
     float weight = 1;
-    if (fr.flag(STHIP_eSampleBSDFs)) weight = mis2(fr, cand.pdfA, pdfA_fwd);
+    if (fr.flag(STHIP_eSampleBSDFs)) weight = mis2(fr, pdfA, pdfA_fwd);
+    if (!defer) {
+      accumulate_contribution(beta * contrib, weight, 1);  // path.hlsli:365
+      return;
+    }
     const v3 c = beta * contrib * weight;
     if (diffuse_vertices >= 1 && diffuse_vertices <= max_shadow) {
       sthip_ShadowRayData& rd = shadow_rays[diffuse_vertices - 1];
@@ -3243,9 +3258,9 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
         r.v[1] = y;
         r.v[2] = seed;
         r.v[3] = rd.rng_offset;
-        float nee_pdf = 1;
+        float dir_pdf = 1, nee_pdf = 1;
         path.trace_visibility_media(r, V3(rd.ray_origin[0], rd.ray_origin[1], rd.ray_origin[2]), V3(rd.ray_direction[0], rd.ray_direction[1], rd.ray_direction[2]), rd.ray_distance, rd.medium,
-                                    contribution, nee_pdf);
+                                    contribution, dir_pdf, nee_pdf);
         if (nee_pdf > 0) contribution = contribution / nee_pdf;
       } else if (path.occluded(V3(rd.ray_origin[0], rd.ray_origin[1], rd.ray_origin[2]), V3(rd.ray_direction[0], rd.ray_direction[1], rd.ray_direction[2]), rd.ray_distance))
         contribution = V3(0.0f);
@@ -3684,10 +3699,9 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (!fr.flag(STHIP_ePresampleLights) && !fr.flag(STHIP_eLVC)) fr.sampling_flags &= ~(1u << STHIP_eCoherentSampling);
   if (fr.flag(STHIP_eCoherentSampling) && (scene_flags & STHIP_BDPT_FLAG_HAS_MEDIA) && !sc->volumes.empty()) return STHIP_ERR_UNSUPPORTED;  // walks through volumes break the lockstep
   if (has_media(fr)) {
-    // with media every visibility ray draws random numbers: inline ones (NEE without eDeferShadowRays, the connections of
-    // eConnectToViews / eConnectToLightPaths) would advance the path's own stream mid-vertex; only the deferred form is restated
+    // with media every visibility ray draws random numbers from the stream it is given: the path's own for an inline NEE ray
+    // (path.hlsli:329-332). The connections of eConnectToViews / eConnectToLightPaths and the reservoirs are not restated with media.
     if (sc->volumes.empty()) fr.scene_flags &= ~STHIP_BDPT_FLAG_HAS_MEDIA;
-    else if ((sampling_flags & (1u << STHIP_eNEE)) && !(sampling_flags & (1u << STHIP_eDeferShadowRays)) && fr.flag(STHIP_eNEE)) return STHIP_ERR_UNSUPPORTED;
     else if (fr.sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eNEEReservoirs))) return STHIP_ERR_UNSUPPORTED;
   }
   // presample_lights, bdpt.hlsl:84-99, once per seed (BDPT.cpp:644-651): rng_init(-1, index), reference point 0.

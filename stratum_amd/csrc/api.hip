@@ -257,6 +257,7 @@ struct sthip_ctx {
   DevBuf<BvhTriUv> tri_uvs;
   DevBuf<BvhTriShade> tri_shade;  // beside the leaf triangles: their vertices' normals and uvs (k_fill_tri_shade)
   DevBuf<uint32_t> hit_leaf;      // per path: the leaf triangle of its hit
+  DevBuf<uint32_t> shade_stack;   // media without eDeferShadowRays: a traversal stack column per k_shade thread (visibility_walk_media)
   DevBuf<float4> debug, out_debug, shadow_debug;  // BDPTDebugMode: per-path pixel of gDebugImage, the image's staging (host pointers), the debug halves of inline shadow rays
   DevBuf<uint32_t> inst_alpha;
   DevBuf<uint8_t> inst_flags;  // per instance: INST_FLAG_* of its (untextured) material, for k_cull_terminal
@@ -468,6 +469,7 @@ void sthip_destroy(sthip_ctx* ctx) {
   ctx->shadow_rays.release();
   ctx->light_vertices.release();
   ctx->media_state.release();
+  ctx->shade_stack.release();
   ctx->shadow_hit.release();
   ctx->shadow_ext.release();
   ctx->shadow_result.release();
@@ -1393,6 +1395,7 @@ static void release_path_state(sthip_ctx* ctx) {
   ctx->light_vertices.release();
   ctx->conn.release();
   ctx->media_state.release();
+  ctx->shade_stack.release();
   ctx->shadow_hit.release();
   ctx->shadow_ext.release();
   ctx->shadow_result.release();
@@ -1494,10 +1497,9 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   const bool media = ctx->has_volumes;
   if (media && (sampling_flags & (1u << STHIP_eCoherentSampling))) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eCoherentSampling with media (walks through volumes break the lockstep of a workgroup)");
   if (media) {
-    // with media every visibility ray draws random numbers; an inline one (NEE without eDeferShadowRays, the connections
-    // of eConnectToViews / eConnectToLightPaths) advances the path's own stream in the middle of a vertex: only the deferred form is built
-    if ((sampling_flags & (1u << STHIP_eNEE)) && !(sampling_flags & (1u << STHIP_eDeferShadowRays)))
-      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media need eDeferShadowRays (inline visibility rays through media are not built)");
+    // with media every visibility ray draws random numbers. An inline NEE ray (no eDeferShadowRays) draws them from the path's
+    // own stream in the middle of a vertex: k_shade walks it itself (visibility_walk_media). The connections of
+    // eConnectToViews / eConnectToLightPaths and the reservoirs would need the same and are not built.
     if (sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eNEEReservoirs)))
       return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media together with light subpaths or NEE reservoirs are not built");
   } else {
@@ -1784,6 +1786,12 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   p.seg_stride = (uint32_t)seg_stride;
   p.shadow_stride = (uint32_t)shadow_stride;
   p.media = media ? 1u : 0u;
+  const bool inline_media = media && (sampling_flags & (1u << STHIP_eNEE)) && !(sampling_flags & (1u << STHIP_eDeferShadowRays));
+  p.inline_media = inline_media ? 1u : 0u;
+  if (inline_media) {
+    HIP_TRY(ctx, ctx->shade_stack.ensure((size_t)shade_grid * STHIP_BLOCK * std::max(1u, ctx->bvh.stack_depth)));
+    p.shade_stack = ctx->shade_stack.p;
+  }
   if (media) {
     p.shadow_alt = (uint32_t)shadow_entries;
     p.media_state = ctx->media_state.p;
@@ -2142,7 +2150,7 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
       if (rc) return rc;
     }
     p.emitter_count = ctx->answer_last_rays ? ctx->emitter_count : 0u;  // (only the plain k_shade instantiation looks at it)
-    rc = run_rounds(false, nee || connect_paths, [&](uint32_t depth) {
+    rc = run_rounds(false, (nee || connect_paths) && !inline_media, [&](uint32_t depth) {  // (inline walks through media: nothing is queued)
       // eCoherentRR: a vertex shaded in round `depth` has path_length depth + 2; the roulette runs for
       // gMinPathVertices <= path_length < gMaxPathVertices at a non-specular vertex that is within the diffuse budget —
       // without specular materials that is vertex number depth + 1 of at most gMaxDiffuseVertices. In such a round the

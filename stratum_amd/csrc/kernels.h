@@ -140,6 +140,10 @@ struct FrameParams {
   float4* shadow_ext;         // per shadow record: (bits(rng counter), nee_pdf, bits(result entry), 0)
   float4* shadow_result;      // per path gMaxDiffuseVertices entries: what the NEE ray of diffuse vertex i adds (trace_shadows' c += ...)
   const uint32_t* view_medium;  // gViewMediumInstances
+  // media without eDeferShadowRays: an NEE ray draws from the path's own stream in the middle of its vertex (path.hlsli:329-332),
+  // so k_shade walks it itself, then and there (visibility_walk_media); one full-height stack column per k_shade thread
+  uint32_t inline_media;
+  uint32_t* shade_stack;
   float4* presampled;   // gPresampledLights (ePresampleLights): per seed in flight, 2 x float4 per point: (position, bits(packed normal)) (Le, pdfA)
   float4* shadow_rays;  // 3 x float4 per entry: (origin, distance) (direction, bits(slot)) (contribution, 0)
   unsigned long long* counters;  // CNT_* (64-bit each)
@@ -393,8 +397,11 @@ DEV void finish_ray(const FrameParams& p, float4* target, uint32_t slot, bool sh
 // steps. Its stack has three levels from the last usable one on: every step writes top, top + 1 and top + 2.
 // WIDE = 2: the walk goes over the 8-wide compressed form (DeviceBvh::wide8_nodes, "wide_bvh" = 3; traverse.h: Traversal8):
 // the stack holds 64-bit groups, one push per step at most.
+#ifndef STHIP_TRACE_ATTR
+#define STHIP_TRACE_ATTR  // (experiments: e.g. __attribute__((amdgpu_waves_per_eu(5))) — EXPERIMENTS.md, round 4)
+#endif
 template <bool COUNT, bool ALPHA, bool BOUNDED = false, bool TOP = false, int WIDE = 0>
-__global__ void __launch_bounds__(STHIP_BLOCK) k_trace(FrameParams p, uint32_t depth_closest, uint32_t depth_shadow) {
+__global__ void __launch_bounds__(STHIP_BLOCK) STHIP_TRACE_ATTR k_trace(FrameParams p, uint32_t depth_closest, uint32_t depth_shadow) {
   extern __shared__ uint32_t lds_stack[];
   // the treetop behind the stacks: copied once per (persistent) block
   float4* top_lds = reinterpret_cast<float4*>(lds_stack + (size_t)p.bvh.lds_levels * STHIP_BLOCK);
@@ -1238,6 +1245,59 @@ __global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, u
   }
 }
 
+// One step of trace_visibility_ray with media (intersection.hlsli:192-239), after the closest hit (dt, ip) of the walk's
+// current segment is known: a surface ends the walk with nothing; a volume boundary is crossed — delta tracking that cannot
+// scatter over the segment if it ran inside a medium — and the walk goes on from the other side. Returns true when the walk
+// has ended (the miss / end of the ray included).
+DEV bool visibility_step_media(const FrameParams& p, Rng& rng, f3& o, f3 d, float& t_max, uint32_t& cur_medium, f3& contribution, float& T_dir, float& T_nee, float dt, uint32_t ip) {
+  if (!isinf(t_max)) t_max -= dt;
+  if (ip == 0xFFFFFFFFu) return true;
+  const uint32_t hit_inst = ip & 0xFFFFu;
+  const Inst hin = load_inst(p.scene, hit_inst);
+  if (hin.type() != STHIP_INSTANCE_TYPE_VOLUME) {  // a surface: occluded
+    contribution = F3s(0.0f);
+    T_dir = 0;
+    T_nee = 0;
+    return true;
+  }
+  if (cur_medium != 0xFFFFu) {
+    Medium mm;
+    mm.load(p.scene, load_inst(p.scene, cur_medium).material_address());
+    const Xf inv = load_xf(p.scene.inv_xf, cur_medium);
+    f3 dir_pdf = F3s(1.0f), nee3 = F3s(1.0f), scatter_p;
+    mm.delta_track(p.scene, rng, xf_point(inv, o), xf_vector(inv, d), dt, contribution, dir_pdf, nee3, false, p.pc.gMaxNullCollisions, scatter_p);
+    T_dir *= average3(dir_pdf);
+    T_nee *= average3(nee3);
+  }
+  f3 bpos;
+  uint32_t bn;
+  volume_boundary(p.scene, hit_inst, hin, o, d, dt, bpos, bn);
+  const f3 bgn = unpack_normal_octahedron(bn);
+  if (dot3(d, bgn) < 0) {  // entering
+    cur_medium = hit_inst;
+    o = ray_offset(bpos, -bgn);
+  } else {
+    cur_medium = 0xFFFFu;
+    o = ray_offset(bpos, bgn);
+  }
+  return !(t_max > 1e-6f);
+}
+// The whole walk at once, by the calling thread, with `column` as its traversal stack (global memory, as k_trace_deep's): the
+// form media take WITHOUT eDeferShadowRays, where the walk draws from the path's own stream between the light sample and the
+// BSDF sample of a vertex (path.hlsli:329-332). Returns the closest-hit queries it made (gRayCount[0] counts them).
+DEV uint32_t visibility_walk_media(const FrameParams& p, Rng& rng, f3 o, f3 d, float t_max, uint32_t cur_medium, f3& contribution, float& T_dir, float& T_nee, uint32_t* column) {
+  uint32_t segments = 0;
+  TraverseCounters cnt;
+  cnt.clear();
+  while (t_max > 1e-6f) {
+    RayHit h;
+    traverse<TRAV_CLOSEST, false, 1, true>(p.bvh, o, d, 0.0f, t_max, column, h, cnt);
+    segments++;
+    if (visibility_step_media(p, rng, o, d, t_max, cur_medium, contribution, T_dir, T_nee, h.t, h.ip)) break;
+  }
+  return segments;
+}
+
 // ---------------------------------------------------------------------------------------------
 // shade: the tail of trace() (path.hlsli:1012-1043), the first-hit block of sample_visibility
 // (bdpt.hlsl:222-296) at depth 0, then next_vertex() (path.hlsli:955-998,1048-1075) up to the point
@@ -1328,7 +1388,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
     const uint32_t ip = __float_as_uint(hh.w);
     const bool primary = MEDIA ? path_length == 1 : depth == 0;  // this vertex is the first one of the path
     uint32_t medium = 0xFFFFu;   // _medium: the volume instance the path is inside of
-    float T_dir_pdf = 1;
+    float T_dir_pdf = 1, T_nee_pdf = 1;
+    uint32_t walk_segments = 0;  // closest-hit queries of this vertex's inline visibility walk (MEDIA without eDeferShadowRays)
     bool medium_vertex = false;  // the vertex is a scattering event inside `medium`
     f3 scatter_p = F3s(0.0f);
     if (MEDIA) {
@@ -1336,7 +1397,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
       const float4 m0 = p.media_state[2 * (size_t)slot], m1 = p.media_state[2 * (size_t)slot + 1];
       origin = xyz(m0);
       T_dir_pdf = m0.w;
-      float T_nee_pdf = m1.x;
+      T_nee_pdf = m1.x;
       medium = __float_as_uint(m1.y);
       const uint32_t segments = __float_as_uint(m1.z);
       if (medium != 0xFFFFu) {
@@ -1439,6 +1500,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
       // trace(), path.hlsli:1009-1010: the ray was traced (and counted) even if beta died meanwhile
       if ((MEDIA && T_dir_pdf <= 0) || all_le0(beta)) break;
       if (MEDIA) beta = beta / T_dir_pdf;  // path.hlsli:1009 (bsdf_pdf keeps its value with eDeferShadowRays, :1010)
+      if (MEDIA && p.inline_media) bsdf_pdf *= T_dir_pdf;
       path_length++;
       if (MEDIA && medium_vertex) {
         // ---- a vertex inside a medium: trace()'s tail (path.hlsli:1033-1043) and next_vertex(Medium) (:955-998,1062-1066) ----
@@ -1533,6 +1595,20 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             const float f = mm.phase(local_dir_in, c_dir);
             const float pdfA_fwd = f * c_G;
             if (pdfA_fwd < 1e-6f) break;
+            if (p.inline_media) {  // path.hlsli:329-365 at a medium vertex (no shading-normal term, :334)
+              f3 wLe = cLe;
+              float w_fwd = pdfA_fwd, w_pdfA = c_pdfA;
+              walk_segments += visibility_walk_media(p, rng, scatter_p, c_dir, c_dist, medium, wLe, w_fwd, w_pdfA, p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth);
+              if (all_le0(wLe)) break;
+              const f3 contrib = wLe * f * c_G / w_pdfA;
+              if (all_le0(contrib)) break;
+              float weight = 1;
+              if (sample_bsdfs) weight = mis2(use_mis, w_pdfA, w_fwd);
+              debug_path_length(beta * contrib, path_length, 1);
+              radiance = radiance + (beta * contrib) * weight;
+              radiance_dirty = true;
+              break;
+            }
             const f3 contrib = cLe * f * c_G / c_pdfA;
             if (all_le0(contrib)) break;
             float weight = 1;
@@ -1608,6 +1684,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
           if (!all_le0(eLe)) {
             float light_pdf = env.eval_pdf(p.scene, direction, flag(p, STHIP_eSampleEnvironmentMapDirectly));
             if (has_emissives) light_pdf *= p.pc.gEnvironmentSampleProbability;
+            if (MEDIA && p.inline_media) light_pdf *= T_nee_pdf;  // path.hlsli:866
             float weight = 1;
             if (path_length > 2 && use_nee) weight = flag(p, STHIP_eNEEReservoirs) ? 0.5f : mis2(use_mis, bsdf_pdf, light_pdf);
             if (debug_is(STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION)) debug_add(beta * eLe);  // path.hlsli:890-891
@@ -1696,6 +1773,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
           if (has_env) light_pdfA *= 1 - p.pc.gEnvironmentSampleProbability;
           if (!shape_pdf_area_measure) light_pdfA = light_pdfA * G;  // pdfWtoA, path.hlsli:864
         }
+        if (MEDIA && p.inline_media) light_pdfA *= T_nee_pdf;  // path.hlsli:866
         float weight = 1;
         if (path_length > 2) {
           if (LT) {  // path.hlsli:870-880
@@ -1991,6 +2069,23 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             m.eval(ev, local_dir_in, local_to_light, false);
             const float pdfA_fwd = ev.pdf_fwd * cG;
             if (!reservoirs && pdfA_fwd < 1e-6f) break;
+            if (MEDIA && p.inline_media) {
+              // path.hlsli:329-365 in upstream's order: the walk first — it attenuates Le, scales both pdfs and advances THIS
+              // path's stream — then the shading-normal term, the contribution and its weight, added at once
+              f3 wLe = lLe;
+              float w_fwd = pdfA_fwd, w_pdfA = pdfA;
+              walk_segments += visibility_walk_media(p, rng, ray_origin, to_light, ray_distance, medium, wLe, w_fwd, w_pdfA, p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth);
+              if (all_le0(wLe)) break;
+              const float wG = cG * shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, dot3(gn, sd.shading_normal()), EXT && flag(p, STHIP_eShadingNormalShadowFix));
+              const f3 contrib = wLe * ev.f * wG / w_pdfA;
+              if (all_le0(contrib)) break;
+              float weight = 1;
+              if (sample_bsdfs) weight = mis2(use_mis, w_pdfA, w_fwd);
+              debug_path_length(beta * contrib, path_length, 1);  // accumulate_contribution, path.hlsli:302-303
+              radiance = radiance + (beta * contrib) * weight;
+              radiance_dirty = true;
+              break;
+            }
             cG *= shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, dot3(gn, sd.shading_normal()), EXT && flag(p, STHIP_eShadingNormalShadowFix));
             const f3 contrib = reservoirs ? lLe * ev.f * cG * ris_W : lLe * ev.f * cG / pdfA;
             // Without eDeferShadowRays the reference has traced (and counted) the visibility ray by now (path.hlsli:329-332,
@@ -2327,6 +2422,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
     } while (0);
     if (PROBE) continue;
 
+    if (MEDIA && walk_segments) atomicAdd(&p.counters[CNT_RAYS_SHADOW], (unsigned long long)walk_segments);  // (inline walks: not in any queue)
     if (DEBUG && dbg_dirty) p.debug[slot] = dbg;
     if (radiance_dirty) p.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
     if (!TEXTURED && !EXT && !LT && !MEDIA && p.emitter_count) {  // (the plain instantiation only: in the extended one this code cost 10 % of k_shade in spills)
@@ -2438,42 +2534,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_shadow_media(FrameParams p, uin
     rng.y = py;
     rng.seed = p.seed + slot / p.paths_per_seed;
     rng.counter = __float_as_uint(ext.x);
-    const float dt = hh.x;
-    const uint32_t ip = __float_as_uint(hh.w);
-    if (!isinf(t_max)) t_max -= dt;
-    bool done = false;
-    if (ip == 0xFFFFFFFFu) {
-      done = true;
-    } else {
-      const uint32_t hit_inst = ip & 0xFFFFu;
-      const Inst hin = load_inst(p.scene, hit_inst);
-      if (hin.type() != STHIP_INSTANCE_TYPE_VOLUME) {  // a surface: occluded
-        contribution = F3s(0.0f);
-        nee_pdf = 0;
-        done = true;
-      } else {
-        if (cur_medium != 0xFFFFu) {
-          Medium mm;
-          mm.load(p.scene, load_inst(p.scene, cur_medium).material_address());
-          const Xf inv = load_xf(p.scene.inv_xf, cur_medium);
-          f3 dir_pdf = F3s(1.0f), nee3 = F3s(1.0f), scatter_p;
-          mm.delta_track(p.scene, rng, xf_point(inv, o), xf_vector(inv, d), dt, contribution, dir_pdf, nee3, false, p.pc.gMaxNullCollisions, scatter_p);
-          nee_pdf *= average3(nee3);
-        }
-        f3 bpos;
-        uint32_t bn;
-        volume_boundary(p.scene, hit_inst, hin, o, d, dt, bpos, bn);
-        const f3 bgn = unpack_normal_octahedron(bn);
-        if (dot3(d, bgn) < 0) {  // entering
-          cur_medium = hit_inst;
-          o = ray_offset(bpos, -bgn);
-        } else {
-          cur_medium = 0xFFFFu;
-          o = ray_offset(bpos, bgn);
-        }
-        if (!(t_max > 1e-6f)) done = true;
-      }
-    }
+    float dir_pdf = 1;  // (only the inline form reads it)
+    const bool done = visibility_step_media(p, rng, o, d, t_max, cur_medium, contribution, dir_pdf, nee_pdf, hh.x, __float_as_uint(hh.w));
     if (done) {
       if (nee_pdf > 0) contribution = contribution / nee_pdf;
       p.shadow_result[entry] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);

@@ -1346,6 +1346,11 @@ def test_trace_contract_with_volumes(renderer):
         ({"anisotropy": -0.3}, ["~nee"], {"maxDiffuseVertices": 4}),
         ({}, ["~samplebsdfs"], {}),
         ({"density": (12.0, 12.0, 12.0)}, ["presamplelights", "~mis"], {"maxDiffuseVertices": 5, "minPathVertices": 2}),
+        # without eDeferShadowRays an NEE ray's walk draws from the path's own stream, between the light sample and the BSDF
+        # sample of its vertex, and scales both pdfs of the MIS weight (path.hlsli:329-332,866,1011): k_shade walks it itself
+        ({}, ["~defershadowrays"], {"maxDiffuseVertices": 3}),
+        ({"anisotropy": 0.5, "density": (9.0, 6.0, 3.0)}, ["~defershadowrays", "~mis"], {"maxDiffuseVertices": 4, "maxPathVertices": 6, "minPathVertices": 2}),
+        ({"density": (12.0, 12.0, 12.0)}, ["~defershadowrays", "presamplelights", "~samplebsdfs"], {"maxDiffuseVertices": 4}),
     ],
 )
 def test_media(kwargs, flags, args):
@@ -1388,7 +1393,7 @@ def test_media_limits(renderer):
     sc, cam = scenes.cornell_box(fog=_fog())
     renderer.update(sc)
     frame = camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"])
-    for f in ("~defershadowrays", "connecttoviews"):
+    for f in ("neereservoirs", "connecttoviews"):
         renderer.set_flag(f)
         try:
             with pytest.raises(_lib.StratumHipError, match="media"):
