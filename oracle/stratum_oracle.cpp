@@ -2644,16 +2644,81 @@ struct PathIntegrator {
         rd.ray_origin[0] = ray_origin.x;
         rd.ray_origin[1] = ray_origin.y;
         rd.ray_origin[2] = ray_origin.z;
-        rd.medium = STHIP_INVALID_INSTANCE;
+        rd.medium = medium;
         rd.ray_direction[0] = c.ray_direction.x;
         rd.ray_direction[1] = c.ray_direction.y;
         rd.ray_direction[2] = c.ray_direction.z;
         rd.ray_distance = ray_distance;
       }
     } else {
-      if (occluded(ray_origin, c.ray_direction, ray_distance)) return;
+      if (has_media(fr)) {  // path.hlsli:474-479: the walk attenuates the contribution itself, in the path's own stream
+        float dir_pdf = 1, nee_pdf = 1;
+        trace_visibility_media(rng, ray_origin, c.ray_direction, ray_distance, medium, contrib, dir_pdf, nee_pdf);
+        if (nee_pdf <= 0) return;
+        contrib = contrib / nee_pdf;
+        if (all_le0(contrib)) return;
+      } else if (occluded(ray_origin, c.ray_direction, ray_distance))
+        return;
       if (dbg && fr.debug(STHIP_DEBUG_RESERVOIR_WEIGHT)) debug_add(V3(W));  // path.hlsli:482-483
       accumulate_contribution(beta * contrib, weight, 1);                  // :485
+    }
+  }
+
+  // connect_light_reservoir at a vertex inside a medium (the same function upstream, BSDF = Medium): setup()'s medium branch
+  // (path.hlsli:207-212) makes local_to_light the WORLD direction, so the target is luminance(Le) G |direction.z|; no ray
+  // offset, no distance epsilon, no shading-normal term (:446). Spatial reuse is not restated with media.
+  void connect_light_reservoir_medium(const Medium& m) {
+    const bool presampled = fr.flag(STHIP_ePresampleLights);
+    LightCandidate c;
+    memset(&c, 0, sizeof(c));
+    float total_weight = 0, r_target_pdf = 0;
+    uint32_t M = 0;
+    uint32_t ti = rng.next_uint();  // :378 (drawn in either mode)
+    for (uint32_t i = 0; i < fr.pc.gReservoirM; i++) {
+      if (presampled) ti = rng.next_uint();  // :385
+      const LightCandidate c_i = light_candidate(presampled, ti);
+      if (c_i.pdfA <= 0 || all_le0(c_i.Le)) continue;
+      const float target_pdf_i = luminance(c_i.Le) * c_i.G * fabsf(c_i.ray_direction.z);
+      const float w = target_pdf_i / c_i.pdfA;
+      M++;
+      total_weight += w;
+      if (rng.next_float() * total_weight <= w) {
+        r_target_pdf = target_pdf_i;
+        c = c_i;
+      }
+    }
+    const float W = (r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0;
+    if (W <= 1e-6f || W != W) return;
+    const float f = m.phase(local_dir_in, c.ray_direction);
+    v3 contrib = c.Le * f * c.G * W;
+    if (all_le0(contrib) || c.pdfA < 1e-6f) return;
+    float weight = 1;
+    if (fr.flag(STHIP_eSampleBSDFs)) weight = 1 - 0.5f;
+    if (fr.flag(STHIP_eDeferShadowRays)) {
+      const v3 cc = beta * contrib * weight;
+      if (diffuse_vertices >= 1 && diffuse_vertices <= max_shadow) {
+        sthip_ShadowRayData& rd = shadow_rays[diffuse_vertices - 1];
+        rd.contribution[0] = cc.x;
+        rd.contribution[1] = cc.y;
+        rd.contribution[2] = cc.z;
+        rd.rng_offset = rng.v[3];
+        rd.ray_origin[0] = isect.sd.position.x;
+        rd.ray_origin[1] = isect.sd.position.y;
+        rd.ray_origin[2] = isect.sd.position.z;
+        rd.medium = medium;
+        rd.ray_direction[0] = c.ray_direction.x;
+        rd.ray_direction[1] = c.ray_direction.y;
+        rd.ray_direction[2] = c.ray_direction.z;
+        rd.ray_distance = c.ray_distance;
+      }
+    } else {
+      float dir_pdf = 1, nee_pdf = 1;
+      trace_visibility_media(rng, isect.sd.position, c.ray_direction, c.ray_distance, medium, contrib, dir_pdf, nee_pdf);
+      if (nee_pdf <= 0) return;
+      contrib = contrib / nee_pdf;
+      if (all_le0(contrib)) return;
+      if (dbg && fr.debug(STHIP_DEBUG_RESERVOIR_WEIGHT)) debug_add(V3(W));
+      accumulate_contribution(beta * contrib, weight, 1);
     }
   }
 
@@ -2739,7 +2804,10 @@ struct PathIntegrator {
       if (diffuse_vertices > fr.pc.gMaxDiffuseVertices) return false;
       if (path_length >= fr.pc.gMinPathVertices)
         if (!russian_roulette()) return false;
-      if (fr.flag(STHIP_eNEE)) connect_light_medium(m);
+      if (fr.flag(STHIP_eNEE)) {
+        if (fr.flag(STHIP_eNEEReservoirs)) connect_light_reservoir_medium(m);
+        else connect_light_medium(m);
+      }
     }
     if (!fr.flag(STHIP_eSampleBSDFs)) return false;
     // sample_direction, path.hlsli:898-952, medium branch
@@ -3700,9 +3768,10 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (fr.flag(STHIP_eCoherentSampling) && (scene_flags & STHIP_BDPT_FLAG_HAS_MEDIA) && !sc->volumes.empty()) return STHIP_ERR_UNSUPPORTED;  // walks through volumes break the lockstep
   if (has_media(fr)) {
     // with media every visibility ray draws random numbers from the stream it is given: the path's own for an inline NEE ray
-    // (path.hlsli:329-332). The connections of eConnectToViews / eConnectToLightPaths and the reservoirs are not restated with media.
+    // (path.hlsli:329-332, 474-479). The connections of eConnectToViews / eConnectToLightPaths and the reservoirs' spatial
+    // reuse are not restated with media.
     if (sc->volumes.empty()) fr.scene_flags &= ~STHIP_BDPT_FLAG_HAS_MEDIA;
-    else if (fr.sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eNEEReservoirs))) return STHIP_ERR_UNSUPPORTED;
+    else if (fr.sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eNEEReservoirReuse))) return STHIP_ERR_UNSUPPORTED;
   }
   // presample_lights, bdpt.hlsl:84-99, once per seed (BDPT.cpp:644-651): rng_init(-1, index), reference point 0.
   // An environment sample leaves `position` unset upstream, so that combination is not restated.

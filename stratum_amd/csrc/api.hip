@@ -1499,9 +1499,9 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   if (media) {
     // with media every visibility ray draws random numbers. An inline NEE ray (no eDeferShadowRays) draws them from the path's
     // own stream in the middle of a vertex: k_shade walks it itself (visibility_walk_media). The connections of
-    // eConnectToViews / eConnectToLightPaths and the reservoirs would need the same and are not built.
-    if (sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eNEEReservoirs)))
-      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media together with light subpaths or NEE reservoirs are not built");
+    // eConnectToViews / eConnectToLightPaths would need the same in the light pass and are not built.
+    if (sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths)))
+      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media together with light subpaths are not built");
   } else {
     pcn.gMaxNullCollisions = 0;
   }

@@ -1556,10 +1556,11 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
           if (use_nee) do {
             // connect_light at a medium vertex, path.hlsli:311-366 with DirectLightSample::setup's medium branch (:207-212):
             // no ray offset, no distance epsilon, no shading-normal terms; the phase function is f and both pdfs
-            f3 cLe, c_dir;
-            float c_pdfA, c_dist, c_G;
-            if (flag(p, STHIP_ePresampleLights)) {
-              const uint32_t ti = rng.next_uint();
+            f3 cLe = F3s(0.0f), c_dir = F3s(0.0f);
+            float c_pdfA = 0, c_dist = 0, c_G = 0;
+            const bool presampled = flag(p, STHIP_ePresampleLights);
+            auto medium_candidate = [&](uint32_t ti, f3& cLe, float& c_pdfA, f3& c_dir, float& c_dist, float& c_G) {
+            if (presampled) {
               uint32_t path_index;
               if (flag(p, STHIP_eRemapThreads))
                 path_index = ((py >> 2) * ((p.pc.gOutputExtent[0] + 7u) >> 3) + (px >> 3)) * 32u + (py & 3u) * 8u + (px & 7u);
@@ -1591,6 +1592,66 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
                 if (!ls.area_measure) c_pdfA = c_pdfA * c_G;
               }
             }
+            };
+            uint32_t* column = p.inline_media ? p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth : nullptr;
+            if (EXT && flag(p, STHIP_eNEEReservoirs)) {
+              // connect_light_reservoir at a medium vertex (path.hlsli:368-486 with setup()'s medium branch, :207-212: local_to_light
+              // is the WORLD direction, so the target is luminance(Le) G |direction.z|); no spatial reuse with media
+              float total_weight = 0, r_target_pdf = 0;
+              uint32_t M = 0;
+              uint32_t ti = rng.next_uint();
+              for (uint32_t k = 0; k < p.pc.gReservoirM; k++) {
+                if (presampled) ti = rng.next_uint();
+                f3 iLe = F3s(0.0f), i_dir = F3s(0.0f);
+                float i_pdfA = 0, i_dist = 0, i_G = 0;
+                medium_candidate(ti, iLe, i_pdfA, i_dir, i_dist, i_G);
+                if (i_pdfA <= 0 || all_le0(iLe)) continue;
+                const float target_pdf = luminance3(iLe) * i_G * fabsf(i_dir.z);
+                const float w = target_pdf / i_pdfA;
+                M++;
+                total_weight += w;
+                if (rng.next_float() * total_weight <= w) {
+                  r_target_pdf = target_pdf;
+                  cLe = iLe;
+                  c_dir = i_dir;
+                  c_pdfA = i_pdfA;
+                  c_dist = i_dist;
+                  c_G = i_G;
+                }
+              }
+              const float W = (r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0;
+              if (W <= 1e-6f || W != W) break;
+              const float f = mm.phase(local_dir_in, c_dir);
+              f3 contrib = cLe * f * c_G * W;
+              if (all_le0(contrib) || c_pdfA < 1e-6f) break;
+              const float weight = sample_bsdfs ? 1 - 0.5f : 1.0f;
+              if (p.inline_media) {  // :474-485
+                float dir_pdf = 1, nee_pdf = 1;
+                walk_segments += visibility_walk_media(p, rng, scatter_p, c_dir, c_dist, medium, contrib, dir_pdf, nee_pdf, column);
+                if (nee_pdf <= 0) break;
+                contrib = contrib / nee_pdf;
+                if (all_le0(contrib)) break;
+                if (debug_is(STHIP_DEBUG_RESERVOIR_WEIGHT)) debug_add(F3s(W));
+                debug_path_length(beta * contrib, path_length, 1);
+                radiance = radiance + (beta * contrib) * weight;
+                radiance_dirty = true;
+                break;
+              }
+              const f3 c = beta * contrib * weight;
+              if (all_le0(c)) break;
+              const uint32_t entry = slot * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
+              if (!(c_dist > 1e-6f)) {
+                p.shadow_result[entry] = make_float4(c.x, c.y, c.z, 0.0f);
+                break;
+              }
+              const uint32_t k = (uint32_t)atomicAdd(shadow_size, 1ull);
+              shadow_out[3 * (size_t)k] = make_float4(scatter_p.x, scatter_p.y, scatter_p.z, c_dist);
+              shadow_out[3 * (size_t)k + 1] = make_float4(c_dir.x, c_dir.y, c_dir.z, __uint_as_float(slot));
+              shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, __uint_as_float(medium));
+              p.shadow_ext[shadow_base + k] = make_float4(__uint_as_float(rng.counter), 1.0f, __uint_as_float(entry), 0.0f);
+              break;
+            }
+            medium_candidate(presampled ? rng.next_uint() : 0u, cLe, c_pdfA, c_dir, c_dist, c_G);
             if (all_le0(cLe) && c_pdfA < 1e-6f) break;
             const float f = mm.phase(local_dir_in, c_dir);
             const float pdfA_fwd = f * c_G;
@@ -1598,7 +1659,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             if (p.inline_media) {  // path.hlsli:329-365 at a medium vertex (no shading-normal term, :334)
               f3 wLe = cLe;
               float w_fwd = pdfA_fwd, w_pdfA = c_pdfA;
-              walk_segments += visibility_walk_media(p, rng, scatter_p, c_dir, c_dist, medium, wLe, w_fwd, w_pdfA, p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth);
+              walk_segments += visibility_walk_media(p, rng, scatter_p, c_dir, c_dist, medium, wLe, w_fwd, w_pdfA, column);
               if (all_le0(wLe)) break;
               const f3 contrib = wLe * f * c_G / w_pdfA;
               if (all_le0(contrib)) break;
@@ -2069,6 +2130,23 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             m.eval(ev, local_dir_in, local_to_light, false);
             const float pdfA_fwd = ev.pdf_fwd * cG;
             if (!reservoirs && pdfA_fwd < 1e-6f) break;
+            if (MEDIA && p.inline_media && reservoirs) {
+              // connect_light_reservoir's inline tail, path.hlsli:441-485: the walk attenuates the finished contribution
+              const float wG = cG * shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, dot3(gn, sd.shading_normal()), EXT && flag(p, STHIP_eShadingNormalShadowFix));
+              f3 contrib = lLe * ev.f * wG * ris_W;
+              if (all_le0(contrib) || pdfA < 1e-6f) break;
+              const float weight = sample_bsdfs ? 1 - 0.5f : 1.0f;
+              float dir_pdf = 1, nee_pdf = 1;
+              walk_segments += visibility_walk_media(p, rng, ray_origin, to_light, ray_distance, medium, contrib, dir_pdf, nee_pdf, p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth);
+              if (nee_pdf <= 0) break;
+              contrib = contrib / nee_pdf;
+              if (all_le0(contrib)) break;
+              if (debug_is(STHIP_DEBUG_RESERVOIR_WEIGHT)) debug_add(F3s(ris_W));
+              debug_path_length(beta * contrib, path_length, 1);
+              radiance = radiance + (beta * contrib) * weight;
+              radiance_dirty = true;
+              break;
+            }
             if (MEDIA && p.inline_media) {
               // path.hlsli:329-365 in upstream's order: the walk first — it attenuates Le, scales both pdfs and advances THIS
               // path's stream — then the shading-normal term, the contribution and its weight, added at once

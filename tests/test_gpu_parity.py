@@ -1351,6 +1351,11 @@ def test_trace_contract_with_volumes(renderer):
         ({}, ["~defershadowrays"], {"maxDiffuseVertices": 3}),
         ({"anisotropy": 0.5, "density": (9.0, 6.0, 3.0)}, ["~defershadowrays", "~mis"], {"maxDiffuseVertices": 4, "maxPathVertices": 6, "minPathVertices": 2}),
         ({"density": (12.0, 12.0, 12.0)}, ["~defershadowrays", "presamplelights", "~samplebsdfs"], {"maxDiffuseVertices": 4}),
+        # NEE reservoirs: resampling at surface and medium vertices (there with setup()'s world-space direction in the target,
+        # path.hlsli:207-212,391), deferred records and inline walks (:474-485)
+        ({}, ["neereservoirs"], {"maxDiffuseVertices": 3, "reservoirM": 4}),
+        ({"density": (9.0, 9.0, 9.0)}, ["neereservoirs", "presamplelights", "~samplebsdfs"], {"maxDiffuseVertices": 4, "reservoirM": 3}),
+        ({"anisotropy": 0.4, "density": (9.0, 6.0, 3.0)}, ["neereservoirs", "~defershadowrays"], {"maxDiffuseVertices": 4, "reservoirM": 2, "minPathVertices": 2}),
     ],
 )
 def test_media(kwargs, flags, args):
@@ -1393,7 +1398,7 @@ def test_media_limits(renderer):
     sc, cam = scenes.cornell_box(fog=_fog())
     renderer.update(sc)
     frame = camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"])
-    for f in ("neereservoirs", "connecttoviews"):
+    for f in ("connecttolightpaths", "connecttoviews"):
         renderer.set_flag(f)
         try:
             with pytest.raises(_lib.StratumHipError, match="media"):
