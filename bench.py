@@ -215,6 +215,47 @@ def forest_record(device):
         r.close()
 
 
+def scene_build_record(sc, device):
+    """Acceleration-structure build and update times of the bench scene (outside every timed region): both builders, a
+    transforms-only update, and the rebuild the library runs itself when an instance of the merged world-space mesh has moved
+    (Scene.cpp:345,435-459,614-629 rebuild whenever dirty)."""
+    import copy
+
+    from stratum_amd.bdpt import BDPT
+
+    rec = {"unit": "ms", "triangles": int(sc.triangle_count), "instances": int(len(sc.instances))}
+    for name, builder in (("host_sah", 0), ("device_ploc", 1)):
+        r = BDPT(device=device)
+        try:
+            r.set_option("bvh_builder", builder)
+            t = time.perf_counter()
+            r.update(sc)
+            up = (time.perf_counter() - t) * 1e3
+            st = r.stats()
+            rec[name] = {"sthip_scene_upload_ms": round(up, 1), "bvh_build_ms": round(float(st["bvh_build_ms"]), 1), "bvh_build_gpu_ms": round(float(st["bvh_build_gpu_ms"]), 2), "bvh_nodes": int(st["bvh_nodes"])}
+            moved = copy.deepcopy(sc)
+            ident = [i for i in range(len(moved.instances)) if np.array_equal(moved.transforms["m"][i], np.eye(4, dtype=np.float32)[:3])]
+            others = [i for i in range(len(moved.instances)) if i not in ident]
+            if others:  # an instance with a transform of its own moves: the top level alone is rebuilt
+                m = moved.transforms["m"][others[0]].copy()
+                m[:, 3] += np.float32(0.01)
+                moved.set_instance_transform(int(others[0]), m)
+                t = time.perf_counter()
+                r.update_transforms(moved)
+                rec[name]["transforms_only_update_ms"] = round((time.perf_counter() - t) * 1e3, 2)
+            if ident:  # an instance of the merged mesh moves: the library rebuilds from the scene it kept (no STHIP_ERR_UNSUPPORTED)
+                m = moved.transforms["m"][ident[0]].copy()
+                m[:, 3] += np.float32(0.01)
+                moved.set_instance_transform(int(ident[0]), m)
+                t = time.perf_counter()
+                r.update_transforms(moved)
+                rec[name]["moved_merged_instance_update_ms"] = round((time.perf_counter() - t) * 1e3, 1)
+                rec[name]["full_rebuilds"] = int(r.stats().get("full_rebuilds", 0))
+        finally:
+            r.close()
+    return rec
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -759,7 +800,7 @@ def main():
         # instanced forest, 3840x2160, 16 seeds in one call, 8 diffuse / 10 path vertices, ~coherentrr, every output written
         other_workloads = None
         if world == 1 and not args.no_other_workloads and args.scene == "atrium":
-            other_workloads = {"forest": forest_record(local_rank)}
+            other_workloads = {"forest": forest_record(local_rank), "scene_build": scene_build_record(sc, local_rank)}
         flags_text = "default BDPT flags" if not (args.bdpt_flag or args.max_diffuse_vertices) else "flags %s maxDiffuseVertices %s" % (args.bdpt_flag, args.max_diffuse_vertices)
         result = {
             "metric": "Mray/s at 1920x1080x1spp (1M-tri scene)",
