@@ -1709,6 +1709,7 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   p.inv_view_xf = reinterpret_cast<const sthip_TransformData*>(ctx->views.p + 4 * vbytes);
   p.bdpt = bdpt ? ctx->bdpt.p : nullptr;
   p.light_trace = light_tracing && connect_views ? ctx->light_trace.p : nullptr;
+  p.light_trace_empty = connect_views && !light_tracing ? 1u : 0u;
   p.light_vertices = connect_paths ? ctx->light_vertices.p : nullptr;
   p.conn = connect_paths && conn_per_path ? ctx->conn.p : nullptr;
   // eCoherentRR takes effect in rounds in which a path can reach the roulette (see run below); never with media

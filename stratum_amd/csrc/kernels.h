@@ -83,6 +83,7 @@ struct FrameParams {
   uint32_t light_pass;        // this pass traces light subpaths (sample_photons)
   uint32_t light_threads;     // threads of sample_photons' padded dispatch per seed
   uint32_t light_trace_quantization;
+  uint32_t light_trace_empty;  // eConnectToViews with gMaxPathVertices <= 2: add_light_trace still runs (BDPT.cpp:753), over samples nobody wrote this frame — pinned to zero, as the oracle
   // light-subpath connections (eConnectToLightPaths)
   float4* light_vertices;     // gLightPathVertices: per seed in flight gLightPathCount * gMaxDiffuseVertices PathVertex records of 4 x float4 (bdpt.h:108-121)
   // the light vertex cache (eLVC, path.hlsli:523-527,683-800). Upstream hands out cache slots with an atomic counter; the
@@ -2649,7 +2650,22 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < p.paths_per_seed; q += gridDim.x * blockDim.x) {
     uint32_t px, py;
     const bool inside = slot_to_pixel(p, q, px, py);
-    if (!inside || p.meta[q] == 0xFFFFFFFFu) continue;
+    if (!inside) continue;
+    if (p.meta[q] == 0xFFFFFFFFu) {
+      // no view covers the pixel: sample_visibility returned at once, but add_light_trace runs for every pixel of the image
+      // (bdpt.hlsl:328-338) and, in two debug modes, writes what it loaded — nothing, no splat lands outside the views — there
+      if ((p.light_trace || p.light_trace_empty) && (p.debug_mode == STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION || (p.debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && p.pc.gDebugViewPathLength == 1))) {
+        f3 lc = F3s(0.0f);
+        if (p.light_trace) {
+          const uint4 v = *reinterpret_cast<const uint4*>(p.light_trace + 4 * ((size_t)(p.seeds_in_flight - 1u) * p.pc.gOutputExtent[0] * p.pc.gOutputExtent[1] + (size_t)py * p.pc.gOutputExtent[0] + px));
+          const float qq = (float)p.light_trace_quantization;
+          lc = F3((float)((v.w & 1u) ? 0xFFFFFFFFu : v.x), (float)((v.w & 2u) ? 0xFFFFFFFFu : v.y), (float)((v.w & 4u) ? 0xFFFFFFFFu : v.z)) / qq;
+          if (lc.x < 0 || lc.y < 0 || lc.z < 0 || any_nan(lc)) lc = F3s(0.0f);
+        }
+        p.out_debug[(size_t)py * p.pc.gOutputExtent[0] + px] = make_float4(lc.x, lc.y, lc.z, 1);
+      }
+      continue;
+    }
     float4 acc = first_seed ? make_float4(0, 0, 0, 0) : p.accum[q];
     // the seeds in flight are folded in seed order, so the result does not depend on how many were in flight
     for (uint32_t s = 0; s < p.seeds_in_flight; s++) {
@@ -2687,6 +2703,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
         cur.z = cur.z + lc.z;
         if (p.debug_mode == STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION || (p.debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && p.pc.gDebugViewPathLength == 1)) p.debug[slot] = make_float4(lc.x, lc.y, lc.z, 1);  // bdpt.hlsl:335-336
       }
+      if (p.light_trace_empty && p.debug_mode != STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION &&
+          (p.debug_mode == STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION || (p.debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && p.pc.gDebugViewPathLength == 1)))
+        p.debug[slot] = make_float4(0, 0, 0, 1);
       if (p.debug_mode) p.out_debug[(size_t)py * p.pc.gOutputExtent[0] + px] = p.debug[slot];  // (one seed in flight: the seeds of a call are upstream's successive frames)
       if (isinf(cur.x) || isinf(cur.y) || isinf(cur.z) || cur.x != cur.x || cur.y != cur.y || cur.z != cur.z) cur = make_float4(0, 0, 0, 0);
       if (acc.w > 0) {

@@ -172,6 +172,7 @@ def run(cases=60, seed=1):
                 bad += 1
                 continue
             ok = True
+            ref0_debug = ref["debug"].copy() if debug_mode else None
             if shard_n > 1:  # a shard renders its own tiles and writes zeros elsewhere; ray counts are the shard's own
                 from stratum_amd import shard as shard_mod
 
@@ -202,6 +203,10 @@ def run(cases=60, seed=1):
                 bad += 1
                 nd = int((got["radiance"].view(np.uint32) != ref["radiance"].view(np.uint32)).any(axis=-1).sum())
                 print("MISMATCH %s %s %s opts %s shard %d/%d %dx%d seeds %d+%d mode %d debug %d %s: %d radiance pixels differ, rays %s vs %s" % (kind, flags, args, opts, shard_r, shard_n, W, H, seed0, seeds, mode, debug_mode, fog_params if kind == "fog" else "", nd, got["ray_count"], ref["ray_count"]))
+                if debug_mode and os.environ.get("STHIP_FUZZ_VERBOSE"):
+                    dd = (got["debug"].view(np.uint32) != ref0_debug.view(np.uint32)).any(axis=-1)
+                    ys, xs = np.nonzero(dd)
+                    print("  debug image: %d pixels differ; first: %s" % (int(dd.sum()), [(int(x), int(y), got["debug"][y, x].tolist(), ref0_debug[y, x].tolist(), debug_start[y, x].tolist()) for y, x in list(zip(ys, xs))[:4]]))
         finally:
             r.close()
     print("%d cases compared, %d rejected on both sides, %d mismatches, %.0f s" % (done, rejected, bad, time.time() - t0))
