@@ -215,6 +215,42 @@ def forest_record(device):
         r.close()
 
 
+def config_record(device, sc, cam, W, H, seeds, what, shard_of=None):
+    """One more BASELINE.json configuration on this GPU, timed like tools/baseline_table.py's rows (median of 5 calls after a
+    warm-up call, radiance + ray counts as device outputs, every ray traced); `shard_of`: the work of rank 0 of that many
+    (its 64x32 tiles, packed-tile output)."""
+    import torch
+
+    from stratum_amd import camera
+    from stratum_amd.bdpt import BDPT
+
+    r = BDPT(device=device)
+    try:
+        if shard_of:
+            r.set_shard(0, shard_of, 64, 32)
+        r.update(sc)
+        r.set_option("answer_last_rays", 0)
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
+        fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+        packed = shard_of is not None
+        rad = torch.zeros((r.shard_slot_count(fr), 4) if packed else (H, W, 4), device="cuda")
+        rc = torch.zeros(2, dtype=torch.int64, device="cuda")
+        out = {"radiance": rad.data_ptr(), "ray_count": rc.data_ptr()}
+        r.render(fr, 0, min(seeds, 2), device_outputs=out, packed_tiles=packed)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter()
+            r.render(fr, 0, seeds, device_outputs=out, packed_tiles=packed)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t)
+        rays = int(rc[0].item())
+        dt = float(np.median(ts))
+        return {"workload": what, "value": round(rays / dt / 1e6, 2), "unit": "Mray/s", "ms_per_call": round(dt * 1e3, 2), "rays_per_call": rays, "seeds_per_call": seeds}
+    finally:
+        r.close()
+
+
 def scene_build_record(sc, device):
     """Acceleration-structure build and update times of the bench scene (outside every timed region): both builders, a
     transforms-only update, and the rebuild the library runs itself when an instance of the merged world-space mesh has moved
@@ -800,7 +836,13 @@ def main():
         # instanced forest, 3840x2160, 16 seeds in one call, 8 diffuse / 10 path vertices, ~coherentrr, every output written
         other_workloads = None
         if world == 1 and not args.no_other_workloads and args.scene == "atrium":
-            other_workloads = {"forest": forest_record(local_rank), "scene_build": scene_build_record(sc, local_rank)}
+            box, box_cam = scenes.cornell_box()
+            other_workloads = {
+                "cornell_1080p_64spp": config_record(local_rank, box, box_cam, 1920, 1080, 64, "BASELINE.json configs[1]: Cornell box, 1920x1080, 64 samples/pixel in one call, default flags, radiance only, every ray traced"),
+                "atrium_256spp_share_of_one_of_8_ranks": config_record(local_rank, sc, cam, W, H, 256, "BASELINE.json configs[3], the work of ONE of its 8 ranks on this GPU: atrium 1920x1080, 256 samples/pixel, the 64x32 tiles t % 8 == 0, packed-tile output, radiance only, every ray traced", shard_of=8),
+                "forest": forest_record(local_rank),
+                "scene_build": scene_build_record(sc, local_rank),
+            }
         flags_text = "default BDPT flags" if not (args.bdpt_flag or args.max_diffuse_vertices) else "flags %s maxDiffuseVertices %s" % (args.bdpt_flag, args.max_diffuse_vertices)
         result = {
             "metric": "Mray/s at 1920x1080x1spp (1M-tri scene)",
