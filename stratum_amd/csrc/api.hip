@@ -2199,17 +2199,24 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
         hipLaunchKernelGGL(k_cs_reduce, dim3(reduce_grid), dim3(STHIP_BLOCK), 0, st, p.cs_lvc, p.path_count);
       }
       if (debug_mode) {  // BDPTDebugMode: the general instantiation with the statements that feed gDebugImage
-        if (media)
-          hipLaunchKernelGGL((k_shade<true, true, false, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        if (media && inline_media)
+          hipLaunchKernelGGL((k_shade<true, true, false, 2, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else if (media)
+          hipLaunchKernelGGL((k_shade<true, true, false, 1, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
         else if (bdpt)
           hipLaunchKernelGGL((k_shade<true, true, true, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
         else
           hipLaunchKernelGGL((k_shade<true, true, false, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+      } else if (media && inline_media) {
+        if (ctx->textured)
+          hipLaunchKernelGGL((k_shade<true, true, false, 2>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else
+          hipLaunchKernelGGL((k_shade<false, true, false, 2>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
       } else if (media) {
         if (ctx->textured)
-          hipLaunchKernelGGL((k_shade<true, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+          hipLaunchKernelGGL((k_shade<true, true, false, 1>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
         else
-          hipLaunchKernelGGL((k_shade<false, true, false, true>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
+          hipLaunchKernelGGL((k_shade<false, true, false, 1>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
       } else if (bdpt) {
         if (ctx->textured)
           hipLaunchKernelGGL((k_shade<true, true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);

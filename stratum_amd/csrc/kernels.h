@@ -1319,7 +1319,7 @@ DEV uint32_t visibility_walk_media(const FrameParams& p, Rng& rng, f3 o, f3 d, f
 // path records its p and the random number it would draw, and nothing else is written.
 // DEBUG: BDPTDebugMode is live (FrameParams::debug_mode): the statements that feed gDebugImage are compiled in (the general
 // instantiations only: TEXTURED and EXT)
-template <bool TEXTURED, bool EXT, bool LT = false, bool MEDIA = false, bool PROBE = false, bool DEBUG = false>
+template <bool TEXTURED, bool EXT, bool LT = false, int MEDIA = 0, bool PROBE = false, bool DEBUG = false>  // MEDIA: 1 = volumes, NEE walks deferred (k_shadow_media); 2 = volumes, NEE walks inline (visibility_walk_media: an instantiation of its own, its registers are not the deferred form's business)
 __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams p, uint32_t depth) {
   // gMaterialData staged in LDS (untextured instantiations; the table of a scene is a few KB): a vertex then reads its 72-byte
   // record with LDS reads instead of a divergent gather. p.lds_material_bytes = 0 turns it off (table too large, option).
@@ -1501,7 +1501,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
       // trace(), path.hlsli:1009-1010: the ray was traced (and counted) even if beta died meanwhile
       if ((MEDIA && T_dir_pdf <= 0) || all_le0(beta)) break;
       if (MEDIA) beta = beta / T_dir_pdf;  // path.hlsli:1009 (bsdf_pdf keeps its value with eDeferShadowRays, :1010)
-      if (MEDIA && p.inline_media) bsdf_pdf *= T_dir_pdf;
+      if (MEDIA == 2) bsdf_pdf *= T_dir_pdf;
       path_length++;
       if (MEDIA && medium_vertex) {
         // ---- a vertex inside a medium: trace()'s tail (path.hlsli:1033-1043) and next_vertex(Medium) (:955-998,1062-1066) ----
@@ -1594,7 +1594,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
               }
             }
             };
-            uint32_t* column = p.inline_media ? p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth : nullptr;
+            uint32_t* column = (MEDIA == 2) ? p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth : nullptr;
             if (EXT && flag(p, STHIP_eNEEReservoirs)) {
               // connect_light_reservoir at a medium vertex (path.hlsli:368-486 with setup()'s medium branch, :207-212: local_to_light
               // is the WORLD direction, so the target is luminance(Le) G |direction.z|); no spatial reuse with media
@@ -1626,7 +1626,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
               f3 contrib = cLe * f * c_G * W;
               if (all_le0(contrib) || c_pdfA < 1e-6f) break;
               const float weight = sample_bsdfs ? 1 - 0.5f : 1.0f;
-              if (p.inline_media) {  // :474-485
+              if ((MEDIA == 2)) {  // :474-485
                 float dir_pdf = 1, nee_pdf = 1;
                 walk_segments += visibility_walk_media(p, rng, scatter_p, c_dir, c_dist, medium, contrib, dir_pdf, nee_pdf, column);
                 if (nee_pdf <= 0) break;
@@ -1657,7 +1657,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             const float f = mm.phase(local_dir_in, c_dir);
             const float pdfA_fwd = f * c_G;
             if (pdfA_fwd < 1e-6f) break;
-            if (p.inline_media) {  // path.hlsli:329-365 at a medium vertex (no shading-normal term, :334)
+            if ((MEDIA == 2)) {  // path.hlsli:329-365 at a medium vertex (no shading-normal term, :334)
               f3 wLe = cLe;
               float w_fwd = pdfA_fwd, w_pdfA = c_pdfA;
               walk_segments += visibility_walk_media(p, rng, scatter_p, c_dir, c_dist, medium, wLe, w_fwd, w_pdfA, column);
@@ -1746,7 +1746,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
           if (!all_le0(eLe)) {
             float light_pdf = env.eval_pdf(p.scene, direction, flag(p, STHIP_eSampleEnvironmentMapDirectly));
             if (has_emissives) light_pdf *= p.pc.gEnvironmentSampleProbability;
-            if (MEDIA && p.inline_media) light_pdf *= T_nee_pdf;  // path.hlsli:866
+            if (MEDIA == 2) light_pdf *= T_nee_pdf;  // path.hlsli:866
             float weight = 1;
             if (path_length > 2 && use_nee) weight = flag(p, STHIP_eNEEReservoirs) ? 0.5f : mis2(use_mis, bsdf_pdf, light_pdf);
             if (debug_is(STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION)) debug_add(beta * eLe);  // path.hlsli:890-891
@@ -1835,7 +1835,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
           if (has_env) light_pdfA *= 1 - p.pc.gEnvironmentSampleProbability;
           if (!shape_pdf_area_measure) light_pdfA = light_pdfA * G;  // pdfWtoA, path.hlsli:864
         }
-        if (MEDIA && p.inline_media) light_pdfA *= T_nee_pdf;  // path.hlsli:866
+        if (MEDIA == 2) light_pdfA *= T_nee_pdf;  // path.hlsli:866
         float weight = 1;
         if (path_length > 2) {
           if (LT) {  // path.hlsli:870-880
@@ -2131,7 +2131,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
             m.eval(ev, local_dir_in, local_to_light, false);
             const float pdfA_fwd = ev.pdf_fwd * cG;
             if (!reservoirs && pdfA_fwd < 1e-6f) break;
-            if (MEDIA && p.inline_media && reservoirs) {
+            if (MEDIA == 2 && reservoirs) {
               // connect_light_reservoir's inline tail, path.hlsli:441-485: the walk attenuates the finished contribution
               const float wG = cG * shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, dot3(gn, sd.shading_normal()), EXT && flag(p, STHIP_eShadingNormalShadowFix));
               f3 contrib = lLe * ev.f * wG * ris_W;
@@ -2148,7 +2148,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams
               radiance_dirty = true;
               break;
             }
-            if (MEDIA && p.inline_media) {
+            if (MEDIA == 2) {
               // path.hlsli:329-365 in upstream's order: the walk first — it attenuates Le, scales both pdfs and advances THIS
               // path's stream — then the shading-normal term, the contribution and its weight, added at once
               f3 wLe = lLe;
