@@ -2239,10 +2239,12 @@ struct PathIntegrator {
 
   // trace_visibility_ray with media, intersection.hlsli:192-239: surfaces block, volume boundaries are crossed, the
   // medium in between attenuates (delta tracking that cannot scatter)
-  void trace_visibility_media(Rng& r, v3 o, v3 d, float t_max, uint32_t cur_medium, v3& contribution, float& T_dir, float& T_nee) {
+  // max_segments: the inline walks (no eDeferShadowRays) are pinned to at most 64 closest-hit queries — upstream's loop has no
+  // bound, its path walk has this one (intersection.hlsli:247); the product must not let a thread spin on a degenerate boundary
+  void trace_visibility_media(Rng& r, v3 o, v3 d, float t_max, uint32_t cur_medium, v3& contribution, float& T_dir, float& T_nee, uint32_t max_segments = 0xFFFFFFFFu) {
     Medium m;
     if (cur_medium != STHIP_INVALID_INSTANCE) m.load(*fr.sc, fr.sc->instances[cur_medium].material_address());
-    while (t_max > 1e-6f) {
+    for (uint32_t segment = 0; t_max > 1e-6f && segment < max_segments; segment++) {
       IntersectionVertex sh = isect;  // a scratch vertex (its untouched fields do not matter)
       rays_total++;
       const float dt = trace_ray(fr, o, d, t_max, sh, false, counters);
@@ -2483,7 +2485,7 @@ struct PathIntegrator {
     if (pdfA_fwd < 1e-6f) return;
     const bool defer = fr.flag(STHIP_eDeferShadowRays);
     if (!defer) {  // path.hlsli:329-332: with media the walk attenuates Le, scales both pdfs and draws from the path's own stream
-      if (has_media(fr)) trace_visibility_media(rng, ray_origin, ray_direction, ray_distance, medium, Le, pdfA_fwd, pdfA);
+      if (has_media(fr)) trace_visibility_media(rng, ray_origin, ray_direction, ray_distance, medium, Le, pdfA_fwd, pdfA, 64);
       else if (occluded(ray_origin, ray_direction, ray_distance)) Le = V3(0.0f);
       if (all_le0(Le)) return;
     }
@@ -2653,7 +2655,7 @@ struct PathIntegrator {
     } else {
       if (has_media(fr)) {  // path.hlsli:474-479: the walk attenuates the contribution itself, in the path's own stream
         float dir_pdf = 1, nee_pdf = 1;
-        trace_visibility_media(rng, ray_origin, c.ray_direction, ray_distance, medium, contrib, dir_pdf, nee_pdf);
+        trace_visibility_media(rng, ray_origin, c.ray_direction, ray_distance, medium, contrib, dir_pdf, nee_pdf, 64);
         if (nee_pdf <= 0) return;
         contrib = contrib / nee_pdf;
         if (all_le0(contrib)) return;
@@ -2713,7 +2715,7 @@ struct PathIntegrator {
       }
     } else {
       float dir_pdf = 1, nee_pdf = 1;
-      trace_visibility_media(rng, isect.sd.position, c.ray_direction, c.ray_distance, medium, contrib, dir_pdf, nee_pdf);
+      trace_visibility_media(rng, isect.sd.position, c.ray_direction, c.ray_distance, medium, contrib, dir_pdf, nee_pdf, 64);
       if (nee_pdf <= 0) return;
       contrib = contrib / nee_pdf;
       if (all_le0(contrib)) return;
@@ -2849,7 +2851,7 @@ struct PathIntegrator {
     float pdfA = cand.pdfA;
     const bool defer = fr.flag(STHIP_eDeferShadowRays);
     if (!defer) {  // path.hlsli:329-332 (a medium vertex: no ray offset, no distance epsilon, :207-212)
-      trace_visibility_media(rng, isect.sd.position, cand.ray_direction, cand.ray_distance, medium, Le, pdfA_fwd, pdfA);
+      trace_visibility_media(rng, isect.sd.position, cand.ray_direction, cand.ray_distance, medium, Le, pdfA_fwd, pdfA, 64);
       if (all_le0(Le)) return;
     }
     const v3 contrib = Le * f * cand.G / pdfA;

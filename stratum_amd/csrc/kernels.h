@@ -1290,7 +1290,9 @@ DEV uint32_t visibility_walk_media(const FrameParams& p, Rng& rng, f3 o, f3 d, f
   uint32_t segments = 0;
   TraverseCounters cnt;
   cnt.clear();
-  while (t_max > 1e-6f) {
+  // (upstream's loop has no bound; 64 segments — the bound of its path walk, intersection.hlsli:247 — pins the end of a walk
+  // that never gets anywhere, on both sides: a thread of k_shade must not spin on a degenerate boundary)
+  while (t_max > 1e-6f && segments < 64u) {
     RayHit h;
     traverse<TRAV_CLOSEST, false, 1, true>(p.bvh, o, d, 0.0f, t_max, column, h, cnt);
     segments++;

@@ -1959,6 +1959,11 @@ def test_debug_modes_that_accumulate():
     for mode, vl, ll in ((W.DEBUG_LIGHT_TRACE_CONTRIBUTION, 0, 0), (W.DEBUG_PATH_LENGTH_CONTRIBUTION, 1, 2), (W.DEBUG_PATH_LENGTH_CONTRIBUTION, 1, 3), (W.DEBUG_VIEW_TRACE_CONTRIBUTION, 0, 0)):
         got = _debug_case(sc, cam, mode, flags=["connecttoviews"], view_length=vl, light_length=ll, start=start, w=128, h=96)
         assert got["debug"][..., :3].mean() > 0
+    # ... with gMaxPathVertices = 2 no photon is sampled, yet add_light_trace runs (BDPT.cpp:653,753) over samples nobody wrote
+    # this frame (pinned to zero) and overwrites every pixel of the image in these two modes (bdpt.hlsl:335-336)
+    for mode, vl in ((W.DEBUG_LIGHT_TRACE_CONTRIBUTION, 0), (W.DEBUG_PATH_LENGTH_CONTRIBUTION, 1)):
+        got = _debug_case(sc, cam, mode, flags=["connecttoviews"], args={"maxPathVertices": 2}, view_length=vl, light_length=1, start=start)
+        assert not got["debug"][..., :3].any() and (got["debug"][..., 3] == 1).all()
     # several seeds of a call are upstream's successive frames: the same image as call after call
     a = _debug_case(sc, cam, W.DEBUG_RESERVOIR_WEIGHT, flags=["neereservoirs", "~defershadowrays"], seeds=3, start=start)
     b = start
