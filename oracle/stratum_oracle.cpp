@@ -3293,9 +3293,30 @@ struct RRControl {
 // overwrite it where a path gets somewhere), or null
 bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float out_rgb[3], PixelAOV* aov, uint64_t stats[4], RRControl* rr = nullptr, float* dbg = nullptr) {
   const int view_index = get_view_index(fr, x, y);
-  if (view_index < 0) return false;
-  PathIntegrator path(fr, x, y, seed);
   if (fr.debug_mode == 0) dbg = nullptr;
+  // add_light_trace's debug write (bdpt.hlsl:328-338) for a pixel whose sample_visibility returned before tracing anything — it
+  // is a pass of its own over EVERY pixel of the image, dispatched whenever eConnectToViews is set (BDPT.cpp:753); the samples
+  // it loads are this frame's (zero where no photon landed, or where none was sampled: pinned, see render_frame)
+  auto light_trace_debug_only = [&]() {
+    if (!dbg || !fr.light_trace || fr.debug(STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION)) return;
+    if (!(fr.debug(STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION) || (fr.debug(STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION) && fr.pc.gDebugViewPathLength == 1))) return;
+    const size_t idx = (size_t)y * fr.pc.gOutputExtent[0] + x;
+    uint32_t v[4];
+    for (int k = 0; k < 4; k++) v[k] = fr.light_trace[4 * idx + k].load(std::memory_order_relaxed);
+    for (int k = 0; k < 3; k++)
+      if (v[3] & (1u << k)) v[k] = 0xFFFFFFFFu;
+    v3 lc = V3((float)v[0], (float)v[1], (float)v[2]) / (float)fr.light_trace_quantization;
+    if (lc.x < 0 || lc.y < 0 || lc.z < 0 || any_nan(lc)) lc = V3(0.0f);
+    dbg[0] = lc.x;
+    dbg[1] = lc.y;
+    dbg[2] = lc.z;
+    dbg[3] = 1;
+  };
+  if (view_index < 0) {
+    light_trace_debug_only();
+    return false;
+  }
+  PathIntegrator path(fr, x, y, seed);
   path.dbg = dbg;
   PixelAOV aov_scratch;
   if (dbg && fr.debug(STHIP_DEBUG_PREV_UV) && !aov) {  // (the mode reads the previous-frame uv the G-buffer block computes)
@@ -3313,7 +3334,10 @@ bool render_pixel(const Frame& fr, uint32_t x, uint32_t y, uint32_t seed, float 
     path.lane = (y & 3u) * 8u + (x & 7u);
   }
   out_rgb[0] = out_rgb[1] = out_rgb[2] = 0;
-  if (fr.pc.gMaxPathVertices < 2) return true;
+  if (fr.pc.gMaxPathVertices < 2) {
+    light_trace_debug_only();
+    return true;
+  }
   // what follows the path for every pixel inside a view, also one whose sample_visibility returned early: trace_shadows, add_light_trace, the outputs
   auto finish = [&]() -> bool {
     // trace_shadows, bdpt.hlsl:302-326
@@ -3964,13 +3988,15 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
       }
     }
     for (uint32_t l = 0; l < 32; l++) {
-      if (!lanes[l].inside) continue;
       const uint32_t x = gx * 8 + (l & 7), y = gy * 4 + (l >> 3);
+      if (x >= W || y >= H) continue;
       float* acc = acc_of(x, y);
       if (!acc) continue;
+      // (a pixel outside every view has no path, but add_light_trace may have written its debug pixel: render_pixel)
+      if (out->gDebugImage && out->debug_mode) memcpy(out->gDebugImage + 4 * ((size_t)y * W + x), lanes[l].dbg, 16);
+      if (!lanes[l].inside) continue;
       for (int k = 0; k < 4; k++) tstats[(size_t)tid * 4 + k] += lanes[l].stats[k];
       fold(x, y, s, acc, lanes[l].rgb, lanes[l].aov);
-      if (out->gDebugImage && out->debug_mode) memcpy(out->gDebugImage + 4 * ((size_t)y * W + x), lanes[l].dbg, 16);
     }
   };
   if (fr.flag(STHIP_eNEEReservoirReuse) || fr.flag(STHIP_eLVCReservoirReuse)) {

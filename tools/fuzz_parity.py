@@ -205,6 +205,11 @@ def run(cases=60, seed=1):
                 print("MISMATCH %s %s %s opts %s shard %d/%d %dx%d seeds %d+%d mode %d debug %d %s: %d radiance pixels differ, rays %s vs %s" % (kind, flags, args, opts, shard_r, shard_n, W, H, seed0, seeds, mode, debug_mode, fog_params if kind == "fog" else "", nd, got["ray_count"], ref["ray_count"]))
                 if debug_mode and os.environ.get("STHIP_FUZZ_VERBOSE"):
                     dd = (got["debug"].view(np.uint32) != ref0_debug.view(np.uint32)).any(axis=-1)
+                    if shard_n > 1:  # the others' pixels must be as they were
+                        from stratum_amd import shard as shard_mod
+
+                        mine = shard_mod.owner_map(W, H, shard_n, 16, 8) == shard_r
+                        dd = np.where(mine, dd, (got["debug"].view(np.uint32) != debug_start.view(np.uint32)).any(axis=-1))
                     ys, xs = np.nonzero(dd)
                     print("  debug image: %d pixels differ; first: %s" % (int(dd.sum()), [(int(x), int(y), got["debug"][y, x].tolist(), ref0_debug[y, x].tolist(), debug_start[y, x].tolist()) for y, x in list(zip(ys, xs))[:4]]))
         finally:
