@@ -1322,7 +1322,10 @@ DEV uint32_t visibility_walk_media(const FrameParams& p, Rng& rng, f3 o, f3 d, f
 // DEBUG: BDPTDebugMode is live (FrameParams::debug_mode): the statements that feed gDebugImage are compiled in (the general
 // instantiations only: TEXTURED and EXT)
 template <bool TEXTURED, bool EXT, bool LT = false, int MEDIA = 0, bool PROBE = false, bool DEBUG = false>  // MEDIA: 1 = volumes, NEE walks deferred (k_shadow_media); 2 = volumes, NEE walks inline (visibility_walk_media: an instantiation of its own, its registers are not the deferred form's business)
-__global__ void __launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade(FrameParams p, uint32_t depth) {
+// Resident blocks per CU: the plain instantiations (the bench path; textured or not) run best at SHADE_BLOCKS = 3 (168 registers,
+// a handful of spills); the extended ones (EXT: spheres, environments, reservoirs, media; LT: light subpaths) spill 200-950
+// registers there and are 4-8 % faster at 2 (256 registers): EXPERIMENTS.md round 4. The probes without light subpaths do not spill: 3.
+__global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHADE_BLOCKS) k_shade(FrameParams p, uint32_t depth) {
   // gMaterialData staged in LDS (untextured instantiations; the table of a scene is a few KB): a vertex then reads its 72-byte
   // record with LDS reads instead of a divergent gather. p.lds_material_bytes = 0 turns it off (table too large, option).
   extern __shared__ uint32_t shade_lds[];

@@ -1816,10 +1816,10 @@ def test_render_halves_its_batch_when_the_device_is_nearly_full():
         assert st["batch_halvings"] >= 1 and 1 <= st["seeds_in_flight"] < seeds, st
         again = r.render(frame, 0, seeds, aovs=False)  # the smaller batch stays: no second round of failures
         assert r.stats()["batch_halvings"] == st["batch_halvings"]
-        late = BDPT(device=0)  # a context created on the full device starts small
+        late = BDPT(device=0)  # a context created on the full device starts small (a frame that fits what the first context left: a few hundred MB)
         try:
             late.update(sc)
-            small = late.render(frame, 0, 4, aovs=False)
+            small = late.render(camera.Frame(640, 360, cam["fovy"], cam["eye"], cam["target"]), 0, 4, aovs=False)
             assert late.stats()["max_paths_in_flight"] < st["max_paths_in_flight"] * 4 and late.stats()["batch_halvings"] == 0
         finally:
             late.close()
@@ -1830,7 +1830,7 @@ def test_render_halves_its_batch_when_the_device_is_nearly_full():
     assert np.array_equal(ref["radiance"].view(np.uint32), got["radiance"].view(np.uint32))
     assert np.array_equal(ref["radiance"].view(np.uint32), again["radiance"].view(np.uint32))
     assert np.array_equal(ref["ray_count"], got["ray_count"])
-    assert small["radiance"].shape == (1080, 1920, 4)
+    assert small["radiance"].shape == (360, 640, 4)
 
 
 def test_last_ray_filter_on_ill_conditioned_emitters():

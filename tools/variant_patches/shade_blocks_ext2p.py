@@ -1,0 +1,6 @@
+# the extended k_shade instantiations (EXT or LT; not the probes) at 2 blocks per CU
+p = "kernels.h"
+s = open(p).read()
+old = "__launch_bounds__(STHIP_BLOCK, SHADE_BLOCKS) k_shade("
+assert s.count(old) == 1
+open(p, "w").write(s.replace(old, "__launch_bounds__(STHIP_BLOCK, ((LT || EXT) && !PROBE) ? 2 : SHADE_BLOCKS) k_shade("))
