@@ -615,3 +615,14 @@ def foliage():
 SCENES["foliage"] = foliage
 SCENES["spheres_room"] = spheres_room
 SCENES["environment"] = environment_scene
+
+
+def fog_box(**kwargs):
+    """The Cornell box with the test suite's NanoVDB fog sphere in it (tests/golden/fog_sphere.npz): media for bench.py --scene."""
+    import os
+
+    grid = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "fog_sphere.npz"))["grid"]
+    return cornell_box(fog=grid, **kwargs)
+
+
+SCENES["fog_box"] = fog_box
