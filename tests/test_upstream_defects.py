@@ -106,3 +106,25 @@ def test_the_padding_columns_collide_with_the_next_row(width, races):
     live = index < width * height  # gLightPathCount = W * H without the vertex cache (BDPT.cpp:469-470)
     collisions = np.unique(index[live]).size != int(live.sum())
     assert collisions == races
+
+
+@needs_reference
+def test_every_image_read_of_the_path_names_its_level():
+    """The reference's sampler asks for 8x anisotropic filtering (BDPT.cpp:130-133), the library models trilinear filtering over a
+    mip chain. Not a gap: anisotropic filtering works on the derivatives of an implicit-level read, and every image read of the
+    path tracer's shaders is `SampleLevel` with the level worked out from the ray cone (image_value.h:81-97; environment.h:53,74;
+    the alpha test in intersection.hlsli) — no derivative ever reaches the sampler, so its maxAnisotropy has nothing to act on.
+    The one implicit-level `.Sample(` of the tree is the GUI's rasteriser (kernels/renderers/raster.hlsl), out of scope."""
+    explicit, implicit = [], []
+    for root, _, files in os.walk(REF):
+        for f in files:
+            if not f.endswith((".h", ".hlsli", ".hlsl", ".slang")):
+                continue
+            rel = os.path.relpath(os.path.join(root, f), REF)
+            text = open(os.path.join(root, f), errors="replace").read()
+            if re.search(r"\.SampleLevel\(", text):
+                explicit.append(rel)
+            if re.search(r"\.(Sample|SampleGrad|SampleBias|SampleCmp)\(", text):
+                implicit.append(rel)
+    assert "image_value.h" in explicit and "environment.h" in explicit and os.path.join("common", "intersection.hlsli") in explicit
+    assert implicit == [os.path.join("kernels", "renderers", "raster.hlsl")], implicit
