@@ -2668,7 +2668,9 @@ struct PathIntegrator {
 
   // connect_light_reservoir at a vertex inside a medium (the same function upstream, BSDF = Medium): setup()'s medium branch
   // (path.hlsli:207-212) makes local_to_light the WORLD direction, so the target is luminance(Le) G |direction.z|; no ray
-  // offset, no distance epsilon, no shading-normal term (:446). Spatial reuse is not restated with media.
+  // offset, no distance epsilon, no shading-normal term (:446). Spatial reuse as at a surface (:402-439); the geometry normal
+  // upstream takes the jitter's tangent plane from, and stores with the reservoir, is the stale one of the last surface query
+  // at a vertex inside a medium: pinned to the packed value 0, as the first-hit normals of such a vertex are.
   void connect_light_reservoir_medium(const Medium& m) {
     const bool presampled = fr.flag(STHIP_ePresampleLights);
     LightCandidate c;
@@ -2689,8 +2691,64 @@ struct PathIntegrator {
         c = c_i;
       }
     }
+    const bool reuse = fr.flag(STHIP_eNEEReservoirReuse);
+    v3 t = V3(0.0f), b = V3(0.0f);
+    float cell_size = 0;
+    auto jittered = [&]() {
+      const float phi = rng.next_float() * 2 * DET_PI;
+      if (!fr.flag(STHIP_eHashGridJitter)) return isect.sd.position;
+      const float radius = cell_size * rng.next_float();
+      float sn, cs;
+      det_sincosf(phi, &sn, &cs);
+      return isect.sd.position + (t * cs + b * sn) * radius;
+    };
+    if (reuse) {
+      make_orthonormal(unpack_normal_octahedron(0), t, b);
+      cell_size = hashgrid_cell_size(isect.sd.position);
+      if (fr.prev_nee_grid && fr.pc.gReservoirSpatialM > 0) {
+        const v3 at = jittered();
+        const uint32_t bucket = fr.prev_nee_grid->table.find(at, cell_size);
+        if (bucket != 0xFFFFFFFFu) {
+          const uint32_t bucket_start = fr.prev_nee_grid->table.indices[bucket], bucket_size = fr.prev_nee_grid->table.counters[bucket];
+          uint32_t Msum = M;
+          for (uint32_t i = 0; i < fr.pc.gReservoirSpatialM; i++) {
+            const NEEReservoir& prev = fr.prev_nee_grid->data[bucket_start + rng.next_uint() % bucket_size];
+            const LightCandidate c_i = light_candidate_from(prev.y);
+            if (c_i.pdfA <= 0 || all_le0(c_i.Le)) continue;
+            Msum += prev.r.M;
+            const float target_pdf_i = luminance(c_i.Le) * c_i.G * fabsf(c_i.ray_direction.z);
+            const float w = target_pdf_i * prev.W * (float)prev.r.M;
+            M++;
+            total_weight += w;
+            if (rng.next_float() * total_weight <= w) {
+              r_target_pdf = target_pdf_i;
+              c = c_i;
+            }
+          }
+          M = Msum;
+        }
+      }
+    }
     const float W = (r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0;
     if (W <= 1e-6f || W != W) return;
+    if (reuse) {  // path.hlsli:434-439
+      const v3 at = jittered();
+      const size_t k = (size_t)path_index() * fr.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
+      if (fr.nee_appends && diffuse_vertices >= 1 && diffuse_vertices <= fr.pc.gMaxDiffuseVertices) {
+        HashGridOf<NEEReservoir>::Append& a = fr.nee_appends[k];
+        a.pos = at;
+        a.cell_size = cell_size;
+        a.y.r.total_weight = total_weight;
+        a.y.r.M = std::min(M, fr.pc.gReservoirMaxM);
+        a.y.packed_geometry_normal = 0;
+        a.y.W = W;
+        a.y.y.position = c.position;
+        a.y.y.packed_geometry_normal = c.packed_geometry_normal;
+        a.y.y.Le = c.Le;
+        a.y.y.pdfA = c.pdfA;
+        fr.nee_append_valid[k] = 1;
+      }
+    }
     const float f = m.phase(local_dir_in, c.ray_direction);
     v3 contrib = c.Le * f * c.G * W;
     if (all_le0(contrib) || c.pdfA < 1e-6f) return;
@@ -3794,10 +3852,9 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (fr.flag(STHIP_eCoherentSampling) && (scene_flags & STHIP_BDPT_FLAG_HAS_MEDIA) && !sc->volumes.empty()) return STHIP_ERR_UNSUPPORTED;  // walks through volumes break the lockstep
   if (has_media(fr)) {
     // with media every visibility ray draws random numbers from the stream it is given: the path's own for an inline NEE ray
-    // (path.hlsli:329-332, 474-479). The connections of eConnectToViews / eConnectToLightPaths and the reservoirs' spatial
-    // reuse are not restated with media.
+    // (path.hlsli:329-332, 474-479). The connections of eConnectToViews / eConnectToLightPaths are not restated with media.
     if (sc->volumes.empty()) fr.scene_flags &= ~STHIP_BDPT_FLAG_HAS_MEDIA;
-    else if (fr.sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths) | (1u << STHIP_eNEEReservoirReuse))) return STHIP_ERR_UNSUPPORTED;
+    else if (fr.sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths))) return STHIP_ERR_UNSUPPORTED;
   }
   // presample_lights, bdpt.hlsl:84-99, once per seed (BDPT.cpp:644-651): rng_init(-1, index), reference point 0.
   // An environment sample leaves `position` unset upstream, so that combination is not restated.

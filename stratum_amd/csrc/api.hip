@@ -1590,7 +1590,6 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   const uint32_t hg_buckets = (nee_reuse || lvc_reuse) ? pc->gHashGridBucketCount + 32u : 0u;  // probing does not wrap (hashgrid.h)
   if (nee_reuse || lvc_reuse) {
     if (has_env) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eNEEReservoirReuse with an environment (a stored environment sample is read back as a surface point upstream: sample_Le leaves its pdfA positive)");
-    if (media) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eNEEReservoirReuse with media is not built");
     if (ctx->shard_count > 1) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eNEEReservoirReuse on a pixel-tile shard (the grid is a whole-frame structure: render replicas and reduce)");
     if (pc->gHashGridBucketCount == 0 || pc->gHashGridBucketCount > (1u << 28) || !(pc->gHashGridMinBucketRadius > 0)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eNEEReservoirReuse needs 0 < gHashGridBucketCount <= 2^28 and gHashGridMinBucketRadius > 0");
     hg_slots = (size_t)((W + 7) / 8) * ((H + 3) / 4) * 32 * std::max(1u, pc->gMaxDiffuseVertices);  // covers both map_pixel_coord forms

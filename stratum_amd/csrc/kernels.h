@@ -1565,7 +1565,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             f3 cLe = F3s(0.0f), c_dir = F3s(0.0f);
             float c_pdfA = 0, c_dist = 0, c_G = 0;
             const bool presampled = flag(p, STHIP_ePresampleLights);
-            auto medium_candidate = [&](uint32_t ti, f3& cLe, float& c_pdfA, f3& c_dir, float& c_dist, float& c_G) {
+            auto medium_candidate = [&](uint32_t ti, f3& cLe, float& c_pdfA, f3& c_dir, float& c_dist, float& c_G, f3& c_pos, uint32_t& c_pgn) {
             if (presampled) {
               uint32_t path_index;
               if (flag(p, STHIP_eRemapThreads))
@@ -1578,6 +1578,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
               const float4 l0 = lp[0], l1 = lp[1];
               cLe = xyz(l1);
               c_pdfA = l1.w;
+              c_pos = xyz(l0);
+              c_pgn = __float_as_uint(l0.w);
               c_dir = xyz(l0) - scatter_p;
               const float d2 = len_sqr(c_dir);
               c_dist = sqrtf(d2);
@@ -1591,6 +1593,8 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
               c_dir = ls.to_light;
               c_dist = ls.dist;
               c_pdfA = ls.pdf;
+              c_pos = ls.position;
+              c_pgn = pack_normal_octahedron(ls.normal);
               if (ls.is_env) {
                 c_G = 1;
               } else {
@@ -1602,15 +1606,20 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             uint32_t* column = (MEDIA == 2) ? p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth : nullptr;
             if (EXT && flag(p, STHIP_eNEEReservoirs)) {
               // connect_light_reservoir at a medium vertex (path.hlsli:368-486 with setup()'s medium branch, :207-212: local_to_light
-              // is the WORLD direction, so the target is luminance(Le) G |direction.z|); no spatial reuse with media
+              // is the WORLD direction, so the target is luminance(Le) G |direction.z|). Spatial reuse as at a surface (:402-439);
+              // the geometry normal upstream takes the jitter's tangent plane from, and stores, is the stale one of the last
+              // surface query here: pinned to the packed value 0 on both sides
               float total_weight = 0, r_target_pdf = 0;
               uint32_t M = 0;
+              f3 y_pos = F3s(0.0f);  // the chosen candidate's PresampledLightPoint (what a reservoir stores)
+              uint32_t y_pgn = 0;
               uint32_t ti = rng.next_uint();
               for (uint32_t k = 0; k < p.pc.gReservoirM; k++) {
                 if (presampled) ti = rng.next_uint();
-                f3 iLe = F3s(0.0f), i_dir = F3s(0.0f);
+                f3 iLe = F3s(0.0f), i_dir = F3s(0.0f), i_pos = F3s(0.0f);
                 float i_pdfA = 0, i_dist = 0, i_G = 0;
-                medium_candidate(ti, iLe, i_pdfA, i_dir, i_dist, i_G);
+                uint32_t i_pgn = 0;
+                medium_candidate(ti, iLe, i_pdfA, i_dir, i_dist, i_G, i_pos, i_pgn);
                 if (i_pdfA <= 0 || all_le0(iLe)) continue;
                 const float target_pdf = luminance3(iLe) * i_G * fabsf(i_dir.z);
                 const float w = target_pdf / i_pdfA;
@@ -1623,10 +1632,78 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
                   c_pdfA = i_pdfA;
                   c_dist = i_dist;
                   c_G = i_G;
+                  y_pos = i_pos;
+                  y_pgn = i_pgn;
+                }
+              }
+              const bool reuse = p.hg_appends != nullptr;
+              f3 hg_t = F3s(0.0f), hg_b = F3s(0.0f);
+              float cell_size = 0;
+              auto jittered = [&]() {
+                const float phi = rng.next_float() * 2 * DET_PI;
+                if (!flag(p, STHIP_eHashGridJitter)) return scatter_p;
+                const float radius = cell_size * rng.next_float();
+                float sn, cs;
+                det_sincosf(phi, &sn, &cs);
+                return scatter_p + (hg_t * cs + hg_b * sn) * radius;
+              };
+              if (reuse) {
+                make_orthonormal(unpack_normal_octahedron(0u), hg_t, hg_b);
+                const Xf vt = load_xf(p.view_xf, 0);
+                cell_size = hashgrid_cell_size(p.pc, p.views[0], F3(vt.r0.w, vt.r1.w, vt.r2.w), scatter_p);
+                if (p.hg_prev && p.pc.gReservoirSpatialM > 0) {
+                  const f3 at = jittered();
+                  const uint32_t bucket = hashgrid_find(p.hg_checksums, p.pc.gHashGridBucketCount, at, cell_size);
+                  if (bucket != 0xFFFFFFFFu) {
+                    const uint32_t bucket_start = p.hg_indices[bucket], bucket_size = p.hg_counters[bucket];
+                    uint32_t Msum = M;
+                    for (uint32_t k = 0; k < p.pc.gReservoirSpatialM; k++) {
+                      const float4* pr = p.hg_data + 3 * (size_t)(bucket_start + rng.next_uint() % bucket_size);
+                      const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+                      const f3 iLe = xyz(q2);
+                      const float i_pdfA = q2.w;
+                      f3 i_dir = xyz(q1) - scatter_p;
+                      const float d2 = len_sqr(i_dir);
+                      const float i_dist = sqrtf(d2);
+                      i_dir = i_dir / i_dist;
+                      const float i_G = fabsf(dot3(i_dir, unpack_normal_octahedron(__float_as_uint(q1.w)))) / d2;
+                      if (i_pdfA <= 0 || all_le0(iLe)) continue;
+                      const uint32_t prev_M = __float_as_uint(q0.y);
+                      Msum += prev_M;
+                      const float target_pdf = luminance3(iLe) * i_G * fabsf(i_dir.z);
+                      const float w = target_pdf * q0.w * (float)prev_M;
+                      M++;
+                      total_weight += w;
+                      if (rng.next_float() * total_weight <= w) {
+                        r_target_pdf = target_pdf;
+                        cLe = iLe;
+                        c_dir = i_dir;
+                        c_pdfA = i_pdfA;
+                        c_dist = i_dist;
+                        c_G = i_G;
+                        y_pos = xyz(q1);
+                        y_pgn = __float_as_uint(q1.w);
+                      }
+                    }
+                    M = Msum;
+                  }
                 }
               }
               const float W = (r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0;
               if (W <= 1e-6f || W != W) break;
+              if (reuse) {  // path.hlsli:434-439
+                const f3 at = jittered();
+                uint32_t path_index;  // map_pixel_coord, bdpt_util.hlsli:76-83
+                if (flag(p, STHIP_eRemapThreads))
+                  path_index = ((py >> 2) * ((p.pc.gOutputExtent[0] + 7u) >> 3) + (px >> 3)) * 32u + (py & 3u) * 8u + (px & 7u);
+                else
+                  path_index = py * p.pc.gOutputExtent[0] + px;
+                float4* a = p.hg_appends + 4 * ((size_t)path_index * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1));
+                a[0] = make_float4(at.x, at.y, at.z, total_weight);
+                a[1] = make_float4(__uint_as_float(min(M, p.pc.gReservoirMaxM)), __uint_as_float(0u), W, c_pdfA);
+                a[2] = make_float4(y_pos.x, y_pos.y, y_pos.z, cell_size);
+                a[3] = make_float4(cLe.x, cLe.y, cLe.z, __uint_as_float(y_pgn));
+              }
               const float f = mm.phase(local_dir_in, c_dir);
               f3 contrib = cLe * f * c_G * W;
               if (all_le0(contrib) || c_pdfA < 1e-6f) break;
@@ -1657,7 +1734,9 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
               p.shadow_ext[shadow_base + k] = make_float4(__uint_as_float(rng.counter), 1.0f, __uint_as_float(entry), 0.0f);
               break;
             }
-            medium_candidate(presampled ? rng.next_uint() : 0u, cLe, c_pdfA, c_dir, c_dist, c_G);
+            f3 unused_pos = F3s(0.0f);
+            uint32_t unused_pgn = 0;
+            medium_candidate(presampled ? rng.next_uint() : 0u, cLe, c_pdfA, c_dir, c_dist, c_G, unused_pos, unused_pgn);
             if (all_le0(cLe) && c_pdfA < 1e-6f) break;
             const float f = mm.phase(local_dir_in, c_dir);
             const float pdfA_fwd = f * c_G;

@@ -1356,6 +1356,9 @@ def test_trace_contract_with_volumes(renderer):
         ({}, ["neereservoirs"], {"maxDiffuseVertices": 3, "reservoirM": 4}),
         ({"density": (9.0, 9.0, 9.0)}, ["neereservoirs", "presamplelights", "~samplebsdfs"], {"maxDiffuseVertices": 4, "reservoirM": 3}),
         ({"anisotropy": 0.4, "density": (9.0, 6.0, 3.0)}, ["neereservoirs", "~defershadowrays"], {"maxDiffuseVertices": 4, "reservoirM": 2, "minPathVertices": 2}),
+        # ... with spatial reuse: seeds 1 and 2 look into the grid the seed before them built, from surface and medium vertices alike
+        ({"density": (9.0, 9.0, 9.0)}, ["neereservoirs", "neereservoirreuse"], {"maxDiffuseVertices": 3, "reservoirM": 2, "reservoirSpatialM": 3, "hashGridBucketCount": 20000}),
+        ({"anisotropy": 0.3}, ["neereservoirs", "neereservoirreuse", "~jitterhashgridlookups", "~defershadowrays", "presamplelights"], {"maxDiffuseVertices": 4, "reservoirM": 3, "reservoirSpatialM": 2, "hashGridBucketCount": 5000}),
     ],
 )
 def test_media(kwargs, flags, args):
