@@ -2753,7 +2753,13 @@ struct PathIntegrator {
     v3 contrib = c.Le * f * c.G * W;
     if (all_le0(contrib) || c.pdfA < 1e-6f) return;
     float weight = 1;
-    if (fr.flag(STHIP_eSampleBSDFs)) weight = 1 - 0.5f;
+    if (fr.bdpt()) {  // path.hlsli:458-465, emission_pdfA = 0 at a medium vertex
+      const float dL = connection_dVC(W, 0.0f, 1 / W, false);
+      const float G_rev = prev_cos_out / len_sqr(origin - isect.sd.position);
+      const float dE = connection_dVC(dVC, f * G_rev, bsdf_pdf * G, prev_specular);
+      weight = 1 / (1 + dE * pow2(0.0f) + dL * pow2(f * c.G));
+    } else if (fr.flag(STHIP_eSampleBSDFs))
+      weight = 1 - 0.5f;
     if (fr.flag(STHIP_eDeferShadowRays)) {
       const v3 cc = beta * contrib * weight;
       if (diffuse_vertices >= 1 && diffuse_vertices <= max_shadow) {
@@ -2862,14 +2868,18 @@ struct PathIntegrator {
     if (!m.is_specular()) {
       diffuse_vertices++;
       if (diffuse_vertices > fr.pc.gMaxDiffuseVertices) return false;
-      if (path_length >= fr.pc.gMinPathVertices)
-        if (!russian_roulette()) return false;
-      if (fr.flag(STHIP_eNEE)) {
-        if (fr.flag(STHIP_eNEEReservoirs)) connect_light_reservoir_medium(m);
-        else connect_light_medium(m);
+      if (trace_light) {  // (eConnectToLightPaths is not restated with media: no vertex is stored)
+        if (fr.flag(STHIP_eConnectToViews)) connect_view_medium(m);
+      } else {
+        if (path_length >= fr.pc.gMinPathVertices)
+          if (!russian_roulette()) return false;
+        if (fr.flag(STHIP_eNEE)) {
+          if (fr.flag(STHIP_eNEEReservoirs)) connect_light_reservoir_medium(m);
+          else connect_light_medium(m);
+        }
       }
     }
-    if (!fr.flag(STHIP_eSampleBSDFs)) return false;
+    if (!fr.flag(STHIP_eSampleBSDFs) && !trace_light) return false;
     // sample_direction, path.hlsli:898-952, medium branch
     const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float();
     (void)r2;
@@ -2915,7 +2925,17 @@ struct PathIntegrator {
     const v3 contrib = Le * f * cand.G / pdfA;
     if (all_le0(contrib)) return;
     float weight = 1;
-    if (fr.flag(STHIP_eSampleBSDFs)) weight = mis2(fr, pdfA, pdfA_fwd);
+    if (fr.bdpt()) {  // BDPT MIS, path.hlsli:341-351; setup()'s medium branch leaves emission_pdfA = 0 (:211), the phase function is pdf_rev
+      if (fr.flag(STHIP_eMIS)) {
+        const float dL = connection_dVC(1 / pdfA, 0.0f, pdfA, false);
+        const float G_rev = prev_cos_out / len_sqr(origin - isect.sd.position);
+        const float dE = connection_dVC(dVC, f * G_rev, bsdf_pdf * G, prev_specular);
+        weight = 1 / (1 + dE * pow2(0.0f) + dL * pow2(pdfA_fwd));
+      } else {
+        weight = path_weight(path_length, 1);
+      }
+    } else if (fr.flag(STHIP_eSampleBSDFs))
+      weight = mis2(fr, pdfA, pdfA_fwd);
     if (!defer) {
       accumulate_contribution(beta * contrib, weight, 1);  // path.hlsli:365
       return;
@@ -3183,7 +3203,11 @@ struct PathIntegrator {
   }
 
   // connect_view, path.hlsli:533-613: the light-path vertex seen from the camera, splatted into gLightTraceSamples
-  void connect_view(const DisneyMaterial& m) {
+  // connect_view, path.hlsli:533-613. At a vertex inside a medium (`phase` != null): no geometry — ngdotout = 1, the direction
+  // itself as local_to_view, no ray offset, no shading-normal factor (:562-565) — and the phase function as f and both pdfs.
+  void connect_view(const DisneyMaterial& m) { connect_view_any(&m, nullptr); }
+  void connect_view_medium(const Medium& mm) { connect_view_any(nullptr, &mm); }
+  void connect_view_any(const DisneyMaterial* mp, const Medium* phase) {
     uint32_t view_index = 0;
     if (fr.pc.gViewCount > 1) view_index = (uint32_t)fminf(rng.next_float() * (float)fr.pc.gViewCount, (float)(fr.pc.gViewCount - 1));
     const sthip_ViewData& view = fr.fd.gViews[view_index];
@@ -3209,17 +3233,29 @@ struct PathIntegrator {
     // pdfAtoW(1 / lens_area, cos / dist^2) = 1 / (cos / dist^2)
     v3 contribution = beta * sensor_importance / (1.0f / (sensor_cos_theta / pow2(dist)));
     const float G_rev = fabsf(prev_cos_out) / len_sqr(origin - isect.sd.position);
-    const v3 geometry_normal = isect.sd.geometry_normal();
-    const float ngdotout = dot(to_view, geometry_normal);
-    const v3 ray_origin = ray_offset(isect.sd.position, ngdotout > 0 ? geometry_normal : -geometry_normal);
-    const v3 local_to_view = normalize(isect.sd.to_local(to_view));
-    contribution = contribution * shading_normal_correction(local_dir_in.z, local_to_view.z, ngdotin, ngdotout, dot(geometry_normal, isect.sd.shading_normal()), fr.flag(STHIP_eShadingNormalShadowFix), true);
+    v3 ray_origin = isect.sd.position;
     MaterialEvalRecord ev;
-    m.eval(ev, local_dir_in, local_to_view, true);
+    if (phase) {
+      const float v = phase->phase(local_dir_in, to_view);
+      ev.f = V3(v);
+      ev.pdf_fwd = ev.pdf_rev = v;
+    } else {
+      const v3 geometry_normal = isect.sd.geometry_normal();
+      const float ngdotout = dot(to_view, geometry_normal);
+      ray_origin = ray_offset(isect.sd.position, ngdotout > 0 ? geometry_normal : -geometry_normal);
+      const v3 local_to_view = normalize(isect.sd.to_local(to_view));
+      contribution = contribution * shading_normal_correction(local_dir_in.z, local_to_view.z, ngdotin, ngdotout, dot(geometry_normal, isect.sd.shading_normal()), fr.flag(STHIP_eShadingNormalShadowFix), true);
+      mp->eval(ev, local_dir_in, local_to_view, true);
+    }
     if (ev.pdf_fwd < 1e-6f) return;
     contribution = contribution * ev.f;
     if (all_le0(contribution)) return;
-    if (occluded(ray_origin, to_view, dist)) return;  // trace_visibility_ray over the full distance (:580)
+    if (has_media(fr)) {  // trace_visibility_ray through the media, in this light path's own stream (:577-581)
+      float nee_pdf = 1, dir_pdf = 1;
+      trace_visibility_media(rng, ray_origin, to_view, dist, medium, contribution, dir_pdf, nee_pdf, 64);
+      if (nee_pdf > 0) contribution = contribution / nee_pdf;
+    } else if (occluded(ray_origin, to_view, dist))
+      return;  // trace_visibility_ray over the full distance (:580)
     float weight;
     if (fr.flag(STHIP_eMIS)) {
       if (fr.flag(STHIP_eConnectToLightPaths)) {  // dL_1, path.hlsli:591-596
@@ -3852,9 +3888,9 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (fr.flag(STHIP_eCoherentSampling) && (scene_flags & STHIP_BDPT_FLAG_HAS_MEDIA) && !sc->volumes.empty()) return STHIP_ERR_UNSUPPORTED;  // walks through volumes break the lockstep
   if (has_media(fr)) {
     // with media every visibility ray draws random numbers from the stream it is given: the path's own for an inline NEE ray
-    // (path.hlsli:329-332, 474-479). The connections of eConnectToViews / eConnectToLightPaths are not restated with media.
+    // (path.hlsli:329-332, 474-479), the light path's for connect_view (:577-581). eConnectToLightPaths is not restated with media.
     if (sc->volumes.empty()) fr.scene_flags &= ~STHIP_BDPT_FLAG_HAS_MEDIA;
-    else if (fr.sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths))) return STHIP_ERR_UNSUPPORTED;
+    else if (fr.sampling_flags & (1u << STHIP_eConnectToLightPaths)) return STHIP_ERR_UNSUPPORTED;
   }
   // presample_lights, bdpt.hlsl:84-99, once per seed (BDPT.cpp:644-651): rng_init(-1, index), reference point 0.
   // An environment sample leaves `position` unset upstream, so that combination is not restated.

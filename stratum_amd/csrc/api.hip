@@ -1498,10 +1498,10 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   if (media && (sampling_flags & (1u << STHIP_eCoherentSampling))) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eCoherentSampling with media (walks through volumes break the lockstep of a workgroup)");
   if (media) {
     // with media every visibility ray draws random numbers. An inline NEE ray (no eDeferShadowRays) draws them from the path's
-    // own stream in the middle of a vertex: k_shade walks it itself (visibility_walk_media). The connections of
-    // eConnectToViews / eConnectToLightPaths would need the same in the light pass and are not built.
-    if (sampling_flags & ((1u << STHIP_eConnectToViews) | (1u << STHIP_eConnectToLightPaths)))
-      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media together with light subpaths are not built");
+    // own stream in the middle of a vertex: k_shade walks it itself (visibility_walk_media); so does k_shade_light for every
+    // connect_view of light tracing. The connections to stored light vertices (eConnectToLightPaths) are not built with media.
+    if (sampling_flags & (1u << STHIP_eConnectToLightPaths))
+      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media together with eConnectToLightPaths are not built");
   } else {
     pcn.gMaxNullCollisions = 0;
   }
@@ -1788,7 +1788,7 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   p.media = media ? 1u : 0u;
   const bool inline_media = media && (sampling_flags & (1u << STHIP_eNEE)) && !(sampling_flags & (1u << STHIP_eDeferShadowRays));
   p.inline_media = inline_media ? 1u : 0u;
-  if (inline_media) {
+  if (inline_media || (media && connect_views)) {  // (light tracing's connect_view walks inline whatever eDeferShadowRays says)
     HIP_TRY(ctx, ctx->shade_stack.ensure((size_t)shade_grid * STHIP_BLOCK * std::max(1u, ctx->bvh.stack_depth)));
     p.shade_stack = ctx->shade_stack.p;
   }
@@ -2089,8 +2089,12 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
           hipLaunchKernelGGL((k_generate_light<false, true>), dim3(lgrid), dim3(STHIP_BLOCK), 0, st, p);
       });
       if (rc) return rc;
-      rc = run_rounds(true, true, [&](uint32_t depth) {
-        if (ctx->textured)
+      rc = run_rounds(true, !media, [&](uint32_t depth) {  // (media: connect_view walks its ray itself: nothing is queued)
+        if (media && ctx->textured)
+          hipLaunchKernelGGL((k_shade_light<true, true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else if (media)
+          hipLaunchKernelGGL((k_shade_light<false, true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else if (ctx->textured)
           hipLaunchKernelGGL((k_shade_light<true, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
         else
           hipLaunchKernelGGL((k_shade_light<false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
@@ -2198,7 +2202,11 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
         hipLaunchKernelGGL(k_cs_reduce, dim3(reduce_grid), dim3(STHIP_BLOCK), 0, st, p.cs_lvc, p.path_count);
       }
       if (debug_mode) {  // BDPTDebugMode: the general instantiation with the statements that feed gDebugImage
-        if (media && inline_media)
+        if (media && bdpt && inline_media)
+          hipLaunchKernelGGL((k_shade<true, true, true, 2, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else if (media && bdpt)
+          hipLaunchKernelGGL((k_shade<true, true, true, 1, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else if (media && inline_media)
           hipLaunchKernelGGL((k_shade<true, true, false, 2, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
         else if (media)
           hipLaunchKernelGGL((k_shade<true, true, false, 1, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
@@ -2206,6 +2214,15 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
           hipLaunchKernelGGL((k_shade<true, true, true, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
         else
           hipLaunchKernelGGL((k_shade<true, true, false, false, false, true>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+      } else if (media && bdpt) {  // light tracing through media: the view paths carry the BDPT quantities
+        if (ctx->textured && inline_media)
+          hipLaunchKernelGGL((k_shade<true, true, true, 2>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else if (ctx->textured)
+          hipLaunchKernelGGL((k_shade<true, true, true, 1>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);
+        else if (inline_media)
+          hipLaunchKernelGGL((k_shade<false, true, true, 2>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
+        else
+          hipLaunchKernelGGL((k_shade<false, true, true, 1>), dim3(grid), dim3(STHIP_BLOCK), shade_lds, st, p, depth);
       } else if (media && inline_media) {
         if (ctx->textured)
           hipLaunchKernelGGL((k_shade<true, true, false, 2>), dim3(grid), dim3(STHIP_BLOCK), 0, st, p, depth);

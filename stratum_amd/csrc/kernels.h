@@ -994,6 +994,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate_light(FrameParams p) {
     }
     p.meta[slot] = 1u;
     if (TEXTURED) p.cone[slot] = make_float2(0.0f, 0.0f);
+    if (p.media) {  // bdpt.hlsl:114: a light path starts outside every medium; T_dir_pdf = T_nee_pdf = 1, no segment walked yet
+      p.media_state[2 * (size_t)slot] = make_float4(origin.x, origin.y, origin.z, 1.0f);
+      p.media_state[2 * (size_t)slot + 1] = make_float4(1.0f, __uint_as_float(0xFFFFu), __uint_as_float(0u), 0.0f);
+    }
     live++;
   }
   wave_add(&p.counters[CNT_RAYS_CLOSEST], live);  // every live light path traces its first ray (path.hlsli:1006)
@@ -1011,239 +1015,6 @@ __global__ void k_count_rays(FrameParams p) {
   p.counters[CNT_RAYS_CLOSEST] += closest + answered;
   p.counters[CNT_RAYS_ANSWERED] += answered;
   p.counters[CNT_RAYS_SHADOW] += shadow;
-}
-
-// path_weight, path.hlsli:16-28: one over the number of ways upstream counts for a path of this many vertices
-DEV float path_weight(const FrameParams& p, uint32_t view_length, uint32_t light_length) {
-  const uint32_t nv = view_length + light_length;
-  if (nv <= 2) return 1;
-  uint32_t ways = 1;
-  if (flag(p, STHIP_eNEE)) ways++;
-  if (flag(p, STHIP_eConnectToViews) && nv <= p.pc.gMaxPathVertices + 1) ways++;
-  if (flag(p, STHIP_eConnectToLightPaths)) ways += min(p.pc.gMaxPathVertices, nv - 2);
-  return 1.f / (float)ways;
-}
-
-template <bool TEXTURED, bool EXT>
-__global__ void __launch_bounds__(STHIP_BLOCK, 3) k_shade_light(FrameParams p, uint32_t depth) {
-  const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
-  const uint32_t seg_base = seg * p.seg_stride;
-  uint32_t n, slot0 = 0;
-  if (depth == 0) {
-    const uint32_t per = (((p.path_count + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) + 63u) & ~63u;
-    slot0 = seg * per;
-    n = slot0 < p.path_count ? (slot0 + per < p.path_count ? per : p.path_count - slot0) : 0u;
-  } else {
-    n = (uint32_t)queue_ctl(p.qctl, 0, depth, seg)[QCTL_SIZE];
-  }
-  const uint32_t first = (blockIdx.x / QUEUE_SEGMENTS) * blockDim.x + threadIdx.x;
-  const uint32_t step = ((gridDim.x - seg + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) * blockDim.x;
-  const uint32_t* queue_in = p.queue[depth & 1u] + seg_base;
-  uint32_t* queue_out = p.queue[(depth + 1) & 1u] + seg_base;
-  float4* shadow_out = p.shadow_rays + 3 * (size_t)seg * p.shadow_stride;
-  unsigned long long* queue_size = &queue_ctl(p.qctl, 0, depth + 1, seg)[QCTL_SIZE];
-  unsigned long long* shadow_size = &queue_ctl(p.qctl, 1, depth, seg)[QCTL_SIZE];
-  const uint32_t W = p.pc.gOutputExtent[0], H = p.pc.gOutputExtent[1];
-  const bool connect_views = flag(p, STHIP_eConnectToViews), connect_paths = flag(p, STHIP_eConnectToLightPaths);
-  for (uint32_t i = first; i < n; i += step) {
-    const uint32_t slot = depth == 0 ? slot0 + i : queue_in[i];
-    const uint32_t meta = p.meta[slot];
-    if (meta >= 0xFFFFFFFEu) continue;
-    const uint32_t seed_index = slot / p.light_threads;
-    uint32_t tx, ty, path_index;
-    light_thread(p, slot - seed_index * p.light_threads, tx, ty, path_index);
-    const float4 ro = p.ray_o[slot], rd = p.ray_d[slot], hh = p.hit[slot], bb = p.beta[slot], bd = p.bdpt[slot];
-    const uint32_t hit_leaf = p.hit_leaf[slot];
-    const f3 origin = xyz(ro), direction = xyz(rd);
-    float bsdf_pdf = ro.w, eta_scale = rd.w;
-    f3 beta = xyz(bb);
-    float path_pdf = bd.x, path_pdf_rev = bd.y, dVC = bd.z, prev_cos_out = bd.w;
-    bool prev_specular = (meta >> 16) & 1u;
-    f3 path_contrib = p.path_contrib ? xyz(p.path_contrib[slot]) : F3s(0.0f);
-    Rng rng;
-    rng.x = tx;
-    rng.y = ty;
-    rng.seed = p.seed + seed_index;
-    rng.counter = __float_as_uint(bb.w);
-    uint32_t path_length = meta & 0xFFu, diffuse_vertices = (meta >> 8) & 0xFFu;
-    const uint32_t ip = __float_as_uint(hh.w);
-    bool alive = false;
-    f3 new_origin = origin, new_direction = direction;
-    float2 cone_out = make_float2(0.0f, 0.0f);
-    do {
-      if (all_le0(beta)) break;  // trace(), path.hlsli:1009-1010
-      path_length++;
-      if (ip == 0xFFFFFFFFu) break;  // light paths that leave the scene end (no environment with light tracing)
-      const uint32_t inst_index = ip & 0xFFFFu;
-      const Inst in = load_inst(p.scene, inst_index);
-      ShadingData sd;
-      if (EXT && in.type() == STHIP_INSTANCE_TYPE_SPHERE) {
-        const Xf inv = load_xf(p.scene.inv_xf, inst_index);
-        const float im[12] = {inv.r0.x, inv.r0.y, inv.r0.z, inv.r0.w, inv.r1.x, inv.r1.y, inv.r1.z, inv.r1.w, inv.r2.x, inv.r2.y, inv.r2.z, inv.r2.w};
-        make_sphere_shading_data(p.scene, sd, inst_index, in, obj_point(im, origin) + obj_vector(im, direction) * hh.x);
-      } else {
-        make_hit_shading_data(p.scene, sd, inst_index, hit_leaf, hh.y, hh.z, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
-      }
-      const f3 gn = sd.geometry_normal();
-      const float dist2 = len_sqr(sd.position - origin);
-      float G = 1 / dist2;
-      const float ngdotin = -dot3(direction, gn);
-      G *= fabsf(ngdotin);
-      path_pdf *= bsdf_pdf * G;  // path.hlsli:1042
-      if (p.path_contrib) path_contrib = path_contrib * G;  // path.hlsli:1043
-      DisneyMaterial m;
-      float rd_radius = 0, rd_spread = 0;  // RayDifferential of the light path: starts at (0, 0), bounces spread it (path.hlsli:911-916)
-      if (TEXTURED) {
-        const float2 cone = p.cone[slot];
-        rd_radius = cone.x;
-        rd_spread = cone.y;
-        if (flag(p, STHIP_eRayCones)) {  // path.hlsli:1026-1029
-          rd_radius += rd_spread * sqrtf(dist2);
-          sd.uv_screen_size *= rd_radius;
-        }
-        m.load_textured(p.scene, in.material_address(), sd.u, sd.v, sd.uv_screen_size, sd.packed_shading_normal, sd.packed_tangent, p.sampling_flags);
-      } else {
-        m.load(p.scene, in.material_address());
-      }
-      const Frame3 frame = make_frame(sd);
-      const f3 local_dir_in = normalize3(frame.to_local(-direction));
-      // next_vertex(BSDF), path.hlsli:955-998, light branch
-      if (!m.can_eval() || path_length >= p.pc.gMaxPathVertices) break;
-      const float ngdotns = dot3(gn, sd.shading_normal());
-      const bool fix = flag(p, STHIP_eShadingNormalShadowFix);
-      if (!m.is_specular()) {
-        diffuse_vertices++;
-        if (diffuse_vertices > p.pc.gMaxDiffuseVertices) break;
-        if (connect_paths && path_length + 2 <= p.pc.gMaxPathVertices && diffuse_vertices < p.pc.gMaxDiffuseVertices) {
-          // vertex() / store_light_vertex(), path.hlsli:491-531: slot light_vertex_index(path_index, diffuse_vertices) (:64)
-          const size_t per_seed = (size_t)p.pc.gLightPathCount * p.pc.gMaxDiffuseVertices;
-          const size_t idx = (size_t)W * H * (diffuse_vertices - 1) + path_index;
-          if (p.lvc_staging || idx < per_seed) {
-            // eLVC: staged per (path, vertex) and compacted in that order afterwards (see FrameParams::lvc_staging)
-            float4* lv = p.lvc_staging ? p.lvc_staging + 4 * (((size_t)seed_index * p.pc.gLightPathCount + path_index) * (p.pc.gMaxDiffuseVertices - 1) + (diffuse_vertices - 1))
-                                       : p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
-            const uint32_t vflags = 2u | (prev_specular ? 8u : 0u);  // IS_BACKGROUND as upstream sets it (SURVEY B6), IS_PREV_DELTA
-            const f3 stored = flag(p, STHIP_eLVCReservoirs) ? path_contrib : beta;  // path.hlsli:513
-            const uint32_t pb0 = det_f32tof16(stored.x) | (det_f32tof16(stored.y) << 16);
-            const uint32_t pb1 = det_f32tof16(stored.z) | ((path_length & 0x7Fu) << 16) | ((diffuse_vertices & 0x1Fu) << 23) | (vflags << 28);
-            lv[0] = make_float4(sd.position.x, sd.position.y, sd.position.z, __uint_as_float(sd.packed_geometry_normal));
-            lv[1] = make_float4(__uint_as_float(in.material_address()), __uint_as_float(pack_normal_octahedron(local_dir_in)), __uint_as_float(sd.packed_shading_normal),
-                                __uint_as_float(sd.packed_tangent));
-            lv[2] = make_float4(sd.u, sd.v, __uint_as_float(pb0), __uint_as_float(pb1));
-            lv[3] = make_float4(dVC, prev_cos_out / len_sqr(origin - sd.position), bsdf_pdf * G, path_pdf);
-          }
-        }
-        if (connect_views) do {  // connect_view, path.hlsli:533-613
-          uint32_t view_index = 0;
-          if (p.pc.gViewCount > 1) view_index = (uint32_t)fminf(rng.next_float() * (float)p.pc.gViewCount, (float)(p.pc.gViewCount - 1));
-          const sthip_ViewData& view = p.views[view_index];
-          float4 sp = project_point(view.projection, xf_point(load_xf(p.inv_view_xf, view_index), sd.position));
-          sp.y = -sp.y;
-          sp.x = sp.x / sp.w;
-          sp.y = sp.y / sp.w;
-          sp.z = sp.z / sp.w;
-          if (fabsf(sp.x) >= 1 || fabsf(sp.y) >= 1 || fabsf(sp.z) >= 1 || sp.z <= 0) break;
-          const float u = sp.x * .5f + .5f, v = sp.y * .5f + .5f;
-          const int ix = view.image_min[0] + (int)((float)(view.image_max[0] - view.image_min[0]) * u);
-          const int iy = view.image_min[1] + (int)((float)(view.image_max[1] - view.image_min[1]) * v);
-          const Xf t = load_xf(p.view_xf, view_index);
-          const f3 position = F3(t.r0.w, t.r1.w, t.r2.w);
-          const f3 view_normal = normalize3(xf_vector(t, F3(0, 0, 1)));
-          f3 to_view = position - sd.position;
-          const float dist = length3(to_view);
-          to_view = to_view / dist;
-          const float sensor_cos_theta = fabsf(dot3(to_view, view_normal));
-          const float sensor_importance = 1 / (view.projection.sensor_area * 1.0f * (pow2f(sensor_cos_theta) * pow2f(sensor_cos_theta)));
-          f3 contribution = beta * sensor_importance / (1.0f / (sensor_cos_theta / pow2f(dist)));
-          const float G_rev = fabsf(prev_cos_out) / len_sqr(origin - sd.position);
-          const float ngdotout = dot3(to_view, gn);
-          const f3 ray_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
-          const f3 local_to_view = normalize3(frame.to_local(to_view));
-          contribution = contribution * shading_normal_correction(local_dir_in.z, local_to_view.z, ngdotin, ngdotout, ngdotns, fix, true);
-          MaterialEvalRecord ev;
-          m.eval(ev, local_dir_in, local_to_view, true);
-          if (ev.pdf_fwd < 1e-6f) break;
-          contribution = contribution * ev.f;
-          if (all_le0(contribution)) break;
-          float weight;
-          if (flag(p, STHIP_eMIS)) {
-            if (connect_paths)  // dL_1, path.hlsli:591-596
-              weight = 1 / (1 + connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular) * pow2f(1.0f));
-            else
-              weight = prev_specular ? 1.0f : mis2(true, path_pdf, 1.0f * path_pdf_rev * (ev.pdf_rev * G_rev));
-          } else {
-            weight = path_weight(p, 1, path_length);
-          }
-          if (p.debug_mode == STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION) weight = 1;  // path.hlsli:608-609
-          if (p.debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && p.pc.gDebugViewPathLength == 1)  // :611-613: only the asked light length adds, unweighted (its visibility ray has been traced either way, :588)
-            weight = p.pc.gDebugLightPathLength == path_length ? 1.0f : 0.0f;
-          const f3 c = contribution * weight;
-          // the splat lands on pixel (ix, iy) of this seed's image; a sharded renderer keeps only its own pixels
-          if (ix < 0 || iy < 0 || (uint32_t)ix >= W || (uint32_t)iy >= H) break;
-          if (p.shard_count > 1 && (((uint32_t)iy / p.tile_h) * p.tiles_x + (uint32_t)ix / p.tile_w) % p.shard_count != p.shard_rank) break;
-          if (!(dist > 1e-6f)) {  // trace_visibility_ray's loop never runs: visible, no ray
-            uint32_t* lt = p.light_trace + 4 * ((size_t)seed_index * W * H + (size_t)iy * W + ix);
-            const float q = (float)p.light_trace_quantization;
-            const float cf[3] = {fmaxf(0.0f, c.x) * q, fmaxf(0.0f, c.y) * q, fmaxf(0.0f, c.z) * q};
-            uint32_t overflow = 0;
-            for (int k = 0; k < 3; k++) {
-              const uint32_t ci = cf[k] >= 4294967296.0f ? 0xFFFFFFFFu : (cf[k] == cf[k] ? (uint32_t)cf[k] : 0u);
-              if (ci) {
-                const uint32_t prev = atomicAdd(&lt[k], ci);
-                if (ci > 0xFFFFFFFFu - prev) overflow |= 1u << k;
-              }
-            }
-            if (overflow) atomicOr(&lt[3], overflow);
-            break;
-          }
-          const uint32_t k = (uint32_t)atomicAdd(shadow_size, 1ull);
-          shadow_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, dist);
-          shadow_out[3 * (size_t)k + 1] = make_float4(to_view.x, to_view.y, to_view.z, __uint_as_float(0x80000000u | (uint32_t)((size_t)seed_index * W * H + (size_t)iy * W + ix)));
-          shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
-        } while (0);
-      }
-      // sample_direction with the adjoint BSDF, path.hlsli:898-952
-      const float s0 = rng.next_float(), s1 = rng.next_float(), s2 = rng.next_float();
-      MaterialSampleRecord ms;
-      const f3 sampled_f = m.sample(ms, F3(s0, s1, s2), local_dir_in, beta, true);
-      if (p.path_contrib) path_contrib = path_contrib * sampled_f;  // path.hlsli:901
-      if (ms.pdf_fwd < 1e-6f) break;
-      if (ms.eta != 0) eta_scale /= pow2f(ms.eta);
-      if (TEXTURED && flag(p, STHIP_eRayCones)) {
-        float spec_spread = rd_spread + 2 * sd.mean_curvature * rd_radius;
-        if (ms.eta != 0) spec_spread = spec_spread / ms.eta;
-        rd_spread = fmaxf(0.0f, lerp1(spec_spread, 0.2f, ms.roughness));
-      }
-      cone_out = make_float2(rd_radius, rd_spread);
-      {
-        const float G_rev = prev_cos_out / len_sqr(origin - sd.position);
-        path_pdf_rev *= ms.pdf_rev * G_rev;
-        dVC = connection_dVC(dVC, ms.pdf_rev * G_rev, bsdf_pdf * G, m.is_specular());
-        prev_specular = m.is_specular();
-      }
-      bsdf_pdf = ms.pdf_fwd;
-      const float ndotout = ms.dir_out.z;
-      const f3 dir_out = normalize3(frame.to_world(ms.dir_out));
-      const float ngdotout = dot3(gn, dir_out);
-      new_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
-      beta = beta * shading_normal_correction(local_dir_in.z, ndotout, ngdotin, ngdotout, ngdotns, fix, true);
-      prev_cos_out = ngdotout;
-      if (all_le0(beta)) break;
-      new_direction = dir_out;
-      alive = true;
-    } while (0);
-    if (alive) {
-      p.ray_o[slot] = make_float4(new_origin.x, new_origin.y, new_origin.z, bsdf_pdf);
-      p.ray_d[slot] = make_float4(new_direction.x, new_direction.y, new_direction.z, eta_scale);
-      p.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(rng.counter));
-      p.bdpt[slot] = make_float4(path_pdf, path_pdf_rev, dVC, prev_cos_out);
-      if (p.path_contrib) p.path_contrib[slot] = make_float4(path_contrib.x, path_contrib.y, path_contrib.z, 0.0f);
-      if (TEXTURED) p.cone[slot] = cone_out;
-      p.meta[slot] = path_length | (diffuse_vertices << 8) | (prev_specular ? 1u << 16 : 0u);
-      const uint32_t k = (uint32_t)atomicAdd(queue_size, 1ull);
-      queue_out[k] = slot;
-    }
-  }
 }
 
 // One step of trace_visibility_ray with media (intersection.hlsli:192-239), after the closest hit (dt, ip) of the walk's
@@ -1299,6 +1070,395 @@ DEV uint32_t visibility_walk_media(const FrameParams& p, Rng& rng, f3 o, f3 d, f
     if (visibility_step_media(p, rng, o, d, t_max, cur_medium, contribution, T_dir, T_nee, h.t, h.ip)) break;
   }
   return segments;
+}
+
+// path_weight, path.hlsli:16-28: one over the number of ways upstream counts for a path of this many vertices
+DEV float path_weight(const FrameParams& p, uint32_t view_length, uint32_t light_length) {
+  const uint32_t nv = view_length + light_length;
+  if (nv <= 2) return 1;
+  uint32_t ways = 1;
+  if (flag(p, STHIP_eNEE)) ways++;
+  if (flag(p, STHIP_eConnectToViews) && nv <= p.pc.gMaxPathVertices + 1) ways++;
+  if (flag(p, STHIP_eConnectToLightPaths)) ways += min(p.pc.gMaxPathVertices, nv - 2);
+  return 1.f / (float)ways;
+}
+
+// MEDIA: the scene has volume instances: a light path's trace() is the same walk from volume boundary to volume boundary as a view
+// path's (k_shade), it scatters inside media (phase function, connect_view from there), and every connect_view walks its
+// visibility ray through the media itself, in the light path's own stream (path.hlsli:577-581: trace_visibility_ray is inline
+// there whatever eDeferShadowRays says) — visibility_walk_media, then the splat at once.
+template <bool TEXTURED, bool EXT, bool MEDIA = false>
+__global__ void __launch_bounds__(STHIP_BLOCK, MEDIA ? 2 : 3) k_shade_light(FrameParams p, uint32_t depth) {
+  const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
+  const uint32_t seg_base = seg * p.seg_stride;
+  uint32_t n, slot0 = 0;
+  if (depth == 0) {
+    const uint32_t per = (((p.path_count + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) + 63u) & ~63u;
+    slot0 = seg * per;
+    n = slot0 < p.path_count ? (slot0 + per < p.path_count ? per : p.path_count - slot0) : 0u;
+  } else {
+    n = (uint32_t)queue_ctl(p.qctl, 0, depth, seg)[QCTL_SIZE];
+  }
+  const uint32_t first = (blockIdx.x / QUEUE_SEGMENTS) * blockDim.x + threadIdx.x;
+  const uint32_t step = ((gridDim.x - seg + QUEUE_SEGMENTS - 1u) / QUEUE_SEGMENTS) * blockDim.x;
+  const uint32_t* queue_in = p.queue[depth & 1u] + seg_base;
+  uint32_t* queue_out = p.queue[(depth + 1) & 1u] + seg_base;
+  float4* shadow_out = p.shadow_rays + 3 * (size_t)seg * p.shadow_stride;
+  unsigned long long* queue_size = &queue_ctl(p.qctl, 0, depth + 1, seg)[QCTL_SIZE];
+  unsigned long long* shadow_size = &queue_ctl(p.qctl, 1, depth, seg)[QCTL_SIZE];
+  const uint32_t W = p.pc.gOutputExtent[0], H = p.pc.gOutputExtent[1];
+  const bool connect_views = flag(p, STHIP_eConnectToViews), connect_paths = flag(p, STHIP_eConnectToLightPaths);
+  for (uint32_t i = first; i < n; i += step) {
+    const uint32_t slot = depth == 0 ? slot0 + i : queue_in[i];
+    const uint32_t meta = p.meta[slot];
+    if (meta >= 0xFFFFFFFEu) continue;
+    const uint32_t seed_index = slot / p.light_threads;
+    uint32_t tx, ty, path_index;
+    light_thread(p, slot - seed_index * p.light_threads, tx, ty, path_index);
+    const float4 ro = p.ray_o[slot], rd = p.ray_d[slot], hh = p.hit[slot], bb = p.beta[slot], bd = p.bdpt[slot];
+    const uint32_t hit_leaf = p.hit_leaf[slot];
+    const f3 seg_origin = xyz(ro), direction = xyz(rd);  // the ray k_trace traced
+    f3 origin = seg_origin;                              // the previous vertex (differs from seg_origin only with MEDIA)
+    float bsdf_pdf = ro.w, eta_scale = rd.w;
+    f3 beta = xyz(bb);
+    float path_pdf = bd.x, path_pdf_rev = bd.y, dVC = bd.z, prev_cos_out = bd.w;
+    bool prev_specular = (meta >> 16) & 1u;
+    f3 path_contrib = p.path_contrib ? xyz(p.path_contrib[slot]) : F3s(0.0f);
+    Rng rng;
+    rng.x = tx;
+    rng.y = ty;
+    rng.seed = p.seed + seed_index;
+    rng.counter = __float_as_uint(bb.w);
+    uint32_t path_length = meta & 0xFFu, diffuse_vertices = (meta >> 8) & 0xFFu;
+    const uint32_t ip = __float_as_uint(hh.w);
+    uint32_t medium = 0xFFFFu;
+    float T_dir_pdf = 1;
+    bool medium_vertex = false;
+    f3 scatter_p = F3s(0.0f);
+    uint32_t walk_segments = 0;
+    uint32_t* column = MEDIA ? p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth : nullptr;
+    if (MEDIA) {
+      // one step of the medium-aware trace_ray, intersection.hlsli:246-283 (as k_shade's)
+      const float4 m0 = p.media_state[2 * (size_t)slot], m1 = p.media_state[2 * (size_t)slot + 1];
+      origin = xyz(m0);
+      T_dir_pdf = m0.w;
+      float T_nee_pdf = m1.x;
+      medium = __float_as_uint(m1.y);
+      const uint32_t segments = __float_as_uint(m1.z);
+      if (medium != 0xFFFFu) {
+        Medium mm;
+        mm.load(p.scene, load_inst(p.scene, medium).material_address());
+        const Xf inv = load_xf(p.scene.inv_xf, medium);
+        f3 dir_pdf = F3s(1.0f), nee_pdf = F3s(1.0f);
+        const bool scattered = mm.delta_track(p.scene, rng, xf_point(inv, seg_origin), xf_vector(inv, direction), hh.x, beta, dir_pdf, nee_pdf, true, p.pc.gMaxNullCollisions, scatter_p);
+        T_dir_pdf *= average3(dir_pdf);
+        T_nee_pdf *= average3(nee_pdf);
+        medium_vertex = scattered && isfinite(scatter_p.x) && isfinite(scatter_p.y) && isfinite(scatter_p.z);
+      }
+      if (!medium_vertex && ip != 0xFFFFFFFFu) {
+        const uint32_t hit_inst = ip & 0xFFFFu;
+        const Inst hin = load_inst(p.scene, hit_inst);
+        if (hin.type() == STHIP_INSTANCE_TYPE_VOLUME) {  // a volume boundary: enter or leave, walk on from the other side; no vertex
+          if (segments >= 62u) continue;
+          f3 bpos;
+          uint32_t bn;
+          volume_boundary(p.scene, hit_inst, hin, seg_origin, direction, hh.x, bpos, bn);
+          const f3 bgn = unpack_normal_octahedron(bn);
+          f3 next_origin;
+          if (dot3(direction, bgn) < 0) {
+            medium = hit_inst;
+            next_origin = ray_offset(bpos, -bgn);
+          } else {
+            medium = 0xFFFFu;
+            next_origin = ray_offset(bpos, bgn);
+          }
+          p.ray_o[slot] = make_float4(next_origin.x, next_origin.y, next_origin.z, bsdf_pdf);
+          p.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(rng.counter));
+          p.media_state[2 * (size_t)slot] = make_float4(origin.x, origin.y, origin.z, T_dir_pdf);
+          p.media_state[2 * (size_t)slot + 1] = make_float4(T_nee_pdf, __uint_as_float(medium), __uint_as_float(segments + 1u), 0.0f);
+          const uint32_t k = (uint32_t)atomicAdd(queue_size, 1ull);
+          queue_out[k] = slot;
+          atomicAdd(&p.counters[CNT_CROSSINGS], 1ull);
+          continue;
+        }
+      }
+    }
+    bool alive = false;
+    f3 new_origin = origin, new_direction = direction;
+    float2 cone_out = make_float2(0.0f, 0.0f);
+    // the splat of a connect_view whose visibility is known at once (accumulate_light_contribution, path.hlsli:47-60)
+    auto splat = [&](uint32_t ix, uint32_t iy, f3 c) {
+      uint32_t* lt = p.light_trace + 4 * ((size_t)seed_index * W * H + (size_t)iy * W + ix);
+      const float q = (float)p.light_trace_quantization;
+      const float cf[3] = {fmaxf(0.0f, c.x) * q, fmaxf(0.0f, c.y) * q, fmaxf(0.0f, c.z) * q};
+      uint32_t overflow = 0;
+      for (int k = 0; k < 3; k++) {
+        const uint32_t ci = cf[k] >= 4294967296.0f ? 0xFFFFFFFFu : (cf[k] == cf[k] ? (uint32_t)cf[k] : 0u);
+        if (ci) {
+          const uint32_t prev = atomicAdd(&lt[k], ci);
+          if (ci > 0xFFFFFFFFu - prev) overflow |= 1u << k;
+        }
+      }
+      if (overflow) atomicOr(&lt[3], overflow);
+    };
+    // connect_view up to the material's part (path.hlsli:533-560): the pixel, the direction, the sensor's terms. False: no connection.
+    struct ViewLink {
+      int ix, iy;
+      f3 to_view, contribution;
+      float dist, G_rev;
+    };
+    auto view_link = [&](f3 position_v, ViewLink& L) -> bool {
+      uint32_t view_index = 0;
+      if (p.pc.gViewCount > 1) view_index = (uint32_t)fminf(rng.next_float() * (float)p.pc.gViewCount, (float)(p.pc.gViewCount - 1));
+      const sthip_ViewData& view = p.views[view_index];
+      float4 sp = project_point(view.projection, xf_point(load_xf(p.inv_view_xf, view_index), position_v));
+      sp.y = -sp.y;
+      sp.x = sp.x / sp.w;
+      sp.y = sp.y / sp.w;
+      sp.z = sp.z / sp.w;
+      if (fabsf(sp.x) >= 1 || fabsf(sp.y) >= 1 || fabsf(sp.z) >= 1 || sp.z <= 0) return false;
+      const float u = sp.x * .5f + .5f, v = sp.y * .5f + .5f;
+      L.ix = view.image_min[0] + (int)((float)(view.image_max[0] - view.image_min[0]) * u);
+      L.iy = view.image_min[1] + (int)((float)(view.image_max[1] - view.image_min[1]) * v);
+      const Xf t = load_xf(p.view_xf, view_index);
+      const f3 position = F3(t.r0.w, t.r1.w, t.r2.w);
+      const f3 view_normal = normalize3(xf_vector(t, F3(0, 0, 1)));
+      L.to_view = position - position_v;
+      L.dist = length3(L.to_view);
+      L.to_view = L.to_view / L.dist;
+      const float sensor_cos_theta = fabsf(dot3(L.to_view, view_normal));
+      const float sensor_importance = 1 / (view.projection.sensor_area * 1.0f * (pow2f(sensor_cos_theta) * pow2f(sensor_cos_theta)));
+      L.contribution = beta * sensor_importance / (1.0f / (sensor_cos_theta / pow2f(L.dist)));
+      L.G_rev = fabsf(prev_cos_out) / len_sqr(origin - position_v);
+      return true;
+    };
+    // ... and its weight (path.hlsli:583-613)
+    auto view_weight = [&](float pdf_rev, float G_rev, float G_here) {
+      float weight;
+      if (flag(p, STHIP_eMIS)) {
+        if (connect_paths)  // dL_1, path.hlsli:591-596
+          weight = 1 / (1 + connection_dVC(dVC, pdf_rev * G_rev, bsdf_pdf * G_here, prev_specular) * pow2f(1.0f));
+        else
+          weight = prev_specular ? 1.0f : mis2(true, path_pdf, 1.0f * path_pdf_rev * (pdf_rev * G_rev));
+      } else {
+        weight = path_weight(p, 1, path_length);
+      }
+      if (p.debug_mode == STHIP_DEBUG_LIGHT_TRACE_CONTRIBUTION) weight = 1;  // path.hlsli:608-609
+      if (p.debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && p.pc.gDebugViewPathLength == 1)  // :611-613
+        weight = p.pc.gDebugLightPathLength == path_length ? 1.0f : 0.0f;
+      return weight;
+    };
+    do {
+      // trace(), path.hlsli:1009-1012
+      if ((MEDIA && T_dir_pdf <= 0) || all_le0(beta)) break;
+      if (MEDIA) {
+        beta = beta / T_dir_pdf;
+        if (!flag(p, STHIP_eDeferShadowRays)) bsdf_pdf *= T_dir_pdf;
+        path_pdf *= T_dir_pdf;
+      }
+      path_length++;
+      if (MEDIA && medium_vertex) {
+        // ---- a vertex inside a medium: trace()'s tail (path.hlsli:1033-1043) and next_vertex(Medium), light branch (:955-998) ----
+        Medium mm;
+        mm.load(p.scene, load_inst(p.scene, medium).material_address());
+        const float dist2 = len_sqr(scatter_p - origin);
+        const float G = 1 / dist2;  // no cosine at a medium vertex (ngdotin = 1)
+        path_pdf *= bsdf_pdf * G;
+        if (p.path_contrib) path_contrib = path_contrib * G;
+        const f3 local_dir_in = -direction;
+        if (!mm.can_eval() || path_length >= p.pc.gMaxPathVertices) break;
+        if (!mm.is_specular()) {
+          diffuse_vertices++;
+          if (diffuse_vertices > p.pc.gMaxDiffuseVertices) break;
+          if (connect_views) do {  // connect_view at a medium vertex: no geometry (path.hlsli:562-565), the phase function as f and both pdfs
+            ViewLink L;
+            if (!view_link(scatter_p, L)) break;
+            const float v = mm.phase(local_dir_in, L.to_view);
+            if (v < 1e-6f) break;
+            f3 contribution = L.contribution * v;
+            if (all_le0(contribution)) break;
+            float nee_pdf = 1, dir_pdf = 1;
+            walk_segments += visibility_walk_media(p, rng, scatter_p, L.to_view, L.dist, medium, contribution, dir_pdf, nee_pdf, column);
+            if (nee_pdf > 0) contribution = contribution / nee_pdf;
+            const float weight = view_weight(v, L.G_rev, G);
+            const f3 c = contribution * weight;
+            if (L.ix < 0 || L.iy < 0 || (uint32_t)L.ix >= W || (uint32_t)L.iy >= H) break;
+            if (p.shard_count > 1 && (((uint32_t)L.iy / p.tile_h) * p.tiles_x + (uint32_t)L.ix / p.tile_w) % p.shard_count != p.shard_rank) break;
+            splat((uint32_t)L.ix, (uint32_t)L.iy, c);
+          } while (0);
+        }
+        // sample_direction with the phase function (path.hlsli:898-952, medium branch)
+        const float s0 = rng.next_float(), s1 = rng.next_float(), s2 = rng.next_float();
+        (void)s2;
+        float ppdf, proughness;
+        const f3 dir_out = mm.sample(s0, s1, local_dir_in, ppdf, proughness);
+        if (p.path_contrib) path_contrib = path_contrib * ppdf;  // path.hlsli:901 (Medium::sample returns the phase value)
+        if (ppdf < 1e-6f) break;
+        if (TEXTURED) {
+          const float2 cone = p.cone[slot];
+          float rd_radius = cone.x, rd_spread = cone.y;
+          if (flag(p, STHIP_eRayCones)) {
+            rd_radius += rd_spread * sqrtf(dist2);
+            rd_spread = fmaxf(0.0f, lerp1((rd_spread + 2 * 0.0f * rd_radius) / -1.0f, 0.2f, proughness));
+          }
+          cone_out = make_float2(rd_radius, rd_spread);
+        }
+        {
+          const float G_rev = prev_cos_out / len_sqr(origin - scatter_p);
+          path_pdf_rev *= ppdf * G_rev;
+          dVC = connection_dVC(dVC, ppdf * G_rev, bsdf_pdf * G, mm.is_specular());
+          prev_specular = mm.is_specular();
+        }
+        bsdf_pdf = ppdf;
+        prev_cos_out = 1;
+        new_origin = scatter_p;
+        new_direction = dir_out;
+        alive = true;
+        break;
+      }
+      if (ip == 0xFFFFFFFFu) break;  // light paths that leave the scene end (no environment with light tracing)
+      const uint32_t inst_index = ip & 0xFFFFu;
+      const Inst in = load_inst(p.scene, inst_index);
+      ShadingData sd;
+      if (EXT && in.type() == STHIP_INSTANCE_TYPE_SPHERE) {
+        const Xf inv = load_xf(p.scene.inv_xf, inst_index);
+        const float im[12] = {inv.r0.x, inv.r0.y, inv.r0.z, inv.r0.w, inv.r1.x, inv.r1.y, inv.r1.z, inv.r1.w, inv.r2.x, inv.r2.y, inv.r2.z, inv.r2.w};
+        make_sphere_shading_data(p.scene, sd, inst_index, in, obj_point(im, seg_origin) + obj_vector(im, direction) * hh.x);
+      } else {
+        make_hit_shading_data(p.scene, sd, inst_index, hit_leaf, hh.y, hh.z, TEXTURED && flag(p, STHIP_eFlipTriangleUVs));
+      }
+      const f3 gn = sd.geometry_normal();
+      const float dist2 = len_sqr(sd.position - origin);
+      float G = 1 / dist2;
+      const float ngdotin = -dot3(direction, gn);
+      G *= fabsf(ngdotin);
+      path_pdf *= bsdf_pdf * G;  // path.hlsli:1042
+      if (p.path_contrib) path_contrib = path_contrib * G;  // path.hlsli:1043
+      DisneyMaterial m;
+      float rd_radius = 0, rd_spread = 0;  // RayDifferential of the light path: starts at (0, 0), bounces spread it (path.hlsli:911-916)
+      if (TEXTURED) {
+        const float2 cone = p.cone[slot];
+        rd_radius = cone.x;
+        rd_spread = cone.y;
+        if (flag(p, STHIP_eRayCones)) {  // path.hlsli:1026-1029
+          rd_radius += rd_spread * sqrtf(dist2);
+          sd.uv_screen_size *= rd_radius;
+        }
+        m.load_textured(p.scene, in.material_address(), sd.u, sd.v, sd.uv_screen_size, sd.packed_shading_normal, sd.packed_tangent, p.sampling_flags);
+      } else {
+        m.load(p.scene, in.material_address());
+      }
+      const Frame3 frame = make_frame(sd);
+      const f3 local_dir_in = normalize3(frame.to_local(-direction));
+      // next_vertex(BSDF), path.hlsli:955-998, light branch
+      if (!m.can_eval() || path_length >= p.pc.gMaxPathVertices) break;
+      const float ngdotns = dot3(gn, sd.shading_normal());
+      const bool fix = flag(p, STHIP_eShadingNormalShadowFix);
+      if (!m.is_specular()) {
+        diffuse_vertices++;
+        if (diffuse_vertices > p.pc.gMaxDiffuseVertices) break;
+        if (connect_paths && path_length + 2 <= p.pc.gMaxPathVertices && diffuse_vertices < p.pc.gMaxDiffuseVertices) {
+          // vertex() / store_light_vertex(), path.hlsli:491-531: slot light_vertex_index(path_index, diffuse_vertices) (:64)
+          const size_t per_seed = (size_t)p.pc.gLightPathCount * p.pc.gMaxDiffuseVertices;
+          const size_t idx = (size_t)W * H * (diffuse_vertices - 1) + path_index;
+          if (p.lvc_staging || idx < per_seed) {
+            // eLVC: staged per (path, vertex) and compacted in that order afterwards (see FrameParams::lvc_staging)
+            float4* lv = p.lvc_staging ? p.lvc_staging + 4 * (((size_t)seed_index * p.pc.gLightPathCount + path_index) * (p.pc.gMaxDiffuseVertices - 1) + (diffuse_vertices - 1))
+                                       : p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
+            const uint32_t vflags = 2u | (prev_specular ? 8u : 0u);  // IS_BACKGROUND as upstream sets it (SURVEY B6), IS_PREV_DELTA
+            const f3 stored = flag(p, STHIP_eLVCReservoirs) ? path_contrib : beta;  // path.hlsli:513
+            const uint32_t pb0 = det_f32tof16(stored.x) | (det_f32tof16(stored.y) << 16);
+            const uint32_t pb1 = det_f32tof16(stored.z) | ((path_length & 0x7Fu) << 16) | ((diffuse_vertices & 0x1Fu) << 23) | (vflags << 28);
+            lv[0] = make_float4(sd.position.x, sd.position.y, sd.position.z, __uint_as_float(sd.packed_geometry_normal));
+            lv[1] = make_float4(__uint_as_float(in.material_address()), __uint_as_float(pack_normal_octahedron(local_dir_in)), __uint_as_float(sd.packed_shading_normal),
+                                __uint_as_float(sd.packed_tangent));
+            lv[2] = make_float4(sd.u, sd.v, __uint_as_float(pb0), __uint_as_float(pb1));
+            lv[3] = make_float4(dVC, prev_cos_out / len_sqr(origin - sd.position), bsdf_pdf * G, path_pdf);
+          }
+        }
+        if (connect_views) do {  // connect_view, path.hlsli:533-613
+          ViewLink L;
+          if (!view_link(sd.position, L)) break;
+          const f3 to_view = L.to_view;
+          const float dist = L.dist;
+          f3 contribution = L.contribution;
+          const float ngdotout = dot3(to_view, gn);
+          const f3 ray_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
+          const f3 local_to_view = normalize3(frame.to_local(to_view));
+          contribution = contribution * shading_normal_correction(local_dir_in.z, local_to_view.z, ngdotin, ngdotout, ngdotns, fix, true);
+          MaterialEvalRecord ev;
+          m.eval(ev, local_dir_in, local_to_view, true);
+          if (ev.pdf_fwd < 1e-6f) break;
+          contribution = contribution * ev.f;
+          if (all_le0(contribution)) break;
+          if (MEDIA) {  // the visibility ray walks through the media now, in this path's stream (path.hlsli:577-581)
+            float nee_pdf = 1, dir_pdf = 1;
+            walk_segments += visibility_walk_media(p, rng, ray_origin, to_view, dist, medium, contribution, dir_pdf, nee_pdf, column);
+            if (nee_pdf > 0) contribution = contribution / nee_pdf;
+          }
+          const float weight = view_weight(ev.pdf_rev, L.G_rev, G);
+          const f3 c = contribution * weight;
+          const int ix = L.ix, iy = L.iy;
+          // the splat lands on pixel (ix, iy) of this seed's image; a sharded renderer keeps only its own pixels
+          if (ix < 0 || iy < 0 || (uint32_t)ix >= W || (uint32_t)iy >= H) break;
+          if (p.shard_count > 1 && (((uint32_t)iy / p.tile_h) * p.tiles_x + (uint32_t)ix / p.tile_w) % p.shard_count != p.shard_rank) break;
+          if (MEDIA || !(dist > 1e-6f)) {  // visibility known: with media the walk above; a zero-length ray never runs trace_visibility_ray's loop
+            splat((uint32_t)ix, (uint32_t)iy, c);
+            break;
+          }
+          const uint32_t k = (uint32_t)atomicAdd(shadow_size, 1ull);
+          shadow_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, dist);
+          shadow_out[3 * (size_t)k + 1] = make_float4(to_view.x, to_view.y, to_view.z, __uint_as_float(0x80000000u | (uint32_t)((size_t)seed_index * W * H + (size_t)iy * W + ix)));
+          shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+        } while (0);
+      }
+      // sample_direction with the adjoint BSDF, path.hlsli:898-952
+      const float s0 = rng.next_float(), s1 = rng.next_float(), s2 = rng.next_float();
+      MaterialSampleRecord ms;
+      const f3 sampled_f = m.sample(ms, F3(s0, s1, s2), local_dir_in, beta, true);
+      if (p.path_contrib) path_contrib = path_contrib * sampled_f;  // path.hlsli:901
+      if (ms.pdf_fwd < 1e-6f) break;
+      if (ms.eta != 0) eta_scale /= pow2f(ms.eta);
+      if (TEXTURED && flag(p, STHIP_eRayCones)) {
+        float spec_spread = rd_spread + 2 * sd.mean_curvature * rd_radius;
+        if (ms.eta != 0) spec_spread = spec_spread / ms.eta;
+        rd_spread = fmaxf(0.0f, lerp1(spec_spread, 0.2f, ms.roughness));
+      }
+      cone_out = make_float2(rd_radius, rd_spread);
+      {
+        const float G_rev = prev_cos_out / len_sqr(origin - sd.position);
+        path_pdf_rev *= ms.pdf_rev * G_rev;
+        dVC = connection_dVC(dVC, ms.pdf_rev * G_rev, bsdf_pdf * G, m.is_specular());
+        prev_specular = m.is_specular();
+      }
+      bsdf_pdf = ms.pdf_fwd;
+      const float ndotout = ms.dir_out.z;
+      const f3 dir_out = normalize3(frame.to_world(ms.dir_out));
+      const float ngdotout = dot3(gn, dir_out);
+      new_origin = ray_offset(sd.position, ngdotout > 0 ? gn : -gn);
+      beta = beta * shading_normal_correction(local_dir_in.z, ndotout, ngdotin, ngdotout, ngdotns, fix, true);
+      prev_cos_out = ngdotout;
+      if (all_le0(beta)) break;
+      new_direction = dir_out;
+      alive = true;
+    } while (0);
+    if (MEDIA && walk_segments) atomicAdd(&p.counters[CNT_RAYS_SHADOW], (unsigned long long)walk_segments);  // (inline walks: not in any queue)
+    if (alive) {
+      p.ray_o[slot] = make_float4(new_origin.x, new_origin.y, new_origin.z, bsdf_pdf);
+      p.ray_d[slot] = make_float4(new_direction.x, new_direction.y, new_direction.z, eta_scale);
+      p.beta[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(rng.counter));
+      p.bdpt[slot] = make_float4(path_pdf, path_pdf_rev, dVC, prev_cos_out);
+      if (p.path_contrib) p.path_contrib[slot] = make_float4(path_contrib.x, path_contrib.y, path_contrib.z, 0.0f);
+      if (TEXTURED) p.cone[slot] = cone_out;
+      if (MEDIA) {  // a new trace() starts at this vertex
+        p.media_state[2 * (size_t)slot] = make_float4(new_origin.x, new_origin.y, new_origin.z, 1.0f);
+        p.media_state[2 * (size_t)slot + 1] = make_float4(1.0f, __uint_as_float(medium), __uint_as_float(0u), 0.0f);
+      }
+      p.meta[slot] = path_length | (diffuse_vertices << 8) | (prev_specular ? 1u << 16 : 0u);
+      const uint32_t k = (uint32_t)atomicAdd(queue_size, 1ull);
+      queue_out[k] = slot;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1506,16 +1666,21 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
       // trace(), path.hlsli:1009-1010: the ray was traced (and counted) even if beta died meanwhile
       if ((MEDIA && T_dir_pdf <= 0) || all_le0(beta)) break;
       if (MEDIA) beta = beta / T_dir_pdf;  // path.hlsli:1009 (bsdf_pdf keeps its value with eDeferShadowRays, :1010)
-      if (MEDIA == 2) bsdf_pdf *= T_dir_pdf;
+      if (MEDIA && !flag(p, STHIP_eDeferShadowRays)) bsdf_pdf *= T_dir_pdf;  // (the RESOLVED flag: without eNEE and eLVC the host clears it, BDPT.cpp:522-523 — so also where no NEE ray exists to walk inline)
+      if (LT && MEDIA) path_pdf *= T_dir_pdf;  // path.hlsli:1012
       path_length++;
       if (MEDIA && medium_vertex) {
         // ---- a vertex inside a medium: trace()'s tail (path.hlsli:1033-1043) and next_vertex(Medium) (:955-998,1062-1066) ----
         const uint32_t maddr = load_inst(p.scene, medium).material_address();
         Medium mm;
         mm.load(p.scene, maddr);
-        const float dist2 = len_sqr(scatter_p - origin);  // G = 1 / dist2 (no cosine, path.hlsli:1035-1036) only feeds the BDPT quantities
+        const float dist2 = len_sqr(scatter_p - origin);
+        float G = 1 / dist2;  // no cosine at a medium vertex (path.hlsli:1035-1036)
+        if (LT) path_pdf *= bsdf_pdf * G;  // path.hlsli:1042
         if (primary) {  // bdpt.hlsl:213-220,245-296: no albedo / emission for a medium vertex; the visibility normal and
           bsdf_pdf = 1;   // the depth derivatives read the stale surface of the last query upstream and are pinned to 0
+          G = 1;
+          if (LT) path_pdf = path_pdf_rev = dVC = 1;
           if (DEBUG) {    // (bdpt.hlsl:222-223: the stale normals again, pinned likewise; :294-295)
             if (p.debug_mode == STHIP_DEBUG_GEOMETRY_NORMAL || p.debug_mode == STHIP_DEBUG_SHADING_NORMAL) debug_set(unpack_normal_octahedron(0u) * .5f + F3s(.5f));
             else if (p.debug_mode == STHIP_DEBUG_PREV_UV) debug_prev_uv(medium, scatter_p);
@@ -1557,6 +1722,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             if (!(rr >= 1)) {
               if (rng.next_float() > rr) break;
               beta = beta / rr;
+              if (LT) path_pdf *= rr;  // path.hlsli:842
             }
           }
           if (use_nee) do {
@@ -1707,8 +1873,14 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
               const float f = mm.phase(local_dir_in, c_dir);
               f3 contrib = cLe * f * c_G * W;
               if (all_le0(contrib) || c_pdfA < 1e-6f) break;
-              const float weight = sample_bsdfs ? 1 - 0.5f : 1.0f;
-              if ((MEDIA == 2)) {  // :474-485
+              float weight = sample_bsdfs ? 1 - 0.5f : 1.0f;
+              if (LT) {  // path.hlsli:458-465; setup()'s medium branch leaves emission_pdfA = 0 (:211), the phase function is pdf_rev
+                const float dL = connection_dVC(W, 0.0f, 1 / W, false);
+                const float G_rev = prev_cos_out / len_sqr(origin - scatter_p);
+                const float dE = connection_dVC(dVC, f * G_rev, bsdf_pdf * G, prev_specular);
+                weight = 1 / (1 + dE * pow2f(0.0f) + dL * pow2f(f * c_G));
+              }
+              if (MEDIA == 2) {  // :474-485
                 float dir_pdf = 1, nee_pdf = 1;
                 walk_segments += visibility_walk_media(p, rng, scatter_p, c_dir, c_dist, medium, contrib, dir_pdf, nee_pdf, column);
                 if (nee_pdf <= 0) break;
@@ -1741,7 +1913,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             const float f = mm.phase(local_dir_in, c_dir);
             const float pdfA_fwd = f * c_G;
             if (pdfA_fwd < 1e-6f) break;
-            if ((MEDIA == 2)) {  // path.hlsli:329-365 at a medium vertex (no shading-normal term, :334)
+            if (MEDIA == 2) {  // path.hlsli:329-365 at a medium vertex (no shading-normal term, :334)
               f3 wLe = cLe;
               float w_fwd = pdfA_fwd, w_pdfA = c_pdfA;
               walk_segments += visibility_walk_media(p, rng, scatter_p, c_dir, c_dist, medium, wLe, w_fwd, w_pdfA, column);
@@ -1749,7 +1921,17 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
               const f3 contrib = wLe * f * c_G / w_pdfA;
               if (all_le0(contrib)) break;
               float weight = 1;
-              if (sample_bsdfs) weight = mis2(use_mis, w_pdfA, w_fwd);
+              if (LT) {  // BDPT MIS, path.hlsli:341-351 (emission_pdfA = 0 at a medium vertex)
+                if (use_mis) {
+                  const float dL = connection_dVC(1 / w_pdfA, 0.0f, w_pdfA, false);
+                  const float G_rev = prev_cos_out / len_sqr(origin - scatter_p);
+                  const float dE = connection_dVC(dVC, f * G_rev, bsdf_pdf * G, prev_specular);
+                  weight = 1 / (1 + dE * pow2f(0.0f) + dL * pow2f(w_fwd));
+                } else {
+                  weight = path_weight(p, path_length, 1);
+                }
+              } else if (sample_bsdfs)
+                weight = mis2(use_mis, w_pdfA, w_fwd);
               debug_path_length(beta * contrib, path_length, 1);
               radiance = radiance + (beta * contrib) * weight;
               radiance_dirty = true;
@@ -1758,7 +1940,17 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             const f3 contrib = cLe * f * c_G / c_pdfA;
             if (all_le0(contrib)) break;
             float weight = 1;
-            if (sample_bsdfs) weight = mis2(use_mis, c_pdfA, pdfA_fwd);
+            if (LT) {
+              if (use_mis) {
+                const float dL = connection_dVC(1 / c_pdfA, 0.0f, c_pdfA, false);
+                const float G_rev = prev_cos_out / len_sqr(origin - scatter_p);
+                const float dE = connection_dVC(dVC, f * G_rev, bsdf_pdf * G, prev_specular);
+                weight = 1 / (1 + dE * pow2f(0.0f) + dL * pow2f(pdfA_fwd));
+              } else {
+                weight = path_weight(p, path_length, 1);
+              }
+            } else if (sample_bsdfs)
+              weight = mis2(use_mis, c_pdfA, pdfA_fwd);
             const f3 c = beta * contrib * weight;
             if (all_le0(c)) break;
             const uint32_t entry = slot * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
@@ -1789,6 +1981,13 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             rd_radius += rd_spread * sqrtf(dist2);  // path.hlsli:1026-1029
             rd_spread = fmaxf(0.0f, lerp1((rd_spread + 2 * 0.0f * rd_radius) / -1.0f, 0.2f, proughness));
           }
+        }
+        if (LT) {  // path.hlsli:918-924,927-929
+          const float G_rev = prev_cos_out / len_sqr(origin - scatter_p);
+          if (path_length > 2) path_pdf_rev *= ppdf * G_rev;
+          dVC = connection_dVC(dVC, ppdf * G_rev, bsdf_pdf * G, mm.is_specular());
+          prev_specular = mm.is_specular();
+          prev_cos_out = 1;
         }
         bsdf_pdf = ppdf;
         new_origin = scatter_p;
@@ -1830,7 +2029,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
           if (!all_le0(eLe)) {
             float light_pdf = env.eval_pdf(p.scene, direction, flag(p, STHIP_eSampleEnvironmentMapDirectly));
             if (has_emissives) light_pdf *= p.pc.gEnvironmentSampleProbability;
-            if (MEDIA == 2) light_pdf *= T_nee_pdf;  // path.hlsli:866
+            if (MEDIA && !flag(p, STHIP_eDeferShadowRays)) light_pdf *= T_nee_pdf;  // path.hlsli:866
             float weight = 1;
             if (path_length > 2 && use_nee) weight = flag(p, STHIP_eNEEReservoirs) ? 0.5f : mis2(use_mis, bsdf_pdf, light_pdf);
             if (debug_is(STHIP_DEBUG_VIEW_TRACE_CONTRIBUTION)) debug_add(beta * eLe);  // path.hlsli:890-891
@@ -1919,7 +2118,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
           if (has_env) light_pdfA *= 1 - p.pc.gEnvironmentSampleProbability;
           if (!shape_pdf_area_measure) light_pdfA = light_pdfA * G;  // pdfWtoA, path.hlsli:864
         }
-        if (MEDIA == 2) light_pdfA *= T_nee_pdf;  // path.hlsli:866
+        if (MEDIA && !flag(p, STHIP_eDeferShadowRays)) light_pdfA *= T_nee_pdf;  // path.hlsli:866
         float weight = 1;
         if (path_length > 2) {
           if (LT) {  // path.hlsli:870-880
@@ -2220,7 +2419,14 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
               const float wG = cG * shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, dot3(gn, sd.shading_normal()), EXT && flag(p, STHIP_eShadingNormalShadowFix));
               f3 contrib = lLe * ev.f * wG * ris_W;
               if (all_le0(contrib) || pdfA < 1e-6f) break;
-              const float weight = sample_bsdfs ? 1 - 0.5f : 1.0f;
+              float weight = sample_bsdfs ? 1 - 0.5f : 1.0f;
+              if (LT) {  // path.hlsli:458-465
+                const float emission_pdfA = cosine_hemisphere_pdfW(ngdotout) * (ngdotout / pow2f(ray_distance));
+                const float dL = connection_dVC(ris_W, emission_pdfA, 1 / ris_W, false);
+                const float G_rev = prev_cos_out / len_sqr(origin - sd.position);
+                const float dE = connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular);
+                weight = 1 / (1 + dE * pow2f(emission_pdfA) + dL * pow2f(ev.pdf_fwd * wG));
+              }
               float dir_pdf = 1, nee_pdf = 1;
               walk_segments += visibility_walk_media(p, rng, ray_origin, to_light, ray_distance, medium, contrib, dir_pdf, nee_pdf, p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth);
               if (nee_pdf <= 0) break;
@@ -2243,7 +2449,18 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
               const f3 contrib = wLe * ev.f * wG / w_pdfA;
               if (all_le0(contrib)) break;
               float weight = 1;
-              if (sample_bsdfs) weight = mis2(use_mis, w_pdfA, w_fwd);
+              if (LT) {  // BDPT MIS, path.hlsli:341-351, with the pdfs as the walk left them
+                if (use_mis) {
+                  const float emission_pdfA = cosine_hemisphere_pdfW(ngdotout) * (ngdotout / pow2f(ray_distance));
+                  const float dL = connection_dVC(1 / w_pdfA, emission_pdfA, w_pdfA, false);
+                  const float G_rev = prev_cos_out / len_sqr(origin - sd.position);
+                  const float dE = connection_dVC(dVC, ev.pdf_rev * G_rev, bsdf_pdf * G, prev_specular);
+                  weight = 1 / (1 + dE * pow2f(emission_pdfA) + dL * pow2f(w_fwd));
+                } else {
+                  weight = path_weight(p, path_length, 1);
+                }
+              } else if (sample_bsdfs)
+                weight = mis2(use_mis, w_pdfA, w_fwd);
               debug_path_length(beta * contrib, path_length, 1);  // accumulate_contribution, path.hlsli:302-303
               radiance = radiance + (beta * contrib) * weight;
               radiance_dirty = true;

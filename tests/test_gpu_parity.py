@@ -1356,6 +1356,12 @@ def test_trace_contract_with_volumes(renderer):
         ({}, ["neereservoirs"], {"maxDiffuseVertices": 3, "reservoirM": 4}),
         ({"density": (9.0, 9.0, 9.0)}, ["neereservoirs", "presamplelights", "~samplebsdfs"], {"maxDiffuseVertices": 4, "reservoirM": 3}),
         ({"anisotropy": 0.4, "density": (9.0, 6.0, 3.0)}, ["neereservoirs", "~defershadowrays"], {"maxDiffuseVertices": 4, "reservoirM": 2, "minPathVertices": 2}),
+        # light tracing through the media (eConnectToViews): light paths walk and scatter like view paths, every connect_view — from
+        # surfaces and from medium vertices — walks its visibility ray itself, in the light path's stream (path.hlsli:533-613)
+        ({}, ["connecttoviews"], {"maxDiffuseVertices": 3}),
+        ({"anisotropy": 0.5, "density": (9.0, 6.0, 3.0)}, ["connecttoviews", "~defershadowrays"], {"maxDiffuseVertices": 4, "maxPathVertices": 6}),
+        ({"density": (12.0, 12.0, 12.0)}, ["connecttoviews", "~mis", "~nee"], {"maxDiffuseVertices": 4}),
+        ({}, ["connecttoviews", "neereservoirs", "presamplelights"], {"maxDiffuseVertices": 3, "reservoirM": 2}),
         # ... with spatial reuse: seeds 1 and 2 look into the grid the seed before them built, from surface and medium vertices alike
         ({"density": (9.0, 9.0, 9.0)}, ["neereservoirs", "neereservoirreuse"], {"maxDiffuseVertices": 3, "reservoirM": 2, "reservoirSpatialM": 3, "hashGridBucketCount": 20000}),
         ({"anisotropy": 0.3}, ["neereservoirs", "neereservoirreuse", "~jitterhashgridlookups", "~defershadowrays", "presamplelights"], {"maxDiffuseVertices": 4, "reservoirM": 3, "reservoirSpatialM": 2, "hashGridBucketCount": 5000}),
@@ -1401,7 +1407,7 @@ def test_media_limits(renderer):
     sc, cam = scenes.cornell_box(fog=_fog())
     renderer.update(sc)
     frame = camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"])
-    for f in ("connecttolightpaths", "connecttoviews"):
+    for f in ("connecttolightpaths",):
         renderer.set_flag(f)
         try:
             with pytest.raises(_lib.StratumHipError, match="media"):

@@ -91,6 +91,9 @@ def run(cases=60, seed=1):
         if rng.integers(4) == 0:  # objects that moved since the previous frame (gInstanceMotionTransforms feeds prev-uv / prev_z)
             m = sc.motion_transforms["m"]
             m += rng.normal(scale=0.02, size=m.shape).astype(np.float32)
+        for kv in filter(None, os.environ.get("STHIP_FUZZ_ARGS", "").split(",")):  # "maxPathVertices=3,...": renderer arguments forced (narrowing a case down)
+            k, _, v = kv.partition("=")
+            args[k] = int(v)
         selected = True
         if ONLY:
             lo, _, hi = ONLY.partition("-")
@@ -122,6 +125,7 @@ def run(cases=60, seed=1):
             # BDPTDebugMode in about a fifth of the cases: gDebugImage must come out of both sides bit for bit, started from noise
             dm = (seed0 >> 4) & 63
             debug_mode = dm if 0 < dm < 14 else 0
+            if os.environ.get("STHIP_FUZZ_DEBUG_MODE") and selected: debug_mode = int(os.environ["STHIP_FUZZ_DEBUG_MODE"])  # (narrowing a case down: which part of the frame differs)
             for k, v in opts.items():
                 r.set_option(k, v)
             shard_n = 1 if reuse else int(rng.choice([1, 1, 2, 3]))  # a hash grid is a whole-frame structure: rejected on a shard
@@ -173,6 +177,7 @@ def run(cases=60, seed=1):
                 continue
             ok = True
             ref0_debug = ref["debug"].copy() if debug_mode else None
+            ref0_rad = ref["radiance"].copy()
             if shard_n > 1:  # a shard renders its own tiles and writes zeros elsewhere; ray counts are the shard's own
                 from stratum_amd import shard as shard_mod
 
@@ -203,6 +208,15 @@ def run(cases=60, seed=1):
                 bad += 1
                 nd = int((got["radiance"].view(np.uint32) != ref["radiance"].view(np.uint32)).any(axis=-1).sum())
                 print("MISMATCH %s %s %s opts %s shard %d/%d %dx%d seeds %d+%d mode %d debug %d %s: %d radiance pixels differ, rays %s vs %s" % (kind, flags, args, opts, shard_r, shard_n, W, H, seed0, seeds, mode, debug_mode, fog_params if kind == "fog" else "", nd, got["ray_count"], ref["ray_count"]))
+                if os.environ.get("STHIP_FUZZ_VERBOSE"):
+                    rb = (got["radiance"].view(np.uint32) != ref0_rad.view(np.uint32)).any(axis=-1)
+                    if shard_n > 1:  # (a shard: its own pixels against the frame's, the others' must be zero)
+                        from stratum_amd import shard as shard_mod
+
+                        mine = shard_mod.owner_map(W, H, shard_n, 16, 8) == shard_r
+                        rb = np.where(mine, rb, got["radiance"].any(axis=-1))
+                    ys, xs = np.nonzero(rb)
+                    print("  radiance: %d pixels; first: %s" % (int(rb.sum()), [(int(x), int(y), got["radiance"][y, x].tolist(), ref0_rad[y, x].tolist()) for y, x in list(zip(ys, xs))[:6]]))
                 if debug_mode and os.environ.get("STHIP_FUZZ_VERBOSE"):
                     dd = (got["debug"].view(np.uint32) != ref0_debug.view(np.uint32)).any(axis=-1)
                     if shard_n > 1:  # the others' pixels must be as they were
