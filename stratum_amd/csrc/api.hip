@@ -16,9 +16,11 @@
 
 #include "../../include/sthip.h"
 #include "bvh_build.h"
-#include "kernels.h"
+#include "kernel_instances.h"  // kernels.h + the instantiations that live in shade_*.hip / trace_kernels.hip
 #include "post.h"
 #include "ceilings.h"
+
+STHIP_DECLARE_KERNEL_INSTANCES
 
 namespace sthip {
 hipError_t lvc_compact(const float4* staging, uint32_t slots_per_seed, uint32_t seeds, uint32_t vertices_per_seed, float4* cache, uint32_t* counts, uint32_t* flags, uint32_t* offsets,

@@ -266,7 +266,7 @@ DEV f3 primary_dir(const sthip_ViewData& view, const Xf& t, float fx, float fy, 
 // generate: PathIntegrator ctor (path.hlsli:285-298) + the prologue of sample_visibility
 // (bdpt.hlsl:151-220): one primary ray per owned pixel
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
   for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.path_count; slot += gridDim.x * blockDim.x) {
     uint32_t px, py;
     const bool inside = slot_to_pixel(p, slot, px, py);
@@ -1004,7 +1004,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate_light(FrameParams p) {
 }
 
 // ray counts of a finished pass: every queued path / shadow record was traced exactly once
-__global__ void k_count_rays(FrameParams p) {
+inline __global__ void k_count_rays(FrameParams p) {
   unsigned long long closest = 0, shadow = 0, answered = 0;
   for (uint32_t d = 0; d < p.rounds; d++)
     for (uint32_t s = 0; s < QUEUE_SEGMENTS; s++) {
@@ -2843,7 +2843,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
 // ---------------------------------------------------------------------------------------------
 #define CULL_BLOCKS_PER_SEGMENT 64u  // a block gathers what it keeps in LDS and appends it with ONE atomic (a wave-level append would
                                      // put ~25 000 atomics on the eight control lines: 11 ns each, longer than the pass itself)
-__global__ void __launch_bounds__(STHIP_BLOCK) k_cull_terminal(FrameParams p, uint32_t depth, uint32_t* kept, uint32_t capacity) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_cull_terminal(FrameParams p, uint32_t depth, uint32_t* kept, uint32_t capacity) {
   extern __shared__ uint32_t cull_lds[];  // [0] count, [1] base, [2 ..] up to `capacity` kept slots
   const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
   const uint32_t seg_base = seg * p.seg_stride;
@@ -2888,7 +2888,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_cull_terminal(FrameParams p, ui
 // record is queued again for round depth + 1, the end of the ray (or a miss) finishes it: contribution / nee_pdf goes to
 // the record's own entry of shadow_result, which k_resolve sums in the order of trace_shadows (bdpt.hlsl:311-325).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(STHIP_BLOCK) k_shadow_media(FrameParams p, uint32_t depth) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_shadow_media(FrameParams p, uint32_t depth) {
   const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
   const uint32_t n = (uint32_t)queue_ctl(p.qctl, 1, depth, seg)[QCTL_SIZE];
   const uint32_t first = (blockIdx.x / QUEUE_SEGMENTS) * blockDim.x + threadIdx.x;
@@ -2933,7 +2933,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_shadow_media(FrameParams p, uin
 // resolve: gRadiance += c (bdpt.hlsl:325), then the running mean that defines N samples per pixel
 // (temporal_accumulation.hlsl:102-131), and on the last seed the scatter to the output image
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t first_seed, uint32_t last_seed, uint32_t primary_rays) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t first_seed, uint32_t last_seed, uint32_t primary_rays) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // every queued path / shadow record was traced exactly once: ray counts are the queue sizes
     // (a last ray answered by k_shade is a trace_ray call too: QCTL_ANSWERED of the bounce it belongs to)
@@ -3026,7 +3026,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t
 }
 
 // the zero fills a pass starts with, as one launch: up to three ranges of 64-bit words
-__global__ void __launch_bounds__(STHIP_BLOCK) k_clear(unsigned long long* a, uint32_t na, unsigned long long* b, uint32_t nb, unsigned long long* c, uint32_t nc) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_clear(unsigned long long* a, uint32_t na, unsigned long long* b, uint32_t nb, unsigned long long* c, uint32_t nc) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nb + nc; i += gridDim.x * blockDim.x) {
     if (i < na)
       a[i] = 0ull;
@@ -3041,7 +3041,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_clear(unsigned long long* a, ui
 // eCoherentRR: the probes of a round (FrameParams::rr) -> one verdict per 8x4 group. A wave covers 64 consecutive slots = one
 // 8x8 pixel block; its lanes 0-31 (rows 0-3) and 32-63 (rows 4-7) are the two reference workgroups in it, in the
 // workgroup's own thread order (y * 8 + x).
-__global__ void __launch_bounds__(STHIP_BLOCK) k_rr_reduce(FrameParams p) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_rr_reduce(FrameParams p) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u, half = lane >> 5;
   const float4 v = slot < p.path_count ? p.rr[slot] : make_float4(0, 0, 0, 0);
@@ -3056,7 +3056,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_rr_reduce(FrameParams p) {
 }
 
 // eCoherentSampling: WaveReadLaneFirst over the group's lanes that reached the site (entries (1, own draw) written by the probe)
-__global__ void __launch_bounds__(STHIP_BLOCK) k_cs_reduce(uint2* values, uint32_t path_count) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_cs_reduce(uint2* values, uint32_t path_count) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u, half = lane >> 5;
   const uint2 v = slot < path_count ? values[slot] : make_uint2(0u, 0u);
@@ -3068,7 +3068,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_cs_reduce(uint2* values, uint32
 }
 
 // ---- hash grid build (hashgrid.h): keys of the compacted appends, and the scatter into the bucket ranges ----
-__global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys(const float4* appends, const uint32_t* count, uint32_t bucket_count, uint2* keys) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys(const float4* appends, const uint32_t* count, uint32_t bucket_count, uint2* keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= *count) return;
   const float4 a0 = appends[4 * (size_t)i], a2 = appends[4 * (size_t)i + 2];
@@ -3077,7 +3077,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys(const float4* appends, 
   keys[i] = make_uint2(home, checksum);
 }
 // dest[i] = index into gNEEHashGrid.mData of append i, or 0xFFFFFFFF when its 32 probes found no slot (dropped, hashgrid.hlsli:56-58)
-__global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter(const float4* appends, const uint32_t* count, const uint32_t* dest, float4* data) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter(const float4* appends, const uint32_t* count, const uint32_t* dest, float4* data) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= *count) return;
   const uint32_t d = dest[i];
@@ -3088,7 +3088,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter(const float4* append
   data[3 * (size_t)d + 2] = make_float4(a3.x, a3.y, a3.z, a1.w);  // y.Le, y.pdfA
 }
 
-__global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys_lvc(const float4* appends, const uint32_t* count, uint32_t bucket_count, uint2* keys) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys_lvc(const float4* appends, const uint32_t* count, uint32_t bucket_count, uint2* keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= *count) return;
   const float4 a0 = appends[6 * (size_t)i];
@@ -3096,7 +3096,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys_lvc(const float4* appen
   const uint32_t home = hashgrid_bucket_index(xyz(a0), a0.w, bucket_count, checksum);
   keys[i] = make_uint2(home, checksum);
 }
-__global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter_lvc(const float4* appends, const uint32_t* count, const uint32_t* dest, float4* data) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter_lvc(const float4* appends, const uint32_t* count, const uint32_t* dest, float4* data) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= *count) return;
   const uint32_t d = dest[i];
@@ -3104,7 +3104,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter_lvc(const float4* ap
   for (int q = 0; q < 5; q++) data[5 * (size_t)d + q] = appends[6 * (size_t)i + 1 + q];
 }
 
-__global__ void k_write_ray_count(const unsigned long long* counters, unsigned long long* out) {
+inline __global__ void k_write_ray_count(const unsigned long long* counters, unsigned long long* out) {
   out[0] = counters[CNT_RAYS_CLOSEST] + counters[CNT_RAYS_SHADOW];
   out[1] = counters[CNT_RAYS_CLOSEST] - counters[CNT_CROSSINGS];  // one per trace() call (path.hlsli:1006), however many segments it walked
 }
@@ -3153,7 +3153,7 @@ DEV bool shard_slot_pixel(uint32_t rank, uint32_t slot, uint32_t shard_count, ui
   p.pc.gOutputExtent[1] = height;
   return slot_to_pixel(p, slot, px, py);
 }
-__global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const uint32_t* packed, size_t rank_stride, uint32_t shard_count, uint32_t slots, uint32_t tile_w, uint32_t tile_h, uint32_t width,
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const uint32_t* packed, size_t rank_stride, uint32_t shard_count, uint32_t slots, uint32_t tile_w, uint32_t tile_h, uint32_t width,
                                                                  uint32_t height, uint32_t words, uint32_t* frame) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)shard_count * slots) return;
@@ -3170,7 +3170,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const uint32_t* 
 // traces anything — eight environment samples drawn from the path's stream as spots around the view direction, or the
 // environment's pdf of that direction. Runs behind k_generate (which has made the view ray and loaded / cleared the pixel of
 // the debug image) in place of the rounds; the paths are marked dead, radiance stays 0.
-__global__ void __launch_bounds__(STHIP_BLOCK) k_debug_environment(FrameParams p) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_debug_environment(FrameParams p) {
   for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.path_count; slot += gridDim.x * blockDim.x) {
     const uint32_t meta = p.meta[slot];
     if (meta >= 0xFFFFFFFEu) continue;
@@ -3210,7 +3210,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_debug_environment(FrameParams p
 // What shading needs of a leaf triangle's vertices apart from their positions (bvh.h: BvhTriShade), written once per scene
 // upload beside the leaf triangles as they lie in HBM: the triangle says where its index triple is (BvhTri::src_indices /
 // src_vertex), the vertices are read again — so the record holds the floats shading would have gathered (shading_data.hlsli:2-6)
-__global__ void __launch_bounds__(STHIP_BLOCK) k_fill_tri_shade(const BvhTri* tris, uint32_t n, const uint8_t* is_tri, const sthip_PackedVertexData* vertices, uint32_t vertex_count, const uint8_t* indices,
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_fill_tri_shade(const BvhTri* tris, uint32_t n, const uint8_t* is_tri, const sthip_PackedVertexData* vertices, uint32_t vertex_count, const uint8_t* indices,
                                                                 uint64_t indices_bytes, BvhTriShade* out, BvhTriUv* out_uv) {
   for (uint32_t i = blockIdx.x * STHIP_BLOCK + threadIdx.x; i < n; i += gridDim.x * STHIP_BLOCK) {
     BvhTriShade r;
@@ -3255,7 +3255,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_fill_tri_shade(const BvhTri* tr
 
 // The seed-split replica mode (sthip.h: sthip_radiance_to_sums): a call's output is (mean over its seeds, their number); what a
 // sum-reduce over replicas can add up is (sum over its seeds, their number). Back: mean = sum / number, correctly rounded.
-__global__ void __launch_bounds__(STHIP_BLOCK) k_radiance_sums(float4* image, size_t n, uint32_t to_sums) {
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_radiance_sums(float4* image, size_t n, uint32_t to_sums) {
   for (size_t i = blockIdx.x * (size_t)STHIP_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * STHIP_BLOCK) {
     float4 v = image[i];
     if (to_sums) {
@@ -3271,7 +3271,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_radiance_sums(float4* image, si
   }
 }
 
-__global__ void __launch_bounds__(STHIP_BLOCK) k_pack_tiles(const uint32_t* image, uint32_t rank, uint32_t shard_count, uint32_t slots, uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height,
+inline __global__ void __launch_bounds__(STHIP_BLOCK) k_pack_tiles(const uint32_t* image, uint32_t rank, uint32_t shard_count, uint32_t slots, uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height,
                                                              uint32_t words, uint32_t* packed) {
   const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= slots) return;

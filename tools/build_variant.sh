@@ -10,5 +10,11 @@ d=$base/pkg/csrc
 rm -rf $base; mkdir -p $base/pkg; cp -r $root/stratum_amd/csrc $d; cp -r $root/include $base/include
 if [ -n "$patch" ]; then (cd $d && python3 $patch); fi
 mkdir -p $root/_variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math $EXTRA_FLAGS -o $root/_variants/$name.so $d/api.hip $d/lbvh.hip $d/lvc.hip $d/hashgrid.hip $d/wide.hip $d/bvh_build.cpp $d/hdr_writer.cpp
+# one hipcc process per translation unit (as __graft_entry__.build_product), then the link
+mkdir -p $base/obj
+for f in api.hip shade_plain.hip shade_lt.hip shade_media.hip shade_media_lt.hip trace_kernels.hip lbvh.hip lvc.hip hashgrid.hip wide.hip bvh_build.cpp hdr_writer.cpp; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-cuda-compat $EXTRA_FLAGS -c -o $base/obj/$f.o $d/$f &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/_variants/$name.so $base/obj/*.o
 echo built _variants/$name.so
