@@ -1495,6 +1495,7 @@ struct PathVertex {
   uint32_t subpath_length() const { return (packed_beta[1] >> 16) & 0x7Fu; }
   uint32_t diffuse_vertices() const { return (packed_beta[1] >> 23) & 0x1Fu; }
   bool is_prev_delta() const { return (packed_beta[1] >> 28) & 8u; }  // PATH_VERTEX_FLAG_IS_PREV_DELTA
+  bool is_medium() const { return (packed_beta[1] >> 28) & 4u; }      // PATH_VERTEX_FLAG_IS_MEDIUM
   bool flip_bitangent() const { return (packed_beta[1] >> 28) & 1u; }
 };
 static_assert(sizeof(PathVertex) == 64, "PathVertex is 64 bytes");
@@ -2868,7 +2869,9 @@ struct PathIntegrator {
     if (!m.is_specular()) {
       diffuse_vertices++;
       if (diffuse_vertices > fr.pc.gMaxDiffuseVertices) return false;
-      if (trace_light) {  // (eConnectToLightPaths is not restated with media: no vertex is stored)
+      if (trace_light && fr.flag(STHIP_eConnectToLightPaths) && path_length + 2 <= fr.pc.gMaxPathVertices && diffuse_vertices < fr.pc.gMaxDiffuseVertices)
+        store_light_vertex();
+      if (trace_light) {
         if (fr.flag(STHIP_eConnectToViews)) connect_view_medium(m);
       } else {
         if (path_length >= fr.pc.gMinPathVertices)
@@ -2877,6 +2880,7 @@ struct PathIntegrator {
           if (fr.flag(STHIP_eNEEReservoirs)) connect_light_reservoir_medium(m);
           else connect_light_medium(m);
         }
+        if (fr.flag(STHIP_eConnectToLightPaths)) connect_light_subpath_any(nullptr, &m);  // (the vertex cache is not restated with media)
       }
     }
     if (!fr.flag(STHIP_eSampleBSDFs) && !trace_light) return false;
@@ -2974,6 +2978,8 @@ struct PathIntegrator {
     uint32_t flags = 0;
     if (isect.instance_index() != STHIP_INVALID_INSTANCE) flags |= 2u;  // IS_BACKGROUND as upstream sets it
     if (prev_specular) flags |= 8u;
+    const bool in_medium = has_media(fr) && isect.sd.shape_area == 0;
+    if (in_medium) flags |= 4u;  // PATH_VERTEX_FLAG_IS_MEDIUM, path.hlsli:494
     PathVertex v;
     if (path_length > 1) {
       v.material_address = fr.pc.gEnvironmentMaterialAddress;
@@ -2989,6 +2995,10 @@ struct PathIntegrator {
     v.packed_tangent = isect.sd.packed_tangent;
     v.uv[0] = isect.sd.u;
     v.uv[1] = isect.sd.v;
+    if (in_medium) {  // (normals, tangent and uv are the stale ones of the last surface query upstream; nothing reads them of a medium vertex: pinned to 0)
+      v.packed_geometry_normal = v.packed_shading_normal = v.packed_tangent = 0;
+      v.uv[0] = v.uv[1] = 0;
+    }
     v.pack_beta(fr.flag(STHIP_eLVCReservoirs) ? path_contrib : beta, path_length, diffuse_vertices, flags);  // path.hlsli:513
     v.prev_dVC = dVC;
     v.G_rev = prev_cos_out / len_sqr(origin - isect.sd.position);
@@ -3006,6 +3016,16 @@ struct PathIntegrator {
   // loaded again at the stored uv with a zero footprint, and a normal map perturbs the stored (already perturbed) frame
   // a second time, as upstream's inout arguments do.
   bool eval_bsdf_vertex(PathVertex v, v3 dir_out, MaterialEvalRecord& ev, float& ngdotout) const {
+    if (has_media(fr) && v.is_medium()) {  // path.hlsli:103-108: the phase function with the stored (octahedron-packed) direction
+      Medium mm;
+      mm.load(*fr.sc, v.material_address);
+      if (mm.is_specular()) return false;
+      const float ph = mm.phase(unpack_normal_octahedron(v.packed_local_dir_in), dir_out);
+      ev.f = V3(ph);
+      ev.pdf_fwd = ev.pdf_rev = ph;
+      ngdotout = 1;
+      return true;
+    }
     DisneyMaterial lm;
     lm.load(*fr.sc, v.material_address, v.uv[0], v.uv[1], 0.0f, v.packed_shading_normal, v.packed_tangent, fr.sampling_flags);
     if (lm.is_specular()) return false;
@@ -3024,6 +3044,10 @@ struct PathIntegrator {
 
   // connect_light_vertex, path.hlsli:618-680 (surfaces only)
   v3 connect_light_vertex(const DisneyMaterial& m, const PathVertex& lv, float& weight, v3& ray_origin, v3& ray_direction, float& ray_distance) const {
+    return connect_light_vertex_any(&m, nullptr, lv, weight, ray_origin, ray_direction, ray_distance);
+  }
+  // (`phase` != null: the view vertex lies inside a medium — no geometry, the direction itself as local_to_light, :649-650)
+  v3 connect_light_vertex_any(const DisneyMaterial* mp, const Medium* phase, const PathVertex& lv, float& weight, v3& ray_origin, v3& ray_direction, float& ray_distance) const {
     v3 contrib = lv.beta();
     if (all_le0(contrib) || any_nan(contrib)) return V3(0.0f);
     ray_origin = isect.sd.position;
@@ -3034,7 +3058,7 @@ struct PathIntegrator {
     const float rcp_dist2 = pow2(rcp_dist);
     contrib = contrib * rcp_dist2;
     float connection_G_fwd = rcp_dist2;
-    ray_distance = ray_distance * 0.999f;  // visibility_distance_epsilon
+    if (!lv.is_medium()) ray_distance = ray_distance * 0.999f;  // visibility_distance_epsilon (:634-635)
     float cos_theta_light = 0;
     MaterialEvalRecord lv_eval;
     if (!eval_bsdf_vertex(lv, -ray_direction, lv_eval, cos_theta_light)) return V3(0.0f);  // f = 0 upstream
@@ -3043,15 +3067,21 @@ struct PathIntegrator {
     const float dL = connection_dVC(lv.prev_dVC, lv_eval.pdf_rev * lv.G_rev, lv.prev_pdfA_fwd, lv.is_prev_delta());
     float pdfA_rev = lv_eval.pdf_fwd * rcp_dist2;
     if (all_le0(contrib) || any_nan(contrib)) return V3(0.0f);
-    const v3 local_to_light = normalize(isect.sd.to_local(ray_direction));
-    const v3 geometry_normal = isect.sd.geometry_normal();
-    const float ngdotout = dot(geometry_normal, ray_direction);
-    const float ngdotns = dot(geometry_normal, isect.sd.shading_normal());
-    ray_origin = ray_offset(ray_origin, ngdotout > 0 ? geometry_normal : -geometry_normal);
-    pdfA_rev *= fabsf(ngdotout);
-    contrib = contrib * shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, ngdotns, fr.flag(STHIP_eShadingNormalShadowFix), false);
     MaterialEvalRecord ev;
-    m.eval(ev, local_dir_in, local_to_light, false);
+    if (phase) {
+      const float ph = phase->phase(local_dir_in, ray_direction);
+      ev.f = V3(ph);
+      ev.pdf_fwd = ev.pdf_rev = ph;
+    } else {
+      const v3 local_to_light = normalize(isect.sd.to_local(ray_direction));
+      const v3 geometry_normal = isect.sd.geometry_normal();
+      const float ngdotout = dot(geometry_normal, ray_direction);
+      const float ngdotns = dot(geometry_normal, isect.sd.shading_normal());
+      ray_origin = ray_offset(ray_origin, ngdotout > 0 ? geometry_normal : -geometry_normal);
+      pdfA_rev *= fabsf(ngdotout);
+      contrib = contrib * shading_normal_correction(local_dir_in.z, local_to_light.z, ngdotin, ngdotout, ngdotns, fr.flag(STHIP_eShadingNormalShadowFix), false);
+      mp->eval(ev, local_dir_in, local_to_light, false);
+    }
     if (ev.pdf_fwd < 1e-6f) return V3(0.0f);
     contrib = contrib * ev.f;
     if (all_le0(contrib)) return V3(0.0f);
@@ -3066,7 +3096,8 @@ struct PathIntegrator {
 
   // connect_light_subpath, path.hlsli:802-822: this view vertex to every stored vertex of the light subpath that shares
   // its path index; a slot beyond the buffer reads as a zero vertex (robust buffer access)
-  void connect_light_subpath(const DisneyMaterial& m) {
+  void connect_light_subpath(const DisneyMaterial& m) { connect_light_subpath_any(&m, nullptr); }
+  void connect_light_subpath_any(const DisneyMaterial* mp, const Medium* phase) {
     for (uint32_t i = 1; i < fr.pc.gMaxDiffuseVertices; i++) {
       const size_t idx = (size_t)fr.pc.gOutputExtent[0] * fr.pc.gOutputExtent[1] * (i - 1) + path_index();
       if (idx >= fr.light_vertex_count) break;
@@ -3074,9 +3105,15 @@ struct PathIntegrator {
       if (lv.subpath_length() + path_length > fr.pc.gMaxPathVertices || lv.diffuse_vertices() + diffuse_vertices > fr.pc.gMaxDiffuseVertices || all_le0(lv.beta())) break;
       v3 ray_origin, ray_direction;
       float ray_distance = 0, weight = 0;
-      const v3 contrib = beta * connect_light_vertex(m, lv, weight, ray_origin, ray_direction, ray_distance);
+      v3 contrib = beta * connect_light_vertex_any(mp, phase, lv, weight, ray_origin, ray_direction, ray_distance);
       if (all_le0(contrib) || weight <= 0) continue;
-      if (occluded(ray_origin, ray_direction, ray_distance)) continue;
+      if (has_media(fr)) {  // :814-818: the walk through the media, in this path's own stream
+        float dir_pdf = 1, nee_pdf = 1;
+        trace_visibility_media(rng, ray_origin, ray_direction, ray_distance, medium, contrib, dir_pdf, nee_pdf, 64);
+        if (all_le0(contrib) || nee_pdf <= 0) continue;
+        contrib = contrib / nee_pdf;
+      } else if (occluded(ray_origin, ray_direction, ray_distance))
+        continue;
       accumulate_contribution(contrib, weight, lv.subpath_length());  // path.hlsli:820
     }
   }
@@ -3890,7 +3927,7 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
     // with media every visibility ray draws random numbers from the stream it is given: the path's own for an inline NEE ray
     // (path.hlsli:329-332, 474-479), the light path's for connect_view (:577-581). eConnectToLightPaths is not restated with media.
     if (sc->volumes.empty()) fr.scene_flags &= ~STHIP_BDPT_FLAG_HAS_MEDIA;
-    else if (fr.sampling_flags & (1u << STHIP_eConnectToLightPaths)) return STHIP_ERR_UNSUPPORTED;
+    else if (fr.sampling_flags & (1u << STHIP_eLVC)) return STHIP_ERR_UNSUPPORTED;
   }
   // presample_lights, bdpt.hlsl:84-99, once per seed (BDPT.cpp:644-651): rng_init(-1, index), reference point 0.
   // An environment sample leaves `position` unset upstream, so that combination is not restated.

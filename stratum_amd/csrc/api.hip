@@ -1501,9 +1501,10 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   if (media) {
     // with media every visibility ray draws random numbers. An inline NEE ray (no eDeferShadowRays) draws them from the path's
     // own stream in the middle of a vertex: k_shade walks it itself (visibility_walk_media); so does k_shade_light for every
-    // connect_view of light tracing. The connections to stored light vertices (eConnectToLightPaths) are not built with media.
-    if (sampling_flags & (1u << STHIP_eConnectToLightPaths))
-      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media together with eConnectToLightPaths are not built");
+    // connect_view of light tracing and for the connections to the stored light vertices. The light vertex cache (eLVC) is not
+    // built with media.
+    if (sampling_flags & (1u << STHIP_eLVC))
+      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media together with eLVC are not built");
   } else {
     pcn.gMaxNullCollisions = 0;
   }
@@ -1790,7 +1791,7 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   p.media = media ? 1u : 0u;
   const bool inline_media = media && (sampling_flags & (1u << STHIP_eNEE)) && !(sampling_flags & (1u << STHIP_eDeferShadowRays));
   p.inline_media = inline_media ? 1u : 0u;
-  if (inline_media || (media && connect_views)) {  // (light tracing's connect_view walks inline whatever eDeferShadowRays says)
+  if (inline_media || (media && bdpt)) {  // (light tracing's connect_view and the light-subpath connections walk inline whatever eDeferShadowRays says)
     HIP_TRY(ctx, ctx->shade_stack.ensure((size_t)shade_grid * STHIP_BLOCK * std::max(1u, ctx->bvh.stack_depth)));
     p.shade_stack = ctx->shade_stack.p;
   }

@@ -1270,6 +1270,22 @@ __global__ void __launch_bounds__(STHIP_BLOCK, MEDIA ? 2 : 3) k_shade_light(Fram
         if (!mm.is_specular()) {
           diffuse_vertices++;
           if (diffuse_vertices > p.pc.gMaxDiffuseVertices) break;
+          if (connect_paths && path_length + 2 <= p.pc.gMaxPathVertices && diffuse_vertices < p.pc.gMaxDiffuseVertices) {
+            // vertex() / store_light_vertex() at a vertex inside a medium (path.hlsli:491-531): PATH_VERTEX_FLAG_IS_MEDIUM; the normals,
+            // tangent and uv upstream stores are the stale ones of the last surface query and nothing reads them: pinned to 0
+            const size_t per_seed = (size_t)p.pc.gLightPathCount * p.pc.gMaxDiffuseVertices;
+            const size_t idx = (size_t)W * H * (diffuse_vertices - 1) + path_index;
+            if (idx < per_seed) {
+              float4* lv = p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
+              const uint32_t vflags = 2u | 4u | (prev_specular ? 8u : 0u);
+              const uint32_t pb0 = det_f32tof16(beta.x) | (det_f32tof16(beta.y) << 16);
+              const uint32_t pb1 = det_f32tof16(beta.z) | ((path_length & 0x7Fu) << 16) | ((diffuse_vertices & 0x1Fu) << 23) | (vflags << 28);
+              lv[0] = make_float4(scatter_p.x, scatter_p.y, scatter_p.z, __uint_as_float(0u));
+              lv[1] = make_float4(__uint_as_float(load_inst(p.scene, medium).material_address()), __uint_as_float(pack_normal_octahedron(local_dir_in)), __uint_as_float(0u), __uint_as_float(0u));
+              lv[2] = make_float4(0.0f, 0.0f, __uint_as_float(pb0), __uint_as_float(pb1));
+              lv[3] = make_float4(dVC, prev_cos_out / len_sqr(origin - scatter_p), bsdf_pdf * G, path_pdf);
+            }
+          }
           if (connect_views) do {  // connect_view at a medium vertex: no geometry (path.hlsli:562-565), the phase function as f and both pdfs
             ViewLink L;
             if (!view_link(scatter_p, L)) break;
@@ -1654,6 +1670,44 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
       pc4.y = pc4.y / pc4.w;
       debug_set(F3(fabsf((pc4.x * .5f + .5f) - uvx) * (float)p.pc.gOutputExtent[0], fabsf((pc4.y * .5f + .5f) - uvy) * (float)p.pc.gOutputExtent[1], 0.0f));
     };
+    // eval_bsdf(PathVertex, dir_out, adjoint), path.hlsli:100-123, of a stored light vertex (4 x float4, bdpt.h:108-156) towards
+    // dir_out: a surface vertex loads its material again at the stored uv with a zero footprint (a normal map perturbs the stored,
+    // already perturbed frame once more, as upstream); a vertex inside a medium (PATH_VERTEX_FLAG_IS_MEDIUM) is its phase function
+    // with the stored direction, no geometry. False: f = 0.
+    auto eval_light_vertex = [&](const float4* lvp, f3 dir_out, MaterialEvalRecord& lev, float& cos_theta_light) -> bool {
+      const float4 v0 = lvp[0], v1 = lvp[1], v2 = lvp[2];
+      const uint32_t pb1 = __float_as_uint(v2.w);
+      const f3 lv_dir_in = unpack_normal_octahedron(__float_as_uint(v1.y));
+      if (MEDIA && ((pb1 >> 28) & 4u)) {
+        Medium lmm;
+        lmm.load(p.scene, __float_as_uint(v1.x));
+        if (lmm.is_specular()) return false;
+        const float ph = lmm.phase(lv_dir_in, dir_out);
+        lev.f = F3s(ph);
+        lev.pdf_fwd = lev.pdf_rev = ph;
+        cos_theta_light = 1;
+        return true;
+      }
+      uint32_t lv_ns = __float_as_uint(v1.z), lv_tg = __float_as_uint(v1.w);
+      DisneyMaterial lm;
+      if (TEXTURED)
+        lm.load_textured(p.scene, __float_as_uint(v1.x), v2.x, v2.y, 0.0f, lv_ns, lv_tg, p.sampling_flags);
+      else
+        lm.load(p.scene, __float_as_uint(v1.x));
+      if (lm.is_specular()) return false;
+      Frame3 lf;
+      lf.n = unpack_normal_octahedron(lv_ns);
+      lf.t = unpack_normal_octahedron(lv_tg);
+      lf.b = cross3(lf.n, lf.t) * (((pb1 >> 28) & 1u) ? -1.0f : 1.0f);
+      const f3 lv_dir_out = normalize3(lf.to_local(dir_out));
+      lm.eval(lev, lv_dir_in, lv_dir_out, true);
+      if (lev.pdf_fwd < 1e-6f) return false;
+      const f3 lv_ng = unpack_normal_octahedron(__float_as_uint(v0.w));
+      cos_theta_light = dot3(lv_ng, dir_out);
+      lev.f = lev.f * shading_normal_correction(lv_dir_in.z, lv_dir_out.z, dot3(lv_ng, normalize3(lf.to_world(lv_dir_in))), cos_theta_light, dot3(lv_ng, lf.n),
+                                                flag(p, STHIP_eShadingNormalShadowFix), true);
+      return true;
+    };
     // accumulate_contribution's debug half (path.hlsli:302-303): the unweighted contribution of one (view, light) length pair
     auto debug_path_length = [&](f3 contrib, uint32_t view_length, uint32_t light_length) {
       if (debug_is(STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION) && p.pc.gDebugLightPathLength == light_length && view_length == p.pc.gDebugViewPathLength) debug_add(contrib);
@@ -1964,6 +2018,67 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, __uint_as_float(medium));
             p.shadow_ext[shadow_base + k] = make_float4(__uint_as_float(rng.counter), 1.0f, __uint_as_float(entry), 0.0f);
           } while (0);
+        }
+        if (LT && connect_paths && !mm.is_specular()) {
+          // connect_light_subpath from a vertex inside a medium (path.hlsli:802-822 with connect_light_vertex's medium branch,
+          // :649-650): the direction itself as local_to_light, no ray offset, no cosine in the reverse pdf, the phase function
+          // as f and both pdfs; every connection walks its visibility ray at once
+          uint32_t path_index;  // map_pixel_coord, bdpt_util.hlsli:76-83
+          if (flag(p, STHIP_eRemapThreads))
+            path_index = ((py >> 2) * ((p.pc.gOutputExtent[0] + 7u) >> 3) + (px >> 3)) * 32u + (py & 3u) * 8u + (px & 7u);
+          else
+            path_index = py * p.pc.gOutputExtent[0] + px;
+          const size_t per_seed = (size_t)p.pc.gLightPathCount * p.pc.gMaxDiffuseVertices;
+          const size_t level = (size_t)p.pc.gOutputExtent[0] * p.pc.gOutputExtent[1];
+          for (uint32_t li = 1; li < p.pc.gMaxDiffuseVertices; li++) {
+            const size_t idx = level * (li - 1) + path_index;
+            if (idx >= per_seed) break;
+            const float4* lvp = p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
+            const float4 v0 = lvp[0], v2 = lvp[2], v3 = lvp[3];
+            const uint32_t pb0 = __float_as_uint(v2.z), pb1 = __float_as_uint(v2.w);
+            const f3 lv_beta = F3(det_f16tof32(pb0 & 0xFFFFu), det_f16tof32(pb0 >> 16), det_f16tof32(pb1 & 0xFFFFu));
+            const uint32_t lv_length = (pb1 >> 16) & 0x7Fu, lv_diffuse = (pb1 >> 23) & 0x1Fu;
+            if (lv_length + path_length > p.pc.gMaxPathVertices || lv_diffuse + diffuse_vertices > p.pc.gMaxDiffuseVertices || all_le0(lv_beta)) break;
+            // connect_light_vertex, path.hlsli:618-680
+            f3 contrib = lv_beta;
+            if (any_nan(contrib)) continue;
+            f3 ray_direction = xyz(v0) - scatter_p;
+            float ray_distance = length3(ray_direction);
+            const float rcp_dist = 1 / ray_distance;
+            ray_direction = ray_direction * rcp_dist;
+            const float rcp_dist2 = pow2f(rcp_dist);
+            contrib = contrib * rcp_dist2;
+            float connection_G_fwd = rcp_dist2;
+            if (!((pb1 >> 28) & 4u)) ray_distance = ray_distance * 0.999f;
+            MaterialEvalRecord lev;
+            float cos_theta_light = 0;
+            if (!eval_light_vertex(lvp, -ray_direction, lev, cos_theta_light)) continue;
+            contrib = contrib * lev.f;
+            connection_G_fwd *= fabsf(cos_theta_light);
+            const float dL = connection_dVC(v3.x, lev.pdf_rev * v3.y, v3.z, ((pb1 >> 28) & 8u) != 0);
+            const float pdfA_rev = lev.pdf_fwd * rcp_dist2;
+            if (all_le0(contrib) || any_nan(contrib)) continue;
+            const float ph = mm.phase(local_dir_in, ray_direction);
+            if (ph < 1e-6f) continue;
+            contrib = contrib * ph;
+            if (all_le0(contrib)) continue;
+            float weight;
+            if (use_mis) {
+              const float G_rev = prev_cos_out / len_sqr(origin - scatter_p);
+              const float dE = connection_dVC(dVC, ph * G_rev, bsdf_pdf * G, prev_specular);
+              weight = 1 / (1 + dE * pow2f(pdfA_rev) + dL * pow2f(ph * connection_G_fwd));
+            } else
+              weight = path_weight(p, path_length, lv_length);
+            contrib = beta * contrib;
+            if (all_le0(contrib) || weight <= 0) continue;
+            float dir_pdf = 1, nee_pdf = 1;
+            walk_segments += visibility_walk_media(p, rng, scatter_p, ray_direction, ray_distance, medium, contrib, dir_pdf, nee_pdf, p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth);
+            if (all_le0(contrib) || nee_pdf <= 0) continue;
+            contrib = contrib / nee_pdf;
+            debug_path_length(contrib, path_length, lv_length);
+            radiance = radiance + contrib * weight;
+            radiance_dirty = true;
+          }
         }
         if (!sample_bsdfs) break;
         // sample_direction, path.hlsli:898-952, with the phase function
@@ -2586,29 +2701,10 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             const float rcp_dist2 = pow2f(rcp_dist);
             contrib = contrib * rcp_dist2;
             float connection_G_fwd = rcp_dist2;
-            ray_distance = ray_distance * 0.999f;  // visibility_distance_epsilon
-            // eval_bsdf(PathVertex, -ray_direction, adjoint), path.hlsli:100-123: the material is loaded again at the stored
-            // uv with a zero footprint; a normal map perturbs the stored (already perturbed) frame once more, as upstream
-            uint32_t lv_ns = __float_as_uint(v1.z), lv_tg = __float_as_uint(v1.w);
-            DisneyMaterial lm;
-            if (TEXTURED)
-              lm.load_textured(p.scene, __float_as_uint(v1.x), v2.x, v2.y, 0.0f, lv_ns, lv_tg, p.sampling_flags);
-            else
-              lm.load(p.scene, __float_as_uint(v1.x));
-            if (lm.is_specular()) return none;
-            Frame3 lf;
-            lf.n = unpack_normal_octahedron(lv_ns);
-            lf.t = unpack_normal_octahedron(lv_tg);
-            lf.b = cross3(lf.n, lf.t) * (((pb1 >> 28) & 1u) ? -1.0f : 1.0f);
-            const f3 lv_dir_in = unpack_normal_octahedron(__float_as_uint(v1.y));
-            const f3 lv_dir_out = normalize3(lf.to_local(-ray_direction));
+            if (!(MEDIA && ((pb1 >> 28) & 4u))) ray_distance = ray_distance * 0.999f;  // visibility_distance_epsilon (not towards a vertex inside a medium, path.hlsli:634-635)
             MaterialEvalRecord lev;
-            lm.eval(lev, lv_dir_in, lv_dir_out, true);
-            if (lev.pdf_fwd < 1e-6f) return none;
-            const f3 lv_ng = unpack_normal_octahedron(__float_as_uint(v0.w));
-            const float cos_theta_light = dot3(lv_ng, -ray_direction);
-            lev.f = lev.f * shading_normal_correction(lv_dir_in.z, lv_dir_out.z, dot3(lv_ng, normalize3(lf.to_world(lv_dir_in))), cos_theta_light, dot3(lv_ng, lf.n),
-                                                      flag(p, STHIP_eShadingNormalShadowFix), true);
+            float cos_theta_light = 0;
+            if (!eval_light_vertex(lvp, -ray_direction, lev, cos_theta_light)) return none;
             contrib = contrib * lev.f;
             connection_G_fwd *= fabsf(cos_theta_light);
             const float dL = connection_dVC(v3.x, lev.pdf_rev * v3.y, v3.z, ((pb1 >> 28) & 8u) != 0);
@@ -2764,8 +2860,18 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             if (!vertex_fits(lvp)) break;
             f3 ray_origin = F3s(0.0f), ray_direction = F3s(0.0f);
             float ray_distance = 0, weight = 0;
-            const f3 contrib = beta * connect_light_vertex(lvp, weight, ray_origin, ray_direction, ray_distance);
+            f3 contrib = beta * connect_light_vertex(lvp, weight, ray_origin, ray_direction, ray_distance);
             if (all_le0(contrib) || weight <= 0) continue;
+            if (MEDIA) {  // path.hlsli:814-820: the visibility ray walks through the media now, in this path's stream; added at once
+              float dir_pdf = 1, nee_pdf = 1;
+              walk_segments += visibility_walk_media(p, rng, ray_origin, ray_direction, ray_distance, medium, contrib, dir_pdf, nee_pdf, p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth);
+              if (all_le0(contrib) || nee_pdf <= 0) continue;
+              contrib = contrib / nee_pdf;
+              debug_path_length(contrib, path_length, (__float_as_uint(lvp[2].w) >> 16) & 0x7Fu);
+              radiance = radiance + contrib * weight;
+              radiance_dirty = true;
+              continue;
+            }
             queue_connection(contrib * weight, slot * (p.pc.gMaxDiffuseVertices - 1) + (li - 1), ray_origin, ray_direction, ray_distance);
           }
         }

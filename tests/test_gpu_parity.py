@@ -1362,6 +1362,12 @@ def test_trace_contract_with_volumes(renderer):
         ({"anisotropy": 0.5, "density": (9.0, 6.0, 3.0)}, ["connecttoviews", "~defershadowrays"], {"maxDiffuseVertices": 4, "maxPathVertices": 6}),
         ({"density": (12.0, 12.0, 12.0)}, ["connecttoviews", "~mis", "~nee"], {"maxDiffuseVertices": 4}),
         ({}, ["connecttoviews", "neereservoirs", "presamplelights"], {"maxDiffuseVertices": 3, "reservoirM": 2}),
+        # ... and the connections to the stored light vertices (eConnectToLightPaths): light vertices inside media
+        # (PATH_VERTEX_FLAG_IS_MEDIUM: the phase function with the stored direction), view vertices inside media, every connection's
+        # visibility ray walked at once in the view path's stream (path.hlsli:618-680,802-822)
+        ({}, ["connecttolightpaths"], {"maxDiffuseVertices": 3}),
+        ({"anisotropy": 0.5, "density": (9.0, 6.0, 3.0)}, ["connecttolightpaths", "connecttoviews", "~defershadowrays"], {"maxDiffuseVertices": 4, "maxPathVertices": 6}),
+        ({"density": (12.0, 12.0, 12.0)}, ["connecttolightpaths", "~mis", "~nee"], {"maxDiffuseVertices": 4}),
         # ... with spatial reuse: seeds 1 and 2 look into the grid the seed before them built, from surface and medium vertices alike
         ({"density": (9.0, 9.0, 9.0)}, ["neereservoirs", "neereservoirreuse"], {"maxDiffuseVertices": 3, "reservoirM": 2, "reservoirSpatialM": 3, "hashGridBucketCount": 20000}),
         ({"anisotropy": 0.3}, ["neereservoirs", "neereservoirreuse", "~jitterhashgridlookups", "~defershadowrays", "presamplelights"], {"maxDiffuseVertices": 4, "reservoirM": 3, "reservoirSpatialM": 2, "hashGridBucketCount": 5000}),
@@ -1407,13 +1413,15 @@ def test_media_limits(renderer):
     sc, cam = scenes.cornell_box(fog=_fog())
     renderer.update(sc)
     frame = camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"])
-    for f in ("connecttolightpaths",):
-        renderer.set_flag(f)
+    for fs in (("connecttolightpaths", "lightvertexcache"),):
+        for f in fs:
+            renderer.set_flag(f)
         try:
             with pytest.raises(_lib.StratumHipError, match="media"):
                 renderer.render(frame)
         finally:
-            renderer.set_flag(f[1:] if f[0] == "~" else "~" + f)
+            for f in fs:
+                renderer.set_flag("~" + f)
 
 
 def test_media_stereo_and_long_walks():
