@@ -193,7 +193,7 @@ int sthip_scene_update_transforms(sthip_ctx* ctx, const sthip_TransformData* gIn
  * are then traced one at a time, seed s reading the grid of seed s - 1; not on a pixel-tile shard), eCoherentRR and
  * eCoherentSampling (the wave = the 8x4 pixel group, its first lane = the lowest lane that executes the statement).
  * Rejected with STHIP_ERR_UNSUPPORTED, never ignored: eSampleLightPower (reads an uninitialised table upstream) and the
- * combinations DESIGN.md section 5 lists (media exclude eLVC / eCoherentSampling; light
+ * combinations DESIGN.md section 5 lists (media exclude eCoherentSampling; light
  * subpaths and reuse exclude environments). Media without eDeferShadowRays are traced with k_shade walking every NEE ray itself.
  * ePerformanceCounters does not change results here; eRemapThreads only through the path index
  * (map_pixel_coord, bdpt_util.hlsli:76-83) that ePresampleLights and the light subpaths key on. */

@@ -2880,7 +2880,10 @@ struct PathIntegrator {
           if (fr.flag(STHIP_eNEEReservoirs)) connect_light_reservoir_medium(m);
           else connect_light_medium(m);
         }
-        if (fr.flag(STHIP_eConnectToLightPaths)) connect_light_subpath_any(nullptr, &m);  // (the vertex cache is not restated with media)
+        if (fr.flag(STHIP_eConnectToLightPaths)) {
+          if (fr.flag(STHIP_eLVC)) connect_lvc_any(nullptr, &m);
+          else connect_light_subpath_any(nullptr, &m);
+        }
       }
     }
     if (!fr.flag(STHIP_eSampleBSDFs) && !trace_light) return false;
@@ -2889,6 +2892,7 @@ struct PathIntegrator {
     (void)r2;
     float pdf, roughness;
     const v3 dir_out = m.sample(r0, r1, local_dir_in, pdf, roughness);
+    path_contrib = path_contrib * pdf;  // path.hlsli:901 (Medium::sample returns the phase value)
     if (pdf < 1e-6f) {
       beta = V3(0.0f);
       return false;
@@ -3123,7 +3127,10 @@ struct PathIntegrator {
   // gReservoirM uniform picks with target luminance(contribution). The cache order is the defined one (see Frame). An
   // empty cache (n = 0) is a division by zero upstream; here the random numbers are drawn and nothing connects. With
   // eDeferShadowRays the record goes to this vertex's gShadowRays slot — the slot connect_light has just written, as upstream.
-  void connect_lvc(const DisneyMaterial& m) {
+  void connect_lvc(const DisneyMaterial& m) { connect_lvc_any(&m, nullptr); }
+  // (`phase` != null: from a vertex inside a medium — connect_light_vertex's medium branch; the geometry normal the reuse takes its
+  // jitter plane from and stores is the stale one of the last surface query there: pinned to the packed value 0)
+  void connect_lvc_any(const DisneyMaterial* mp, const Medium* phase) {
     const uint32_t n = std::min<uint64_t>(fr.lvc_count, (uint64_t)fr.pc.gLightPathCount * fr.pc.gMaxDiffuseVertices);
     uint32_t li = rng.next_uint();
     const bool coherent = coherent_sampling();
@@ -3145,7 +3152,7 @@ struct PathIntegrator {
         if (!fits(lv_i)) continue;
         v3 ro_i = V3(0.0f), rd_i = V3(0.0f);
         float dist_i = 0, weight_i = 0;
-        const v3 contrib_i = connect_light_vertex(m, lv_i, weight_i, ro_i, rd_i, dist_i);
+        const v3 contrib_i = connect_light_vertex_any(mp, phase, lv_i, weight_i, ro_i, rd_i, dist_i);
         const float target_pdf_i = luminance(contrib_i);
         if (r.update(rng.next_float(), target_pdf_i / lv_i.path_pdf)) {
           contrib = contrib_i;
@@ -3159,7 +3166,7 @@ struct PathIntegrator {
       }
       if (fr.flag(STHIP_eLVCReservoirReuse)) {  // path.hlsli:727-768
         v3 t, b;
-        make_orthonormal(isect.sd.geometry_normal(), t, b);
+        make_orthonormal(phase ? unpack_normal_octahedron(0) : isect.sd.geometry_normal(), t, b);
         const float cell_size = hashgrid_cell_size(isect.sd.position);
         auto jittered = [&]() {
           const float phi = rng.next_float() * 2 * DET_PI;
@@ -3182,7 +3189,7 @@ struct PathIntegrator {
               M += prev.r.M;
               v3 ro_i = V3(0.0f), rd_i = V3(0.0f);
               float dist_i = 0, weight_i = 0;
-              const v3 contrib_i = connect_light_vertex(m, lv_i, weight_i, ro_i, rd_i, dist_i);
+              const v3 contrib_i = connect_light_vertex_any(mp, phase, lv_i, weight_i, ro_i, rd_i, dist_i);
               const float target_pdf_i = luminance(contrib_i);
               if (r.update(rng.next_float(), target_pdf_i / lv_i.path_pdf)) {
                 contrib = contrib_i;
@@ -3206,7 +3213,7 @@ struct PathIntegrator {
           a.pos = at;
           a.cell_size = cell_size;
           a.y.r = r;
-          a.y.packed_geometry_normal = isect.sd.packed_geometry_normal;
+          a.y.packed_geometry_normal = phase ? 0u : isect.sd.packed_geometry_normal;
           a.y.W = W;
           a.y.y = lv;
           fr.lvc_append_valid[k] = 1;
@@ -3214,7 +3221,7 @@ struct PathIntegrator {
       }
       contrib = contrib * r.W(r_target_pdf);
     } else if (fits(lv)) {
-      contrib = connect_light_vertex(m, lv, weight, ray_origin, ray_direction, ray_distance);
+      contrib = connect_light_vertex_any(mp, phase, lv, weight, ray_origin, ray_direction, ray_distance);
     }
     contrib = contrib * (float)(fr.pc.gMaxDiffuseVertices - 1);
     contrib = contrib * beta;
@@ -3235,7 +3242,14 @@ struct PathIntegrator {
       rd.ray_direction[2] = ray_direction.z;
       rd.ray_distance = ray_distance;
     } else if (any_gt0(contrib) && weight > 0) {
-      if (!occluded(ray_origin, ray_direction, ray_distance)) accumulate_contribution(contrib, weight, lv.subpath_length());  // path.hlsli:797
+      if (has_media(fr)) {  // :791-796: the walk through the media, in this path's own stream
+        float dir_pdf = 1, nee_pdf = 1;
+        trace_visibility_media(rng, ray_origin, ray_direction, ray_distance, medium, contrib, dir_pdf, nee_pdf, 64);
+        if (all_le0(contrib) || nee_pdf <= 0) return;
+        contrib = contrib / nee_pdf;
+        accumulate_contribution(contrib, weight, lv.subpath_length());
+      } else if (!occluded(ray_origin, ray_direction, ray_distance))
+        accumulate_contribution(contrib, weight, lv.subpath_length());  // path.hlsli:797
     }
   }
 
@@ -3925,9 +3939,8 @@ int orc_render_window(orc_scene* sc, const sthip_BDPTPushConstants* pc, uint32_t
   if (fr.flag(STHIP_eCoherentSampling) && (scene_flags & STHIP_BDPT_FLAG_HAS_MEDIA) && !sc->volumes.empty()) return STHIP_ERR_UNSUPPORTED;  // walks through volumes break the lockstep
   if (has_media(fr)) {
     // with media every visibility ray draws random numbers from the stream it is given: the path's own for an inline NEE ray
-    // (path.hlsli:329-332, 474-479), the light path's for connect_view (:577-581). eConnectToLightPaths is not restated with media.
+    // (path.hlsli:329-332, 474-479), the light path's for connect_view (:577-581), the view path's for the connections to light vertices (:791-796,814-818).
     if (sc->volumes.empty()) fr.scene_flags &= ~STHIP_BDPT_FLAG_HAS_MEDIA;
-    else if (fr.sampling_flags & (1u << STHIP_eLVC)) return STHIP_ERR_UNSUPPORTED;
   }
   // presample_lights, bdpt.hlsl:84-99, once per seed (BDPT.cpp:644-651): rng_init(-1, index), reference point 0.
   // An environment sample leaves `position` unset upstream, so that combination is not restated.

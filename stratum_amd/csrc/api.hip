@@ -1501,10 +1501,7 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   if (media) {
     // with media every visibility ray draws random numbers. An inline NEE ray (no eDeferShadowRays) draws them from the path's
     // own stream in the middle of a vertex: k_shade walks it itself (visibility_walk_media); so does k_shade_light for every
-    // connect_view of light tracing and for the connections to the stored light vertices. The light vertex cache (eLVC) is not
-    // built with media.
-    if (sampling_flags & (1u << STHIP_eLVC))
-      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: media together with eLVC are not built");
+    // connect_view of light tracing and for the connections to the stored light vertices or to the light vertex cache.
   } else {
     pcn.gMaxNullCollisions = 0;
   }
@@ -1558,7 +1555,6 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   if (lvc) {
     if (pc->gMaxDiffuseVertices < 2) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eLVC needs gMaxDiffuseVertices >= 2 (a light path stores vertices 1 .. gMaxDiffuseVertices - 1)");
     if (pc->gLightPathCount == 0 || (uint64_t)pc->gLightPathCount * pc->gMaxDiffuseVertices > (1ull << 28)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: eLVC needs 0 < gLightPathCount * gMaxDiffuseVertices <= 2^28");
-    if (media) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eLVC with media is not built");
   }
   const uint32_t light_rows = (pc->gLightPathCount + W - 1) / W;
   const uint32_t light_threads = light_tracing ? ((W + 7) / 8) * 8 * ((light_rows + 3) / 4) * 4 : 0;

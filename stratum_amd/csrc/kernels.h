@@ -1275,11 +1275,13 @@ __global__ void __launch_bounds__(STHIP_BLOCK, MEDIA ? 2 : 3) k_shade_light(Fram
             // tangent and uv upstream stores are the stale ones of the last surface query and nothing reads them: pinned to 0
             const size_t per_seed = (size_t)p.pc.gLightPathCount * p.pc.gMaxDiffuseVertices;
             const size_t idx = (size_t)W * H * (diffuse_vertices - 1) + path_index;
-            if (idx < per_seed) {
-              float4* lv = p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
+            if (p.lvc_staging || idx < per_seed) {
+              float4* lv = p.lvc_staging ? p.lvc_staging + 4 * (((size_t)seed_index * p.pc.gLightPathCount + path_index) * (p.pc.gMaxDiffuseVertices - 1) + (diffuse_vertices - 1))
+                                         : p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
               const uint32_t vflags = 2u | 4u | (prev_specular ? 8u : 0u);
-              const uint32_t pb0 = det_f32tof16(beta.x) | (det_f32tof16(beta.y) << 16);
-              const uint32_t pb1 = det_f32tof16(beta.z) | ((path_length & 0x7Fu) << 16) | ((diffuse_vertices & 0x1Fu) << 23) | (vflags << 28);
+              const f3 stored = flag(p, STHIP_eLVCReservoirs) ? path_contrib : beta;  // path.hlsli:513
+              const uint32_t pb0 = det_f32tof16(stored.x) | (det_f32tof16(stored.y) << 16);
+              const uint32_t pb1 = det_f32tof16(stored.z) | ((path_length & 0x7Fu) << 16) | ((diffuse_vertices & 0x1Fu) << 23) | (vflags << 28);
               lv[0] = make_float4(scatter_p.x, scatter_p.y, scatter_p.z, __uint_as_float(0u));
               lv[1] = make_float4(__uint_as_float(load_inst(p.scene, medium).material_address()), __uint_as_float(pack_normal_octahedron(local_dir_in)), __uint_as_float(0u), __uint_as_float(0u));
               lv[2] = make_float4(0.0f, 0.0f, __uint_as_float(pb0), __uint_as_float(pb1));
@@ -1948,6 +1950,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
               }
               const f3 c = beta * contrib * weight;
               if (all_le0(c)) break;
+              if (LT && flag(p, STHIP_eLVC) && connect_paths) break;  // (connect_lvc's record takes the slot, as above)
               const uint32_t entry = slot * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
               if (!(c_dist > 1e-6f)) {
                 p.shadow_result[entry] = make_float4(c.x, c.y, c.z, 0.0f);
@@ -2007,6 +2010,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
               weight = mis2(use_mis, c_pdfA, pdfA_fwd);
             const f3 c = beta * contrib * weight;
             if (all_le0(c)) break;
+            if (LT && flag(p, STHIP_eLVC) && connect_paths) break;  // (eDeferShadowRays here: connect_lvc's record takes this vertex's slot right after, path.hlsli:775-783)
             const uint32_t entry = slot * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
             if (!(c_dist > 1e-6f)) {  // trace_visibility_ray's loop never runs
               p.shadow_result[entry] = make_float4(c.x, c.y, c.z, 0.0f);
@@ -2030,20 +2034,24 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             path_index = py * p.pc.gOutputExtent[0] + px;
           const size_t per_seed = (size_t)p.pc.gLightPathCount * p.pc.gMaxDiffuseVertices;
           const size_t level = (size_t)p.pc.gOutputExtent[0] * p.pc.gOutputExtent[1];
-          for (uint32_t li = 1; li < p.pc.gMaxDiffuseVertices; li++) {
-            const size_t idx = level * (li - 1) + path_index;
-            if (idx >= per_seed) break;
-            const float4* lvp = p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
-            const float4 v0 = lvp[0], v2 = lvp[2], v3 = lvp[3];
+          // fits(): the three tests in front of every connection; connect_light_vertex (path.hlsli:618-680) from this medium vertex:
+          // the contribution without beta, zero when the connection fails; weight, direction and distance come out with it
+          auto vertex_fits = [&](const float4* lvp) {
+            const float4 v2 = lvp[2];
             const uint32_t pb0 = __float_as_uint(v2.z), pb1 = __float_as_uint(v2.w);
             const f3 lv_beta = F3(det_f16tof32(pb0 & 0xFFFFu), det_f16tof32(pb0 >> 16), det_f16tof32(pb1 & 0xFFFFu));
             const uint32_t lv_length = (pb1 >> 16) & 0x7Fu, lv_diffuse = (pb1 >> 23) & 0x1Fu;
-            if (lv_length + path_length > p.pc.gMaxPathVertices || lv_diffuse + diffuse_vertices > p.pc.gMaxDiffuseVertices || all_le0(lv_beta)) break;
-            // connect_light_vertex, path.hlsli:618-680
-            f3 contrib = lv_beta;
-            if (any_nan(contrib)) continue;
-            f3 ray_direction = xyz(v0) - scatter_p;
-            float ray_distance = length3(ray_direction);
+            return !(lv_length + path_length > p.pc.gMaxPathVertices || lv_diffuse + diffuse_vertices > p.pc.gMaxDiffuseVertices || all_le0(lv_beta));
+          };
+          auto connect_from_medium = [&](const float4* lvp, float& weight, f3& ray_direction, float& ray_distance) -> f3 {
+            const float4 v0 = lvp[0], v2 = lvp[2], v3 = lvp[3];
+            const uint32_t pb0 = __float_as_uint(v2.z), pb1 = __float_as_uint(v2.w);
+            const uint32_t lv_length = (pb1 >> 16) & 0x7Fu;
+            const f3 none = F3s(0.0f);
+            f3 contrib = F3(det_f16tof32(pb0 & 0xFFFFu), det_f16tof32(pb0 >> 16), det_f16tof32(pb1 & 0xFFFFu));
+            if (all_le0(contrib) || any_nan(contrib)) return none;
+            ray_direction = xyz(v0) - scatter_p;
+            ray_distance = length3(ray_direction);
             const float rcp_dist = 1 / ray_distance;
             ray_direction = ray_direction * rcp_dist;
             const float rcp_dist2 = pow2f(rcp_dist);
@@ -2052,30 +2060,146 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             if (!((pb1 >> 28) & 4u)) ray_distance = ray_distance * 0.999f;
             MaterialEvalRecord lev;
             float cos_theta_light = 0;
-            if (!eval_light_vertex(lvp, -ray_direction, lev, cos_theta_light)) continue;
+            if (!eval_light_vertex(lvp, -ray_direction, lev, cos_theta_light)) return none;
             contrib = contrib * lev.f;
             connection_G_fwd *= fabsf(cos_theta_light);
             const float dL = connection_dVC(v3.x, lev.pdf_rev * v3.y, v3.z, ((pb1 >> 28) & 8u) != 0);
             const float pdfA_rev = lev.pdf_fwd * rcp_dist2;
-            if (all_le0(contrib) || any_nan(contrib)) continue;
+            if (all_le0(contrib) || any_nan(contrib)) return none;
             const float ph = mm.phase(local_dir_in, ray_direction);
-            if (ph < 1e-6f) continue;
+            if (ph < 1e-6f) return none;
             contrib = contrib * ph;
-            if (all_le0(contrib)) continue;
-            float weight;
+            if (all_le0(contrib)) return none;
             if (use_mis) {
               const float G_rev = prev_cos_out / len_sqr(origin - scatter_p);
               const float dE = connection_dVC(dVC, ph * G_rev, bsdf_pdf * G, prev_specular);
               weight = 1 / (1 + dE * pow2f(pdfA_rev) + dL * pow2f(ph * connection_G_fwd));
             } else
               weight = path_weight(p, path_length, lv_length);
-            contrib = beta * contrib;
+            return contrib;
+          };
+          uint32_t* column = p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth;
+          if (flag(p, STHIP_eLVC)) {
+            // connect_lvc, path.hlsli:683-800, from a vertex inside a medium: ONE vertex of the cache, picked uniformly or, with
+            // eLVCReservoirs, by resampled importance sampling; reuse through the hash grid as at a surface, with the stale
+            // geometry normal pinned to the packed value 0
+            const float4* cache = p.light_vertices + 4 * (size_t)seed_index * per_seed;
+            const uint32_t n = (uint32_t)min((unsigned long long)p.lvc_count[seed_index], (unsigned long long)per_seed);
+            const uint32_t li0 = rng.next_uint();
+            f3 contrib = F3s(0.0f), ray_direction = F3s(0.0f);
+            float weight = 1, ray_distance = 0;
+            uint32_t lvc_length = n ? (__float_as_uint(cache[4 * (size_t)(li0 % n) + 2].w) >> 16) & 0x7Fu : 0u;
+            if (flag(p, STHIP_eLVCReservoirs)) {
+              float total_weight = 0, r_target_pdf = 0;
+              uint32_t M = 0;
+              const float4* chosen = n ? cache + 4 * (size_t)(li0 % n) : nullptr;
+              auto resample = [&](const float4* lvp) {
+                f3 rd_i = F3s(0.0f);
+                float dist_i = 0, weight_i = 0;
+                const f3 contrib_i = connect_from_medium(lvp, weight_i, rd_i, dist_i);
+                const float target_pdf_i = luminance3(contrib_i);
+                const float w = target_pdf_i / lvp[3].w;
+                M++;
+                total_weight += w;
+                if (rng.next_float() * total_weight <= w) {
+                  contrib = contrib_i;
+                  weight = weight_i;
+                  ray_direction = rd_i;
+                  ray_distance = dist_i;
+                  r_target_pdf = target_pdf_i;
+                  chosen = lvp;
+                  lvc_length = (__float_as_uint(lvp[2].w) >> 16) & 0x7Fu;
+                }
+              };
+              for (uint32_t ri = 0; ri < p.pc.gReservoirM; ri++) {
+                const uint32_t pick = rng.next_uint();
+                if (!n) continue;
+                const float4* lvp = cache + 4 * (size_t)(pick % n);
+                if (!vertex_fits(lvp)) continue;
+                resample(lvp);
+              }
+              if (p.lg_appends) {  // eLVCReservoirReuse, path.hlsli:727-768
+                f3 hg_t, hg_b;
+                make_orthonormal(unpack_normal_octahedron(0u), hg_t, hg_b);
+                const Xf vt = load_xf(p.view_xf, 0);
+                const float cell_size = hashgrid_cell_size(p.pc, p.views[0], F3(vt.r0.w, vt.r1.w, vt.r2.w), scatter_p);
+                auto jittered = [&]() {
+                  const float phi = rng.next_float() * 2 * DET_PI;
+                  if (!flag(p, STHIP_eHashGridJitter)) return scatter_p;
+                  const float radius = cell_size * rng.next_float();
+                  float sn, cs;
+                  det_sincosf(phi, &sn, &cs);
+                  return scatter_p + (hg_t * cs + hg_b * sn) * radius;
+                };
+                if (p.hg_prev && p.pc.gReservoirSpatialM > 0) {
+                  const f3 at = jittered();
+                  const uint32_t bucket = hashgrid_find(p.lg_checksums, p.pc.gHashGridBucketCount, at, cell_size);
+                  if (bucket != 0xFFFFFFFFu) {
+                    const uint32_t bucket_start = p.lg_indices[bucket], bucket_size = p.lg_counters[bucket];
+                    uint32_t Msum = M;
+                    for (uint32_t k = 0; k < p.pc.gReservoirSpatialM; k++) {
+                      const float4* pr = p.lg_data + 5 * (size_t)(bucket_start + rng.next_uint() % bucket_size);
+                      if (!vertex_fits(pr + 1)) continue;
+                      Msum += __float_as_uint(pr[0].y);
+                      resample(pr + 1);
+                    }
+                    M = Msum;
+                  }
+                }
+                const float W = (r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0.0f;
+                const f3 at = jittered();
+                M = min(M, p.pc.gReservoirMaxM);
+                float4* a = p.lg_appends + 6 * ((size_t)path_index * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1));
+                a[0] = make_float4(at.x, at.y, at.z, cell_size);
+                a[1] = make_float4(total_weight, __uint_as_float(M), __uint_as_float(0u), W);
+                for (int q = 0; q < 4; q++) a[2 + q] = chosen ? chosen[q] : make_float4(0, 0, 0, 0);
+              }
+              contrib = contrib * ((r_target_pdf > 0 && M > 0) ? total_weight / ((float)M * r_target_pdf) : 0.0f);
+            } else if (n) {
+              const float4* lvp = cache + 4 * (size_t)(li0 % n);
+              if (vertex_fits(lvp)) contrib = connect_from_medium(lvp, weight, ray_direction, ray_distance);
+            }
+            contrib = contrib * (float)(p.pc.gMaxDiffuseVertices - 1);
+            contrib = contrib * beta;
+            if (flag(p, STHIP_eDeferShadowRays)) {  // the record takes this vertex's entry (the one connect_light's record would have taken)
+              const f3 c = contrib * weight;
+              if (!all_le0(c)) {
+                const uint32_t entry = slot * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
+                if (!(ray_distance > 1e-6f)) {
+                  p.shadow_result[entry] = make_float4(c.x, c.y, c.z, 0.0f);
+                } else {
+                  const uint32_t k = (uint32_t)atomicAdd(shadow_size, 1ull);
+                  shadow_out[3 * (size_t)k] = make_float4(scatter_p.x, scatter_p.y, scatter_p.z, ray_distance);
+                  shadow_out[3 * (size_t)k + 1] = make_float4(ray_direction.x, ray_direction.y, ray_direction.z, __uint_as_float(slot));
+                  shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, __uint_as_float(medium));
+                  p.shadow_ext[shadow_base + k] = make_float4(__uint_as_float(rng.counter), 1.0f, __uint_as_float(entry), 0.0f);
+                }
+              }
+            } else if (any_gt0(contrib) && weight > 0) {
+              float dir_pdf = 1, nee_pdf = 1;
+              walk_segments += visibility_walk_media(p, rng, scatter_p, ray_direction, ray_distance, medium, contrib, dir_pdf, nee_pdf, column);
+              if (!(all_le0(contrib) || nee_pdf <= 0)) {
+                contrib = contrib / nee_pdf;
+                debug_path_length(contrib, path_length, lvc_length);
+                radiance = radiance + contrib * weight;
+                radiance_dirty = true;
+              }
+            }
+          } else
+          for (uint32_t li = 1; li < p.pc.gMaxDiffuseVertices; li++) {
+            const size_t idx = level * (li - 1) + path_index;
+            if (idx >= per_seed) break;
+            const float4* lvp = p.light_vertices + 4 * ((size_t)seed_index * per_seed + idx);
+            if (!vertex_fits(lvp)) break;
+            f3 ray_direction = F3s(0.0f);
+            float ray_distance = 0, weight = 0;
+            f3 contrib = beta * connect_from_medium(lvp, weight, ray_direction, ray_distance);
             if (all_le0(contrib) || weight <= 0) continue;
             float dir_pdf = 1, nee_pdf = 1;
-            walk_segments += visibility_walk_media(p, rng, scatter_p, ray_direction, ray_distance, medium, contrib, dir_pdf, nee_pdf, p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth);
+            walk_segments += visibility_walk_media(p, rng, scatter_p, ray_direction, ray_distance, medium, contrib, dir_pdf, nee_pdf, column);
             if (all_le0(contrib) || nee_pdf <= 0) continue;
             contrib = contrib / nee_pdf;
-            debug_path_length(contrib, path_length, lv_length);
+            debug_path_length(contrib, path_length, (__float_as_uint(lvp[2].w) >> 16) & 0x7Fu);
             radiance = radiance + contrib * weight;
             radiance_dirty = true;
           }
@@ -2757,6 +2881,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             }
             f3 contrib = F3s(0.0f), ray_origin = F3s(0.0f), ray_direction = F3s(0.0f);
             float weight = 1, ray_distance = 0;
+            uint32_t lvc_length = n ? (__float_as_uint(cache[4 * (size_t)(li0 % n) + 2].w) >> 16) & 0x7Fu : 0u;  // subpath_length() of the vertex connected to (MEDIA: accumulate_contribution's debug half)
             if (flag(p, STHIP_eLVCReservoirs)) {
               float total_weight = 0, r_target_pdf = 0;  // Reservoir, reservoir.h:4-27
               uint32_t M = 0;
@@ -2777,6 +2902,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
                   ray_distance = dist_i;
                   r_target_pdf = target_pdf_i;
                   chosen = lvp;
+                  lvc_length = (__float_as_uint(lvp[2].w) >> 16) & 0x7Fu;
                 }
               };
               for (uint32_t ri = 0; ri < p.pc.gReservoirM; ri++) {
@@ -2838,7 +2964,20 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             if (flag(p, STHIP_eDeferShadowRays)) {
               // the record takes this vertex's gShadowRays slot (the one connect_light wrote, which is why that record was
               // not queued above); trace_shadows skips a record whose contribution is <= 0 (bdpt.hlsl:313)
-              if (!all_le0(c)) {
+              if (MEDIA) {  // the record of a walk through the media (k_shadow_media), in this vertex's own entry — the one connect_light's record would have taken
+                if (!all_le0(c)) {
+                  const uint32_t entry = slot * p.pc.gMaxDiffuseVertices + (diffuse_vertices - 1);
+                  if (!(ray_distance > 1e-6f)) {
+                    p.shadow_result[entry] = make_float4(c.x, c.y, c.z, 0.0f);
+                  } else {
+                    const uint32_t k = (uint32_t)atomicAdd(shadow_size, 1ull);
+                    shadow_out[3 * (size_t)k] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
+                    shadow_out[3 * (size_t)k + 1] = make_float4(ray_direction.x, ray_direction.y, ray_direction.z, __uint_as_float(slot));
+                    shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, __uint_as_float(medium));
+                    p.shadow_ext[shadow_base + k] = make_float4(__uint_as_float(rng.counter), 1.0f, __uint_as_float(entry), 0.0f);
+                  }
+                }
+              } else if (!all_le0(c)) {
                 if (!(ray_distance > 1e-6f)) {
                   float4 acc = p.shadow_sum[slot];
                   p.shadow_sum[slot] = make_float4(acc.x + c.x, acc.y + c.y, acc.z + c.z, 0.0f);
@@ -2850,7 +2989,18 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
                 }
               }
             } else if (any_gt0(contrib) && weight > 0) {
-              queue_connection(c, slot * (p.pc.gMaxDiffuseVertices - 1), ray_origin, ray_direction, ray_distance);
+              if (MEDIA) {  // path.hlsli:791-797: walked and added at once
+                float dir_pdf = 1, nee_pdf = 1;
+                walk_segments += visibility_walk_media(p, rng, ray_origin, ray_direction, ray_distance, medium, contrib, dir_pdf, nee_pdf, p.shade_stack + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * p.bvh.stack_depth);
+                if (!(all_le0(contrib) || nee_pdf <= 0)) {
+                  contrib = contrib / nee_pdf;
+                  debug_path_length(contrib, path_length, lvc_length);
+                  radiance = radiance + contrib * weight;
+                  radiance_dirty = true;
+                }
+              } else {
+                queue_connection(c, slot * (p.pc.gMaxDiffuseVertices - 1), ray_origin, ray_direction, ray_distance);
+              }
             }
           } else
           for (uint32_t li = 1; li < p.pc.gMaxDiffuseVertices; li++) {

@@ -1368,6 +1368,12 @@ def test_trace_contract_with_volumes(renderer):
         ({}, ["connecttolightpaths"], {"maxDiffuseVertices": 3}),
         ({"anisotropy": 0.5, "density": (9.0, 6.0, 3.0)}, ["connecttolightpaths", "connecttoviews", "~defershadowrays"], {"maxDiffuseVertices": 4, "maxPathVertices": 6}),
         ({"density": (12.0, 12.0, 12.0)}, ["connecttolightpaths", "~mis", "~nee"], {"maxDiffuseVertices": 4}),
+        # ... and to the light vertex cache (eLVC): medium vertices staged and compacted like the others, connect_lvc from surfaces
+        # and from medium vertices, the deferred record taking the vertex's shadow-ray slot, reservoirs and their reuse
+        ({}, ["connecttolightpaths", "lightvertexcache"], {"maxDiffuseVertices": 3, "lightPathCount": 6000}),
+        ({"anisotropy": 0.4}, ["connecttolightpaths", "lightvertexcache", "~defershadowrays", "connecttoviews"], {"maxDiffuseVertices": 4, "lightPathCount": 12288}),
+        ({"density": (9.0, 9.0, 9.0)}, ["connecttolightpaths", "lightvertexcache", "lvcreservoirs"], {"maxDiffuseVertices": 3, "lightPathCount": 8000, "reservoirM": 3}),
+        ({}, ["connecttolightpaths", "lightvertexcache", "lvcreservoirs", "lvcreservoirreuse", "~defershadowrays"], {"maxDiffuseVertices": 3, "lightPathCount": 9000, "reservoirM": 2, "reservoirSpatialM": 2, "hashGridBucketCount": 20000}),
         # ... with spatial reuse: seeds 1 and 2 look into the grid the seed before them built, from surface and medium vertices alike
         ({"density": (9.0, 9.0, 9.0)}, ["neereservoirs", "neereservoirreuse"], {"maxDiffuseVertices": 3, "reservoirM": 2, "reservoirSpatialM": 3, "hashGridBucketCount": 20000}),
         ({"anisotropy": 0.3}, ["neereservoirs", "neereservoirreuse", "~jitterhashgridlookups", "~defershadowrays", "presamplelights"], {"maxDiffuseVertices": 4, "reservoirM": 3, "reservoirSpatialM": 2, "hashGridBucketCount": 5000}),
@@ -1413,7 +1419,7 @@ def test_media_limits(renderer):
     sc, cam = scenes.cornell_box(fog=_fog())
     renderer.update(sc)
     frame = camera.Frame(32, 32, cam["fovy"], cam["eye"], cam["target"])
-    for fs in (("connecttolightpaths", "lightvertexcache"),):
+    for fs in (("presamplelights", "coherentsampling"),):
         for f in fs:
             renderer.set_flag(f)
         try:

@@ -7,7 +7,7 @@ is only as good as the claim about upstream it rests on, so each claim is pinned
     of it is stored here: the assertions are about which names are (not) assigned in which line ranges;
   * as arithmetic, where the defect is a formula (thread padding).
 
-The combinations rejected for another reason — media together with the light vertex cache (eLVC), reservoir reuse on a tile shard (a whole-frame structure) — are design limits of this
+The combinations rejected for another reason — media together with eCoherentSampling (walks through volumes break the lockstep of a group), reservoir reuse on a tile shard (a whole-frame structure) — are design limits of this
 library, not upstream defects, and are listed as such in DESIGN.md; nothing here covers them."""
 import os
 import re
