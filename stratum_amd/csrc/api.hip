@@ -1498,13 +1498,11 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   if (ctx->has_volumes && !(scene_flags & STHIP_BDPT_FLAG_HAS_MEDIA)) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: the scene has volume instances but BDPT_FLAG_HAS_MEDIA is not set");
   const bool media = ctx->has_volumes;
   if (media && (sampling_flags & (1u << STHIP_eCoherentSampling))) return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: eCoherentSampling with media (walks through volumes break the lockstep of a workgroup)");
-  if (media) {
-    // with media every visibility ray draws random numbers. An inline NEE ray (no eDeferShadowRays) draws them from the path's
-    // own stream in the middle of a vertex: k_shade walks it itself (visibility_walk_media); so does k_shade_light for every
-    // connect_view of light tracing and for the connections to the stored light vertices or to the light vertex cache.
-  } else {
-    pcn.gMaxNullCollisions = 0;
-  }
+  // With media every visibility ray draws random numbers. A deferred NEE ray carries its own offset (k_shadow_media walks it);
+  // everything else draws from the path's own stream in the middle of a vertex — NEE without eDeferShadowRays, light tracing's
+  // connect_view, the connections to stored light vertices or to the light vertex cache — and k_shade / k_shade_light walk those
+  // themselves (visibility_walk_media).
+  if (!media) pcn.gMaxNullCollisions = 0;
   const uint32_t W = pc->gOutputExtent[0], H = pc->gOutputExtent[1];
   if (W == 0 || H == 0) return fail(ctx, STHIP_ERR_INVALID_ARGUMENT, "render: empty output extent");
   const size_t pixels = (size_t)W * H;

@@ -165,6 +165,7 @@ def run(cases=60, seed=1):
                     oracle_py.OracleScene(sc).render(fr, r.push_constants(fr), r.mSamplingFlags, seed0, seeds, debug_mode=debug_mode, debug_image=debug_start)
                 except RuntimeError:
                     rejected += 1
+                    if os.environ.get("STHIP_FUZZ_VERBOSE"): print("REJECTED (both): %s" % str(e).split("): ", 1)[-1][:110])
                     continue
                 print("MISMATCH (GPU rejects, oracle accepts): %s %s %s: %s" % (kind, flags, args, e))
                 bad += 1
