@@ -14,9 +14,8 @@
 #define STHIP_SHADE_MEDIA(X) \
   X(false, true, false, 1, false, false) X(true, true, false, 1, false, false) X(true, true, false, 1, false, true) X(false, true, false, 2, false, false) X(true, true, false, 2, false, false) \
   X(true, true, false, 2, false, true)
-#define STHIP_SHADE_MEDIA_LT(X) \
-  X(false, true, true, 1, false, false) X(true, true, true, 1, false, false) X(true, true, true, 1, false, true) X(false, true, true, 2, false, false) X(true, true, true, 2, false, false) \
-  X(true, true, true, 2, false, true)
+#define STHIP_SHADE_MEDIA_LT(X) X(false, true, true, 1, false, false) X(true, true, true, 1, false, false) X(true, true, true, 1, false, true)
+#define STHIP_SHADE_MEDIA_LT2(X) X(false, true, true, 2, false, false) X(true, true, true, 2, false, false) X(true, true, true, 2, false, true)
 // Y(COUNT, ALPHA, BOUNDED, TOP, WIDE)
 #define STHIP_TRACE_ROWS(Y, TOP, WIDE) \
   Y(false, false, false, TOP, WIDE) Y(true, false, false, TOP, WIDE) Y(false, true, false, TOP, WIDE) Y(true, true, false, TOP, WIDE) Y(false, false, true, TOP, WIDE) Y(true, false, true, TOP, WIDE) \
@@ -33,5 +32,5 @@
 #define STHIP_LIGHT_DEFINE(T, E, M) template __global__ void k_shade_light<T, E, M>(FrameParams, uint32_t);
 
 #define STHIP_DECLARE_KERNEL_INSTANCES \
-  STHIP_SHADE_PLAIN(STHIP_SHADE_EXTERN) STHIP_SHADE_LT(STHIP_SHADE_EXTERN) STHIP_SHADE_MEDIA(STHIP_SHADE_EXTERN) STHIP_SHADE_MEDIA_LT(STHIP_SHADE_EXTERN) STHIP_TRACE_ALL(STHIP_TRACE_EXTERN) \
+  STHIP_SHADE_PLAIN(STHIP_SHADE_EXTERN) STHIP_SHADE_LT(STHIP_SHADE_EXTERN) STHIP_SHADE_MEDIA(STHIP_SHADE_EXTERN) STHIP_SHADE_MEDIA_LT(STHIP_SHADE_EXTERN) STHIP_SHADE_MEDIA_LT2(STHIP_SHADE_EXTERN) STHIP_TRACE_ALL(STHIP_TRACE_EXTERN) \
       STHIP_SHADE_LIGHT(STHIP_LIGHT_EXTERN)

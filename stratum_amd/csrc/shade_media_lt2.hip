@@ -1,0 +1,10 @@
+// shade_media_lt2.hip — the k_shade instantiations STHIP_SHADE_MEDIA_LT2 lists (kernel_instances.h), as a translation unit of their own
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/sthip.h"
+#include "bvh_build.h"
+#include "kernel_instances.h"
+STHIP_SHADE_MEDIA_LT2(STHIP_SHADE_DEFINE)

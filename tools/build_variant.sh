@@ -12,7 +12,7 @@ if [ -n "$patch" ]; then (cd $d && python3 $patch); fi
 mkdir -p $root/_variants
 # one hipcc process per translation unit (as __graft_entry__.build_product), then the link
 mkdir -p $base/obj
-for f in api.hip shade_plain.hip shade_lt.hip shade_media.hip shade_media_lt.hip trace_kernels.hip lbvh.hip lvc.hip hashgrid.hip wide.hip bvh_build.cpp hdr_writer.cpp; do
+for f in api.hip shade_plain.hip shade_lt.hip shade_media.hip shade_media_lt.hip shade_media_lt2.hip trace_kernels.hip lbvh.hip lvc.hip hashgrid.hip wide.hip bvh_build.cpp hdr_writer.cpp; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-cuda-compat $EXTRA_FLAGS -c -o $base/obj/$f.o $d/$f &
 done
 wait
