@@ -266,6 +266,7 @@ DEV f3 primary_dir(const sthip_ViewData& view, const Xf& t, float fx, float fy, 
 // generate: PathIntegrator ctor (path.hlsli:285-298) + the prologue of sample_visibility
 // (bdpt.hlsl:151-220): one primary ray per owned pixel
 // ---------------------------------------------------------------------------------------------
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) {
   for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.path_count; slot += gridDim.x * blockDim.x) {
     uint32_t px, py;
@@ -318,6 +319,7 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_generate(FrameParams p) 
     if (p.bdpt) p.bdpt[slot] = make_float4(1, 1, 1, fabsf(local_dir.z));  // bdpt.hlsl:172,213-220: path_pdf, path_pdf_rev, dVC, prev_cos_out
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // trace: trace_ray (intersection.hlsli:65-191) for every queued path, trace_visibility_ray for every shadow record.
@@ -1004,6 +1006,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK) k_generate_light(FrameParams p) {
 }
 
 // ray counts of a finished pass: every queued path / shadow record was traced exactly once
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void k_count_rays(FrameParams p) {
   unsigned long long closest = 0, shadow = 0, answered = 0;
   for (uint32_t d = 0; d < p.rounds; d++)
@@ -1016,6 +1019,7 @@ inline __global__ void k_count_rays(FrameParams p) {
   p.counters[CNT_RAYS_ANSWERED] += answered;
   p.counters[CNT_RAYS_SHADOW] += shadow;
 }
+#endif
 
 // One step of trace_visibility_ray with media (intersection.hlsli:192-239), after the closest hit (dt, ip) of the walk's
 // current segment is known: a surface ends the walk with nothing; a volume boundary is crossed — delta tracking that cannot
@@ -2811,7 +2815,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
           // connect_light_vertex, path.hlsli:618-680: the contribution (without beta) of connecting this vertex to the stored
           // light vertex, zero when the connection fails; weight and the visibility ray come out with it
           auto connect_light_vertex = [&](const float4* lvp, float& weight, f3& ray_origin, f3& ray_direction, float& ray_distance) -> f3 {
-            const float4 v0 = lvp[0], v1 = lvp[1], v2 = lvp[2], v3 = lvp[3];
+            const float4 v0 = lvp[0], v2 = lvp[2], v3 = lvp[3];
             const uint32_t pb0 = __float_as_uint(v2.z), pb1 = __float_as_uint(v2.w);
             const uint32_t lv_length = (pb1 >> 16) & 0x7Fu;
             f3 contrib = F3(det_f16tof32(pb0 & 0xFFFFu), det_f16tof32(pb0 >> 16), det_f16tof32(pb1 & 0xFFFFu));
@@ -3099,6 +3103,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
 // ---------------------------------------------------------------------------------------------
 #define CULL_BLOCKS_PER_SEGMENT 64u  // a block gathers what it keeps in LDS and appends it with ONE atomic (a wave-level append would
                                      // put ~25 000 atomics on the eight control lines: 11 ns each, longer than the pass itself)
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_cull_terminal(FrameParams p, uint32_t depth, uint32_t* kept, uint32_t capacity) {
   extern __shared__ uint32_t cull_lds[];  // [0] count, [1] base, [2 ..] up to `capacity` kept slots
   const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
@@ -3136,6 +3141,7 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_cull_terminal(FrameParam
   const uint32_t base = cull_lds[1];
   for (uint32_t k = threadIdx.x; k < count; k += blockDim.x) kept[seg_base + base + k] = cull_lds[2 + k];
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // shadow_media: one step of trace_visibility_ray with media (intersection.hlsli:192-239) for every shadow record of
@@ -3144,6 +3150,7 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_cull_terminal(FrameParam
 // record is queued again for round depth + 1, the end of the ray (or a miss) finishes it: contribution / nee_pdf goes to
 // the record's own entry of shadow_result, which k_resolve sums in the order of trace_shadows (bdpt.hlsl:311-325).
 // ---------------------------------------------------------------------------------------------
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_shadow_media(FrameParams p, uint32_t depth) {
   const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
   const uint32_t n = (uint32_t)queue_ctl(p.qctl, 1, depth, seg)[QCTL_SIZE];
@@ -3184,11 +3191,13 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_shadow_media(FrameParams
     }
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // resolve: gRadiance += c (bdpt.hlsl:325), then the running mean that defines N samples per pixel
 // (temporal_accumulation.hlsl:102-131), and on the last seed the scatter to the output image
 // ---------------------------------------------------------------------------------------------
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, uint32_t first_seed, uint32_t last_seed, uint32_t primary_rays) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // every queued path / shadow record was traced exactly once: ray counts are the queue sizes
@@ -3280,8 +3289,10 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_resolve(FrameParams p, u
     if (last_seed && p.out_radiance) p.out_radiance[p.out_packed ? (size_t)q : (size_t)py * p.pc.gOutputExtent[0] + px] = acc;
   }
 }
+#endif
 
 // the zero fills a pass starts with, as one launch: up to three ranges of 64-bit words
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_clear(unsigned long long* a, uint32_t na, unsigned long long* b, uint32_t nb, unsigned long long* c, uint32_t nc) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nb + nc; i += gridDim.x * blockDim.x) {
     if (i < na)
@@ -3292,11 +3303,13 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_clear(unsigned long long
       c[i - na - nb] = 0ull;
   }
 }
+#endif
 
 // gRayCount[0] = every trace_ray call, [1] = path (closest-hit) rays; intersection.hlsli:66, path.hlsli:1006
 // eCoherentRR: the probes of a round (FrameParams::rr) -> one verdict per 8x4 group. A wave covers 64 consecutive slots = one
 // 8x8 pixel block; its lanes 0-31 (rows 0-3) and 32-63 (rows 4-7) are the two reference workgroups in it, in the
 // workgroup's own thread order (y * 8 + x).
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_rr_reduce(FrameParams p) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u, half = lane >> 5;
@@ -3310,8 +3323,10 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_rr_reduce(FrameParams p)
   const float rnd_first = __shfl(v.y, first, 64);  // WaveReadLaneFirst
   if (slot < p.path_count) p.rr[slot] = make_float4(pm, (mine && pm < 1.0f && rnd_first > pm) ? 1.0f : 0.0f, mine ? 1.0f : 0.0f, 0.0f);
 }
+#endif
 
 // eCoherentSampling: WaveReadLaneFirst over the group's lanes that reached the site (entries (1, own draw) written by the probe)
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_cs_reduce(uint2* values, uint32_t path_count) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u, half = lane >> 5;
@@ -3322,8 +3337,10 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_cs_reduce(uint2* values,
   const uint32_t first_value = (uint32_t)__shfl((int)v.y, first, 64);
   if (slot < path_count) values[slot] = make_uint2(mine ? 1u : 0u, first_value);
 }
+#endif
 
 // ---- hash grid build (hashgrid.h): keys of the compacted appends, and the scatter into the bucket ranges ----
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys(const float4* appends, const uint32_t* count, uint32_t bucket_count, uint2* keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= *count) return;
@@ -3332,7 +3349,9 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys(const float4* ap
   const uint32_t home = hashgrid_bucket_index(xyz(a0), a2.w, bucket_count, checksum);
   keys[i] = make_uint2(home, checksum);
 }
+#endif
 // dest[i] = index into gNEEHashGrid.mData of append i, or 0xFFFFFFFF when its 32 probes found no slot (dropped, hashgrid.hlsli:56-58)
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter(const float4* appends, const uint32_t* count, const uint32_t* dest, float4* data) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= *count) return;
@@ -3343,7 +3362,9 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter(const float4*
   data[3 * (size_t)d + 1] = make_float4(a2.x, a2.y, a2.z, a3.w);  // y.position, bits(y.packed_geometry_normal)
   data[3 * (size_t)d + 2] = make_float4(a3.x, a3.y, a3.z, a1.w);  // y.Le, y.pdfA
 }
+#endif
 
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys_lvc(const float4* appends, const uint32_t* count, uint32_t bucket_count, uint2* keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= *count) return;
@@ -3352,6 +3373,8 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_keys_lvc(const float4
   const uint32_t home = hashgrid_bucket_index(xyz(a0), a0.w, bucket_count, checksum);
   keys[i] = make_uint2(home, checksum);
 }
+#endif
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter_lvc(const float4* appends, const uint32_t* count, const uint32_t* dest, float4* data) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= *count) return;
@@ -3359,11 +3382,14 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_hg_scatter_lvc(const flo
   if (d == 0xFFFFFFFFu) return;
   for (int q = 0; q < 5; q++) data[5 * (size_t)d + q] = appends[6 * (size_t)i + 1 + q];
 }
+#endif
 
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void k_write_ray_count(const unsigned long long* counters, unsigned long long* out) {
   out[0] = counters[CNT_RAYS_CLOSEST] + counters[CNT_RAYS_SHADOW];
   out[1] = counters[CNT_RAYS_CLOSEST] - counters[CNT_CROSSINGS];  // one per trace() call (path.hlsli:1006), however many segments it walked
 }
+#endif
 
 // plain ray batches: the traversal contract on its own (sthip_trace_rays)
 template <bool ANY_HIT, bool COUNT>
@@ -3409,6 +3435,7 @@ DEV bool shard_slot_pixel(uint32_t rank, uint32_t slot, uint32_t shard_count, ui
   p.pc.gOutputExtent[1] = height;
   return slot_to_pixel(p, slot, px, py);
 }
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const uint32_t* packed, size_t rank_stride, uint32_t shard_count, uint32_t slots, uint32_t tile_w, uint32_t tile_h, uint32_t width,
                                                                  uint32_t height, uint32_t words, uint32_t* frame) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3420,12 +3447,14 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_assemble_tiles(const uin
   uint32_t* dst = frame + ((size_t)py * width + px) * words;
   for (uint32_t k = 0; k < words; k++) dst[k] = src[k];
 }
+#endif
 // The other direction (sthip_pack_tiles): a W x H image on one rank -> that rank's tiles in slot order (slots outside the
 // image: zero). What the ranks exchange of the G-buffer outputs, which sthip_render writes as images.
 // BDPTDebugMode eEnvironmentSampleTest / eEnvironmentSamplePDF (bdpt.hlsl:190-205): sample_visibility returns before it
 // traces anything — eight environment samples drawn from the path's stream as spots around the view direction, or the
 // environment's pdf of that direction. Runs behind k_generate (which has made the view ray and loaded / cleared the pixel of
 // the debug image) in place of the rounds; the paths are marked dead, radiance stays 0.
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_debug_environment(FrameParams p) {
   for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.path_count; slot += gridDim.x * blockDim.x) {
     const uint32_t meta = p.meta[slot];
@@ -3462,10 +3491,12 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_debug_environment(FrameP
     p.debug[slot] = dbg;
   }
 }
+#endif
 
 // What shading needs of a leaf triangle's vertices apart from their positions (bvh.h: BvhTriShade), written once per scene
 // upload beside the leaf triangles as they lie in HBM: the triangle says where its index triple is (BvhTri::src_indices /
 // src_vertex), the vertices are read again — so the record holds the floats shading would have gathered (shading_data.hlsli:2-6)
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_fill_tri_shade(const BvhTri* tris, uint32_t n, const uint8_t* is_tri, const sthip_PackedVertexData* vertices, uint32_t vertex_count, const uint8_t* indices,
                                                                 uint64_t indices_bytes, BvhTriShade* out, BvhTriUv* out_uv) {
   for (uint32_t i = blockIdx.x * STHIP_BLOCK + threadIdx.x; i < n; i += gridDim.x * STHIP_BLOCK) {
@@ -3508,9 +3539,11 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_fill_tri_shade(const Bvh
     }
   }
 }
+#endif
 
 // The seed-split replica mode (sthip.h: sthip_radiance_to_sums): a call's output is (mean over its seeds, their number); what a
 // sum-reduce over replicas can add up is (sum over its seeds, their number). Back: mean = sum / number, correctly rounded.
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_radiance_sums(float4* image, size_t n, uint32_t to_sums) {
   for (size_t i = blockIdx.x * (size_t)STHIP_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * STHIP_BLOCK) {
     float4 v = image[i];
@@ -3526,7 +3559,9 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_radiance_sums(float4* im
     image[i] = v;
   }
 }
+#endif
 
+#ifndef STHIP_TEMPLATE_INSTANCES_ONLY
 inline __global__ void __launch_bounds__(STHIP_BLOCK) k_pack_tiles(const uint32_t* image, uint32_t rank, uint32_t shard_count, uint32_t slots, uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height,
                                                              uint32_t words, uint32_t* packed) {
   const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3537,3 +3572,4 @@ inline __global__ void __launch_bounds__(STHIP_BLOCK) k_pack_tiles(const uint32_
   const uint32_t* src = image + ((size_t)py * width + px) * words;
   for (uint32_t k = 0; k < words; k++) dst[k] = inside ? src[k] : 0u;
 }
+#endif

@@ -1,4 +1,5 @@
 // shade_lt.hip — the k_shade instantiations STHIP_SHADE_LT lists (kernel_instances.h), as a translation unit of their own
+#define STHIP_TEMPLATE_INSTANCES_ONLY  // the non-template kernels of kernels.h are compiled once, in api.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>

@@ -1,4 +1,5 @@
 // shade_media_lt2.hip — the k_shade instantiations STHIP_SHADE_MEDIA_LT2 lists (kernel_instances.h), as a translation unit of their own
+#define STHIP_TEMPLATE_INSTANCES_ONLY  // the non-template kernels of kernels.h are compiled once, in api.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>

@@ -1,4 +1,5 @@
 // trace_kernels.hip — every k_trace instantiation and the light pass's k_shade_light (kernel_instances.h), as a translation unit of their own
+#define STHIP_TEMPLATE_INSTANCES_ONLY  // the non-template kernels of kernels.h are compiled once, in api.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
