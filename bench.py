@@ -101,6 +101,7 @@ def parse_args():
     ap.add_argument("--radiance-only", action="store_true", help="do not write the G-buffer AOVs (not the headline configuration)")
     ap.add_argument("--bdpt-flag", action="append", default=[], help="as the reference's --bdptFlag (e.g. connecttolightpaths, ~nee); not the headline configuration")
     ap.add_argument("--max-diffuse-vertices", type=int, default=None)
+    ap.add_argument("--light-path-count", type=int, default=None, help="as the reference's --lightPathCount: light paths behind the light vertex cache (lightvertexcache); 64 upstream")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="sthip_set_option before the scene upload (e.g. wide_bvh=3: the 8-wide walk); recorded in config.options; not the headline configuration")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): a step renders N seeds of the frame on N GPUs (per-GPU work fixed); strong: a step renders --strong-seeds seeds whatever N (total work fixed)")
@@ -340,9 +341,16 @@ def main():
     W, H = args.width, args.height
     sc, cam = scenes.SCENES[args.scene]()
     frame = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+    from stratum_amd.bdpt import known_flag
+
+    unknown = [f for f in args.bdpt_flag if not known_flag(f)]
+    if unknown:  # (the reference ignores them silently: a measurement must not)
+        raise SystemExit("bench.py: unknown --bdpt-flag %s" % unknown)
     bargs = {"bdptFlag": args.bdpt_flag}
     if args.max_diffuse_vertices is not None:
         bargs["maxDiffuseVertices"] = args.max_diffuse_vertices
+    if args.light_path_count is not None:
+        bargs["lightPathCount"] = args.light_path_count
     r = BDPT(device=local_rank, args=bargs)
     options = {}
     for kv in args.option:

@@ -52,6 +52,11 @@ def _flag_key(name):
 _FLAG_BY_KEY = {_flag_key(n): i for i, n in enumerate(wire.FLAG_NAMES)}
 
 
+def known_flag(arg):
+    """Whether --bdptFlag would act on `arg` (BDPT.cpp:94-127 ignores a name it does not know; a tool that measures may not)."""
+    return bool(arg) and arg.lstrip("~!").lower() in _FLAG_BY_KEY
+
+
 class BDPT:
     def __init__(self, device=0, args=None):
         self._lib = lib()
@@ -63,6 +68,7 @@ class BDPT:
         self.device = device
         self.mSamplingFlags = wire.DEFAULT_SAMPLING_FLAGS
         self.mPushConstants = wire.default_push_constants(0, 0, 0)
+        self.mPushConstants.gLightPathCount = 64  # BDPT.cpp:70: the size of the light vertex cache unless --lightPathCount says otherwise (without eLVC: one path per pixel, :469-470)
         self._scene = None
         self._prev_result = None
         args = args or {}

@@ -1823,8 +1823,6 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   p.out_debug = nullptr;
   p.shadow_debug = nullptr;
   if (debug_mode) {
-    if (debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && connect_paths && pc->gDebugLightPathLength >= 2)
-      return fail(ctx, STHIP_ERR_UNSUPPORTED, "render: ePathLengthContribution of a light-subpath connection (gDebugLightPathLength >= 2) is not built");
     if (dev) {
       p.out_debug = reinterpret_cast<float4*>(out->gDebugImage);
     } else {  // in / out: what the caller's image holds goes up first
@@ -1835,7 +1833,11 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
     // inline shadow rays add to the debug image only where they are unoccluded: they are traced once more, with what they add
     const bool inline_adds = (debug_mode == STHIP_DEBUG_RESERVOIR_WEIGHT || (debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && pc->gDebugLightPathLength == 1)) &&
                              (sampling_flags & (1u << STHIP_eNEE)) && !(sampling_flags & (1u << STHIP_eDeferShadowRays)) && !media;
-    if (inline_adds) {
+    // so do light-subpath connections (accumulate_contribution with the light vertex's length, path.hlsli:797,820); connect_lvc's
+    // deferred record (:781-789) adds to the radiance only
+    const bool connection_adds = debug_mode == STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION && pc->gDebugLightPathLength >= 2 && connect_paths && !media &&
+                                 !((sampling_flags & (1u << STHIP_eLVC)) && (sampling_flags & (1u << STHIP_eDeferShadowRays)));
+    if (inline_adds || connection_adds) {
       HIP_TRY(ctx, ctx->shadow_debug.ensure(ctx->shadow_rays.n));
       p.shadow_debug = ctx->shadow_debug.p;
     }
@@ -1997,6 +1999,7 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
           FrameParams q = p;
           q.shadow_rays = p.shadow_debug;
           q.radiance = p.debug;
+          q.shadow_sum = p.debug;  // (a connection's debug half exists while NEE's rays are deferred: finish_ray's target either way)
           q.qctl = p.qctl + (size_t)64 * QUEUE_SEGMENTS * QCTL_STRIDE;  // its "shadow queues" (kind 1) are the debug queues (kind 2) k_shade filled
           const uint32_t none = TRACE_NONE;
           void* qargs[3] = {(void*)&q, (void*)&none, (void*)&ds};

@@ -2867,6 +2867,20 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
             shadow_out[3 * (size_t)k + 1] = make_float4(ray_direction.x, ray_direction.y, ray_direction.z, __uint_as_float(0x40000000u | entry));
             shadow_out[3 * (size_t)k + 2] = make_float4(c.x, c.y, c.z, 0.0f);
           };
+          // accumulate_contribution's debug half for a connection (path.hlsli:302-303): the UNWEIGHTED contribution of the one
+          // (view, light) length pair asked for, where the connection is visible — the same ray once more, in the debug queue
+          auto debug_connection = [&](f3 dc, uint32_t light_length, f3 ray_origin, f3 ray_direction, float ray_distance) {
+            if (!(debug_is(STHIP_DEBUG_PATH_LENGTH_CONTRIBUTION) && p.pc.gDebugLightPathLength == light_length && path_length == p.pc.gDebugViewPathLength)) return;
+            if (!(ray_distance > 1e-6f)) {
+              debug_add(dc);
+            } else if (p.shadow_debug) {
+              const uint32_t k2 = (uint32_t)atomicAdd(&queue_ctl(p.qctl, 2, depth, seg)[QCTL_SIZE], 1ull);
+              float4* dbg_out = p.shadow_debug + 3 * shadow_base;
+              dbg_out[3 * (size_t)k2] = make_float4(ray_origin.x, ray_origin.y, ray_origin.z, ray_distance);
+              dbg_out[3 * (size_t)k2 + 1] = make_float4(ray_direction.x, ray_direction.y, ray_direction.z, __uint_as_float(slot));
+              dbg_out[3 * (size_t)k2 + 2] = make_float4(dc.x, dc.y, dc.z, 0.0f);
+            }
+          };
           if (flag(p, STHIP_eLVC)) {
             // connect_lvc, path.hlsli:683-800 (without the reuse through the hash grid): ONE vertex of the cache, picked
             // uniformly or, with eLVCReservoirs, by resampled importance sampling over gReservoirM uniform picks. An empty
@@ -3004,6 +3018,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
                 }
               } else {
                 queue_connection(c, slot * (p.pc.gMaxDiffuseVertices - 1), ray_origin, ray_direction, ray_distance);
+                if (DEBUG) debug_connection(contrib, lvc_length, ray_origin, ray_direction, ray_distance);
               }
             }
           } else
@@ -3027,6 +3042,7 @@ __global__ void __launch_bounds__(STHIP_BLOCK, (LT || (EXT && !PROBE)) ? 2 : SHA
               continue;
             }
             queue_connection(contrib * weight, slot * (p.pc.gMaxDiffuseVertices - 1) + (li - 1), ray_origin, ray_direction, ray_distance);
+            if (DEBUG) debug_connection(contrib, (__float_as_uint(lvp[2].w) >> 16) & 0x7Fu, ray_origin, ray_direction, ray_distance);
           }
         }
       }

@@ -1117,7 +1117,7 @@ def test_hash_grid_build_paths_agree():
     for flags, args in (
         (["neereservoirs", "neereservoirreuse"], {"reservoirM": 2, "hashGridBucketCount": 40}),
         (["neereservoirs", "neereservoirreuse"], {"reservoirM": 4}),
-        (["connecttolightpaths", "lvc", "lvcreservoirs", "lvcreservoirreuse"], {"lightPathCount": 3000, "hashGridBucketCount": 500}),
+        (["connecttolightpaths", "lightvertexcache", "lvcreservoirs", "lvcreservoirreuse"], {"lightPathCount": 3000, "hashGridBucketCount": 500}),
     ):
         out = []
         for serial in (0, 1):
@@ -1987,6 +1987,14 @@ def test_debug_modes_that_accumulate():
     for mode, vl in ((W.DEBUG_LIGHT_TRACE_CONTRIBUTION, 0), (W.DEBUG_PATH_LENGTH_CONTRIBUTION, 1)):
         got = _debug_case(sc, cam, mode, flags=["connecttoviews"], args={"maxPathVertices": 2}, view_length=vl, light_length=1, start=start)
         assert not got["debug"][..., :3].any() and (got["debug"][..., 3] == 1).all()
+    # light-subpath connections (accumulate_contribution with the light vertex's length, path.hlsli:797,820): the (view, light)
+    # pairs with a light length of 2 and more, from the subpath of the same index or one vertex of the cache; connect_lvc's
+    # deferred record adds to the radiance only (:781-789)
+    for flags, adds in ((["connecttolightpaths"], True), (["connecttolightpaths", "lightvertexcache", "~defershadowrays"], True), (["connecttolightpaths", "lightvertexcache"], False),
+                        (["connecttolightpaths", "lightvertexcache", "lvcreservoirs", "~defershadowrays"], True)):
+        for vl, ll in ((2, 2), (2, 3), (3, 2)):
+            got = _debug_case(sc, cam, W.DEBUG_PATH_LENGTH_CONTRIBUTION, flags=flags, view_length=vl, light_length=ll, start=start, args={"maxDiffuseVertices": 4, "maxPathVertices": 6, "lightPathCount": 5000})
+            assert (got["debug"][..., :3].sum() > 0) == adds, (flags, vl, ll)
     # several seeds of a call are upstream's successive frames: the same image as call after call
     a = _debug_case(sc, cam, W.DEBUG_RESERVOIR_WEIGHT, flags=["neereservoirs", "~defershadowrays"], seeds=3, start=start)
     b = start

@@ -156,7 +156,7 @@ def run(cases=60, seed=1):
             debug_start = None
             if debug_mode:
                 r.mPushConstants.gDebugViewPathLength = 1 + (seed0 >> 10) % 3
-                r.mPushConstants.gDebugLightPathLength = (seed0 >> 12) & 1
+                r.mPushConstants.gDebugLightPathLength = (seed0 >> 12) & 3
                 debug_start = np.random.default_rng(seed0).random((fr.height, fr.width, 4), dtype=np.float32)
             try:
                 got = r.render(fr, seed0, seeds, debug_mode=debug_mode, debug_image=debug_start)

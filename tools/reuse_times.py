@@ -10,9 +10,9 @@ sc, cam = scenes.atrium()
 fr = camera.Frame(1920, 1080, cam["fovy"], cam["eye"], cam["target"])
 buf = torch.zeros((1080, 1920, 4), device="cuda")
 out = {"radiance": buf.data_ptr()}
-for flags in (["neereservoirs"], ["neereservoirs", "neereservoirreuse"], ["connecttolightpaths", "lvc", "lvcreservoirs"], ["connecttolightpaths", "lvc", "lvcreservoirs", "lvcreservoirreuse"]):
+for flags in (["neereservoirs"], ["neereservoirs", "neereservoirreuse"], ["connecttolightpaths", "lightvertexcache", "lvcreservoirs"], ["connecttolightpaths", "lightvertexcache", "lvcreservoirs", "lvcreservoirreuse"]):
     for serial in ((0, 1) if any("reuse" in f for f in flags) else (0,)):
-        r = BDPT(0, args={"bdptFlag": flags})
+        r = BDPT(0, args={"bdptFlag": flags, "lightPathCount": 1920 * 1080})  # (the cache as large as the light paths of a frame without it)
         r.set_option("hashgrid_serial", serial)
         r.update(sc)
         r.render(fr, 0, 2, device_outputs=out)

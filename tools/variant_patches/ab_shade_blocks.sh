@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/variant_patches/ab_shade_blocks.sh — the extended k_shade instantiations at 2 instead of 3 blocks per CU
 # (variants ext2 / lt2, tools/variant_patches/shade_blocks_*.py) on the bench scene with the estimators that use them
-for flags in "--bdpt-flag neereservoirs" "--bdpt-flag connecttoviews" "--bdpt-flag connecttolightpaths" "--bdpt-flag connecttolightpaths --bdpt-flag lvc"; do
+for flags in "--bdpt-flag neereservoirs" "--bdpt-flag connecttoviews" "--bdpt-flag connecttolightpaths" "--bdpt-flag connecttolightpaths --bdpt-flag lightvertexcache"; do
   for round in 1 2; do
     for v in base ext2 lt2; do
       line=$(STHIP_LIB=_variants/$v.so python3 bench.py --steps 10 --warmup 2 --reps 3 --no-cpu-baseline --no-ceilings --no-other-workloads --sustained-seconds 0 --no-last-ray-filter $flags 2>/dev/null | grep '"metric"')
