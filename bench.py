@@ -252,6 +252,50 @@ def config_record(device, sc, cam, W, H, seeds, what, shard_of=None):
         r.close()
 
 
+def host_outputs_record(device, sc, cam, W, H):
+    """The headline step through HOST output pointers (the boundary's other form, include/sthip.h `device_ptrs` = 0): the frame
+    and its AOVs come back over PCIe inside sthip_render, which synchronises before it returns. Never `value`: the rate a
+    caller without device buffers sees, one sample per pixel per call, median of 7 calls after a warm-up."""
+    from stratum_amd import camera
+    from stratum_amd.bdpt import BDPT
+
+    r = BDPT(device=device)
+    try:
+        r.update(sc)
+        r.set_option("answer_last_rays", 0)
+        fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+        import ctypes as C
+
+        from stratum_amd import wire
+
+        # the caller's buffers, allocated and touched once (pageable memory, as a plugin host's would be), through the C ABI itself
+        bufs = {"radiance": np.ones((H, W, 4), np.float32), "albedo": np.ones((H, W, 4), np.float32), "visibility": np.ones((H, W), wire.VisibilityInfo),
+                "depth": np.ones((H, W), wire.DepthInfo), "prev_uv": np.ones((H, W, 2), np.float32), "ray_count": np.zeros(2, np.uint64)}
+        pc, fd = r.push_constants(fr), fr.desc()
+        out = {}
+        for aovs in (True, False):
+            o = wire.Outputs()
+            o.device_ptrs = 0
+            o.radiance_layout = wire.LAYOUT_IMAGE
+            o.gRadiance = wire.ptr(bufs["radiance"])
+            o.gRayCount = wire.ptr(bufs["ray_count"])
+            if aovs:
+                o.gAlbedo, o.gVisibility, o.gDepth, o.gPrevUVs = wire.ptr(bufs["albedo"]), wire.ptr(bufs["visibility"]), wire.ptr(bufs["depth"]), wire.ptr(bufs["prev_uv"])
+            ts = []
+            for i in range(8):
+                t = time.perf_counter()
+                r._check(r._lib.sthip_render(r._h, C.byref(pc), r.mSamplingFlags, sc.scene_flags, C.byref(fd), i, 1, C.byref(o)), "sthip_render")
+                ts.append(time.perf_counter() - t)
+            dt = float(np.median(ts[1:]))
+            rays = int(bufs["ray_count"][0])
+            nbytes = sum(int(v.nbytes) for k, v in bufs.items() if aovs or k in ("radiance", "ray_count"))
+            out["radiance_and_aovs" if aovs else "radiance_only"] = {"value": round(rays / dt / 1e6, 2), "unit": "Mray/s", "ms_per_call": round(dt * 1e3, 3), "bytes_read_back": nbytes}
+        out["workload"] = "the headline step (atrium %dx%d, one sample per pixel per call, default flags, every ray traced) with HOST output pointers: PCIe read-back and the synchronisation inside the call" % (W, H)
+        return out
+    finally:
+        r.close()
+
+
 def scene_build_record(sc, device):
     """Acceleration-structure build and update times of the bench scene (outside every timed region): both builders, a
     transforms-only update, and the rebuild the library runs itself when an instance of the merged world-space mesh has moved
@@ -850,6 +894,7 @@ def main():
                 "atrium_256spp_share_of_one_of_8_ranks": config_record(local_rank, sc, cam, W, H, 256, "BASELINE.json configs[3], the work of ONE of its 8 ranks on this GPU: atrium 1920x1080, 256 samples/pixel, the 64x32 tiles t % 8 == 0, packed-tile output, radiance only, every ray traced", shard_of=8),
                 "forest": forest_record(local_rank),
                 "scene_build": scene_build_record(sc, local_rank),
+                "host_outputs": host_outputs_record(local_rank, sc, cam, W, H),
             }
         flags_text = "default BDPT flags" if not (args.bdpt_flag or args.max_diffuse_vertices) else "flags %s maxDiffuseVertices %s" % (args.bdpt_flag, args.max_diffuse_vertices)
         result = {
