@@ -112,7 +112,14 @@ def parse_args():
     ap.add_argument("--sustained-seconds", type=float, default=3.0, help="after the timed repetitions: one pass of back-to-back steps (the same seeds cycling) at least this long, reported as `sustained` beside `value` (0: skip)")
     ap.add_argument("--dump-frame", default=None, help="rank 0 saves the outputs of one more step (seed block 0) as <path>.npz after the measurements: what tests compare between N = 1 and N > 1")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the config-5 forest sub-record (other_workloads.forest; N = 1 only)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    os.environ.setdefault("STHIP_STRICT_FLAGS", "1")
+    from stratum_amd.bdpt import known_flag
+
+    unknown = [f for f in args.bdpt_flag if not known_flag(f)]
+    if unknown:  # (the reference ignores an unknown name silently, BDPT.cpp:94-127: a measurement must not)
+        ap.error("unknown --bdpt-flag %s" % unknown)
+    return args
 
 
 def spawn_ranks(n):
@@ -385,11 +392,6 @@ def main():
     W, H = args.width, args.height
     sc, cam = scenes.SCENES[args.scene]()
     frame = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
-    from stratum_amd.bdpt import known_flag
-
-    unknown = [f for f in args.bdpt_flag if not known_flag(f)]
-    if unknown:  # (the reference ignores them silently: a measurement must not)
-        raise SystemExit("bench.py: unknown --bdpt-flag %s" % unknown)
     bargs = {"bdptFlag": args.bdpt_flag}
     if args.max_diffuse_vertices is not None:
         bargs["maxDiffuseVertices"] = args.max_diffuse_vertices

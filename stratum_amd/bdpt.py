@@ -9,6 +9,7 @@ BDPT.cpp:78-127); `update()` is where the reference binds the scene descriptors
 dispatch sequence (BDPT.cpp:423-838) by one sthip_render call.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -101,6 +102,8 @@ class BDPT:
             on, arg = False, arg[1:]
         bit = _FLAG_BY_KEY.get(arg.lower())
         if bit is None:
+            if os.environ.get("STHIP_STRICT_FLAGS"):  # the measuring tools and bench.py set it: a misspelt flag is an error there
+                raise ValueError("unknown --bdptFlag name %r" % (arg,))
             return  # the reference silently ignores unknown names
         if on:
             self.mSamplingFlags |= 1 << bit

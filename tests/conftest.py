@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "unknown_flags: the test passes flag names BDPT does not know, on purpose")
 
 
 @pytest.fixture(scope="session")
@@ -26,3 +27,20 @@ def cornell():
     from stratum_amd import scenes
 
     return scenes.cornell_box()
+
+
+@pytest.fixture(autouse=True)
+def _every_flag_name_a_test_passes_is_a_real_one(monkeypatch, request):
+    """BDPT.set_flag ignores a name it does not know, as upstream does (BDPT.cpp:94-127) — so a test that misspells a flag would
+    pass while testing something else. Tests opt out with @pytest.mark.unknown_flags (the one that pins the ignoring)."""
+    if request.node.get_closest_marker("unknown_flags"):
+        return
+    from stratum_amd import bdpt
+
+    plain = bdpt.BDPT.set_flag
+
+    def checked(self, arg):
+        assert not arg or bdpt.known_flag(arg), "unknown --bdptFlag name in a test: %r" % (arg,)
+        return plain(self, arg)
+
+    monkeypatch.setattr(bdpt.BDPT, "set_flag", checked)

@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("STHIP_STRICT_FLAGS", "1")  # a misspelt --bdptFlag name is an error in a tool that measures (the mirror ignores it, as upstream does)
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 from stratum_amd import camera, scenes

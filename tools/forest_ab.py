@@ -2,6 +2,7 @@
 """Config 5 (forest, 3840x2160 x 16 seeds, 8 / 10 / 4 vertices, ~coherentrr) under context options, e.g. wide_bvh=1,3:
 python tools/forest_ab.py wide_bvh=1,3 [other=value ...]  (GPU box)"""
 import os, sys, time
+os.environ.setdefault("STHIP_STRICT_FLAGS", "1")  # a misspelt --bdptFlag name is an error in a tool that measures (the mirror ignores it, as upstream does)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from stratum_amd import camera, scenes

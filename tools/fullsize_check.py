@@ -1,5 +1,6 @@
 """Full-size runs of the non-default paths (GPU box): they complete, stay finite, and report their rates."""
 import os, sys, time
+os.environ.setdefault("STHIP_STRICT_FLAGS", "1")  # a misspelt --bdptFlag name is an error in a tool that measures (the mirror ignores it, as upstream does)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from stratum_amd import camera, scenes

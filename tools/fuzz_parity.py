@@ -1,6 +1,7 @@
 """Randomised differential test (GPU box): random scenes x supported flag combinations x limits x frame sizes, the HIP
 path against the oracle, bit for bit. usage: tools/fuzz_parity.py [cases] [seed]. Prints every mismatch and exits non-zero."""
 import os, sys, time
+os.environ.setdefault("STHIP_STRICT_FLAGS", "1")  # a misspelt --bdptFlag name is an error in a tool that measures (the mirror ignores it, as upstream does)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -1,5 +1,7 @@
 """GPU box: "max_paths_in_flight" (how many seeds of the owned pixels are traced together) on the multi-seed configurations:
 atrium 1080p x 8 seeds and the forest at 4K x 4 seeds with config 5's budgets. usage: python tools/in_flight_sweep.py"""
+import os
+os.environ.setdefault("STHIP_STRICT_FLAGS", "1")  # a misspelt --bdptFlag name is an error in a tool that measures (the mirror ignores it, as upstream does)
 import sys, time
 
 import numpy as np

@@ -2,6 +2,7 @@
 """GPU box: one sthip option swept on the bench frame — per-kernel ms of a step (time_kernels) and the frame's bytes against the first value.
 usage: [STHIP_SWEEP_FLAGS=flag,flag] tools/option_sweep.py <scene> <option> <value> [value ...] [-- other=value ...]"""
 import os
+os.environ.setdefault("STHIP_STRICT_FLAGS", "1")  # a misspelt --bdptFlag name is an error in a tool that measures (the mirror ignores it, as upstream does)
 import sys
 
 import numpy as np

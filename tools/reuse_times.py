@@ -1,6 +1,7 @@
 """The reservoir-reuse estimators with their hash grids built between the seeds of a call (GPU box): ms per seed of an 8-seed
 call on the bench scene at 1080p, with the grids built by the parallel device path and by its one-thread serial path."""
 import os, sys, time
+os.environ.setdefault("STHIP_STRICT_FLAGS", "1")  # a misspelt --bdptFlag name is an error in a tool that measures (the mirror ignores it, as upstream does)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stratum_amd import camera, scenes
