@@ -35,7 +35,10 @@ def _every_flag_name_a_test_passes_is_a_real_one(monkeypatch, request):
     pass while testing something else. Tests opt out with @pytest.mark.unknown_flags (the one that pins the ignoring)."""
     if request.node.get_closest_marker("unknown_flags"):
         return
-    from stratum_amd import bdpt
+    try:
+        from stratum_amd import bdpt
+    except Exception:  # (a tree where the package does not import has its own failing tests to say so)
+        return
 
     plain = bdpt.BDPT.set_flag
 
