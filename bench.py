@@ -271,27 +271,13 @@ def host_outputs_record(device, sc, cam, W, H):
         r.update(sc)
         r.set_option("answer_last_rays", 0)
         fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
-        import ctypes as C
-
-        from stratum_amd import wire
-
-        # the caller's buffers, allocated and touched once (pageable memory, as a plugin host's would be), through the C ABI itself
-        bufs = {"radiance": np.ones((H, W, 4), np.float32), "albedo": np.ones((H, W, 4), np.float32), "visibility": np.ones((H, W), wire.VisibilityInfo),
-                "depth": np.ones((H, W), wire.DepthInfo), "prev_uv": np.ones((H, W, 2), np.float32), "ray_count": np.zeros(2, np.uint64)}
-        pc, fd = r.push_constants(fr), fr.desc()
+        bufs = r.render(fr, 0, 1)  # the caller's buffers, allocated and touched once (pageable memory, as a plugin host's would be)
         out = {}
         for aovs in (True, False):
-            o = wire.Outputs()
-            o.device_ptrs = 0
-            o.radiance_layout = wire.LAYOUT_IMAGE
-            o.gRadiance = wire.ptr(bufs["radiance"])
-            o.gRayCount = wire.ptr(bufs["ray_count"])
-            if aovs:
-                o.gAlbedo, o.gVisibility, o.gDepth, o.gPrevUVs = wire.ptr(bufs["albedo"]), wire.ptr(bufs["visibility"]), wire.ptr(bufs["depth"]), wire.ptr(bufs["prev_uv"])
             ts = []
             for i in range(8):
                 t = time.perf_counter()
-                r._check(r._lib.sthip_render(r._h, C.byref(pc), r.mSamplingFlags, sc.scene_flags, C.byref(fd), i, 1, C.byref(o)), "sthip_render")
+                r.render(fr, i, 1, aovs=aovs, host_outputs=bufs)
                 ts.append(time.perf_counter() - t)
             dt = float(np.median(ts[1:]))
             rays = int(bufs["ray_count"][0])

@@ -178,8 +178,9 @@ class BDPT:
         return pc
 
     # ---- BDPT::render ----
-    def render(self, frame, seed_begin=0, seed_count=1, aovs=True, device_outputs=None, packed_tiles=False, debug_mode=0, debug_image=None):
-        """Host outputs by default (dict of numpy arrays). `device_outputs` = dict of raw device pointers
+    def render(self, frame, seed_begin=0, seed_count=1, aovs=True, device_outputs=None, packed_tiles=False, debug_mode=0, debug_image=None, host_outputs=None):
+        """Host outputs by default (dict of numpy arrays; `host_outputs` = such a dict from an earlier call: its arrays are
+        written in place instead of fresh ones — a caller's own buffers). `device_outputs` = dict of raw device pointers
         {"radiance": ptr, ["albedo", "visibility", "depth", "prev_uv", "ray_count"]} renders in place on the
         GPU without synchronising. packed_tiles: "radiance" holds only this shard's tiles in slot order
         (shard_slot_count() float4 entries) — the form ranks exchange, see assemble_tiles."""
@@ -205,7 +206,12 @@ class BDPT:
                 o.gDebugImage = device_outputs["debug"]
         else:
             W, H = frame.width, frame.height
-            out = {"radiance": np.zeros((self.shard_slot_count(frame), 4) if packed_tiles else (H, W, 4), np.float32), "ray_count": np.zeros(2, np.uint64)}
+            if host_outputs is None:
+                out = {"radiance": np.zeros((self.shard_slot_count(frame), 4) if packed_tiles else (H, W, 4), np.float32), "ray_count": np.zeros(2, np.uint64)}
+            else:
+                out = {k: host_outputs[k] for k in ("radiance", "ray_count")}
+                if out["radiance"].nbytes != (self.shard_slot_count(frame) if packed_tiles else H * W) * 16 or out["radiance"].dtype != np.float32 or not out["radiance"].flags["C_CONTIGUOUS"]:
+                    raise ValueError("host_outputs['radiance'] does not fit the frame")
             o.device_ptrs = 0
             o.gRadiance = wire.ptr(out["radiance"])
             o.gRayCount = wire.ptr(out["ray_count"])
@@ -213,11 +219,18 @@ class BDPT:
                 out["debug"] = np.ascontiguousarray(debug_image, np.float32).copy() if debug_image is not None else np.zeros((H, W, 4), np.float32)
                 o.debug_mode = debug_mode
                 o.gDebugImage = wire.ptr(out["debug"])
-            if aovs:
+            if aovs and host_outputs is not None:
+                for k, dtype, per_pixel in (("albedo", np.float32, 16), ("visibility", wire.VisibilityInfo, None), ("depth", wire.DepthInfo, None), ("prev_uv", np.float32, 8)):
+                    a = host_outputs[k]
+                    if a.dtype != dtype or a.nbytes != H * W * (per_pixel or a.dtype.itemsize) or not a.flags["C_CONTIGUOUS"]:
+                        raise ValueError("host_outputs[%r] does not fit the frame" % k)
+                    out[k] = a
+            elif aovs:
                 out["albedo"] = np.zeros((H, W, 4), np.float32)
                 out["visibility"] = np.zeros((H, W), wire.VisibilityInfo)
                 out["depth"] = np.zeros((H, W), wire.DepthInfo)
                 out["prev_uv"] = np.zeros((H, W, 2), np.float32)
+            if aovs:
                 o.gAlbedo = wire.ptr(out["albedo"])
                 o.gVisibility = wire.ptr(out["visibility"])
                 o.gDepth = wire.ptr(out["depth"])

@@ -2040,3 +2040,29 @@ def test_bounded_wide8_walk_with_recycled_device_memory():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "130", "302"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "1 cases compared, 0 rejected on both sides, 0 mismatches" in out.stdout
+
+
+@pytest.mark.gpu
+def test_host_outputs_written_in_place():
+    """A caller's own host buffers (`host_outputs`: the dict an earlier call returned) are filled in place with what a call with
+    fresh buffers returns; a buffer of the wrong size is refused before anything is launched."""
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = scenes.cornell_box()
+    r = BDPT(device=0)
+    try:
+        r.update(sc)
+        frame = camera.Frame(96, 64, cam["fovy"], cam["eye"], cam["target"])
+        fresh = r.render(frame, 3, 2)
+        bufs = r.render(frame, 0, 1)
+        keep = {k: v for k, v in bufs.items()}
+        again = r.render(frame, 3, 2, host_outputs=bufs)
+        for k in ("radiance", "albedo", "visibility", "depth", "prev_uv", "ray_count"):
+            assert again[k] is keep[k], k
+            assert again[k].tobytes() == fresh[k].tobytes(), k
+        only = r.render(frame, 4, 1, aovs=False, host_outputs=bufs)
+        assert set(only) == {"radiance", "ray_count"} and only["radiance"] is keep["radiance"]
+        with pytest.raises(ValueError):
+            r.render(camera.Frame(100, 64, cam["fovy"], cam["eye"], cam["target"]), 0, 1, host_outputs=bufs)
+    finally:
+        r.close()
