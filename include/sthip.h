@@ -337,7 +337,12 @@ int sthip_measure_ceiling(sthip_ctx* ctx, uint32_t kind, double* gbytes_per_s);
  * compressed form (80-byte nodes whose children are addressed by a base and a mask, 64-bit group stack) for host-built
  * trees, the 4-wide form for the others; not with "treetop" or "embed_leaves"), "tri_min_lanes" (1..64, default 1: the
  * 8-wide walk's leaf phase goes on while at least this many lanes hold a triangle), "hashgrid_serial" (0/1: build the reservoir-reuse hash grids with the one-thread serial probe
- * sequence instead of the parallel device build: the same grids, for tests), "cull_terminal" (default 1: in a round where the
+ * sequence instead of the parallel device build: the same grids, for tests), "reuse_grids_persist" (default 0: every call starts a
+ * new chain, its first seed finds no grid — upstream's first frame, gReservoirSpatialM = 0, BDPT.cpp:482-483. 1: the grids the
+ * last seed of a call leaves are what the first seed of the NEXT call looks into, as long as that call asks for the same reuse
+ * flags, gHashGridBucketCount, extent and gMaxDiffuseVertices — a host that renders one frame per call; N calls of one seed are
+ * then one call of N seeds. Setting the option, to either value, also drops the kept grids (upstream: a frame whose camera moved
+ * without reprojection), and so does sthip_scene_upload), "cull_terminal" (default 1: in a round where the
  * path or diffuse budget can end, only the paths that still have something to do reach the shading kernel), "answer_last_rays"
  * (default 1: a path's last ray is traced only if it can reach the bounds of an emissive instance; sthip_stats::rays_answered;
  * identical results for rays that start within a few scene sizes of the scene — as every path ray does — which is also what

@@ -281,6 +281,10 @@ struct sthip_ctx {
   // options / stats
   bool count_traversal = false, time_kernels = false;
   bool hashgrid_serial = false;  // "hashgrid_serial": build the reuse grids with the one-thread probe sequence (hashgrid.hip's rare-case path; tests)
+  // "reuse_grids_persist": the grids the LAST seed of a call leaves are what the FIRST seed of the next call looks into — upstream's
+  // previous frame for a host that renders one frame per call (BDPT.cpp:482-483,621-627). The key says what they were built for.
+  bool reuse_persist = false, reuse_grids_valid = false;
+  uint64_t reuse_key[3] = {0, 0, 0};
   uint32_t refill_idle = 16, inner_min_lanes = 24, trace_blocks_per_cu = 0;
   uint64_t max_paths_in_flight = 1ull << 22;  // (sthip_create sizes it to the device: 2^26 on a 288 GB MI355X — launches large enough that their
                                               // tails stop mattering: atrium x 8 seeds +7 %, forest at 4K x 16 +38 % over 2^22; tools/in_flight_sweep.py)
@@ -575,6 +579,10 @@ int sthip_set_option(sthip_ctx* ctx, const char* name, int64_t value) {
     ctx->use_treetop = value != 0;
   else if (!strcmp(name, "hashgrid_serial"))
     ctx->hashgrid_serial = value != 0;
+  else if (!strcmp(name, "reuse_grids_persist")) {  // setting it (to either value) also drops the grids kept so far
+    ctx->reuse_persist = value != 0;
+    ctx->reuse_grids_valid = false;
+  }
   else if (!strcmp(name, "inner_min_lanes"))
     ctx->inner_min_lanes = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value));
   else
@@ -1113,6 +1121,7 @@ int sthip_scene_upload(sthip_ctx* ctx, const sthip_scene_desc* s) {
     if (rc != STHIP_OK) return rc;
   }
   ctx->has_scene = true;
+  ctx->reuse_grids_valid = false;  // (stored samples name materials and lights of the scene they were taken in)
   if (ctx->keep_scene) {
     if (s->gVertices != ctx->kept.vertices.data() || !ctx->kept.valid) ctx->kept.keep(*s);  // (a rebuild from the kept copy itself keeps nothing anew)
   } else {
@@ -1726,7 +1735,10 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
   p.hg_counters = ctx->hg_counters.p;
   p.hg_indices = ctx->hg_indices.p;
   p.hg_data = ctx->hg_data.p;
-  p.hg_prev = 0;
+  // the first seed of the call looks into the grids the previous call left, if it left them for the same estimator and table
+  const uint64_t reuse_key[3] = {(uint64_t)(nee_reuse ? 1u : 0u) | (lvc_reuse ? 2u : 0u), hg_buckets, hg_slots};
+  p.hg_prev = ((nee_reuse || lvc_reuse) && ctx->reuse_persist && ctx->reuse_grids_valid && !memcmp(reuse_key, ctx->reuse_key, sizeof reuse_key)) ? 1u : 0u;
+  if (nee_reuse || lvc_reuse) ctx->reuse_grids_valid = false;  // (until this call has left its own)
   p.hg_appends = nee_reuse ? ctx->hg_appends.p : nullptr;
   p.lg_checksums = ctx->lg_checksums.p;
   p.lg_counters = ctx->lg_counters.p;
@@ -2266,7 +2278,7 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
     if (rc) return rc;
     rc = timed(ms_other, [&]() { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(STHIP_BLOCK), 0, st, p, s == 0 ? 1u : 0u, s + in_flight == seed_count ? 1u : 0u, primary_rays * in_flight); });
     if (rc) return rc;
-    if ((nee_reuse || lvc_reuse) && s + in_flight < seed_count) {
+    if ((nee_reuse || lvc_reuse) && (s + in_flight < seed_count || ctx->reuse_persist)) {
       // This seed's appends become the grids the next seed looks up (hashgrid.h)
       if (nee_reuse) {
         const int rc2 = build_hash_grid(ctx, st, ctx->hg_appends.p, ctx->hg_compact.p, ctx->hg_data.p, hg_slots, 4, 2, false, pc->gHashGridBucketCount, ctx->hg_checksums, ctx->hg_counters, ctx->hg_indices);
@@ -2278,6 +2290,10 @@ static int render_once(sthip_ctx* ctx, const sthip_BDPTPushConstants* pc, uint32
       }
       p.hg_prev = 1;
     }
+  }
+  if ((nee_reuse || lvc_reuse) && ctx->reuse_persist) {  // what the next call's first seed may look into
+    memcpy(ctx->reuse_key, reuse_key, sizeof reuse_key);
+    ctx->reuse_grids_valid = true;
   }
 
   if (!dev) {

@@ -2066,3 +2066,53 @@ def test_host_outputs_written_in_place():
             r.render(camera.Frame(100, 64, cam["fovy"], cam["eye"], cam["target"]), 0, 1, host_outputs=bufs)
     finally:
         r.close()
+
+
+@pytest.mark.gpu
+def test_reuse_grids_persist_between_calls():
+    """`reuse_grids_persist`: the hash grids the last seed of a call leaves are what the first seed of the next call looks into
+    (upstream's previous frame for a host that renders one frame per call, BDPT.cpp:482-483,621-627). Three calls of one seed
+    are then the chain a call of three seeds traces — which the oracle tests pin — frame by frame: the running mean
+    (temporal_accumulation.hlsl:118-131) of the three frames, bit for bit, and the same rays. Setting the option again drops the
+    grids: that frame is a chain's first (gReservoirSpatialM = 0 upstream)."""
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = scenes.cornell_box()
+    frame = camera.Frame(96, 72, cam["fovy"], cam["eye"], cam["target"])
+    for flags, args in (
+        (["neereservoirs", "neereservoirreuse"], {"reservoirM": 2}),
+        (["connecttolightpaths", "lightvertexcache", "lvcreservoirs", "lvcreservoirreuse", "~defershadowrays"], {"lightPathCount": 3000, "reservoirM": 2, "maxDiffuseVertices": 3}),
+    ):
+        r = BDPT(device=0, args=dict(args, bdptFlag=flags))
+        try:
+            r.update(sc)
+            chain = r.render(frame, 4, 3, aovs=False)
+            alone = [r.render(frame, 4 + i, 1, aovs=False) for i in range(3)]  # every call a chain of its own
+            r.set_option("reuse_grids_persist", 1)
+            kept = [r.render(frame, 4 + i, 1, aovs=False) for i in range(3)]
+            acc = kept[0]["radiance"].copy()  # k_resolve's running mean: rgb and, in .w, the samples that counted (a non-finite one does not)
+            for f in (kept[1]["radiance"], kept[2]["radiance"]):
+                nn = acc[..., 3] + f[..., 3]
+                with np.errstate(all="ignore"):
+                    alpha = np.clip(f[..., 3] / nn, np.float32(0), np.float32(1))[..., None]
+                live = acc[..., 3] > 0
+                rgb = np.where(live[..., None], acc[..., :3] + alpha * (f[..., :3] - acc[..., :3]), f[..., :3])
+                acc = np.concatenate([rgb, np.where(live, nn, f[..., 3])[..., None]], -1).astype(np.float32)
+            assert np.array_equal(acc.view(np.uint32), chain["radiance"].view(np.uint32)), flags
+            assert np.array_equal(sum(f["ray_count"] for f in kept), chain["ray_count"]), flags
+            assert np.array_equal(kept[0]["radiance"], alone[0]["radiance"]) and not np.array_equal(kept[1]["radiance"], alone[1]["radiance"]), flags
+            # dropped: by setting the option again, by another table size, by a new scene
+            r.set_option("reuse_grids_persist", 1)
+            assert np.array_equal(r.render(frame, 6, 1, aovs=False)["radiance"], alone[2]["radiance"]), flags
+            r.render(frame, 5, 1, aovs=False)
+            r.mPushConstants.gHashGridBucketCount = 150000
+            other = r.render(frame, 6, 1, aovs=False)["radiance"]
+            r.set_option("reuse_grids_persist", 0)
+            assert np.array_equal(other, r.render(frame, 6, 1, aovs=False)["radiance"]), flags
+            r.mPushConstants.gHashGridBucketCount = 200000
+            r.set_option("reuse_grids_persist", 1)
+            r.render(frame, 5, 1, aovs=False)
+            r.update(sc)
+            assert np.array_equal(r.render(frame, 6, 1, aovs=False)["radiance"], alone[2]["radiance"]), flags
+        finally:
+            r.close()
