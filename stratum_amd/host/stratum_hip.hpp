@@ -826,6 +826,8 @@ class BDPT {
 
   explicit BDPT(Node& node, int device = 0) : mNode(node) {
     if (sthip_create(device, &mCtx) != STHIP_OK) throw std::runtime_error(std::string("sthip_create: ") + sthip_last_error(nullptr));
+    // one frame per call: the reservoir-reuse hash grids of a frame are the next frame's "previous" ones (BDPT.cpp:621-627)
+    (void)sthip_set_option(mCtx, "reuse_grids_persist", 1);
     // BDPT.cpp:55-76
     mSamplingFlags = (1u << STHIP_eRemapThreads) | (1u << STHIP_eRayCones) | (1u << STHIP_eSampleBSDFs) | (1u << STHIP_eCoherentRR) | (1u << STHIP_eNormalMaps) |
                      (1u << STHIP_eNEE) | (1u << STHIP_eMIS) | (1u << STHIP_eDeferShadowRays);
@@ -1032,6 +1034,10 @@ class BDPT {
       o.gDebugImage = mDebugImage.data();
     }
     (void)sthip_set_stream(mCtx, cb.hip_stream);
+    // BDPT.cpp:474,482-483: a frame whose first camera moved since the last one reuses nothing (gReservoirSpatialM = 0) unless the
+    // denoiser reprojects; setting the option drops the grids the last frame left (include/sthip.h)
+    const bool changed = !mPrevInverseViewTransforms.empty() && !fs.ti.empty() && std::memcmp(&mPrevInverseViewTransforms[0], &fs.ti[0], sizeof(TransformData)) != 0;
+    if (changed && !mReprojection) (void)sthip_set_option(mCtx, "reuse_grids_persist", 1);
     if (sthip_render(mCtx, &pc, mSamplingFlags, scene_flags, &f, mFrameNumber, seed_count, &o) != STHIP_OK)
       throw std::runtime_error(std::string("sthip_render: ") + sthip_last_error(mCtx));
     if (mDebugMode != STHIP_DEBUG_NONE) fr.mDebugImage = mDebugImage;
@@ -1044,6 +1050,8 @@ class BDPT {
     mDebugMode = mode < STHIP_DEBUG_MODE_COUNT ? mode : (uint32_t)STHIP_DEBUG_NONE;
   }
   uint32_t debug_mode() const { return mDebugMode; }
+  // Denoiser::reprojection() (BDPT.cpp:472-473): with it a moving camera keeps the previous frame's reuse grids
+  void set_reprojection(bool on) { mReprojection = on; }
 
  protected:
   uint32_t frame_number() const { return mFrameNumber; }
@@ -1104,6 +1112,7 @@ class BDPT {
   BDPTPushConstants mPushConstants;
   uint32_t mFrameNumber = 0;
   uint32_t mDebugMode = STHIP_DEBUG_NONE;
+  bool mReprojection = false;
   std::vector<float> mDebugImage;
   uint32_t mTonemapMode = STHIP_TONEMAP_RAW;  // BDPT.cpp:48
   float mExposure = 0;

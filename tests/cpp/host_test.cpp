@@ -87,6 +87,19 @@ int main(int argc, char** argv) {
       out.write((const char*)fr.mTonemapResult.data(), fr.mTonemapResult.size() * 4);
       if (argc >= 8) renderer->export_hdr(argv[7]);
       std::printf("RENDER OK %ux%u rays %llu\n", W, H, (unsigned long long)fr.mRayCount[0]);
+      // --frames=N: N - 1 more frames of the unchanged scene and camera (the frame number is the seed, BDPT.cpp:480); the last one
+      // is written beside the first — what frame-to-frame state (the reservoir-reuse grids) makes of it
+      for (int a = 8; a < argc; a++) {
+        const std::string kv = argv[a];
+        if (kv.rfind("--frames=", 0) != 0) continue;
+        const int frames = std::atoi(kv.c_str() + 9);
+        for (int i = 1; i < frames; i++) app->run_frame(cb);
+        const auto& frn = renderer->prev_result();
+        std::ofstream outn(std::string(argv[3]) + ".last", std::ios::binary);
+        outn.write((const char*)frn.mRadiance.data(), frn.mRadiance.size() * 4);
+        outn.write((const char*)frn.mRayCount, 16);
+        std::printf("FRAMES %d\n", frames);
+      }
       // --move=dx,dy,dz (must come last): every node whose transform is not the identity moves, the scene is marked
       // dirty, and a second frame is rendered: Scene::update makes a new SceneData (motion transforms from the previous
       // one), BDPT::update sees that only transforms changed and rebuilds the top level alone

@@ -67,6 +67,7 @@ int sthip_create(int device, sthip_ctx** out) {
 void sthip_destroy(sthip_ctx* ctx) { delete reinterpret_cast<mock::Ctx*>(ctx); }
 const char* sthip_last_error(const sthip_ctx* ctx) { return ctx ? reinterpret_cast<const mock::Ctx*>(ctx)->error.c_str() : "no context"; }
 int sthip_set_stream(sthip_ctx*, void*) { return STHIP_OK; }
+int sthip_set_option(sthip_ctx*, const char*, int64_t) { return STHIP_OK; }
 int sthip_set_shard(sthip_ctx* ctx, uint32_t rank, uint32_t count, uint32_t tw, uint32_t th) {
   auto* c = reinterpret_cast<mock::Ctx*>(ctx);
   c->rank = rank;

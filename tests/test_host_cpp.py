@@ -98,6 +98,40 @@ def test_cpp_host_renders_what_the_python_host_renders(host_test, tmp_path, make
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags, extra", [(["neereservoirs", "neereservoirreuse"], {"reservoirM": 2}),
+                                          (["connecttolightpaths", "lightvertexcache", "lvcreservoirs", "lvcreservoirreuse"], {"lightPathCount": 3000, "reservoirM": 2, "maxDiffuseVertices": 3})])
+def test_cpp_host_reuses_the_previous_frames_reservoirs(host_test, tmp_path, flags, extra):
+    """A host that renders one frame per call: frame n looks into the hash grids frame n - 1 left (BDPT.cpp:482-483,621-627;
+    `reuse_grids_persist`). The C++ host's third frame of an unchanged scene and camera is the third seed of the chain — the
+    Python host's three one-seed calls with the option set, itself pinned to one call of three seeds in test_gpu_parity — and not
+    the third seed rendered on its own."""
+    from stratum_amd.bdpt import BDPT
+
+    sc, cam = scenes.cornell_box()
+    W, H = 96, 64
+    fr = camera.Frame(W, H, cam["fovy"], cam["eye"], cam["target"])
+    desc, outp = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    dump_description(desc, sc, fr)
+    argv = ["--bdptFlag=%s" % f for f in flags] + ["--%s=%s" % kv for kv in extra.items()] + ["--frames=3"]
+    out = subprocess.run([host_test, "render", desc, outp, "1", "0", "0", str(tmp_path / "image.hdr")] + argv, capture_output=True, text=True)
+    assert out.returncode == 0 and "FRAMES 3" in out.stdout, out.stdout + out.stderr
+    raw = np.fromfile(outp + ".last", dtype=np.uint8)
+    rad = raw[: W * H * 16].view(np.float32).reshape(H, W, 4)
+    rays = raw[W * H * 16 :].view(np.uint64)
+    r = BDPT(device=0, args=dict(extra, bdptFlag=flags))
+    try:
+        r.update(sc)
+        alone = r.render(fr, 2, 1, aovs=False)
+        r.set_option("reuse_grids_persist", 1)
+        for seed in range(3):
+            ref = r.render(fr, seed, 1, aovs=False)
+    finally:
+        r.close()
+    assert np.array_equal(rad.view(np.uint32), ref["radiance"].view(np.uint32)) and np.array_equal(rays, ref["ray_count"])
+    assert not np.array_equal(rad, alone["radiance"])
+
+
+@pytest.mark.gpu
 def test_cpp_host_moves_instances_with_a_top_level_rebuild(host_test, tmp_path):
     """Nodes move between two frames: Scene::update repacks (motion transforms from the previous frame's), BDPT::update
     finds only transforms changed and calls sthip_scene_update_transforms; the second frame and its prev-uv output equal
