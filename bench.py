@@ -389,6 +389,10 @@ def main():
         k, v = kv.split("=", 1)
         options[k] = int(v)
         r.set_option(k, int(v))
+    if any("reuse" in f.lower() and f[0] not in "~!" for f in args.bdpt_flag) and "reuse_grids_persist" not in options:
+        # a step is a frame: with a reservoir-reuse estimator it looks into the grids the step before left, as upstream's frames do
+        options["reuse_grids_persist"] = 1
+        r.set_option("reuse_grids_persist", 1)
     r.update(sc)
     # The headline traces EVERY ray. The library's default answers the last ray of a path from the emitters' bounds when it cannot
     # reach one (sthip.h "answer_last_rays": same frames, same gRayCount, 1/5 of the rays of this workload never walk the tree);
